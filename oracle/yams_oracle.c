@@ -1,0 +1,413 @@
+/*
+ * oracle/yams_oracle.c — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker.  Nothing under yams_amd/ or include/ links, loads or calls it.
+ *
+ * Every function cites the reference lines (under /root/reference) it follows.  The SHA-256 and
+ * CDC restatements are pinned against the reference's own translation units (oracle/_ref, built by
+ * oracle/Makefile from the sources where they lie) and against the reference's known-answer
+ * vectors (tests/unit/crypto/crypto_test.cpp:92-99) in tests/test_oracle.py.  The exact cosine
+ * scan is a line-for-line restatement (the reference file cannot be compiled here: its
+ * sqlite-vec-cpp / simeon submodules are empty) pinned by the reference's vector known-answer
+ * tests (tests/unit/vector/vector_smoke_catch2_test.cpp:188-353).  The L2 scan restates an ABSENT
+ * dependency (trvon/sqlite-vec-cpp, unpinned revision): parity unpinned for L2.
+ *
+ * Plain C, scalar, single-threaded by design: this is the "port" cpu_baseline.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------
+ * SHA-256 (FIPS 180-4).  Reference: src/crypto/sha256_hasher.cpp:167-195 (one-shot hash through
+ * OpenSSL EVP_sha256, pinned openssl/3.2.0 in conanfile.py:95) and :19-30 (lower-case hex).
+ * ---------------------------------------------------------------------------------------------- */
+static const uint32_t K256[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u,
+    0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu,
+    0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu,
+    0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u,
+    0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu,
+    0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu,
+    0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u,
+    0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u,
+    0xc67178f2u};
+
+static inline uint32_t ror32(uint32_t x, unsigned n) { return (x >> n) | (x << (32u - n)); }
+
+static void sha256_compress(uint32_t st[8], const uint8_t blk[64]) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) {
+        w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) |
+               ((uint32_t)blk[4 * i + 2] << 8) | (uint32_t)blk[4 * i + 3];
+    }
+    for (int i = 16; i < 64; ++i) {
+        uint32_t s0 = ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6],
+             h = st[7];
+    for (int i = 0; i < 64; ++i) {
+        uint32_t S1 = ror32(e, 6) ^ ror32(e, 11) ^ ror32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + ch + K256[i] + w[i];
+        uint32_t S0 = ror32(a, 2) ^ ror32(a, 13) ^ ror32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+ORACLE_API void oracle_sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
+    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                      0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    size_t full = n / 64;
+    for (size_t i = 0; i < full; ++i) sha256_compress(st, data + 64 * i);
+    uint8_t tail[128];
+    size_t rem = n - 64 * full;
+    memset(tail, 0, sizeof tail);
+    if (rem) memcpy(tail, data + 64 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = (rem < 56) ? 64 : 128;
+    uint64_t bits = (uint64_t)n * 8u;
+    for (int i = 0; i < 8; ++i) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_compress(st, tail);
+    if (tl == 128) sha256_compress(st, tail + 64);
+    for (int i = 0; i < 8; ++i) {
+        out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
+    }
+}
+
+/* bytesToHex, src/crypto/sha256_hasher.cpp:19-30: lower-case, 64 chars + NUL. */
+ORACLE_API void oracle_sha256_hex(const uint8_t* data, size_t n, char out[65]) {
+    static const char hexd[] = "0123456789abcdef";
+    uint8_t dg[32];
+    oracle_sha256(data, n, dg);
+    for (int i = 0; i < 32; ++i) { out[2 * i] = hexd[dg[i] >> 4]; out[2 * i + 1] = hexd[dg[i] & 15]; }
+    out[64] = 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Rolling-hash CDC.  Table: src/chunking/rabin_fingerprint_table.h:12-28.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t window_size;  /* ChunkingConfig::windowSize, chunker.h:45 (default 48)            */
+    uint64_t min_size;     /* minChunkSize  (default 16 KiB, core/types.h:282)                 */
+    uint64_t max_size;     /* maxChunkSize  (default 1 MiB,  core/types.h:284)                 */
+    uint64_t polynomial;   /* default 0x3DA3358B4DC173, chunker.h:49                            */
+    uint64_t mask;         /* chunkMask, default 0x1FFF, chunker.h:50                           */
+} oracle_cdc_config;
+
+ORACLE_API void oracle_rabin_table(uint64_t polynomial, uint64_t out[256]) {
+    /* rabin_fingerprint_table.h:17-26 */
+    for (int byte = 0; byte < 256; ++byte) {
+        uint64_t h = 0;
+        for (int bit = 0; bit < 8; ++bit)
+            if (byte & (1 << bit)) h ^= polynomial << bit;
+        out[byte] = h;
+    }
+}
+
+/* RabinChunker::chunkDataImpl + findChunkBoundary, src/chunking/rabin_chunker.cpp:63-152.
+ * One RabinWindow (48-byte ring, pos, hash) for the whole buffer, never reset (:126).
+ * Returns the number of chunks; writes at most cap (offset,size) pairs. */
+ORACLE_API size_t oracle_chunk_rabin(const uint8_t* data, size_t n, const oracle_cdc_config* cfg,
+                                     uint64_t* offsets, uint64_t* sizes, size_t cap) {
+    uint64_t table[256];
+    uint64_t poly = cfg->polynomial ? cfg->polynomial : 0x3DA3358B4DC173ULL; /* :29-37 */
+    oracle_rabin_table(poly, table);
+    uint8_t ring[48];
+    memset(ring, 0, sizeof ring);
+    size_t ring_pos = 0;
+    uint64_t hash = 0;
+    const size_t wsz = (size_t)cfg->window_size;
+    size_t count = 0, pos = 0;
+    while (pos < n) { /* :128 */
+        const size_t start = pos;
+        size_t min_b = start + cfg->min_size; if (min_b > n) min_b = n;   /* :67 */
+        size_t max_b = start + cfg->max_size; if (max_b > n) max_b = n;   /* :68 */
+        size_t p = start, end;
+        int found = 0;
+        while (p < min_b) { /* :78-88, no boundary test */
+            uint8_t nb = data[p++], ob = ring[ring_pos];
+            ring[ring_pos] = nb;
+            if (++ring_pos == wsz) ring_pos = 0;
+            hash = ((hash - table[ob]) << 8) ^ table[nb];
+        }
+        while (p < max_b) { /* :90-105 */
+            uint8_t nb = data[p], ob = ring[ring_pos];
+            ring[ring_pos] = nb;
+            if (++ring_pos == wsz) ring_pos = 0;
+            hash = ((hash - table[ob]) << 8) ^ table[nb];
+            if ((hash & cfg->mask) == cfg->mask) { found = 1; break; }
+            ++p;
+        }
+        end = found ? p + 1 : p; /* :101-109 */
+        if (count < cap) { offsets[count] = start; sizes[count] = end - start; }
+        ++count;
+        pos = end;
+    }
+    return count;
+}
+
+/* StreamingChunker::processBuffer / emitChunk / updateRabinHash,
+ * include/yams/chunking/streaming_chunker.h:146-204, src/chunking/streaming_chunker.cpp:37-69.
+ * The result does not depend on how the stream is fragmented into buffers, so one pass. */
+ORACLE_API size_t oracle_chunk_streaming(const uint8_t* data, size_t n,
+                                         const oracle_cdc_config* cfg, uint64_t* offsets,
+                                         uint64_t* sizes, size_t cap) {
+    uint64_t table[256];
+    uint64_t poly = cfg->polynomial ? cfg->polynomial : 0x3DA3358B4DC173ULL;
+    oracle_rabin_table(poly, table);
+    uint8_t ring[48];
+    memset(ring, 0, sizeof ring);
+    size_t wsz = (size_t)cfg->window_size; /* .cpp:44-49: 0 -> 1, > 48 -> 48 */
+    if (wsz == 0) wsz = 1; else if (wsz > 48) wsz = 48;
+    size_t ring_pos = 0;
+    uint64_t hash = 0;
+    size_t count = 0, acc = 0, chunk_start = 0;
+    for (size_t off = 0; off < n; ++off) {
+        ++acc; /* accumulator.push_back, .h:153 */
+        if (ring_pos >= wsz) ring_pos = 0; /* .cpp:50-52 */
+        uint8_t nb = data[off], ob = ring[ring_pos];
+        ring[ring_pos] = nb;
+        if (++ring_pos >= wsz) ring_pos = 0;
+        hash = ((hash - table[ob]) << 8) ^ table[nb]; /* .cpp:68 */
+        int emit = 0;
+        if (acc >= cfg->min_size) { /* .h:162-170 */
+            if ((hash & cfg->mask) == cfg->mask) emit = 1;
+            else if (acc >= cfg->max_size) emit = 1;
+        }
+        if (emit) { /* .h:184-204 */
+            if (count < cap) { offsets[count] = chunk_start; sizes[count] = acc; }
+            ++count;
+            chunk_start = off + 1;
+            acc = 0;
+        }
+    }
+    if (acc) { /* finalizeChunk, .h:116-118,207-211 */
+        if (count < cap) { offsets[count] = chunk_start; sizes[count] = acc; }
+        ++count;
+    }
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact cosine scan.  Reference: SqliteVecBackend::Impl::bruteForceSearchUnlocked fast path,
+ * src/vector/sqlite_vec_backend.cpp:4123-4135 (pre-checks), :204-211 (zero-norm threshold 1e-10),
+ * :229-236 (finite), :4204-4211 (query norm), :4228-4307 (row loop, skips, bounded heap),
+ * :4315-4326 (final order, relevance_score).  The corpus is a dense row-major fp32 matrix in
+ * rowid order (:4175 ORDER BY rowid); the chunk_id string tie-break (:4218-4223) is modelled by
+ * tie_rank[row] = rank of that row's chunk_id in lexicographic order (NULL: rank = row index).
+ * Return: number of results (<= k), or -1 for the InvalidArgument case (:4127-4130).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float sim; uint64_t rank; int64_t row; } oracle_hit;
+
+static int hit_better(const oracle_hit* a, const oracle_hit* b) { /* :4218-4223 */
+    if (a->sim != b->sim) return a->sim > b->sim;
+    return a->rank < b->rank;
+}
+/* std::push_heap / pop_heap with comparator `better` keep the WORST retained row at the front. */
+static void heap_sift_up(oracle_hit* h, size_t i) {
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (hit_better(&h[p], &h[i])) { oracle_hit t = h[p]; h[p] = h[i]; h[i] = t; i = p; }
+        else break;
+    }
+}
+static void heap_sift_down(oracle_hit* h, size_t n, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && hit_better(&h[m], &h[l])) m = l;
+        if (r < n && hit_better(&h[m], &h[r])) m = r;
+        if (m == i) break;
+        oracle_hit t = h[m]; h[m] = h[i]; h[i] = t; i = m;
+    }
+}
+static int hit_cmp_best_first(const void* pa, const void* pb) {
+    const oracle_hit* a = (const oracle_hit*)pa; const oracle_hit* b = (const oracle_hit*)pb;
+    if (hit_better(a, b)) return -1;
+    if (hit_better(b, a)) return 1;
+    return 0;
+}
+
+ORACLE_API int oracle_query_invalid(const float* q, size_t dim) {
+    /* isFiniteEmbedding :229-236 + isZeroNormEmbedding :204-211 */
+    double nsq = 0.0;
+    for (size_t i = 0; i < dim; ++i) {
+        if (!isfinite(q[i])) return 1;
+        nsq += (double)q[i] * (double)q[i];
+    }
+    return nsq < 1e-10;
+}
+
+ORACLE_API long oracle_exact_scan_cosine(const float* corpus, size_t n_rows, size_t dim,
+                                         const float* query, size_t k, float similarity_threshold,
+                                         const uint64_t* tie_rank, int64_t* out_rows,
+                                         float* out_sims, uint64_t* rows_visited,
+                                         uint64_t* evaluations) {
+    if (rows_visited) *rows_visited = 0;
+    if (evaluations) *evaluations = 0;
+    if (dim == 0 || k == 0) return 0;            /* :4123-4126 */
+    if (oracle_query_invalid(query, dim)) return -1; /* :4127-4130 */
+    double qn_sq = 0.0;
+    for (size_t i = 0; i < dim; ++i) { double v = (double)query[i]; qn_sq += v * v; } /* :4206-4210 */
+    const double qn = sqrt(qn_sq);               /* :4211 */
+    oracle_hit* heap = (oracle_hit*)malloc(sizeof(oracle_hit) * (k + 1));
+    size_t hs = 0;
+    for (size_t r = 0; r < n_rows; ++r) {
+        if (rows_visited) ++*rows_visited;       /* :4229-4231 */
+        const float* e = corpus + r * dim;
+        if (evaluations) ++*evaluations;         /* :4249-4251 */
+        double nsq = 0.0, dot = 0.0; int finite = 1;
+        for (size_t i = 0; i < dim; ++i) {       /* :4256-4266 */
+            float v = e[i];
+            if (!isfinite(v)) { finite = 0; break; }
+            double sv = (double)v, qv = (double)query[i];
+            nsq += sv * sv; dot += sv * qv;
+        }
+        if (!finite || nsq <= 1e-12) continue;   /* :4267-4269 */
+        double denom = sqrt(nsq) * qn;           /* :4271 */
+        double sd = denom > 0.0 ? dot / denom : 0.0;
+        if (!isfinite(sd)) continue;             /* :4273-4275 */
+        float sim = (float)sd;                   /* :4276 */
+        if (sim < similarity_threshold) continue;/* :4277-4279 */
+        oracle_hit h = {sim, tie_rank ? tie_rank[r] : (uint64_t)r, (int64_t)r};
+        if (hs < k) { heap[hs] = h; heap_sift_up(heap, hs); ++hs; }           /* :4289-4295 */
+        else if (hit_better(&h, &heap[0])) { heap[0] = h; heap_sift_down(heap, hs, 0); } /* :4296-4306 */
+    }
+    qsort(heap, hs, sizeof(oracle_hit), hit_cmp_best_first); /* :4315-4319 */
+    for (size_t i = 0; i < hs; ++i) { out_rows[i] = heap[i].row; out_sims[i] = heap[i].sim; }
+    free(heap);
+    return (long)hs;
+}
+
+/* VectorDatabase::computeCosineSimilarity, src/vector/vector_database.cpp:1786-1810. */
+ORACLE_API double oracle_cosine_similarity(const float* a, const float* b, size_t dim) {
+    double dp = 0.0, na = 0.0, nb = 0.0;
+    for (size_t i = 0; i < dim; ++i) {
+        dp += (double)a[i] * (double)b[i];
+        na += (double)a[i] * (double)a[i];
+        nb += (double)b[i] * (double)b[i];
+    }
+    na = sqrt(na); nb = sqrt(nb);
+    if (na == 0.0 || nb == 0.0) return 0.0;
+    return dp / (na * nb);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * L2 (vec0) scan — PARITY UNPINNED.  The arithmetic lives in the absent third_party/sqlite-vec-cpp
+ * (.gitmodules:4-6, no recoverable revision).  What the reference pins at this boundary:
+ * tests/unit/vector/sqlite_vec_c_api_smoke_catch2_test.cpp:20-43 (Euclidean distance WITH sqrt),
+ * and the caller src/vector/sqlite_vec_backend.cpp:4450-4530: k nearest by distance ascending,
+ * each hit re-scored with computeCosineSimilarity (:4506), dropped if below the threshold (:4508),
+ * returned in distance order with relevance_score = cosine (:4512).  Restated here as:
+ * distance = (float)sqrt(sum_i ((double)a_i - (double)b_i)^2), ascending, ties by tie_rank.
+ * vec0's `k = ?2` bounds the candidate list BEFORE the cosine threshold filter (:4464-4473), so
+ * fewer than k rows may come back.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float dist; uint64_t rank; int64_t row; } oracle_l2hit;
+static int l2_cmp(const void* pa, const void* pb) {
+    const oracle_l2hit* a = (const oracle_l2hit*)pa; const oracle_l2hit* b = (const oracle_l2hit*)pb;
+    if (a->dist != b->dist) return a->dist < b->dist ? -1 : 1;
+    if (a->rank != b->rank) return a->rank < b->rank ? -1 : 1;
+    return 0;
+}
+ORACLE_API long oracle_exact_scan_l2(const float* corpus, size_t n_rows, size_t dim,
+                                     const float* query, size_t k, float similarity_threshold,
+                                     const uint64_t* tie_rank, int64_t* out_rows, float* out_dist,
+                                     float* out_sims) {
+    if (dim == 0 || k == 0) return 0; /* :4453-4455 */
+    oracle_l2hit* all = (oracle_l2hit*)malloc(sizeof(oracle_l2hit) * (n_rows ? n_rows : 1));
+    size_t m = 0;
+    for (size_t r = 0; r < n_rows; ++r) {
+        const float* e = corpus + r * dim;
+        double acc = 0.0; int finite = 1;
+        for (size_t i = 0; i < dim; ++i) {
+            if (!isfinite(e[i])) { finite = 0; break; }
+            double d = (double)e[i] - (double)query[i];
+            acc += d * d;
+        }
+        if (!finite) continue; /* insert-time validity, src/vector/vector_database.cpp:1771-1784 */
+        double dd = sqrt(acc);
+        if (!isfinite(dd)) continue;
+        all[m].dist = (float)dd; all[m].rank = tie_rank ? tie_rank[r] : (uint64_t)r;
+        all[m].row = (int64_t)r; ++m;
+    }
+    qsort(all, m, sizeof(oracle_l2hit), l2_cmp);
+    size_t take = m < k ? m : k, outn = 0;
+    for (size_t i = 0; i < take; ++i) {
+        float sim = (float)oracle_cosine_similarity(query, corpus + (size_t)all[i].row * dim, dim);
+        if (sim < similarity_threshold) continue; /* :4508-4510 */
+        out_rows[outn] = all[i].row; out_dist[outn] = all[i].dist; out_sims[outn] = sim; ++outn;
+    }
+    free(all);
+    return (long)outn;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic-data recipes shared by tests and bench (so the CPU side can regenerate any slice).
+ * Philox4x32-10 counter-based generator (Salmon et al., SC'11): key = (seed_lo, seed_hi),
+ * counter = (i0, i1, i2, i3).  Used for corpora too large to hold on the host.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+ORACLE_API void oracle_philox4x32(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t out[4]) {
+    uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi,
+                     (uint32_t)(ctr_hi >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+/* Row r of the synthetic embedding matrix: U(-1,1) from the top 24 bits of each Philox word
+ * (counter = (r, j/4)), then fp32 L2-normalised with the norm accumulated in float, as the
+ * reference's generateNormalizedVector does (tests/benchmarks/vector_backend_engine_compare.cpp:
+ * 83-99). */
+ORACLE_API void oracle_synth_rows(uint64_t seed, uint64_t row0, size_t n_rows, size_t dim,
+                                  float* out) {
+    for (size_t r = 0; r < n_rows; ++r) {
+        float* o = out + r * dim;
+        float nsq = 0.0f;
+        for (size_t j = 0; j < dim; j += 4) {
+            uint32_t w[4];
+            oracle_philox4x32(seed, row0 + r, (uint64_t)(j / 4), w);
+            for (size_t t = 0; t < 4 && j + t < dim; ++t) {
+                float u = (float)(w[t] >> 8) * (1.0f / 8388608.0f) - 1.0f; /* [-1, 1) */
+                o[j + t] = u;
+            }
+        }
+        for (size_t j = 0; j < dim; ++j) nsq += o[j] * o[j];
+        float nrm = sqrtf(nsq);
+        if (nrm > 0.0f) for (size_t j = 0; j < dim; ++j) o[j] /= nrm;
+    }
+}
+/* Synthetic blob bytes: 16 bytes per Philox call, counter = (blob_id, byte_offset / 16). */
+ORACLE_API void oracle_synth_bytes(uint64_t seed, uint64_t blob_id, uint64_t off0, size_t n,
+                                   uint8_t* out) {
+    for (size_t i = 0; i < n;) {
+        uint64_t off = off0 + i;
+        uint32_t w[4];
+        oracle_philox4x32(seed, blob_id, off / 16, w);
+        size_t b = (size_t)(off % 16);
+        for (; b < 16 && i < n; ++b, ++i) out[i] = (uint8_t)(w[b / 4] >> (8 * (b % 4)));
+    }
+}

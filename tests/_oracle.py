@@ -1,0 +1,219 @@
+"""ctypes doors into the CHECKERS under oracle/ — test infrastructure only.
+
+`oracle` = the plain-C restatement (oracle/yams_oracle.c, always buildable);
+`ref`    = the reference's own translation units (oracle/_ref/libyams_ref.so, built in the dev
+           container from /root/reference; travels prebuilt to the GPU box).  May be None.
+Nothing under yams_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libyams_oracle.so")
+_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libyams_ref.so")
+
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+
+
+class CdcConfig(C.Structure):
+    _fields_ = [("window_size", C.c_uint64), ("min_size", C.c_uint64), ("max_size", C.c_uint64),
+                ("polynomial", C.c_uint64), ("mask", C.c_uint64)]
+
+
+DEFAULT_CDC = dict(window=48, min_size=16 * 1024, max_size=1024 * 1024,
+                   polynomial=0x3DA3358B4DC173, mask=0x1FFF)
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "yams_oracle.c")
+    stale = (not os.path.exists(_ORACLE_SO)) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(src)
+    need_ref = os.path.isdir("/root/reference/src") and not os.path.exists(_REF_SO)
+    if stale or need_ref:
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.oracle_sha256.argtypes = [u8p, C.c_size_t, u8p]
+        L.oracle_sha256_hex.argtypes = [u8p, C.c_size_t, C.c_char_p]
+        L.oracle_rabin_table.argtypes = [C.c_uint64, u64p]
+        for f in (L.oracle_chunk_rabin, L.oracle_chunk_streaming):
+            f.argtypes = [u8p, C.c_size_t, C.POINTER(CdcConfig), u64p, u64p, C.c_size_t]
+            f.restype = C.c_size_t
+        L.oracle_query_invalid.argtypes = [f32p, C.c_size_t]
+        L.oracle_query_invalid.restype = C.c_int
+        L.oracle_exact_scan_cosine.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
+                                               C.c_float, u64p, i64p, f32p, u64p, u64p]
+        L.oracle_exact_scan_cosine.restype = C.c_long
+        L.oracle_exact_scan_l2.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
+                                           C.c_float, u64p, i64p, f32p, f32p]
+        L.oracle_exact_scan_l2.restype = C.c_long
+        L.oracle_cosine_similarity.argtypes = [f32p, f32p, C.c_size_t]
+        L.oracle_cosine_similarity.restype = C.c_double
+        L.oracle_philox4x32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+        L.oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, f32p]
+        L.oracle_synth_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, u8p]
+
+    # --- SHA-256 ---
+    def sha256_hex(self, data: bytes | np.ndarray) -> str:
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        out = C.create_string_buffer(65)
+        self.L.oracle_sha256_hex(_ptr(a, u8p) if a.size else None, a.size, out)
+        return out.value.decode()
+
+    # --- CDC ---
+    def chunks(self, data, mode="streaming", **cfg):
+        c = dict(DEFAULT_CDC); c.update(cfg)
+        a = np.ascontiguousarray(data if isinstance(data, np.ndarray)
+                                 else np.frombuffer(bytes(data), dtype=np.uint8), dtype=np.uint8)
+        conf = CdcConfig(c["window"], c["min_size"], c["max_size"], c["polynomial"], c["mask"])
+        floor = max(1, min(c["min_size"], c["max_size"]))
+        cap = a.size // floor + 2
+        off = np.zeros(cap, np.uint64); sz = np.zeros(cap, np.uint64)
+        fn = self.L.oracle_chunk_streaming if mode == "streaming" else self.L.oracle_chunk_rabin
+        n = fn(_ptr(a, u8p) if a.size else None, a.size, C.byref(conf), _ptr(off, u64p),
+               _ptr(sz, u64p), cap)
+        assert n <= cap
+        return off[:n].copy(), sz[:n].copy()
+
+    def rabin_table(self, poly):
+        t = np.zeros(256, np.uint64)
+        self.L.oracle_rabin_table(poly, _ptr(t, u64p))
+        return t
+
+    # --- exact scan ---
+    def scan_cosine(self, corpus, query, k, thr=-1.0, tie_rank=None):
+        corpus = np.ascontiguousarray(corpus, np.float32); query = np.ascontiguousarray(query, np.float32)
+        n, d = corpus.shape
+        rows = np.full(max(k, 1), -1, np.int64); sims = np.zeros(max(k, 1), np.float32)
+        rv = C.c_uint64(0); ev = C.c_uint64(0)
+        tr = None
+        if tie_rank is not None:
+            tie_rank = np.ascontiguousarray(tie_rank, np.uint64); tr = _ptr(tie_rank, u64p)
+        cnt = self.L.oracle_exact_scan_cosine(_ptr(corpus, f32p), n, d, _ptr(query, f32p), k, thr,
+                                              tr, _ptr(rows, i64p), _ptr(sims, f32p),
+                                              C.byref(rv), C.byref(ev))
+        if cnt < 0:
+            return None
+        return rows[:cnt].copy(), sims[:cnt].copy(), rv.value, ev.value
+
+    def scan_l2(self, corpus, query, k, thr=-1.0, tie_rank=None):
+        corpus = np.ascontiguousarray(corpus, np.float32); query = np.ascontiguousarray(query, np.float32)
+        n, d = corpus.shape
+        rows = np.full(max(k, 1), -1, np.int64); dist = np.zeros(max(k, 1), np.float32)
+        sims = np.zeros(max(k, 1), np.float32)
+        tr = None
+        if tie_rank is not None:
+            tie_rank = np.ascontiguousarray(tie_rank, np.uint64); tr = _ptr(tie_rank, u64p)
+        cnt = self.L.oracle_exact_scan_l2(_ptr(corpus, f32p), n, d, _ptr(query, f32p), k, thr, tr,
+                                          _ptr(rows, i64p), _ptr(dist, f32p), _ptr(sims, f32p))
+        return rows[:cnt].copy(), dist[:cnt].copy(), sims[:cnt].copy()
+
+    def cosine(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        return self.L.oracle_cosine_similarity(_ptr(a, f32p), _ptr(b, f32p), a.size)
+
+    # --- synthetic data ---
+    def synth_rows(self, seed, row0, n, dim):
+        out = np.empty((n, dim), np.float32)
+        self.L.oracle_synth_rows(seed, row0, n, dim, _ptr(out, f32p))
+        return out
+
+    def synth_bytes(self, seed, blob, off, n):
+        out = np.empty(n, np.uint8)
+        if n:
+            self.L.oracle_synth_bytes(seed, blob, off, n, _ptr(out, u8p))
+        return out
+
+    def philox(self, seed, lo, hi):
+        o = (C.c_uint32 * 4)()
+        self.L.oracle_philox4x32(seed, lo, hi, o)
+        return list(o)
+
+
+class Ref:
+    """The reference's own TUs.  Raises FileNotFoundError when the prebuilt .so is absent."""
+
+    def __init__(self):
+        build()
+        if not os.path.exists(_REF_SO):
+            raise FileNotFoundError(_REF_SO)
+        L = C.CDLL(_REF_SO)
+        self.L = L
+        L.ref_sha256_hex.argtypes = [u8p, C.c_size_t, C.c_char_p]
+        L.ref_sha256_hex_split.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t,
+                                           C.c_char_p]
+        for f in (L.ref_chunk_rabin, L.ref_chunk_streaming):
+            f.argtypes = [u8p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                          C.c_uint64, u64p, u64p, C.c_char_p, C.c_size_t]
+            f.restype = C.c_size_t
+
+    def sha256_hex(self, data) -> str:
+        a = np.ascontiguousarray(data if isinstance(data, np.ndarray)
+                                 else np.frombuffer(bytes(data), dtype=np.uint8), dtype=np.uint8)
+        out = C.create_string_buffer(65)
+        self.L.ref_sha256_hex(_ptr(a, u8p) if a.size else None, a.size, out)
+        return out.value.decode()
+
+    def sha256_hex_split(self, data, cuts) -> str:
+        a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        arr = (C.c_size_t * len(cuts))(*cuts)
+        out = C.create_string_buffer(65)
+        self.L.ref_sha256_hex_split(_ptr(a, u8p) if a.size else None, a.size, arr, len(cuts), out)
+        return out.value.decode()
+
+    def chunks(self, data, mode="streaming", with_hashes=True, **cfg):
+        c = dict(DEFAULT_CDC); c.update(cfg)
+        a = np.ascontiguousarray(data if isinstance(data, np.ndarray)
+                                 else np.frombuffer(bytes(data), dtype=np.uint8), dtype=np.uint8)
+        floor = max(1, min(c["min_size"], c["max_size"]))
+        cap = a.size // floor + 2
+        off = np.zeros(cap, np.uint64); sz = np.zeros(cap, np.uint64)
+        hexbuf = C.create_string_buffer(65 * cap) if with_hashes else None
+        fn = self.L.ref_chunk_streaming if mode == "streaming" else self.L.ref_chunk_rabin
+        n = fn(_ptr(a, u8p) if a.size else None, a.size, c["window"], c["min_size"], c["max_size"],
+               c["polynomial"], c["mask"], _ptr(off, u64p), _ptr(sz, u64p), hexbuf, cap)
+        assert n <= cap
+        hashes = None
+        if with_hashes:
+            raw = hexbuf.raw
+            hashes = [raw[65 * i:65 * i + 64].decode() for i in range(n)]
+        return off[:n].copy(), sz[:n].copy(), hashes
+
+
+_oracle = None
+_ref = None
+
+
+def oracle() -> Oracle:
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle()
+    return _oracle
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        try:
+            _ref = Ref()
+        except (FileNotFoundError, OSError):
+            _ref = False
+    return _ref or None
