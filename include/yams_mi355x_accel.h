@@ -1,0 +1,363 @@
+/*
+ * yams_mi355x_accel.h — C ABI of libyams_mi355x_accel.so, the MI355X (gfx950) drop-in for the
+ * YAMS vector-scan / SHA-256 / content-defined-chunking hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++ or torch types):
+ *
+ *   1. The flat `yams_accel_*` / `yams_scan_*` / `yams_sha256_*` / `yams_cdc_*` functions below.
+ *      Data pointers marked "device" are HIP device addresses (e.g. a torch tensor's data_ptr());
+ *      pointers marked "host" are ordinary memory.  All work is enqueued on the context's HIP
+ *      stream; functions that hand results back to the host synchronise that stream themselves.
+ *
+ *   2. The YAMS plugin surface (include/yams/plugins/abi.h:26-34 in the reference): the eight
+ *      `yams_plugin_*` entry points plus three vtables — `vector_scan_v1`, `content_hash_v1`,
+ *      `chunker_v1` — written to the conventions of the reference's
+ *      include/yams/plugins/model_provider_v1.h:44-49 (first field abi_version, second `self`,
+ *      every function returns yams_status_t, plugin-allocated buffers are released only through
+ *      the paired free_* of the same vtable).  The reference has no plugin interface for these
+ *      three seams today (its seams are the C++ classes IVectorBackend / IContentHasher /
+ *      IChunker); INTEGRATION.md shows the host-side adapter a maintainer adds.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *   yams_scan_topk_*          SqliteVecBackend::Impl::bruteForceSearchUnlocked fast path,
+ *                             src/vector/sqlite_vec_backend.cpp:4115-4135,4204-4331, batched as
+ *                             searchSimilarBatch (:1612-1647), and for YAMS_SCAN_L2 the vec0 path
+ *                             vec0SearchUnlocked (:4450-4530).
+ *   yams_sha256_*             crypto::SHA256Hasher::hash / init / update / finalize,
+ *                             src/crypto/sha256_hasher.cpp:81-109,167-195.
+ *   yams_cdc_chunk_*          RabinChunker::chunkDataLazy (src/chunking/rabin_chunker.cpp:63-152)
+ *                             and StreamingChunker::chunkData (include/yams/chunking/
+ *                             streaming_chunker.h:146-204, src/chunking/streaming_chunker.cpp:37-137).
+ *   yams_ingest_*             the hash + chunk_file phases of ContentStore::store,
+ *                             src/api/content_store_impl.cpp:199-231 (caller contract only).
+ *
+ * There is NO CPU fallback behind this ABI: without a gfx950 device every compute entry point
+ * returns YAMS_ERR_UNSUPPORTED.
+ */
+#ifndef YAMS_MI355X_ACCEL_H
+#define YAMS_MI355X_ACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__) || defined(__clang__)
+#define YAMS_ACCEL_API __attribute__((visibility("default")))
+#else
+#define YAMS_ACCEL_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes: numerically identical to yams_status_e, model_provider_v1.h:17-25. */
+typedef int yams_status_t;
+#ifndef YAMS_PLUGINS_MODEL_PROVIDER_V1_H
+enum yams_status_e {
+    YAMS_OK = 0,
+    YAMS_ERR_INVALID_ARG = 1,
+    YAMS_ERR_NOT_FOUND = 2,
+    YAMS_ERR_IO = 3,
+    YAMS_ERR_INTERNAL = 4,
+    YAMS_ERR_UNSUPPORTED = 5
+};
+#endif
+
+#define YAMS_ACCEL_VERSION_STRING "0.1.0"
+
+/* ------------------------------------------------------------------------------------------ */
+/* Context                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct yams_accel_ctx yams_accel_ctx;
+
+/* Number of visible HIP devices (0 when there is no GPU or no driver). */
+YAMS_ACCEL_API int yams_accel_device_count(void);
+/* Create a context bound to `device`.  `hip_stream` may be NULL (the context creates its own
+ * non-blocking stream) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+ * on which all work of this context is enqueued.  A context is single-threaded; create one per
+ * host thread (mirrors "one SHA256Hasher per thread", src/crypto/sha256_hasher.cpp:34). */
+YAMS_ACCEL_API yams_status_t yams_accel_ctx_create(int device, void* hip_stream,
+                                                   yams_accel_ctx** out_ctx);
+YAMS_ACCEL_API void yams_accel_ctx_destroy(yams_accel_ctx* ctx);
+YAMS_ACCEL_API yams_status_t yams_accel_ctx_synchronize(yams_accel_ctx* ctx);
+/* Human-readable description of the last failure on this context (static storage, never NULL). */
+YAMS_ACCEL_API const char* yams_accel_last_error(const yams_accel_ctx* ctx);
+/* Device properties as a JSON string (malloc'd; release with yams_accel_free_string). */
+YAMS_ACCEL_API yams_status_t yams_accel_device_info_json(yams_accel_ctx* ctx, char** out_json);
+YAMS_ACCEL_API void yams_accel_free_string(char* s);
+/* Plain device memory helpers for hosts that do not bring their own allocator. */
+YAMS_ACCEL_API yams_status_t yams_accel_malloc(yams_accel_ctx* ctx, size_t bytes, void** out_dev);
+YAMS_ACCEL_API void yams_accel_free(yams_accel_ctx* ctx, void* dev);
+YAMS_ACCEL_API yams_status_t yams_accel_upload(yams_accel_ctx* ctx, void* dst_dev,
+                                               const void* src_host, size_t bytes);
+YAMS_ACCEL_API yams_status_t yams_accel_download(yams_accel_ctx* ctx, void* dst_host,
+                                                 const void* src_dev, size_t bytes);
+/* HIP-event timing of the most recent call's dominant kernel on the context's stream:
+ * average milliseconds per launch and number of launches (bench.py's roofline leg). */
+YAMS_ACCEL_API yams_status_t yams_accel_last_kernel_ms(const yams_accel_ctx* ctx,
+                                                       const char* kernel, double* out_ms_per_launch,
+                                                       uint64_t* out_launches);
+YAMS_ACCEL_API yams_status_t yams_accel_enable_kernel_timing(yams_accel_ctx* ctx, int enable);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Exact vector scan (batched cosine / L2 top-k)                                                */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum yams_scan_metric_e {
+    YAMS_SCAN_COSINE = 0, /* exact_scan engine, sqlite_vec_backend.cpp:4204-4331 */
+    YAMS_SCAN_L2 = 1      /* vec0_l2 engine,    sqlite_vec_backend.cpp:4450-4530 */
+} yams_scan_metric_t;
+
+/* A dense device mirror of `vectors WHERE embedding_dim = dim ORDER BY rowid`
+ * (sqlite_vec_backend.cpp:4140-4175): row-major fp32, raw (not normalised). */
+typedef struct yams_scan_corpus_s {
+    const float* rows;         /* device, [n_rows][dim], 16-byte aligned                          */
+    uint64_t n_rows;           /* < 2^32 per shard                                                */
+    uint32_t dim;              /* embedding dimension                                             */
+    uint32_t reserved;
+    const uint32_t* tie_rank;  /* device, nullable: tie_rank[row] = rank of the row's chunk_id in
+                                  lexicographic order (the reference's secondary sort key,
+                                  :4218-4223).  NULL means rank == row_base + row.               */
+    const uint32_t* rank_row;  /* device, nullable iff tie_rank is: inverse permutation within this
+                                  shard for single-shard corpora (rank_row[tie_rank[r]] == r)     */
+    int64_t row_base;          /* added to local row ordinals in the outputs (shard base)         */
+} yams_scan_corpus_t;
+
+#define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
+                                             caller applies it after merging per-shard lists)  */
+#define YAMS_SCAN_FLAG_FORCE_EXACT 2u     /* skip the MFMA filter, score every row in fp64       */
+#define YAMS_SCAN_MAX_K 1024u
+
+typedef struct yams_scan_params_s {
+    uint32_t k;                 /* results per query; 0 => empty result (:4123-4126)             */
+    float similarity_threshold; /* rows with similarity < threshold are dropped (:4277-4279)     */
+    uint32_t metric;            /* yams_scan_metric_t                                            */
+    uint32_t flags;
+} yams_scan_params_t;
+
+/* Per-call work counters: the VectorSearchDiagnostics subset the exact scan fills
+ * (include/yams/vector/vector_types.h:181-204; set at sqlite_vec_backend.cpp:4131-4135,
+ * 4229-4251,4327-4329) plus this implementation's own filter statistics. */
+typedef struct yams_scan_diag_s {
+    uint32_t used_exact_scan;             /* always 1                                            */
+    uint32_t rows_visited_observed;       /* always 1                                            */
+    uint64_t rows_visited;                /* per query: n_rows (summed over the batch)           */
+    uint64_t exact_distance_evaluations;  /* per query: n_rows (summed over the batch)           */
+    uint64_t returned_rows;
+    uint64_t filter_candidates;           /* rows that passed the fp32 MFMA filter               */
+    uint64_t rescored_rows;               /* rows re-scored in fp64                              */
+    uint32_t widened_queries;             /* queries whose candidate set had to be widened       */
+    uint32_t exact_fallback_queries;      /* queries that took the full fp64 scan                */
+    uint32_t path;                        /* 0 = mfma filter + fp64 re-score, 1 = full fp64 scan */
+    uint32_t reserved;
+} yams_scan_diag_t;
+
+/* Batched exact top-k, everything device-resident.
+ *   queries      device [n_queries][dim] fp32 (raw)
+ *   out_scores   device [n_queries][k] fp32: cosine similarity (relevance_score, :4323-4326),
+ *                best first; unused slots hold -inf
+ *   out_rows     device [n_queries][k] int64: row_base + row ordinal; unused slots hold -1
+ *   out_counts   device [n_queries] uint32
+ *   out_dist     device [n_queries][k] fp32, nullable: L2 distance (YAMS_SCAN_L2 only)
+ *   out_ranks    device [n_queries][k] uint32, nullable: tie rank of each hit (for shard merges)
+ * Returns YAMS_ERR_INVALID_ARG if any query is non-finite or has norm^2 < 1e-10 (:4127-4130;
+ * a batch fails as a whole, :1635-1647), or on a dimension / alignment violation.
+ * The call synchronises the context's stream before returning. */
+YAMS_ACCEL_API yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
+                                                   const yams_scan_corpus_t* corpus,
+                                                   const float* queries, uint32_t n_queries,
+                                                   const yams_scan_params_t* params,
+                                                   float* out_scores, int64_t* out_rows,
+                                                   uint32_t* out_counts, float* out_dist,
+                                                   uint32_t* out_ranks, yams_scan_diag_t* diag);
+
+/* Same, with host-resident queries and outputs (the corpus stays a device mirror). */
+YAMS_ACCEL_API yams_status_t yams_scan_topk_host(yams_accel_ctx* ctx,
+                                                 const yams_scan_corpus_t* corpus,
+                                                 const float* queries_host, uint32_t n_queries,
+                                                 const yams_scan_params_t* params,
+                                                 float* out_scores_host, int64_t* out_rows_host,
+                                                 uint32_t* out_counts_host, float* out_dist_host,
+                                                 yams_scan_diag_t* diag);
+
+/* k-way merge of per-shard top-k lists (the step after an RCCL all-gather): inputs are
+ * device [n_shards][n_queries][k] arrays laid out exactly as yams_scan_topk_device writes them
+ * (ranks nullable => row ids break ties).  Order: similarity desc / distance asc, then rank asc.
+ * For YAMS_SCAN_L2 the similarity_threshold is applied after the merge (:4508-4510). */
+YAMS_ACCEL_API yams_status_t yams_scan_merge_topk_device(
+    yams_accel_ctx* ctx, uint32_t n_shards, uint32_t n_queries, const yams_scan_params_t* params,
+    const float* in_scores, const int64_t* in_rows, const uint32_t* in_counts,
+    const float* in_dist, const uint32_t* in_ranks, float* out_scores, int64_t* out_rows,
+    uint32_t* out_counts, float* out_dist);
+
+/* Fill a device matrix with the synthetic embedding recipe: Philox4x32-10
+ * (seed, row, col/4) -> U[-1,1) -> fp32 L2-normalise.  Used by bench.py and tests so that a
+ * corpus larger than host RAM can be generated in HBM and any slice regenerated on the CPU. */
+YAMS_ACCEL_API yams_status_t yams_synth_rows_device(yams_accel_ctx* ctx, uint64_t seed,
+                                                    uint64_t row0, uint64_t n_rows, uint32_t dim,
+                                                    float* out_dev);
+YAMS_ACCEL_API yams_status_t yams_synth_bytes_device(yams_accel_ctx* ctx, uint64_t seed,
+                                                     uint64_t blob_id0, uint64_t n_blobs,
+                                                     uint64_t blob_len, uint8_t* out_dev);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SHA-256                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* Digest n_msgs byte ranges of one device buffer: message i = data[offsets[i] .. +lengths[i]).
+ * offsets/lengths are DEVICE arrays; digests is device [n_msgs][32] (raw bytes, big-endian words
+ * as FIPS 180-4 prints them).  Asynchronous on the context's stream. */
+YAMS_ACCEL_API yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                                      const uint64_t* offsets,
+                                                      const uint64_t* lengths, uint64_t n_msgs,
+                                                      uint8_t* digests);
+/* One-shot over host memory: SHA256Hasher::hash(span), sha256_hasher.cpp:167-195.
+ * out_hex receives 64 lower-case hex characters + NUL (bytesToHex, :19-30). */
+YAMS_ACCEL_API yams_status_t yams_sha256_host(yams_accel_ctx* ctx, const uint8_t* data_host,
+                                              size_t n, char out_hex[65]);
+/* Many host buffers at once (one message per lane on the device). */
+YAMS_ACCEL_API yams_status_t yams_sha256_many_host(yams_accel_ctx* ctx,
+                                                   const uint8_t* const* msgs_host,
+                                                   const size_t* lens, size_t n_msgs,
+                                                   char* out_hex /* [n_msgs][65] */);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Content-defined chunking                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum yams_cdc_mode_e {
+    YAMS_CDC_RABIN = 0,     /* RabinChunker: first tested byte is start+min, sizes in [min+1,max] */
+    YAMS_CDC_STREAMING = 1  /* StreamingChunker (product default): first tested byte is
+                               start+min-1, sizes in [min,max]                                   */
+} yams_cdc_mode_t;
+
+/* ChunkingConfig, include/yams/chunking/chunker.h:44-51 (target size does not enter the
+ * boundary logic and is omitted).  polynomial == 0 selects the default (rabin_chunker.cpp:29-37). */
+typedef struct yams_cdc_config_s {
+    uint64_t window_size; /* 1..48 (RabinWindow is a 48-byte ring, chunker.h:151-155)            */
+    uint64_t min_size;
+    uint64_t max_size;
+    uint64_t polynomial;
+    uint64_t mask;
+    uint32_t mode;        /* yams_cdc_mode_t */
+    uint32_t reserved;
+} yams_cdc_config_t;
+
+YAMS_ACCEL_API void yams_cdc_default_config(yams_cdc_config_t* cfg, uint32_t mode);
+
+/* Result of chunking (and optionally hashing) a set of blobs; device arrays owned by the
+ * context's workspace, valid until the next ingest/cdc call on the same context. */
+typedef struct yams_ingest_result_s {
+    uint64_t n_chunks;            /* total over all blobs                                        */
+    const uint64_t* chunk_offset; /* device [n_chunks]: offset within its blob                   */
+    const uint64_t* chunk_size;   /* device [n_chunks]                                           */
+    const uint32_t* chunk_blob;   /* device [n_chunks]: blob index                               */
+    const uint64_t* blob_first;   /* device [n_blobs + 1]: first chunk of each blob (prefix)     */
+    const uint8_t* chunk_digest;  /* device [n_chunks][32] or NULL                               */
+    const uint8_t* blob_digest;   /* device [n_blobs][32] or NULL                                */
+} yams_ingest_result_t;
+
+/* Chunk boundaries only.  data: device bytes; blob_offsets/blob_lengths: HOST arrays locating
+ * each blob inside `data`. */
+YAMS_ACCEL_API yams_status_t yams_cdc_chunk_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                                   const uint64_t* blob_offsets_host,
+                                                   const uint64_t* blob_lengths_host,
+                                                   uint64_t n_blobs, const yams_cdc_config_t* cfg,
+                                                   yams_ingest_result_t* out);
+/* The ingest hot path: chunk boundaries + per-chunk SHA-256 + whole-blob SHA-256
+ * (content_store_impl.cpp:199-231).  flags: bit0 = chunk digests, bit1 = blob digests. */
+#define YAMS_INGEST_CHUNK_DIGESTS 1u
+#define YAMS_INGEST_BLOB_DIGESTS 2u
+YAMS_ACCEL_API yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                                const uint64_t* blob_offsets_host,
+                                                const uint64_t* blob_lengths_host,
+                                                uint64_t n_blobs, const yams_cdc_config_t* cfg,
+                                                uint32_t flags, yams_ingest_result_t* out);
+
+/* IChunker::chunkDataLazy over host memory (chunker.h:84-86): fills caller arrays; hex may be
+ * NULL.  Returns the chunk count in *out_count (cap = capacity of the arrays; if the count
+ * exceeds cap the status is YAMS_ERR_INVALID_ARG and *out_count holds the required size). */
+YAMS_ACCEL_API yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint8_t* data_host,
+                                                 size_t n, const yams_cdc_config_t* cfg,
+                                                 uint64_t* offsets, uint64_t* sizes,
+                                                 char* hex /* [cap][65] */, size_t cap,
+                                                 size_t* out_count);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Plugin vtables (obtained through yams_plugin_get_interface)                                  */
+/* ------------------------------------------------------------------------------------------ */
+#define YAMS_IFACE_VECTOR_SCAN_V1 "vector_scan_v1"
+#define YAMS_IFACE_VECTOR_SCAN_V1_VERSION 1u
+#define YAMS_IFACE_CONTENT_HASH_V1 "content_hash_v1"
+#define YAMS_IFACE_CONTENT_HASH_V1_VERSION 1u
+#define YAMS_IFACE_CHUNKER_V1 "chunker_v1"
+#define YAMS_IFACE_CHUNKER_V1_VERSION 1u
+
+typedef struct yams_scan_hit_s {
+    int64_t row;      /* row ordinal in the mirror (host maps it to its VectorRecord)            */
+    float similarity; /* relevance_score */
+    float distance;   /* L2 distance for YAMS_SCAN_L2, else 1 - similarity
+                         (utils::similarityToDistance, vector_database.cpp:1867-1875)           */
+} yams_scan_hit_t;
+
+typedef struct yams_vector_scan_v1 {
+    uint32_t abi_version; /* YAMS_IFACE_VECTOR_SCAN_V1_VERSION */
+    void* self;
+    /* Device mirror lifecycle.  `rows` is host memory [n_rows][dim]; tie_ranks nullable. */
+    yams_status_t (*corpus_create)(void* self, uint32_t dim, uint64_t* out_corpus_id);
+    yams_status_t (*corpus_append)(void* self, uint64_t corpus_id, const float* rows,
+                                   uint64_t n_rows);
+    yams_status_t (*corpus_set_tie_ranks)(void* self, uint64_t corpus_id,
+                                          const uint32_t* tie_ranks, uint64_t n_rows);
+    yams_status_t (*corpus_clear)(void* self, uint64_t corpus_id);
+    yams_status_t (*corpus_destroy)(void* self, uint64_t corpus_id);
+    yams_status_t (*corpus_size)(void* self, uint64_t corpus_id, uint64_t* out_rows,
+                                 uint32_t* out_dim);
+    /* Batched search: one contiguous row-major result buffer [n_queries][k] (padded; counts say
+     * how many entries of each row are valid), released with free_hits. */
+    yams_status_t (*search_batch)(void* self, uint64_t corpus_id, const float* queries,
+                                  uint32_t n_queries, uint32_t dim, uint32_t k,
+                                  float similarity_threshold, uint32_t metric,
+                                  yams_scan_hit_t** out_hits, uint32_t** out_counts,
+                                  yams_scan_diag_t* out_diag /* nullable */);
+    void (*free_hits)(void* self, yams_scan_hit_t* hits, uint32_t* counts);
+    yams_status_t (*get_runtime_info_json)(void* self, char** out_json);
+    void (*free_string)(void* self, char* s);
+} yams_vector_scan_v1;
+
+typedef struct yams_content_hash_v1 {
+    uint32_t abi_version; /* YAMS_IFACE_CONTENT_HASH_V1_VERSION */
+    void* self;
+    /* IContentHasher::hash one-shot: 64 hex chars + NUL into out_hex. */
+    yams_status_t (*hash)(void* self, const uint8_t* data, size_t n, char out_hex[65]);
+    /* Many messages per call (what makes a GPU worthwhile). */
+    yams_status_t (*hash_many)(void* self, const uint8_t* const* msgs, const size_t* lens,
+                               size_t n_msgs, char* out_hex /* [n_msgs][65] */);
+    /* Streaming init/update/finalize (sha256_hasher.cpp:81-109): state lives in an opaque handle;
+     * finalize re-initialises the handle like the reference (:103-106). */
+    yams_status_t (*stream_create)(void* self, void** out_stream);
+    yams_status_t (*stream_init)(void* self, void* stream);
+    yams_status_t (*stream_update)(void* self, void* stream, const uint8_t* data, size_t n);
+    yams_status_t (*stream_finalize)(void* self, void* stream, char out_hex[65]);
+    void (*stream_destroy)(void* self, void* stream);
+} yams_content_hash_v1;
+
+typedef struct yams_chunk_ref_s { /* ChunkRef, chunker.h:32-41 (hash as hex) */
+    uint64_t offset;
+    uint64_t size;
+    char hash_hex[65];
+    char pad[7];
+} yams_chunk_ref_t;
+
+typedef struct yams_chunker_v1 {
+    uint32_t abi_version; /* YAMS_IFACE_CHUNKER_V1_VERSION */
+    void* self;
+    yams_status_t (*get_default_config)(void* self, uint32_t mode, yams_cdc_config_t* out_cfg);
+    /* IChunker::chunkDataLazy: offsets, sizes and per-chunk SHA-256. */
+    yams_status_t (*chunk_data)(void* self, const uint8_t* data, size_t n,
+                                const yams_cdc_config_t* cfg, yams_chunk_ref_t** out_chunks,
+                                size_t* out_count);
+    void (*free_chunks)(void* self, yams_chunk_ref_t* chunks, size_t count);
+} yams_chunker_v1;
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* YAMS_MI355X_ACCEL_H */

@@ -1,0 +1,257 @@
+"""Thin numpy-facing wrapper over the C ABI (one context = one device + one stream).
+
+All compute happens in libyams_mi355x_accel.so on the GPU.  Device memory is addressed by integer
+pointers (e.g. `tensor.data_ptr()`); `DeviceArray` is a minimal owner for hosts without torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AccelError, CdcConfig, IngestResult, ScanCorpus, ScanDiag, ScanParams,
+                   CDC_RABIN, CDC_STREAMING, SCAN_COSINE, SCAN_L2)
+
+DEFAULT_POLY = 0x3DA3358B4DC173
+
+
+def cdc_config(mode="streaming", window=48, min_size=16 * 1024, max_size=1024 * 1024,
+               polynomial=DEFAULT_POLY, mask=0x1FFF) -> CdcConfig:
+    m = CDC_STREAMING if mode in ("streaming", CDC_STREAMING) else CDC_RABIN
+    return CdcConfig(window, min_size, max_size, polynomial, mask, m, 0)
+
+
+class DeviceArray:
+    """Owns a hipMalloc'd buffer; `.ptr` is the device address."""
+
+    def __init__(self, acc: "Accel", nbytes: int):
+        self.acc = acc
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        acc._check(acc.L.yams_accel_malloc(acc.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        self.acc._check(self.acc.L.yams_accel_upload(self.acc.ctx, self.ptr + offset,
+                                                     arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count: int, offset: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            self.acc._check(self.acc.L.yams_accel_download(self.acc.ctx, out.ctypes.data,
+                                                           self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.acc.L.yams_accel_free(self.acc.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+@dataclass
+class ScanResult:
+    scores: np.ndarray   # [nq, k] float32 (cosine similarity / relevance_score)
+    rows: np.ndarray     # [nq, k] int64
+    counts: np.ndarray   # [nq] uint32
+    dist: np.ndarray     # [nq, k] float32
+    diag: dict
+
+
+class Accel:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.L = _lib.load()
+        if self.L.yams_accel_device_count() <= 0:
+            raise AccelError(_lib.YAMS_ERR_UNSUPPORTED,
+                             "no HIP device visible (the accelerator path has no CPU fallback)")
+        ctx = C.c_void_p()
+        st = self.L.yams_accel_ctx_create(device, C.c_void_p(stream) if stream else None,
+                                          C.byref(ctx))
+        if st != 0:
+            raise AccelError(st, "yams_accel_ctx_create failed")
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.yams_accel_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != 0:
+            raise AccelError(st, self.L.yams_accel_last_error(self.ctx).decode())
+
+    # ---- misc ---------------------------------------------------------------------------------
+    def device_info(self) -> dict:
+        p = C.c_void_p()
+        self._check(self.L.yams_accel_device_info_json(self.ctx, C.byref(p)))
+        s = C.string_at(p).decode()
+        self.L.yams_accel_free_string(p)
+        return json.loads(s)
+
+    def synchronize(self):
+        self._check(self.L.yams_accel_ctx_synchronize(self.ctx))
+
+    def alloc(self, nbytes: int) -> DeviceArray:
+        return DeviceArray(self, nbytes)
+
+    def to_device(self, arr: np.ndarray) -> DeviceArray:
+        arr = np.ascontiguousarray(arr)
+        return DeviceArray(self, max(arr.nbytes, 16)).upload(arr)
+
+    def enable_timing(self, on: bool = True):
+        self._check(self.L.yams_accel_enable_kernel_timing(self.ctx, 1 if on else 0))
+
+    def kernel_ms(self, name: str):
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        st = self.L.yams_accel_last_kernel_ms(self.ctx, name.encode(), C.byref(ms), C.byref(n))
+        if st == _lib.YAMS_ERR_NOT_FOUND:
+            return None, 0
+        self._check(st)
+        return ms.value, n.value
+
+    # ---- exact vector scan --------------------------------------------------------------------
+    def corpus_view(self, rows_ptr: int, n_rows: int, dim: int, tie_rank_ptr: int | None = None,
+                    rank_row_ptr: int | None = None, row_base: int = 0) -> ScanCorpus:
+        return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base)
+
+    def scan_topk_device(self, corpus: ScanCorpus, queries_ptr: int, nq: int, k: int,
+                         threshold: float, metric: int, out_scores: int, out_rows: int,
+                         out_counts: int, out_dist: int | None = None,
+                         out_ranks: int | None = None, flags: int = 0, want_diag: bool = True):
+        prm = ScanParams(k, threshold, metric, flags)
+        diag = ScanDiag()
+        self._check(self.L.yams_scan_topk_device(self.ctx, C.byref(corpus), queries_ptr, nq,
+                                                 C.byref(prm), out_scores, out_rows, out_counts,
+                                                 out_dist, out_ranks,
+                                                 C.byref(diag) if want_diag else None))
+        return diag.as_dict() if want_diag else None
+
+    def scan_topk(self, corpus: ScanCorpus, queries: np.ndarray, k: int, threshold: float = 0.0,
+                  metric: int = SCAN_COSINE, flags: int = 0) -> ScanResult:
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        kk = max(k, 1)
+        scores = np.full((nq, kk), -np.inf, np.float32)
+        rows = np.full((nq, kk), -1, np.int64)
+        counts = np.zeros(nq, np.uint32)
+        dist = np.full((nq, kk), np.inf, np.float32)
+        prm = ScanParams(k, threshold, metric, flags)
+        diag = ScanDiag()
+        self._check(self.L.yams_scan_topk_host(self.ctx, C.byref(corpus), q.ctypes.data, nq,
+                                               C.byref(prm), scores.ctypes.data, rows.ctypes.data,
+                                               counts.ctypes.data, dist.ctypes.data,
+                                               C.byref(diag)))
+        return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
+
+    def merge_topk_device(self, n_shards, nq, k, threshold, metric, in_scores, in_rows, in_counts,
+                          in_dist, in_ranks, out_scores, out_rows, out_counts, out_dist):
+        prm = ScanParams(k, threshold, metric, 0)
+        self._check(self.L.yams_scan_merge_topk_device(self.ctx, n_shards, nq, C.byref(prm),
+                                                       in_scores, in_rows, in_counts, in_dist,
+                                                       in_ranks, out_scores, out_rows, out_counts,
+                                                       out_dist))
+
+    def synth_rows(self, seed: int, row0: int, n_rows: int, dim: int, out_ptr: int):
+        self._check(self.L.yams_synth_rows_device(self.ctx, seed, row0, n_rows, dim, out_ptr))
+
+    def synth_bytes(self, seed: int, blob0: int, n_blobs: int, blob_len: int, out_ptr: int):
+        self._check(self.L.yams_synth_bytes_device(self.ctx, seed, blob0, n_blobs, blob_len, out_ptr))
+
+    # ---- SHA-256 ------------------------------------------------------------------------------
+    def sha256_hex(self, data: bytes | np.ndarray) -> str:
+        a = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, np.uint8)
+        out = C.create_string_buffer(65)
+        self._check(self.L.yams_sha256_host(self.ctx, a.ctypes.data if a.size else None, a.size, out))
+        return out.value.decode()
+
+    def sha256_many(self, msgs: list) -> list[str]:
+        arrs = [np.frombuffer(bytes(m), np.uint8) if not isinstance(m, np.ndarray)
+                else np.ascontiguousarray(m, np.uint8) for m in msgs]
+        n = len(arrs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        out = C.create_string_buffer(65 * n)
+        self._check(self.L.yams_sha256_many_host(self.ctx, ptrs, lens, n, out))
+        raw = out.raw
+        return [raw[65 * i:65 * i + 64].decode() for i in range(n)]
+
+    def sha256_batch_device(self, data_ptr, offsets_ptr, lengths_ptr, n, digests_ptr):
+        self._check(self.L.yams_sha256_batch_device(self.ctx, data_ptr, offsets_ptr, lengths_ptr,
+                                                    n, digests_ptr))
+
+    # ---- chunking / ingest ----------------------------------------------------------------------
+    def chunk(self, data, cfg: CdcConfig | None = None, with_hashes: bool = True):
+        """IChunker::chunkDataLazy over host memory -> (offsets, sizes, hex hashes | None)."""
+        cfg = cfg or cdc_config()
+        a = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, np.uint8)
+        floor = max(1, int(cfg.min_size))
+        cap = a.size // floor + 2
+        off = np.zeros(cap, np.uint64)
+        sz = np.zeros(cap, np.uint64)
+        hexbuf = C.create_string_buffer(65 * cap) if with_hashes else None
+        cnt = C.c_size_t(0)
+        self._check(self.L.yams_cdc_chunk_host(self.ctx, a.ctypes.data if a.size else None, a.size,
+                                               C.byref(cfg), off.ctypes.data_as(_lib.u64p),
+                                               sz.ctypes.data_as(_lib.u64p), hexbuf, cap,
+                                               C.byref(cnt)))
+        n = cnt.value
+        hashes = None
+        if with_hashes:
+            raw = hexbuf.raw
+            hashes = [raw[65 * i:65 * i + 64].decode() for i in range(n)]
+        return off[:n].copy(), sz[:n].copy(), hashes
+
+    def ingest_device(self, data_ptr: int, blob_offsets, blob_lengths, cfg: CdcConfig | None = None,
+                      flags: int = 3) -> IngestResult:
+        cfg = cfg or cdc_config()
+        bo = np.ascontiguousarray(blob_offsets, np.uint64)
+        bl = np.ascontiguousarray(blob_lengths, np.uint64)
+        res = IngestResult()
+        self._check(self.L.yams_ingest_device(self.ctx, data_ptr, bo.ctypes.data_as(_lib.u64p),
+                                              bl.ctypes.data_as(_lib.u64p), bo.size, C.byref(cfg),
+                                              flags, C.byref(res)))
+        return res
+
+    def download(self, ptr: int, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            self._check(self.L.yams_accel_download(self.ctx, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def fetch_ingest(self, res: IngestResult, n_blobs: int) -> dict:
+        n = res.n_chunks
+        out = {"n_chunks": n,
+               "chunk_offset": self.download(res.chunk_offset, np.uint64, n),
+               "chunk_size": self.download(res.chunk_size, np.uint64, n),
+               "chunk_blob": self.download(res.chunk_blob, np.uint32, n),
+               "blob_first": self.download(res.blob_first, np.uint64, n_blobs + 1)}
+        if res.chunk_digest:
+            out["chunk_digest"] = self.download(res.chunk_digest, np.uint8, n * 32).reshape(n, 32)
+        if res.blob_digest:
+            out["blob_digest"] = self.download(res.blob_digest, np.uint8, n_blobs * 32).reshape(n_blobs, 32)
+        return out

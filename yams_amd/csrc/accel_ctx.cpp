@@ -1,0 +1,230 @@
+// accel_ctx.cpp — context lifecycle, workspace, timing, memory helpers of the C ABI.
+#include "accel_ctx.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace yams_accel {
+
+yams_status_t fail(yams_accel_ctx* ctx, yams_status_t st, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what) {
+    std::string m = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) +
+                    ") in " + what;
+    (void)hipGetLastError(); // clear the sticky error
+    // out-of-memory is the only error a caller can act on; everything else is internal
+    return fail(ctx, YAMS_ERR_INTERNAL, m);
+}
+
+yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out) {
+    auto& b = ctx->bufs[name];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.p) {
+            YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            YA_HIP(ctx, hipFree(b.p));
+            b.p = nullptr; b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8; // a little headroom so steady-state calls never realloc
+        want = (want + 255) & ~static_cast<size_t>(255);
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            return hip_fail(ctx, e, (std::string("hipMalloc workspace '") + name + "' of " +
+                                     std::to_string(want) + " bytes").c_str());
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return YAMS_OK;
+}
+
+yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->pinned_cap < bytes) {
+        if (ctx->pinned) {
+            YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            YA_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr; ctx->pinned_cap = 0;
+        }
+        size_t want = (bytes * 2 + 4095) & ~static_cast<size_t>(4095);
+        YA_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_cap = want;
+    }
+    *out = ctx->pinned;
+    return YAMS_OK;
+}
+
+static hipEvent_t get_event(yams_accel_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+TimedRegion::TimedRegion(yams_accel_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->timing) return;
+    a = get_event(ctx);
+    b = get_event(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+void TimedRegion::end() {
+    if (!ctx->timing || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->spans[name].push_back({a, b});
+}
+
+} // namespace yams_accel
+
+using namespace yams_accel;
+
+extern "C" {
+
+int yams_accel_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+yams_status_t yams_accel_ctx_create(int device, void* hip_stream, yams_accel_ctx** out_ctx) {
+    if (!out_ctx) return YAMS_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int n = yams_accel_device_count();
+    if (n <= 0) return YAMS_ERR_UNSUPPORTED; // no GPU: there is deliberately no CPU fallback
+    if (device < 0 || device >= n) return YAMS_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return YAMS_ERR_UNSUPPORTED;
+    auto* ctx = new yams_accel_ctx();
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+        ctx->owns_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            delete ctx;
+            return YAMS_ERR_INTERNAL;
+        }
+        ctx->owns_stream = true;
+    }
+    *out_ctx = ctx;
+    return YAMS_OK;
+}
+
+void yams_accel_ctx_destroy(yams_accel_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& kv : ctx->spans)
+        for (auto& s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+yams_status_t yams_accel_ctx_synchronize(yams_accel_ctx* ctx) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return YAMS_OK;
+}
+
+const char* yams_accel_last_error(const yams_accel_ctx* ctx) {
+    return ctx ? ctx->last_error.c_str() : "null context";
+}
+
+yams_status_t yams_accel_device_info_json(yams_accel_ctx* ctx, char** out_json) {
+    if (!ctx || !out_json) return YAMS_ERR_INVALID_ARG;
+    hipDeviceProp_t p;
+    YA_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    std::ostringstream os;
+    os << "{\"backend\":\"hip\",\"arch\":\"" << p.gcnArchName << "\",\"name\":\"" << p.name
+       << "\",\"compute_units\":" << p.multiProcessorCount << ",\"clock_khz\":" << p.clockRate
+       << ",\"memory_clock_khz\":" << p.memoryClockRate << ",\"memory_bus_bits\":" << p.memoryBusWidth
+       << ",\"hbm_bytes\":" << total_b << ",\"hbm_free_bytes\":" << free_b
+       << ",\"lds_per_block\":" << p.sharedMemPerBlock << ",\"wavefront\":" << p.warpSize
+       << ",\"l2_bytes\":" << p.l2CacheSize << ",\"version\":\"" << YAMS_ACCEL_VERSION_STRING
+       << "\"}";
+    const std::string s = os.str();
+    char* buf = static_cast<char*>(std::malloc(s.size() + 1));
+    if (!buf) return YAMS_ERR_INTERNAL;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    *out_json = buf;
+    return YAMS_OK;
+}
+
+void yams_accel_free_string(char* s) { std::free(s); }
+
+yams_status_t yams_accel_malloc(yams_accel_ctx* ctx, size_t bytes, void** out_dev) {
+    if (!ctx || !out_dev) return YAMS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    YA_HIP(ctx, hipMalloc(out_dev, bytes ? bytes : 16));
+    return YAMS_OK;
+}
+void yams_accel_free(yams_accel_ctx* ctx, void* dev) {
+    if (!ctx || !dev) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+}
+yams_status_t yams_accel_upload(yams_accel_ctx* ctx, void* dst_dev, const void* src_host,
+                                size_t bytes) {
+    if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return YAMS_ERR_INVALID_ARG;
+    if (!bytes) return YAMS_OK;
+    YA_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return YAMS_OK;
+}
+yams_status_t yams_accel_download(yams_accel_ctx* ctx, void* dst_host, const void* src_dev,
+                                  size_t bytes) {
+    if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return YAMS_ERR_INVALID_ARG;
+    if (!bytes) return YAMS_OK;
+    YA_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return YAMS_OK;
+}
+
+yams_status_t yams_accel_enable_kernel_timing(yams_accel_ctx* ctx, int enable) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->spans) {
+        for (auto& s : kv.second) { ctx->event_pool.push_back(s.a); ctx->event_pool.push_back(s.b); }
+        kv.second.clear();
+    }
+    ctx->timing = enable != 0;
+    return YAMS_OK;
+}
+
+yams_status_t yams_accel_last_kernel_ms(const yams_accel_ctx* cctx, const char* kernel,
+                                        double* out_ms_per_launch, uint64_t* out_launches) {
+    auto* ctx = const_cast<yams_accel_ctx*>(cctx);
+    if (!ctx || !kernel || !out_ms_per_launch || !out_launches) return YAMS_ERR_INVALID_ARG;
+    *out_ms_per_launch = 0.0;
+    *out_launches = 0;
+    auto it = ctx->spans.find(kernel);
+    if (it == ctx->spans.end() || it->second.empty()) return YAMS_ERR_NOT_FOUND;
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (auto& s : it->second) {
+        float ms = 0.f;
+        YA_HIP(ctx, hipEventElapsedTime(&ms, s.a, s.b));
+        total += ms;
+    }
+    *out_launches = it->second.size();
+    *out_ms_per_launch = total / static_cast<double>(it->second.size());
+    return YAMS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,54 @@
+// accel_ctx.h — the context object behind yams_accel_ctx (host side, C++17).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/yams_mi355x_accel.h"
+
+struct yams_accel_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+
+    // growable named device buffers (workspace); never shrinks
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    std::map<std::string, Buf> bufs;
+    // pinned host staging
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+
+    // optional HIP-event timing of the dominant kernels
+    bool timing = false;
+    struct Span { hipEvent_t a, b; };
+    std::map<std::string, std::vector<Span>> spans;
+    std::vector<hipEvent_t> event_pool;
+
+    // last ingest result (device arrays live in bufs)
+    yams_ingest_result_t ingest{};
+};
+
+namespace yams_accel {
+
+yams_status_t fail(yams_accel_ctx* ctx, yams_status_t st, const std::string& msg);
+yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what);
+
+// Workspace: returns a device pointer of at least `bytes` (contents undefined).
+yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out);
+yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
+
+struct TimedRegion { // RAII-less helper: begin/end record events when timing is enabled
+    yams_accel_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    TimedRegion(yams_accel_ctx* c, const char* n);
+    void end();
+};
+
+#define YA_HIP(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
+    return ::yams_accel::hip_fail((ctx), e__, #expr); } while (0)
+#define YA_TRY(expr) do { yams_status_t s__ = (expr); if (s__ != YAMS_OK) return s__; } while (0)
+
+} // namespace yams_accel

@@ -1,0 +1,279 @@
+// ingest_api.cpp — host orchestration of the content-ingest path behind the C ABI:
+// chunk boundaries (RabinChunker / StreamingChunker semantics), per-chunk SHA-256 and whole-blob
+// SHA-256, i.e. the hash + chunk_file phases of ContentStore::store
+// (src/api/content_store_impl.cpp:199-231 in the reference).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "accel_ctx.h"
+#include "ingest_launch.h"
+
+using namespace yams_accel;
+
+namespace {
+
+constexpr uint64_t kDefaultPoly = 0x3DA3358B4DC173ULL; // rabin_fingerprint_table.h:12
+
+yams_status_t make_params(yams_accel_ctx* ctx, const yams_cdc_config_t* cfg, CdcParams* cp) {
+    if (!cfg) return fail(ctx, YAMS_ERR_INVALID_ARG, "null chunking config");
+    if (cfg->mode != YAMS_CDC_RABIN && cfg->mode != YAMS_CDC_STREAMING)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "unknown chunker mode");
+    cp->polynomial = cfg->polynomial ? cfg->polynomial : kDefaultPoly; // rabin_chunker.cpp:29-37
+    cp->mask = cfg->mask;
+    cp->min_size = cfg->min_size;
+    cp->max_size = cfg->max_size;
+    cp->streaming = cfg->mode == YAMS_CDC_STREAMING;
+    uint64_t w = cfg->window_size;
+    if (cp->streaming) { // streaming_chunker.cpp:44-49 clamps the ring
+        if (w == 0) w = 1; else if (w > 48) w = 48;
+    } else if (w == 0 || w > 48) {
+        // RabinWindow is a fixed 48-byte ring (chunker.h:151-155); other sizes index out of it
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "RabinChunker windowSize must be in [1, 48]");
+    }
+    cp->window = static_cast<uint32_t>(w);
+    if (std::max(cfg->min_size, cfg->max_size) == 0)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "minChunkSize and maxChunkSize are both zero");
+    return YAMS_OK;
+}
+
+yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64_t* blob_off_h,
+                          const uint64_t* blob_len_h, uint64_t n_blobs64,
+                          const yams_cdc_config_t* cfg, uint32_t flags, bool do_chunks,
+                          yams_ingest_result_t* out) {
+    if (!out) return fail(ctx, YAMS_ERR_INVALID_ARG, "null result");
+    std::memset(out, 0, sizeof(*out));
+    if (n_blobs64 >= (1ull << 31)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "too many blobs");
+    const uint32_t n_blobs = static_cast<uint32_t>(n_blobs64);
+    if (n_blobs && (!blob_off_h || !blob_len_h)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob table");
+    CdcParams cp{};
+    if (do_chunks) YA_TRY(make_params(ctx, cfg, &cp));
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+
+    // ---- host metadata -----------------------------------------------------------------------
+    std::vector<uint64_t> meta(static_cast<size_t>(n_blobs) * 2 + 2 * (static_cast<size_t>(n_blobs) + 1));
+    uint64_t* h_off = meta.data();
+    uint64_t* h_len = h_off + n_blobs;
+    uint64_t* h_piece = h_len + n_blobs;        // [n_blobs + 1]
+    uint64_t* h_slot = h_piece + n_blobs + 1;   // [n_blobs + 1]
+    uint64_t pieces = 0, slots = 0, total_bytes = 0;
+    const uint64_t min_eff = std::max<uint64_t>(cp.min_size, 1);
+    for (uint32_t b = 0; b < n_blobs; ++b) {
+        h_off[b] = blob_off_h[b]; h_len[b] = blob_len_h[b];
+        if (h_len[b] && !data) return fail(ctx, YAMS_ERR_INVALID_ARG, "null data");
+        h_piece[b] = pieces; h_slot[b] = slots;
+        pieces += (h_len[b] + kCdcPiece - 1) / kCdcPiece;
+        slots += h_len[b] / min_eff + 2;
+        total_bytes += h_len[b];
+    }
+    h_piece[n_blobs] = pieces; h_slot[n_blobs] = slots;
+    if (pieces >= (1ull << 31)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "more than 2^31 pieces in one call");
+
+    uint64_t* d_meta;
+    YA_TRY(ws_get(ctx, "ing_meta", meta.size() * 8, (void**)&d_meta));
+    if (!meta.empty())
+        YA_HIP(ctx, hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
+    const uint64_t* d_off = d_meta;
+    const uint64_t* d_len = d_off + n_blobs;
+    const uint64_t* d_piece = d_len + n_blobs;
+    const uint64_t* d_slot = d_piece + n_blobs + 1;
+
+    uint64_t* d_blob_first; uint64_t* d_blob_count;
+    YA_TRY(ws_get(ctx, "ing_blob_first", (static_cast<size_t>(n_blobs) + 1) * 8, (void**)&d_blob_first));
+    YA_TRY(ws_get(ctx, "ing_blob_count", (static_cast<size_t>(n_blobs) + 1) * 8, (void**)&d_blob_count));
+
+    uint64_t n_chunks = 0;
+    uint64_t* d_msg_off = nullptr; uint64_t* d_msg_len = nullptr;
+    uint64_t* d_chunk_off = nullptr; uint64_t* d_chunk_size = nullptr; uint32_t* d_chunk_blob = nullptr;
+    const bool want_chunk_dg = do_chunks && (flags & YAMS_INGEST_CHUNK_DIGESTS);
+    const bool want_blob_dg = (flags & YAMS_INGEST_BLOB_DIGESTS) != 0;
+    const uint64_t msg_cap = static_cast<uint64_t>(n_blobs) + (do_chunks ? slots : 0);
+    YA_TRY(ws_get(ctx, "ing_msg_off", msg_cap * 8, (void**)&d_msg_off));
+    YA_TRY(ws_get(ctx, "ing_msg_len", msg_cap * 8, (void**)&d_msg_len));
+    if (n_blobs) {
+        // messages [0, n_blobs) are the whole blobs (longest first in the queue)
+        YA_HIP(ctx, hipMemcpyAsync(d_msg_off, d_off, static_cast<size_t>(n_blobs) * 8, hipMemcpyDeviceToDevice, st));
+        YA_HIP(ctx, hipMemcpyAsync(d_msg_len, d_len, static_cast<size_t>(n_blobs) * 8, hipMemcpyDeviceToDevice, st));
+    }
+
+    if (do_chunks) {
+        uint32_t* d_bitmap; uint64_t* d_slot_off; uint64_t* d_slot_size;
+        YA_TRY(ws_get(ctx, "ing_bitmap", pieces * (kCdcPiece / 32) * 4, (void**)&d_bitmap));
+        YA_TRY(ws_get(ctx, "ing_slot_off", slots * 8, (void**)&d_slot_off));
+        YA_TRY(ws_get(ctx, "ing_slot_size", slots * 8, (void**)&d_slot_size));
+        YA_TRY(ws_get(ctx, "ing_chunk_off", slots * 8, (void**)&d_chunk_off));
+        YA_TRY(ws_get(ctx, "ing_chunk_size", slots * 8, (void**)&d_chunk_size));
+        YA_TRY(ws_get(ctx, "ing_chunk_blob", slots * 4, (void**)&d_chunk_blob));
+        {
+            TimedRegion tr(ctx, "cdc_candidates");
+            YA_HIP(ctx, launch_cdc_candidates(st, data, d_off, d_len, d_piece, n_blobs, pieces, cp, d_bitmap));
+            tr.end();
+        }
+        {
+            TimedRegion tr(ctx, "cdc_walk");
+            YA_HIP(ctx, launch_cdc_walk(st, d_bitmap, d_len, d_piece, d_slot, n_blobs, cp, d_slot_off,
+                                        d_slot_size, d_blob_count));
+            tr.end();
+        }
+        YA_HIP(ctx, launch_chunk_compact(st, d_slot, d_slot_off, d_slot_size, d_blob_count,
+                                         d_blob_first, d_off, n_blobs, d_chunk_off, d_chunk_size,
+                                         d_chunk_blob, d_msg_off + n_blobs, d_msg_len + n_blobs));
+        uint64_t* h_total;
+        YA_TRY(pinned_get(ctx, 64, (void**)&h_total));
+        YA_HIP(ctx, hipMemcpyAsync(h_total, d_blob_first + n_blobs, 8, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipStreamSynchronize(st));
+        n_chunks = *h_total;
+    }
+
+    uint8_t* d_digests = nullptr;
+    if (want_blob_dg || want_chunk_dg) {
+        unsigned long long* d_head;
+        YA_TRY(ws_get(ctx, "ing_queue", 64, (void**)&d_head));
+        YA_TRY(ws_get(ctx, "ing_digests", (static_cast<size_t>(n_blobs) + n_chunks) * 32 + 32, (void**)&d_digests));
+        const uint64_t first = want_blob_dg ? 0 : n_blobs;
+        const uint64_t last = want_chunk_dg ? n_blobs + n_chunks : n_blobs;
+        if (last > first) {
+            TimedRegion tr(ctx, "sha256");
+            YA_HIP(ctx, launch_sha256(st, data, d_msg_off + first, d_msg_len + first, last - first,
+                                      d_digests + first * 32, d_head, nullptr, nullptr, 0, 4096));
+            tr.end();
+        }
+    }
+    out->n_chunks = n_chunks;
+    out->chunk_offset = d_chunk_off;
+    out->chunk_size = d_chunk_size;
+    out->chunk_blob = d_chunk_blob;
+    out->blob_first = do_chunks ? d_blob_first : nullptr;
+    out->chunk_digest = want_chunk_dg ? d_digests + static_cast<size_t>(n_blobs) * 32 : nullptr;
+    out->blob_digest = want_blob_dg ? d_digests : nullptr;
+    ctx->ingest = *out;
+    (void)total_bytes;
+    return YAMS_OK;
+}
+
+void to_hex(const uint8_t* dg, char* out) { // bytesToHex, sha256_hasher.cpp:19-30
+    static const char kHex[] = "0123456789abcdef";
+    for (int i = 0; i < 32; ++i) { out[2 * i] = kHex[dg[i] >> 4]; out[2 * i + 1] = kHex[dg[i] & 15]; }
+    out[64] = 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void yams_cdc_default_config(yams_cdc_config_t* cfg, uint32_t mode) {
+    if (!cfg) return;
+    cfg->window_size = 48;              // chunker.h:45
+    cfg->min_size = 16 * 1024;          // MIN_CHUNK_SIZE, core/types.h:282
+    cfg->max_size = 1024 * 1024;        // MAX_CHUNK_SIZE, core/types.h:284
+    cfg->polynomial = kDefaultPoly;     // chunker.h:49
+    cfg->mask = 0x1FFF;                 // chunker.h:50
+    cfg->mode = mode;
+    cfg->reserved = 0;
+}
+
+yams_status_t yams_cdc_chunk_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                    const uint64_t* blob_offsets_host,
+                                    const uint64_t* blob_lengths_host, uint64_t n_blobs,
+                                    const yams_cdc_config_t* cfg, yams_ingest_result_t* out) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    return ingest_impl(ctx, data, blob_offsets_host, blob_lengths_host, n_blobs, cfg, 0, true, out);
+}
+
+yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                 const uint64_t* blob_offsets_host,
+                                 const uint64_t* blob_lengths_host, uint64_t n_blobs,
+                                 const yams_cdc_config_t* cfg, uint32_t flags,
+                                 yams_ingest_result_t* out) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    return ingest_impl(ctx, data, blob_offsets_host, blob_lengths_host, n_blobs, cfg, flags, true, out);
+}
+
+yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                       const uint64_t* offsets, const uint64_t* lengths,
+                                       uint64_t n_msgs, uint8_t* digests) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (n_msgs == 0) return YAMS_OK;
+    if (!offsets || !lengths || !digests) return fail(ctx, YAMS_ERR_INVALID_ARG, "null message table");
+    (void)hipSetDevice(ctx->device);
+    unsigned long long* d_head;
+    YA_TRY(ws_get(ctx, "ing_queue", 64, (void**)&d_head));
+    TimedRegion tr(ctx, "sha256");
+    YA_HIP(ctx, launch_sha256(ctx->stream, data, offsets, lengths, n_msgs, digests, d_head, nullptr,
+                              nullptr, 0, 4096));
+    tr.end();
+    return YAMS_OK;
+}
+
+yams_status_t yams_sha256_many_host(yams_accel_ctx* ctx, const uint8_t* const* msgs_host,
+                                    const size_t* lens, size_t n_msgs, char* out_hex) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (n_msgs == 0) return YAMS_OK;
+    if (!msgs_host || !lens || !out_hex) return fail(ctx, YAMS_ERR_INVALID_ARG, "null message list");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> table(n_msgs * 2);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_msgs; ++i) {
+        if (lens[i] && !msgs_host[i]) return fail(ctx, YAMS_ERR_INVALID_ARG, "null message");
+        table[i] = total; table[n_msgs + i] = lens[i];
+        total += (lens[i] + 15) & ~static_cast<uint64_t>(15); // keep messages 16-byte aligned
+    }
+    uint8_t* d_data; uint64_t* d_table; uint8_t* d_dg;
+    YA_TRY(ws_get(ctx, "sha_data", total + 64, (void**)&d_data));
+    YA_TRY(ws_get(ctx, "sha_table", table.size() * 8, (void**)&d_table));
+    YA_TRY(ws_get(ctx, "sha_dg", n_msgs * 32, (void**)&d_dg));
+    for (size_t i = 0; i < n_msgs; ++i)
+        if (lens[i])
+            YA_HIP(ctx, hipMemcpyAsync(d_data + table[i], msgs_host[i], lens[i], hipMemcpyHostToDevice, st));
+    YA_HIP(ctx, hipMemcpyAsync(d_table, table.data(), table.size() * 8, hipMemcpyHostToDevice, st));
+    YA_TRY(yams_sha256_batch_device(ctx, d_data, d_table, d_table + n_msgs, n_msgs, d_dg));
+    std::vector<uint8_t> dg(n_msgs * 32);
+    YA_HIP(ctx, hipMemcpyAsync(dg.data(), d_dg, dg.size(), hipMemcpyDeviceToHost, st));
+    YA_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_msgs; ++i) to_hex(dg.data() + 32 * i, out_hex + 65 * i);
+    return YAMS_OK;
+}
+
+yams_status_t yams_sha256_host(yams_accel_ctx* ctx, const uint8_t* data_host, size_t n,
+                               char out_hex[65]) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (!out_hex || (n && !data_host)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null buffer");
+    const uint8_t* msgs[1] = {data_host};
+    const size_t lens[1] = {n};
+    return yams_sha256_many_host(ctx, msgs, lens, 1, out_hex);
+}
+
+yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint8_t* data_host, size_t n,
+                                  const yams_cdc_config_t* cfg, uint64_t* offsets, uint64_t* sizes,
+                                  char* hex, size_t cap, size_t* out_count) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (!out_count || (n && !data_host)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null buffer");
+    *out_count = 0;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    uint8_t* d_data;
+    YA_TRY(ws_get(ctx, "cdc_host_data", n + 64, (void**)&d_data));
+    if (n) YA_HIP(ctx, hipMemcpyAsync(d_data, data_host, n, hipMemcpyHostToDevice, st));
+    const uint64_t off0 = 0, len0 = n;
+    yams_ingest_result_t r;
+    // "Empty input produces no chunks" (tests/unit/chunking/chunking_test.cpp:108-113)
+    YA_TRY(ingest_impl(ctx, d_data, &off0, &len0, n ? 1 : 0, cfg, hex ? YAMS_INGEST_CHUNK_DIGESTS : 0,
+                       true, &r));
+    *out_count = static_cast<size_t>(r.n_chunks);
+    if (r.n_chunks > cap) return fail(ctx, YAMS_ERR_INVALID_ARG, "chunk arrays too small");
+    if (r.n_chunks == 0) return YAMS_OK;
+    if (offsets) YA_HIP(ctx, hipMemcpyAsync(offsets, r.chunk_offset, r.n_chunks * 8, hipMemcpyDeviceToHost, st));
+    if (sizes) YA_HIP(ctx, hipMemcpyAsync(sizes, r.chunk_size, r.n_chunks * 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> dg;
+    if (hex) {
+        dg.resize(r.n_chunks * 32);
+        YA_HIP(ctx, hipMemcpyAsync(dg.data(), r.chunk_digest, dg.size(), hipMemcpyDeviceToHost, st));
+    }
+    YA_HIP(ctx, hipStreamSynchronize(st));
+    if (hex) for (uint64_t i = 0; i < r.n_chunks; ++i) to_hex(dg.data() + 32 * i, hex + 65 * i);
+    return YAMS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,462 @@
+// ingest_kernels.hip — gfx950 integer kernels of the content-ingest path (K5, K6 of SURVEY.md §2).
+//
+// Reference semantics (paths under /root/reference):
+//   src/chunking/rabin_fingerprint_table.h:12-28   out-table
+//   src/chunking/rabin_chunker.cpp:63-152          RabinChunker boundaries
+//   include/yams/chunking/streaming_chunker.h:146-204 + src/chunking/streaming_chunker.cpp:37-69
+//                                                  StreamingChunker boundaries (product default)
+//   src/crypto/sha256_hasher.cpp:167-195           SHA-256 (OpenSSL EVP, FIPS 180-4)
+//
+// The reference's rolling hash  h' = ((h - out[old]) << 8) ^ out[new]  on a uint64_t loses all
+// state after 8 steps (each step shifts it left by 8 bits; subtraction and xor only propagate
+// upward), so the hash at byte n is a pure function of bytes [n-7..n] and [n-W-7..n-W]
+// (SURVEY.md F2).  Candidate detection is therefore a byte-parallel map: every thread warms the
+// recurrence up over the 8 positions before its span and then rolls forward.  Only the min/max
+// selection is sequential, over a sparse bitmap.  No MFMA anywhere: this is byte/integer work.
+#include "common.h"
+#include "ingest_launch.h"
+
+namespace yams_accel {
+
+// ------------------------------------------------------------------------------------------------
+// K6a: candidate bitmap.  One workgroup = one piece (kCdcPiece bytes) of one blob.
+// ------------------------------------------------------------------------------------------------
+constexpr int CDC_THREADS = 256;
+constexpr int CDC_SPAN = kCdcPiece / CDC_THREADS; // bytes per thread (128)
+constexpr int CDC_LOOKBACK = 64;                  // >= window(48) + 8 warm-up steps
+static_assert(CDC_SPAN == 128, "bitmap packing below assumes 128-byte spans");
+
+// skewed LDS byte address: 4 bytes of padding per 128 bytes so that lane-strided spans hit
+// distinct banks.
+__device__ __forceinline__ uint32_t skew(uint32_t b) { return b + ((b >> 7) << 2); }
+
+__global__ __launch_bounds__(CDC_THREADS) void cdc_candidates_kernel(
+    const uint8_t* data, const uint64_t* blob_off, const uint64_t* blob_len,
+    const uint64_t* piece_prefix, uint32_t n_blobs, CdcParams cp, uint32_t* bitmap) {
+    __shared__ uint64_t s_table[256];
+    // lookback + piece + 16 bytes of alignment slack, skewed
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[(CDC_LOOKBACK + kCdcPiece + 32) / 128 * 132 + 264];
+    __shared__ uint32_t s_blob;
+
+    const uint64_t piece = blockIdx.x;
+    if (threadIdx.x == 0) { // binary search: last blob with piece_prefix[b] <= piece
+        uint32_t lo = 0, hi = n_blobs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (piece_prefix[mid] <= piece) lo = mid; else hi = mid;
+        }
+        s_blob = lo;
+    }
+    // out-table (rabin_fingerprint_table.h:17-26): xor of (poly << bit) over the set bits
+    {
+        const int byte = threadIdx.x;
+        uint64_t hsh = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit)
+            if (byte & (1 << bit)) hsh ^= cp.polynomial << bit;
+        s_table[byte] = hsh;
+    }
+    __syncthreads();
+    const uint32_t b = s_blob;
+    const uint64_t blen = blob_len[b];
+    const uint64_t p0 = (piece - piece_prefix[b]) * kCdcPiece; // piece start within the blob
+    const uint8_t* bptr = data + blob_off[b];
+
+    // ---- stage [p0 - LOOKBACK, p0 + piece) into LDS with aligned 16-byte loads -----------------
+    // LDS logical index i corresponds to blob byte (p0 - LOOKBACK - shift + i), where shift makes
+    // the first global address 16-byte aligned.
+    const int64_t first = static_cast<int64_t>(p0) - CDC_LOOKBACK;
+    const uintptr_t gaddr = reinterpret_cast<uintptr_t>(bptr) + first;
+    const uint32_t shift = static_cast<uint32_t>(gaddr & 15u);
+    const uint8_t* gbase = reinterpret_cast<const uint8_t*>(gaddr - shift);
+    const uint32_t total = CDC_LOOKBACK + kCdcPiece + shift; // logical bytes needed
+    const int64_t valid_lo = -first + shift;                          // logical index of blob byte 0
+    const int64_t valid_hi = static_cast<int64_t>(blen) - first + shift; // one past the last byte
+    for (uint32_t i = threadIdx.x * 16; i < total; i += CDC_THREADS * 16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        // a 16-byte granule is loaded only if it overlaps the blob
+        if (static_cast<int64_t>(i) + 16 > valid_lo && static_cast<int64_t>(i) < valid_hi)
+            v = *reinterpret_cast<const uint4*>(gbase + i);
+        // zero bytes that lie outside the blob (before its start or past its end)
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t bi = static_cast<int64_t>(i) + 4 * k;
+            if (bi < valid_lo || bi + 4 > valid_hi) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (bi + e >= valid_lo && bi + e < valid_hi) m |= 0xffu << (8 * e);
+                w[k] &= m;
+            }
+            *reinterpret_cast<uint32_t*>(&s_data[skew(i + 4 * k)]) = w[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- each thread rolls over its 128-byte span ----------------------------------------------
+    const uint32_t W = cp.window;
+    const uint64_t mask = cp.mask;
+    const uint32_t span0 = CDC_LOOKBACK + shift + threadIdx.x * CDC_SPAN; // logical index
+    uint64_t h = 0;
+#pragma unroll
+    for (int wstep = 8; wstep >= 1; --wstep) {
+        const uint32_t i = span0 - wstep;
+        const uint8_t nb = s_data[skew(i)];
+        const uint8_t ob = s_data[skew(i - W)];
+        h = ((h - s_table[ob]) << 8) ^ s_table[nb];
+    }
+    uint32_t bits[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+        uint32_t acc = 0;
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t i = span0 + wd * 32 + j;
+            const uint8_t nb = s_data[skew(i)];
+            const uint8_t ob = s_data[skew(i - W)];
+            h = ((h - s_table[ob]) << 8) ^ s_table[nb];
+            acc |= static_cast<uint32_t>((h & mask) == mask) << j;
+        }
+        bits[wd] = acc;
+    }
+    // positions past the end of the blob carry no candidates
+    const uint64_t pos0 = p0 + static_cast<uint64_t>(threadIdx.x) * CDC_SPAN;
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+        const uint64_t wp = pos0 + wd * 32;
+        if (wp >= blen) bits[wd] = 0;
+        else if (wp + 32 > blen) bits[wd] &= (1u << (blen - wp)) - 1u;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(bitmap + piece * (kCdcPiece / 32) + threadIdx.x * 4);
+    *dst = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6c: boundary walk.  One wave per blob walks the sparse bitmap:
+//   s = 0; while s < N: lo = s + min - delta (delta = 1 for Streaming, 0 for Rabin);
+//   p = first candidate >= lo with p < min(s + max, N); end = found ? p + 1 : min(s + max, N).
+// (rabin_chunker.cpp:63-110; streaming_chunker.h:146-181.)  Chunks go to per-blob slots.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cdc_walk_kernel(const uint32_t* bitmap,
+                                                      const uint64_t* blob_len,
+                                                      const uint64_t* piece_prefix,
+                                                      const uint64_t* slot_prefix,
+                                                      uint32_t n_blobs, CdcParams cp,
+                                                      uint64_t* slot_off, uint64_t* slot_size,
+                                                      uint64_t* blob_count) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blobs) return;
+    const int lane = threadIdx.x;
+    const uint64_t N = blob_len[b];
+    const uint32_t* bm = bitmap + piece_prefix[b] * (kCdcPiece / 32);
+    const uint64_t nwords = (N + 31) / 32;
+    const uint64_t slot0 = slot_prefix[b];
+    const uint64_t minsz = cp.min_size;
+    const uint64_t maxe = cp.max_size > cp.min_size ? cp.max_size : cp.min_size;
+    const uint64_t delta = cp.streaming ? 1 : 0;
+    uint64_t s = 0, count = 0;
+    while (s < N) {
+        uint64_t lo = s + minsz;
+        lo = lo >= delta ? lo - delta : 0;
+        if (lo < s) lo = s;
+        uint64_t hi = s + maxe; // exclusive bound on tested positions
+        if (hi > N) hi = N;
+        uint64_t end = hi;
+        if (lo < hi) {
+            // scan words [lo/32, (hi-1)/32], 64 words per step
+            const uint64_t w_first = lo >> 5, w_last = (hi - 1) >> 5;
+            for (uint64_t wb = w_first; wb <= w_last; wb += 64) {
+                const uint64_t wi = wb + lane;
+                uint32_t word = 0;
+                if (wi <= w_last && wi < nwords) word = bm[wi];
+                if (wi == w_first) word &= 0xffffffffu << (lo & 31);
+                if (wi == w_last) {
+                    const uint32_t keep = static_cast<uint32_t>(((hi - 1) & 31) + 1);
+                    if (keep < 32) word &= (1u << keep) - 1u;
+                }
+                const unsigned long long ball = __ballot(word != 0);
+                if (ball) {
+                    const int src = __ffsll(static_cast<long long>(ball)) - 1;
+                    const uint32_t wsel = __shfl(word, src);
+                    const uint64_t p = ((wb + src) << 5) + (__ffs(static_cast<int>(wsel)) - 1);
+                    end = p + 1;
+                    break;
+                }
+            }
+        }
+        if (lane == 0) { slot_off[slot0 + count] = s; slot_size[slot0 + count] = end - s; }
+        ++count;
+        s = end;
+    }
+    if (lane == 0) blob_count[b] = count;
+}
+
+// Exclusive prefix over per-blob chunk counts (single workgroup; n_blobs is small metadata).
+__global__ __launch_bounds__(1024) void chunk_prefix_kernel(const uint64_t* blob_count,
+                                                            uint32_t n_blobs, uint64_t* blob_first) {
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blobs; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < n_blobs ? blob_count[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+            uint64_t add = 0;
+            if (static_cast<int>(threadIdx.x) >= d) add = s_part[threadIdx.x - d];
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint64_t incl = s_part[threadIdx.x];
+        if (i < n_blobs) blob_first[i] = s_carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blob_first[n_blobs] = s_carry;
+}
+
+// Scatter per-blob slots into the dense chunk arrays + build the SHA message list
+// (absolute byte offset of every chunk inside `data`).
+__global__ __launch_bounds__(256) void chunk_compact_kernel(
+    const uint64_t* slot_prefix, const uint64_t* slot_off, const uint64_t* slot_size,
+    const uint64_t* blob_count, const uint64_t* blob_first, const uint64_t* blob_off,
+    uint32_t n_blobs, uint64_t* chunk_offset, uint64_t* chunk_size, uint32_t* chunk_blob,
+    uint64_t* msg_off, uint64_t* msg_len) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blobs) return;
+    const uint64_t n = blob_count[b], src = slot_prefix[b], dst = blob_first[b];
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t o = slot_off[src + i], z = slot_size[src + i];
+        chunk_offset[dst + i] = o;
+        chunk_size[dst + i] = z;
+        chunk_blob[dst + i] = b;
+        if (msg_off) { msg_off[dst + i] = blob_off[b] + o; msg_len[dst + i] = z; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: SHA-256, one message per lane, lanes pull messages from a shared queue so that ragged
+// message lengths do not idle the wave.  32-bit integer VALU only.
+// ------------------------------------------------------------------------------------------------
+__constant__ uint32_t kSha256K[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u,
+    0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu,
+    0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu,
+    0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u,
+    0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu,
+    0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu,
+    0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u,
+    0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u,
+    0xc67178f2u};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) {
+    return __builtin_amdgcn_alignbit(x, x, n); // v_alignbit_b32
+}
+
+__device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        if (i >= 16) {
+            const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        const uint32_t ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = h + S1 + ch + kSha256K[i] + w[i & 15];
+        const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        const uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+__device__ __forceinline__ void sha256_init(uint32_t st[8]) {
+    st[0] = 0x6a09e667u; st[1] = 0xbb67ae85u; st[2] = 0x3c6ef372u; st[3] = 0xa54ff53au;
+    st[4] = 0x510e527fu; st[5] = 0x9b05688cu; st[6] = 0x1f83d9abu; st[7] = 0x5be0cd19u;
+}
+
+// Load the 64 bytes at p (any alignment) as 16 big-endian words.  Reads the 17 aligned dwords
+// that cover [p, p+64); `limit` is one past the last byte that may be touched: dwords that start
+// at or beyond it are not loaded (tail blocks).
+__device__ __forceinline__ void load_block_be(const uint8_t* p, const uint8_t* limit, uint32_t w[16]) {
+    const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = static_cast<uint32_t>(ad & 3u);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad - sh);
+    const uint32_t sel = 0x00010203u + sh * 0x01010101u;
+    uint32_t d[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i)
+        d[i] = (reinterpret_cast<const uint8_t*>(q + i) < limit) ? q[i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_perm(d[i + 1], d[i], sel);
+}
+
+struct ShaLane {
+    const uint8_t* p;     // next byte to consume
+    const uint8_t* end;   // one past the message
+    uint64_t total;       // message length in bytes
+    uint64_t index;       // message index (digest slot)
+    uint32_t st[8];
+    int phase;            // 0 = data, 1 = length-only block pending, 2 = idle
+};
+
+__global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
+                                                           const uint64_t* offs,
+                                                           const uint64_t* lens, uint64_t n_msgs,
+                                                           uint8_t* digests,
+                                                           unsigned long long* queue_head,
+                                                           const uint32_t* init_state /*nullable*/,
+                                                           uint32_t* out_state /*nullable*/,
+                                                           int raw_blocks_only) {
+    ShaLane L;
+    L.phase = 2; L.p = nullptr; L.end = nullptr; L.total = 0; L.index = 0;
+    for (;;) {
+        if (L.phase == 2) {
+            const unsigned long long idx = atomicAdd(queue_head, 1ull);
+            if (idx < n_msgs) {
+                L.index = idx;
+                L.p = data + offs[idx];
+                L.total = lens[idx];
+                L.end = L.p + L.total;
+                if (init_state) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) L.st[i] = init_state[idx * 8 + i];
+                } else sha256_init(L.st);
+                L.phase = 0;
+            } else {
+                L.phase = 3; // drained
+            }
+        }
+        if (__all(L.phase == 3)) break;
+        uint32_t w[16];
+        bool final_block = false;
+        if (L.phase == 0) {
+            const uint64_t rem = static_cast<uint64_t>(L.end - L.p);
+            if (rem >= 64) {
+                load_block_be(L.p, L.end, w);
+                L.p += 64;
+                if (raw_blocks_only && L.p == L.end) final_block = true;
+            } else if (raw_blocks_only) {
+                final_block = true; // (only whole blocks are fed in this mode)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = 0;
+            } else {
+                load_block_be(L.p, L.end, w);
+                const uint32_t r = static_cast<uint32_t>(rem);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t lo = 4u * j;
+                    if (r <= lo) w[j] = 0;
+                    else if (r < lo + 4) w[j] &= 0xffffffffu << (8u * (lo + 4 - r));
+                    if ((r >> 2) == static_cast<uint32_t>(j)) w[j] |= 0x80u << (24 - 8 * (r & 3));
+                }
+                L.p = L.end;
+                if (r < 56) {
+                    const uint64_t bitlen = L.total * 8ull;
+                    w[14] = static_cast<uint32_t>(bitlen >> 32);
+                    w[15] = static_cast<uint32_t>(bitlen);
+                    final_block = true;
+                } else {
+                    L.phase = 1;
+                }
+            }
+        } else if (L.phase == 1) {
+#pragma unroll
+            for (int i = 0; i < 14; ++i) w[i] = 0;
+            const uint64_t bitlen = L.total * 8ull;
+            w[14] = static_cast<uint32_t>(bitlen >> 32);
+            w[15] = static_cast<uint32_t>(bitlen);
+            final_block = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = 0;
+        }
+        if (L.phase <= 1 && !(raw_blocks_only && L.total == 0)) sha256_compress(L.st, w);
+        if (final_block && L.phase <= 1) {
+            if (out_state) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) out_state[L.index * 8 + i] = L.st[i];
+            }
+            if (digests) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(digests + L.index * 32);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    dst[i] = __builtin_amdgcn_perm(0u, L.st[i], 0x00010203u); // big-endian bytes
+            }
+            L.phase = 2;
+        }
+    }
+}
+
+// =================================================================================================
+// Launchers
+// =================================================================================================
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint64_t* blob_off,
+                                 const uint64_t* blob_len, const uint64_t* piece_prefix,
+                                 uint32_t n_blobs, uint64_t n_pieces, const CdcParams& cp,
+                                 uint32_t* bitmap) {
+    if (n_pieces == 0) return hipSuccess;
+    hipLaunchKernelGGL(cdc_candidates_kernel, dim3(static_cast<uint32_t>(n_pieces)),
+                       dim3(CDC_THREADS), 0, st, data, blob_off, blob_len, piece_prefix, n_blobs,
+                       cp, bitmap);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_cdc_walk(hipStream_t st, const uint32_t* bitmap, const uint64_t* blob_len,
+                           const uint64_t* piece_prefix, const uint64_t* slot_prefix,
+                           uint32_t n_blobs, const CdcParams& cp, uint64_t* slot_off,
+                           uint64_t* slot_size, uint64_t* blob_count) {
+    if (n_blobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(cdc_walk_kernel, dim3(n_blobs), dim3(64), 0, st, bitmap, blob_len,
+                       piece_prefix, slot_prefix, n_blobs, cp, slot_off, slot_size, blob_count);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_chunk_compact(hipStream_t st, const uint64_t* slot_prefix,
+                                const uint64_t* slot_off, const uint64_t* slot_size,
+                                const uint64_t* blob_count, uint64_t* blob_first,
+                                const uint64_t* blob_off, uint32_t n_blobs, uint64_t* chunk_offset,
+                                uint64_t* chunk_size, uint32_t* chunk_blob, uint64_t* msg_off,
+                                uint64_t* msg_len) {
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(1024), 0, st, blob_count, n_blobs,
+                       blob_first);
+    LAUNCH_CHECK();
+    if (n_blobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(chunk_compact_kernel, dim3(n_blobs), dim3(256), 0, st, slot_prefix, slot_off,
+                       slot_size, blob_count, blob_first, blob_off, n_blobs, chunk_offset,
+                       chunk_size, chunk_blob, msg_off, msg_len);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* offs,
+                         const uint64_t* lens, uint64_t n_msgs, uint8_t* digests,
+                         unsigned long long* queue_head, const uint32_t* init_state,
+                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks) {
+    if (n_msgs == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(queue_head, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    uint64_t want = (n_msgs + 255) / 256;
+    if (want > max_blocks) want = max_blocks;
+    if (want == 0) want = 1;
+    hipLaunchKernelGGL(sha256_batch_kernel, dim3(static_cast<uint32_t>(want)), dim3(256), 0, st,
+                       data, offs, lens, n_msgs, digests, queue_head, init_state, out_state,
+                       raw_blocks_only);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+} // namespace yams_accel

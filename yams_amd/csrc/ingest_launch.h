@@ -1,0 +1,37 @@
+// ingest_launch.h — host-visible launch descriptors for ingest_kernels.hip.
+#pragma once
+#include "common.h"
+
+namespace yams_accel {
+
+constexpr int kCdcPiece = 32768; // bytes of one blob handled by one candidate workgroup
+
+struct CdcParams {
+    uint64_t polynomial;
+    uint64_t mask;
+    uint64_t min_size;
+    uint64_t max_size;
+    uint32_t window;    // effective ring size (1..48)
+    uint32_t streaming; // 1 = StreamingChunker semantics, 0 = RabinChunker
+};
+
+hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint64_t* blob_off,
+                                 const uint64_t* blob_len, const uint64_t* piece_prefix,
+                                 uint32_t n_blobs, uint64_t n_pieces, const CdcParams& cp,
+                                 uint32_t* bitmap);
+hipError_t launch_cdc_walk(hipStream_t st, const uint32_t* bitmap, const uint64_t* blob_len,
+                           const uint64_t* piece_prefix, const uint64_t* slot_prefix,
+                           uint32_t n_blobs, const CdcParams& cp, uint64_t* slot_off,
+                           uint64_t* slot_size, uint64_t* blob_count);
+hipError_t launch_chunk_compact(hipStream_t st, const uint64_t* slot_prefix,
+                                const uint64_t* slot_off, const uint64_t* slot_size,
+                                const uint64_t* blob_count, uint64_t* blob_first,
+                                const uint64_t* blob_off, uint32_t n_blobs, uint64_t* chunk_offset,
+                                uint64_t* chunk_size, uint32_t* chunk_blob, uint64_t* msg_off,
+                                uint64_t* msg_len);
+hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* offs,
+                         const uint64_t* lens, uint64_t n_msgs, uint8_t* digests,
+                         unsigned long long* queue_head, const uint32_t* init_state,
+                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks);
+
+} // namespace yams_accel

@@ -1,0 +1,367 @@
+// scan_api.cpp — host orchestration of the exact vector scan behind the C ABI.
+//
+// Mirrors the control flow of SqliteVecBackend::Impl::searchSimilarBatch ->
+// bruteForceSearchUnlocked (src/vector/sqlite_vec_backend.cpp:1612-1647, 4115-4331) with the
+// corpus read ONCE per batch instead of once per query:
+//   prep (validate, fp64 norms)  -> MFMA sample pass -> thresholds -> MFMA filter pass
+//   -> per-query candidate select -> fp64 re-score + verification (-> widen -> exhaustive fp64).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "accel_ctx.h"
+#include "scan_launch.h"
+
+using namespace yams_accel;
+
+namespace {
+
+constexpr uint64_t kMfmaMinRows = 4096;      // below this the exhaustive fp64 kernel is used
+constexpr uint64_t kExactKeyBudget = 1ull << 31; // bytes of fp64-path keys per batch of queries
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k) {
+    ScanPlan p;
+    p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
+    p.n_tiles = static_cast<uint32_t>((n_rows + kTileRows - 1) / kTileRows);
+    p.n_qtiles = (nq + kTileQueries - 1) / kTileQueries;
+    p.kprime = std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
+    const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 16, 8192));
+    uint32_t want_tiles = static_cast<uint32_t>((s_target + kTileRows - 1) / kTileRows);
+    if (want_tiles == 0) want_tiles = 1;
+    p.sample_stride = std::max<uint32_t>(1, p.n_tiles / want_tiles);
+    p.n_sample_tiles = (p.n_tiles + p.sample_stride - 1) / p.sample_stride;
+    p.n_filter_tiles = p.n_tiles - p.n_sample_tiles;
+    p.sample_rows = static_cast<uint64_t>(p.n_sample_tiles) * kTileRows;
+    p.n_groups = static_cast<uint32_t>(p.sample_rows / kGroupRows);
+    uint64_t cap = std::max<uint64_t>(4096, 8ull * p.kprime * p.sample_stride);
+    if (p.n_groups < p.kprime) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
+    cap = std::min<uint64_t>(cap, std::max<uint64_t>(n_rows, 4096));
+    p.list_cap = round_up(static_cast<uint32_t>(cap), 256);
+    return p;
+}
+
+struct ScanIo {
+    const yams_scan_corpus_t* corpus;
+    const float* queries; uint32_t nq;
+    yams_scan_params_t prm;
+    float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist; uint32_t* out_ranks;
+};
+
+// Exhaustive fp64 path for a subset of queries (slots -> query indices in qmap_host; nullptr = all).
+yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_qnorm,
+                        const std::vector<uint32_t>* subset, uint32_t* d_status,
+                        unsigned long long* d_stat) {
+    const auto& c = *io.corpus;
+    const uint32_t total = subset ? static_cast<uint32_t>(subset->size()) : io.nq;
+    if (total == 0) return YAMS_OK;
+    const uint32_t keep = io.prm.k; // exact keys: the best k ARE the answer
+    const uint64_t key_stride = std::max<uint64_t>(c.n_rows, 1);
+    uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, kExactKeyBudget / (key_stride * 8)));
+    batch = std::min(batch, total);
+    uint64_t* d_keys; uint64_t* d_work; uint32_t* d_qmap;
+    const uint32_t chunks = static_cast<uint32_t>((key_stride + kSelectCap - 1) / kSelectCap);
+    YA_TRY(ws_get(ctx, "exact_keys", static_cast<size_t>(batch) * key_stride * 8, (void**)&d_keys));
+    YA_TRY(ws_get(ctx, "exact_work", static_cast<size_t>(2) * batch * chunks * keep * 8, (void**)&d_work));
+    YA_TRY(ws_get(ctx, "exact_qmap", static_cast<size_t>(total) * 4, (void**)&d_qmap));
+    std::vector<uint32_t> ident;
+    const uint32_t* qm_host;
+    if (subset) qm_host = subset->data();
+    else { ident.resize(total); for (uint32_t i = 0; i < total; ++i) ident[i] = i; qm_host = ident.data(); }
+    YA_HIP(ctx, hipMemcpyAsync(d_qmap, qm_host, static_cast<size_t>(total) * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int metric = static_cast<int>(io.prm.metric);
+    // In the L2 (vec0) contract the cosine threshold applies after the top-k (:4506-4510).
+    for (uint32_t b0 = 0; b0 < total; b0 += batch) {
+        const uint32_t nb = std::min(batch, total - b0);
+        if (c.n_rows > 0) {
+            TimedRegion tr(ctx, "exact_keys");
+            YA_HIP(ctx, launch_exact_keys(ctx->stream, metric, c.rows, c.n_rows, c.dim, io.queries,
+                                          d_qnorm, c.tie_rank, d_qmap + b0, nb,
+                                          io.prm.similarity_threshold, d_keys, key_stride));
+            tr.end();
+        }
+        const uint64_t* res; uint64_t res_stride;
+        YA_HIP(ctx, launch_topk_keys(ctx->stream, d_keys, key_stride,
+                                     static_cast<uint32_t>(c.n_rows), nb, keep, d_work, &res,
+                                     &res_stride));
+        RescoreLaunch R{};
+        R.rows = c.rows; R.n_rows = c.n_rows; R.dim = c.dim; R.queries = io.queries; R.qnorm = d_qnorm;
+        R.tie_rank = c.tie_rank; R.rank_row = c.tie_rank ? c.rank_row : nullptr; R.row_base = c.row_base;
+        R.cand = res; R.cand_stride = res_stride; R.n_cand = std::min<uint32_t>(keep, kRescoreMax);
+        R.tau = nullptr; R.list_count = nullptr; R.list_cap = 0; R.all_rows_listed = 1;
+        R.qmap = d_qmap + b0; R.n_slots = nb; R.k = io.prm.k; R.threshold = io.prm.similarity_threshold;
+        R.flags = io.prm.flags; R.err_bound = 0.0;
+        R.out_scores = io.out_scores; R.out_rows = io.out_rows; R.out_counts = io.out_counts;
+        R.out_dist = io.out_dist; R.out_ranks = io.out_ranks; R.out_status = d_status;
+        R.stat_rescored = d_stat;
+        YA_HIP(ctx, launch_rescore(ctx->stream, metric, R));
+    }
+    return YAMS_OK;
+}
+
+} // namespace
+
+extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
+                                               const yams_scan_corpus_t* corpus,
+                                               const float* queries, uint32_t n_queries,
+                                               const yams_scan_params_t* params, float* out_scores,
+                                               int64_t* out_rows, uint32_t* out_counts,
+                                               float* out_dist, uint32_t* out_ranks,
+                                               yams_scan_diag_t* diag) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (!corpus || !params) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus/params");
+    if (diag) std::memset(diag, 0, sizeof(*diag));
+    if (n_queries == 0) return YAMS_OK; // searchSimilarBatch on an empty batch (:1615-1617)
+    if (!queries || !out_counts) return fail(ctx, YAMS_ERR_INVALID_ARG, "null queries/out_counts");
+    if (params->metric != YAMS_SCAN_COSINE && params->metric != YAMS_SCAN_L2)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "unknown metric");
+    if (corpus->dim == 0) { // query_embedding.empty() -> empty result (:4123-4126)
+        YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(n_queries) * 4, ctx->stream));
+        YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return YAMS_OK;
+    }
+    if (params->k == 0) { // k == 0 returns empty BEFORE the query is validated (:4123-4126)
+        YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(n_queries) * 4, ctx->stream));
+        YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return YAMS_OK;
+    }
+    if (!out_scores || !out_rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null outputs");
+    if (params->k > YAMS_SCAN_MAX_K) return fail(ctx, YAMS_ERR_UNSUPPORTED, "k exceeds YAMS_SCAN_MAX_K");
+    if (corpus->n_rows >= (1ull << 32)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "shard must hold < 2^32 rows");
+    if (corpus->n_rows > 0 && !corpus->rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus rows");
+    if ((corpus->tie_rank == nullptr) != (corpus->rank_row == nullptr))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "tie_rank and rank_row must be given together");
+    (void)hipSetDevice(ctx->device);
+
+    const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
+    const int metric = static_cast<int>(params->metric);
+    hipStream_t st = ctx->stream;
+    ScanIo io{corpus, queries, nq, *params, out_scores, out_rows, out_counts, out_dist, out_ranks};
+
+    // ---- prep --------------------------------------------------------------------------------
+    float* d_qprep; double* d_qnorm; float* d_qnorm_up; uint32_t* d_qflags; uint32_t* d_status;
+    unsigned long long* d_stat;
+    YA_TRY(ws_get(ctx, "qprep", static_cast<size_t>(nq) * dim * 4, (void**)&d_qprep));
+    YA_TRY(ws_get(ctx, "qnorm", static_cast<size_t>(nq) * 8, (void**)&d_qnorm));
+    YA_TRY(ws_get(ctx, "qnorm_up", static_cast<size_t>(nq) * 4, (void**)&d_qnorm_up));
+    YA_TRY(ws_get(ctx, "qflags", static_cast<size_t>(nq) * 4, (void**)&d_qflags));
+    YA_TRY(ws_get(ctx, "status", static_cast<size_t>(nq) * 4, (void**)&d_status));
+    YA_TRY(ws_get(ctx, "stat", 64, (void**)&d_stat));
+    YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
+    YA_HIP(ctx, hipMemsetAsync(d_status, 0, static_cast<size_t>(nq) * 4, st));
+    YA_HIP(ctx, launch_prep_queries(st, queries, nq, dim, metric, d_qprep, d_qnorm, d_qnorm_up, d_qflags));
+
+    uint32_t* h_pin;
+    YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 4 * 4 + 64, (void**)&h_pin));
+    uint32_t* h_flags = h_pin;
+    uint32_t* h_status = h_pin + nq;
+    uint32_t* h_lcount = h_pin + 2 * static_cast<size_t>(nq);
+    float* h_qnup = reinterpret_cast<float*>(h_pin + 3 * static_cast<size_t>(nq));
+
+    const bool aligned = (reinterpret_cast<uintptr_t>(corpus->rows) & 15u) == 0 && (dim & 3u) == 0;
+    bool use_mfma = !(params->flags & YAMS_SCAN_FLAG_FORCE_EXACT) && aligned &&
+                    corpus->n_rows >= kMfmaMinRows;
+    if (use_mfma && metric == YAMS_SCAN_L2) {
+        // The L2 filter works on raw magnitudes; queries far outside the fp32 comfort zone take
+        // the fp64 path (needs the norms on the host: one small sync).
+        YA_HIP(ctx, hipMemcpyAsync(h_qnup, d_qnorm_up, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < nq; ++i)
+            if (!(h_qnup[i] < 1e15f) || (h_qnup[i] != 0.f && h_qnup[i] < 1e-15f)) use_mfma = false;
+    }
+
+    uint64_t filter_candidates = 0;
+    uint32_t widened = 0, exact_fb = 0;
+    if (!use_mfma) {
+        YA_TRY(run_exact(ctx, io, d_qnorm, nullptr, d_status, d_stat));
+        YA_HIP(ctx, hipMemcpyAsync(h_flags, d_qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipStreamSynchronize(st));
+        if (diag) diag->path = 1;
+    } else {
+        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k);
+        ScanLaunch L;
+        L.plan = plan; L.rows = corpus->rows; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
+        L.err_coef = static_cast<float>((dim + 8) * 5.9604644775390625e-8 * 1.01);
+        float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
+        YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
+        YA_TRY(ws_get(ctx, "gmax", static_cast<size_t>(nq) * plan.n_groups * 4, (void**)&L.gmax));
+        YA_TRY(ws_get(ctx, "tau", static_cast<size_t>(nq) * 4, (void**)&d_tau));
+        YA_TRY(ws_get(ctx, "lcount", static_cast<size_t>(nq) * 4, (void**)&d_lcount));
+        YA_TRY(ws_get(ctx, "list", static_cast<size_t>(nq) * plan.list_cap * 8, (void**)&d_list));
+        const uint32_t gchunks = (plan.n_groups + kSelectCap - 1) / kSelectCap;
+        YA_TRY(ws_get(ctx, "work32", static_cast<size_t>(2) * nq * std::max(1u, gchunks) * plan.kprime * 4, (void**)&d_work32));
+        const uint32_t lchunks = (plan.list_cap + kSelectCap - 1) / kSelectCap;
+        const uint32_t keep_max = kRescoreMax + 1;
+        YA_TRY(ws_get(ctx, "work64", static_cast<size_t>(2) * nq * lchunks * keep_max * 8, (void**)&d_work64));
+        L.tau = d_tau; L.tau_out = d_tau; L.list_count = d_lcount; L.list = d_list;
+        YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
+
+        { TimedRegion tr(ctx, "scan_sample"); YA_HIP(ctx, launch_scan_sample(st, L, metric)); tr.end(); }
+        YA_HIP(ctx, launch_select_tau(st, L, d_work32));
+        YA_HIP(ctx, launch_collect_sample(st, L));
+        { TimedRegion tr(ctx, "scan_filter"); YA_HIP(ctx, launch_scan_filter(st, L, metric)); tr.end(); }
+
+        // stage 1: re-score the best kprime filter survivors of every query
+        const double err_bound = (metric == YAMS_SCAN_COSINE)
+                                     ? (2.0 * dim + 32.0) * 5.9604644775390625e-8 : 0.0;
+        auto rescore_stage = [&](uint32_t n_slots, const uint32_t* d_qmap, uint32_t n_cand) -> yams_status_t {
+            const uint64_t* res; uint64_t res_stride;
+            YA_HIP(ctx, launch_select_lists(st, d_list, d_lcount, plan.list_cap, n_slots, d_qmap,
+                                            n_cand + 1, d_work64, &res, &res_stride));
+            RescoreLaunch R{};
+            R.rows = corpus->rows; R.n_rows = corpus->n_rows; R.dim = dim; R.queries = queries;
+            R.qnorm = d_qnorm; R.tie_rank = corpus->tie_rank; R.rank_row = nullptr;
+            R.row_base = corpus->row_base; R.cand = res; R.cand_stride = res_stride;
+            R.n_cand = n_cand; R.tau = d_tau; R.list_count = d_lcount; R.list_cap = plan.list_cap;
+            R.all_rows_listed = 0; R.qmap = d_qmap; R.n_slots = n_slots; R.k = k;
+            R.threshold = params->similarity_threshold; R.flags = params->flags;
+            R.err_bound = err_bound; R.out_scores = out_scores; R.out_rows = out_rows;
+            R.out_counts = out_counts; R.out_dist = out_dist; R.out_ranks = out_ranks;
+            R.out_status = d_status; R.stat_rescored = d_stat;
+            YA_HIP(ctx, launch_rescore(st, metric, R));
+            return YAMS_OK;
+        };
+        YA_TRY(rescore_stage(nq, nullptr, plan.kprime));
+        YA_HIP(ctx, hipMemcpyAsync(h_flags, d_qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipMemcpyAsync(h_status, d_status, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipMemcpyAsync(h_lcount, d_lcount, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<uint32_t> failed;
+        for (uint32_t i = 0; i < nq; ++i) {
+            filter_candidates += std::min<uint32_t>(h_lcount[i], plan.list_cap);
+            if (h_status[i] != 0 && h_flags[i] == 0) failed.push_back(i);
+        }
+        if (!failed.empty() && plan.kprime < kRescoreMax) {
+            // stage 2: widen to everything the list holds (up to kRescoreMax candidates)
+            widened = static_cast<uint32_t>(failed.size());
+            uint32_t* d_qmap;
+            YA_TRY(ws_get(ctx, "widen_qmap", failed.size() * 4, (void**)&d_qmap));
+            YA_HIP(ctx, hipMemcpyAsync(d_qmap, failed.data(), failed.size() * 4, hipMemcpyHostToDevice, st));
+            YA_TRY(rescore_stage(static_cast<uint32_t>(failed.size()), d_qmap, kRescoreMax));
+            YA_HIP(ctx, hipMemcpyAsync(h_status, d_status, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            std::vector<uint32_t> still;
+            for (uint32_t q : failed) if (h_status[q] != 0) still.push_back(q);
+            failed.swap(still);
+        }
+        if (!failed.empty()) {
+            // stage 3: exhaustive fp64 for the queries that could not be proven complete
+            exact_fb = static_cast<uint32_t>(failed.size());
+            YA_TRY(run_exact(ctx, io, d_qnorm, &failed, d_status, d_stat));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
+
+    // ---- query validity (:4127-4130): a batch fails as a whole (:1635-1647) ---------------------
+    for (uint32_t i = 0; i < nq; ++i) {
+        const uint32_t f = h_flags[i];
+        const bool bad = (metric == YAMS_SCAN_COSINE) ? (f != 0) : ((f & 1u) != 0);
+        if (bad)
+            return fail(ctx, YAMS_ERR_INVALID_ARG,
+                        "Exact vector search requires a finite, non-zero query embedding");
+    }
+    if (diag) {
+        unsigned long long h_stat = 0;
+        YA_HIP(ctx, hipMemcpyAsync(&h_stat, d_stat, 8, hipMemcpyDeviceToHost, st));
+        uint32_t* h_counts = h_status; // reuse pinned space
+        YA_HIP(ctx, hipMemcpyAsync(h_counts, out_counts, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipStreamSynchronize(st));
+        diag->used_exact_scan = 1;
+        diag->rows_visited_observed = 1;
+        diag->rows_visited = static_cast<uint64_t>(nq) * corpus->n_rows;
+        diag->exact_distance_evaluations = static_cast<uint64_t>(nq) * corpus->n_rows;
+        uint64_t ret = 0;
+        for (uint32_t i = 0; i < nq; ++i) ret += h_counts[i];
+        diag->returned_rows = ret;
+        diag->filter_candidates = filter_candidates;
+        diag->rescored_rows = h_stat;
+        diag->widened_queries = widened;
+        diag->exact_fallback_queries = exact_fb;
+    }
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_scan_topk_host(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus,
+                                             const float* queries_host, uint32_t n_queries,
+                                             const yams_scan_params_t* params,
+                                             float* out_scores_host, int64_t* out_rows_host,
+                                             uint32_t* out_counts_host, float* out_dist_host,
+                                             yams_scan_diag_t* diag) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (!corpus || !params) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus/params");
+    if (diag) std::memset(diag, 0, sizeof(*diag));
+    if (n_queries == 0) return YAMS_OK;
+    if (!queries_host || !out_counts_host) return fail(ctx, YAMS_ERR_INVALID_ARG, "null queries/out_counts");
+    (void)hipSetDevice(ctx->device);
+    const size_t nq = n_queries, k = params->k, dim = corpus->dim;
+    float* d_q; float* d_s; int64_t* d_r; uint32_t* d_c; float* d_d;
+    YA_TRY(ws_get(ctx, "h_queries", nq * std::max<size_t>(dim, 1) * 4, (void**)&d_q));
+    YA_TRY(ws_get(ctx, "h_scores", nq * std::max<size_t>(k, 1) * 4, (void**)&d_s));
+    YA_TRY(ws_get(ctx, "h_rows", nq * std::max<size_t>(k, 1) * 8, (void**)&d_r));
+    YA_TRY(ws_get(ctx, "h_counts", nq * 4, (void**)&d_c));
+    YA_TRY(ws_get(ctx, "h_dist", nq * std::max<size_t>(k, 1) * 4, (void**)&d_d));
+    if (dim)
+        YA_HIP(ctx, hipMemcpyAsync(d_q, queries_host, nq * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+    yams_status_t s = yams_scan_topk_device(ctx, corpus, d_q, n_queries, params, d_s, d_r, d_c,
+                                            d_d, nullptr, diag);
+    if (s != YAMS_OK) return s;
+    YA_HIP(ctx, hipMemcpyAsync(out_counts_host, d_c, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (k && out_scores_host)
+        YA_HIP(ctx, hipMemcpyAsync(out_scores_host, d_s, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (k && out_rows_host)
+        YA_HIP(ctx, hipMemcpyAsync(out_rows_host, d_r, nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (k && out_dist_host && dim)
+        YA_HIP(ctx, hipMemcpyAsync(out_dist_host, d_d, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_scan_merge_topk_device(
+    yams_accel_ctx* ctx, uint32_t n_shards, uint32_t n_queries, const yams_scan_params_t* params,
+    const float* in_scores, const int64_t* in_rows, const uint32_t* in_counts, const float* in_dist,
+    const uint32_t* in_ranks, float* out_scores, int64_t* out_rows, uint32_t* out_counts,
+    float* out_dist) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (!params || n_shards == 0) return fail(ctx, YAMS_ERR_INVALID_ARG, "bad merge arguments");
+    if (n_queries == 0) return YAMS_OK;
+    if (!in_counts || !out_counts) return fail(ctx, YAMS_ERR_INVALID_ARG, "null counts");
+    (void)hipSetDevice(ctx->device);
+    if (params->k == 0) {
+        YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(n_queries) * 4, ctx->stream));
+        return YAMS_OK;
+    }
+    if (!in_scores || !in_rows || !out_scores || !out_rows)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "null merge buffers");
+    if (params->metric == YAMS_SCAN_L2 && !in_dist)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "L2 merge needs distances");
+    if (static_cast<uint64_t>(n_shards) * params->k > 8192)
+        return fail(ctx, YAMS_ERR_UNSUPPORTED, "n_shards * k exceeds 8192");
+    MergeLaunch M{};
+    M.n_shards = n_shards; M.n_queries = n_queries; M.k = params->k; M.metric = params->metric;
+    M.threshold = params->similarity_threshold; M.in_scores = in_scores; M.in_rows = in_rows;
+    M.in_counts = in_counts; M.in_dist = in_dist; M.in_ranks = in_ranks; M.out_scores = out_scores;
+    M.out_rows = out_rows; M.out_counts = out_counts; M.out_dist = out_dist;
+    TimedRegion tr(ctx, "merge_topk");
+    YA_HIP(ctx, launch_merge(ctx->stream, M));
+    tr.end();
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_synth_rows_device(yams_accel_ctx* ctx, uint64_t seed, uint64_t row0,
+                                                uint64_t n_rows, uint32_t dim, float* out_dev) {
+    if (!ctx || (!out_dev && n_rows) || dim == 0) return YAMS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    YA_HIP(ctx, launch_synth_rows(ctx->stream, seed, row0, n_rows, dim, out_dev));
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_synth_bytes_device(yams_accel_ctx* ctx, uint64_t seed,
+                                                 uint64_t blob_id0, uint64_t n_blobs,
+                                                 uint64_t blob_len, uint8_t* out_dev) {
+    if (!ctx || (!out_dev && n_blobs && blob_len)) return YAMS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    YA_HIP(ctx, launch_synth_bytes(ctx->stream, seed, blob_id0, n_blobs, blob_len, out_dev));
+    return YAMS_OK;
+}

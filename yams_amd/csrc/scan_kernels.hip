@@ -1,0 +1,1064 @@
+// scan_kernels.hip — gfx950 kernels of the exact vector scan (K1..K4 of SURVEY.md §2).
+//
+// Reference semantics being reproduced (paths under /root/reference):
+//   src/vector/sqlite_vec_backend.cpp:4204-4331  exact cosine scan, fp64 per-row dot / norm,
+//                                                bounded top-k with (similarity desc, chunk_id asc)
+//   src/vector/sqlite_vec_backend.cpp:4450-4530  vec0 L2 top-k + cosine re-score
+//
+// Strategy: the fp64 arithmetic of the reference is only needed for rows that can
+// reach the top k.  An exact-f32 MFMA contraction (v_mfma_f32_32x32x2_f32) scores every
+// (row, query) pair with a rigorously bounded error E, a threshold filter keeps the rows whose
+// f32 score is within reach of the top k, and only those survivors are re-scored in fp64 in the
+// reference's own summation order.  A per-query verification proves that no discarded row could
+// have entered the result; queries that fail it are widened and finally scored exhaustively in
+// fp64 — on the device, never on the CPU.
+#include "common.h"
+
+namespace yams_accel {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int LDP = kSlabK + 4;                                  // padded LDS row stride (floats)
+constexpr int STAGE_FLOATS = (kTileRows + kTileQueries) * LDP;   // one LDS stage
+constexpr int SCAN_THREADS = 256;
+
+enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
+
+struct ScanArgs {
+    const float* rows;      // [n_rows][dim]
+    const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
+    uint64_t n_rows;
+    uint32_t dim;
+    uint32_t n_queries;
+    uint32_t n_sel_tiles;   // tiles this launch covers
+    uint32_t stride;        // sample stride (tile % stride == 0 is a sample tile)
+    uint32_t n_qtiles;
+    // sample mode
+    float* dense;           // [n_queries][sample_rows]
+    uint32_t* gmax;         // [n_queries][n_groups] order-preserving keys
+    uint64_t sample_rows;
+    uint32_t n_groups;
+    // filter mode
+    const float* tau;       // [n_queries]
+    uint32_t* list_count;   // [n_queries]
+    uint64_t* list;         // [n_queries][list_cap]
+    uint32_t list_cap;
+    // L2
+    const float* qnorm_up;  // [n_queries] fp32 upper bound of ||q||
+    float err_coef;         // (dim + 8) * 2^-24 * 1.01
+};
+
+__device__ __forceinline__ bool norm_in_range(float nsq) { return nsq > 1e-30f && nsq < 1e30f; }
+
+// One workgroup = 128 corpus rows x 128 queries, 4 waves as 2 (rows) x 2 (queries), each wave a
+// 64 x 64 block = 2 x 2 MFMA 32x32 tiles.  A operand = corpus rows (accumulator rows, across
+// registers), B operand = queries (accumulator columns, across lanes): a lane owns one query per
+// B tile, so the per-query threshold test in the epilogue is lane-local.
+template <int MODE, int METRIC>
+__global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_FLOATS];
+
+    // XCD-aware mapping: block b runs on XCD b % 8 (observed dispatch); consecutive blocks of one
+    // XCD walk the query tiles of ONE row tile, so the row tile is fetched from HBM once and
+    // re-read from that XCD's L2.
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t w = bid >> 3;
+    const uint32_t qt = w % a.n_qtiles;
+    const uint32_t sel = (w / a.n_qtiles) * 8u + xcd;
+    if (sel >= a.n_sel_tiles) return;
+    uint32_t tile;
+    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
+    else tile = sel + sel / (a.stride - 1u) + 1u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wq = wid & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const uint64_t row0 = static_cast<uint64_t>(tile) * kTileRows;
+    const uint32_t q0 = qt * kTileQueries;
+    const uint32_t dim = a.dim;
+    const int nslab = (dim + kSlabK - 1) / kSlabK;
+
+    // ---- staging addresses: thread -> (row lr + 32*j, float4 column c4) -------------------------
+    const int lr = tid >> 3, c4 = tid & 7;
+    const float* gptr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int R = lr + 32 * j;
+        if (R < kTileRows) {
+            uint64_t r = row0 + R;
+            if (r >= a.n_rows) r = a.n_rows - 1;
+            gptr[j] = a.rows + r * dim + c4 * 4;
+        } else {
+            uint32_t q = q0 + (R - kTileRows);
+            if (q >= a.n_queries) q = a.n_queries - 1;
+            gptr[j] = a.qprep + static_cast<uint64_t>(q) * dim + c4 * 4;
+        }
+    }
+    float4 stage[8];
+    auto load_slab = [&](int s) {
+        const int k = s * kSlabK + c4 * 4;
+        const bool in = k < static_cast<int>(dim);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            stage[j] = in ? *reinterpret_cast<const float4*>(gptr[j] + s * kSlabK)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_slab = [&](int buf) {
+        float* base = lds + buf * STAGE_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *reinterpret_cast<float4*>(base + (lr + 32 * j) * LDP + c4 * 4) = stage[j];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    float nsq[2] = {0.f, 0.f};
+
+    // LDS fragment offsets: lane reads 4 consecutive k of its row; lanes 0-31 take k 0..3 and
+    // lanes 32-63 k 4..7 of each 8-wide k group (the same permutation of k on both operands).
+    const int a_off = (wr * 64 + l31) * LDP + 4 * h;
+    const int b_off = (kTileRows + wq * 64 + l31) * LDP + 4 * h;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab) load_slab(s + 1);
+        const float* base = lds + (s & 1) * STAGE_FLOATS;
+#pragma unroll
+        for (int kg = 0; kg < kSlabK / 8; ++kg) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                af[t] = *reinterpret_cast<const float4*>(base + a_off + t * 32 * LDP + kg * 8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                bf[u] = *reinterpret_cast<const float4*>(base + b_off + u * 32 * LDP + kg * 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                nsq[t] = fmaf(af[t].x, af[t].x, nsq[t]);
+                nsq[t] = fmaf(af[t].y, af[t].y, nsq[t]);
+                nsq[t] = fmaf(af[t].z, af[t].z, nsq[t]);
+                nsq[t] = fmaf(af[t].w, af[t].w, nsq[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].x, bf[u].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].y, bf[u].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].z, bf[u].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].w, bf[u].w, acc[t][u], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nslab) store_slab((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    // Accumulator layout (32x32): column j = lane & 31 (query), row i = (r&3) + 8*(r>>2) + 4*h.
+    uint32_t qidx[2];
+    bool qok[2];
+    float qn_up[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qidx[u] = q0 + wq * 64 + u * 32 + l31;
+        qok[u] = qidx[u] < a.n_queries;
+        if (METRIC == YAMS_SCAN_L2) qn_up[u] = qok[u] ? a.qnorm_up[qidx[u]] : 0.f;
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float nfull = nsq[t] + __shfl_xor(nsq[t], 32);
+        float p0, p1 = 0.f;
+        const bool ok = norm_in_range(nfull);
+        if (METRIC == YAMS_SCAN_COSINE) {
+            p0 = ok ? rsqrtf(nfull) : __builtin_nanf("");
+        } else {
+            // upper bound of g = q.x - |x|^2/2:  dot + nsq*(-0.5 + 0.5 c) + (c*|x|)*|q|
+            p0 = ok ? nfull * (-0.5f + 0.5f * a.err_coef) : __builtin_nanf("");
+            p1 = ok ? a.err_coef * sqrtf(nfull) * 1.000001f : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float rp0 = __shfl(p0, i);
+            if (METRIC == YAMS_SCAN_COSINE) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u][r] = acc[t][u][r] * rp0;
+            } else {
+                const float rp1 = __shfl(p1, i);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u][r] = acc[t][u][r] + rp0 + rp1 * qn_up[u];
+            }
+        }
+    }
+
+    const uint64_t wave_row0 = row0 + wr * 64;
+    if (MODE == MODE_SAMPLE) {
+        const float ninf = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float m = ninf;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const uint64_t rbase = wave_row0 + t * 32 + 8 * g4 + 4 * h;
+                    float4 v;
+                    v.x = (rbase + 0 < a.n_rows) ? acc[t][u][4 * g4 + 0] : ninf;
+                    v.y = (rbase + 1 < a.n_rows) ? acc[t][u][4 * g4 + 1] : ninf;
+                    v.z = (rbase + 2 < a.n_rows) ? acc[t][u][4 * g4 + 2] : ninf;
+                    v.w = (rbase + 3 < a.n_rows) ? acc[t][u][4 * g4 + 3] : ninf;
+                    m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                    if (qok[u]) {
+                        const uint64_t srow = static_cast<uint64_t>(sel) * kTileRows + wr * 64 +
+                                              t * 32 + 8 * g4 + 4 * h;
+                        *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
+                    }
+                }
+                if (qok[u]) {
+                    const uint32_t gid = ((sel * 4u + wr * 2u + t) << 1) + h;
+                    a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = f2ord(m);
+                }
+            }
+    } else {
+        float tau[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) tau[u] = qok[u] ? a.tau[qidx[u]] : __builtin_inff();
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) any |= !(acc[t][u][r] < tau[u]);
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float s = acc[t][u][r];
+                        if (!(s < tau[u])) {
+                            const uint64_t row =
+                                wave_row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (row < a.n_rows && qok[u]) {
+                                const uint32_t pos = atomicAdd(&a.list_count[qidx[u]], 1u);
+                                if (pos < a.list_cap)
+                                    a.list[static_cast<uint64_t>(qidx[u]) * a.list_cap + pos] =
+                                        pack_key(s, static_cast<uint32_t>(row));
+                            }
+                        }
+                    }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// prep_queries: validity + fp64 norm in the reference's summation order (:4206-4211) + the
+// operand the MFMA pass consumes (unit-norm fp32 for cosine, raw for L2).
+//   flags: bit0 = non-finite element, bit1 = norm^2 < 1e-10 (isZeroNormEmbedding, :204-211)
+// -------------------------------------------------------------------------------------------------
+__global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t dim, int metric,
+                                    float* qprep, double* qnorm, float* qnorm_up,
+                                    uint32_t* qflags) {
+    const uint32_t qi = blockIdx.x;
+    __shared__ double s_norm;
+    __shared__ uint32_t s_flag;
+    const float* src = q + static_cast<uint64_t>(qi) * dim;
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        bool finite = true;
+        for (uint32_t i = 0; i < dim; ++i) {
+            const float v = src[i];
+            if (!isfinite(v)) finite = false;
+            const double d = static_cast<double>(v);
+            acc = fma(d, d, acc); // v*v is exact in fp64, so fma == mul then add
+        }
+        uint32_t f = 0;
+        if (!finite) f |= 1u;
+        if (!(acc >= 1e-10)) f |= 2u;
+        s_flag = f;
+        s_norm = sqrt(acc);
+        qflags[qi] = f;
+        qnorm[qi] = s_norm;
+        if (qnorm_up) {
+            float up = static_cast<float>(s_norm);
+            if (static_cast<double>(up) < s_norm) up = nextafterf(up, __builtin_inff());
+            qnorm_up[qi] = up;
+        }
+    }
+    __syncthreads();
+    const double n = s_norm;
+    const bool bad = s_flag != 0;
+    float* dst = qprep + static_cast<uint64_t>(qi) * dim;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) {
+        const float v = src[i];
+        float o;
+        if (bad) o = 0.f;
+        else if (metric == YAMS_SCAN_COSINE) o = static_cast<float>(static_cast<double>(v) / n);
+        else o = v;
+        dst[i] = o;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Block top-k by bitonic sort in LDS.  Grid (n_chunks, n_queries).  Sorts one chunk of up to CAP
+// keys of one query in descending order and writes its best `keep` keys (0-padded).
+// -------------------------------------------------------------------------------------------------
+template <typename K, int CAP, int NT>
+__device__ __forceinline__ void bitonic_desc(K* s) {
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < CAP; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const K x = s[i], y = s[ixj];
+                    const bool up = (i & k) == 0; // descending overall
+                    if (up ? (x < y) : (x > y)) { s[i] = y; s[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename K, int CAP>
+__global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint32_t* in_counts,
+                                                         uint64_t in_stride, uint32_t n_fixed,
+                                                         uint32_t count_clip, K* out,
+                                                         uint64_t out_stride, uint32_t keep,
+                                                         const uint32_t* qmap) {
+    __shared__ K s[CAP];
+    const uint32_t qslot = blockIdx.y;
+    const uint32_t q = qmap ? qmap[qslot] : qslot;
+    uint32_t n = in_counts ? in_counts[q] : n_fixed;
+    if (n > count_clip) n = count_clip;
+    const uint64_t c0 = static_cast<uint64_t>(blockIdx.x) * CAP;
+    const K* src = in + static_cast<uint64_t>(q) * in_stride;
+    K* dst = out + static_cast<uint64_t>(qslot) * out_stride + static_cast<uint64_t>(blockIdx.x) * keep;
+    if (c0 >= n) { // empty chunk: nothing to sort
+        for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = K(0);
+        return;
+    }
+    for (int i = threadIdx.x; i < CAP; i += 256) {
+        const uint64_t e = c0 + i;
+        s[i] = (e < n) ? src[e] : K(0);
+    }
+    __syncthreads();
+    bitonic_desc<K, CAP, 256>(s);
+    for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = (i < CAP) ? s[i] : K(0);
+}
+
+// tau[q] = score of the kprime-th best group maximum (or -inf when there are fewer groups).
+__global__ void tau_from_keys_kernel(const uint32_t* sorted, uint64_t stride, uint32_t kprime,
+                                     uint32_t nq, float* tau) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t key = sorted[static_cast<uint64_t>(q) * stride + (kprime - 1)];
+    tau[q] = key ? ord2f(key) : -__builtin_inff();
+}
+
+// Sample rows that reach the threshold join the candidate lists.
+__global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
+                                                             uint64_t sample_rows, uint32_t stride,
+                                                             uint64_t n_rows, const float* tau,
+                                                             uint32_t* list_count, uint64_t* list,
+                                                             uint32_t list_cap) {
+    const uint32_t q = blockIdx.y;
+    const float t = tau[q];
+    const float* src = dense + static_cast<uint64_t>(q) * sample_rows;
+    for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+         s < sample_rows; s += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float v = src[s];
+        if (!(v < t)) {
+            const uint64_t row = (s / kTileRows) * stride * kTileRows + (s % kTileRows);
+            if (row < n_rows) {
+                const uint32_t pos = atomicAdd(&list_count[q], 1u);
+                if (pos < list_cap)
+                    list[static_cast<uint64_t>(q) * list_cap + pos] =
+                        pack_key(v, static_cast<uint32_t>(row));
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K3: exact fp64 re-score of the candidates, final ordering, verification.
+//
+// One workgroup per query.  Thread c walks candidate c's row in the reference's order
+// (sequential i, fp64 accumulate; v*q and v*v are exact products in fp64 so fma == mul+add),
+// applies the reference's skips (:4258-4279), then the block sorts by (similarity desc, rank asc)
+// and emits the best k.  `bound_key` carries the best f32 filter score among everything that was
+// NOT re-scored; the result is proven complete when even bound + E cannot reach the k-th result.
+// -------------------------------------------------------------------------------------------------
+struct RescoreArgs {
+    const float* rows;
+    uint64_t n_rows;
+    uint32_t dim;
+    const float* queries;       // raw queries [nq][dim]
+    const double* qnorm;        // [nq]
+    const uint32_t* tie_rank;   // nullable
+    const uint32_t* rank_row;   // nullable: candidate keys carry ranks, not rows (exact path)
+    int64_t row_base;
+    const uint64_t* cand;       // [slots][cand_stride] keys sorted best-first (0 = empty)
+    uint64_t cand_stride;
+    uint32_t n_cand;            // candidates to re-score per query
+    const float* tau;           // nullable: list completeness threshold per query
+    const uint32_t* list_count; // nullable
+    uint32_t list_cap;
+    uint32_t all_rows_listed;   // 1: the candidate set is the whole corpus -> always verified
+    const uint32_t* qmap;       // nullable: slot -> query index
+    uint32_t k;
+    float threshold;
+    uint32_t flags;
+    double err_bound;           // E (cosine) ; for L2 the bound is folded into the filter score
+    float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
+    uint32_t* out_ranks;
+    uint32_t* out_status;       // [nq]: 0 verified, 1 needs widening
+    unsigned long long* stat_rescored;
+};
+
+constexpr int RS_MAX = 2048; // max candidates per query per launch
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);              // [RS_MAX]
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + RS_MAX);     // [RS_MAX] candidate slot
+    float* saux = reinterpret_cast<float*>(sidx + RS_MAX);           // [RS_MAX] cosine (L2 mode)
+    float* sq = saux + RS_MAX;                                       // [dim]
+
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = a.qmap ? a.qmap[slot] : slot;
+    const uint32_t dim = a.dim;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
+        sq[i] = a.queries[static_cast<uint64_t>(q) * dim + i];
+    for (int i = threadIdx.x; i < RS_MAX; i += blockDim.x) { skey[i] = 0; sidx[i] = 0; saux[i] = 0.f; }
+    __syncthreads();
+    const double qn = a.qnorm[q];
+    const uint64_t* cand = a.cand + static_cast<uint64_t>(slot) * a.cand_stride;
+
+    uint32_t local_rescored = 0;
+    for (uint32_t c = threadIdx.x; c < a.n_cand; c += blockDim.x) {
+        const uint64_t ck = cand[c];
+        if (ck == 0) continue;
+        const uint32_t row = a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck);
+        const float* x = a.rows + static_cast<uint64_t>(row) * dim;
+        ++local_rescored;
+        double nsq = 0.0, dot = 0.0, dsq = 0.0;
+        const bool vec4 = (dim & 3u) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+        if (vec4) {
+            for (uint32_t i = 0; i < dim; i += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + i);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double sv = static_cast<double>(vv[e]);
+                    const double qv = static_cast<double>(sq[i + e]);
+                    nsq = fma(sv, sv, nsq);
+                    dot = fma(sv, qv, dot);
+                    if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < dim; ++i) {
+                const double sv = static_cast<double>(x[i]);
+                const double qv = static_cast<double>(sq[i]);
+                nsq = fma(sv, sv, nsq);
+                dot = fma(sv, qv, dot);
+                if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+            }
+        }
+        const uint32_t rank = a.tie_rank ? a.tie_rank[row] : row;
+        if (METRIC == YAMS_SCAN_COSINE) {
+            // all elements finite <=> nsq finite (fp64 cannot overflow on fp32 squares)
+            if (!isfinite(nsq) || nsq <= 1e-12) continue;           // :4258-4269
+            const double denom = sqrt(nsq) * qn;                    // :4271
+            const double sd = denom > 0.0 ? dot / denom : 0.0;
+            if (!isfinite(sd)) continue;                            // :4273-4275
+            const float sim = static_cast<float>(sd);               // :4276
+            if (sim < a.threshold) continue;                        // :4277-4279
+            skey[c] = pack_key(sim, rank);
+            sidx[c] = c;
+        } else {
+            if (!isfinite(nsq)) continue; // non-finite rows cannot be stored (vector_database.cpp:1771-1784)
+            const double dd = sqrt(dsq);
+            if (!isfinite(dd)) continue;
+            const float dist = static_cast<float>(dd);
+            // computeCosineSimilarity (vector_database.cpp:1786-1810): sqrt each norm, 0 on zero norm
+            const double na = qn, nb = sqrt(nsq);
+            const double cs = (na == 0.0 || nb == 0.0) ? 0.0 : dot / (na * nb);
+            saux[c] = static_cast<float>(cs);
+            skey[c] = pack_key(-dist, rank); // ascending distance == descending -dist
+            sidx[c] = c;
+        }
+    }
+    if (a.stat_rescored && local_rescored) atomicAdd(a.stat_rescored, (unsigned long long)local_rescored);
+    __syncthreads();
+
+    // bitonic sort (key desc) of RS_MAX pairs
+    for (int kk = 2; kk <= RS_MAX; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < RS_MAX; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = skey[i], y = skey[ixj];
+                    const bool up = (i & kk) == 0;
+                    if (up ? (x < y) : (x > y)) {
+                        skey[i] = y; skey[ixj] = x;
+                        const uint32_t t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- verification ---------------------------------------------------------------------------
+    // Everything outside the re-scored set has filter score <= `ob`:
+    //   * the first list entry that was not re-scored (cand[n_cand]) if there is one,
+    //   * else the list threshold tau (rows below tau never entered the list),
+    //   * or nothing at all when the whole corpus was listed.
+    __shared__ uint32_t s_nvalid;
+    __shared__ uint32_t s_status;
+    if (threadIdx.x == 0) {
+        uint32_t nv = 0;
+        // count valid (non-zero) keys by binary search on the sorted array
+        uint32_t lo = 0, hi = RS_MAX;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skey[mid] != 0) lo = mid + 1; else hi = mid; }
+        nv = lo;
+        s_nvalid = nv;
+        uint32_t status = 0;
+        if (!a.all_rows_listed) {
+            const bool overflow = a.list_count && a.list_count[q] > a.list_cap;
+            const float ninf = -__builtin_inff();
+            double ob = 0.0;
+            bool has_outside = false;
+            const uint64_t nextk = (a.n_cand < a.cand_stride) ? cand[a.n_cand] : 0;
+            if (nextk != 0) { has_outside = true; ob = static_cast<double>(key_score(nextk)); }
+            else if (a.tau && a.tau[q] > ninf) { has_outside = true; ob = static_cast<double>(a.tau[q]); }
+            // (a NaN tau admitted every row to the list, so nothing is outside)
+            if (overflow) status = 1;
+            else if (has_outside) {
+                if (ob != ob) status = 1; // NaN bound: cannot prove anything
+                else if (METRIC == YAMS_SCAN_COSINE) {
+                    const float reach = static_cast<float>(ob + a.err_bound + 1e-12);
+                    if (nv >= a.k) {
+                        const float sim_w = key_score(skey[a.k - 1]);
+                        if (!(reach < sim_w)) status = 1;
+                    } else if (!(reach < a.threshold)) {
+                        status = 1; // an outside row might still pass the threshold
+                    }
+                } else {
+                    // ob bounds g = q.x - |x|^2/2 of every outside row from above:
+                    // d^2 = |q|^2 - 2 g >= |q|^2 - 2 ob
+                    if (nv >= a.k) {
+                        double d2 = qn * qn - 2.0 * ob;
+                        if (d2 < 0.0) d2 = 0.0;
+                        const float dmin = static_cast<float>(sqrt(d2) * (1.0 - 1e-12));
+                        const float dist_w = -key_score(skey[a.k - 1]);
+                        if (!(dmin > dist_w)) status = 1;
+                    } else {
+                        status = 1; // fewer than k valid rows re-scored while others exist
+                    }
+                }
+            }
+        }
+        s_status = status;
+        a.out_status[q] = status;
+    }
+    __syncthreads();
+    const uint32_t nv = s_nvalid;
+    const uint32_t take = nv < a.k ? nv : a.k;
+    if (METRIC == YAMS_SCAN_COSINE) {
+        for (uint32_t i = threadIdx.x; i < a.k; i += blockDim.x) {
+            const uint64_t o = static_cast<uint64_t>(q) * a.k + i;
+            if (i < take) {
+                const uint32_t row = a.rank_row ? a.rank_row[key_idx(cand[sidx[i]])] : key_idx(cand[sidx[i]]);
+                a.out_scores[o] = key_score(skey[i]);
+                a.out_rows[o] = a.row_base + static_cast<int64_t>(row);
+                if (a.out_ranks) a.out_ranks[o] = key_idx(skey[i]);
+            } else {
+                a.out_scores[o] = -__builtin_inff();
+                a.out_rows[o] = -1;
+                if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
+            }
+            if (a.out_dist) a.out_dist[o] = (i < take) ? 1.0f - key_score(skey[i]) : __builtin_inff();
+        }
+        if (threadIdx.x == 0) a.out_counts[q] = take;
+    } else {
+        // vec0 semantics: the k nearest, THEN the cosine threshold (:4506-4510), order preserved.
+        __shared__ uint32_t s_outn;
+        if (threadIdx.x == 0) {
+            uint32_t outn = 0;
+            const bool defer = (a.flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) != 0;
+            for (uint32_t i = 0; i < take; ++i) {
+                const float cs = saux[sidx[i]];
+                if (!defer && cs < a.threshold) continue;
+                const uint64_t o = static_cast<uint64_t>(q) * a.k + outn;
+                const uint32_t row = a.rank_row ? a.rank_row[key_idx(cand[sidx[i]])] : key_idx(cand[sidx[i]]);
+                a.out_scores[o] = cs;
+                a.out_rows[o] = a.row_base + static_cast<int64_t>(row);
+                if (a.out_dist) a.out_dist[o] = -key_score(skey[i]);
+                if (a.out_ranks) a.out_ranks[o] = key_idx(skey[i]);
+                ++outn;
+            }
+            s_outn = outn;
+            a.out_counts[q] = outn;
+        }
+        __syncthreads();
+        for (uint32_t i = s_outn + threadIdx.x; i < a.k; i += blockDim.x) {
+            const uint64_t o = static_cast<uint64_t>(q) * a.k + i;
+            a.out_scores[o] = -__builtin_inff();
+            a.out_rows[o] = -1;
+            if (a.out_dist) a.out_dist[o] = __builtin_inff();
+            if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Exhaustive fp64 scoring (small corpora, and the last-resort path for queries that cannot be
+// verified).  One thread per (row, query slot); key = (score, row) so a multi-level block top-k
+// can reduce it; the survivors then go through rescore_select_kernel like any candidate list.
+// -------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint64_t n_rows,
+                                                         uint32_t dim, const float* queries,
+                                                         const double* qnorm,
+                                                         const uint32_t* tie_rank,
+                                                         const uint32_t* qmap, float threshold,
+                                                         uint64_t* keys, uint64_t key_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sq = reinterpret_cast<float*>(smem);
+    const uint32_t slot = blockIdx.y;
+    const uint32_t q = qmap ? qmap[slot] : slot;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
+        sq[i] = queries[static_cast<uint64_t>(q) * dim + i];
+    __syncthreads();
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const float* x = rows + row * dim;
+    double nsq = 0.0, dot = 0.0, dsq = 0.0;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const double sv = static_cast<double>(x[i]);
+        const double qv = static_cast<double>(sq[i]);
+        nsq = fma(sv, sv, nsq);
+        dot = fma(sv, qv, dot);
+        if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+    }
+    uint64_t key = 0;
+    const uint32_t kidx = tie_rank ? tie_rank[row] : static_cast<uint32_t>(row);
+    if (METRIC == YAMS_SCAN_COSINE) {
+        if (isfinite(nsq) && nsq > 1e-12) {
+            const double denom = sqrt(nsq) * qnorm[q];
+            const double sd = denom > 0.0 ? dot / denom : 0.0;
+            if (isfinite(sd)) {
+                const float sim = static_cast<float>(sd);
+                if (!(sim < threshold)) key = pack_key(sim, kidx);
+            }
+        }
+    } else {
+        if (isfinite(nsq)) {
+            const double dd = sqrt(dsq);
+            if (isfinite(dd)) key = pack_key(-static_cast<float>(dd), kidx);
+        }
+    }
+    keys[static_cast<uint64_t>(slot) * key_stride + row] = key;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Shard merge (after the all-gather): per query, the union of n_shards sorted lists -> top k.
+// -------------------------------------------------------------------------------------------------
+struct MergeArgs {
+    uint32_t n_shards, n_queries, k, metric;
+    float threshold;
+    const float* in_scores; const int64_t* in_rows; const uint32_t* in_counts;
+    const float* in_dist; const uint32_t* in_ranks;
+    float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
+};
+
+__global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // keys: (primary score, tie) packed as 96 bits is awkward; sort indices by comparing tuples.
+    const uint32_t q = blockIdx.x;
+    const uint32_t total = a.n_shards * a.k;
+    uint32_t cap = 1;
+    while (cap < total) cap <<= 1;
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(smem); // [cap]
+    auto valid = [&](uint32_t e) -> bool {
+        if (e >= total) return false;
+        const uint32_t sh = e / a.k, i = e % a.k;
+        return i < a.in_counts[static_cast<uint64_t>(sh) * a.n_queries + q];
+    };
+    auto off = [&](uint32_t e) -> uint64_t {
+        const uint32_t sh = e / a.k, i = e % a.k;
+        return (static_cast<uint64_t>(sh) * a.n_queries + q) * a.k + i;
+    };
+    // better(x, y): x sorts before y
+    auto better = [&](uint32_t x, uint32_t y) -> bool {
+        const bool vx = valid(x), vy = valid(y);
+        if (vx != vy) return vx;
+        if (!vx) return x < y;
+        const uint64_t ox = off(x), oy = off(y);
+        if (a.metric == YAMS_SCAN_L2) {
+            const float dx = a.in_dist[ox], dy = a.in_dist[oy];
+            if (dx != dy) return dx < dy;
+        } else {
+            const float sx = a.in_scores[ox], sy = a.in_scores[oy];
+            if (sx != sy) return sx > sy;
+        }
+        if (a.in_ranks) {
+            const uint32_t rx = a.in_ranks[ox], ry = a.in_ranks[oy];
+            if (rx != ry) return rx < ry;
+        }
+        const int64_t ix = a.in_rows[ox], iy = a.in_rows[oy];
+        if (ix != iy) return ix < iy;
+        return x < y;
+    };
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) sidx[i] = i;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t x = sidx[i], y = sidx[ixj];
+                    const bool up = (i & kk) == 0;
+                    // "up" segments want best first
+                    const bool swap = up ? better(y, x) : better(x, y);
+                    if (swap) { sidx[i] = y; sidx[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __shared__ uint32_t s_outn;
+    if (threadIdx.x == 0) {
+        uint32_t outn = 0;
+        for (uint32_t i = 0; i < a.k && i < cap; ++i) {
+            const uint32_t e = sidx[i];
+            if (!valid(e)) break;
+            const uint64_t o = off(e);
+            if (a.metric == YAMS_SCAN_L2 && a.in_scores[o] < a.threshold) continue; // :4508-4510
+            const uint64_t d = static_cast<uint64_t>(q) * a.k + outn;
+            a.out_scores[d] = a.in_scores[o];
+            a.out_rows[d] = a.in_rows[o];
+            if (a.out_dist) a.out_dist[d] = a.in_dist ? a.in_dist[o] : 1.0f - a.in_scores[o];
+            ++outn;
+        }
+        s_outn = outn;
+        a.out_counts[q] = outn;
+    }
+    __syncthreads();
+    for (uint32_t i = s_outn + threadIdx.x; i < a.k; i += blockDim.x) {
+        const uint64_t d = static_cast<uint64_t>(q) * a.k + i;
+        a.out_scores[d] = -__builtin_inff();
+        a.out_rows[d] = -1;
+        if (a.out_dist) a.out_dist[d] = __builtin_inff();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Synthetic data: Philox4x32-10, identical to oracle_philox4x32.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t c_lo, uint64_t c_hi,
+                                              uint32_t out[4]) {
+    uint32_t c0 = static_cast<uint32_t>(c_lo), c1 = static_cast<uint32_t>(c_lo >> 32);
+    uint32_t c2 = static_cast<uint32_t>(c_hi), c3 = static_cast<uint32_t>(c_hi >> 32);
+    uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = static_cast<uint32_t>(p1);
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = static_cast<uint32_t>(p0);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One wave per row: lanes generate 4 columns each per step, the norm is accumulated in float in
+// COLUMN ORDER (a single lane walks the row) so that it matches oracle_synth_rows bit for bit.
+__global__ __launch_bounds__(64) void synth_rows_kernel(uint64_t seed, uint64_t row0,
+                                                        uint64_t n_rows, uint32_t dim, float* out) {
+    extern __shared__ float srow[];
+    const uint64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    for (uint32_t j4 = threadIdx.x; j4 * 4 < dim; j4 += 64) {
+        uint32_t w[4];
+        philox4x32_10(seed, row0 + r, j4, w);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (j4 * 4 + t < dim)
+                srow[j4 * 4 + t] = static_cast<float>(w[t] >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    }
+    __syncthreads();
+    __shared__ float s_nrm;
+    if (threadIdx.x == 0) {
+        float nsq = 0.f;
+        for (uint32_t j = 0; j < dim; ++j) nsq = __fadd_rn(nsq, __fmul_rn(srow[j], srow[j]));
+        s_nrm = __fsqrt_rn(nsq);
+    }
+    __syncthreads();
+    const float nrm = s_nrm;
+    for (uint32_t j = threadIdx.x; j < dim; j += 64) {
+        const float v = srow[j];
+        out[r * dim + j] = nrm > 0.f ? __fdiv_rn(v, nrm) : v;
+    }
+}
+
+__global__ void synth_bytes_kernel(uint64_t seed, uint64_t blob_id0, uint64_t n_blobs,
+                                   uint64_t blob_len, uint8_t* out) {
+    const uint64_t words_per_blob = (blob_len + 15) / 16;
+    const uint64_t total = words_per_blob * n_blobs;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t b = i / words_per_blob, w16 = i % words_per_blob;
+        uint32_t w[4];
+        philox4x32_10(seed, blob_id0 + b, w16, w);
+        uint8_t* dst = out + b * blob_len + w16 * 16;
+        const uint64_t left = blob_len - w16 * 16;
+        if (left >= 16 && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (uint64_t t = 0; t < 16 && t < left; ++t)
+                dst[t] = static_cast<uint8_t>(w[t / 4] >> (8 * (t % 4)));
+        }
+    }
+}
+
+// =================================================================================================
+// Host-side launchers (called from accel_api.cpp through scan_launch.h)
+// =================================================================================================
+} // namespace yams_accel
+
+#include "scan_launch.h"
+
+namespace yams_accel {
+
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
+                               int metric, float* qprep, double* qnorm, float* qnorm_up,
+                               uint32_t* qflags) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq), dim3(128), 0, st, q, nq, dim, metric, qprep,
+                       qnorm, qnorm_up, qflags);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static ScanArgs make_args(const ScanLaunch& L) {
+    ScanArgs a{};
+    a.rows = L.rows; a.qprep = L.qprep; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
+    a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
+    a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
+    a.list_cap = L.plan.list_cap; a.qnorm_up = L.qnorm_up; a.err_coef = L.err_coef;
+    return a;
+}
+
+hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric) {
+    ScanArgs a = make_args(L);
+    a.n_sel_tiles = L.plan.n_sample_tiles;
+    if (a.n_sel_tiles == 0) return hipSuccess;
+    const uint32_t groups = (a.n_sel_tiles + 7) / 8;
+    const uint32_t grid = groups * a.n_qtiles * 8;
+    if (metric == YAMS_SCAN_COSINE)
+        hipLaunchKernelGGL((scan_tiles_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid),
+                           dim3(SCAN_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((scan_tiles_kernel<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid),
+                           dim3(SCAN_THREADS), 0, st, a);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric) {
+    ScanArgs a = make_args(L);
+    a.n_sel_tiles = L.plan.n_filter_tiles;
+    if (a.n_sel_tiles == 0) return hipSuccess;
+    const uint32_t groups = (a.n_sel_tiles + 7) / 8;
+    const uint32_t grid = groups * a.n_qtiles * 8;
+    if (metric == YAMS_SCAN_COSINE)
+        hipLaunchKernelGGL((scan_tiles_kernel<MODE_FILTER, YAMS_SCAN_COSINE>), dim3(grid),
+                           dim3(SCAN_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((scan_tiles_kernel<MODE_FILTER, YAMS_SCAN_L2>), dim3(grid),
+                           dim3(SCAN_THREADS), 0, st, a);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// Multi-level descending top-`keep` of per-query key arrays.  `work` must hold
+// 2 * n_slots * ceil(n_max / kSelectCap) * keep keys.  The result (sorted, 0-padded, `keep` keys
+// per slot) ends up at `*result` with stride `*result_stride`.
+template <typename K>
+static hipError_t topk_multilevel(hipStream_t st, const K* in, const uint32_t* in_counts,
+                                  uint64_t in_stride, uint32_t n_max, uint32_t count_clip,
+                                  uint32_t n_slots, const uint32_t* qmap, uint32_t keep, K* work,
+                                  const K** result, uint64_t* result_stride) {
+    const K* cur = in;
+    const uint32_t* cur_counts = in_counts;
+    uint64_t cur_stride = in_stride;
+    uint32_t cur_n = n_max < count_clip ? n_max : count_clip;
+    const uint32_t* cur_qmap = qmap;
+    K* bufs[2];
+    uint32_t chunks0 = (cur_n + kSelectCap - 1) / kSelectCap;
+    if (chunks0 == 0) chunks0 = 1;
+    bufs[0] = work;
+    bufs[1] = work + static_cast<uint64_t>(n_slots) * chunks0 * keep;
+    int which = 0;
+    for (;;) {
+        uint32_t chunks = (cur_n + kSelectCap - 1) / kSelectCap;
+        if (chunks == 0) chunks = 1;
+        K* dst = bufs[which];
+        const uint64_t dst_stride = static_cast<uint64_t>(chunks) * keep;
+        hipLaunchKernelGGL((topk_block_kernel<K, kSelectCap>), dim3(chunks, n_slots), dim3(256), 0,
+                           st, cur, cur_counts, cur_stride, cur_n, count_clip, dst, dst_stride,
+                           keep, cur_qmap);
+        LAUNCH_CHECK();
+        cur = dst; cur_counts = nullptr; cur_stride = dst_stride; cur_n = chunks * keep;
+        cur_qmap = nullptr; // outputs are slot-indexed from now on
+        count_clip = 0xffffffffu;
+        which ^= 1;
+        if (chunks == 1) break;
+    }
+    *result = cur;
+    *result_stride = cur_stride;
+    return hipSuccess;
+}
+
+hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32) {
+    const uint32_t* res; uint64_t stride;
+    uint32_t keep = L.plan.kprime;
+    hipError_t e = topk_multilevel<uint32_t>(st, L.gmax, nullptr, L.plan.n_groups, L.plan.n_groups,
+                                             0xffffffffu, L.plan.n_queries, nullptr, keep, work32,
+                                             &res, &stride);
+    if (e != hipSuccess) return e;
+    const uint32_t nq = L.plan.n_queries;
+    hipLaunchKernelGGL(tau_from_keys_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, res, stride,
+                       keep, nq, L.tau_out);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L) {
+    if (L.plan.sample_rows == 0) return hipSuccess;
+    uint32_t gx = static_cast<uint32_t>((L.plan.sample_rows + 256 * 8 - 1) / (256 * 8));
+    if (gx > 512) gx = 512;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.dense,
+                       L.plan.sample_rows, L.plan.sample_stride, L.plan.n_rows, L.tau,
+                       L.list_count, L.list, L.plan.list_cap);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_select_lists(hipStream_t st, const uint64_t* list, const uint32_t* list_count,
+                               uint32_t list_cap, uint32_t n_slots, const uint32_t* qmap,
+                               uint32_t keep, uint64_t* work, const uint64_t** result,
+                               uint64_t* result_stride) {
+    return topk_multilevel<uint64_t>(st, list, list_count, list_cap, list_cap, list_cap, n_slots,
+                                     qmap, keep, work, result, result_stride);
+}
+
+hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint64_t n_rows,
+                             uint32_t dim, const float* queries, const double* qnorm,
+                             const uint32_t* tie_rank, const uint32_t* qmap, uint32_t n_slots,
+                             float threshold, uint64_t* keys, uint64_t key_stride) {
+    const uint32_t gx = static_cast<uint32_t>((n_rows + 255) / 256);
+    const size_t sh = static_cast<size_t>(dim) * sizeof(float);
+    if (metric == YAMS_SCAN_COSINE)
+        hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_COSINE>), dim3(gx, n_slots), dim3(256), sh,
+                           st, rows, n_rows, dim, queries, qnorm, tie_rank, qmap, threshold, keys, key_stride);
+    else
+        hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2>), dim3(gx, n_slots), dim3(256), sh, st,
+                           rows, n_rows, dim, queries, qnorm, tie_rank, qmap, threshold, keys, key_stride);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_topk_keys(hipStream_t st, const uint64_t* keys, uint64_t key_stride,
+                            uint32_t n_per_slot, uint32_t n_slots, uint32_t keep, uint64_t* work,
+                            const uint64_t** result, uint64_t* result_stride) {
+    return topk_multilevel<uint64_t>(st, keys, nullptr, key_stride, n_per_slot, 0xffffffffu,
+                                     n_slots, nullptr, keep, work, result, result_stride);
+}
+
+hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
+    RescoreArgs a{};
+    a.rows = R.rows; a.n_rows = R.n_rows; a.dim = R.dim; a.queries = R.queries; a.qnorm = R.qnorm;
+    a.tie_rank = R.tie_rank; a.rank_row = R.rank_row; a.row_base = R.row_base; a.cand = R.cand;
+    a.cand_stride = R.cand_stride; a.n_cand = R.n_cand; a.tau = R.tau;
+    a.list_count = R.list_count; a.list_cap = R.list_cap; a.all_rows_listed = R.all_rows_listed;
+    a.qmap = R.qmap; a.k = R.k; a.threshold = R.threshold; a.flags = R.flags;
+    a.err_bound = R.err_bound; a.out_scores = R.out_scores; a.out_rows = R.out_rows;
+    a.out_counts = R.out_counts; a.out_dist = R.out_dist; a.out_ranks = R.out_ranks;
+    a.out_status = R.out_status; a.stat_rescored = R.stat_rescored;
+    const size_t sh = RS_MAX * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
+                      static_cast<size_t>(R.dim) * sizeof(float);
+    if (metric == YAMS_SCAN_COSINE)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(256),
+                           sh, st, a);
+    else
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2>), dim3(R.n_slots), dim3(256), sh,
+                           st, a);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_merge(hipStream_t st, const MergeLaunch& M) {
+    MergeArgs a{};
+    a.n_shards = M.n_shards; a.n_queries = M.n_queries; a.k = M.k; a.metric = M.metric;
+    a.threshold = M.threshold; a.in_scores = M.in_scores; a.in_rows = M.in_rows;
+    a.in_counts = M.in_counts; a.in_dist = M.in_dist; a.in_ranks = M.in_ranks;
+    a.out_scores = M.out_scores; a.out_rows = M.out_rows; a.out_counts = M.out_counts;
+    a.out_dist = M.out_dist;
+    uint32_t cap = 1;
+    while (cap < M.n_shards * M.k) cap <<= 1;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(M.n_queries), dim3(256), cap * sizeof(uint32_t), st, a);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_synth_rows(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n_rows,
+                             uint32_t dim, float* out) {
+    if (n_rows == 0) return hipSuccess;
+    // grid.x is limited to 2^31-1 blocks; split very large requests
+    const uint64_t kMax = 1u << 30;
+    for (uint64_t done = 0; done < n_rows; done += kMax) {
+        const uint64_t n = (n_rows - done < kMax) ? n_rows - done : kMax;
+        hipLaunchKernelGGL(synth_rows_kernel, dim3(static_cast<uint32_t>(n)), dim3(64),
+                           dim * sizeof(float), st, seed, row0 + done, n, dim,
+                           out + done * dim);
+        LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_synth_bytes(hipStream_t st, uint64_t seed, uint64_t blob_id0, uint64_t n_blobs,
+                              uint64_t blob_len, uint8_t* out) {
+    if (n_blobs == 0 || blob_len == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_bytes_kernel, dim3(4096), dim3(256), 0, st, seed, blob_id0, n_blobs,
+                       blob_len, out);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+} // namespace yams_accel

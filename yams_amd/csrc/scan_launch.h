@@ -1,0 +1,67 @@
+// scan_launch.h — host-visible launch descriptors for scan_kernels.hip.
+#pragma once
+#include "common.h"
+
+namespace yams_accel {
+
+struct ScanLaunch {
+    ScanPlan plan;
+    const float* rows = nullptr;
+    const float* qprep = nullptr;
+    float* dense = nullptr;
+    uint32_t* gmax = nullptr;
+    const float* tau = nullptr;   // read by filter / collect
+    float* tau_out = nullptr;     // written by select_tau
+    uint32_t* list_count = nullptr;
+    uint64_t* list = nullptr;
+    const float* qnorm_up = nullptr;
+    float err_coef = 0.f;
+};
+
+struct RescoreLaunch {
+    const float* rows; uint64_t n_rows; uint32_t dim;
+    const float* queries; const double* qnorm;
+    const uint32_t* tie_rank; const uint32_t* rank_row; int64_t row_base;
+    const uint64_t* cand; uint64_t cand_stride; uint32_t n_cand;
+    const float* tau; const uint32_t* list_count; uint32_t list_cap; uint32_t all_rows_listed;
+    const uint32_t* qmap; uint32_t n_slots;
+    uint32_t k; float threshold; uint32_t flags; double err_bound;
+    float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
+    uint32_t* out_ranks; uint32_t* out_status; unsigned long long* stat_rescored;
+};
+
+struct MergeLaunch {
+    uint32_t n_shards, n_queries, k, metric; float threshold;
+    const float* in_scores; const int64_t* in_rows; const uint32_t* in_counts;
+    const float* in_dist; const uint32_t* in_ranks;
+    float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
+};
+
+constexpr uint32_t kRescoreMax = 2048;
+
+hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
+                               int metric, float* qprep, double* qnorm, float* qnorm_up,
+                               uint32_t* qflags);
+hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
+hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric);
+hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32);
+hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L);
+hipError_t launch_select_lists(hipStream_t st, const uint64_t* list, const uint32_t* list_count,
+                               uint32_t list_cap, uint32_t n_slots, const uint32_t* qmap,
+                               uint32_t keep, uint64_t* work, const uint64_t** result,
+                               uint64_t* result_stride);
+hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint64_t n_rows,
+                             uint32_t dim, const float* queries, const double* qnorm,
+                             const uint32_t* tie_rank, const uint32_t* qmap, uint32_t n_slots,
+                             float threshold, uint64_t* keys, uint64_t key_stride);
+hipError_t launch_topk_keys(hipStream_t st, const uint64_t* keys, uint64_t key_stride,
+                            uint32_t n_per_slot, uint32_t n_slots, uint32_t keep, uint64_t* work,
+                            const uint64_t** result, uint64_t* result_stride);
+hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R);
+hipError_t launch_merge(hipStream_t st, const MergeLaunch& M);
+hipError_t launch_synth_rows(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n_rows,
+                             uint32_t dim, float* out);
+hipError_t launch_synth_bytes(hipStream_t st, uint64_t seed, uint64_t blob_id0, uint64_t n_blobs,
+                              uint64_t blob_len, uint8_t* out);
+
+} // namespace yams_accel
