@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — the hot path measured the way BASELINE.json asks.
+
+Metric: k-NN QPS (+ recall@k) for batched exact cosine top-100 over fp32 embeddings, corpus
+row-sharded over the GPUs of one node; ingest GB/s (SHA-256 + CDC) reported alongside.
+
+Workload per GPU (weak scaling in corpus size): one 12.5M x 768 fp32 row shard of
+BASELINE config 4 (100M x 768 cosine top-100 over 8 GPUs), query batch 1024 — at N GPUs the job
+searches N x 12.5M rows; N = 8 is the headline configuration.  A "step" = one query batch: every
+rank scans its shard, one RCCL all-gather moves the per-shard top-k, every rank merges.
+`value` is the true whole-job QPS (batch / step time): with a fixed shard per GPU it stays flat
+as N grows while the searched corpus grows N-fold (`config.corpus_rows`), which is what perfect
+weak scaling looks like for a row-sharded search; `row_queries_per_s` is the N-scaling quantity.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from yams_amd import dist as ydist  # noqa: E402
+from yams_amd.accel import Accel, cdc_config  # noqa: E402
+from yams_amd._lib import SCAN_COSINE  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows-per-gpu", type=int, default=12_500_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
+    ap.add_argument("--seed", type=int, default=42)
+    return ap.parse_args()
+
+
+def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_queries=8):
+    """The oracle (scalar fp64 restatement of sqlite_vec_backend.cpp:4204-4331) timed on this
+    box's host cores on a bounded sample of the same workload; also the recall check."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    o = _oracle.oracle()
+    n_s = min(seed_rows, rows_total)
+    corpus = tc[:n_s].cpu().numpy()
+    queries = tq[:n_queries].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = [o.scan_cosine(corpus, queries[i], k, -1.0) for i in range(n_queries)]
+    dt = time.perf_counter() - t0
+    qps_slice = n_queries / dt
+    qps_full = qps_slice * n_s / rows_total
+    # recall@k of the device path against the oracle on the same slice (outside the timed region)
+    r = acc.scan_topk(acc.corpus_view(tc.data_ptr(), n_s, dim), queries, k, -1.0, SCAN_COSINE)
+    inter = sum(len(set(r.rows[i, :k].tolist()) & set(ref[i][0].tolist())) for i in range(n_queries))
+    recall = inter / float(n_queries * k)
+    exact = all(np.array_equal(r.rows[i], ref[i][0]) and
+                np.array_equal(r.scores[i].view(np.uint32), ref[i][1].view(np.uint32))
+                for i in range(n_queries))
+    return {"value": qps_full, "unit": "QPS", "cores": 1, "kind": "port",
+            "sample": f"{n_queries} queries x first {n_s} rows of the same shard, scalar fp64 "
+                      f"oracle scan, 1 thread, {dt:.1f} s; QPS scaled by {n_s}/{rows_total} to the "
+                      f"full shard (SQLite row fetch of the real reference excluded: upper bound)",
+            "host_cores_available": os.cpu_count()}, recall, exact
+
+
+def ingest_leg(acc, gib, seed):
+    """SHA-256 + CDC over device-resident Philox blobs (4 MiB each, product-default chunker)."""
+    blen = 4 << 20
+    free_b, _ = torch.cuda.mem_get_info()
+    gib = min(gib, max(1.0, (free_b * 0.70) / (1 << 30) / 1.2))   # blobs + bitmap/slot workspace
+    n_blobs = max(1, int(gib * (1 << 30) // blen))
+    tb = torch.empty(n_blobs * blen, dtype=torch.uint8, device="cuda")
+    acc.synth_bytes(seed, 0, n_blobs, blen, tb.data_ptr())
+    offs = [i * blen for i in range(n_blobs)]
+    lens = [blen] * n_blobs
+    cfg = cdc_config("streaming")
+    acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=3)   # warm-up (workspace allocation)
+    acc.synchronize()
+    acc.enable_timing(True)
+    reps = 3
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        res = acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=3)
+    acc.synchronize(); dt = (time.perf_counter() - t0) / reps
+    sha_ms, _ = acc.kernel_ms("sha256")
+    cdc_ms, _ = acc.kernel_ms("cdc_candidates")
+    acc.enable_timing(False)
+    total = n_blobs * blen
+    out = {"value": total / dt / 1e9, "unit": "GB/s", "bytes": total, "blobs": n_blobs,
+           "blob_bytes": blen, "chunks": int(res.n_chunks), "ms": dt * 1e3,
+           "sha256_kernel_ms": sha_ms, "cdc_candidates_kernel_ms": cdc_ms,
+           "chunker": "StreamingChunker defaults (min 16 KiB, max 1 MiB, mask 0x1FFF)",
+           "digests": "per-chunk + whole-blob (every byte hashed twice)"}
+    del tb
+    return out
+
+
+def main():
+    a = parse()
+    rank, world, local = ydist.init_from_env()
+    assert world == max(1, a.gpus) or world == 1, (world, a.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    acc = Accel(local, torch.cuda.current_stream().cuda_stream)
+    n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
+    total_rows = n * world
+    row_base = n * rank
+
+    # synthetic data, generated in HBM (Philox recipe of SURVEY.md 8d; regenerable on the CPU)
+    tc = torch.empty((n, d), dtype=torch.float32, device=dev)
+    acc.synth_rows(a.seed, row_base, n, d, tc.data_ptr())
+    tq = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    acc.synth_rows(a.seed, 1 << 40, nq, d, tq.data_ptr())        # same queries on every rank
+    s_loc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    r_loc = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    c_loc = torch.empty(nq, dtype=torch.int32, device=dev)
+    s_out = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    r_out = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    c_out = torch.empty(nq, dtype=torch.int32, device=dev)
+    view = acc.corpus_view(tc.data_ptr(), n, d, row_base=row_base)
+    acc.synchronize()
+
+    def merge_fn(g, w):
+        acc.merge_topk_device(w, nq, k, -1.0, SCAN_COSINE, g["scores"].data_ptr(), g["rows"].data_ptr(),
+                              g["counts"].data_ptr(), None, None, s_out.data_ptr(), r_out.data_ptr(),
+                              c_out.data_ptr(), None)
+        return s_out, r_out, c_out
+
+    def step():
+        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s_loc.data_ptr(),
+                                    r_loc.data_ptr(), c_loc.data_ptr(), want_diag=True)
+        if world > 1:
+            ydist.gather_and_merge({"scores": s_loc, "rows": r_loc, "counts": c_loc}, k, merge_fn)
+        return diag
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    acc.enable_timing(True)
+    fence(); t0 = time.perf_counter()
+    fallbacks = 0
+    for _ in range(a.steps):
+        dg = step()
+        fallbacks += dg["exact_fallback_queries"]
+    fence(); dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    filt_ms, filt_n = acc.kernel_ms("scan_filter")
+    samp_ms, samp_n = acc.kernel_ms("scan_sample")
+    acc.enable_timing(False)
+    ms_per_step = dt / a.steps * 1e3
+    qps = nq * a.steps / dt
+
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel (scan_tiles_kernel<FILTER>): exact-f32 MFMA -------------
+    n_tiles = (n + 127) // 128
+    s_target = min(n, max(n // 16, 8192))
+    stride = max(1, n_tiles // ((s_target + 127) // 128))
+    n_sample = (n_tiles + stride - 1) // stride
+    filt_rows = min(n, (n_tiles - n_sample) * 128)
+    flops = 2.0 * nq * d * filt_rows + 1.0 * filt_rows * d * ((nq + 127) // 128)  # contraction + fused row norms
+    ach_tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms else None
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "scan_filter_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            j = json.load(open(pmc))
+            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq:
+                traffic = j.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "scan_tiles_kernel<FILTER,COSINE> (v_mfma_f32_32x32x2_f32)",
+                "achieved": ach_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": (ach_tf / PEAK_F32_MFMA_TFLOPS) if ach_tf else None, "traffic": traffic,
+                "launch_ms": filt_ms, "launches": filt_n, "flops_per_launch": flops,
+                "sample_pass_ms": samp_ms,
+                "hbm_view": {"algorithmic_bytes_per_step": n * d * 4 + nq * d * 4 + nq * k * 12,
+                             "achieved_GBps": (n * d * 4 + nq * d * 4 + nq * k * 12) / (ms_per_step * 1e-3) / 1e9,
+                             "peak_GBps": PEAK_HBM_GBPS}}
+    out = {"metric": "k-NN QPS + recall@k, 100M x 768 fp32 cosine top-100; ingest GB/s SHA-256+CDC",
+           "value": qps, "unit": "QPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 (MFMA filter) + f64 (re-score)", "data": "synthetic",
+           "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: "
+                                  f"100Mx768 over 8 GPUs), query batch {nq}",
+                      "rows_per_gpu": n, "corpus_rows": total_rows, "dim": d, "k": k, "query_batch": nq,
+                      "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge" if world > 1 else "single shard"},
+           "row_queries_per_s": total_rows * nq * a.steps / dt,
+           "exact_fallback_queries": fallbacks,
+           "roofline": roofline}
+    if not a.no_cpu_baseline:
+        cb, recall, exact = cpu_baseline_scan(acc, tc, tq, n, d, k)
+        out["cpu_baseline"] = cb
+        out["recall_at_k"] = recall
+        out["bit_exact_vs_oracle_sample"] = exact
+    if not a.no_ingest:
+        del tc
+        acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg
+        acc.ctx = None
+        acc = Accel(local, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.empty_cache()
+        out["ingest"] = ingest_leg(acc, a.ingest_gib, a.seed)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()

@@ -1,0 +1,67 @@
+"""Shared test inputs: golden fixture loading and the reference tests' own data recipes."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def pattern(n):  # makePatternData, tests/unit/chunking/chunking_test.cpp:55-62 (reference)
+    i = np.arange(n, dtype=np.uint64)
+    return ((i * np.uint64(1315423911) + np.uint64(0x9E3779B9)) & np.uint64(0xFF)).astype(np.uint8)
+
+
+def gen_input(spec, oracle=None):
+    kind, n = spec["kind"], spec["n"]
+    if kind == "random":
+        return np.random.default_rng(spec["seed"]).integers(0, 256, n, dtype=np.uint8)
+    if kind == "pattern":
+        return pattern(n)
+    if kind == "zeros":
+        return np.zeros(n, np.uint8)
+    if kind == "const":
+        return np.full(n, spec["value"], np.uint8)
+    if kind == "philox":
+        return oracle.synth_bytes(spec["seed"], spec.get("blob", 0), 0, n)
+    raise ValueError(kind)
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)["cases"]
+
+
+def fixture_embedding(dim, seed):
+    """SqliteVecBackendFixture::createEmbedding (reference tests/unit/vector/
+    sqlite_vec_backend_comprehensive_catch2_test.cpp:84-101): mt19937(seed*1000), U(-1,1), fp32
+    normalise.  numpy's MT19937 with the same 32-bit seed yields the same raw 32-bit stream;
+    libstdc++'s uniform_real_distribution<float> maps one draw to (x / 2^32) * 2 - 1 in float."""
+    bg = np.random.MT19937()
+    # seed exactly like std::mt19937(uint32 seed)
+    st = np.zeros(624, dtype=np.uint32)
+    st[0] = np.uint32(seed * 1000)
+    for i in range(1, 624):
+        st[i] = np.uint32((1812433253 * (int(st[i - 1]) ^ (int(st[i - 1]) >> 30)) + i) & 0xFFFFFFFF)
+    bg.state = {"bit_generator": "MT19937", "state": {"key": st, "pos": 624}}
+    raw = bg.random_raw(dim).astype(np.uint32)
+    u = (raw.astype(np.float32) * np.float32(2.3283064365386963e-10))  # generate_canonical<float,24>
+    u = np.minimum(u, np.nextafter(np.float32(1.0), np.float32(0.0)))
+    v = u * np.float32(2.0) + np.float32(-1.0)
+    nrm = np.float32(0.0)
+    for x in v:
+        nrm = np.float32(nrm + x * x)
+    nrm = np.sqrt(nrm, dtype=np.float32)
+    return (v / nrm).astype(np.float32) if nrm > 0 else v.astype(np.float32)
+
+
+def string_ranks(ids):
+    """tie_rank[row] = rank of the row's chunk_id in lexicographic (byte) order
+    (the comparator of sqlite_vec_backend.cpp:4218-4223 compares std::string chunk ids)."""
+    order = sorted(range(len(ids)), key=lambda i: ids[i].encode())
+    rank = np.zeros(len(ids), np.uint32)
+    for r, i in enumerate(order):
+        rank[i] = r
+    inv = np.array(order, np.uint32)
+    return rank, inv

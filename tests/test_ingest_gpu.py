@@ -1,0 +1,249 @@
+"""GPU parity suite for the content-ingest path (SHA-256 + content-defined chunking), through the
+C ABI, against the oracle and the golden fixtures generated from the reference's own sources.
+Bar: bit-exact digests and chunk boundaries."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import _cases
+from yams_amd import _lib
+from yams_amd.accel import cdc_config
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- SHA-256 ------------------------------------------------------------------------------------
+def test_sha256_reference_known_answers(acc):
+    # tests/unit/crypto/crypto_test.cpp:92-99,134-170 (reference)
+    assert acc.sha256_hex(b"") == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    assert acc.sha256_hex(b"abc") == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    assert acc.sha256_hex(b"Hello World") == "a591a6d40bf420404a011733cfb7b190d62c65bf0bcda32b57b277d9ad9f146e"
+
+
+def test_sha256_golden(acc):
+    for c in _cases.load_golden("sha256.json"):
+        data = c["ascii"].encode() if "ascii" in c else \
+            np.random.default_rng(c["seed"]).integers(0, 256, c["n"], dtype=np.uint8)
+        assert acc.sha256_hex(data) == c["hex"], c
+
+
+def test_sha256_every_length_and_alignment(acc, oracle):
+    rng = np.random.default_rng(41)
+    base = rng.integers(0, 256, 5000, dtype=np.uint8)
+    # every length 0..300 (all padding cases) at every byte alignment 0..3 of the source
+    msgs = [base[a:a + n] for n in range(0, 301) for a in range(4)]
+    msgs += [rng.integers(0, 256, n, dtype=np.uint8) for n in (4095, 4096, 4097, 65537, 1 << 20, (1 << 20) + 3)]
+    got = acc.sha256_many(msgs)
+    for h, m in zip(got, msgs):
+        assert h == hashlib.sha256(m.tobytes()).hexdigest(), len(m)
+    assert got[7] == oracle.sha256_hex(msgs[7])
+
+
+def test_sha256_ragged_batch_on_device(acc):
+    """Device-resident batch with unaligned offsets: the lane queue must not lose or mix messages."""
+    import torch
+    rng = np.random.default_rng(42)
+    blob = rng.integers(0, 256, 3_000_000, dtype=np.uint8)
+    n = 5000
+    lens = rng.integers(0, 1500, n).astype(np.uint64)
+    lens[::97] = rng.integers(20000, 60000, len(lens[::97]))
+    offs = rng.integers(0, blob.size - 60000, n).astype(np.uint64)
+    tb = torch.from_numpy(blob).cuda()
+    to, tl = torch.from_numpy(offs.view(np.int64)).cuda(), torch.from_numpy(lens.view(np.int64)).cuda()
+    dg = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    acc.sha256_batch_device(tb.data_ptr(), to.data_ptr(), tl.data_ptr(), n, dg.data_ptr())
+    acc.synchronize()
+    got = dg.cpu().numpy()
+    for i in range(n):
+        exp = hashlib.sha256(blob[int(offs[i]):int(offs[i] + lens[i])].tobytes()).digest()
+        assert got[i].tobytes() == exp, i
+
+
+def test_sha256_streaming_vtable_matches_one_shot(accel_lib):
+    # "Chunked hashing matches single-pass hashing", crypto_test.cpp:209-228; sizes :172-187
+    L = accel_lib
+    assert L.yams_plugin_init(b"{}", None) == 0
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"content_hash_v1", 1, C.byref(p)) == 0
+    vt = C.cast(p, C.POINTER(_lib.ContentHashV1)).contents
+    rng = np.random.default_rng(43)
+    st = C.c_void_p()
+    assert vt.stream_create(None, C.byref(st)) == 0
+    out = C.create_string_buffer(65)
+    for size, cuts in [(0, []), (1, []), (17, [5]), (1000, [100, 500]), (4096, [64, 128, 4000]),
+                       (65537, [1, 63, 64, 65, 30000])]:
+        data = rng.integers(0, 256, size, dtype=np.uint8)
+        assert vt.stream_init(None, st) == 0
+        prev = 0
+        for c in cuts + [size]:
+            piece = np.ascontiguousarray(data[prev:c])
+            assert vt.stream_update(None, st, piece.ctypes.data_as(_lib.u8p) if piece.size else None, piece.size) == 0
+            prev = c
+        assert vt.stream_finalize(None, st, out) == 0
+        assert out.value.decode() == hashlib.sha256(data.tobytes()).hexdigest(), size
+        one = C.create_string_buffer(65)
+        assert vt.hash(None, data.ctypes.data_as(_lib.u8p) if size else None, size, one) == 0
+        assert one.value == out.value
+    # finalize re-initialises the stream (sha256_hasher.cpp:103-106): hashing nothing gives sha256("")
+    assert vt.stream_finalize(None, st, out) == 0
+    assert out.value.decode() == hashlib.sha256(b"").hexdigest()
+    vt.stream_destroy(None, st)
+    L.yams_plugin_shutdown()
+
+
+# ---- content-defined chunking -------------------------------------------------------------------
+def _check_chunks(acc, oracle, data, mode, **cfg):
+    off, sz, hx = acc.chunk(data, cdc_config(mode, **cfg), with_hashes=True)
+    ooff, osz = oracle.chunks(data, mode, **cfg)
+    assert len(off) == len(ooff), (mode, cfg, len(off), len(ooff))
+    assert np.array_equal(off, ooff) and np.array_equal(sz, osz), (mode, cfg)
+    step = max(1, len(off) // 64)
+    for i in list(range(0, len(off), step)) + [len(off) - 1] if len(off) else []:
+        assert hx[i] == hashlib.sha256(data[int(off[i]):int(off[i] + sz[i])].tobytes()).hexdigest()
+    return off, sz, hx
+
+
+def test_cdc_golden_from_reference_sources(acc, oracle):
+    for c in _cases.load_golden("cdc.json"):
+        data = _cases.gen_input(c["input"], oracle)
+        off, sz, hx = acc.chunk(data, cdc_config(c["mode"], **c["config"]), with_hashes=True)
+        assert [int(x) for x in off] == c["offsets"], (c["input"], c["config"], c["mode"])
+        assert [int(x) for x in sz] == c["sizes"]
+        assert hx[:3] == c["hash_head"] and hx[-3:] == c["hash_tail"]
+        assert hashlib.sha256("".join(hx).encode()).hexdigest() == c["hash_of_hashes"]
+
+
+@pytest.mark.parametrize("mode", ["rabin", "streaming"])
+def test_cdc_config_sweep(acc, oracle, mode):
+    rng = np.random.default_rng(44)
+    data = rng.integers(0, 256, 6 << 20, dtype=np.uint8)
+    _check_chunks(acc, oracle, data, mode)                                       # product default
+    _check_chunks(acc, oracle, data, mode, min_size=4096, max_size=65536)        # core_benchmarks.cpp:226-227
+    small = data[:400000]
+    for cfg in [dict(min_size=64, max_size=256, mask=0xF), dict(min_size=1, max_size=100, mask=3, window=16),
+                dict(min_size=2048, max_size=8192, mask=0xFFFFF), dict(min_size=512, max_size=4096, mask=(1 << 40) - 1),
+                dict(min_size=100, max_size=100), dict(min_size=300, max_size=200, mask=0xFF),
+                dict(min_size=1000, max_size=3000, mask=0xFFFFFFFFFFFFFFFF), dict(min_size=37, max_size=4001, mask=0x155, window=1),
+                dict(min_size=5000, max_size=9000, mask=0x3FF, window=7, polynomial=0xBFE6B8A5BF378D83),
+                dict(min_size=0, max_size=50, mask=1)]:
+        _check_chunks(acc, oracle, small, mode, **cfg)
+
+
+@pytest.mark.parametrize("mode", ["rabin", "streaming"])
+def test_cdc_edge_inputs(acc, oracle, mode):
+    # "Empty input produces no chunks" (chunking_test.cpp:108-113), sizes around min/max and < window
+    off, sz, hx = acc.chunk(np.zeros(0, np.uint8), cdc_config(mode))
+    assert len(off) == 0
+    rng = np.random.default_rng(45)
+    for n in [1, 7, 47, 48, 49, 55, 56, 57, 4095, 4096, 4097, 8191, 8192, 8193, 32767, 32768, 32769, 65600]:
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        _check_chunks(acc, oracle, d, mode, min_size=4096, max_size=8192, mask=0x3FF)
+    _check_chunks(acc, oracle, np.zeros(3 << 20, np.uint8), mode)               # no candidates: max-size chunks
+    _check_chunks(acc, oracle, np.full(200000, 0x42, np.uint8), mode, min_size=4096, max_size=32768)
+    _check_chunks(acc, oracle, _cases.pattern(256 * 1024 + 777), mode, min_size=2048, max_size=65536)
+
+
+def test_cdc_rabin_equals_streaming_on_constant_buffer(acc):
+    # chunking_test.cpp:230-251 (reference): identical boundaries on a constant buffer
+    d = np.full(1 << 20, 0x42, np.uint8)
+    a = acc.chunk(d, cdc_config("rabin", min_size=4096, max_size=65536), with_hashes=False)
+    b = acc.chunk(d, cdc_config("streaming", min_size=4096, max_size=65536), with_hashes=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_cdc_invalid_configs_are_rejected(acc):
+    d = np.zeros(1000, np.uint8)
+    for cfg in [cdc_config("rabin", window=0), cdc_config("rabin", window=49), cdc_config("rabin", min_size=0, max_size=0)]:
+        with pytest.raises(_lib.AccelError) as e:
+            acc.chunk(d, cfg)
+        assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    # the streaming chunker clamps the ring instead (streaming_chunker.cpp:44-49)
+    acc.chunk(d, cdc_config("streaming", window=0, min_size=10, max_size=100))
+    acc.chunk(d, cdc_config("streaming", window=500, min_size=10, max_size=100))
+
+
+def test_ingest_many_blobs_unaligned(acc, oracle):
+    """The ingest hot path over a ragged blob set placed at arbitrary byte offsets: boundaries,
+    per-chunk digests and whole-blob digests, all against the CPU."""
+    import torch
+    rng = np.random.default_rng(46)
+    lens = [0, 1, 47, 5000, 16384, 16385, 100_000, 1 << 20, (1 << 20) + 1, 3_333_333, 40, 70_001]
+    gaps = [3, 1, 0, 7, 13, 2, 5, 1, 9, 0, 11, 6]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    offs, pos, parts = [], 5, [np.zeros(5, np.uint8)]
+    for b, g in zip(blobs, gaps):
+        offs.append(pos); parts.append(b); parts.append(np.zeros(g, np.uint8)); pos += len(b) + g
+    buf = np.concatenate(parts + [np.zeros(64, np.uint8)])
+    tb = torch.from_numpy(buf).cuda()
+    for mode in ("streaming", "rabin"):
+        cfg = dict(min_size=4096, max_size=65536)
+        res = acc.ingest_device(tb.data_ptr(), offs, lens, cdc_config(mode, **cfg), flags=3)
+        out = acc.fetch_ingest(res, len(lens))
+        first = out["blob_first"]
+        for bi, b in enumerate(blobs):
+            ooff, osz = oracle.chunks(b, mode, **cfg)
+            lo, hi = int(first[bi]), int(first[bi + 1])
+            assert hi - lo == len(ooff), (mode, bi)
+            assert np.array_equal(out["chunk_offset"][lo:hi], ooff) and np.array_equal(out["chunk_size"][lo:hi], osz)
+            assert (out["chunk_blob"][lo:hi] == bi).all()
+            assert out["blob_digest"][bi].tobytes() == hashlib.sha256(b.tobytes()).digest()
+            for j in range(lo, hi):
+                o, s = int(out["chunk_offset"][j]), int(out["chunk_size"][j])
+                assert out["chunk_digest"][j].tobytes() == hashlib.sha256(b[o:o + s].tobytes()).digest()
+
+
+def test_ingest_full_size_properties(acc, oracle):
+    """A slice of BASELINE config 5 (Philox blobs, 4 MiB each, product-default chunker) large
+    enough to fill the device: invariants on everything, the CPU oracle on a sample of blobs."""
+    import torch
+    n_blobs, blen = 256, 4 << 20                      # 1 GiB
+    tb = torch.empty(n_blobs * blen, dtype=torch.uint8, device="cuda")
+    acc.synth_bytes(42, 0, n_blobs, blen, tb.data_ptr())
+    offs = [i * blen for i in range(n_blobs)]
+    res = acc.ingest_device(tb.data_ptr(), offs, [blen] * n_blobs, cdc_config("streaming"), flags=3)
+    out = acc.fetch_ingest(res, n_blobs)
+    first, co, cs = out["blob_first"], out["chunk_offset"], out["chunk_size"]
+    assert first[0] == 0 and first[-1] == out["n_chunks"]
+    for bi in range(n_blobs):                         # coverage, contiguity, size bounds (chunking_test.cpp:146-183)
+        lo, hi = int(first[bi]), int(first[bi + 1])
+        o, s = co[lo:hi], cs[lo:hi]
+        assert o[0] == 0 and int(o[-1] + s[-1]) == blen
+        assert np.array_equal(o[1:], (o + s)[:-1])
+        assert (s[:-1] >= 16384).all() and (s <= 1 << 20).all()
+    assert 20000 < out["n_chunks"] / n_blobs * 256 < 60000   # avg chunk ~24.5 KB on random data
+    for bi in (0, 101, 255):                          # bit-exact against the CPU
+        blob = oracle.synth_bytes(42, bi, 0, blen)
+        ooff, osz = oracle.chunks(blob, "streaming")
+        lo, hi = int(first[bi]), int(first[bi + 1])
+        assert np.array_equal(co[lo:hi], ooff) and np.array_equal(cs[lo:hi], osz)
+        assert out["blob_digest"][bi].tobytes() == hashlib.sha256(blob.tobytes()).digest()
+        for j in range(lo, hi, 7):
+            assert out["chunk_digest"][j].tobytes() == \
+                hashlib.sha256(blob[int(co[j]):int(co[j] + cs[j])].tobytes()).digest()
+    # determinism: the same call again gives the same chunk digests (chunking_test.cpp:185-228)
+    res2 = acc.ingest_device(tb.data_ptr(), offs, [blen] * n_blobs, cdc_config("streaming"), flags=3)
+    out2 = acc.fetch_ingest(res2, n_blobs)
+    assert np.array_equal(out2["chunk_digest"], out["chunk_digest"])
+
+
+def test_chunker_vtable(accel_lib, oracle):
+    L = accel_lib
+    assert L.yams_plugin_init(b"{}", None) == 0
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"chunker_v1", 1, C.byref(p)) == 0
+    vt = C.cast(p, C.POINTER(_lib.ChunkerV1)).contents
+    cfg = _lib.CdcConfig()
+    assert vt.get_default_config(None, _lib.CDC_STREAMING, C.byref(cfg)) == 0
+    cfg.min_size, cfg.max_size = 2048, 16384
+    data = np.random.default_rng(47).integers(0, 256, 500000, dtype=np.uint8)
+    chunks = C.POINTER(_lib.ChunkRef)(); n = C.c_size_t()
+    assert vt.chunk_data(None, data.ctypes.data_as(_lib.u8p), data.size, C.byref(cfg), C.byref(chunks), C.byref(n)) == 0
+    ooff, osz = oracle.chunks(data, "streaming", min_size=2048, max_size=16384)
+    assert n.value == len(ooff)
+    for i in range(n.value):
+        assert (chunks[i].offset, chunks[i].size) == (int(ooff[i]), int(osz[i]))
+        assert chunks[i].hash_hex.decode() == hashlib.sha256(data[int(ooff[i]):int(ooff[i] + osz[i])].tobytes()).hexdigest()
+    vt.free_chunks(None, chunks, n)
+    L.yams_plugin_shutdown()

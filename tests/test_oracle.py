@@ -1,0 +1,162 @@
+"""CPU suite part 1: the oracle is pinned before it is trusted.
+
+  * against the reference's known-answer vectors (crypto_test.cpp:92-99; vector_smoke tests),
+  * against golden fixtures generated from the reference's own translation units
+    (tests/golden/make_golden.py), which travel to the GPU box,
+  * live against oracle/_ref when it is present (dev container).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import _cases
+
+
+# ---- SHA-256 ------------------------------------------------------------------------------------
+def test_sha256_reference_known_answers(oracle):
+    # TestVectors, tests/unit/crypto/crypto_test.cpp:92-99 (reference)
+    assert oracle.sha256_hex(b"") == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    assert oracle.sha256_hex(b"abc") == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    assert oracle.sha256_hex(b"Hello World") == "a591a6d40bf420404a011733cfb7b190d62c65bf0bcda32b57b277d9ad9f146e"
+
+
+def test_sha256_golden(oracle):
+    for c in _cases.load_golden("sha256.json"):
+        if "ascii" in c:
+            data = c["ascii"].encode()
+        else:
+            data = np.random.default_rng(c["seed"]).integers(0, 256, c["n"], dtype=np.uint8)
+        assert oracle.sha256_hex(data) == c["hex"], c
+
+
+def test_sha256_vs_hashlib_and_ref(oracle):
+    import _oracle
+    r = _oracle.ref()
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 200)) + [4095, 4096, 4097, 65537, 1 << 20]:
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        h = oracle.sha256_hex(d)
+        assert h == hashlib.sha256(d.tobytes()).hexdigest()
+        if r is not None and n < 70000:
+            assert h == r.sha256_hex(d)
+
+
+def test_sha256_split_updates_match_single(ref):
+    # "Chunked hashing matches single-pass hashing", crypto_test.cpp:209-228 (reference)
+    d = np.random.default_rng(6).integers(0, 256, 1000, dtype=np.uint8).tobytes()
+    assert ref.sha256_hex_split(d, [100, 500]) == ref.sha256_hex(d)
+
+
+# ---- CDC ----------------------------------------------------------------------------------------
+def test_rabin_table_default(oracle):
+    t = oracle.rabin_table(0x3DA3358B4DC173)
+    assert t[0] == 0 and t[1] == 0x3DA3358B4DC173 and t[3] == (0x3DA3358B4DC173 ^ (0x3DA3358B4DC173 << 1))
+    # the low 13 bits are injective over byte values
+    assert len(set(int(x) & 0x1FFF for x in t)) == 256
+
+
+def test_cdc_golden(oracle):
+    for c in _cases.load_golden("cdc.json"):
+        data = _cases.gen_input(c["input"], oracle)
+        off, sz = oracle.chunks(data, c["mode"], **c["config"])
+        assert [int(x) for x in off] == c["offsets"], (c["input"], c["config"], c["mode"])
+        assert [int(x) for x in sz] == c["sizes"]
+        hashes = [oracle.sha256_hex(data[int(o):int(o + s)]) for o, s in zip(off, sz)]
+        assert hashes[:3] == c["hash_head"] and hashes[-3:] == c["hash_tail"]
+        assert oracle.sha256_hex("".join(hashes).encode()) == c["hash_of_hashes"]
+
+
+def test_cdc_live_vs_reference(oracle, ref):
+    rng = np.random.default_rng(21)
+    data = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    for mode in ("rabin", "streaming"):
+        for cfg in [{}, {"min_size": 4096, "max_size": 65536}, {"min_size": 1, "max_size": 64, "mask": 7, "window": 5},
+                    {"min_size": 100, "max_size": 100}, {"min_size": 300, "max_size": 200, "mask": 0xFF}]:
+            d = data if cfg.get("min_size", 16384) >= 4096 else data[:200000]
+            a = oracle.chunks(d, mode, **cfg)
+            b = ref.chunks(d, mode, with_hashes=False, **cfg)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (mode, cfg)
+
+
+def test_cdc_invariants(oracle):
+    # coverage / contiguity / size bounds, chunking_test.cpp:146-183 (reference)
+    data = np.random.default_rng(22).integers(0, 256, 2 << 20, dtype=np.uint8)
+    for mode, lo in (("rabin", 4097), ("streaming", 4096)):
+        off, sz = oracle.chunks(data, mode, min_size=4096, max_size=32768)
+        assert off[0] == 0 and int(off[-1] + sz[-1]) == data.size
+        assert np.array_equal(off[1:], (off + sz)[:-1])
+        assert (sz[:-1] >= lo).all() and (sz <= 32768).all()
+
+
+def test_rolling_hash_is_position_local(oracle):
+    """the hash at byte n depends only on bytes [n-7..n] and [n-W-7..n-W]; this is
+    what lets the device kernel warm up over 8 bytes.  Checked against the sequential ring."""
+    rng = np.random.default_rng(23)
+    data = rng.integers(0, 256, 5000, dtype=np.uint8)
+    W = 48
+    t = [int(x) for x in oracle.rabin_table(0x3DA3358B4DC173)]
+    M = (1 << 64) - 1
+    ring = [0] * W; pos = 0; h = 0; seq = []
+    for b in data:
+        ob = ring[pos]; ring[pos] = int(b); pos = (pos + 1) % W
+        h = (((h - t[ob]) & M) << 8 & M) ^ t[int(b)]
+        seq.append(h)
+    for n in list(range(0, 120)) + list(rng.integers(120, 5000, 200)):
+        g = 0
+        for i in range(n - 7, n + 1):
+            nb = int(data[i]) if i >= 0 else 0
+            ob = int(data[i - W]) if i - W >= 0 else 0
+            g = (((g - t[ob]) & M) << 8 & M) ^ t[nb]
+        assert g == seq[n], n
+
+
+# ---- exact scan ---------------------------------------------------------------------------------
+def test_scan_reference_known_answers(oracle):
+    # "exact scan is a global vector reference", vector_smoke_catch2_test.cpp:188-225 (reference)
+    c = np.array([[1.0, i, 0, 0] for i in range(6)], np.float32)
+    rows, sims, visited, evals = oracle.scan_cosine(c, np.array([1, 0, 0, 0], np.float32), 3, -1.0)
+    assert rows[0] == 0 and len(rows) == 3 and visited == 6 and evals == 6
+    # "rejects invalid query vectors" :227-261
+    assert oracle.scan_cosine(c, np.zeros(4, np.float32), 1, -1.0) is None
+    assert oracle.scan_cosine(c, np.array([1, np.nan, 0, 0], np.float32), 1, -1.0) is None
+    # "keeps large finite scores consistent" :263-302
+    L = np.float32(np.finfo(np.float32).max / 4)
+    e = np.array([[L, -L, L, -L]], np.float32)
+    rows, sims, _, _ = oracle.scan_cosine(e, e[0], 1, -1.0)
+    assert len(rows) == 1 and np.isfinite(sims[0]) and sims[0] > 0.999
+    # "breaks score ties deterministically" :304-353 — ties resolved by chunk_id, not insertion order
+    for ids in (["tie_c", "tie_a", "tie_b"], ["tie_b", "tie_a", "tie_c"]):
+        rank, _ = _cases.string_ranks(ids)
+        c3 = np.tile(np.array([1, 0, 0, 0], np.float32), (3, 1))
+        rows, _, _, _ = oracle.scan_cosine(c3, np.array([1, 0, 0, 0], np.float32), 2, -1.0, tie_rank=rank)
+        assert [ids[r] for r in rows] == ["tie_a", "tie_b"]
+
+
+def test_scan_fixture_recipe_cases(oracle):
+    # sqlite_vec_backend_comprehensive_catch2_test.cpp:815-844 (reference): 10 seeded vectors dim 64,
+    # query = seed 1 -> top-1 is the vector with seed 1 ("chunk_search_0"), 5 results
+    corpus = np.stack([_cases.fixture_embedding(64, s + 1) for s in range(10)])
+    rows, sims, _, _ = oracle.scan_cosine(corpus, _cases.fixture_embedding(64, 1), 5, 0.0)
+    assert rows[0] == 0 and abs(sims[0] - 1.0) < 1e-6
+    # :1451-1478 k=100 over 3 rows -> 1..3 results; :1152-1181 thresholds
+    rows, _, _, _ = oracle.scan_cosine(corpus[:3], corpus[0], 100, 0.0)
+    assert 1 <= len(rows) <= 3
+    hi, _, _, _ = oracle.scan_cosine(corpus, corpus[0], 10, 0.99)
+    lo, _, _, _ = oracle.scan_cosine(corpus, corpus[0], 10, -1.0)
+    assert len(hi) <= 2 and len(lo) == 10
+
+
+def test_scan_skips_and_cosine_helper(oracle):
+    c = np.array([[1, 0, 0, 0], [0, 0, 0, 0], [np.nan, 1, 0, 0], [1e-7, 0, 0, 0], [2, 0, 0, 0]], np.float32)
+    rows, sims, visited, evals = oracle.scan_cosine(c, np.array([1, 0, 0, 0], np.float32), 10, -1.0)
+    # zero-norm (<=1e-12), NaN and tiny-norm rows are skipped (:4258-4269); rows 0 and 4 tie at 1.0
+    assert list(rows) == [0, 4] and visited == 5 and evals == 5
+    assert oracle.cosine(c[0], c[4]) == 1.0 and oracle.cosine(c[0], c[1]) == 0.0
+
+
+def test_l2_known_answers(oracle):
+    # sqlite_vec_c_api_smoke_catch2_test.cpp:20-43 (reference): Euclidean distance WITH sqrt
+    a = np.arange(8, dtype=np.float32)
+    rows, dist, sims = oracle.scan_l2(np.stack([a, a + 1]), a, 2, -1.0)
+    assert list(rows) == [0, 1] and dist[0] == 0.0 and abs(dist[1] - np.sqrt(8)) < 1e-5

@@ -1,0 +1,384 @@
+"""GPU parity suite for the exact vector scan, through the C ABI, against the oracle.
+
+Bar: top-k index sets bit-exact (including order and the chunk_id tie-break), similarities /
+distances bit-identical to the fp64-then-cast reference arithmetic (north_star allows 1e-5; we
+hold 0 ulp and assert it)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _cases
+from yams_amd import _lib
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT
+
+pytestmark = pytest.mark.gpu
+
+TOL = 0.0  # similarities must be bit-identical; the north_star tolerance would be 1e-5
+
+
+def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0):
+    corpus = np.ascontiguousarray(corpus, np.float32)
+    dc = acc.to_device(corpus) if corpus.size else None
+    dr = di = None
+    if tie_rank is not None:
+        inv = np.empty_like(tie_rank)
+        inv[tie_rank] = np.arange(tie_rank.size, dtype=tie_rank.dtype)
+        dr, di = acc.to_device(tie_rank.astype(np.uint32)), acc.to_device(inv.astype(np.uint32))
+    view = acc.corpus_view(dc.ptr if dc else None, corpus.shape[0], corpus.shape[1],
+                           dr.ptr if dr else None, di.ptr if di else None, row_base)
+    return acc.scan_topk(view, queries, k, thr, metric, flags)
+
+
+def check(acc, oracle, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None,
+          max_queries=None, expect_path=None):
+    queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
+    r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank)
+    if expect_path is not None:
+        assert r.diag["path"] == expect_path, r.diag
+    tr64 = None if tie_rank is None else tie_rank.astype(np.uint64)
+    nq = queries.shape[0]
+    for qi in range(nq if max_queries is None else min(nq, max_queries)):
+        if metric == SCAN_COSINE:
+            rows, sims, _, _ = oracle.scan_cosine(corpus, queries[qi], k, thr, tr64)
+            dist = None
+        else:
+            rows, dist, sims = oracle.scan_l2(corpus, queries[qi], k, thr, tr64)
+        cnt = int(r.counts[qi])
+        assert cnt == len(rows), (qi, cnt, len(rows), r.diag)
+        assert np.array_equal(r.rows[qi, :cnt], rows), (qi, r.rows[qi, :cnt][:10], rows[:10], r.diag)
+        assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), qi
+        if dist is not None:
+            assert np.array_equal(r.dist[qi, :cnt].view(np.uint32), dist.view(np.uint32)), qi
+        assert (r.rows[qi, cnt:] == -1).all()
+    assert r.diag["used_exact_scan"] == 1 and r.diag["rows_visited"] == nq * corpus.shape[0]
+    assert r.diag["exact_distance_evaluations"] == nq * corpus.shape[0]
+    return r
+
+
+# ---- the reference's own known-answer tests, replayed through the C ABI --------------------------
+def test_reference_exact_scan_contract(acc, oracle):
+    # vector_smoke_catch2_test.cpp:188-225 (reference): 6 rows {1,i,0,0}, query {1,0,0,0}, k=3
+    c = np.array([[1.0, i, 0, 0] for i in range(6)], np.float32)
+    r = check(acc, oracle, c, [1, 0, 0, 0], 3)
+    assert r.rows[0, 0] == 0 and r.counts[0] == 3
+    assert r.diag["rows_visited"] == 6 and r.diag["exact_distance_evaluations"] == 6
+    assert r.diag["returned_rows"] == 3
+
+
+def test_reference_rejects_invalid_queries(acc):
+    # vector_smoke_catch2_test.cpp:227-261 (reference): zero norm / NaN -> InvalidArgument
+    c = np.array([[1.0, 0, 0, 0]], np.float32)
+    for bad in ([0, 0, 0, 0], [1, np.nan, 0, 0], [np.inf, 0, 0, 0], [1e-6, 0, 0, 0]):
+        with pytest.raises(_lib.AccelError) as e:
+            run(acc, c, np.array(bad, np.float32), 1)
+        assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    # a batch fails as a whole (sqlite_vec_backend.cpp:1635-1647)
+    with pytest.raises(_lib.AccelError):
+        run(acc, c, np.array([[1, 0, 0, 0], [0, 0, 0, 0]], np.float32), 1)
+    # k == 0 returns empty BEFORE validation (:4123-4126)
+    r = run(acc, c, np.array([0, 0, 0, 0], np.float32), 0)
+    assert r.counts[0] == 0
+
+
+def test_reference_large_finite_scores(acc, oracle):
+    # vector_smoke_catch2_test.cpp:263-302 (reference): +-FLT_MAX/4 self match stays finite, > 0.999
+    L = np.float32(np.finfo(np.float32).max / 4)
+    e = np.array([[L, -L, L, -L]], np.float32)
+    r = check(acc, oracle, e, e[0], 1)
+    assert np.isfinite(r.scores[0, 0]) and r.scores[0, 0] > 0.999
+    # the same rows inside a corpus large enough for the MFMA filter (fp32 overflows there and the
+    # row must be routed to the fp64 re-score)
+    corpus = oracle.synth_rows(1, 0, 6000, 4)
+    corpus[100] = e[0]; corpus[5000] = -e[0]
+    r = check(acc, oracle, corpus, np.stack([e[0], corpus[7]]), 5, expect_path=0)
+    assert r.rows[0, 0] == 100
+
+
+def test_reference_tie_break_by_chunk_id(acc, oracle):
+    # vector_smoke_catch2_test.cpp:304-353 (reference)
+    for ids in (["tie_c", "tie_a", "tie_b"], ["tie_b", "tie_a", "tie_c"]):
+        rank, _ = _cases.string_ranks(ids)
+        c = np.tile(np.array([1, 0, 0, 0], np.float32), (3, 1))
+        r = run(acc, c, np.array([1, 0, 0, 0], np.float32), 2, -1.0, tie_rank=rank)
+        assert [ids[i] for i in r.rows[0, :2]] == ["tie_a", "tie_b"]
+
+
+def test_reference_fixture_cases(acc, oracle):
+    # sqlite_vec_backend_comprehensive_catch2_test.cpp:815-844, 1152-1181, 1451-1478 (reference)
+    corpus = np.stack([_cases.fixture_embedding(64, s + 1) for s in range(10)])
+    r = check(acc, oracle, corpus, _cases.fixture_embedding(64, 1), 5, 0.0)
+    assert r.rows[0, 0] == 0 and r.counts[0] == 5
+    r = check(acc, oracle, corpus[:3], corpus[0], 100, 0.0)          # k > corpus
+    assert 1 <= r.counts[0] <= 3
+    assert check(acc, oracle, corpus, corpus[0], 10, 0.99).counts[0] <= 2
+    assert check(acc, oracle, corpus, corpus[0], 10, -1.0).counts[0] == 10
+    # 64 x 64 self query, exactDistanceEvaluations == corpus (:1068-1112)
+    c64 = np.stack([_cases.fixture_embedding(64, s + 1) for s in range(64)])
+    r = check(acc, oracle, c64, c64[17], 1)
+    assert r.rows[0, 0] == 17 and r.diag["exact_distance_evaluations"] == 64
+
+
+def test_empty_and_degenerate(acc):
+    r = run(acc, np.zeros((0, 8), np.float32), np.ones(8, np.float32), 5)
+    assert r.counts[0] == 0 and r.diag["rows_visited"] == 0
+    c = np.zeros((10, 8), np.float32)                      # only zero-norm rows: all skipped
+    assert run(acc, c, np.ones(8, np.float32), 5).counts[0] == 0
+    with pytest.raises(_lib.AccelError):                   # k beyond the supported bound
+        run(acc, np.ones((4, 8), np.float32), np.ones(8, np.float32), 5000)
+
+
+# ---- seeded parity sweeps ---------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k,metric,thr", [
+    (1, 4, 1, 1, SCAN_COSINE, -1.0),
+    (100, 3, 2, 7, SCAN_COSINE, -1.0),            # dim not a multiple of 4 -> fp64 path
+    (3000, 64, 5, 10, SCAN_COSINE, 0.0),
+    (3000, 384, 3, 100, SCAN_L2, -1.0),
+    (4096, 128, 9, 10, SCAN_COSINE, -1.0),        # smallest MFMA-path corpus
+    (5001, 100, 4, 20, SCAN_COSINE, -1.0),        # ragged tile + dim % 32 != 0
+    (20000, 384, 37, 100, SCAN_COSINE, -1.0),
+    (20000, 768, 130, 10, SCAN_L2, -1.0),
+    (150000, 384, 130, 100, SCAN_COSINE, -1.0),   # sample + filter passes, 2 query tiles
+    (150000, 384, 40, 100, SCAN_COSINE, 0.16),    # threshold cuts the result short
+    (150000, 256, 16, 100, SCAN_L2, 0.05),        # vec0: top-k by distance, then cosine threshold
+    (60000, 128, 8, 1000, SCAN_COSINE, -1.0),     # large k
+    (33000, 1024, 3, 1, SCAN_COSINE, -1.0),
+])
+def test_parity_sweep(acc, oracle, n, d, nq, k, metric, thr):
+    corpus = oracle.synth_rows(7, 0, n, d)
+    queries = oracle.synth_rows(7, 1 << 40, nq, d)
+    path = 0 if (n >= 4096 and d % 4 == 0) else 1
+    check(acc, oracle, corpus, queries, k, thr, metric, max_queries=24, expect_path=path)
+
+
+def test_unnormalised_and_scaled_vectors(acc, oracle):
+    rng = np.random.default_rng(31)
+    corpus = (rng.standard_normal((30000, 96)) * rng.uniform(1e-3, 1e3, (30000, 1))).astype(np.float32)
+    queries = (rng.standard_normal((6, 96)) * 50).astype(np.float32)
+    check(acc, oracle, corpus, queries, 25, expect_path=0)
+    check(acc, oracle, corpus, queries, 25, metric=SCAN_L2, expect_path=0)
+
+
+def test_adversarial_rows_on_the_filter_path(acc, oracle):
+    """Zero rows, NaN/inf rows, tiny and huge norms, duplicates and scaled copies (exact fp64 ties
+    that differ in fp32) inside a corpus that takes the MFMA filter; ties go by a shuffled rank."""
+    rng = np.random.default_rng(32)
+    n, d = 12000, 64
+    corpus = oracle.synth_rows(9, 0, n, d)
+    q = oracle.synth_rows(9, 1 << 40, 4, d)
+    corpus[10] = 0
+    corpus[11, 3] = np.nan
+    corpus[12, 5] = np.inf
+    corpus[13] *= np.float32(1e-25)        # norm^2 ~ 1e-50 <= 1e-12 -> skipped by the reference
+    corpus[14] *= np.float32(3e-7)         # norm^2 ~ 9e-14 <= 1e-12 -> skipped
+    corpus[15] *= np.float32(1e18)
+    corpus[16] *= np.float32(np.finfo(np.float32).max / 8)
+    best = int(oracle.scan_cosine(corpus, q[0], 1)[0][0])
+    for j, s in enumerate([2.0, 0.5, 3.0, 1.0, 7.0, 1.0]):   # scaled + exact duplicates of the winner
+        corpus[2000 + 17 * j] = corpus[best] * np.float32(s)
+    corpus[9000:9040] = corpus[best]                       # 40 exact duplicates (> k ties at rank 1)
+    rank = rng.permutation(n).astype(np.uint32)
+    for k in (1, 10, 60):
+        r = check(acc, oracle, corpus, q, k, tie_rank=rank)
+        check(acc, oracle, corpus, q, k, metric=SCAN_L2, tie_rank=rank)
+    assert r.diag["path"] == 0
+
+
+def test_ties_beyond_the_candidate_budget_are_widened(acc, oracle):
+    """More identical rows than the first-stage candidate budget (k' = 96) but fewer than the
+    candidate list holds: stage 1 cannot prove completeness, stage 2 re-scores the whole list."""
+    n, d = 20000, 32
+    corpus = oracle.synth_rows(10, 0, n, d)
+    q = oracle.synth_rows(10, 1 << 40, 3, d)
+    corpus[100:20000:66][:120] = q[1]                       # 120 rows tie with similarity 1.0
+    rank = np.random.default_rng(33).permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0)
+    assert r.diag["widened_queries"] >= 1 and r.diag["exact_fallback_queries"] == 0
+
+
+def test_massive_ties_take_the_exhaustive_fp64_path(acc, oracle):
+    """More identical rows than the candidate list can hold: the list overflows, the query is
+    scored exhaustively in fp64 on the device — results stay exact, other queries stay fast."""
+    n, d = 20000, 32
+    corpus = oracle.synth_rows(10, 0, n, d)
+    q = oracle.synth_rows(10, 1 << 40, 3, d)
+    corpus[::4] = q[1]                                      # 5000 rows tie with similarity 1.0
+    rank = np.random.default_rng(33).permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0)
+    assert 1 <= r.diag["exact_fallback_queries"] <= 2
+
+
+def test_sorted_corpus_defeats_the_sample_but_not_the_result(acc, oracle):
+    """Rows ordered by similarity to the query: every tile beats the sampled threshold's
+    expectation; the candidate lists may overflow — the answer must not change."""
+    n, d = 60000, 64
+    corpus = oracle.synth_rows(11, 0, n, d)
+    q = oracle.synth_rows(11, 1 << 40, 2, d)
+    order = np.argsort(corpus @ q[0])
+    check(acc, oracle, corpus[order], q, 100)
+    check(acc, oracle, corpus[order[::-1]], q, 100)
+
+
+def test_forced_exact_equals_filter_path(acc, oracle):
+    corpus = oracle.synth_rows(12, 0, 50000, 128)
+    q = oracle.synth_rows(12, 1 << 40, 6, 128)
+    a = run(acc, corpus, q, 40)
+    b = run(acc, corpus, q, 40, flags=FLAG_FORCE_EXACT)
+    assert a.diag["path"] == 0 and b.diag["path"] == 1
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
+
+
+def test_row_base_and_device_entry_point(acc, oracle):
+    import torch
+    n, d, nq, k = 10000, 64, 3, 5
+    corpus = oracle.synth_rows(13, 0, n, d)
+    q = oracle.synth_rows(13, 1 << 40, nq, d)
+    tc, tq = torch.from_numpy(corpus).cuda(), torch.from_numpy(q).cuda()
+    s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    rws = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+    rk = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    view = acc.corpus_view(tc.data_ptr(), n, d, row_base=1_000_000)
+    acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), rws.data_ptr(),
+                         cnt.data_ptr(), None, rk.data_ptr())
+    for qi in range(nq):
+        rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k)
+        assert np.array_equal(rws[qi].cpu().numpy(), rows + 1_000_000)
+        assert np.array_equal(rk[qi].cpu().numpy().astype(np.int64), rows)
+
+
+# ---- shard merge (the step after the RCCL all-gather) ---------------------------------------------
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
+def test_sharded_merge_equals_single_device_and_oracle(acc, oracle, n_shards, metric):
+    import torch
+    n, d, nq, k = 24000, 64, 5, 20
+    corpus = oracle.synth_rows(14, 0, n, d)
+    q = oracle.synth_rows(14, 1 << 40, nq, d)
+    corpus[5] = corpus[23000]                  # a cross-shard exact tie
+    q[0] = corpus[5]
+    thr = 0.05 if metric == SCAN_L2 else -1.0
+    tq = torch.from_numpy(q).cuda()
+    bounds = [n * i // n_shards for i in range(n_shards + 1)]
+    S = torch.empty((n_shards, nq, k), dtype=torch.float32, device="cuda")
+    R = torch.empty((n_shards, nq, k), dtype=torch.int64, device="cuda")
+    Cn = torch.empty((n_shards, nq), dtype=torch.int32, device="cuda")
+    D = torch.empty((n_shards, nq, k), dtype=torch.float32, device="cuda")
+    keep = []
+    for s in range(n_shards):
+        tc = torch.from_numpy(corpus[bounds[s]:bounds[s + 1]]).cuda(); keep.append(tc)
+        view = acc.corpus_view(tc.data_ptr(), bounds[s + 1] - bounds[s], d, row_base=bounds[s])
+        acc.scan_topk_device(view, tq.data_ptr(), nq, k, thr, metric, S[s].data_ptr(), R[s].data_ptr(),
+                             Cn[s].data_ptr(), D[s].data_ptr(), None,
+                             flags=_lib.FLAG_DEFER_THRESHOLD if metric == SCAN_L2 else 0)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    or_ = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    oc = torch.empty(nq, dtype=torch.int32, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    acc.merge_topk_device(n_shards, nq, k, thr, metric, S.data_ptr(), R.data_ptr(), Cn.data_ptr(),
+                          D.data_ptr(), None, os_.data_ptr(), or_.data_ptr(), oc.data_ptr(), od.data_ptr())
+    acc.synchronize()
+    for qi in range(nq):
+        if metric == SCAN_COSINE:
+            rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, thr)
+        else:
+            rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, thr)
+        c = int(oc[qi])
+        assert c == len(rows)
+        assert np.array_equal(or_[qi, :c].cpu().numpy(), rows)
+        assert np.array_equal(os_[qi, :c].cpu().numpy().view(np.uint32), sims.view(np.uint32))
+
+
+# ---- BASELINE.json full sizes: size-independent properties ----------------------------------------
+def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
+    import torch
+    tc = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    acc.synth_rows(42, 0, n, d, tc.data_ptr())
+    tq = torch.empty((nq, d), dtype=torch.float32, device="cuda")
+    acc.synth_rows(42, n, nq, d, tq.data_ptr())
+    s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    c = torch.empty(nq, dtype=torch.int32, device="cuda")
+    dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    view = acc.corpus_view(tc.data_ptr(), n, d)
+    diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(),
+                                c.data_ptr(), dist.data_ptr())
+    assert diag["path"] == 0 and diag["exact_fallback_queries"] == 0
+    assert (c == k).all()
+    key = dist if metric == SCAN_L2 else -s
+    assert (key[:, 1:] >= key[:, :-1]).all()                                 # sortedness
+    assert ((r >= 0) & (r < n)).all()
+    assert all(len(set(row.tolist())) == k for row in r.cpu().numpy()[:32])  # no duplicates
+    # the fp64 scores of the returned rows, recomputed independently with torch on the device
+    sub = slice(0, 8)
+    rows = tc[r[sub].reshape(-1)].double().reshape(8, k, d)
+    qd = tq[sub].double()
+    if metric == SCAN_COSINE:
+        ref = (rows * qd[:, None, :]).sum(-1) / (rows.norm(dim=-1) * qd.norm(dim=-1)[:, None])
+        assert (ref.float() - s[sub]).abs().max().item() <= 1e-6
+    else:
+        ref = (rows - qd[:, None, :]).norm(dim=-1)
+        assert (ref.float() - dist[sub]).abs().max().item() <= 1e-5
+    # recall@k = 1.0 against the exhaustive fp64 device path (itself pinned to the oracle above)
+    qsel = torch.arange(0, nq, max(1, nq // 4))[:4].cuda()
+    s2 = torch.empty((len(qsel), k), dtype=torch.float32, device="cuda")
+    r2 = torch.empty((len(qsel), k), dtype=torch.int64, device="cuda")
+    c2 = torch.empty(len(qsel), dtype=torch.int32, device="cuda")
+    tq2 = tq[qsel].contiguous()
+    acc.scan_topk_device(view, tq2.data_ptr(), len(qsel), k, -1.0, metric, s2.data_ptr(), r2.data_ptr(),
+                         c2.data_ptr(), None, None, flags=FLAG_FORCE_EXACT)
+    assert torch.equal(r2, r[qsel]) and torch.equal(s2, s[qsel])
+    # and against the CPU oracle on a regenerated corpus for a few queries
+    if n_oracle_queries:
+        corpus = oracle.synth_rows(42, 0, n, d)
+        queries = oracle.synth_rows(42, n, nq, d)
+        for qi in list(range(nq))[:n_oracle_queries]:
+            rows_o, sims_o, _, _ = oracle.scan_cosine(corpus, queries[qi], k, -1.0)
+            assert np.array_equal(r[qi].cpu().numpy(), rows_o)
+            assert np.array_equal(s[qi].cpu().numpy().view(np.uint32), sims_o.view(np.uint32))
+
+
+def test_full_size_config2_1Mx384_cosine_top100_q256(acc, oracle):
+    _full_size(acc, oracle, 1_000_000, 384, 256, 100, SCAN_COSINE, n_oracle_queries=2)
+
+
+def test_full_size_config3_10Mx768_l2_top100_q1024(acc, oracle):
+    _full_size(acc, oracle, 10_000_000, 768, 1024, 100, SCAN_L2, n_oracle_queries=0)
+
+
+# ---- the plugin vtable door ------------------------------------------------------------------------
+def test_vector_scan_vtable(accel_lib, oracle):
+    L = accel_lib
+    assert L.yams_plugin_init(b'{"device": 0}', None) == 0
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"vector_scan_v1", 1, C.byref(p)) == 0
+    vt = C.cast(p, C.POINTER(_lib.VectorScanV1)).contents
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, 64, C.byref(cid)) == 0
+    corpus = oracle.synth_rows(15, 0, 9000, 64)
+    half = 4000
+    assert vt.corpus_append(None, cid, corpus[:half].ctypes.data_as(_lib.f32p), half) == 0
+    assert vt.corpus_append(None, cid, corpus[half:].ctypes.data_as(_lib.f32p), 9000 - half) == 0
+    n = C.c_uint64(); dim = C.c_uint32()
+    assert vt.corpus_size(None, cid, C.byref(n), C.byref(dim)) == 0 and (n.value, dim.value) == (9000, 64)
+    q = oracle.synth_rows(15, 1 << 40, 3, 64)
+    hits = C.POINTER(_lib.ScanHit)(); counts = _lib.u32p(); diag = _lib.ScanDiag()
+    # dimension mismatch -> InvalidArgument (vector_database.cpp:545-550)
+    assert vt.search_batch(None, cid, q.ctypes.data_as(_lib.f32p), 3, 32, 5, -1.0, 0,
+                           C.byref(hits), C.byref(counts), None) == _lib.YAMS_ERR_INVALID_ARG
+    assert vt.search_batch(None, cid, q.ctypes.data_as(_lib.f32p), 3, 64, 5, -1.0, 0,
+                           C.byref(hits), C.byref(counts), C.byref(diag)) == 0
+    for qi in range(3):
+        rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], 5)
+        assert counts[qi] == 5
+        assert [hits[qi * 5 + i].row for i in range(5)] == list(rows)
+        assert [hits[qi * 5 + i].similarity for i in range(5)] == [float(x) for x in sims]
+        assert abs(hits[qi * 5].distance - (1.0 - hits[qi * 5].similarity)) < 1e-7
+    vt.free_hits(None, hits, counts)
+    assert vt.search_batch(None, C.c_uint64(999), q.ctypes.data_as(_lib.f32p), 3, 64, 5, -1.0, 0,
+                           C.byref(hits), C.byref(counts), None) == _lib.YAMS_ERR_NOT_FOUND
+    info = C.c_void_p()
+    assert vt.get_runtime_info_json(None, C.byref(info)) == 0 and b"gfx950" in C.string_at(info)
+    vt.free_string(None, info)
+    assert vt.corpus_destroy(None, cid) == 0
+    L.yams_plugin_shutdown()

@@ -284,31 +284,26 @@ __device__ __forceinline__ void sha256_init(uint32_t st[8]) {
     st[4] = 0x510e527fu; st[5] = 0x9b05688cu; st[6] = 0x1f83d9abu; st[7] = 0x5be0cd19u;
 }
 
-// Load the 64 bytes at p (any alignment) as 16 big-endian words.  Reads the 17 aligned dwords
-// that cover [p, p+64); `limit` is one past the last byte that may be touched: dwords that start
-// at or beyond it are not loaded (tail blocks).
-__device__ __forceinline__ void load_block_be(const uint8_t* p, const uint8_t* limit, uint32_t w[16]) {
+// Raw fetch of the 17 aligned dwords that cover the 64 bytes at p (any alignment).  `limit` is one
+// past the last byte that may be touched: dwords that start at or beyond it read as zero.
+__device__ __forceinline__ void fetch_block(const uint8_t* p, const uint8_t* limit, uint32_t d[17]) {
     const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
-    const uint32_t sh = static_cast<uint32_t>(ad & 3u);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad - sh);
-    const uint32_t sel = 0x00010203u + sh * 0x01010101u;
-    uint32_t d[17];
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~static_cast<uintptr_t>(3));
 #pragma unroll
     for (int i = 0; i < 17; ++i)
         d[i] = (reinterpret_cast<const uint8_t*>(q + i) < limit) ? q[i] : 0u;
+}
+// Realign + byte-swap in one v_perm_b32 per word: big-endian word i = bytes [sh+4i, sh+4i+4).
+__device__ __forceinline__ void words_be(const uint32_t d[17], uint32_t sh, uint32_t w[16]) {
+    const uint32_t sel = 0x00010203u + sh * 0x01010101u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_perm(d[i + 1], d[i], sel);
 }
 
-struct ShaLane {
-    const uint8_t* p;     // next byte to consume
-    const uint8_t* end;   // one past the message
-    uint64_t total;       // message length in bytes
-    uint64_t index;       // message index (digest slot)
-    uint32_t st[8];
-    int phase;            // 0 = data, 1 = length-only block pending, 2 = idle
-};
-
+// Lane state machine.  phase: 0 = data blocks, 1 = length-only block pending, 2 = needs a new
+// message, 3 = queue drained.  `nxt` always holds the raw dwords of the block at `p` (fetched one
+// iteration ahead so that the HBM latency of block i+1 hides under the 64 rounds of block i —
+// a whole-blob digest is one long dependent chain on a single lane and has no other cover).
 __global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
                                                            const uint64_t* offs,
                                                            const uint64_t* lens, uint64_t n_msgs,
@@ -317,82 +312,98 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
                                                            const uint32_t* init_state /*nullable*/,
                                                            uint32_t* out_state /*nullable*/,
                                                            int raw_blocks_only) {
-    ShaLane L;
-    L.phase = 2; L.p = nullptr; L.end = nullptr; L.total = 0; L.index = 0;
+    const uint8_t* p = nullptr;   // next block to consume
+    const uint8_t* end = nullptr; // one past the message
+    uint64_t total = 0, index = 0;
+    uint32_t st[8];
+    uint32_t nxt[17];
+    int phase = 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) nxt[i] = 0;
     for (;;) {
-        if (L.phase == 2) {
+        if (phase == 2) {
             const unsigned long long idx = atomicAdd(queue_head, 1ull);
             if (idx < n_msgs) {
-                L.index = idx;
-                L.p = data + offs[idx];
-                L.total = lens[idx];
-                L.end = L.p + L.total;
+                index = idx;
+                p = data + offs[idx];
+                total = lens[idx];
+                end = p + total;
                 if (init_state) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) L.st[i] = init_state[idx * 8 + i];
-                } else sha256_init(L.st);
-                L.phase = 0;
+                    for (int i = 0; i < 8; ++i) st[i] = init_state[idx * 8 + i];
+                } else sha256_init(st);
+                fetch_block(p, end, nxt); // the only un-hidden fetch of this message
+                phase = 0;
             } else {
-                L.phase = 3; // drained
+                phase = 3;
             }
         }
-        if (__all(L.phase == 3)) break;
+        if (__all(phase == 3)) break;
         uint32_t w[16];
-        bool final_block = false;
-        if (L.phase == 0) {
-            const uint64_t rem = static_cast<uint64_t>(L.end - L.p);
-            if (rem >= 64) {
-                load_block_be(L.p, L.end, w);
-                L.p += 64;
-                if (raw_blocks_only && L.p == L.end) final_block = true;
-            } else if (raw_blocks_only) {
-                final_block = true; // (only whole blocks are fed in this mode)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) w[i] = 0;
+        bool final_block = false, run = false;
+        if (phase == 0) {
+            const uint64_t rem = static_cast<uint64_t>(end - p);
+            const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p) & 3u);
+            if (raw_blocks_only && rem < 64) {
+                final_block = true; // no data at all (total == 0): state passes through
             } else {
-                load_block_be(L.p, L.end, w);
-                const uint32_t r = static_cast<uint32_t>(rem);
+                words_be(nxt, sh, w);
+                run = true;
+                if (rem >= 64) {
+                    p += 64;
+                    if (raw_blocks_only && p == end) final_block = true;
+                    if (p < end) fetch_block(p, end, nxt); // prefetch; consumed next iteration
+                    else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t lo = 4u * j;
-                    if (r <= lo) w[j] = 0;
-                    else if (r < lo + 4) w[j] &= 0xffffffffu << (8u * (lo + 4 - r));
-                    if ((r >> 2) == static_cast<uint32_t>(j)) w[j] |= 0x80u << (24 - 8 * (r & 3));
-                }
-                L.p = L.end;
-                if (r < 56) {
-                    const uint64_t bitlen = L.total * 8ull;
-                    w[14] = static_cast<uint32_t>(bitlen >> 32);
-                    w[15] = static_cast<uint32_t>(bitlen);
-                    final_block = true;
+                        for (int i = 0; i < 17; ++i) nxt[i] = 0;
+                    }
                 } else {
-                    L.phase = 1;
+                    const uint32_t r = static_cast<uint32_t>(rem);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t lo = 4u * j;
+                        if (r <= lo) w[j] = 0;
+                        else if (r < lo + 4) w[j] &= 0xffffffffu << (8u * (lo + 4 - r));
+                        if ((r >> 2) == static_cast<uint32_t>(j)) w[j] |= 0x80u << (24 - 8 * (r & 3));
+                    }
+                    p = end;
+                    if (r < 56) {
+                        const uint64_t bitlen = total * 8ull;
+                        w[14] = static_cast<uint32_t>(bitlen >> 32);
+                        w[15] = static_cast<uint32_t>(bitlen);
+                        final_block = true;
+                    } else {
+                        phase = 1;
+                    }
                 }
             }
-        } else if (L.phase == 1) {
+        } else if (phase == 1) {
 #pragma unroll
             for (int i = 0; i < 14; ++i) w[i] = 0;
-            const uint64_t bitlen = L.total * 8ull;
+            const uint64_t bitlen = total * 8ull;
             w[14] = static_cast<uint32_t>(bitlen >> 32);
             w[15] = static_cast<uint32_t>(bitlen);
             final_block = true;
+            run = true;
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) w[i] = 0;
         }
-        if (L.phase <= 1 && !(raw_blocks_only && L.total == 0)) sha256_compress(L.st, w);
-        if (final_block && L.phase <= 1) {
+        if (run) sha256_compress(st, w);
+        if (final_block) {
             if (out_state) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) out_state[L.index * 8 + i] = L.st[i];
+                for (int i = 0; i < 8; ++i) out_state[index * 8 + i] = st[i];
             }
             if (digests) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(digests + L.index * 32);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(digests + index * 32);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    dst[i] = __builtin_amdgcn_perm(0u, L.st[i], 0x00010203u); // big-endian bytes
+                    dst[i] = __builtin_amdgcn_perm(0u, st[i], 0x00010203u); // big-endian bytes
             }
-            L.phase = 2;
+            phase = 2;
         }
     }
 }

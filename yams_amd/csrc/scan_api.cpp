@@ -228,10 +228,13 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipMemcpyAsync(h_status, d_status, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
         YA_HIP(ctx, hipMemcpyAsync(h_lcount, d_lcount, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
         YA_HIP(ctx, hipStreamSynchronize(st));
-        std::vector<uint32_t> failed;
+        std::vector<uint32_t> failed, overflowed;
         for (uint32_t i = 0; i < nq; ++i) {
             filter_candidates += std::min<uint32_t>(h_lcount[i], plan.list_cap);
-            if (h_status[i] != 0 && h_flags[i] == 0) failed.push_back(i);
+            if (h_status[i] != 0 && h_flags[i] == 0) {
+                // a list that overflowed is incomplete: widening cannot help, go exhaustive
+                if (h_lcount[i] > plan.list_cap) overflowed.push_back(i); else failed.push_back(i);
+            }
         }
         if (!failed.empty() && plan.kprime < kRescoreMax) {
             // stage 2: widen to everything the list holds (up to kRescoreMax candidates)
@@ -246,6 +249,7 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
             for (uint32_t q : failed) if (h_status[q] != 0) still.push_back(q);
             failed.swap(still);
         }
+        failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {
             // stage 3: exhaustive fp64 for the queries that could not be proven complete
             exact_fb = static_cast<uint32_t>(failed.size());

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Synthetic data: Philox4x32-10, identical to oracle_philox4x32.
+// Synthetic data: Philox4x32-10, the same generator the CPU checker restates.
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t c_lo, uint64_t c_hi,
                                               uint32_t out[4]) {
@@ -794,7 +794,7 @@ __device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t c_lo, uint
 }
 
 // One wave per row: lanes generate 4 columns each per step, the norm is accumulated in float in
-// COLUMN ORDER (a single lane walks the row) so that it matches oracle_synth_rows bit for bit.
+// COLUMN ORDER (a single lane walks the row) so that a CPU regeneration of the same rows matches bit for bit.
 __global__ __launch_bounds__(64) void synth_rows_kernel(uint64_t seed, uint64_t row0,
                                                         uint64_t n_rows, uint32_t dim, float* out) {
     extern __shared__ float srow[];
@@ -913,6 +913,8 @@ static hipError_t topk_multilevel(hipStream_t st, const K* in, const uint32_t* i
                                   uint64_t in_stride, uint32_t n_max, uint32_t count_clip,
                                   uint32_t n_slots, const uint32_t* qmap, uint32_t keep, K* work,
                                   const K** result, uint64_t* result_stride) {
+    // each level must shrink the problem: 2 chunks * keep has to fit one chunk
+    if (keep == 0 || keep > static_cast<uint32_t>(kSelectCap) / 2) return hipErrorInvalidValue;
     const K* cur = in;
     const uint32_t* cur_counts = in_counts;
     uint64_t cur_stride = in_stride;

@@ -37,7 +37,7 @@ struct MergeLaunch {
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
 };
 
-constexpr uint32_t kRescoreMax = 2048;
+constexpr uint32_t kRescoreMax = 2047; // + 1 boundary key == kSelectCap / 2 (select convergence)
 
 hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
