@@ -1,0 +1,61 @@
+"""Condenses rocprofv3 output under gpurun_out/prof_* into small tracked files under profiles/.
+
+    python scripts/summarize_profiles.py r01
+
+Writes profiles/<round>_scan_kernel_stats.csv (the --kernel-trace --stats summary, verbatim),
+profiles/<round>_ingest_kernel_stats.csv, profiles/<round>_pmc.json (per-kernel counter averages)
+and profiles/scan_filter_pmc.json (HBM traffic per launch of the dominant kernel, read by bench.py).
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(P, exist_ok=True)
+
+
+def copy(src, dst):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+        print("copied", dst)
+
+
+copy(os.path.join(G, "prof_trace", "scan_kernel_stats.csv"), os.path.join(P, f"{tag}_scan_kernel_stats.csv"))
+copy(os.path.join(G, "prof_ingest", "ingest_kernel_stats.csv"), os.path.join(P, f"{tag}_ingest_kernel_stats.csv"))
+
+pmc = {}
+for d in ("prof_pmc1", "prof_pmc2", "prof_pmc3"):
+    f = os.path.join(G, d, "scan_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        e = pmc.setdefault(name, {}).setdefault(r["Counter_Name"], [])
+        e.append(float(r["Counter_Value"]))
+summary = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
+meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 1 --warmup 1 "
+                   "--no-cpu-baseline --no-ingest (separate passes: FETCH_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
+                   "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE)",
+        "notes": ["FETCH_SIZE is in KiB; on gfx950 it under-reports wide coalesced reads by 2x "
+                  "(MI355X_MICROARCH.md, HBM section): hbm_bytes = 2 * FETCH_SIZE * 1024",
+                  "GRBM_GUI_ACTIVE is summed over the 8 XCDs",
+                  "SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32, summed over 1024 SIMDs"]}
+json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
+print("wrote", os.path.join(P, f"{tag}_pmc.json"))
+
+filt = [k for k in summary if "scan_tiles_kernel<1, 0>" in k]
+if filt and "FETCH_SIZE" in summary[filt[0]]:
+    fs = summary[filt[0]]["FETCH_SIZE"]["mean"]
+    out = {"kernel": filt[0], "rows_per_gpu": 12_500_000, "dim": 768, "queries": 1024,
+           "fetch_size_kib": fs, "hbm_bytes_per_launch": 2.0 * fs * 1024.0,
+           "correction": "2x (gfx950 FETCH_SIZE halves wide coalesced reads)", "round": tag}
+    k2 = summary[filt[0]]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in k2 and "GRBM_GUI_ACTIVE" in k2:
+        out["mfma_busy_frac"] = k2["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (k2["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0)
+    json.dump(out, open(os.path.join(P, "scan_filter_pmc.json"), "w"), indent=1)
+    print(out)

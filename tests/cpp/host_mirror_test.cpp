@@ -1,0 +1,140 @@
+// host_mirror_test.cpp — the C++ host-side mirror (include/yams_accel/*.hpp) exercised the way the
+// reference's Catch2 tests exercise the seams it replaces:
+//   tests/unit/vector/vector_smoke_catch2_test.cpp:188-353   (exact-scan contract, ties, invalid queries)
+//   tests/unit/crypto/crypto_test.cpp:92-99,134-228          (SHA-256 known answers, split updates)
+//   tests/unit/chunking/chunking_test.cpp:146-228            (chunk invariants, hash == SHA-256 of slice)
+// Usage: host_mirror_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu]
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+
+#include "yams_accel/chunker.hpp"
+#include "yams_accel/hasher.hpp"
+#include "yams_accel/vector_index.hpp"
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+using namespace yams;
+
+static std::span<const std::byte> bytes(const std::string& s) {
+    return {reinterpret_cast<const std::byte*>(s.data()), s.size()};
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("usage: %s <plugin.so> [--expect-no-gpu]\n", argv[0]); return 2; }
+    const bool expectNoGpu = argc > 2 && std::strcmp(argv[2], "--expect-no-gpu") == 0;
+    auto loaded = accel::Plugin::load(argv[1], "{\"device\":0}");
+    if (expectNoGpu) {
+        CHECK(!loaded.has_value());
+        if (!loaded.has_value()) CHECK(loaded.error().code == ErrorCode::NotInitialized);
+        std::printf("%s\n", failures ? "FAILED" : "OK (refused without a GPU)");
+        return failures ? 1 : 0;
+    }
+    if (!loaded) { std::printf("load failed: %s\n", loaded.error().message.c_str()); return 1; }
+    auto plugin = loaded.value();
+    CHECK(plugin->manifestJson().find("vector_scan_v1") != std::string::npos);
+
+    // ---- crypto ----------------------------------------------------------------------------
+    auto hasherR = crypto::createAccelSHA256Hasher(plugin);
+    CHECK(hasherR.has_value());
+    auto& hasher = *hasherR.value();
+    hasher.init();
+    CHECK(hasher.finalize() == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855");
+    hasher.init(); hasher.update(bytes("abc"));
+    CHECK(hasher.finalize() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad");
+    CHECK(hasher.hash(bytes("Hello World")) == "a591a6d40bf420404a011733cfb7b190d62c65bf0bcda32b57b277d9ad9f146e");
+    {
+        std::mt19937 rng(7); std::string data(1000, '\0');
+        for (auto& c : data) c = static_cast<char>(rng());
+        hasher.init();
+        hasher.update(bytes(data).subspan(0, 100)); hasher.update(bytes(data).subspan(100, 400));
+        hasher.update(bytes(data).subspan(500, 500));
+        const auto h1 = hasher.finalize();
+        CHECK(h1 == hasher.hash(bytes(data)));
+        auto many = hasher.hashMany({bytes(data), bytes("abc")});
+        CHECK(many.size() == 2 && many[0] == h1 && many[1] == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad");
+    }
+
+    // ---- chunking --------------------------------------------------------------------------
+    for (auto kind : {chunking::AccelChunkerKind::Rabin, chunking::AccelChunkerKind::Streaming}) {
+        chunking::ChunkingConfig cfg; cfg.minChunkSize = 4096; cfg.maxChunkSize = 32768;
+        auto chunkerR = chunking::createAccelChunker(plugin, kind, cfg);
+        CHECK(chunkerR.has_value());
+        auto& chunker = *chunkerR.value();
+        CHECK(chunker.chunkData({}).empty()); // "Empty input produces no chunks"
+        std::mt19937 rng(11); std::string data((1 << 20) + 777, '\0');
+        for (auto& c : data) c = static_cast<char>(rng());
+        auto chunks = chunker.chunkData(bytes(data));
+        CHECK(!chunks.empty());
+        size_t pos = 0;
+        const size_t lo = kind == chunking::AccelChunkerKind::Rabin ? cfg.minChunkSize + 1 : cfg.minChunkSize;
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            CHECK(chunks[i].offset == pos);                       // contiguity / coverage
+            CHECK(chunks[i].size <= cfg.maxChunkSize);
+            if (i + 1 < chunks.size()) CHECK(chunks[i].size >= lo);
+            CHECK(chunks[i].data.size() == chunks[i].size);
+            pos += chunks[i].size;
+        }
+        CHECK(pos == data.size());
+        for (size_t i = 0; i < chunks.size(); i += 5)          // chunk hash == SHA-256 of the slice
+            CHECK(chunks[i].hash == hasher.hash(bytes(data).subspan(chunks[i].offset, chunks[i].size)));
+        auto lazy = chunker.chunkDataLazy(bytes(data));
+        CHECK(lazy.size() == chunks.size() && lazy.back().hash == chunks.back().hash && lazy.front().data.empty());
+    }
+
+    // ---- vector ----------------------------------------------------------------------------
+    {
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        CHECK(idxR.has_value());
+        auto& db = *idxR.value();
+        CHECK(!db.searchSimilar({1, 0, 0, 0}, 3).has_value());           // NotInitialized
+        CHECK(db.initialize().has_value());
+        for (int i = 0; i < 6; ++i) {
+            vector::VectorRecord r; r.chunk_id = "exact_" + std::to_string(i); r.document_hash = "doc_" + std::to_string(i);
+            r.embedding = {1.0f, static_cast<float>(i), 0.0f, 0.0f};
+            CHECK(db.insertVector(r).has_value());
+        }
+        vector::VectorSearchDiagnostics diag;
+        auto res = db.searchSimilar({1, 0, 0, 0}, 3, -1.0f, &diag);
+        CHECK(res.has_value());
+        if (res) {
+            CHECK(res.value().size() == 3 && res.value().front().chunk_id == "exact_0");
+            CHECK(res.value().front().relevance_score == 1.0f);
+        }
+        CHECK(diag.usedExactScan && !diag.usedAnn && diag.rowsVisited == 6 && diag.exactDistanceEvaluations == 6);
+        auto zero = db.searchSimilar({0, 0, 0, 0}, 1, -1.0f);
+        CHECK(!zero.has_value() && zero.error().code == ErrorCode::InvalidArgument);
+        auto nan = db.searchSimilar({1, std::numeric_limits<float>::quiet_NaN(), 0, 0}, 1, -1.0f);
+        CHECK(!nan.has_value() && nan.error().code == ErrorCode::InvalidArgument);
+        auto dimErr = db.searchSimilar({1, 0, 0}, 1, -1.0f);
+        CHECK(!dimErr.has_value() && dimErr.error().code == ErrorCode::InvalidArgument);
+        auto batch = db.searchSimilarBatch({{1, 0, 0, 0}, {1, 5, 0, 0}}, 2, -1.0f);
+        CHECK(batch.has_value() && batch.value().size() == 2 && batch.value()[1].front().chunk_id == "exact_5");
+        CHECK(db.deleteVector("exact_0").has_value());
+        auto after = db.searchSimilar({1, 0, 0, 0}, 1, -1.0f);
+        CHECK(after.has_value() && after.value().front().chunk_id == "exact_1");
+    }
+    for (auto order : {std::vector<std::string>{"tie_c", "tie_a", "tie_b"}, std::vector<std::string>{"tie_b", "tie_a", "tie_c"}}) {
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        for (auto& id : order) { vector::VectorRecord r; r.chunk_id = id; r.embedding = {1, 0, 0, 0}; CHECK(db.insertVector(r).has_value()); }
+        auto res = db.searchSimilar({1, 0, 0, 0}, 2, -1.0f);
+        CHECK(res.has_value() && res.value().size() == 2 && res.value()[0].chunk_id == "tie_a" && res.value()[1].chunk_id == "tie_b");
+    }
+    {   // large finite scores (+-FLT_MAX/4) stay finite
+        const float L = std::numeric_limits<float>::max() / 4.0f;
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        vector::VectorRecord r; r.chunk_id = "large_finite"; r.embedding = {L, -L, L, -L};
+        CHECK(db.insertVector(r).has_value());
+        auto res = db.searchSimilar(r.embedding, 1, -1.0f);
+        CHECK(res.has_value() && res.value().size() == 1 && std::isfinite(res.value()[0].relevance_score) && res.value()[0].relevance_score > 0.999f);
+    }
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
+    return failures ? 1 : 0;
+}

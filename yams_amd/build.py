@@ -72,3 +72,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+def build_host_tests() -> str:
+    """Compiles the C++ host-side mirror test (plain g++, dlopens the plugin at run time)."""
+    root = os.path.dirname(HERE)
+    out_dir = os.path.join(root, "tests", "cpp", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "host_mirror_test")
+    src = os.path.join(root, "tests", "cpp", "host_mirror_test.cpp")
+    deps = [src] + [os.path.join(root, "include", "yams_accel", f)
+                    for f in os.listdir(os.path.join(root, "include", "yams_accel"))]
+    deps.append(os.path.join(root, "include", "yams_mi355x_accel.h"))
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+        return exe
+    cxx = os.environ.get("CXX", "g++")
+    r = subprocess.run([cxx, "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(root, "include"),
+                        "-o", exe, src, "-ldl"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("host mirror test failed to compile:\n" + r.stdout.decode())
+    return exe

@@ -49,6 +49,11 @@ def gather_and_merge(local, k: int, merge_fn):
             gathered[name] = t.unsqueeze(0)
         else:
             out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t)
+            if dist.get_backend() == "gloo":   # CPU tests: gloo has no flat all-gather
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                out = torch.stack(parts, 0)
+            else:
+                dist.all_gather_into_tensor(out, t)
             gathered[name] = out
     return merge_fn(gathered, world)
