@@ -125,6 +125,7 @@ typedef struct yams_scan_corpus_s {
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
                                              caller applies it after merging per-shard lists)  */
 #define YAMS_SCAN_FLAG_FORCE_EXACT 2u     /* skip the MFMA filter, score every row in fp64       */
+#define YAMS_SCAN_FLAG_F32_FILTER 4u      /* use the exact-f32 MFMA filter instead of split-bf16 */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {

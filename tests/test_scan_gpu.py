@@ -10,7 +10,7 @@ import pytest
 
 import _cases
 from yams_amd import _lib
-from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,18 @@ def test_sorted_corpus_defeats_the_sample_but_not_the_result(acc, oracle):
     order = np.argsort(corpus @ q[0])
     check(acc, oracle, corpus[order], q, 100)
     check(acc, oracle, corpus[order[::-1]], q, 100)
+
+
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+def test_both_filters_agree_with_the_oracle(acc, oracle, metric):
+    """The split-bf16 filter (default) and the exact-f32 filter are interchangeable: both are only
+    filters in front of the same fp64 re-score + proof."""
+    corpus = oracle.synth_rows(16, 0, 70000, 256)
+    q = oracle.synth_rows(16, 1 << 40, 300, 256)          # > 256 queries: two bf16 query tiles
+    a = check(acc, oracle, corpus, q, 50, metric=metric, max_queries=12, expect_path=0)
+    b = check(acc, oracle, corpus, q, 50, metric=metric, flags=FLAG_F32_FILTER, max_queries=12, expect_path=0)
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
+    assert a.diag["exact_fallback_queries"] == 0 and b.diag["exact_fallback_queries"] == 0
 
 
 def test_forced_exact_equals_filter_path(acc, oracle):

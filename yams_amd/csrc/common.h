@@ -55,12 +55,14 @@ struct ScanPlan {
     uint64_t n_rows = 0;
     uint32_t dim = 0;
     uint32_t n_queries = 0;
-    uint32_t n_tiles = 0;        // ceil(n_rows / kTileRows)
+    uint32_t tile_rows = kTileRows;        // 128 (exact-f32 kernel) or 256 (split-bf16 kernel)
+    uint32_t tile_queries = kTileQueries;
+    uint32_t n_tiles = 0;        // ceil(n_rows / tile_rows)
     uint32_t sample_stride = 1;  // every sample_stride-th tile is a sample tile
     uint32_t n_sample_tiles = 0;
     uint32_t n_filter_tiles = 0;
-    uint32_t n_qtiles = 0;       // ceil(n_queries / kTileQueries)
-    uint64_t sample_rows = 0;    // n_sample_tiles * kTileRows (padded)
+    uint32_t n_qtiles = 0;       // ceil(n_queries / tile_queries)
+    uint64_t sample_rows = 0;    // n_sample_tiles * tile_rows (padded)
     uint32_t n_groups = 0;       // sample_rows / kGroupRows
     uint32_t list_cap = 0;       // per-query candidate list capacity
     uint32_t kprime = 0;         // candidates re-scored per query in stage 1

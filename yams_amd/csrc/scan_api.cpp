@@ -22,19 +22,21 @@ constexpr uint64_t kExactKeyBudget = 1ull << 31; // bytes of fp64-path keys per 
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k) {
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16) {
     ScanPlan p;
     p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
-    p.n_tiles = static_cast<uint32_t>((n_rows + kTileRows - 1) / kTileRows);
-    p.n_qtiles = (nq + kTileQueries - 1) / kTileQueries;
+    p.tile_rows = bf16 ? 256 : kTileRows;
+    p.tile_queries = bf16 ? 256 : kTileQueries;
+    p.n_tiles = static_cast<uint32_t>((n_rows + p.tile_rows - 1) / p.tile_rows);
+    p.n_qtiles = (nq + p.tile_queries - 1) / p.tile_queries;
     p.kprime = std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
     const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 16, 8192));
-    uint32_t want_tiles = static_cast<uint32_t>((s_target + kTileRows - 1) / kTileRows);
+    uint32_t want_tiles = static_cast<uint32_t>((s_target + p.tile_rows - 1) / p.tile_rows);
     if (want_tiles == 0) want_tiles = 1;
     p.sample_stride = std::max<uint32_t>(1, p.n_tiles / want_tiles);
     p.n_sample_tiles = (p.n_tiles + p.sample_stride - 1) / p.sample_stride;
     p.n_filter_tiles = p.n_tiles - p.n_sample_tiles;
-    p.sample_rows = static_cast<uint64_t>(p.n_sample_tiles) * kTileRows;
+    p.sample_rows = static_cast<uint64_t>(p.n_sample_tiles) * p.tile_rows;
     p.n_groups = static_cast<uint32_t>(p.sample_rows / kGroupRows);
     uint64_t cap = std::max<uint64_t>(4096, 8ull * p.kprime * p.sample_stride);
     if (p.n_groups < p.kprime) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
@@ -180,10 +182,24 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipStreamSynchronize(st));
         if (diag) diag->path = 1;
     } else {
-        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k);
+        // split-bf16 filter (3 MFMA passes at the bf16 rate) unless the caller asks for exact f32
+        const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 7u) == 0;
+        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
-        L.err_coef = static_cast<float>((dim + 8) * 5.9604644775390625e-8 * 1.01);
+        // relative error of the filter's dot product, in units of |x||q|:
+        //   exact f32 : fp32 FMA chain over dim terms
+        //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + 3*2^-18 split residue
+        const double u24 = 5.9604644775390625e-8;
+        const double dot_rel = bf16 ? (6.0 * dim + 64.0) * u24 + 3.0 / 262144.0 : (dim + 8.0) * u24;
+        L.err_coef = static_cast<float>(dot_rel * 1.01);
+        if (bf16) {
+            uint16_t* d_qhi; uint16_t* d_qlo;
+            YA_TRY(ws_get(ctx, "q_hi", static_cast<size_t>(nq) * dim * 2, (void**)&d_qhi));
+            YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(nq) * dim * 2, (void**)&d_qlo));
+            YA_HIP(ctx, launch_prep_split(st, d_qprep, static_cast<uint64_t>(nq) * dim, d_qhi, d_qlo));
+            L.q_hi = d_qhi; L.q_lo = d_qlo;
+        }
         float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
         YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
         YA_TRY(ws_get(ctx, "gmax", static_cast<size_t>(nq) * plan.n_groups * 4, (void**)&L.gmax));
@@ -198,14 +214,19 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         L.tau = d_tau; L.tau_out = d_tau; L.list_count = d_lcount; L.list = d_list;
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
 
-        { TimedRegion tr(ctx, "scan_sample"); YA_HIP(ctx, launch_scan_sample(st, L, metric)); tr.end(); }
+        { TimedRegion tr(ctx, "scan_sample");
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
+          tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         YA_HIP(ctx, launch_collect_sample(st, L));
-        { TimedRegion tr(ctx, "scan_filter"); YA_HIP(ctx, launch_scan_filter(st, L, metric)); tr.end(); }
+        { TimedRegion tr(ctx, "scan_filter");
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
+          tr.end(); }
 
         // stage 1: re-score the best kprime filter survivors of every query
+        // cosine: |s32 - cos| <= dot_rel + norm (dim/2 u) + rsqrt/product/unit-query rounding
         const double err_bound = (metric == YAMS_SCAN_COSINE)
-                                     ? (2.0 * dim + 32.0) * 5.9604644775390625e-8 : 0.0;
+                                     ? dot_rel + (dim + 24.0) * u24 : 0.0;
         auto rescore_stage = [&](uint32_t n_slots, const uint32_t* d_qmap, uint32_t n_cand) -> yams_status_t {
             const uint64_t* res; uint64_t res_stride;
             YA_HIP(ctx, launch_select_lists(st, d_list, d_lcount, plan.list_cap, n_slots, d_qmap,

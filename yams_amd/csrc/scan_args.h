@@ -1,0 +1,37 @@
+// scan_args.h — kernel argument block shared by the exact-f32 and the split-bf16 scan kernels.
+#pragma once
+#include "common.h"
+
+namespace yams_accel {
+
+enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
+
+struct ScanArgs {
+    const float* rows;      // [n_rows][dim]
+    const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
+    const uint16_t* q_hi;   // [n_queries][dim] bf16 head of qprep        (split-bf16 kernel)
+    const uint16_t* q_lo;   // [n_queries][dim] bf16 of (qprep - head)    (split-bf16 kernel)
+    uint64_t n_rows;
+    uint32_t dim;
+    uint32_t n_queries;
+    uint32_t n_sel_tiles;   // tiles this launch covers
+    uint32_t stride;        // sample stride (tile % stride == 0 is a sample tile)
+    uint32_t n_qtiles;
+    // sample mode
+    float* dense;           // [n_queries][sample_rows]
+    uint32_t* gmax;         // [n_queries][n_groups] order-preserving keys
+    uint64_t sample_rows;
+    uint32_t n_groups;
+    // filter mode
+    const float* tau;       // [n_queries]
+    uint32_t* list_count;   // [n_queries]
+    uint64_t* list;         // [n_queries][list_cap]
+    uint32_t list_cap;
+    // L2
+    const float* qnorm_up;  // [n_queries] fp32 upper bound of ||q||
+    float err_coef;         // (dim + 8) * 2^-24 * 1.01
+};
+
+__device__ __forceinline__ bool norm_in_range(float nsq) { return nsq > 1e-30f && nsq < 1e30f; }
+
+} // namespace yams_accel

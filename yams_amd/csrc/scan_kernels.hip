@@ -13,6 +13,7 @@
 // have entered the result; queries that fail it are widened and finally scored exhaustively in
 // fp64 — on the device, never on the CPU.
 #include "common.h"
+#include "scan_args.h"
 
 namespace yams_accel {
 
@@ -22,33 +23,6 @@ constexpr int LDP = kSlabK + 4;                                  // padded LDS r
 constexpr int STAGE_FLOATS = (kTileRows + kTileQueries) * LDP;   // one LDS stage
 constexpr int SCAN_THREADS = 256;
 
-enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
-
-struct ScanArgs {
-    const float* rows;      // [n_rows][dim]
-    const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
-    uint64_t n_rows;
-    uint32_t dim;
-    uint32_t n_queries;
-    uint32_t n_sel_tiles;   // tiles this launch covers
-    uint32_t stride;        // sample stride (tile % stride == 0 is a sample tile)
-    uint32_t n_qtiles;
-    // sample mode
-    float* dense;           // [n_queries][sample_rows]
-    uint32_t* gmax;         // [n_queries][n_groups] order-preserving keys
-    uint64_t sample_rows;
-    uint32_t n_groups;
-    // filter mode
-    const float* tau;       // [n_queries]
-    uint32_t* list_count;   // [n_queries]
-    uint64_t* list;         // [n_queries][list_cap]
-    uint32_t list_cap;
-    // L2
-    const float* qnorm_up;  // [n_queries] fp32 upper bound of ||q||
-    float err_coef;         // (dim + 8) * 2^-24 * 1.01
-};
-
-__device__ __forceinline__ bool norm_in_range(float nsq) { return nsq > 1e-30f && nsq < 1e30f; }
 
 // One workgroup = 128 corpus rows x 128 queries, 4 waves as 2 (rows) x 2 (queries), each wave a
 // 64 x 64 block = 2 x 2 MFMA 32x32 tiles.  A operand = corpus rows (accumulator rows, across
@@ -372,7 +346,8 @@ __global__ void tau_from_keys_kernel(const uint32_t* sorted, uint64_t stride, ui
 
 // Sample rows that reach the threshold join the candidate lists.
 __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
-                                                             uint64_t sample_rows, uint32_t stride,
+                                                             uint64_t sample_rows, uint32_t tile_rows,
+                                                             uint32_t stride,
                                                              uint64_t n_rows, const float* tau,
                                                              uint32_t* list_count, uint64_t* list,
                                                              uint32_t list_cap) {
@@ -383,7 +358,7 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
          s < sample_rows; s += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const float v = src[s];
         if (!(v < t)) {
-            const uint64_t row = (s / kTileRows) * stride * kTileRows + (s % kTileRows);
+            const uint64_t row = (s / tile_rows) * stride * tile_rows + (s % tile_rows);
             if (row < n_rows) {
                 const uint32_t pos = atomicAdd(&list_count[q], 1u);
                 if (pos < list_cap)
@@ -863,9 +838,9 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
     return hipSuccess;
 }
 
-static ScanArgs make_args(const ScanLaunch& L) {
+ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
-    a.rows = L.rows; a.qprep = L.qprep; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.rows = L.rows; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
@@ -874,7 +849,7 @@ static ScanArgs make_args(const ScanLaunch& L) {
 }
 
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric) {
-    ScanArgs a = make_args(L);
+    ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = L.plan.n_sample_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
@@ -890,7 +865,7 @@ hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric) {
 }
 
 hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric) {
-    ScanArgs a = make_args(L);
+    ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
@@ -966,7 +941,7 @@ hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L) {
     if (gx > 512) gx = 512;
     if (gx == 0) gx = 1;
     hipLaunchKernelGGL(collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.dense,
-                       L.plan.sample_rows, L.plan.sample_stride, L.plan.n_rows, L.tau,
+                       L.plan.sample_rows, L.plan.tile_rows, L.plan.sample_stride, L.plan.n_rows, L.tau,
                        L.list_count, L.list, L.plan.list_cap);
     LAUNCH_CHECK();
     return hipSuccess;
