@@ -34,6 +34,8 @@ from yams_amd.accel import Accel, cdc_config  # noqa: E402
 from yams_amd._lib import SCAN_COSINE  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak (NOT the 2:1-sparse 5 PF)
+BF16_PASSES = 3                # hi*hi + hi*lo + lo*hi per algorithmic multiply-add
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -50,6 +52,7 @@ def parse():
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
     return ap.parse_args()
 
 
@@ -144,9 +147,11 @@ def main():
                               c_out.data_ptr(), None)
         return s_out, r_out, c_out
 
+    scan_flags = 4 if a.f32_filter else 0   # YAMS_SCAN_FLAG_F32_FILTER
+
     def step():
         diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s_loc.data_ptr(),
-                                    r_loc.data_ptr(), c_loc.data_ptr(), want_diag=True)
+                                    r_loc.data_ptr(), c_loc.data_ptr(), flags=scan_flags, want_diag=True)
         if world > 1:
             ydist.gather_and_merge({"scores": s_loc, "rows": r_loc, "counts": c_loc}, k, merge_fn)
         return diag
@@ -177,27 +182,37 @@ def main():
 
     if rank != 0:
         return
-    # ---- roofline of the dominant kernel (scan_tiles_kernel<FILTER>): exact-f32 MFMA -------------
-    n_tiles = (n + 127) // 128
+    # ---- roofline of the dominant kernel (the FILTER pass of the scan) -----------------------------
+    bf16 = (not a.f32_filter) and d % 16 == 0
+    tr = 256 if bf16 else 128
+    n_tiles = (n + tr - 1) // tr
     s_target = min(n, max(n // 16, 8192))
-    stride = max(1, n_tiles // ((s_target + 127) // 128))
+    stride = max(1, n_tiles // ((s_target + tr - 1) // tr))
     n_sample = (n_tiles + stride - 1) // stride
-    filt_rows = min(n, (n_tiles - n_sample) * 128)
-    flops = 2.0 * nq * d * filt_rows + 1.0 * filt_rows * d * ((nq + 127) // 128)  # contraction + fused row norms
+    filt_rows = min(n, (n_tiles - n_sample) * tr)
+    flops = 2.0 * nq * d * filt_rows            # ALGORITHMIC flops of the contraction per launch
     ach_tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms else None
+    if bf16:
+        kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"
+        peak = PEAK_BF16_MFMA_TFLOPS / BF16_PASSES  # each algorithmic multiply-add costs 3 bf16 MFMA passes
+    else:
+        kname = "scan_tiles_kernel<FILTER,COSINE> (v_mfma_f32_32x32x2_f32)"
+        peak = PEAK_F32_MFMA_TFLOPS
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "scan_filter_pmc.json")
     if os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
-            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq:
+            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq \
+                    and j.get("bf16", False) == bf16:
                 traffic = j.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": "scan_tiles_kernel<FILTER,COSINE> (v_mfma_f32_32x32x2_f32)",
-                "achieved": ach_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": (ach_tf / PEAK_F32_MFMA_TFLOPS) if ach_tf else None, "traffic": traffic,
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": (ach_tf / peak) if ach_tf else None, "traffic": traffic,
                 "launch_ms": filt_ms, "launches": filt_n, "flops_per_launch": flops,
+                "executed_mfma_tflops": (ach_tf * BF16_PASSES if bf16 else ach_tf) if ach_tf else None,
+                "mfma_peak_for_executed": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS,
                 "sample_pass_ms": samp_ms,
                 "hbm_view": {"algorithmic_bytes_per_step": n * d * 4 + nq * d * 4 + nq * k * 12,
                              "achieved_GBps": (n * d * 4 + nq * d * 4 + nq * k * 12) / (ms_per_step * 1e-3) / 1e9,
@@ -205,7 +220,9 @@ def main():
     out = {"metric": "k-NN QPS + recall@k, 100M x 768 fp32 cosine top-100; ingest GB/s SHA-256+CDC",
            "value": qps, "unit": "QPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32 (MFMA filter) + f64 (re-score)", "data": "synthetic",
+           "vs_baseline": None,
+           "dtype": ("bf16x3 split-f32 (MFMA filter) + f64 (exact re-score)" if bf16 else "f32 (MFMA filter) + f64 (exact re-score)"),
+           "data": "synthetic",
            "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: "
                                   f"100Mx768 over 8 GPUs), query batch {nq}",
                       "rows_per_gpu": n, "corpus_rows": total_rows, "dim": d, "k": k, "query_batch": nq,

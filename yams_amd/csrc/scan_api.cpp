@@ -7,6 +7,7 @@
 //   -> per-query candidate select -> fp64 re-score + verification (-> widen -> exhaustive fp64).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -183,22 +184,27 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         if (diag) diag->path = 1;
     } else {
         // split-bf16 filter (3 MFMA passes at the bf16 rate) unless the caller asks for exact f32
-        const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 7u) == 0;
+        const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 15u) == 0;
+        // measurement knob (never set by the product path)
+        const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL");
+        const int bf16_version = kv ? std::atoi(kv) : 2; // 12 = staging-only ablation (perf measurement only)
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
-        //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + 3*2^-18 split residue
+        //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + the split residue:
+        //               corpus head truncated (tail error 2^-16), query split RNE (2^-18), lo*lo dropped (2^-16)
         const double u24 = 5.9604644775390625e-8;
-        const double dot_rel = bf16 ? (6.0 * dim + 64.0) * u24 + 3.0 / 262144.0 : (dim + 8.0) * u24;
+        const double dot_rel = bf16 ? (6.0 * dim + 64.0) * u24 + 3.0 / 65536.0 : (dim + 8.0) * u24;
         L.err_coef = static_cast<float>(dot_rel * 1.01);
         if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
-            YA_TRY(ws_get(ctx, "q_hi", static_cast<size_t>(nq) * dim * 2, (void**)&d_qhi));
-            YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(nq) * dim * 2, (void**)&d_qlo));
-            YA_HIP(ctx, launch_prep_split(st, d_qprep, static_cast<uint64_t>(nq) * dim, d_qhi, d_qlo));
-            L.q_hi = d_qhi; L.q_lo = d_qlo;
+            const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
+            YA_TRY(ws_get(ctx, "q_hi", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qhi));
+            YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qlo));
+            YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, d_qhi, d_qlo));
+            L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
         float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
         YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
@@ -215,12 +221,12 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
 
         { TimedRegion tr(ctx, "scan_sample");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         YA_HIP(ctx, launch_collect_sample(st, L));
         { TimedRegion tr(ctx, "scan_filter");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
 
         // stage 1: re-score the best kprime filter survivors of every query

@@ -9,8 +9,9 @@ enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
 struct ScanArgs {
     const float* rows;      // [n_rows][dim]
     const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
-    const uint16_t* q_hi;   // [n_queries][dim] bf16 head of qprep        (split-bf16 kernel)
-    const uint16_t* q_lo;   // [n_queries][dim] bf16 of (qprep - head)    (split-bf16 kernel)
+    const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
+    const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)
+    uint32_t q_pad;         // padded query count of the k-slab-major planes (n_qtiles * 256)
     uint64_t n_rows;
     uint32_t dim;
     uint32_t n_queries;

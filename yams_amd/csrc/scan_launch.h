@@ -10,6 +10,7 @@ struct ScanLaunch {
     const float* qprep = nullptr;
     const uint16_t* q_hi = nullptr;
     const uint16_t* q_lo = nullptr;
+    uint32_t q_pad = 0;
     float* dense = nullptr;
     uint32_t* gmax = nullptr;
     const float* tau = nullptr;   // read by filter / collect
@@ -44,9 +45,9 @@ constexpr uint32_t kRescoreMax = 2047; // + 1 boundary key == kSelectCap / 2 (se
 hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
                                uint32_t* qflags);
-hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint64_t n_elems, uint16_t* q_hi,
-                             uint16_t* q_lo);
-hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode);
+hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
+                             uint16_t* q_hi, uint16_t* q_lo);
+hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int version);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32);
