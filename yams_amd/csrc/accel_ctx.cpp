@@ -69,15 +69,16 @@ static hipEvent_t get_event(yams_accel_ctx* ctx) {
     return e;
 }
 
-TimedRegion::TimedRegion(yams_accel_ctx* c, const char* n) : ctx(c), name(n) {
+TimedRegion::TimedRegion(yams_accel_ctx* c, const char* n, hipStream_t on) : ctx(c), name(n) {
+    stream = on ? on : ctx->stream;
     if (!ctx->timing) return;
     a = get_event(ctx);
     b = get_event(ctx);
-    if (a) (void)hipEventRecord(a, ctx->stream);
+    if (a) (void)hipEventRecord(a, stream);
 }
 void TimedRegion::end() {
     if (!ctx->timing || !a || !b) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, stream);
     ctx->spans[name].push_back({a, b});
 }
 
@@ -116,6 +117,16 @@ yams_status_t yams_accel_ctx_create(int device, void* hip_stream, yams_accel_ctx
         }
         ctx->owns_stream = true;
     }
+    // side stream for work that must not queue behind the main stream (long SHA-256 chains)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        yams_accel_ctx_destroy(ctx);
+        return YAMS_ERR_INTERNAL;
+    }
     *out_ctx = ctx;
     return YAMS_OK;
 }
@@ -124,6 +135,9 @@ void yams_accel_ctx_destroy(yams_accel_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -13,6 +13,8 @@ struct yams_accel_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    hipStream_t aux_stream = nullptr;   // high-priority side stream (whole-blob digest chains)
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     std::string last_error;
 
     // growable named device buffers (workspace); never shrinks
@@ -43,7 +45,8 @@ yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
 
 struct TimedRegion { // RAII-less helper: begin/end record events when timing is enabled
     yams_accel_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    TimedRegion(yams_accel_ctx* c, const char* n);
+    TimedRegion(yams_accel_ctx* c, const char* n, hipStream_t on = nullptr);
+    hipStream_t stream = nullptr;
     void end();
 };
 

@@ -3,6 +3,7 @@
 // SHA-256, i.e. the hash + chunk_file phases of ContentStore::store
 // (src/api/content_store_impl.cpp:199-231 in the reference).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -83,11 +84,28 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     YA_TRY(ws_get(ctx, "ing_blob_first", (static_cast<size_t>(n_blobs) + 1) * 8, (void**)&d_blob_first));
     YA_TRY(ws_get(ctx, "ing_blob_count", (static_cast<size_t>(n_blobs) + 1) * 8, (void**)&d_blob_count));
 
+    // Whole-blob digests are long sequential chains (65 536 blocks for 4 MiB) that bound the call:
+    // they start NOW on the high-priority side stream and run concurrently with boundary detection
+    // and chunk hashing (which alone reach their VALU / HBM rooflines in a fraction of the time).
+    const bool fork_blobs = (flags & YAMS_INGEST_BLOB_DIGESTS) && n_blobs > 0;
+    uint8_t* d_blob_digests = nullptr;
+    if (fork_blobs) {
+        unsigned long long* d_head2;
+        YA_TRY(ws_get(ctx, "ing_queue_blobs", 64, (void**)&d_head2));
+        YA_TRY(ws_get(ctx, "ing_blob_digests", static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
+        YA_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
+        YA_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+        TimedRegion tr(ctx, "sha256_blobs", ctx->aux_stream);
+        YA_HIP(ctx, launch_sha256(ctx->aux_stream, data, d_off, d_len, n_blobs, n_blobs, d_blob_digests,
+                                  d_head2, nullptr, nullptr, 0, 4096, 1));
+        tr.end();
+        YA_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+    }
+
     uint64_t n_chunks = 0;
     uint64_t* d_msg_off = nullptr; uint64_t* d_msg_len = nullptr;
     uint64_t* d_chunk_off = nullptr; uint64_t* d_chunk_size = nullptr; uint32_t* d_chunk_blob = nullptr;
     const bool want_chunk_dg = do_chunks && (flags & YAMS_INGEST_CHUNK_DIGESTS);
-    const bool want_blob_dg = (flags & YAMS_INGEST_BLOB_DIGESTS) != 0;
     const uint64_t msg_cap = static_cast<uint64_t>(n_blobs) + (do_chunks ? slots : 0);
     YA_TRY(ws_get(ctx, "ing_msg_off", msg_cap * 8, (void**)&d_msg_off));
     YA_TRY(ws_get(ctx, "ing_msg_len", msg_cap * 8, (void**)&d_msg_len));
@@ -127,26 +145,23 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     }
 
     uint8_t* d_digests = nullptr;
-    if (want_blob_dg || want_chunk_dg) {
+    if (want_chunk_dg && n_chunks) {
         unsigned long long* d_head;
         YA_TRY(ws_get(ctx, "ing_queue", 64, (void**)&d_head));
-        YA_TRY(ws_get(ctx, "ing_digests", (static_cast<size_t>(n_blobs) + n_chunks) * 32 + 32, (void**)&d_digests));
-        const uint64_t first = want_blob_dg ? 0 : n_blobs;
-        const uint64_t last = want_chunk_dg ? n_blobs + n_chunks : n_blobs;
-        if (last > first) {
-            TimedRegion tr(ctx, "sha256");
-            YA_HIP(ctx, launch_sha256(st, data, d_msg_off + first, d_msg_len + first, last - first,
-                                      d_digests + first * 32, d_head, nullptr, nullptr, 0, 4096));
-            tr.end();
-        }
+        YA_TRY(ws_get(ctx, "ing_digests", static_cast<size_t>(n_chunks) * 32 + 32, (void**)&d_digests));
+        TimedRegion tr(ctx, "sha256");
+        YA_HIP(ctx, launch_sha256(st, data, d_msg_off + n_blobs, d_msg_len + n_blobs, 0, n_chunks,
+                                  d_digests, d_head, nullptr, nullptr, 0, 4096, 1));
+        tr.end();
     }
+    if (fork_blobs) YA_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0)); // join the side stream
     out->n_chunks = n_chunks;
     out->chunk_offset = d_chunk_off;
     out->chunk_size = d_chunk_size;
     out->chunk_blob = d_chunk_blob;
     out->blob_first = do_chunks ? d_blob_first : nullptr;
-    out->chunk_digest = want_chunk_dg ? d_digests + static_cast<size_t>(n_blobs) * 32 : nullptr;
-    out->blob_digest = want_blob_dg ? d_digests : nullptr;
+    out->chunk_digest = want_chunk_dg ? d_digests : nullptr;
+    out->blob_digest = fork_blobs ? d_blob_digests : nullptr;
     ctx->ingest = *out;
     (void)total_bytes;
     return YAMS_OK;
@@ -200,8 +215,8 @@ yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const uint8_t* data,
     unsigned long long* d_head;
     YA_TRY(ws_get(ctx, "ing_queue", 64, (void**)&d_head));
     TimedRegion tr(ctx, "sha256");
-    YA_HIP(ctx, launch_sha256(ctx->stream, data, offsets, lengths, n_msgs, digests, d_head, nullptr,
-                              nullptr, 0, 4096));
+    YA_HIP(ctx, launch_sha256(ctx->stream, data, offsets, lengths, 0, n_msgs, digests, d_head, nullptr,
+                              nullptr, 0, 4096, 2));
     tr.end();
     return YAMS_OK;
 }

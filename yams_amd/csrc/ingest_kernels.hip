@@ -284,126 +284,240 @@ __device__ __forceinline__ void sha256_init(uint32_t st[8]) {
     st[4] = 0x510e527fu; st[5] = 0x9b05688cu; st[6] = 0x1f83d9abu; st[7] = 0x5be0cd19u;
 }
 
-// Raw fetch of the 17 aligned dwords that cover the 64 bytes at p (any alignment).  `limit` is one
-// past the last byte that may be touched: dwords that start at or beyond it read as zero.
-__device__ __forceinline__ void fetch_block(const uint8_t* p, const uint8_t* limit, uint32_t d[17]) {
-    const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~static_cast<uintptr_t>(3));
-#pragma unroll
-    for (int i = 0; i < 17; ++i)
-        d[i] = (reinterpret_cast<const uint8_t*>(q + i) < limit) ? q[i] : 0u;
+// Two-message round function: the two states are independent dependency chains, so the scheduler
+// interleaves them and a wave that holds long messages (whole-blob digests: 65 536 sequential
+// blocks for 4 MiB) is no longer bound by the VALU result latency of a single chain.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); // one v_bitop3_b32 instead of two v_xor_b32
 }
-// Realign + byte-swap in one v_perm_b32 per word: big-endian word i = bytes [sh+4i, sh+4i+4).
-__device__ __forceinline__ void words_be(const uint32_t d[17], uint32_t sh, uint32_t w[16]) {
+template <int NS>
+__device__ __forceinline__ void sha256_compress_n(uint32_t st[NS][8], uint32_t w[NS][16]) {
+    uint32_t a[NS], b[NS], c[NS], d[NS], e[NS], f[NS], g[NS], h[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        a[k] = st[k][0]; b[k] = st[k][1]; c[k] = st[k][2]; d[k] = st[k][3];
+        e[k] = st[k][4]; f[k] = st[k][5]; g[k] = st[k][6]; h[k] = st[k][7];
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (i >= 16) {
+                const uint32_t w15 = w[k][(i - 15) & 15], w2 = w[k][(i - 2) & 15];
+                const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+                const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+                w[k][i & 15] = w[k][i & 15] + s0 + w[k][(i - 7) & 15] + s1;
+            }
+            const uint32_t S1 = xor3(rotr(e[k], 6), rotr(e[k], 11), rotr(e[k], 25));
+            const uint32_t ch = __builtin_amdgcn_bitop3_b32(e[k], f[k], g[k], 0xCA);  // e ? f : g
+            const uint32_t t1 = h[k] + S1 + ch + kSha256K[i] + w[k][i & 15];
+            const uint32_t S0 = xor3(rotr(a[k], 2), rotr(a[k], 13), rotr(a[k], 22));
+            const uint32_t mj = __builtin_amdgcn_bitop3_b32(a[k], b[k], c[k], 0xE8);  // majority
+            const uint32_t t2 = S0 + mj;
+            h[k] = g[k]; g[k] = f[k]; f[k] = e[k]; e[k] = d[k] + t1;
+            d[k] = c[k]; c[k] = b[k]; b[k] = a[k]; a[k] = t1 + t2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        st[k][0] += a[k]; st[k][1] += b[k]; st[k][2] += c[k]; st[k][3] += d[k];
+        st[k][4] += e[k]; st[k][5] += f[k]; st[k][6] += g[k]; st[k][7] += h[k];
+    }
+}
+
+// Fetch of the 17 dwords that cover the 64 bytes at p (any alignment) as four 16-byte loads + one
+// dword from the 4-byte-aligned address below p (global_load_dwordx4 only needs dword alignment):
+// 5 requests per block instead of 17 (the lanes of a wave walk different messages, so every
+// request is its own cache-line access).  Nothing beyond the dword that holds the last message
+// byte is ever touched: a 16-byte piece that would cross it falls back to guarded dword loads
+// (only in the last block or two of a message).
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+struct ShaWindow { u32x4_a4 v[4]; uint32_t tail; };
+__device__ __forceinline__ void fetch_window(const uint8_t* p, const uint8_t* limit, ShaWindow& win) {
+    const uint8_t* q = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~static_cast<uintptr_t>(3));
+    const uint8_t* limit4 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(limit) + 3) & ~static_cast<uintptr_t>(3));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint8_t* a = q + 16 * i;
+        if (a + 16 <= limit4) {
+            win.v[i] = *reinterpret_cast<const u32x4_a4*>(a);
+        } else {
+            u32x4_a4 t = {0, 0, 0, 0};
+            if (a < limit) t[0] = *reinterpret_cast<const uint32_t*>(a);
+            if (a + 4 < limit) t[1] = *reinterpret_cast<const uint32_t*>(a + 4);
+            if (a + 8 < limit) t[2] = *reinterpret_cast<const uint32_t*>(a + 8);
+            if (a + 12 < limit) t[3] = *reinterpret_cast<const uint32_t*>(a + 12);
+            win.v[i] = t;
+        }
+    }
+    win.tail = (q + 64 < limit) ? *reinterpret_cast<const uint32_t*>(q + 64) : 0u;
+}
+// Realign + byte-swap with one v_perm_b32 per word: big-endian word i = bytes [sh+4i, sh+4i+4).
+__device__ __forceinline__ void window_words_be(const ShaWindow& win, const uint8_t* p, uint32_t w[16]) {
+    const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p) & 3u);
     const uint32_t sel = 0x00010203u + sh * 0x01010101u;
+    const uint32_t d[17] = {win.v[0][0], win.v[0][1], win.v[0][2], win.v[0][3], win.v[1][0], win.v[1][1],
+                            win.v[1][2], win.v[1][3], win.v[2][0], win.v[2][1], win.v[2][2], win.v[2][3],
+                            win.v[3][0], win.v[3][1], win.v[3][2], win.v[3][3], win.tail};
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_perm(d[i + 1], d[i], sel);
 }
 
-// Lane state machine.  phase: 0 = data blocks, 1 = length-only block pending, 2 = needs a new
-// message, 3 = queue drained.  `nxt` always holds the raw dwords of the block at `p` (fetched one
-// iteration ahead so that the HBM latency of block i+1 hides under the 64 rounds of block i —
-// a whole-blob digest is one long dependent chain on a single lane and has no other cover).
+// Lane state machine, NS message slots per lane.  phase: 0 = data blocks, 1 = length-only block
+// pending, 2 = needs a new message, 3 = queue drained.  `win` always holds the window of the block
+// at `p` (fetched one iteration ahead so the memory latency hides under the 64 rounds).
+// Messages [0, n_long) are "long" (whole blobs), the rest "short" (chunks): slot 0 of a lane
+// prefers long messages, the other slots short ones, so long chains spread over as many lanes as
+// possible and every lane that holds one also has independent work to overlap with it.
+template <int NS>
 __global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
                                                            const uint64_t* offs,
-                                                           const uint64_t* lens, uint64_t n_msgs,
-                                                           uint8_t* digests,
-                                                           unsigned long long* queue_head,
+                                                           const uint64_t* lens, uint64_t n_long,
+                                                           uint64_t n_msgs, uint8_t* digests,
+                                                           unsigned long long* heads /*[2]*/,
                                                            const uint32_t* init_state /*nullable*/,
                                                            uint32_t* out_state /*nullable*/,
                                                            int raw_blocks_only) {
-    const uint8_t* p = nullptr;   // next block to consume
-    const uint8_t* end = nullptr; // one past the message
-    uint64_t total = 0, index = 0;
-    uint32_t st[8];
-    uint32_t nxt[17];
-    int phase = 2;
+    const uint8_t* p[NS];
+    const uint8_t* end[NS];
+    uint64_t total[NS], index[NS];
+    uint32_t st[NS][8];
+    ShaWindow win[NS];
+    int phase[NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st[i] = 0;
+    for (int k = 0; k < NS; ++k) {
+        p[k] = nullptr; end[k] = nullptr; total[k] = 0; index[k] = 0; phase[k] = 2;
 #pragma unroll
-    for (int i = 0; i < 17; ++i) nxt[i] = 0;
+        for (int i = 0; i < 8; ++i) st[k][i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[k].v[i] = u32x4_a4{0, 0, 0, 0};
+        win[k].tail = 0;
+    }
+    const uint64_t n_short = n_msgs - n_long;
     for (;;) {
-        if (phase == 2) {
-            const unsigned long long idx = atomicAdd(queue_head, 1ull);
-            if (idx < n_msgs) {
-                index = idx;
-                p = data + offs[idx];
-                total = lens[idx];
-                end = p + total;
-                if (init_state) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) st[i] = init_state[idx * 8 + i];
-                } else sha256_init(st);
-                fetch_block(p, end, nxt); // the only un-hidden fetch of this message
-                phase = 0;
-            } else {
-                phase = 3;
-            }
-        }
-        if (__all(phase == 3)) break;
-        uint32_t w[16];
-        bool final_block = false, run = false;
-        if (phase == 0) {
-            const uint64_t rem = static_cast<uint64_t>(end - p);
-            const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p) & 3u);
-            if (raw_blocks_only && rem < 64) {
-                final_block = true; // no data at all (total == 0): state passes through
-            } else {
-                words_be(nxt, sh, w);
-                run = true;
-                if (rem >= 64) {
-                    p += 64;
-                    if (raw_blocks_only && p == end) final_block = true;
-                    if (p < end) fetch_block(p, end, nxt); // prefetch; consumed next iteration
-                    else {
+        for (int k = 0; k < NS; ++k) {
+            if (phase[k] == 2) {
+                // two queues: [0, n_long) and [n_long, n_msgs); preferred one first
+                unsigned long long idx = ~0ull;
+                const bool prefer_long = (k == 0);
+                if (prefer_long && n_long) {
+                    const unsigned long long i = atomicAdd(&heads[0], 1ull);
+                    if (i < n_long) idx = i;
+                }
+                if (idx == ~0ull && n_short) {
+                    const unsigned long long i = atomicAdd(&heads[1], 1ull);
+                    if (i < n_short) idx = n_long + i;
+                }
+                if (idx == ~0ull && !prefer_long && n_long) {
+                    const unsigned long long i = atomicAdd(&heads[0], 1ull);
+                    if (i < n_long) idx = i;
+                }
+                if (idx != ~0ull) {
+                    // a whole-blob digest is one long dependent chain: let the waves that carry
+                    // one win issue arbitration against the short-message waves on their SIMD
+                    if (__any(idx < n_long)) __builtin_amdgcn_s_setprio(3);
+                    index[k] = idx;
+                    p[k] = data + offs[idx];
+                    total[k] = lens[idx];
+                    end[k] = p[k] + total[k];
+                    if (init_state) {
 #pragma unroll
-                        for (int i = 0; i < 17; ++i) nxt[i] = 0;
-                    }
+                        for (int i = 0; i < 8; ++i) st[k][i] = init_state[idx * 8 + i];
+                    } else sha256_init(st[k]);
+                    fetch_window(p[k], end[k], win[k]); // the only un-hidden fetch of this message
+                    phase[k] = 0;
                 } else {
-                    const uint32_t r = static_cast<uint32_t>(rem);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const uint32_t lo = 4u * j;
-                        if (r <= lo) w[j] = 0;
-                        else if (r < lo + 4) w[j] &= 0xffffffffu << (8u * (lo + 4 - r));
-                        if ((r >> 2) == static_cast<uint32_t>(j)) w[j] |= 0x80u << (24 - 8 * (r & 3));
-                    }
-                    p = end;
-                    if (r < 56) {
-                        const uint64_t bitlen = total * 8ull;
-                        w[14] = static_cast<uint32_t>(bitlen >> 32);
-                        w[15] = static_cast<uint32_t>(bitlen);
-                        final_block = true;
-                    } else {
-                        phase = 1;
-                    }
+                    phase[k] = 3;
                 }
             }
-        } else if (phase == 1) {
-#pragma unroll
-            for (int i = 0; i < 14; ++i) w[i] = 0;
-            const uint64_t bitlen = total * 8ull;
-            w[14] = static_cast<uint32_t>(bitlen >> 32);
-            w[15] = static_cast<uint32_t>(bitlen);
-            final_block = true;
-            run = true;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) w[i] = 0;
         }
-        if (run) sha256_compress(st, w);
-        if (final_block) {
-            if (out_state) {
+        bool drained = true;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) out_state[index * 8 + i] = st[i];
-            }
-            if (digests) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(digests + index * 32);
+        for (int k = 0; k < NS; ++k) drained &= (phase[k] == 3);
+        if (__all(drained)) break;
+
+        uint32_t w[NS][16];
+        bool final_block[NS];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    dst[i] = __builtin_amdgcn_perm(0u, st[i], 0x00010203u); // big-endian bytes
+        for (int k = 0; k < NS; ++k) {
+            final_block[k] = false;
+            if (phase[k] == 0) {
+                const uint64_t rem = static_cast<uint64_t>(end[k] - p[k]);
+                if (raw_blocks_only && rem < 64) {
+                    final_block[k] = true; // no data at all (total == 0): state passes through
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[k][i] = 0;
+                    phase[k] = 4;          // skip the compression below for this slot
+                } else {
+                    window_words_be(win[k], p[k], w[k]);
+                    if (rem >= 64) {
+                        p[k] += 64;
+                        if (raw_blocks_only && p[k] == end[k]) final_block[k] = true;
+                        if (p[k] < end[k]) fetch_window(p[k], end[k], win[k]); // prefetch for the next iteration
+                    } else {
+                        const uint32_t r = static_cast<uint32_t>(rem);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const uint32_t lo = 4u * j;
+                            if (r <= lo) w[k][j] = 0;
+                            else if (r < lo + 4) w[k][j] &= 0xffffffffu << (8u * (lo + 4 - r));
+                            if ((r >> 2) == static_cast<uint32_t>(j)) w[k][j] |= 0x80u << (24 - 8 * (r & 3));
+                        }
+                        p[k] = end[k];
+                        if (r < 56) {
+                            const uint64_t bitlen = total[k] * 8ull;
+                            w[k][14] = static_cast<uint32_t>(bitlen >> 32);
+                            w[k][15] = static_cast<uint32_t>(bitlen);
+                            final_block[k] = true;
+                        } else {
+                            phase[k] = 1;
+                            // (the length-only block is built on the next iteration)
+                            final_block[k] = false;
+                            // mark: this iteration still compresses the padded data block
+                        }
+                    }
+                }
+            } else if (phase[k] == 1) {
+#pragma unroll
+                for (int i = 0; i < 14; ++i) w[k][i] = 0;
+                const uint64_t bitlen = total[k] * 8ull;
+                w[k][14] = static_cast<uint32_t>(bitlen >> 32);
+                w[k][15] = static_cast<uint32_t>(bitlen);
+                final_block[k] = true;
+                phase[k] = 5; // length block in flight
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[k][i] = 0;
             }
-            phase = 2;
+        }
+        // Slots that are idle (phase 3) or pass-through (phase 4) compress zeros into a state that
+        // is re-initialised before its next use; saving the branch keeps the two chains interleaved.
+        uint32_t keep[NS][8];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) keep[k][i] = st[k][i];
+        sha256_compress_n<NS>(st, w);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (phase[k] == 4) { // raw pass-through: restore the untouched state
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[k][i] = keep[k][i];
+            }
+            if (final_block[k]) {
+                if (out_state) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) out_state[index[k] * 8 + i] = st[k][i];
+                }
+                if (digests) {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(digests + index[k] * 32);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        dst[i] = __builtin_amdgcn_perm(0u, st[k][i], 0x00010203u); // big-endian bytes
+                }
+                phase[k] = 2;
+            }
         }
     }
 }
@@ -454,18 +568,24 @@ hipError_t launch_chunk_compact(hipStream_t st, const uint64_t* slot_prefix,
 }
 
 hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* offs,
-                         const uint64_t* lens, uint64_t n_msgs, uint8_t* digests,
-                         unsigned long long* queue_head, const uint32_t* init_state,
-                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks) {
+                         const uint64_t* lens, uint64_t n_long, uint64_t n_msgs, uint8_t* digests,
+                         unsigned long long* queue_heads, const uint32_t* init_state,
+                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks, int slots) {
     if (n_msgs == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(queue_head, 0, sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(queue_heads, 0, 2 * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    uint64_t want = (n_msgs + 255) / 256;
+    const uint64_t per_block = 256ull * static_cast<uint64_t>(slots);
+    uint64_t want = (n_msgs + per_block - 1) / per_block;
     if (want > max_blocks) want = max_blocks;
     if (want == 0) want = 1;
-    hipLaunchKernelGGL(sha256_batch_kernel, dim3(static_cast<uint32_t>(want)), dim3(256), 0, st,
-                       data, offs, lens, n_msgs, digests, queue_head, init_state, out_state,
-                       raw_blocks_only);
+    if (slots == 2)
+        hipLaunchKernelGGL(sha256_batch_kernel<2>, dim3(static_cast<uint32_t>(want)), dim3(256), 0, st,
+                           data, offs, lens, n_long, n_msgs, digests, queue_heads, init_state, out_state,
+                           raw_blocks_only);
+    else
+        hipLaunchKernelGGL(sha256_batch_kernel<1>, dim3(static_cast<uint32_t>(want)), dim3(256), 0, st,
+                           data, offs, lens, n_long, n_msgs, digests, queue_heads, init_state, out_state,
+                           raw_blocks_only);
     LAUNCH_CHECK();
     return hipSuccess;
 }

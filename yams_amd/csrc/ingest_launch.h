@@ -29,9 +29,10 @@ hipError_t launch_chunk_compact(hipStream_t st, const uint64_t* slot_prefix,
                                 const uint64_t* blob_off, uint32_t n_blobs, uint64_t* chunk_offset,
                                 uint64_t* chunk_size, uint32_t* chunk_blob, uint64_t* msg_off,
                                 uint64_t* msg_len);
+// Messages [0, n_long) are long (whole blobs), the rest short; queue_heads is 2 x u64 of scratch.
 hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* offs,
-                         const uint64_t* lens, uint64_t n_msgs, uint8_t* digests,
-                         unsigned long long* queue_head, const uint32_t* init_state,
-                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks);
+                         const uint64_t* lens, uint64_t n_long, uint64_t n_msgs, uint8_t* digests,
+                         unsigned long long* queue_heads, const uint32_t* init_state,
+                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks, int slots);
 
 } // namespace yams_accel

@@ -253,9 +253,9 @@ const uint32_t kShaInit[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au
 
 namespace yams_accel { // from ingest_kernels.hip
 hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* offs,
-                         const uint64_t* lens, uint64_t n_msgs, uint8_t* digests,
-                         unsigned long long* queue_head, const uint32_t* init_state,
-                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks);
+                         const uint64_t* lens, uint64_t n_long, uint64_t n_msgs, uint8_t* digests,
+                         unsigned long long* queue_heads, const uint32_t* init_state,
+                         uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks, int slots);
 }
 
 namespace {
@@ -274,8 +274,8 @@ yams_status_t stream_blocks(HashStream* hs, const uint8_t* bytes, size_t n) {
     YA_HIP(ctx, hipMemcpyAsync(d_data, bytes, n, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, hipMemcpyAsync(d_tab, tab, 16, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, hipMemcpyAsync(d_state, hs->state, 32, hipMemcpyHostToDevice, ctx->stream));
-    YA_HIP(ctx, launch_sha256(ctx->stream, d_data, d_tab, d_tab + 1, 1, nullptr, d_head, d_state,
-                              d_state + 8, 1, 1));
+    YA_HIP(ctx, launch_sha256(ctx->stream, d_data, d_tab, d_tab + 1, 0, 1, nullptr, d_head, d_state,
+                              d_state + 8, 1, 1, 1));
     YA_HIP(ctx, hipMemcpyAsync(hs->state, d_state + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return YAMS_OK;
