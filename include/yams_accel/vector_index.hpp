@@ -19,6 +19,7 @@
 #include <optional>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "plugin.hpp"
@@ -99,7 +100,29 @@ public:
     Result<std::vector<VectorRecord>> searchSimilar(const std::vector<float>& query, size_t k,
                                                     float similarityThreshold = 0.0f,
                                                     VectorSearchDiagnostics* diagnostics = nullptr) {
-        auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics);
+        auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics, nullptr);
+        if (!r) return r.error();
+        return std::move(r.value().front());
+    }
+    // The filtered form of IVectorStore::searchSimilar (vector_store.h:44-49): only rows whose
+    // document_hash equals `document_hash` (if given) AND is in `candidate_hashes` (if non-empty)
+    // take part — the SQL restriction of sqlite_vec_backend.cpp:4137-4175, as a row allow-mask.
+    // (metadata_filters need the parsed record per row and stay with the SQLite backend.)
+    Result<std::vector<VectorRecord>>
+    searchSimilar(const std::vector<float>& query, size_t k, float similarityThreshold,
+                  const std::optional<std::string>& document_hash,
+                  const std::unordered_set<std::string>& candidate_hashes,
+                  VectorSearchDiagnostics* diagnostics = nullptr) {
+        if (!document_hash && candidate_hashes.empty()) return searchSimilar(query, k, similarityThreshold, diagnostics);
+        std::vector<uint32_t> mask((records_.size() + 31) / 32, 0u);
+        for (size_t r = 0; r < records_.size(); ++r) {
+            const auto& h = records_[r].document_hash;
+            if (document_hash && h != *document_hash) continue;
+            if (!candidate_hashes.empty() && !candidate_hashes.count(h)) continue;
+            mask[r >> 5] |= 1u << (r & 31);
+        }
+        if (mask.empty()) mask.push_back(0u);
+        auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics, mask.data());
         if (!r) return r.error();
         return std::move(r.value().front());
     }
@@ -107,7 +130,7 @@ public:
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatch(const std::vector<std::vector<float>>& queries, size_t k,
                        float similarityThreshold = 0.0f, size_t /*num_threads*/ = 0) {
-        return searchSimilarBatchImpl(queries, k, similarityThreshold, nullptr);
+        return searchSimilarBatchImpl(queries, k, similarityThreshold, nullptr, nullptr);
     }
 
 private:
@@ -132,7 +155,7 @@ private:
 
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatchImpl(const std::vector<std::vector<float>>& queries, size_t k, float thr,
-                           VectorSearchDiagnostics* diagnostics) {
+                           VectorSearchDiagnostics* diagnostics, const uint32_t* rowMask) {
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
         if (queries.empty()) return std::vector<std::vector<VectorRecord>>{};
         for (const auto& q : queries) // vector_database.cpp:545-550, 626-633
@@ -144,9 +167,9 @@ private:
         for (size_t i = 0; i < queries.size(); ++i) std::copy(queries[i].begin(), queries[i].end(), flat.begin() + i * dim_);
         yams_scan_hit_t* hits = nullptr; uint32_t* counts = nullptr; yams_scan_diag_t diag{};
         const uint32_t metric = engine_ == VectorSearchEngine::Vec0L2 ? YAMS_SCAN_L2 : YAMS_SCAN_COSINE;
-        const yams_status_t st = vt_->search_batch(vt_->self, corpus_, flat.data(), static_cast<uint32_t>(queries.size()),
-                                                   static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, metric,
-                                                   &hits, &counts, &diag);
+        const yams_status_t st = vt_->search_batch_masked(vt_->self, corpus_, flat.data(), static_cast<uint32_t>(queries.size()),
+                                                          static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, metric,
+                                                          rowMask, &hits, &counts, &diag);
         if (st == YAMS_ERR_INVALID_ARG)
             return Error{ErrorCode::InvalidArgument, "Exact vector search requires a finite, non-zero query embedding"};
         if (st != YAMS_OK) return Error{accel::mapStatus(st), "vector scan failed"};

@@ -120,6 +120,12 @@ typedef struct yams_scan_corpus_s {
     const uint32_t* rank_row;  /* device, nullable iff tie_rank is: inverse permutation within this
                                   shard for single-shard corpora (rank_row[tie_rank[r]] == r)     */
     int64_t row_base;          /* added to local row ordinals in the outputs (shard base)         */
+    const uint32_t* row_mask;  /* device, nullable: bit (r & 31) of word (r >> 5) set = row r takes
+                                  part in the search.  This is the `AND document_hash = ?` /
+                                  `AND document_hash IN (...)` restriction of the reference's scan
+                                  (sqlite_vec_backend.cpp:4137-4175): masked-out rows are neither
+                                  visited nor evaluated.  ceil(n_rows / 32) words.               */
+    uint64_t row_mask_count;   /* number of set bits (the host built the mask, it knows)          */
 } yams_scan_corpus_t;
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
@@ -321,6 +327,13 @@ typedef struct yams_vector_scan_v1 {
     void (*free_hits)(void* self, yams_scan_hit_t* hits, uint32_t* counts);
     yams_status_t (*get_runtime_info_json)(void* self, char** out_json);
     void (*free_string)(void* self, char* s);
+    /* Filtered search (document_hash / candidate_hashes, vector_store.h:44-49): `row_mask` is a
+     * HOST bitmap over the mirror's rows (bit r & 31 of word r >> 5), NULL = all rows. */
+    yams_status_t (*search_batch_masked)(void* self, uint64_t corpus_id, const float* queries,
+                                         uint32_t n_queries, uint32_t dim, uint32_t k,
+                                         float similarity_threshold, uint32_t metric,
+                                         const uint32_t* row_mask, yams_scan_hit_t** out_hits,
+                                         uint32_t** out_counts, yams_scan_diag_t* out_diag);
 } yams_vector_scan_v1;
 
 typedef struct yams_content_hash_v1 {

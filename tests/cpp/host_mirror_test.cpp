@@ -125,6 +125,29 @@ int main(int argc, char** argv) {
         auto res = db.searchSimilar({1, 0, 0, 0}, 2, -1.0f);
         CHECK(res.has_value() && res.value().size() == 2 && res.value()[0].chunk_id == "tie_a" && res.value()[1].chunk_id == "tie_b");
     }
+    {   // "exact candidate mode scores only allowed documents" (vector_smoke_catch2_test.cpp:355-401)
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        auto insert = [&](const char* id, const char* doc, std::vector<float> e) {
+            vector::VectorRecord r; r.chunk_id = id; r.document_hash = doc; r.embedding = std::move(e);
+            return db.insertVector(r);
+        };
+        CHECK(insert("allowed_best", "allowed", {1.0f, 0.0f, 0.0f, 0.0f}).has_value());
+        CHECK(insert("allowed_second", "allowed", {0.8f, 0.6f, 0.0f, 0.0f}).has_value());
+        CHECK(insert("blocked", "blocked", {1.0f, 0.0f, 0.0f, 0.0f}).has_value());
+        vector::VectorSearchDiagnostics diag;
+        auto res = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::nullopt, {"allowed"}, &diag);
+        CHECK(res.has_value() && res.value().size() == 2);
+        if (res && res.value().size() == 2) {
+            CHECK(res.value()[0].chunk_id == "allowed_best" && res.value()[1].chunk_id == "allowed_second");
+        }
+        CHECK(diag.usedExactScan && diag.rowsVisited == 2 && diag.exactDistanceEvaluations == 2 && diag.returnedRows == 2);
+        auto one = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::optional<std::string>("blocked"), {});
+        CHECK(one.has_value() && one.value().size() == 1 && one.value()[0].chunk_id == "blocked");
+        auto none = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::optional<std::string>("blocked"), {"allowed"});
+        CHECK(none.has_value() && none.value().empty());
+    }
     {   // large finite scores (+-FLT_MAX/4) stay finite
         const float L = std::numeric_limits<float>::max() / 4.0f;
         auto idxR = vector::createAccelVectorIndex(plugin, 4);

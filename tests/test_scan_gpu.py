@@ -259,6 +259,62 @@ def test_row_base_and_device_entry_point(acc, oracle):
         assert np.array_equal(rk[qi].cpu().numpy().astype(np.int64), rows)
 
 
+# ---- filtered search: document_hash / candidate_hashes as a row allow-mask -----------------------
+def _masked(acc, oracle, corpus, queries, k, allowed, metric=SCAN_COSINE, thr=-1.0, tie_rank=None):
+    n, d = corpus.shape
+    bits = np.zeros((n + 31) // 32 * 32, np.uint8)
+    bits[allowed] = 1
+    words = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+    dc, dm = acc.to_device(corpus), acc.to_device(words)
+    dr = di = None
+    if tie_rank is not None:
+        inv = np.empty_like(tie_rank); inv[tie_rank] = np.arange(n, dtype=tie_rank.dtype)
+        dr, di = acc.to_device(tie_rank), acc.to_device(inv)
+    view = acc.corpus_view(dc.ptr, n, d, dr.ptr if dr else None, di.ptr if di else None, 0, dm.ptr, len(allowed))
+    r = acc.scan_topk(view, queries, k, thr, metric)
+    sub = corpus[allowed]
+    sub_rank = None if tie_rank is None else tie_rank[allowed].astype(np.uint64)
+    for qi in range(queries.shape[0]):
+        if metric == SCAN_COSINE:
+            rows, sims, _, _ = oracle.scan_cosine(sub, queries[qi], k, thr, sub_rank)
+        else:
+            rows, _, sims = oracle.scan_l2(sub, queries[qi], k, thr, sub_rank)
+        cnt = int(r.counts[qi])
+        assert cnt == len(rows), (qi, cnt, len(rows), r.diag)
+        assert np.array_equal(r.rows[qi, :cnt], np.asarray(allowed)[rows]), qi
+        assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32))
+    # only the allowed rows are visited / evaluated (vector_smoke_catch2_test.cpp:355-401)
+    assert r.diag["rows_visited"] == queries.shape[0] * len(allowed)
+    assert r.diag["exact_distance_evaluations"] == queries.shape[0] * len(allowed)
+    return r
+
+
+def test_reference_candidate_mode_scores_only_allowed_documents(acc, oracle):
+    c = np.array([[1, 0, 0, 0], [0.8, 0.6, 0, 0], [1, 0, 0, 0]], np.float32)   # allowed, allowed, blocked
+    r = _masked(acc, oracle, c, np.array([[1, 0, 0, 0]], np.float32), 4, [0, 1])
+    assert list(r.rows[0, :2]) == [0, 1] and r.counts[0] == 2 and r.diag["returned_rows"] == 2
+
+
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+def test_row_mask_dense_and_sparse(acc, oracle, metric):
+    rng = np.random.default_rng(51)
+    n, d = 60000, 128
+    corpus = oracle.synth_rows(17, 0, n, d)
+    q = oracle.synth_rows(17, 1 << 40, 5, d)
+    rank = rng.permutation(n).astype(np.uint32)
+    dense = np.sort(rng.choice(n, 40000, replace=False))          # MFMA filter with masked rows
+    r = _masked(acc, oracle, corpus, q, 30, dense, metric, tie_rank=rank)
+    assert r.diag["path"] == 0
+    sparse = np.sort(rng.choice(n, 700, replace=False))           # gathered fp64 path
+    r = _masked(acc, oracle, corpus, q, 30, sparse, metric, tie_rank=rank)
+    assert r.diag["path"] == 1
+    # the best unmasked row must not leak: mask out each query's global winner
+    best = [int(oracle.scan_cosine(corpus, q[i], 1)[0][0]) for i in range(5)]
+    keep = np.setdiff1d(np.arange(n), best)
+    _masked(acc, oracle, corpus, q, 10, keep, metric)
+    _masked(acc, oracle, corpus, q, 10, [], metric)               # empty candidate set -> no results
+
+
 # ---- shard merge (the step after the RCCL all-gather) ---------------------------------------------
 @pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
 @pytest.mark.parametrize("n_shards", [1, 2, 3, 8])

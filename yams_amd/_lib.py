@@ -31,7 +31,8 @@ f32p = C.POINTER(C.c_float)
 
 class ScanCorpus(C.Structure):
     _fields_ = [("rows", vp), ("n_rows", C.c_uint64), ("dim", C.c_uint32), ("reserved", C.c_uint32),
-                ("tie_rank", vp), ("rank_row", vp), ("row_base", C.c_int64)]
+                ("tie_rank", vp), ("rank_row", vp), ("row_base", C.c_int64),
+                ("row_mask", vp), ("row_mask_count", C.c_uint64)]
 
 
 class ScanParams(C.Structure):
@@ -90,6 +91,10 @@ class VectorScanV1(C.Structure):
         ("free_hits", C.CFUNCTYPE(None, vp, C.POINTER(ScanHit), u32p)),
         ("get_runtime_info_json", C.CFUNCTYPE(ST, vp, C.POINTER(C.c_void_p))),
         ("free_string", C.CFUNCTYPE(None, vp, C.c_void_p)),
+        ("search_batch_masked", C.CFUNCTYPE(ST, vp, C.c_uint64, f32p, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_float, C.c_uint32, u32p,
+                                            C.POINTER(C.POINTER(ScanHit)), C.POINTER(u32p),
+                                            C.POINTER(ScanDiag))),
     ]
 
 

@@ -130,8 +130,10 @@ class Accel:
 
     # ---- exact vector scan --------------------------------------------------------------------
     def corpus_view(self, rows_ptr: int, n_rows: int, dim: int, tie_rank_ptr: int | None = None,
-                    rank_row_ptr: int | None = None, row_base: int = 0) -> ScanCorpus:
-        return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base)
+                    rank_row_ptr: int | None = None, row_base: int = 0,
+                    row_mask_ptr: int | None = None, row_mask_count: int = 0) -> ScanCorpus:
+        return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base,
+                          row_mask_ptr, row_mask_count)
 
     def scan_topk_device(self, corpus: ScanCorpus, queries_ptr: int, nq: int, k: int,
                          threshold: float, metric: int, out_scores: int, out_rows: int,

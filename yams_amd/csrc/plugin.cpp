@@ -173,10 +173,10 @@ yams_status_t vs_corpus_size(void*, uint64_t id, uint64_t* out_rows, uint32_t* o
     return YAMS_OK;
 }
 
-yams_status_t vs_search_batch(void*, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
-                              uint32_t k, float threshold, uint32_t metric,
-                              yams_scan_hit_t** out_hits, uint32_t** out_counts,
-                              yams_scan_diag_t* out_diag) {
+yams_status_t vs_search_batch_masked(void*, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
+                                     uint32_t k, float threshold, uint32_t metric,
+                                     const uint32_t* row_mask_host, yams_scan_hit_t** out_hits,
+                                     uint32_t** out_counts, yams_scan_diag_t* out_diag) {
     std::lock_guard<std::mutex> lk(g.mu);
     NEED_CTX();
     if (!out_hits || !out_counts) return YAMS_ERR_INVALID_ARG;
@@ -190,6 +190,19 @@ yams_status_t vs_search_batch(void*, uint64_t id, const float* queries, uint32_t
     yams_scan_corpus_t view{};
     view.rows = c.d_rows; view.n_rows = c.n_rows; view.dim = c.dim;
     view.tie_rank = c.d_tie; view.rank_row = c.d_inv; view.row_base = 0;
+    if (row_mask_host && c.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175)
+        const size_t words = (c.n_rows + 31) / 32;
+        uint64_t bits = 0;
+        for (size_t i = 0; i < words; ++i) {
+            uint32_t w = row_mask_host[i];
+            if (i == words - 1 && (c.n_rows & 31)) w &= (1u << (c.n_rows & 31)) - 1u;
+            bits += static_cast<uint64_t>(__builtin_popcount(w));
+        }
+        uint32_t* d_mask = nullptr;
+        if (yams_accel::ws_get(g.ctx, "plugin_row_mask", words * 4, (void**)&d_mask) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        if (yams_accel_upload(g.ctx, d_mask, row_mask_host, words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        view.row_mask = d_mask; view.row_mask_count = bits;
+    }
     yams_scan_params_t prm{k, threshold, metric, 0};
     const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
     std::vector<float> scores(slots), dist(slots);
@@ -211,6 +224,14 @@ yams_status_t vs_search_batch(void*, uint64_t id, const float* queries, uint32_t
     return YAMS_OK;
 }
 
+yams_status_t vs_search_batch(void* self, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
+                              uint32_t k, float threshold, uint32_t metric,
+                              yams_scan_hit_t** out_hits, uint32_t** out_counts,
+                              yams_scan_diag_t* out_diag) {
+    return vs_search_batch_masked(self, id, queries, nq, dim, k, threshold, metric, nullptr, out_hits,
+                                  out_counts, out_diag);
+}
+
 void vs_free_hits(void*, yams_scan_hit_t* hits, uint32_t* counts) { std::free(hits); std::free(counts); }
 
 yams_status_t vs_runtime_info(void*, char** out_json) {
@@ -223,7 +244,7 @@ void vs_free_string(void*, char* s) { std::free(s); }
 yams_vector_scan_v1 g_vector_scan = {
     YAMS_IFACE_VECTOR_SCAN_V1_VERSION, nullptr, vs_corpus_create, vs_corpus_append,
     vs_corpus_set_tie_ranks, vs_corpus_clear, vs_corpus_destroy, vs_corpus_size, vs_search_batch,
-    vs_free_hits, vs_runtime_info, vs_free_string};
+    vs_free_hits, vs_runtime_info, vs_free_string, vs_search_batch_masked};
 
 // ---- content_hash_v1 --------------------------------------------------------------------------
 yams_status_t ch_hash(void*, const uint8_t* data, size_t n, char out_hex[65]) {

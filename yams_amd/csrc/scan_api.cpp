@@ -56,12 +56,14 @@ struct ScanIo {
 // Exhaustive fp64 path for a subset of queries (slots -> query indices in qmap_host; nullptr = all).
 yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_qnorm,
                         const std::vector<uint32_t>* subset, uint32_t* d_status,
-                        unsigned long long* d_stat) {
+                        unsigned long long* d_stat, const uint32_t* d_rows_sel = nullptr,
+                        uint64_t n_sel = 0) {
     const auto& c = *io.corpus;
     const uint32_t total = subset ? static_cast<uint32_t>(subset->size()) : io.nq;
     if (total == 0) return YAMS_OK;
     const uint32_t keep = io.prm.k; // exact keys: the best k ARE the answer
-    const uint64_t key_stride = std::max<uint64_t>(c.n_rows, 1);
+    const uint64_t n_items = d_rows_sel ? n_sel : c.n_rows; // rows that get a key
+    const uint64_t key_stride = std::max<uint64_t>(n_items, 1);
     uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, kExactKeyBudget / (key_stride * 8)));
     batch = std::min(batch, total);
     uint64_t* d_keys; uint64_t* d_work; uint32_t* d_qmap;
@@ -78,16 +80,17 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
     // In the L2 (vec0) contract the cosine threshold applies after the top-k (:4506-4510).
     for (uint32_t b0 = 0; b0 < total; b0 += batch) {
         const uint32_t nb = std::min(batch, total - b0);
-        if (c.n_rows > 0) {
+        if (n_items > 0) {
             TimedRegion tr(ctx, "exact_keys");
             YA_HIP(ctx, launch_exact_keys(ctx->stream, metric, c.rows, c.n_rows, c.dim, io.queries,
-                                          d_qnorm, c.tie_rank, d_qmap + b0, nb,
-                                          io.prm.similarity_threshold, d_keys, key_stride));
+                                          d_qnorm, c.tie_rank, c.row_mask, d_rows_sel, n_sel,
+                                          d_qmap + b0, nb, io.prm.similarity_threshold, d_keys,
+                                          key_stride));
             tr.end();
         }
         const uint64_t* res; uint64_t res_stride;
         YA_HIP(ctx, launch_topk_keys(ctx->stream, d_keys, key_stride,
-                                     static_cast<uint32_t>(c.n_rows), nb, keep, d_work, &res,
+                                     static_cast<uint32_t>(n_items), nb, keep, d_work, &res,
                                      &res_stride));
         RescoreLaunch R{};
         R.rows = c.rows; R.n_rows = c.n_rows; R.dim = c.dim; R.queries = io.queries; R.qnorm = d_qnorm;
@@ -136,6 +139,8 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
     if (corpus->n_rows > 0 && !corpus->rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus rows");
     if ((corpus->tie_rank == nullptr) != (corpus->rank_row == nullptr))
         return fail(ctx, YAMS_ERR_INVALID_ARG, "tie_rank and rank_row must be given together");
+    if (corpus->row_mask && corpus->row_mask_count > corpus->n_rows)
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "row_mask_count exceeds n_rows");
     (void)hipSetDevice(ctx->device);
 
     const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
@@ -157,15 +162,19 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
     YA_HIP(ctx, launch_prep_queries(st, queries, nq, dim, metric, d_qprep, d_qnorm, d_qnorm_up, d_qflags));
 
     uint32_t* h_pin;
-    YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 4 * 4 + 64, (void**)&h_pin));
+    YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 4 * 4 + 128, (void**)&h_pin));
     uint32_t* h_flags = h_pin;
     uint32_t* h_status = h_pin + nq;
     uint32_t* h_lcount = h_pin + 2 * static_cast<size_t>(nq);
     float* h_qnup = reinterpret_cast<float*>(h_pin + 3 * static_cast<size_t>(nq));
 
     const bool aligned = (reinterpret_cast<uintptr_t>(corpus->rows) & 15u) == 0 && (dim & 3u) == 0;
+    // rows that take part in the scan: all of them, or the set bits of the allow-mask
+    const uint64_t n_eff = corpus->row_mask ? corpus->row_mask_count : corpus->n_rows;
+    // a sparse allow-mask (document_hash / small candidate sets) is gathered and scored in fp64
+    const bool sparse_mask = corpus->row_mask && n_eff < 4 * kMfmaMinRows;
     bool use_mfma = !(params->flags & YAMS_SCAN_FLAG_FORCE_EXACT) && aligned &&
-                    corpus->n_rows >= kMfmaMinRows;
+                    corpus->n_rows >= kMfmaMinRows && !sparse_mask;
     if (use_mfma && metric == YAMS_SCAN_L2) {
         // The L2 filter works on raw magnitudes; queries far outside the fp32 comfort zone take
         // the fp64 path (needs the norms on the host: one small sync).
@@ -178,7 +187,20 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
     uint64_t filter_candidates = 0;
     uint32_t widened = 0, exact_fb = 0;
     if (!use_mfma) {
-        YA_TRY(run_exact(ctx, io, d_qnorm, nullptr, d_status, d_stat));
+        const uint32_t* d_rows_sel = nullptr;
+        uint64_t n_sel = 0;
+        if (corpus->row_mask && corpus->n_rows > 0) {
+            uint32_t* d_sel; unsigned long long* d_cnt;
+            YA_TRY(ws_get(ctx, "mask_rows", static_cast<size_t>(corpus->n_rows) * 4, (void**)&d_sel));
+            YA_TRY(ws_get(ctx, "mask_count", 64, (void**)&d_cnt));
+            YA_HIP(ctx, launch_compact_mask(st, corpus->row_mask, corpus->n_rows, d_sel, d_cnt));
+            unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_pin + 4 * static_cast<size_t>(nq));
+            YA_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            n_sel = *h_cnt;
+            d_rows_sel = d_sel;
+        }
+        YA_TRY(run_exact(ctx, io, d_qnorm, nullptr, d_status, d_stat, d_rows_sel, n_sel));
         YA_HIP(ctx, hipMemcpyAsync(h_flags, d_qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
         YA_HIP(ctx, hipStreamSynchronize(st));
         if (diag) diag->path = 1;
@@ -190,7 +212,7 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         const int bf16_version = kv ? std::atoi(kv) : 2; // 12 = staging-only ablation (perf measurement only)
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16);
         ScanLaunch L;
-        L.plan = plan; L.rows = corpus->rows; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
+        L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
         //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + the split residue:
@@ -301,8 +323,8 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipStreamSynchronize(st));
         diag->used_exact_scan = 1;
         diag->rows_visited_observed = 1;
-        diag->rows_visited = static_cast<uint64_t>(nq) * corpus->n_rows;
-        diag->exact_distance_evaluations = static_cast<uint64_t>(nq) * corpus->n_rows;
+        diag->rows_visited = static_cast<uint64_t>(nq) * n_eff;
+        diag->exact_distance_evaluations = static_cast<uint64_t>(nq) * n_eff;
         uint64_t ret = 0;
         for (uint32_t i = 0; i < nq; ++i) ret += h_counts[i];
         diag->returned_rows = ret;

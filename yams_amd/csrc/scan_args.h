@@ -12,6 +12,7 @@ struct ScanArgs {
     const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
     const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)
     uint32_t q_pad;         // padded query count of the k-slab-major planes (n_qtiles * 256)
+    const uint32_t* row_mask; // nullable allow-bitmap over rows
     uint64_t n_rows;
     uint32_t dim;
     uint32_t n_queries;
@@ -34,5 +35,11 @@ struct ScanArgs {
 };
 
 __device__ __forceinline__ bool norm_in_range(float nsq) { return nsq > 1e-30f && nsq < 1e30f; }
+
+// allow-mask word of the 32 rows starting at row32 (a multiple of 32); all ones without a mask
+__device__ __forceinline__ uint32_t mask_word(const uint32_t* row_mask, uint64_t row32, uint64_t n_rows) {
+    if (!row_mask) return 0xffffffffu;
+    return row32 < n_rows ? row_mask[row32 >> 5] : 0u;
+}
 
 } // namespace yams_accel

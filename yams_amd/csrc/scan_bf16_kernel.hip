@@ -221,6 +221,17 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16v2_kernel(ScanAr
     }
 
     const uint64_t wave_row0 = row0 + wid * 32;
+    if (a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
+        const uint32_t mw = mask_word(a.row_mask, wave_row0, a.n_rows);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (!((mw >> i) & 1u)) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u][r] = -__builtin_inff();
+            }
+        }
+    }
     if (MODE == MODE_SAMPLE) {
         const float ninf = -__builtin_inff();
 #pragma unroll

@@ -178,6 +178,20 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
     }
 
     const uint64_t wave_row0 = row0 + wr * 64;
+    if (a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t mw = mask_word(a.row_mask, wave_row0 + t * 32, a.n_rows);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!((mw >> i) & 1u)) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u][r] = -__builtin_inff();
+                }
+            }
+        }
+    }
     if (MODE == MODE_SAMPLE) {
         const float ninf = -__builtin_inff();
 #pragma unroll
@@ -614,6 +628,8 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
                                                          uint32_t dim, const float* queries,
                                                          const double* qnorm,
                                                          const uint32_t* tie_rank,
+                                                         const uint32_t* row_mask,
+                                                         const uint32_t* rows_sel, uint64_t n_sel,
                                                          const uint32_t* qmap, float threshold,
                                                          uint64_t* keys, uint64_t key_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -623,8 +639,18 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
         sq[i] = queries[static_cast<uint64_t>(q) * dim + i];
     __syncthreads();
-    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    const uint64_t slot_i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint64_t row = slot_i;
+    if (rows_sel) {
+        if (slot_i >= n_sel) return;
+        row = rows_sel[slot_i];
+    } else {
+        if (row >= n_rows) return;
+        if (row_mask && !((row_mask[row >> 5] >> (row & 31)) & 1u)) {
+            keys[static_cast<uint64_t>(slot) * key_stride + slot_i] = 0;
+            return;
+        }
+    }
     const float* x = rows + row * dim;
     double nsq = 0.0, dot = 0.0, dsq = 0.0;
     for (uint32_t i = 0; i < dim; ++i) {
@@ -651,7 +677,22 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
             if (isfinite(dd)) key = pack_key(-static_cast<float>(dd), kidx);
         }
     }
-    keys[static_cast<uint64_t>(slot) * key_stride + row] = key;
+    keys[static_cast<uint64_t>(slot) * key_stride + slot_i] = key;
+}
+
+// Row ordinals of the set bits of an allow-mask (any order: the keys carry the row / rank).
+__global__ __launch_bounds__(256) void compact_mask_kernel(const uint32_t* row_mask, uint64_t n_rows,
+                                                           uint32_t* rows_sel,
+                                                           unsigned long long* counter) {
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool on = row < n_rows && ((row_mask[row >> 5] >> (row & 31)) & 1u);
+    const unsigned long long ball = __ballot(on);
+    if (ball == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(ball)));
+    base = __shfl(base, 0);
+    if (on) rows_sel[base + __popcll(ball & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(row);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -840,7 +881,7 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
 
 ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
-    a.rows = L.rows; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.rows = L.rows; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
@@ -957,16 +998,30 @@ hipError_t launch_select_lists(hipStream_t st, const uint64_t* list, const uint3
 
 hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint64_t n_rows,
                              uint32_t dim, const float* queries, const double* qnorm,
-                             const uint32_t* tie_rank, const uint32_t* qmap, uint32_t n_slots,
-                             float threshold, uint64_t* keys, uint64_t key_stride) {
-    const uint32_t gx = static_cast<uint32_t>((n_rows + 255) / 256);
+                             const uint32_t* tie_rank, const uint32_t* row_mask,
+                             const uint32_t* rows_sel, uint64_t n_sel, const uint32_t* qmap,
+                             uint32_t n_slots, float threshold, uint64_t* keys, uint64_t key_stride) {
+    const uint64_t n_items = rows_sel ? n_sel : n_rows;
+    if (n_items == 0) return hipSuccess;
+    const uint32_t gx = static_cast<uint32_t>((n_items + 255) / 256);
     const size_t sh = static_cast<size_t>(dim) * sizeof(float);
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_COSINE>), dim3(gx, n_slots), dim3(256), sh,
-                           st, rows, n_rows, dim, queries, qnorm, tie_rank, qmap, threshold, keys, key_stride);
+                           st, rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, keys, key_stride);
     else
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2>), dim3(gx, n_slots), dim3(256), sh, st,
-                           rows, n_rows, dim, queries, qnorm, tie_rank, qmap, threshold, keys, key_stride);
+                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, keys, key_stride);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_compact_mask(hipStream_t st, const uint32_t* row_mask, uint64_t n_rows,
+                               uint32_t* rows_sel, unsigned long long* counter) {
+    if (n_rows == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(compact_mask_kernel, dim3(static_cast<uint32_t>((n_rows + 255) / 256)),
+                       dim3(256), 0, st, row_mask, n_rows, rows_sel, counter);
     LAUNCH_CHECK();
     return hipSuccess;
 }

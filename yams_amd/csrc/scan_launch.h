@@ -7,6 +7,7 @@ namespace yams_accel {
 struct ScanLaunch {
     ScanPlan plan;
     const float* rows = nullptr;
+    const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
     const uint16_t* q_hi = nullptr;
     const uint16_t* q_lo = nullptr;
@@ -56,10 +57,15 @@ hipError_t launch_select_lists(hipStream_t st, const uint64_t* list, const uint3
                                uint32_t list_cap, uint32_t n_slots, const uint32_t* qmap,
                                uint32_t keep, uint64_t* work, const uint64_t** result,
                                uint64_t* result_stride);
+// rows_sel: nullable list of n_sel row ordinals to score (sparse allow-mask); else all n_rows rows,
+// skipping rows whose bit in row_mask (nullable) is clear.  keys[slot][i], i < (rows_sel ? n_sel : n_rows).
 hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint64_t n_rows,
                              uint32_t dim, const float* queries, const double* qnorm,
-                             const uint32_t* tie_rank, const uint32_t* qmap, uint32_t n_slots,
-                             float threshold, uint64_t* keys, uint64_t key_stride);
+                             const uint32_t* tie_rank, const uint32_t* row_mask,
+                             const uint32_t* rows_sel, uint64_t n_sel, const uint32_t* qmap,
+                             uint32_t n_slots, float threshold, uint64_t* keys, uint64_t key_stride);
+hipError_t launch_compact_mask(hipStream_t st, const uint32_t* row_mask, uint64_t n_rows,
+                               uint32_t* rows_sel, unsigned long long* counter);
 hipError_t launch_topk_keys(hipStream_t st, const uint64_t* keys, uint64_t key_stride,
                             uint32_t n_per_slot, uint32_t n_slots, uint32_t keep, uint64_t* work,
                             const uint64_t** result, uint64_t* result_stride);
