@@ -84,6 +84,32 @@ def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_qu
             "host_cores_available": os.cpu_count()}, recall, exact
 
 
+def ingest_cpu_baseline(seed, blen, n_sample=16):
+    """The reference's own translation units (oracle/_ref: StreamingChunker::chunkData incl. the
+    per-chunk SHA-256, + SHA256Hasher::hash of the whole blob) on one host core, on a bounded
+    sample of the same Philox blobs; falls back to the plain-C port when _ref did not travel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    o = _oracle.oracle()
+    r = _oracle.ref()
+    blobs = [o.synth_bytes(seed, b, 0, blen) for b in range(n_sample)]
+    t0 = time.perf_counter()
+    for b in blobs:
+        if r is not None:
+            r.chunks(b, "streaming", with_hashes=True)
+            r.sha256_hex(b)
+        else:
+            off, sz = o.chunks(b, "streaming")
+            for x, y in zip(off, sz):
+                o.sha256_hex(b[int(x):int(x + y)])
+            o.sha256_hex(b)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample * blen / dt / 1e9, "unit": "GB/s", "cores": 1,
+            "kind": "reference" if r is not None else "port",
+            "sample": f"{n_sample} x {blen >> 20} MiB Philox blobs, StreamingChunker defaults + per-chunk and "
+                      f"whole-blob SHA-256, 1 thread, {dt:.1f} s"}
+
+
 def ingest_leg(acc, gib, seed):
     """SHA-256 + CDC over device-resident Philox blobs (4 MiB each, product-default chunker)."""
     blen = 4 << 20
@@ -107,7 +133,8 @@ def ingest_leg(acc, gib, seed):
     cdc_ms, _ = acc.kernel_ms("cdc_candidates")
     acc.enable_timing(False)
     total = n_blobs * blen
-    out = {"value": total / dt / 1e9, "unit": "GB/s", "bytes": total, "blobs": n_blobs,
+    cpu = ingest_cpu_baseline(seed, blen)
+    out = {"value": total / dt / 1e9, "unit": "GB/s", "bytes": total, "blobs": n_blobs, "cpu_baseline": cpu,
            "blob_bytes": blen, "chunks": int(res.n_chunks), "ms": dt * 1e3,
            "sha256_kernel_ms": sha_ms, "cdc_candidates_kernel_ms": cdc_ms,
            "chunker": "StreamingChunker defaults (min 16 KiB, max 1 MiB, mask 0x1FFF)",

@@ -1,0 +1,34 @@
+"""Times the BASELINE.json configurations that fit one GPU (informational table for DESIGN.md;
+bench.py remains the contract).  C1 10k x 384 cosine k=10 Q=1 | C2 1M x 384 cosine k=100 Q=256 |
+C3 10M x 768 L2 k=100 Q=1024 | C4-shard 12.5M x 768 cosine k=100 Q in {64, 256, 1024}."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from yams_amd.accel import Accel
+from yams_amd._lib import SCAN_COSINE, SCAN_L2
+
+acc = Accel(0, torch.cuda.current_stream().cuda_stream)
+rows = []
+for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2", 1_000_000, 384, 256, 100, SCAN_COSINE),
+                                  ("C3", 10_000_000, 768, 1024, 100, SCAN_L2), ("C4/8 Q=64", 12_500_000, 768, 64, 100, SCAN_COSINE),
+                                  ("C4/8 Q=256", 12_500_000, 768, 256, 100, SCAN_COSINE), ("C4/8 Q=1024", 12_500_000, 768, 1024, 100, SCAN_COSINE)]:
+    tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 0, n, d, tc.data_ptr())
+    tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 1 << 40, nq, d, tq.data_ptr())
+    s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    view = acc.corpus_view(tc.data_ptr(), n, d)
+    for _ in range(2):
+        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr())
+    reps = 10 if n <= 1_000_000 else 4
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr(), want_diag=False)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    rows.append({"config": name, "rows": n, "dim": d, "Q": nq, "k": k, "metric": "l2" if metric else "cosine",
+                 "ms": dt * 1e3, "QPS": nq / dt, "algorithmic_TFLOPs": 2.0 * n * d * nq / dt / 1e12,
+                 "corpus_GBps": n * d * 4 / dt / 1e9, "path": diag["path"], "fallbacks": diag["exact_fallback_queries"]})
+    del tc, tq
+    torch.cuda.empty_cache()
+for r_ in rows:
+    print(json.dumps(r_))
