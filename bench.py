@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
+    # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
+    ap.add_argument("--dist-backend", default=None, help="override the collective backend (gloo for dry runs)")
+    ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry runs only)")
     return ap.parse_args()
 
 
@@ -145,7 +148,9 @@ def ingest_leg(acc, gib, seed):
 
 def main():
     a = parse()
-    rank, world, local = ydist.init_from_env()
+    if a.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = ydist.init_from_env(a.dist_backend)
     assert world == max(1, a.gpus) or world == 1, (world, a.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

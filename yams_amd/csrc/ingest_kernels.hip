@@ -522,6 +522,150 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long messages (whole-blob digests).  A 4 MiB blob is ONE chain of 65 536 dependent compressions
+// on one lane, and a wave issues at most one instruction per ~4.8 cycles however much ILP it has,
+// so the per-lane kernel above needs ~197 ms for it regardless of how many blobs there are.  Here
+// a workgroup of two waves shares 64 messages (lane j of both waves <-> message j): the PRODUCER
+// wave fetches block b, builds padding, runs the 48-step message schedule and pre-adds the round
+// constants; it hands the 64 words (w[i] + K[i]) to the CONSUMER wave through LDS, double-buffered
+// with one s_barrier per block; the consumer executes only the 64 rounds (~14 instructions each)
+// and carries the chaining state.  Critical path per block: ~920 instead of ~1400 instructions.
+// ------------------------------------------------------------------------------------------------
+constexpr int LONG_LANE_STRIDE = 272;                  // bytes per lane per buffer: 64 words + pad,
+                                                       // 68-word stride keeps ds_*_b128 conflict-free
+constexpr int LONG_BUF_BYTES = 64 * LONG_LANE_STRIDE;  // 17 408
+__global__ __launch_bounds__(128) void sha256_long_kernel(const uint8_t* data, const uint64_t* offs,
+                                                          const uint64_t* lens,
+                                                          const uint32_t* out_slot /*nullable*/,
+                                                          uint64_t n_msgs, uint8_t* digests) {
+    __shared__ __attribute__((aligned(16))) unsigned char kw_lds[2 * LONG_BUF_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 = consumer, 1 = producer
+    const uint64_t m = static_cast<uint64_t>(blockIdx.x) * 64 + lane;
+    const bool have = m < n_msgs;
+    const uint64_t total = have ? lens[m] : 0;
+    // blocks this lane's message needs, padding included: data + 0x80 + 8-byte length
+    const uint64_t nblk = have ? (total + 8) / 64 + 1 : 0;
+    uint64_t maxblk = nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t o = __shfl_xor(maxblk, d);
+        maxblk = o > maxblk ? o : maxblk;
+    }
+    unsigned char* mybuf0 = kw_lds + lane * LONG_LANE_STRIDE;
+
+    if (role == 1) {
+        // ---------------- producer ----------------
+        __builtin_amdgcn_s_setprio(2);
+        const uint8_t* p = have ? data + offs[m] : nullptr;
+        const uint8_t* end = p + total;
+        ShaWindow win;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win.v[i] = u32x4_a4{0, 0, 0, 0};
+        win.tail = 0;
+        if (have) fetch_window(p, end, win);
+        int phase = have ? 0 : 3; // 0 data, 1 length-only block pending, 3 done
+        for (uint64_t b = 0; b < maxblk; ++b) {
+            uint32_t w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = 0;
+            if (phase == 0) {
+                const uint64_t rem = static_cast<uint64_t>(end - p);
+                window_words_be(win, p, w);
+                if (rem >= 64) {
+                    p += 64;
+                    if (p < end) fetch_window(p, end, win);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) win.v[i] = u32x4_a4{0, 0, 0, 0};
+                        win.tail = 0;
+                    }
+                } else {
+                    const uint32_t r = static_cast<uint32_t>(rem);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t lo = 4u * j;
+                        if (r <= lo) w[j] = 0;
+                        else if (r < lo + 4) w[j] &= 0xffffffffu << (8u * (lo + 4 - r));
+                        if ((r >> 2) == static_cast<uint32_t>(j)) w[j] |= 0x80u << (24 - 8 * (r & 3));
+                    }
+                    p = end;
+                    if (r < 56) {
+                        const uint64_t bitlen = total * 8ull;
+                        w[14] = static_cast<uint32_t>(bitlen >> 32);
+                        w[15] = static_cast<uint32_t>(bitlen);
+                        phase = 3;
+                    } else {
+                        phase = 1;
+                    }
+                }
+            } else if (phase == 1) {
+                const uint64_t bitlen = total * 8ull;
+                w[14] = static_cast<uint32_t>(bitlen >> 32);
+                w[15] = static_cast<uint32_t>(bitlen);
+                phase = 3;
+            }
+            unsigned char* dst = mybuf0 + (b & 1) * LONG_BUF_BYTES;
+            // rounds 0..15 use the block words, 16..63 the schedule; K is folded in here
+#pragma unroll
+            for (int i = 0; i < 64; i += 4) {
+                uint32_t o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = i + e;
+                    if (r >= 16) {
+                        const uint32_t w15 = w[(r - 15) & 15], w2 = w[(r - 2) & 15];
+                        const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+                        const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+                        w[r & 15] = w[r & 15] + s0 + w[(r - 7) & 15] + s1;
+                    }
+                    o4[e] = w[r & 15] + kSha256K[r];
+                }
+                *reinterpret_cast<uint4*>(dst + i * 4) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the LDS writes have landed
+            __builtin_amdgcn_s_barrier();       // block b is published; buffer (b+1)&1 is free again
+        }
+        __builtin_amdgcn_s_barrier(); // pairs with the consumer's final barrier
+    } else {
+        // ---------------- consumer ----------------
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t st[8];
+        sha256_init(st);
+        __builtin_amdgcn_s_barrier(); // block 0 is published
+        for (uint64_t b = 0; b < maxblk; ++b) {
+            const unsigned char* src = mybuf0 + (b & 1) * LONG_BUF_BYTES;
+            if (b < nblk) {
+                uint32_t a = st[0], bb = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+                for (int i = 0; i < 64; i += 4) {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(src + i * 4);
+                    const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+                        const uint32_t ch = __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);
+                        const uint32_t t1 = h + S1 + ch + kw[q];
+                        const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+                        const uint32_t mj = __builtin_amdgcn_bitop3_b32(a, bb, c, 0xE8);
+                        h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + S0 + mj;
+                    }
+                }
+                st[0] += a; st[1] += bb; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // my LDS reads of this buffer are complete
+            __builtin_amdgcn_s_barrier();       // producer may overwrite it; block b+1 is published
+        }
+        if (have) {
+            const uint64_t slot = out_slot ? out_slot[m] : m;
+            uint32_t* dstd = reinterpret_cast<uint32_t*>(digests + slot * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dstd[i] = __builtin_amdgcn_perm(0u, st[i], 0x00010203u);
+        }
+    }
+}
+
 // =================================================================================================
 // Launchers
 // =================================================================================================
@@ -586,6 +730,16 @@ hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* of
         hipLaunchKernelGGL(sha256_batch_kernel<1>, dim3(static_cast<uint32_t>(want)), dim3(256), 0, st,
                            data, offs, lens, n_long, n_msgs, digests, queue_heads, init_state, out_state,
                            raw_blocks_only);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_t* offs,
+                              const uint64_t* lens, const uint32_t* out_slot, uint64_t n_msgs,
+                              uint8_t* digests) {
+    if (n_msgs == 0) return hipSuccess;
+    hipLaunchKernelGGL(sha256_long_kernel, dim3(static_cast<uint32_t>((n_msgs + 63) / 64)), dim3(128), 0,
+                       st, data, offs, lens, out_slot, n_msgs, digests);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -49,10 +49,11 @@ def gather_and_merge(local, k: int, merge_fn):
             gathered[name] = t.unsqueeze(0)
         else:
             out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            if dist.get_backend() == "gloo":   # CPU tests: gloo has no flat all-gather
-                parts = [torch.empty_like(t) for _ in range(world)]
-                dist.all_gather(parts, t)
-                out = torch.stack(parts, 0)
+            if dist.get_backend() == "gloo":   # CPU tests / single-GPU dry runs: no flat all-gather
+                src = t.cpu() if t.is_cuda else t
+                parts = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(parts, src)
+                out = torch.stack(parts, 0).to(t.device)
             else:
                 dist.all_gather_into_tensor(out, t)
             gathered[name] = out
