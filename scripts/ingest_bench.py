@@ -26,6 +26,6 @@ for _ in range(a.reps):
 acc.synchronize(); dt = (time.perf_counter() - t0) / a.reps
 out = {"GBps": n_blobs * blen / dt / 1e9, "ms": dt * 1e3, "blobs": n_blobs, "blob_bytes": blen,
        "chunks": int(res.n_chunks), "flags": a.flags}
-for k in ("sha256", "cdc_candidates", "cdc_walk"):
+for k in ("sha256", "sha256_blobs", "cdc_candidates", "cdc_walk"):
     out[k + "_ms"] = acc.kernel_ms(k)[0]
 print(json.dumps(out))

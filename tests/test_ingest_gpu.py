@@ -127,7 +127,10 @@ def test_cdc_config_sweep(acc, oracle, mode):
                 dict(min_size=100, max_size=100), dict(min_size=300, max_size=200, mask=0xFF),
                 dict(min_size=1000, max_size=3000, mask=0xFFFFFFFFFFFFFFFF), dict(min_size=37, max_size=4001, mask=0x155, window=1),
                 dict(min_size=5000, max_size=9000, mask=0x3FF, window=7, polynomial=0xBFE6B8A5BF378D83),
-                dict(min_size=0, max_size=50, mask=1)]:
+                dict(min_size=0, max_size=50, mask=1),
+                # both sides of the 2^31 mask limit of the narrow (32-bit) candidate kernel, and mask 0
+                dict(min_size=8, max_size=5000, mask=0x7FFFFFFF), dict(min_size=8, max_size=5000, mask=0x80000000),
+                dict(min_size=8, max_size=5000, mask=0x40000001), dict(min_size=40, max_size=90, mask=0)]:
         _check_chunks(acc, oracle, small, mode, **cfg)
 
 

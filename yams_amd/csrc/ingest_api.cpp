@@ -90,14 +90,30 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     const bool fork_blobs = (flags & YAMS_INGEST_BLOB_DIGESTS) && n_blobs > 0;
     uint8_t* d_blob_digests = nullptr;
     if (fork_blobs) {
-        unsigned long long* d_head2;
-        YA_TRY(ws_get(ctx, "ing_queue_blobs", 64, (void**)&d_head2));
+        // Lanes of one workgroup advance in lock step, so messages are grouped by length
+        // (longest first); out_slot maps the sorted position back to the blob index.
+        std::vector<uint32_t> order(n_blobs);
+        for (uint32_t b = 0; b < n_blobs; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t x, uint32_t y) { return h_len[x] > h_len[y]; });
+        std::vector<uint64_t> sorted(static_cast<size_t>(n_blobs) * 2 + (static_cast<size_t>(n_blobs) + 1) / 2);
+        uint32_t* h_slot32 = reinterpret_cast<uint32_t*>(sorted.data() + static_cast<size_t>(n_blobs) * 2);
+        for (uint32_t i = 0; i < n_blobs; ++i) {
+            sorted[i] = h_off[order[i]];
+            sorted[static_cast<size_t>(n_blobs) + i] = h_len[order[i]];
+            h_slot32[i] = order[i];
+        }
+        uint64_t* d_sorted;
+        YA_TRY(ws_get(ctx, "ing_meta_blobs", sorted.size() * 8, (void**)&d_sorted));
+        YA_HIP(ctx, hipMemcpyAsync(d_sorted, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, st));
+        YA_HIP(ctx, hipStreamSynchronize(st)); // `sorted` is pageable and dies with this scope
         YA_TRY(ws_get(ctx, "ing_blob_digests", static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
         YA_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
         YA_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
         TimedRegion tr(ctx, "sha256_blobs", ctx->aux_stream);
-        YA_HIP(ctx, launch_sha256(ctx->aux_stream, data, d_off, d_len, n_blobs, n_blobs, d_blob_digests,
-                                  d_head2, nullptr, nullptr, 0, 4096, 1));
+        YA_HIP(ctx, launch_sha256_long(ctx->aux_stream, data, d_sorted, d_sorted + n_blobs,
+                                       reinterpret_cast<const uint32_t*>(d_sorted + static_cast<size_t>(n_blobs) * 2),
+                                       n_blobs, d_blob_digests));
         tr.end();
         YA_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
     }

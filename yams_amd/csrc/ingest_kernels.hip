@@ -13,10 +13,16 @@
 // (SURVEY.md F2).  Candidate detection is therefore a byte-parallel map: every thread warms the
 // recurrence up over the 8 positions before its span and then rolls forward.  Only the min/max
 // selection is sequential, over a sparse bitmap.  No MFMA anywhere: this is byte/integer work.
+#include <cstdlib>
+
 #include "common.h"
 #include "ingest_launch.h"
 
 namespace yams_accel {
+
+// 16 bytes with dword alignment only: lets the compiler emit global_load_dwordx4 on addresses that
+// are merely 4-byte aligned.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // ------------------------------------------------------------------------------------------------
 // K6a: candidate bitmap.  One workgroup = one piece (kCdcPiece bytes) of one blob.
@@ -129,6 +135,105 @@ __global__ __launch_bounds__(CDC_THREADS) void cdc_candidates_kernel(
     }
     uint4* dst = reinterpret_cast<uint4*>(bitmap + piece * (kCdcPiece / 32) + threadIdx.x * 4);
     *dst = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6b: candidate bitmap, narrow form (window == 48 and mask < 2^31 — the product defaults).
+// The match test only looks at the low bits of h, and subtraction, left shift and xor only carry
+// upward, so the low 32 bits of h follow the same recurrence on uint32_t and forget their history
+// after 4 steps.  One lane = one 32-byte unit = one bitmap word: it loads the unit and the 32 bytes
+// 48 behind it straight from global memory (consecutive lanes -> consecutive units, fully
+// coalesced; no data staging in LDS), realigns with v_alignbyte, warms up over 4 bytes and rolls.
+// Per byte: 2 LDS table reads + ~9 VALU, about half of the generic kernel above.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CDC_THREADS) void cdc_candidates_w48_kernel(
+    const uint8_t* data, const uint64_t* blob_off, const uint64_t* blob_len,
+    const uint64_t* piece_prefix, uint32_t n_blobs, CdcParams cp, uint32_t* bitmap) {
+    __shared__ uint32_t s_t32[256];
+    __shared__ uint32_t s_blob;
+    const uint64_t piece = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = n_blobs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (piece_prefix[mid] <= piece) lo = mid; else hi = mid;
+        }
+        s_blob = lo;
+    }
+    {
+        const int byte = threadIdx.x;
+        const uint32_t poly = static_cast<uint32_t>(cp.polynomial);
+        uint32_t hsh = 0;
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit)
+            if (byte & (1 << bit)) hsh ^= poly << bit;
+        s_t32[byte] = hsh;
+    }
+    __syncthreads();
+    const uint32_t b = s_blob;
+    const uint64_t blen = blob_len[b];
+    const uint64_t p0 = (piece - piece_prefix[b]) * kCdcPiece;
+    const uint8_t* bptr = data + blob_off[b];
+    const uint32_t mask = static_cast<uint32_t>(cp.mask);
+    uint32_t* out = bitmap + piece * (kCdcPiece / 32);
+
+#pragma unroll 1
+    for (int it = 0; it < kCdcPiece / 32 / CDC_THREADS; ++it) {
+        const uint32_t unit = it * CDC_THREADS + threadIdx.x;
+        const uint64_t pos = p0 + 32ull * unit;
+        uint32_t bits = 0;
+        if (pos >= 56 && pos + 36 <= blen) {
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(bptr + pos);
+            const uint32_t sh = static_cast<uint32_t>(addr & 3u);
+            const uint32_t* a = reinterpret_cast<const uint32_t*>(addr - sh);
+            uint32_t N[10], O[10];
+            N[0] = a[-1];
+            O[0] = a[-13];
+            {
+                const u32x4_a4 n0 = *reinterpret_cast<const u32x4_a4*>(a);
+                const u32x4_a4 n1 = *reinterpret_cast<const u32x4_a4*>(a + 4);
+                const u32x4_a4 o0 = *reinterpret_cast<const u32x4_a4*>(a - 12);
+                const u32x4_a4 o1 = *reinterpret_cast<const u32x4_a4*>(a - 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { N[1 + j] = n0[j]; N[5 + j] = n1[j]; O[1 + j] = o0[j]; O[5 + j] = o1[j]; }
+            }
+            N[9] = a[8];
+            O[9] = a[-4];
+            uint32_t n[9], o[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                n[j] = __builtin_amdgcn_alignbyte(N[j + 1], N[j], sh);
+                o[j] = __builtin_amdgcn_alignbyte(O[j + 1], O[j], sh);
+            }
+            uint32_t h = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                h = ((h - s_t32[(o[0] >> (8 * e)) & 0xffu]) << 8) ^ s_t32[(n[0] >> (8 * e)) & 0xffu];
+            uint32_t acc = 0; // first position ends up in bit 31
+#pragma unroll
+            for (int j = 1; j < 9; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h = ((h - s_t32[(o[j] >> (8 * e)) & 0xffu]) << 8) ^ s_t32[(n[j] >> (8 * e)) & 0xffu];
+                    const uint32_t x = ~h & mask;               // 0 iff every mask bit is set
+                    acc = __builtin_amdgcn_alignbit(acc, x - 1u, 31); // (acc << 1) | (x == 0)
+                }
+            }
+            bits = __builtin_bitreverse32(acc);
+        } else if (pos < blen) {
+            // units touching either end of the blob: bytes outside it read as zero
+            uint32_t h = 0;
+            for (int i = -4; i < 32; ++i) {
+                const int64_t q = static_cast<int64_t>(pos) + i;
+                const int64_t qo = q - 48;
+                const uint32_t nb = (q >= 0 && q < static_cast<int64_t>(blen)) ? bptr[q] : 0u;
+                const uint32_t ob = (qo >= 0 && qo < static_cast<int64_t>(blen)) ? bptr[qo] : 0u;
+                h = ((h - s_t32[ob]) << 8) ^ s_t32[nb];
+                if (i >= 0 && q < static_cast<int64_t>(blen) && (h & mask) == mask) bits |= 1u << i;
+            }
+        }
+        out[unit] = bits;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,7 +436,6 @@ __device__ __forceinline__ void sha256_compress_n(uint32_t st[NS][8], uint32_t w
 // request is its own cache-line access).  Nothing beyond the dword that holds the last message
 // byte is ever touched: a 16-byte piece that would cross it falls back to guarded dword loads
 // (only in the last block or two of a message).
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 struct ShaWindow { u32x4_a4 v[4]; uint32_t tail; };
 __device__ __forceinline__ void fetch_window(const uint8_t* p, const uint8_t* limit, ShaWindow& win) {
     const uint8_t* q = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~static_cast<uintptr_t>(3));
@@ -535,14 +639,18 @@ __global__ __launch_bounds__(256) void sha256_batch_kernel(const uint8_t* data,
 constexpr int LONG_LANE_STRIDE = 272;                  // bytes per lane per buffer: 64 words + pad,
                                                        // 68-word stride keeps ds_*_b128 conflict-free
 constexpr int LONG_BUF_BYTES = 64 * LONG_LANE_STRIDE;  // 17 408
-__global__ __launch_bounds__(128) void sha256_long_kernel(const uint8_t* data, const uint64_t* offs,
+constexpr int LONG_PAIRS = 2;                          // producer/consumer pairs per workgroup
+__global__ __launch_bounds__(128 * LONG_PAIRS) void sha256_long_kernel(const uint8_t* data, const uint64_t* offs,
                                                           const uint64_t* lens,
                                                           const uint32_t* out_slot /*nullable*/,
                                                           uint64_t n_msgs, uint8_t* digests) {
-    __shared__ __attribute__((aligned(16))) unsigned char kw_lds[2 * LONG_BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char kw_lds_all[LONG_PAIRS * 2 * LONG_BUF_BYTES];
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 = consumer, 1 = producer
-    const uint64_t m = static_cast<uint64_t>(blockIdx.x) * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave & 1; // 0 = consumer, 1 = producer; a pair sits on neighbouring SIMDs
+    const int pair = wave >> 1;
+    unsigned char* kw_lds = kw_lds_all + pair * (2 * LONG_BUF_BYTES);
+    const uint64_t m = (static_cast<uint64_t>(blockIdx.x) * LONG_PAIRS + pair) * 64 + lane;
     const bool have = m < n_msgs;
     const uint64_t total = have ? lens[m] : 0;
     // blocks this lane's message needs, padding included: data + 0x80 + 8-byte length
@@ -552,6 +660,13 @@ __global__ __launch_bounds__(128) void sha256_long_kernel(const uint8_t* data, c
     for (int d = 32; d >= 1; d >>= 1) {
         const uint64_t o = __shfl_xor(maxblk, d);
         maxblk = o > maxblk ? o : maxblk;
+    }
+    {   // the barrier count must agree across the whole workgroup: take the max over its pairs
+        __shared__ unsigned long long s_maxblk[2 * LONG_PAIRS];
+        if (lane == 0) s_maxblk[wave] = maxblk;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * LONG_PAIRS; ++i) maxblk = s_maxblk[i] > maxblk ? s_maxblk[i] : maxblk;
     }
     unsigned char* mybuf0 = kw_lds + lane * LONG_LANE_STRIDE;
 
@@ -676,9 +791,15 @@ hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint
                                  uint32_t n_blobs, uint64_t n_pieces, const CdcParams& cp,
                                  uint32_t* bitmap) {
     if (n_pieces == 0) return hipSuccess;
-    hipLaunchKernelGGL(cdc_candidates_kernel, dim3(static_cast<uint32_t>(n_pieces)),
-                       dim3(CDC_THREADS), 0, st, data, blob_off, blob_len, piece_prefix, n_blobs,
-                       cp, bitmap);
+    static const bool force_generic = getenv("YAMS_ACCEL_CDC_GENERIC") != nullptr;
+    if (cp.window == 48 && cp.mask < (1ull << 31) && !force_generic)
+        hipLaunchKernelGGL(cdc_candidates_w48_kernel, dim3(static_cast<uint32_t>(n_pieces)),
+                           dim3(CDC_THREADS), 0, st, data, blob_off, blob_len, piece_prefix, n_blobs,
+                           cp, bitmap);
+    else
+        hipLaunchKernelGGL(cdc_candidates_kernel, dim3(static_cast<uint32_t>(n_pieces)),
+                           dim3(CDC_THREADS), 0, st, data, blob_off, blob_len, piece_prefix, n_blobs,
+                           cp, bitmap);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -738,8 +859,8 @@ hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_
                               const uint64_t* lens, const uint32_t* out_slot, uint64_t n_msgs,
                               uint8_t* digests) {
     if (n_msgs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sha256_long_kernel, dim3(static_cast<uint32_t>((n_msgs + 63) / 64)), dim3(128), 0,
-                       st, data, offs, lens, out_slot, n_msgs, digests);
+    hipLaunchKernelGGL(sha256_long_kernel, dim3(static_cast<uint32_t>((n_msgs + 64 * LONG_PAIRS - 1) / (64 * LONG_PAIRS))),
+                       dim3(128 * LONG_PAIRS), 0, st, data, offs, lens, out_slot, n_msgs, digests);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -34,5 +34,10 @@ hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* of
                          const uint64_t* lens, uint64_t n_long, uint64_t n_msgs, uint8_t* digests,
                          unsigned long long* queue_heads, const uint32_t* init_state,
                          uint32_t* out_state, int raw_blocks_only, uint32_t max_blocks, int slots);
+// Long messages: two waves (schedule producer + round consumer) per 64 messages; digest of
+// message i is written to digests[32 * (out_slot ? out_slot[i] : i)].
+hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_t* offs,
+                              const uint64_t* lens, const uint32_t* out_slot, uint64_t n_msgs,
+                              uint8_t* digests);
 
 } // namespace yams_accel
