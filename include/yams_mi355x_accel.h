@@ -126,12 +126,21 @@ typedef struct yams_scan_corpus_s {
                                   (sqlite_vec_backend.cpp:4137-4175): masked-out rows are neither
                                   visited nor evaluated.  ceil(n_rows / 32) words.               */
     uint64_t row_mask_count;   /* number of set bits (the host built the mask, it knows)          */
+    const uint16_t* rows_bf16; /* device, nullable: the SHADOW of `rows` built by
+                                  yams_scan_build_shadow_device — [n_rows][dim] bf16 (round to
+                                  nearest even), 16-byte aligned.  Only the MFMA filter reads it
+                                  (half the bytes, no conversion in the loop); the fp64 re-score
+                                  that decides the result always reads `rows`.  Results are
+                                  bit-identical with and without it.                              */
+    const float* rows_nsq;     /* device, nullable iff rows_bf16 is: [n_rows] fp32 squared norms  */
 } yams_scan_corpus_t;
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
                                              caller applies it after merging per-shard lists)  */
 #define YAMS_SCAN_FLAG_FORCE_EXACT 2u     /* skip the MFMA filter, score every row in fp64       */
-#define YAMS_SCAN_FLAG_F32_FILTER 4u      /* use the exact-f32 MFMA filter instead of split-bf16 */
+#define YAMS_SCAN_FLAG_F32_FILTER 4u      /* use the exact-f32 MFMA filter instead of the bf16 ones */
+#define YAMS_SCAN_FLAG_SPLIT_FILTER 8u    /* start with the split-bf16 (3-pass) filter instead of
+                                             the single-pass bf16 one                            */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {
@@ -155,8 +164,16 @@ typedef struct yams_scan_diag_s {
     uint32_t widened_queries;             /* queries whose candidate set had to be widened       */
     uint32_t exact_fallback_queries;      /* queries that took the full fp64 scan                */
     uint32_t path;                        /* 0 = mfma filter + fp64 re-score, 1 = full fp64 scan */
-    uint32_t reserved;
+    uint32_t escalated_queries;           /* queries re-filtered with the split (3-pass) filter  */
 } yams_scan_diag_t;
+
+/* Builds the filter shadow of `n_rows` rows (call it when rows are uploaded or appended; pass
+ * pointers offset to the first new row to extend an existing shadow).  One pass: reads 4*dim bytes
+ * and writes 2*dim + 4 bytes per row.  dim must be a multiple of 4; rows 16-byte aligned. */
+YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, const float* rows,
+                                                           uint64_t n_rows, uint32_t dim,
+                                                           uint16_t* out_rows_bf16,
+                                                           float* out_rows_nsq);
 
 /* Batched exact top-k, everything device-resident.
  *   queries      device [n_queries][dim] fp32 (raw)

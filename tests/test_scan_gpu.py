@@ -10,30 +10,38 @@ import pytest
 
 import _cases
 from yams_amd import _lib
-from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER
 
 pytestmark = pytest.mark.gpu
 
 TOL = 0.0  # similarities must be bit-identical; the north_star tolerance would be 1e-5
 
 
-def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0):
+def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0,
+        shadow=True):
+    """shadow=True: the corpus view carries the bf16 filter shadow, as the plugin's device mirror
+    always does (plugin.cpp corpus_append); shadow=False: a bare fp32 view (flat C-ABI callers)."""
     corpus = np.ascontiguousarray(corpus, np.float32)
     dc = acc.to_device(corpus) if corpus.size else None
+    db = dn = None
+    if shadow and corpus.size and corpus.shape[1] % 4 == 0:
+        db, dn = acc.alloc(corpus.size * 2), acc.alloc(corpus.shape[0] * 4)
+        acc.build_shadow_device(dc.ptr, corpus.shape[0], corpus.shape[1], db.ptr, dn.ptr)
     dr = di = None
     if tie_rank is not None:
         inv = np.empty_like(tie_rank)
         inv[tie_rank] = np.arange(tie_rank.size, dtype=tie_rank.dtype)
         dr, di = acc.to_device(tie_rank.astype(np.uint32)), acc.to_device(inv.astype(np.uint32))
     view = acc.corpus_view(dc.ptr if dc else None, corpus.shape[0], corpus.shape[1],
-                           dr.ptr if dr else None, di.ptr if di else None, row_base)
+                           dr.ptr if dr else None, di.ptr if di else None, row_base,
+                           rows_bf16_ptr=db.ptr if db else None, rows_nsq_ptr=dn.ptr if dn else None)
     return acc.scan_topk(view, queries, k, thr, metric, flags)
 
 
 def check(acc, oracle, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None,
-          max_queries=None, expect_path=None):
+          max_queries=None, expect_path=None, shadow=True):
     queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
-    r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank)
+    r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank, shadow=shadow)
     if expect_path is not None:
         assert r.diag["path"] == expect_path, r.diag
     tr64 = None if tie_rank is None else tie_rank.astype(np.uint64)
@@ -184,16 +192,43 @@ def test_adversarial_rows_on_the_filter_path(acc, oracle):
     assert r.diag["path"] == 0
 
 
-def test_ties_beyond_the_candidate_budget_are_widened(acc, oracle):
-    """More identical rows than the first-stage candidate budget (k' = 96) but fewer than the
-    candidate list holds: stage 1 cannot prove completeness, stage 2 re-scores the whole list."""
+@pytest.mark.parametrize("flags,ties", [(0, 260), (FLAG_SPLIT_FILTER, 120)])
+def test_ties_beyond_the_candidate_budget_are_widened(acc, oracle, flags, ties):
+    """More identical rows than the first-stage candidate budget (k' = 224 for the single-pass
+    filter, 96 for the split filter at k = 50) but fewer than the candidate list holds: stage 1
+    cannot prove completeness, stage 2 re-scores the whole list."""
     n, d = 20000, 32
     corpus = oracle.synth_rows(10, 0, n, d)
     q = oracle.synth_rows(10, 1 << 40, 3, d)
-    corpus[100:20000:66][:120] = q[1]                       # 120 rows tie with similarity 1.0
+    corpus[100:20000:40][:ties] = q[1]                      # `ties` rows tie with similarity 1.0
     rank = np.random.default_rng(33).permutation(n).astype(np.uint32)
-    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0)
+    r = check(acc, oracle, corpus, q, 50, flags=flags, tie_rank=rank, expect_path=0)
     assert r.diag["widened_queries"] >= 1 and r.diag["exact_fallback_queries"] == 0
+    assert r.diag["escalated_queries"] == 0
+
+
+def test_crowded_top_escalates_to_the_split_filter(acc, oracle):
+    """3000 rows within 0.009 of each other at the top: far more than the single-pass filter
+    (bound 2^-7) can separate within its candidate budget, trivially separable for the split
+    filter (bound 6e-5).  The unproven queries are re-run through the split filter on the device;
+    nothing reaches the exhaustive scan and the other queries are untouched."""
+    n, d = 20000, 64
+    rng = np.random.default_rng(91)
+    corpus = oracle.synth_rows(12, 0, n, d)
+    q = oracle.synth_rows(12, 1 << 40, 5, d)
+    qu = (q[2] / np.linalg.norm(q[2])).astype(np.float64)
+    crowd = rng.choice(n, 3000, replace=False)
+    sims = np.linspace(0.990, 0.999, 3000)
+    for r_, s_ in zip(crowd, sims):
+        v = rng.standard_normal(d)
+        v -= (v @ qu) * qu
+        v /= np.linalg.norm(v)
+        corpus[r_] = (s_ * qu + np.sqrt(1.0 - s_ * s_) * v).astype(np.float32) * np.float32(rng.uniform(0.5, 2.0))
+    r = check(acc, oracle, corpus, q, 50, expect_path=0)
+    assert r.diag["escalated_queries"] >= 1 and r.diag["exact_fallback_queries"] == 0, r.diag
+    r3 = check(acc, oracle, corpus, q, 50, flags=FLAG_SPLIT_FILTER, expect_path=0)
+    assert r3.diag["escalated_queries"] == 0 and r3.diag["exact_fallback_queries"] == 0, r3.diag
+    check(acc, oracle, corpus, q, 50, metric=SCAN_L2, expect_path=0)
 
 
 def test_massive_ties_take_the_exhaustive_fp64_path(acc, oracle):
@@ -220,14 +255,22 @@ def test_sorted_corpus_defeats_the_sample_but_not_the_result(acc, oracle):
 
 
 @pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
-def test_both_filters_agree_with_the_oracle(acc, oracle, metric):
-    """The split-bf16 filter (default) and the exact-f32 filter are interchangeable: both are only
-    filters in front of the same fp64 re-score + proof."""
+def test_all_filters_agree_with_the_oracle(acc, oracle, metric):
+    """The single-pass bf16 filter (default), the split-bf16 filter and the exact-f32 filter are
+    interchangeable: all are only filters in front of the same fp64 re-score + proof."""
     corpus = oracle.synth_rows(16, 0, 70000, 256)
     q = oracle.synth_rows(16, 1 << 40, 300, 256)          # > 256 queries: two bf16 query tiles
     a = check(acc, oracle, corpus, q, 50, metric=metric, max_queries=12, expect_path=0)
     b = check(acc, oracle, corpus, q, 50, metric=metric, flags=FLAG_F32_FILTER, max_queries=12, expect_path=0)
+    c = check(acc, oracle, corpus, q, 50, metric=metric, flags=FLAG_SPLIT_FILTER, max_queries=12, expect_path=0)
     assert np.array_equal(a.rows, b.rows) and np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
+    assert np.array_equal(a.rows, c.rows) and np.array_equal(a.scores.view(np.uint32), c.scores.view(np.uint32))
+    assert c.diag["exact_fallback_queries"] == 0 and a.diag["escalated_queries"] == 0
+    # without the shadow the single-pass filter converts the fp32 rows in its loop
+    p = check(acc, oracle, corpus, q, 50, metric=metric, max_queries=12, expect_path=0, shadow=False)
+    assert np.array_equal(a.rows, p.rows) and np.array_equal(a.scores.view(np.uint32), p.scores.view(np.uint32))
+    # dim 240 (multiple of 16, not of 32) takes the 16-wide-slab form of the single-pass kernel
+    check(acc, oracle, corpus[:30000, :240].copy(), q[:40, :240].copy(), 20, metric=metric, max_queries=6, expect_path=0)
     assert a.diag["exact_fallback_queries"] == 0 and b.diag["exact_fallback_queries"] == 0
 
 
@@ -368,7 +411,14 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     c = torch.empty(nq, dtype=torch.int32, device="cuda")
     dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-    view = acc.corpus_view(tc.data_ptr(), n, d)
+    tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    tn = torch.empty(n, dtype=torch.float32, device="cuda")
+    acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
+    acc.synchronize()
+    # the shadow is exactly the RNE bf16 of the rows and their squared norms
+    assert torch.equal(tb[:4096], tc[:4096].to(torch.bfloat16))
+    assert torch.allclose(tn[:4096], (tc[:4096].double() ** 2).sum(-1).float(), rtol=1e-5)
+    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
     diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(),
                                 c.data_ptr(), dist.data_ptr())
     assert diag["path"] == 0 and diag["exact_fallback_queries"] == 0

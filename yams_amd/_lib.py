@@ -18,7 +18,7 @@ YAMS_OK, YAMS_ERR_INVALID_ARG, YAMS_ERR_NOT_FOUND, YAMS_ERR_IO, YAMS_ERR_INTERNA
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NOT_FOUND", 3: "IO", 4: "INTERNAL", 5: "UNSUPPORTED"}
 SCAN_COSINE, SCAN_L2 = 0, 1
 CDC_RABIN, CDC_STREAMING = 0, 1
-FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER = 1, 2, 4
+FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER = 1, 2, 4, 8
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2
 
 vp = C.c_void_p
@@ -32,7 +32,8 @@ f32p = C.POINTER(C.c_float)
 class ScanCorpus(C.Structure):
     _fields_ = [("rows", vp), ("n_rows", C.c_uint64), ("dim", C.c_uint32), ("reserved", C.c_uint32),
                 ("tie_rank", vp), ("rank_row", vp), ("row_base", C.c_int64),
-                ("row_mask", vp), ("row_mask_count", C.c_uint64)]
+                ("row_mask", vp), ("row_mask_count", C.c_uint64),
+                ("rows_bf16", vp), ("rows_nsq", vp)]
 
 
 class ScanParams(C.Structure):
@@ -46,7 +47,7 @@ class ScanDiag(C.Structure):
                 ("returned_rows", C.c_uint64), ("filter_candidates", C.c_uint64),
                 ("rescored_rows", C.c_uint64), ("widened_queries", C.c_uint32),
                 ("exact_fallback_queries", C.c_uint32), ("path", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("escalated_queries", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -129,6 +130,7 @@ EXPORTS = [
     "yams_accel_free_string", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device",
+    "yams_scan_build_shadow_device",
     "yams_synth_rows_device", "yams_synth_bytes_device", "yams_sha256_batch_device",
     "yams_sha256_host", "yams_sha256_many_host", "yams_cdc_default_config",
     "yams_cdc_chunk_device", "yams_ingest_device", "yams_cdc_chunk_host",
@@ -185,6 +187,7 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
                                         C.POINTER(ScanDiag)]
     L.yams_scan_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32,
                                       C.POINTER(ScanParams), vp, vp, vp, vp, C.POINTER(ScanDiag)]
+    L.yams_scan_build_shadow_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
     L.yams_scan_merge_topk_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]

@@ -131,9 +131,16 @@ class Accel:
     # ---- exact vector scan --------------------------------------------------------------------
     def corpus_view(self, rows_ptr: int, n_rows: int, dim: int, tie_rank_ptr: int | None = None,
                     rank_row_ptr: int | None = None, row_base: int = 0,
-                    row_mask_ptr: int | None = None, row_mask_count: int = 0) -> ScanCorpus:
+                    row_mask_ptr: int | None = None, row_mask_count: int = 0,
+                    rows_bf16_ptr: int | None = None, rows_nsq_ptr: int | None = None) -> ScanCorpus:
         return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base,
-                          row_mask_ptr, row_mask_count)
+                          row_mask_ptr, row_mask_count, rows_bf16_ptr, rows_nsq_ptr)
+
+    def build_shadow_device(self, rows_ptr: int, n_rows: int, dim: int, out_bf16_ptr: int,
+                            out_nsq_ptr: int) -> None:
+        """Filter shadow of the rows (bf16 RNE copy + fp32 squared norms); asynchronous."""
+        self._check(self.L.yams_scan_build_shadow_device(self.ctx, rows_ptr, n_rows, dim,
+                                                         out_bf16_ptr, out_nsq_ptr))
 
     def scan_topk_device(self, corpus: ScanCorpus, queries_ptr: int, nq: int, k: int,
                          threshold: float, metric: int, out_scores: int, out_rows: int,

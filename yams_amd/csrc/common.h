@@ -66,6 +66,7 @@ struct ScanPlan {
     uint32_t n_groups = 0;       // sample_rows / kGroupRows
     uint32_t list_cap = 0;       // per-query candidate list capacity
     uint32_t kprime = 0;         // candidates re-scored per query in stage 1
+    uint32_t tau_rank = 0;       // tau = the tau_rank-th best sample group maximum
 };
 
 } // namespace yams_accel

@@ -30,6 +30,8 @@ struct Corpus {
     uint32_t dim = 0;
     uint64_t n_rows = 0, cap_rows = 0;
     float* d_rows = nullptr;
+    uint16_t* d_bf16 = nullptr; // filter shadow of d_rows (same capacity), kept in step by corpus_append
+    float* d_nsq = nullptr;
     uint32_t* d_tie = nullptr;
     uint32_t* d_inv = nullptr;
 };
@@ -63,6 +65,8 @@ int parse_device(const char* json) {
 
 void free_corpus(Corpus& c) {
     if (c.d_rows) (void)hipFree(c.d_rows);
+    if (c.d_bf16) (void)hipFree(c.d_bf16);
+    if (c.d_nsq) (void)hipFree(c.d_nsq);
     if (c.d_tie) (void)hipFree(c.d_tie);
     if (c.d_inv) (void)hipFree(c.d_inv);
     c = Corpus{};
@@ -101,10 +105,30 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
             (void)hipGetLastError(); (void)hipFree(nd); return YAMS_ERR_INTERNAL;
         }
         if (c.d_rows) (void)hipFree(c.d_rows);
-        c.d_rows = nd; c.cap_rows = cap;
+        c.d_rows = nd;
+        if ((c.dim & 3u) == 0) { // the shadow grows with the mirror
+            uint16_t* nb = nullptr; float* nn = nullptr;
+            if (hipMalloc(&nb, cap * c.dim * sizeof(uint16_t)) != hipSuccess || hipMalloc(&nn, cap * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError(); if (nb) (void)hipFree(nb); return YAMS_ERR_INTERNAL;
+            }
+            if (c.n_rows && (hipMemcpy(nb, c.d_bf16, c.n_rows * c.dim * sizeof(uint16_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+                             hipMemcpy(nn, c.d_nsq, c.n_rows * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess)) {
+                (void)hipGetLastError(); (void)hipFree(nb); (void)hipFree(nn); return YAMS_ERR_INTERNAL;
+            }
+            if (c.d_bf16) (void)hipFree(c.d_bf16);
+            if (c.d_nsq) (void)hipFree(c.d_nsq);
+            c.d_bf16 = nb; c.d_nsq = nn;
+        }
+        c.cap_rows = cap;
     }
     if (hipMemcpy(c.d_rows + c.n_rows * c.dim, rows, n_rows * c.dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError(); return YAMS_ERR_INTERNAL;
+    }
+    if (c.d_bf16) {
+        if (yams_scan_build_shadow_device(g.ctx, c.d_rows + c.n_rows * c.dim, n_rows, c.dim,
+                                          c.d_bf16 + c.n_rows * c.dim, c.d_nsq + c.n_rows) != YAMS_OK ||
+            yams_accel_ctx_synchronize(g.ctx) != YAMS_OK)
+            return YAMS_ERR_INTERNAL;
     }
     c.n_rows = need;
     // appended rows invalidate a previously supplied chunk_id ranking
@@ -190,6 +214,7 @@ yams_status_t vs_search_batch_masked(void*, uint64_t id, const float* queries, u
     yams_scan_corpus_t view{};
     view.rows = c.d_rows; view.n_rows = c.n_rows; view.dim = c.dim;
     view.tie_rank = c.d_tie; view.rank_row = c.d_inv; view.row_base = 0;
+    view.rows_bf16 = c.d_bf16; view.rows_nsq = c.d_bf16 ? c.d_nsq : nullptr;
     if (row_mask_host && c.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175)
         const size_t words = (c.n_rows + 31) / 32;
         uint64_t bits = 0;

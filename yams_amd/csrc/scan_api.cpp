@@ -23,14 +23,18 @@ constexpr uint64_t kExactKeyBudget = 1ull << 31; // bytes of fp64-path keys per 
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16) {
+// passes: MFMA passes of the filter (0 = exact f32 kernel, 1 = RNE bf16, 3 = split bf16).  A looser
+// filter needs more candidates re-scored before the proof can succeed, not a different threshold.
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes) {
     ScanPlan p;
     p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
     p.tile_rows = bf16 ? 256 : kTileRows;
     p.tile_queries = bf16 ? 256 : kTileQueries;
     p.n_tiles = static_cast<uint32_t>((n_rows + p.tile_rows - 1) / p.tile_rows);
     p.n_qtiles = (nq + p.tile_queries - 1) / p.tile_queries;
-    p.kprime = std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
+    p.kprime = (passes == 1)
+                   ? std::min<uint32_t>(round_up(3 * k + 64, 32), kRescoreMax)
+                   : std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
     const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 16, 8192));
     uint32_t want_tiles = static_cast<uint32_t>((s_target + p.tile_rows - 1) / p.tile_rows);
     if (want_tiles == 0) want_tiles = 1;
@@ -39,8 +43,13 @@ ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool 
     p.n_filter_tiles = p.n_tiles - p.n_sample_tiles;
     p.sample_rows = static_cast<uint64_t>(p.n_sample_tiles) * p.tile_rows;
     p.n_groups = static_cast<uint32_t>(p.sample_rows / kGroupRows);
-    uint64_t cap = std::max<uint64_t>(4096, 8ull * p.kprime * p.sample_stride);
-    if (p.n_groups < p.kprime) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
+    // tau = the tau_rank-th best sample value, i.e. about the (tau_rank * stride)-th best overall:
+    // the lists must hold comfortably more than the kprime candidates stage 1 wants
+    const uint32_t base_rank = round_up(k + std::max<uint32_t>(16, k / 4), 32);
+    const uint32_t need_rank = (p.kprime + p.kprime / 4 + 32 + p.sample_stride - 1) / p.sample_stride;
+    p.tau_rank = std::min<uint32_t>(std::max(base_rank, round_up(need_rank, 32)), kRescoreMax);
+    uint64_t cap = std::max<uint64_t>(4096, 8ull * p.tau_rank * p.sample_stride);
+    if (p.n_groups < p.tau_rank) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
     cap = std::min<uint64_t>(cap, std::max<uint64_t>(n_rows, 4096));
     p.list_cap = round_up(static_cast<uint32_t>(cap), 256);
     return p;
@@ -107,15 +116,11 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
     return YAMS_OK;
 }
 
-} // namespace
-
-extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
-                                               const yams_scan_corpus_t* corpus,
-                                               const float* queries, uint32_t n_queries,
-                                               const yams_scan_params_t* params, float* out_scores,
-                                               int64_t* out_rows, uint32_t* out_counts,
-                                               float* out_dist, uint32_t* out_ranks,
-                                               yams_scan_diag_t* diag) {
+// split_only: this is the escalation run of a batch whose single-pass filter left queries unproven.
+yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, const float* queries,
+                        uint32_t n_queries, const yams_scan_params_t* params, float* out_scores,
+                        int64_t* out_rows, uint32_t* out_counts, float* out_dist,
+                        uint32_t* out_ranks, yams_scan_diag_t* diag, bool split_only) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
     if (!corpus || !params) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus/params");
     if (diag) std::memset(diag, 0, sizeof(*diag));
@@ -139,6 +144,8 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
     if (corpus->n_rows > 0 && !corpus->rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus rows");
     if ((corpus->tie_rank == nullptr) != (corpus->rank_row == nullptr))
         return fail(ctx, YAMS_ERR_INVALID_ARG, "tie_rank and rank_row must be given together");
+    if ((corpus->rows_bf16 == nullptr) != (corpus->rows_nsq == nullptr))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "rows_bf16 and rows_nsq must be given together");
     if (corpus->row_mask && corpus->row_mask_count > corpus->n_rows)
         return fail(ctx, YAMS_ERR_INVALID_ARG, "row_mask_count exceeds n_rows");
     (void)hipSetDevice(ctx->device);
@@ -184,8 +191,9 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
             if (!(h_qnup[i] < 1e15f) || (h_qnup[i] != 0.f && h_qnup[i] < 1e-15f)) use_mfma = false;
     }
 
-    uint64_t filter_candidates = 0;
-    uint32_t widened = 0, exact_fb = 0;
+    uint64_t filter_candidates = 0, rescored_nested = 0;
+    uint32_t widened = 0, exact_fb = 0, escalated = 0;
+    std::vector<uint32_t> flags_keep; // h_flags survives a nested (escalation) call through this copy
     if (!use_mfma) {
         const uint32_t* d_rows_sel = nullptr;
         uint64_t n_sel = 0;
@@ -205,27 +213,43 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipStreamSynchronize(st));
         if (diag) diag->path = 1;
     } else {
-        // split-bf16 filter (3 MFMA passes at the bf16 rate) unless the caller asks for exact f32
+        // bf16 matrix-core filter unless the caller asks for exact f32.  One RNE-bf16 pass is the
+        // default: a third of the matrix work of the split filter for a looser bound (2^-7 |x||q|),
+        // paid for by re-scoring ~3k instead of ~1.25k candidates per query.  Large k (where the
+        // extra candidates would not fit the re-score stage) and escalation runs use the split filter.
         const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 15u) == 0;
-        // measurement knob (never set by the product path)
+        // measurement knobs (never set by the product path)
         const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL");
         const int bf16_version = kv ? std::atoi(kv) : 2; // 12 = staging-only ablation (perf measurement only)
-        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16);
+        const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES");
+        int passes = 0;
+        if (bf16) {
+            passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || k > 256) ? 3 : 1;
+            if (pv && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
+        }
+        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes);
         ScanLaunch L;
-        L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask; L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
+        L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
+        if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
+            L.rows_bf16 = corpus->rows_bf16; L.rows_nsq = corpus->rows_nsq; // used by the single-pass kernel
+        } L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
         //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + the split residue:
         //               corpus head truncated (tail error 2^-16), query split RNE (2^-18), lo*lo dropped (2^-16)
         const double u24 = 5.9604644775390625e-8;
-        const double dot_rel = bf16 ? (6.0 * dim + 64.0) * u24 + 3.0 / 65536.0 : (dim + 8.0) * u24;
+        //   RNE bf16  : both operands rounded to 8 significant bits (u = 2^-8 each): |x^q^ - xq| <=
+        //               (2u + u^2)|x||q| summed with Cauchy-Schwarz, + dim fp32 accumulations (x2)
+        const double dot_rel = passes == 3   ? (6.0 * dim + 64.0) * u24 + 3.0 / 65536.0
+                               : passes == 1 ? (2.0 * dim + 64.0) * u24 + 2.0 / 256.0 + 2.0 / 65536.0
+                                             : (dim + 8.0) * u24;
         L.err_coef = static_cast<float>(dot_rel * 1.01);
         if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
             YA_TRY(ws_get(ctx, "q_hi", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qhi));
-            YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qlo));
-            YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, d_qhi, d_qlo));
+            YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qlo)); // unused by the 1-pass kernel
+            YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, bf16_slab_k(passes, dim), d_qhi, d_qlo));
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
         float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
@@ -235,7 +259,7 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_TRY(ws_get(ctx, "lcount", static_cast<size_t>(nq) * 4, (void**)&d_lcount));
         YA_TRY(ws_get(ctx, "list", static_cast<size_t>(nq) * plan.list_cap * 8, (void**)&d_list));
         const uint32_t gchunks = (plan.n_groups + kSelectCap - 1) / kSelectCap;
-        YA_TRY(ws_get(ctx, "work32", static_cast<size_t>(2) * nq * std::max(1u, gchunks) * plan.kprime * 4, (void**)&d_work32));
+        YA_TRY(ws_get(ctx, "work32", static_cast<size_t>(2) * nq * std::max(1u, gchunks) * plan.tau_rank * 4, (void**)&d_work32));
         const uint32_t lchunks = (plan.list_cap + kSelectCap - 1) / kSelectCap;
         const uint32_t keep_max = kRescoreMax + 1;
         YA_TRY(ws_get(ctx, "work64", static_cast<size_t>(2) * nq * lchunks * keep_max * 8, (void**)&d_work64));
@@ -243,14 +267,19 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
 
         { TimedRegion tr(ctx, "scan_sample");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         YA_HIP(ctx, launch_collect_sample(st, L));
         { TimedRegion tr(ctx, "scan_filter");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
+          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
 
+        if (bf16_version != 2) { // ablated measurement kernels produce no candidates: stop here
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
+            return YAMS_OK;
+        }
         // stage 1: re-score the best kprime filter survivors of every query
         // cosine: |s32 - cos| <= dot_rel + norm (dim/2 u) + rsqrt/product/unit-query rounding
         const double err_bound = (metric == YAMS_SCAN_COSINE)
@@ -298,10 +327,48 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
             for (uint32_t q : failed) if (h_status[q] != 0) still.push_back(q);
             failed.swap(still);
         }
+        if (!failed.empty() && passes == 1) {
+            // stage 2b: precision escalation.  The unproven queries become their own small batch
+            // under the split (3-pass) filter, whose bound is ~170x tighter; that run widens and
+            // falls back to the exhaustive scan on its own.  Results are scattered back.
+            escalated = static_cast<uint32_t>(failed.size());
+            flags_keep.assign(h_flags, h_flags + nq);
+            unsigned long long h_stat0 = 0;
+            YA_HIP(ctx, hipMemcpyAsync(&h_stat0, d_stat, 8, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            rescored_nested = h_stat0;
+            const size_t ns = failed.size(), kk = k;
+            float* s_q; float* s_scores; int64_t* s_rows; uint32_t* s_counts; float* s_dist = nullptr;
+            uint32_t* s_ranks = nullptr; uint32_t* d_submap;
+            YA_TRY(ws_get(ctx, "sub_queries", ns * dim * 4, (void**)&s_q));
+            YA_TRY(ws_get(ctx, "sub_scores", ns * kk * 4, (void**)&s_scores));
+            YA_TRY(ws_get(ctx, "sub_rows", ns * kk * 8, (void**)&s_rows));
+            YA_TRY(ws_get(ctx, "sub_counts", ns * 4, (void**)&s_counts));
+            if (out_dist) YA_TRY(ws_get(ctx, "sub_dist", ns * kk * 4, (void**)&s_dist));
+            if (out_ranks) YA_TRY(ws_get(ctx, "sub_ranks", ns * kk * 4, (void**)&s_ranks));
+            YA_TRY(ws_get(ctx, "sub_qmap", ns * 4, (void**)&d_submap));
+            YA_HIP(ctx, hipMemcpyAsync(d_submap, failed.data(), ns * 4, hipMemcpyHostToDevice, st));
+            YA_HIP(ctx, launch_gather_queries(st, queries, d_submap, escalated, dim, s_q));
+            YA_HIP(ctx, hipStreamSynchronize(st)); // `failed` is pageable
+            yams_scan_diag_t sub{};
+            YA_TRY(scan_impl(ctx, corpus, s_q, escalated, params, s_scores, s_rows, s_counts, s_dist,
+                             s_ranks, &sub, true));
+            YA_HIP(ctx, launch_scatter_results(st, d_submap, escalated, k, s_scores, s_rows, s_counts,
+                                               s_dist, s_ranks, out_scores, out_rows, out_counts,
+                                               out_dist, out_ranks));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            filter_candidates += sub.filter_candidates;
+            rescored_nested += sub.rescored_rows;
+            widened += sub.widened_queries;
+            exact_fb += sub.exact_fallback_queries;
+            failed.clear();
+            // the nested call reused the workspace: d_stat now counts only its rows (added above)
+            YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
+        }
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {
             // stage 3: exhaustive fp64 for the queries that could not be proven complete
-            exact_fb = static_cast<uint32_t>(failed.size());
+            exact_fb += static_cast<uint32_t>(failed.size());
             YA_TRY(run_exact(ctx, io, d_qnorm, &failed, d_status, d_stat));
             YA_HIP(ctx, hipStreamSynchronize(st));
         }
@@ -309,7 +376,7 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
 
     // ---- query validity (:4127-4130): a batch fails as a whole (:1635-1647) ---------------------
     for (uint32_t i = 0; i < nq; ++i) {
-        const uint32_t f = h_flags[i];
+        const uint32_t f = flags_keep.empty() ? h_flags[i] : flags_keep[i];
         const bool bad = (metric == YAMS_SCAN_COSINE) ? (f != 0) : ((f & 1u) != 0);
         if (bad)
             return fail(ctx, YAMS_ERR_INVALID_ARG,
@@ -329,10 +396,40 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         for (uint32_t i = 0; i < nq; ++i) ret += h_counts[i];
         diag->returned_rows = ret;
         diag->filter_candidates = filter_candidates;
-        diag->rescored_rows = h_stat;
+        diag->rescored_rows = h_stat + rescored_nested;
         diag->widened_queries = widened;
         diag->exact_fallback_queries = exact_fb;
+        diag->escalated_queries = escalated;
     }
+    return YAMS_OK;
+}
+
+} // namespace
+
+extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
+                                               const yams_scan_corpus_t* corpus,
+                                               const float* queries, uint32_t n_queries,
+                                               const yams_scan_params_t* params, float* out_scores,
+                                               int64_t* out_rows, uint32_t* out_counts,
+                                               float* out_dist, uint32_t* out_ranks,
+                                               yams_scan_diag_t* diag) {
+    return scan_impl(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts,
+                     out_dist, out_ranks, diag, false);
+}
+
+extern "C" yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, const float* rows,
+                                                       uint64_t n_rows, uint32_t dim,
+                                                       uint16_t* out_rows_bf16, float* out_rows_nsq) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (n_rows == 0) return YAMS_OK;
+    if (!rows || !out_rows_bf16 || !out_rows_nsq) return fail(ctx, YAMS_ERR_INVALID_ARG, "null shadow buffers");
+    if (dim == 0 || (dim & 3u) || (reinterpret_cast<uintptr_t>(rows) & 15u) ||
+        (reinterpret_cast<uintptr_t>(out_rows_bf16) & 7u))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "shadow needs dim % 4 == 0 and 16-byte aligned rows");
+    (void)hipSetDevice(ctx->device);
+    TimedRegion tr(ctx, "shadow_build");
+    YA_HIP(ctx, launch_shadow_build(ctx->stream, rows, n_rows, dim, out_rows_bf16, out_rows_nsq));
+    tr.end();
     return YAMS_OK;
 }
 

@@ -8,6 +8,8 @@ enum { MODE_SAMPLE = 0, MODE_FILTER = 1 };
 
 struct ScanArgs {
     const float* rows;      // [n_rows][dim]
+    const uint16_t* rows_bf16; // nullable shadow: [n_rows][dim] RNE bf16 of rows
+    const float* rows_nsq;     // with it: [n_rows] fp32 squared norms
     const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
     const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
     const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)

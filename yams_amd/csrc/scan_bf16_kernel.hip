@@ -13,6 +13,8 @@
 // fp32 (that is the input contract) and split on the VALU at fragment time; queries are split once
 // per batch by prep_split_kernel into k-slab-major bf16 planes.  (A first, register-staged version
 // of this kernel is in the history of this file; the measurements that replaced it are below.)
+#include <type_traits>
+
 #include "scan_args.h"
 
 namespace yams_accel {
@@ -23,6 +25,124 @@ using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BT_ROWS = 256, BT_QUERIES = 256, BT_THREADS = 512;
+
+// Shared epilogue of the bf16 filter kernels: norms -> scores, allow-mask, then either the sample
+// outputs (dense scores + group maxima) or the threshold test + candidate append.
+// One call handles a block of 32 rows x (32 * NCB) queries held by one wave:
+// acc[u][r] = dot(row row0 + row_in_tile + (r&3) + 8(r>>2) + 4h, query q0 + 32u + l31); nfull = the
+// fp32 squared norm of row (lane & 31) of the block.
+template <int MODE, int METRIC, int ABL, int NCB>
+__device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[NCB], float nfull,
+                                              uint64_t row0, uint32_t row_in_tile, uint32_t q0,
+                                              uint32_t sel, int h, int l31) {
+    if (ABL != 0) { // measurement builds: keep the accumulators alive, emit nothing
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < NCB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[u][r];
+        if (t + nfull == 12345.678f && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        return;
+    }
+    // ---- epilogue ------------------------------------------------------------------------------
+    uint32_t qidx[NCB];
+    bool qok[NCB];
+    float qn_up[NCB];
+#pragma unroll
+    for (int u = 0; u < NCB; ++u) {
+        qidx[u] = q0 + u * 32 + l31;
+        qok[u] = qidx[u] < a.n_queries;
+        qn_up[u] = (METRIC == YAMS_SCAN_L2 && qok[u]) ? a.qnorm_up[qidx[u]] : 0.f;
+    }
+    {
+        float p0, p1 = 0.f;
+        const bool ok = norm_in_range(nfull);
+        if (METRIC == YAMS_SCAN_COSINE) {
+            p0 = ok ? rsqrtf(nfull) : __builtin_nanf("");
+        } else {
+            p0 = ok ? nfull * (-0.5f + 0.5f * a.err_coef) : __builtin_nanf("");
+            p1 = ok ? a.err_coef * sqrtf(nfull) * 1.000001f : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float rp0 = __shfl(p0, i);
+            if (METRIC == YAMS_SCAN_COSINE) {
+#pragma unroll
+                for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] * rp0;
+            } else {
+                const float rp1 = __shfl(p1, i);
+#pragma unroll
+                for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] + rp0 + rp1 * qn_up[u];
+            }
+        }
+    }
+
+    const uint64_t wave_row0 = row0 + row_in_tile;
+    if (a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
+        const uint32_t mw = mask_word(a.row_mask, wave_row0, a.n_rows);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (!((mw >> i) & 1u)) {
+#pragma unroll
+                for (int u = 0; u < NCB; ++u) acc[u][r] = -__builtin_inff();
+            }
+        }
+    }
+    if (MODE == MODE_SAMPLE) {
+        const float ninf = -__builtin_inff();
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) {
+            float m = ninf;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint64_t rbase = wave_row0 + 8 * g4 + 4 * h;
+                float4 v;
+                v.x = (rbase + 0 < a.n_rows) ? acc[u][4 * g4 + 0] : ninf;
+                v.y = (rbase + 1 < a.n_rows) ? acc[u][4 * g4 + 1] : ninf;
+                v.z = (rbase + 2 < a.n_rows) ? acc[u][4 * g4 + 2] : ninf;
+                v.w = (rbase + 3 < a.n_rows) ? acc[u][4 * g4 + 3] : ninf;
+                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                if (qok[u]) {
+                    const uint64_t srow = static_cast<uint64_t>(sel) * BT_ROWS + row_in_tile + 8 * g4 + 4 * h;
+                    *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
+                }
+            }
+            if (qok[u]) {
+                const uint32_t gid = (sel * BT_ROWS + row_in_tile) / 16u + h;
+                a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = f2ord(m);
+            }
+        }
+    } else {
+        float tau[NCB];
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) tau[u] = (qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff();
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < NCB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) any |= !(acc[u][r] < tau[u]);
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < NCB; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sc = acc[u][r];
+                    if (!(sc < tau[u])) {
+                        const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < a.n_rows && qok[u]) {
+                            const uint32_t pos = atomicAdd(&a.list_count[qidx[u]], 1u);
+                            if (pos < a.list_cap)
+                                a.list[static_cast<uint64_t>(qidx[u]) * a.list_cap + pos] =
+                                    pack_key(sc, static_cast<uint32_t>(row));
+                        }
+                    }
+                }
+        }
+    }
+}
+
 // =================================================================================================
 // v2: LDS-DMA staged, 4-deep ring, one A tile per wave.
 //
@@ -44,8 +164,9 @@ constexpr int BT_ROWS = 256, BT_QUERIES = 256, BT_THREADS = 512;
 constexpr int V2_K = 16, V2_NST = 4;
 constexpr int V2_A_BYTES = BT_ROWS * V2_K * 4;          // raw fp32 rows: 64 B per row
 constexpr int V2_B_BYTES = BT_QUERIES * V2_K * 2;       // one bf16 plane: 32 B per row
-constexpr int V2_STAGE = V2_A_BYTES + 2 * V2_B_BYTES;   // 32 KiB
-static_assert(V2_STAGE == 32768, "stage size");
+// stage = raw A rows + PASSES==3 ? (query head + tail planes) : (query head plane)
+constexpr int v2_stage_bytes(int passes) { return V2_A_BYTES + (passes == 3 ? 2 : 1) * V2_B_BYTES; }
+static_assert(v2_stage_bytes(3) == 32768 && v2_stage_bytes(1) == 24576, "stage size");
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
@@ -55,10 +176,14 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// ABL is a measurement knob (never set by the product path): 1 = no DMA refills after the prologue
-// (compute-only time), 2 = no MFMAs (staging-only time); the epilogue then appends nothing.
-template <int MODE, int METRIC, int ABL = 0>
+// ABL is a measurement knob (never set by the product path): 2 = no MFMAs (staging-only time);
+// the epilogue then appends nothing.
+// PASSES: 3 = split operands, hi*hi + hi*lo + lo*hi (error ~2^-14.4 |x||q|);
+//         1 = RNE bf16 operands, one MFMA pass (error ~2^-7 |x||q|: more candidates to re-score,
+//             a third of the matrix work and no tail plane in LDS).
+template <int MODE, int METRIC, int PASSES, int ABL = 0>
 __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16v2_kernel(ScanArgs a) {
+    constexpr int V2_STAGE = v2_stage_bytes(PASSES);
     __shared__ __attribute__((aligned(16))) unsigned char lds[V2_NST * V2_STAGE];
 
     const uint32_t bid = blockIdx.x;
@@ -105,7 +230,8 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16v2_kernel(ScanAr
         lds_dma16(srcA[0] + kb * 4, __builtin_amdgcn_readfirstlane(st + (wid * 2 + 0) * 1024));
         lds_dma16(srcA[1] + kb * 4, __builtin_amdgcn_readfirstlane(st + (wid * 2 + 1) * 1024));
         lds_dma16(srcBh + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + V2_A_BYTES + wid * 1024));
-        lds_dma16(srcBl + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + V2_A_BYTES + V2_B_BYTES + wid * 1024));
+        if (PASSES == 3)
+            lds_dma16(srcBl + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + V2_A_BYTES + V2_B_BYTES + wid * 1024));
     };
 
     f32x16 acc[8];
@@ -135,11 +261,18 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16v2_kernel(ScanAr
     }
     for (int s = 0; s < nslab; ++s) {
         const int rem = nslab - 1 - s; // slabs issued after s that may still be in flight: min(2, rem)
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // DMA instructions per slab: 4 (PASSES == 3) or 3
+        if (PASSES == 3) {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (ABL != 1 && s + 3 < nslab) issue(s + 3); // refills the stage every wave finished reading last iteration
+        if (s + 3 < nslab) issue(s + 3); // refills the stage every wave finished reading last iteration
         const unsigned char* base = lds + (s & (V2_NST - 1)) * V2_STAGE;
         // A: 8 raw floats -> head (truncated upper halves, packed by v_perm) + tail (RNE of the remainder)
         const u32x4 x0 = *reinterpret_cast<const u32x4*>(base + offA[0]);
@@ -148,155 +281,508 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16v2_kernel(ScanAr
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             bhi[u] = *reinterpret_cast<const bf16x8*>(base + offB[u]);
-            blo[u] = *reinterpret_cast<const bf16x8*>(base + offB[u] + V2_B_BYTES);
+            if (PASSES == 3) blo[u] = *reinterpret_cast<const bf16x8*>(base + offB[u] + V2_B_BYTES);
         }
         uint32_t xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        typedef __attribute__((ext_vector_type(2))) float f32x2v;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
         u32x4 hi_p, lo_p;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float f0 = __uint_as_float(xs[2 * j]), f1 = __uint_as_float(xs[2 * j + 1]);
             nsq = fmaf(f0, f0, nsq);
             nsq = fmaf(f1, f1, nsq);
-            hi_p[j] = __builtin_amdgcn_perm(xs[2 * j + 1], xs[2 * j], 0x07060302u);
-            const float r0 = f0 - __uint_as_float(xs[2 * j] & 0xffff0000u);      // exact
-            const float r1 = f1 - __uint_as_float(xs[2 * j + 1] & 0xffff0000u);
-            typedef __attribute__((ext_vector_type(2))) float f32x2v;
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
-            const f32x2v rr = {r0, r1};
-            const bf16x2v lp = __builtin_convertvector(rr, bf16x2v);
-            lo_p[j] = __builtin_bit_cast(uint32_t, lp);
+            if (PASSES == 3) {
+                hi_p[j] = __builtin_amdgcn_perm(xs[2 * j + 1], xs[2 * j], 0x07060302u);
+                const float r0 = f0 - __uint_as_float(xs[2 * j] & 0xffff0000u);      // exact
+                const float r1 = f1 - __uint_as_float(xs[2 * j + 1] & 0xffff0000u);
+                const f32x2v rr = {r0, r1};
+                const bf16x2v lp = __builtin_convertvector(rr, bf16x2v);
+                lo_p[j] = __builtin_bit_cast(uint32_t, lp);
+            } else {
+                const f32x2v ff = {f0, f1};
+                const bf16x2v hp = __builtin_convertvector(ff, bf16x2v); // RNE, one v_cvt_pk_bf16_f32
+                hi_p[j] = __builtin_bit_cast(uint32_t, hp);
+                lo_p[j] = 0;
+            }
         }
         const bf16x8 ahi = __builtin_bit_cast(bf16x8, hi_p);
         const bf16x8 alo = __builtin_bit_cast(bf16x8, lo_p);
         if (ABL == 2) {
             asm volatile("" :: "v"(ahi), "v"(alo));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(bhi[u]), "v"(blo[u]));
+            for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(bhi[u]));
         } else {
+            if (PASSES == 3) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 8; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[u], acc[u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 8; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[u], acc[u], 0, 0, 0);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[u], acc[u], 0, 0, 0);
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------
-    uint32_t qidx[8];
-    bool qok[8];
-    float qn_up[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        qidx[u] = q0 + u * 32 + l31;
-        qok[u] = qidx[u] < a.n_queries;
-        qn_up[u] = (METRIC == YAMS_SCAN_L2 && qok[u]) ? a.qnorm_up[qidx[u]] : 0.f;
-    }
-    {
-        const float nfull = nsq + __shfl_xor(nsq, 32);
-        float p0, p1 = 0.f;
-        const bool ok = norm_in_range(nfull);
-        if (METRIC == YAMS_SCAN_COSINE) {
-            p0 = ok ? rsqrtf(nfull) : __builtin_nanf("");
-        } else {
-            p0 = ok ? nfull * (-0.5f + 0.5f * a.err_coef) : __builtin_nanf("");
-            p1 = ok ? a.err_coef * sqrtf(nfull) * 1.000001f : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float rp0 = __shfl(p0, i);
-            if (METRIC == YAMS_SCAN_COSINE) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u][r] = acc[u][r] * rp0;
-            } else {
-                const float rp1 = __shfl(p1, i);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u][r] = acc[u][r] + rp0 + rp1 * qn_up[u];
-            }
-        }
-    }
+    bf16_epilogue<MODE, METRIC, ABL, 8>(a, acc, nsq + __shfl_xor(nsq, 32), row0, static_cast<uint32_t>(wid) * 32u, q0, sel, h, l31);
+}
 
-    const uint64_t wave_row0 = row0 + wid * 32;
-    if (a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
-        const uint32_t mw = mask_word(a.row_mask, wave_row0, a.n_rows);
+// =================================================================================================
+// Single-pass kernel, 32-wide k-slabs, 2x4 wave tiles, software-pipelined fragment reads.
+//
+// With one MFMA pass the matrix pipe needs only ~8 ms for the bench shard; what bounds the kernel is
+// LDS: staging writes plus fragment reads.  Measurements that shaped it:
+//   * 16-wide slabs fetched HALF a 128-byte line of a corpus row per DMA request (the other half
+//     again one slab later).  Here a slab is 32 k-values: one DMA instruction covers 8 rows x 128 B
+//     (whole lines); a stage is 32 KiB of raw fp32 rows + 16 KiB of RNE-bf16 query heads, 3 stages.
+//   * one 32-row block x all 256 queries per wave re-read the whole query tile in every wave
+//     (20 KiB of LDS reads per wave per slab, 160 KiB per workgroup: more LDS time than MFMA time).
+//     Here a wave owns 64 rows x 128 queries (acc[2][4]): 16 KiB per wave per slab.
+//   * hipcc interleaved `2 ds_read, wait, 2 MFMA` — every MFMA pair waited a full LDS latency.
+//     Here the fragments of the NEXT 16-wide step (also across the slab boundary: the barrier sits
+//     in the middle of the iteration) are requested before the MFMAs of the current one, with
+//     sched_barrier fences so the compiler keeps that order.
+// LDS image per row: 8 chunks of 16 B, logical chunk c stored at position c ^ ((row >> 1) & 7);
+// per query: 4 chunks, logical chunk c at c ^ ((q >> 2) & 3) — both make the b128 fragment reads
+// of 16 consecutive rows / queries hit 16 distinct bank groups.
+// =================================================================================================
+constexpr int K32 = 32, K32_NST = 3;
+constexpr int K32_A_BYTES = BT_ROWS * K32 * 4;     // 32 KiB
+constexpr int K32_B_BYTES = BT_QUERIES * K32 * 2;  // 16 KiB
+constexpr int K32_STAGE = K32_A_BYTES + K32_B_BYTES;
+
+struct K32Frags { u32x4 a[2][2]; bf16x8 b[4]; }; // one 16-wide k-step: 2 row blocks (raw fp32), 4 query blocks
+
+template <int MODE, int METRIC, int ABL = 0>
+__global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16k32_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[K32_NST * K32_STAGE];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t w = bid >> 3;
+    const uint32_t qt = w % a.n_qtiles;
+    const uint32_t sel = (w / a.n_qtiles) * 8u + xcd;
+    if (sel >= a.n_sel_tiles) return;
+    uint32_t tile;
+    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
+    else tile = sel + sel / (a.stride - 1u) + 1u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) x queries [128 wc, +128)
+    const int h = lane >> 5, l31 = lane & 31;
+    const uint64_t row0 = static_cast<uint64_t>(tile) * BT_ROWS;
+    const uint32_t q0 = qt * BT_QUERIES;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / K32; // dim % 32 == 0 is a precondition of this kernel
+
+    // ---- DMA sources: every wave stages 32 rows (4 instructions) and 32 queries (2) -------------
+    const unsigned char* srcA[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (!((mw >> i) & 1u)) {
+    for (int i = 0; i < 4; ++i) {
+        const int rowA = wid * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((rowA >> 1) & 7);
+        uint64_t r = row0 + rowA;
+        if (r >= a.n_rows) r = a.n_rows - 1;
+        srcA[i] = reinterpret_cast<const unsigned char*>(a.rows + r * dim + c * 4);
+    }
+    const unsigned char* srcB[2];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u][r] = -__builtin_inff();
-            }
+    for (int i = 0; i < 2; ++i) {
+        const int rowB = wid * 32 + i * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((rowB >> 2) & 3);
+        // k-slab-major plane: [slab][q_pad][32] bf16 -> 16 queries x 64 B are 1 KiB contiguous
+        srcB[i] = reinterpret_cast<const unsigned char*>(a.q_hi + (static_cast<uint64_t>(q0 + rowB)) * 32 + c * 8);
+    }
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    // measurement builds: ABL 1/3/4 refill nothing after the prologue (stages keep valid data);
+    // 2/3 skip the MFMAs; 4 skips the fragment reads
+    auto issue = [&](int s) {
+        if ((ABL == 1 || ABL == 3 || ABL == 4) && s >= K32_NST) return;
+        const uint32_t st = lds0 + (s % K32_NST) * K32_STAGE;
+        const int kb = s * K32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            lds_dma16(srcA[i] + kb * 4, __builtin_amdgcn_readfirstlane(st + (wid * 4 + i) * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            lds_dma16(srcB[i] + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + K32_A_BYTES + (wid * 2 + i) * 1024));
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][u][r] = 0.f;
+    float nsq[2] = {0.f, 0.f};
+
+    // fragment offsets inside a stage, per 16-wide step t: A logical chunks 4t + 2h (+1), B chunk 2t + h
+    int offA[2][2][2], offB[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int rf = wr * 64 + rb * 32 + l31;
+        const int f = (rf >> 1) & 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            offA[rb][t][0] = rf * 128 + (((4 * t + 2 * h) ^ f) << 4);
+            offA[rb][t][1] = rf * 128 + (((4 * t + 2 * h + 1) ^ f) << 4);
         }
     }
-    if (MODE == MODE_SAMPLE) {
-        const float ninf = -__builtin_inff();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float m = ninf;
+    for (int u = 0; u < 4; ++u) {
+        const int rq = wc * 128 + u * 32 + l31;
+        const int f = (rq >> 2) & 3;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const uint64_t rbase = wave_row0 + 8 * g4 + 4 * h;
-                float4 v;
-                v.x = (rbase + 0 < a.n_rows) ? acc[u][4 * g4 + 0] : ninf;
-                v.y = (rbase + 1 < a.n_rows) ? acc[u][4 * g4 + 1] : ninf;
-                v.z = (rbase + 2 < a.n_rows) ? acc[u][4 * g4 + 2] : ninf;
-                v.w = (rbase + 3 < a.n_rows) ? acc[u][4 * g4 + 3] : ninf;
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-                if (qok[u]) {
-                    const uint64_t srow = static_cast<uint64_t>(sel) * BT_ROWS + wid * 32 + 8 * g4 + 4 * h;
-                    *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
-                }
-            }
-            if (qok[u]) {
-                const uint32_t gid = ((sel * 8u + wid) << 1) + h;
-                a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = f2ord(m);
-            }
+        for (int t = 0; t < 2; ++t) offB[u][t] = K32_A_BYTES + rq * 64 + (((2 * t + h) ^ f) << 4);
+    }
+    auto load = [&](K32Frags& fr, const unsigned char* base, int t) {
+        if (ABL == 4 && base != lds) return;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            fr.a[rb][0] = *reinterpret_cast<const u32x4*>(base + offA[rb][t][0]);
+            fr.a[rb][1] = *reinterpret_cast<const u32x4*>(base + offA[rb][t][1]);
         }
-    } else {
-        float tau[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) tau[u] = (qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff();
-        bool any = false;
+        for (int u = 0; u < 4; ++u) fr.b[u] = *reinterpret_cast<const bf16x8*>(base + offB[u][t]);
+    };
+    typedef __attribute__((ext_vector_type(2))) float f32x2v;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    auto compute = [&](const K32Frags& fr) {
+        bf16x8 av[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint32_t xs[8] = {fr.a[rb][0][0], fr.a[rb][0][1], fr.a[rb][0][2], fr.a[rb][0][3],
+                                    fr.a[rb][1][0], fr.a[rb][1][1], fr.a[rb][1][2], fr.a[rb][1][3]};
+            u32x4 ap;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) any |= !(acc[u][r] < tau[u]);
-        if (any) {
+            for (int j = 0; j < 4; ++j) {
+                const float f0 = __uint_as_float(xs[2 * j]), f1 = __uint_as_float(xs[2 * j + 1]);
+                nsq[rb] = fmaf(f0, f0, nsq[rb]);
+                nsq[rb] = fmaf(f1, f1, nsq[rb]);
+                const f32x2v ff = {f0, f1};
+                const bf16x2v hp = __builtin_convertvector(ff, bf16x2v); // RNE, one v_cvt_pk_bf16_f32
+                ap[j] = __builtin_bit_cast(uint32_t, hp);
+            }
+            av[rb] = __builtin_bit_cast(bf16x8, ap);
+        }
+        if (ABL == 2 || ABL == 3) {
+            asm volatile("" :: "v"(av[0]), "v"(av[1]));
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(fr.b[u]));
+        } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = acc[u][r];
-                    if (!(sc < tau[u])) {
-                        const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < a.n_rows && qok[u]) {
-                            const uint32_t pos = atomicAdd(&a.list_count[qidx[u]], 1u);
-                            if (pos < a.list_cap)
-                                a.list[static_cast<uint64_t>(qidx[u]) * a.list_cap + pos] =
-                                    pack_key(sc, static_cast<uint32_t>(row));
-                        }
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[rb], fr.b[u], acc[rb][u], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: all three stages in flight, slab 0 landed, its first step requested -----------
+    {
+        const int npre = nslab < K32_NST ? nslab : K32_NST;
+        for (int s = 0; s < npre; ++s) issue(s);
+        if (npre == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    K32Frags f0, f1;
+    load(f0, lds, 0);
+    int stage = 0;
+    // One iteration = one slab: second step requested, first step computed, barrier for the next
+    // slab in the MIDDLE (so fragment reads cross the slab boundary), refill, next slab's first
+    // step requested, second step computed.  The steady-state loop body is a single basic block
+    // (ISSUE / VM are compile-time) so the compiler's lgkmcnt bookkeeping stays exact: it waits for
+    // the step it needs, not for the prefetch behind it.
+    auto body = [&](int s, auto issue_tag, auto vm_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int VM = decltype(vm_tag)::value;
+        const unsigned char* base = lds + stage * K32_STAGE;
+        stage = stage + 1 == K32_NST ? 0 : stage + 1;
+        load(f1, base, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        // slab s+1 must have landed (VM newer DMA instructions may still be in flight) and every
+        // wave must be done reading slab s (f1 is complete at lgkmcnt(0)) before its stage is
+        // refilled with slab s+3
+        if (VM == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ISSUE) issue(s + 3);
+        load(f0, lds + stage * K32_STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T = std::integral_constant<bool, true>;
+    using F = std::integral_constant<bool, false>;
+    using V6 = std::integral_constant<int, 6>;
+    using V0 = std::integral_constant<int, 0>;
+    int s = 0;
+    for (; s + 3 < nslab; ++s) body(s, T{}, V6{});
+    if (s + 2 < nslab) { body(s, F{}, V6{}); ++s; }
+    if (s + 1 < nslab) { body(s, F{}, V0{}); ++s; }
+    {   // last slab: nothing left to wait for or to prefetch
+        load(f1, lds + stage * K32_STAGE, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0);
+        compute(f1);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+        bf16_epilogue<MODE, METRIC, ABL, 4>(a, acc[rb], nsq[rb] + __shfl_xor(nsq[rb], 32), row0,
+                                            static_cast<uint32_t>(wr * 64 + rb * 32), q0 + wc * 128, sel, h, l31);
+}
+
+// =================================================================================================
+// Single-pass kernel over the bf16 SHADOW of the corpus.
+//
+// Ablations of the kernel above on the bench shard (scripts/filter_ablation.py): product 24.8 ms;
+// MFMAs + barriers alone 17.6 ms (the fp32 -> bf16 conversion and the norm FMAs sit in front of
+// every MFMA group and both waves of a SIMD do them at the same time, so the matrix pipe idles);
+// staging + fragment reads alone 15.3 ms (48 KiB per slab through a ~22 B/clk/CU load path).
+// Both go away when the corpus side is prepared once, like the query side: a row-major bf16 (RNE)
+// copy of the rows plus their fp32 squared norms, built by shadow_build_kernel when the mirror is
+// uploaded.  The filter then stages 64 B per row per slab instead of 128, reads MFMA operands
+// straight from LDS and has no VALU work in its loop; the fp64 re-score still reads the original
+// fp32 rows, so results stay bit-identical (the error bound is the same 2^-7 |x||q|).
+// Stage = 16 KiB rows + 16 KiB queries, four stages (three slabs = 96 k-values in flight).
+// =================================================================================================
+constexpr int SH_K = 32, SH_NST = 4;
+constexpr int SH_A_BYTES = BT_ROWS * SH_K * 2;     // 16 KiB
+constexpr int SH_B_BYTES = BT_QUERIES * SH_K * 2;  // 16 KiB
+constexpr int SH_STAGE = SH_A_BYTES + SH_B_BYTES;
+
+struct ShFrags { bf16x8 a[2]; bf16x8 b[4]; };
+
+template <int MODE, int METRIC, int ABL = 0>
+__global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SH_NST * SH_STAGE];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t w = bid >> 3;
+    const uint32_t qt = w % a.n_qtiles;
+    const uint32_t sel = (w / a.n_qtiles) * 8u + xcd;
+    if (sel >= a.n_sel_tiles) return;
+    uint32_t tile;
+    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
+    else tile = sel + sel / (a.stride - 1u) + 1u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) x queries [128 wc, +128)
+    const int h = lane >> 5, l31 = lane & 31;
+    const uint64_t row0 = static_cast<uint64_t>(tile) * BT_ROWS;
+    const uint32_t q0 = qt * BT_QUERIES;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / SH_K; // dim % 32 == 0 is a precondition of this kernel
+
+    // ---- DMA sources: every wave stages 32 rows (2 instructions) and 32 queries (2) -------------
+    const unsigned char* srcA[2];
+    const unsigned char* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rowA = wid * 32 + i * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((rowA >> 2) & 3);
+        uint64_t r = row0 + rowA;
+        if (r >= a.n_rows) r = a.n_rows - 1;
+        srcA[i] = reinterpret_cast<const unsigned char*>(a.rows_bf16 + r * dim + c * 8);
+        srcB[i] = reinterpret_cast<const unsigned char*>(a.q_hi + (static_cast<uint64_t>(q0 + rowA)) * 32 + c * 8);
+    }
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    // One slab = 4 DMA pieces per wave (p = 0,1: rows; 2,3: queries).  All 32 pieces of a slab
+    // issued in one burst after the barrier fill the CU's load queue and stall every wave in front
+    // of its MFMAs (measured: adding the refills to an LDS-read + MFMA loop added their whole
+    // stand-alone time), so the pieces are issued one at a time between MFMAs, half a slab per step.
+    auto piece = [&](int s, int p) {
+        if ((ABL == 1 || ABL == 3 || ABL == 4 || ABL == 5) && s >= SH_NST) return; // measurement builds, see above
+        const uint32_t st = lds0 + (s & (SH_NST - 1)) * SH_STAGE;
+        if (p < 2) lds_dma16(srcA[p] + s * (SH_K * 2), __builtin_amdgcn_readfirstlane(st + (wid * 2 + p) * 1024));
+        else lds_dma16(srcB[p - 2] + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + SH_A_BYTES + (wid * 2 + p - 2) * 1024));
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][u][r] = 0.f;
+
+    // fragment offsets inside a stage, per 16-wide step t: logical chunk 2t + h of the row / query,
+    // stored at position chunk ^ ((index >> 2) & 3)
+    int offA[2][2], offB[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int rf = wr * 64 + rb * 32 + l31;
+        const int f = (rf >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offA[rb][t] = rf * 64 + (((2 * t + h) ^ f) << 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rq = wc * 128 + u * 32 + l31;
+        const int f = (rq >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offB[u][t] = SH_A_BYTES + rq * 64 + (((2 * t + h) ^ f) << 4);
+    }
+    auto load = [&](ShFrags& fr, const unsigned char* base, int t) {
+        if ((ABL == 4 || ABL == 5) && base != lds) return;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) fr.a[rb] = *reinterpret_cast<const bf16x8*>(base + offA[rb][t]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fr.b[u] = *reinterpret_cast<const bf16x8*>(base + offB[u][t]);
+    };
+    auto pin = [&](ShFrags& fr) {
+        asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.b[0]), "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
+    };
+    // 8 MFMAs of one 16-wide step; when slab_dma >= 0, DMA pieces p0 and p0+1 of that slab go
+    // out after the 2nd and the 6th MFMA
+    auto compute = [&](const ShFrags& fr, int slab_dma, int p0) {
+        if (ABL == 2 || ABL == 3) {
+            asm volatile("" :: "v"(fr.a[0]), "v"(fr.a[1]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(fr.b[u]));
+            if (slab_dma >= 0) { piece(slab_dma, p0); piece(slab_dma, p0 + 1); }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[rb], fr.b[u], acc[rb][u], 0, 0, 0);
+                    if (u == 1 && slab_dma >= 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(slab_dma, p0 + rb);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+            }
         }
+    };
+
+    // ---- prologue: slabs 0..2 and the first half of slab 3 in flight, slab 0 landed ---------------
+    {
+        int issued = 0;
+        for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < 4; ++p) piece(s, p); issued += 4; }
+        if (nslab > 3) { piece(3, 0); piece(3, 1); issued += 2; }
+        const int newer = issued - 4;
+        if (newer >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (newer >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (newer >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    ShFrags f0, f1;
+    load(f0, lds, 0);
+    int stage = 0;
+    // Same half-shifted pipeline as above: the barrier for slab s+1 sits between the two steps of
+    // slab s; the steady-state body is one basic block.  First step: second half of slab s+3 goes
+    // out (its stage was released by the barrier of the previous iteration); second step: first
+    // half of slab s+4 (released by this iteration's barrier).
+    auto body = [&](int s, auto h1_tag, auto h2_tag, auto vm_tag) {
+        constexpr bool H1 = decltype(h1_tag)::value;
+        constexpr bool H2 = decltype(h2_tag)::value;
+        constexpr int VM = decltype(vm_tag)::value;
+        const unsigned char* base = lds + stage * SH_STAGE;
+        stage = (stage + 1) & (SH_NST - 1);
+        // f0 was requested half an iteration ago: make the compiler place its (conservative,
+        // whole-counter) LDS wait HERE, before the next reads go out, not in front of the MFMAs
+        pin(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(f1, base, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0, H1 ? s + 3 : -1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // slab s+1 landed (VM DMA pieces of newer slabs may be in flight); all reads of slab s
+        // (f1 last) complete before its stage is refilled with slab s+4
+        if (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (ABL != 5) __builtin_amdgcn_s_barrier();
+        pin(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(f0, lds + stage * SH_STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f1, H2 ? s + 4 : -1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T = std::integral_constant<bool, true>;
+    using F = std::integral_constant<bool, false>;
+    using V8 = std::integral_constant<int, 8>;
+    using V4 = std::integral_constant<int, 4>;
+    using V0 = std::integral_constant<int, 0>;
+    int s = 0;
+    for (; s + 4 < nslab; ++s) body(s, T{}, T{}, V8{});
+    if (s + 3 < nslab) { body(s, T{}, F{}, V8{}); ++s; }
+    if (s + 2 < nslab) { body(s, F{}, F{}, V4{}); ++s; }
+    if (s + 1 < nslab) { body(s, F{}, F{}, V0{}); ++s; }
+    {
+        load(f1, lds + stage * SH_STAGE, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0, -1, 0);
+        compute(f1, -1, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const uint32_t rit = static_cast<uint32_t>(wr * 64 + rb * 32);
+        const uint64_t r = row0 + rit + l31;
+        const float nfull = r < a.n_rows ? a.rows_nsq[r] : 1.f;
+        bf16_epilogue<MODE, METRIC, ABL, 4>(a, acc[rb], nfull, row0, rit, q0 + wc * 128, sel, h, l31);
     }
 }
 
-// Split the prepared fp32 queries into bf16 head + tail planes, k-slab-major:
-// plane[(k / 16) * q_pad + q][k % 16]; rows q >= n_queries are zero.
+// bf16 (RNE) copy of the rows + their fp32 squared norms: one wave per row.
+__global__ __launch_bounds__(256) void shadow_build_kernel(const float* rows, uint64_t n_rows, uint32_t dim,
+                                                           uint16_t* out_bf16, float* out_nsq) {
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = rows + row * dim;
+    uint16_t* dst = out_bf16 + row * dim;
+    float nsq = 0.f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2v;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    for (uint32_t c = lane * 4; c < dim; c += 256) { // dim % 4 == 0 (rows are 16-byte aligned)
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        nsq = fmaf(v.x, v.x, nsq); nsq = fmaf(v.y, v.y, nsq);
+        nsq = fmaf(v.z, v.z, nsq); nsq = fmaf(v.w, v.w, nsq);
+        const f32x2v lo = {v.x, v.y}, hi = {v.z, v.w};
+        uint2 o;
+        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+        *reinterpret_cast<uint2*>(dst + c) = o;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
+    if (lane == 0) out_nsq[row] = nsq;
+}
+
+// Split the prepared fp32 queries into bf16 head + tail planes, k-slab-major with slabs of
+// `slab` (16 or 32) k-values: plane[(k / slab) * q_pad + q][k % slab]; rows q >= n_queries are zero.
 __global__ void prep_split_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                                  uint16_t* q_hi, uint16_t* q_lo) {
+                                  uint32_t slab_k, uint16_t* q_hi, uint16_t* q_lo) {
     const uint64_t total = static_cast<uint64_t>(q_pad) * dim;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
          i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-        const uint32_t kk = static_cast<uint32_t>(i & 15u);
-        const uint64_t qs = i >> 4;
+        const uint32_t kk = static_cast<uint32_t>(i % slab_k);
+        const uint64_t qs = i / slab_k;
         const uint32_t q = static_cast<uint32_t>(qs % q_pad);
         const uint32_t slab = static_cast<uint32_t>(qs / q_pad);
-        const float x = q < nq ? qprep[static_cast<uint64_t>(q) * dim + slab * 16 + kk] : 0.f;
+        const float x = q < nq ? qprep[static_cast<uint64_t>(q) * dim + slab * slab_k + kk] : 0.f;
         const __bf16 hi = static_cast<__bf16>(x);
         const float res = x - static_cast<float>(hi);
         const __bf16 lo = static_cast<__bf16>(res);
@@ -314,38 +800,78 @@ namespace yams_accel {
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                             uint16_t* q_hi, uint16_t* q_lo) {
+                             uint32_t slab_k, uint16_t* q_hi, uint16_t* q_lo) {
     const uint64_t n_elems = static_cast<uint64_t>(q_pad) * dim;
     if (n_elems == 0) return hipSuccess;
     uint32_t grid = static_cast<uint32_t>((n_elems + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(prep_split_kernel, dim3(grid), dim3(256), 0, st, qprep, nq, q_pad, dim, q_hi, q_lo);
+    hipLaunchKernelGGL(prep_split_kernel, dim3(grid), dim3(256), 0, st, qprep, nq, q_pad, dim, slab_k, q_hi, q_lo);
     LAUNCH_CHECK();
     return hipSuccess;
 }
 
 ScanArgs make_scan_args(const ScanLaunch& L); // scan_kernels.hip
 
-#define LAUNCH_BF16(KERNEL) do { \
+hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
+                               uint16_t* out_bf16, float* out_nsq) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(shadow_build_kernel, dim3(static_cast<uint32_t>((n_rows + 3) / 4)), dim3(256), 0, st,
+                       rows, n_rows, dim, out_bf16, out_nsq);
+    hipError_t e_ = hipGetLastError();
+    return e_;
+}
+
+#define LAUNCH_BF16(PASSES) do { \
     if (mode == MODE_SAMPLE) { \
-        if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((KERNEL<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
-        else hipLaunchKernelGGL((KERNEL<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
+        if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE, PASSES>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
+        else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_SAMPLE, YAMS_SCAN_L2, PASSES>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
     } else { \
-        if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((KERNEL<MODE_FILTER, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
-        else hipLaunchKernelGGL((KERNEL<MODE_FILTER, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
+        if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, PASSES>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
+        else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_L2, PASSES>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
     } } while (0)
 
-hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int version) {
+// passes: 1 or 3 (see the kernel).  version 12 = staging-only ablation (measurement only).
+hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int passes, int version) {
     ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
     const uint32_t grid = groups * a.n_qtiles * 8;
-    if (version == 11 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
-        hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-    else if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
-        hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-    else LAUNCH_BF16(scan_tiles_bf16v2_kernel);
+    if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE && bf16_slab_k(passes, L.plan.dim) == 16) {
+        if (passes == 3) hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+    } else if (passes == 3) LAUNCH_BF16(3);
+    else if (a.rows_bf16 && bf16_slab_k(passes, L.plan.dim) == 32) {
+        const bool abl = mode == MODE_FILTER && metric == YAMS_SCAN_COSINE;
+        if (abl && version == 11) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (abl && version == 12) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (abl && version == 13) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (abl && version == 14) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 4>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (abl && version == 15) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 5>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (mode == MODE_SAMPLE) {
+            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        } else {
+            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        }
+    } else if (bf16_slab_k(passes, L.plan.dim) == 32) {
+        if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
+            hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (version == 11 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
+            hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (version == 13 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
+            hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (version == 14 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
+            hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 4>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        else if (mode == MODE_SAMPLE) {
+            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        } else {
+            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        }
+    } else LAUNCH_BF16(1);
     LAUNCH_CHECK();
     return hipSuccess;
 }

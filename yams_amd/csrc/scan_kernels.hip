@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint
     for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = (i < CAP) ? s[i] : K(0);
 }
 
-// tau[q] = score of the kprime-th best group maximum (or -inf when there are fewer groups).
+// tau[q] = score of the rank-th best group maximum (or -inf when there are fewer groups).
 __global__ void tau_from_keys_kernel(const uint32_t* sorted, uint64_t stride, uint32_t kprime,
                                      uint32_t nq, float* tau) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -881,7 +881,7 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
 
 ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
-    a.rows = L.rows; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.rows = L.rows; a.rows_bf16 = L.rows_bf16; a.rows_nsq = L.rows_nsq; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
@@ -964,7 +964,7 @@ static hipError_t topk_multilevel(hipStream_t st, const K* in, const uint32_t* i
 
 hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32) {
     const uint32_t* res; uint64_t stride;
-    uint32_t keep = L.plan.kprime;
+    uint32_t keep = L.plan.tau_rank;
     hipError_t e = topk_multilevel<uint32_t>(st, L.gmax, nullptr, L.plan.n_groups, L.plan.n_groups,
                                              0xffffffffu, L.plan.n_queries, nullptr, keep, work32,
                                              &res, &stride);
@@ -1051,6 +1051,56 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     else
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2>), dim3(R.n_slots), dim3(256), sh,
                            st, a);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// Precision escalation helpers: queries whose 1-pass filter could not be proven complete are
+// gathered, re-run through the split (3-pass) filter as their own small batch, and scattered back.
+__global__ void gather_queries_kernel(const float* queries, const uint32_t* qmap, uint32_t n_slots,
+                                      uint32_t dim, float* out) {
+    const uint64_t total = static_cast<uint64_t>(n_slots) * dim;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t s = static_cast<uint32_t>(i / dim), c = static_cast<uint32_t>(i % dim);
+        out[i] = queries[static_cast<uint64_t>(qmap[s]) * dim + c];
+    }
+}
+__global__ void scatter_results_kernel(const uint32_t* qmap, uint32_t n_slots, uint32_t k,
+                                       const float* s_scores, const int64_t* s_rows,
+                                       const uint32_t* s_counts, const float* s_dist,
+                                       const uint32_t* s_ranks, float* scores, int64_t* rows,
+                                       uint32_t* counts, float* dist, uint32_t* ranks) {
+    const uint32_t s = blockIdx.x;
+    if (s >= n_slots) return;
+    const uint64_t q = qmap[s];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        scores[q * k + i] = s_scores[static_cast<uint64_t>(s) * k + i];
+        rows[q * k + i] = s_rows[static_cast<uint64_t>(s) * k + i];
+        if (dist) dist[q * k + i] = s_dist[static_cast<uint64_t>(s) * k + i];
+        if (ranks) ranks[q * k + i] = s_ranks[static_cast<uint64_t>(s) * k + i];
+    }
+    if (threadIdx.x == 0) counts[q] = s_counts[s];
+}
+
+hipError_t launch_gather_queries(hipStream_t st, const float* queries, const uint32_t* qmap,
+                                 uint32_t n_slots, uint32_t dim, float* out) {
+    if (n_slots == 0 || dim == 0) return hipSuccess;
+    const uint64_t total = static_cast<uint64_t>(n_slots) * dim;
+    uint32_t grid = static_cast<uint32_t>((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(grid), dim3(256), 0, st, queries, qmap, n_slots, dim, out);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_scatter_results(hipStream_t st, const uint32_t* qmap, uint32_t n_slots, uint32_t k,
+                                  const float* s_scores, const int64_t* s_rows,
+                                  const uint32_t* s_counts, const float* s_dist,
+                                  const uint32_t* s_ranks, float* scores, int64_t* rows,
+                                  uint32_t* counts, float* dist, uint32_t* ranks) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(n_slots), dim3(128), 0, st, qmap, n_slots, k,
+                       s_scores, s_rows, s_counts, s_dist, s_ranks, scores, rows, counts, dist, ranks);
     LAUNCH_CHECK();
     return hipSuccess;
 }

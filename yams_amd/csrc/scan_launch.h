@@ -7,6 +7,8 @@ namespace yams_accel {
 struct ScanLaunch {
     ScanPlan plan;
     const float* rows = nullptr;
+    const uint16_t* rows_bf16 = nullptr; // nullable shadow (with rows_nsq)
+    const float* rows_nsq = nullptr;
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
     const uint16_t* q_hi = nullptr;
@@ -47,8 +49,11 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
                                uint32_t* qflags);
 hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                             uint16_t* q_hi, uint16_t* q_lo);
-hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int version);
+                             uint32_t slab_k, uint16_t* q_hi, uint16_t* q_lo);
+// k-extent of one LDS stage of the bf16 filter kernels (= the slab size of the query planes):
+// the single-pass kernel uses 32-wide slabs when the dimension allows it.
+inline uint32_t bf16_slab_k(int passes, uint32_t dim) { return (passes == 1 && (dim & 31u) == 0) ? 32u : 16u; }
+hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int passes, int version);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32);
@@ -71,6 +76,15 @@ hipError_t launch_topk_keys(hipStream_t st, const uint64_t* keys, uint64_t key_s
                             const uint64_t** result, uint64_t* result_stride);
 hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R);
 hipError_t launch_merge(hipStream_t st, const MergeLaunch& M);
+hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
+                               uint16_t* out_bf16, float* out_nsq);
+hipError_t launch_gather_queries(hipStream_t st, const float* queries, const uint32_t* qmap,
+                                 uint32_t n_slots, uint32_t dim, float* out);
+hipError_t launch_scatter_results(hipStream_t st, const uint32_t* qmap, uint32_t n_slots, uint32_t k,
+                                  const float* s_scores, const int64_t* s_rows,
+                                  const uint32_t* s_counts, const float* s_dist,
+                                  const uint32_t* s_ranks, float* scores, int64_t* rows,
+                                  uint32_t* counts, float* dist, uint32_t* ranks);
 hipError_t launch_synth_rows(hipStream_t st, uint64_t seed, uint64_t row0, uint64_t n_rows,
                              uint32_t dim, float* out);
 hipError_t launch_synth_bytes(hipStream_t st, uint64_t seed, uint64_t blob_id0, uint64_t n_blobs,
