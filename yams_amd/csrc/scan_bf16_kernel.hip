@@ -95,6 +95,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
 #pragma unroll
         for (int u = 0; u < NCB; ++u) {
             float m = ninf;
+            bool bad = false; // a NaN score marks the whole group (see scan_kernels.hip)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const uint64_t rbase = wave_row0 + 8 * g4 + 4 * h;
@@ -104,6 +105,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
                 v.z = (rbase + 2 < a.n_rows) ? acc[u][4 * g4 + 2] : ninf;
                 v.w = (rbase + 3 < a.n_rows) ? acc[u][4 * g4 + 3] : ninf;
                 m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
                 if (qok[u]) {
                     const uint64_t srow = static_cast<uint64_t>(sel) * BT_ROWS + row_in_tile + 8 * g4 + 4 * h;
                     *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
             }
             if (qok[u]) {
                 const uint32_t gid = (sel * BT_ROWS + row_in_tile) / 16u + h;
-                a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = f2ord(m);
+                a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = bad ? 0xffffffffu : f2ord(m);
             }
         }
     } else {

@@ -199,6 +199,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float m = ninf;
+                bool bad = false; // a NaN score marks the whole group (key 0xffffffff): its rows are
+                                  // untrustworthy for the filter and must reach the fp64 re-score
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const uint64_t rbase = wave_row0 + t * 32 + 8 * g4 + 4 * h;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
                     v.z = (rbase + 2 < a.n_rows) ? acc[t][u][4 * g4 + 2] : ninf;
                     v.w = (rbase + 3 < a.n_rows) ? acc[t][u][4 * g4 + 3] : ninf;
                     m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                    bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
                     if (qok[u]) {
                         const uint64_t srow = static_cast<uint64_t>(sel) * kTileRows + wr * 64 +
                                               t * 32 + 8 * g4 + 4 * h;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
                 }
                 if (qok[u]) {
                     const uint32_t gid = ((sel * 4u + wr * 2u + t) << 1) + h;
-                    a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = f2ord(m);
+                    a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = bad ? 0xffffffffu : f2ord(m);
                 }
             }
     } else {
@@ -350,16 +353,70 @@ __global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint
 }
 
 // tau[q] = score of the rank-th best group maximum (or -inf when there are fewer groups).
-__global__ void tau_from_keys_kernel(const uint32_t* sorted, uint64_t stride, uint32_t kprime,
-                                     uint32_t nq, float* tau) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const uint32_t key = sorted[static_cast<uint64_t>(q) * stride + (kprime - 1)];
-    tau[q] = key ? ord2f(key) : -__builtin_inff();
+// Radix select over the order-preserving keys, one workgroup per query, three histogram passes
+// (11 + 11 + 10 bits): only the rank-th key is needed, not a sorted prefix.
+__global__ __launch_bounds__(256) void tau_select_kernel(const uint32_t* gmax, uint32_t n_groups,
+                                                         uint32_t rank, float* tau) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t s_prefix, s_rank;
+    const uint32_t q = blockIdx.x;
+    const uint32_t* keys = gmax + static_cast<uint64_t>(q) * n_groups;
+    if (n_groups < rank) { // fewer groups than the rank: no threshold
+        if (threadIdx.x == 0) tau[q] = -__builtin_inff();
+        return;
+    }
+    if (threadIdx.x == 0) { s_prefix = 0; s_rank = rank; }
+    // pass p examines bits [shift, shift + bits) of the keys whose higher bits equal s_prefix
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        const int shift = shifts[p], bins = 1 << widths[p];
+        for (int i = threadIdx.x; i < 2048; i += 256) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const int hi_shift = shift + widths[p];
+        for (uint32_t i = threadIdx.x; i < n_groups; i += 256) {
+            const uint32_t k = keys[i];
+            if (hi_shift >= 32 || (k >> hi_shift) == prefix) atomicAdd(&hist[(k >> shift) & (bins - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) { // one wave walks the bins from the top
+            const int lane = threadIdx.x;
+            const int per = bins / 64; // 32 or 16 bins per lane, lane 0 owns the TOP bins
+            uint32_t mine = 0;
+            for (int j = 0; j < per; ++j) mine += hist[bins - 1 - (lane * per + j)];
+            uint32_t incl = mine; // inclusive prefix over lanes (= keys in this lane's bins or above)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t excl = incl - mine;
+            const uint32_t r = s_rank;
+            if (r > excl && r <= incl) { // the rank-th key falls in one of my bins
+                uint32_t above = excl;
+                for (int j = 0; j < per; ++j) {
+                    const int b = bins - 1 - (lane * per + j);
+                    const uint32_t c = hist[b];
+                    if (r <= above + c) { s_prefix = (prefix << widths[p]) | static_cast<uint32_t>(b); s_rank = r - above; break; }
+                    above += c;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t key = s_prefix;
+        tau[q] = key ? ord2f(key) : -__builtin_inff();
+    }
 }
 
-// Sample rows that reach the threshold join the candidate lists.
-__global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
+// Sample rows that reach the threshold join the candidate lists.  Driven by the group maxima:
+// only groups whose maximum reaches tau (a NaN group always does) have their 16 dense scores read.
+// Group gid covers rows  32 * (gid >> 1) + 4 * (gid & 1) + {0..3} + 8 * {0..3}  of the sample
+// (the MFMA accumulator layout of both sample kernels).
+__global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense, const uint32_t* gmax,
+                                                             uint32_t n_groups,
                                                              uint64_t sample_rows, uint32_t tile_rows,
                                                              uint32_t stride,
                                                              uint64_t n_rows, const float* tau,
@@ -368,16 +425,27 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
     const uint32_t q = blockIdx.y;
     const float t = tau[q];
     const float* src = dense + static_cast<uint64_t>(q) * sample_rows;
-    for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-         s < sample_rows; s += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-        const float v = src[s];
-        if (!(v < t)) {
-            const uint64_t row = (s / tile_rows) * stride * tile_rows + (s % tile_rows);
-            if (row < n_rows) {
-                const uint32_t pos = atomicAdd(&list_count[q], 1u);
-                if (pos < list_cap)
-                    list[static_cast<uint64_t>(q) * list_cap + pos] =
-                        pack_key(v, static_cast<uint32_t>(row));
+    const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        const float m = ord2f(gm[g]); // 0xffffffff decodes to NaN
+        if (m < t) continue;
+        const uint64_t s0 = static_cast<uint64_t>(g >> 1) * 32 + 4 * (g & 1);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(src + s0 + 8 * g4);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = vv[e];
+                if (!(v < t)) {
+                    const uint64_t sidx = s0 + 8 * g4 + e;
+                    const uint64_t row = (sidx / tile_rows) * stride * tile_rows + (sidx % tile_rows);
+                    if (row < n_rows) {
+                        const uint32_t pos = atomicAdd(&list_count[q], 1u);
+                        if (pos < list_cap)
+                            list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(v, static_cast<uint32_t>(row));
+                    }
+                }
             }
         }
     }
@@ -962,28 +1030,22 @@ static hipError_t topk_multilevel(hipStream_t st, const K* in, const uint32_t* i
     return hipSuccess;
 }
 
-hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32) {
-    const uint32_t* res; uint64_t stride;
-    uint32_t keep = L.plan.tau_rank;
-    hipError_t e = topk_multilevel<uint32_t>(st, L.gmax, nullptr, L.plan.n_groups, L.plan.n_groups,
-                                             0xffffffffu, L.plan.n_queries, nullptr, keep, work32,
-                                             &res, &stride);
-    if (e != hipSuccess) return e;
+hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* /*work32*/) {
     const uint32_t nq = L.plan.n_queries;
-    hipLaunchKernelGGL(tau_from_keys_kernel, dim3((nq + 127) / 128), dim3(128), 0, st, res, stride,
-                       keep, nq, L.tau_out);
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(tau_select_kernel, dim3(nq), dim3(256), 0, st, L.gmax, L.plan.n_groups,
+                       L.plan.tau_rank, L.tau_out);
     LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L) {
-    if (L.plan.sample_rows == 0) return hipSuccess;
-    uint32_t gx = static_cast<uint32_t>((L.plan.sample_rows + 256 * 8 - 1) / (256 * 8));
-    if (gx > 512) gx = 512;
-    if (gx == 0) gx = 1;
+    if (L.plan.sample_rows == 0 || L.plan.n_groups == 0) return hipSuccess;
+    uint32_t gx = (L.plan.n_groups + 255) / 256;
+    if (gx > 256) gx = 256;
     hipLaunchKernelGGL(collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.dense,
-                       L.plan.sample_rows, L.plan.tile_rows, L.plan.sample_stride, L.plan.n_rows, L.tau,
-                       L.list_count, L.list, L.plan.list_cap);
+                       L.gmax, L.plan.n_groups, L.plan.sample_rows, L.plan.tile_rows,
+                       L.plan.sample_stride, L.plan.n_rows, L.tau, L.list_count, L.list, L.plan.list_cap);
     LAUNCH_CHECK();
     return hipSuccess;
 }
