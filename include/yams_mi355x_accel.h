@@ -128,7 +128,7 @@ typedef struct yams_scan_corpus_s {
     uint64_t row_mask_count;   /* number of set bits (the host built the mask, it knows)          */
     const uint16_t* rows_bf16; /* device, nullable: the SHADOW of `rows` built by
                                   yams_scan_build_shadow_device — [n_rows][dim] bf16 (round to
-                                  nearest even), 16-byte aligned.  Only the MFMA filter reads it
+                                  nearest even) of the unit-normalised rows, 16-byte aligned.  Only the MFMA filter reads it
                                   (half the bytes, no conversion in the loop); the fp64 re-score
                                   that decides the result always reads `rows`.  Results are
                                   bit-identical with and without it.                              */

@@ -415,9 +415,11 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     tn = torch.empty(n, dtype=torch.float32, device="cuda")
     acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
     acc.synchronize()
-    # the shadow is exactly the RNE bf16 of the rows and their squared norms
-    assert torch.equal(tb[:4096], tc[:4096].to(torch.bfloat16))
-    assert torch.allclose(tn[:4096], (tc[:4096].double() ** 2).sum(-1).float(), rtol=1e-5)
+    # the shadow is the RNE bf16 of the unit-normalised rows, plus their squared norms
+    n64 = (tc[:4096].double() ** 2).sum(-1)
+    assert torch.allclose(tn[:4096], n64.float(), rtol=1e-5)
+    unit = (tc[:4096].double() / n64.sqrt()[:, None]).float()
+    assert (tb[:4096].float() - unit).abs().max().item() <= 2.0 ** -8 * unit.abs().max().item() * 1.01
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
     diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(),
                                 c.data_ptr(), dist.data_ptr())

@@ -244,7 +244,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         const double dot_rel = passes == 3   ? (6.0 * dim + 64.0) * u24 + 3.0 / 65536.0
                                : passes == 1 ? (2.0 * dim + 64.0) * u24 + 2.0 / 256.0 + 2.0 / 65536.0
                                              : (dim + 8.0) * u24;
-        L.err_coef = static_cast<float>(dot_rel * 1.01);
+        // with the (pre-normalised) shadow the row-norm rounding sits inside the dot product
+        const bool use_shadow = passes == 1 && L.rows_bf16 && bf16_slab_k(passes, dim) == 32;
+        const double norm_rel = (dim + 32.0) * u24;
+        L.err_coef = static_cast<float>((dot_rel + (use_shadow ? norm_rel : 0.0)) * 1.01);
         if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
@@ -284,7 +287,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // stage 1: re-score the best kprime filter survivors of every query
         // cosine: |s32 - cos| <= dot_rel + norm (dim/2 u) + rsqrt/product/unit-query rounding
         const double err_bound = (metric == YAMS_SCAN_COSINE)
-                                     ? dot_rel + (dim + 24.0) * u24 : 0.0;
+                                     ? dot_rel + (dim + 24.0) * u24 + (use_shadow ? norm_rel : 0.0) : 0.0;
         auto rescore_stage = [&](uint32_t n_slots, const uint32_t* d_qmap, uint32_t n_cand) -> yams_status_t {
             const uint64_t* res; uint64_t res_stride;
             YA_HIP(ctx, launch_select_lists(st, d_list, d_lcount, plan.list_cap, n_slots, d_qmap,

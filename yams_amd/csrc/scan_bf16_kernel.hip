@@ -31,7 +31,10 @@ constexpr int BT_ROWS = 256, BT_QUERIES = 256, BT_THREADS = 512;
 // One call handles a block of 32 rows x (32 * NCB) queries held by one wave:
 // acc[u][r] = dot(row row0 + row_in_tile + (r&3) + 8(r>>2) + 4h, query q0 + 32u + l31); nfull = the
 // fp32 squared norm of row (lane & 31) of the block.
-template <int MODE, int METRIC, int ABL, int NCB>
+// PRENORM: the A operand was the unit-normalised shadow row, so a cosine score needs no scaling
+// (rows whose norm is out of range still turn into NaN = "always a candidate"); L2 scales the dot
+// back by the row norm.
+template <int MODE, int METRIC, int ABL, int NCB, bool PRENORM = false>
 __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[NCB], float nfull,
                                               uint64_t row0, uint32_t row_in_tile, uint32_t q0,
                                               uint32_t sel, int h, int l31) {
@@ -54,14 +57,16 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
         qok[u] = qidx[u] < a.n_queries;
         qn_up[u] = (METRIC == YAMS_SCAN_L2 && qok[u]) ? a.qnorm_up[qidx[u]] : 0.f;
     }
-    {
-        float p0, p1 = 0.f;
-        const bool ok = norm_in_range(nfull);
+    const bool ok = norm_in_range(nfull);
+    const bool any_bad = __builtin_amdgcn_ballot_w64(!ok) != 0; // wave-uniform
+    if (!(PRENORM && METRIC == YAMS_SCAN_COSINE) || any_bad) {
+        float p0, p1 = 0.f, ps = 1.f;
         if (METRIC == YAMS_SCAN_COSINE) {
-            p0 = ok ? rsqrtf(nfull) : __builtin_nanf("");
+            p0 = ok ? (PRENORM ? 1.f : rsqrtf(nfull)) : __builtin_nanf("");
         } else {
             p0 = ok ? nfull * (-0.5f + 0.5f * a.err_coef) : __builtin_nanf("");
             p1 = ok ? a.err_coef * sqrtf(nfull) * 1.000001f : 0.f;
+            if (PRENORM) ps = ok ? sqrtf(nfull) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -72,8 +77,14 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
                 for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] * rp0;
             } else {
                 const float rp1 = __shfl(p1, i);
+                if (PRENORM) {
+                    const float rps = __shfl(ps, i);
 #pragma unroll
-                for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] + rp0 + rp1 * qn_up[u];
+                    for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] * rps + rp0 + rp1 * qn_up[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NCB; ++u) acc[u][r] = acc[u][r] + rp0 + rp1 * qn_up[u];
+                }
             }
         }
     }
@@ -120,16 +131,22 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
         float tau[NCB];
 #pragma unroll
         for (int u = 0; u < NCB; ++u) tau[u] = (qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff();
-        bool any = false;
+        // cheap reject: the maximum of a lane's 16 scores per query block (v_max3 tree); a NaN score
+        // (ignored by max) can only come from a row flagged above, which forces the full scan
+        uint32_t hot = 0;
 #pragma unroll
-        for (int u = 0; u < NCB; ++u)
+        for (int u = 0; u < NCB; ++u) {
+            float m = acc[u][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) any |= !(acc[u][r] < tau[u]);
-        if (any) {
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+            if (!(m < tau[u]) || any_bad) hot |= 1u << u;
+        }
+        if (hot) {
 #pragma unroll
             for (int u = 0; u < NCB; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if (!((hot >> u) & 1u)) continue;
                     const float sc = acc[u][r];
                     if (!(sc < tau[u])) {
                         const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -554,8 +571,8 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16k32_kernel(ScanA
 // every MFMA group and both waves of a SIMD do them at the same time, so the matrix pipe idles);
 // staging + fragment reads alone 15.3 ms (48 KiB per slab through a ~22 B/clk/CU load path).
 // Both go away when the corpus side is prepared once, like the query side: a row-major bf16 (RNE)
-// copy of the rows plus their fp32 squared norms, built by shadow_build_kernel when the mirror is
-// uploaded.  The filter then stages 64 B per row per slab instead of 128, reads MFMA operands
+// copy of the unit-normalised rows plus their fp32 squared norms, built by shadow_build_kernel
+// when the mirror is uploaded (so a cosine score needs no scaling in the epilogue either).  The filter then stages 64 B per row per slab instead of 128, reads MFMA operands
 // straight from LDS and has no VALU work in its loop; the fp64 re-score still reads the original
 // fp32 rows, so results stay bit-identical (the error bound is the same 2^-7 |x||q|).
 // Stage = 16 KiB rows + 16 KiB queries, four stages (three slabs = 96 k-values in flight).
@@ -743,11 +760,13 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
         const uint32_t rit = static_cast<uint32_t>(wr * 64 + rb * 32);
         const uint64_t r = row0 + rit + l31;
         const float nfull = r < a.n_rows ? a.rows_nsq[r] : 1.f;
-        bf16_epilogue<MODE, METRIC, ABL, 4>(a, acc[rb], nfull, row0, rit, q0 + wc * 128, sel, h, l31);
+        bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull, row0, rit, q0 + wc * 128, sel, h, l31);
     }
 }
 
-// bf16 (RNE) copy of the rows + their fp32 squared norms: one wave per row.
+// The shadow: bf16 (RNE) of the UNIT-NORMALISED rows + their fp32 squared norms; one wave per row.
+// Rows whose squared norm is outside (1e-30, 1e30) or not finite get an all-zero shadow row; the
+// filter epilogue turns their scores into NaN (= always a candidate) from the stored norm.
 __global__ __launch_bounds__(256) void shadow_build_kernel(const float* rows, uint64_t n_rows, uint32_t dim,
                                                            uint16_t* out_bf16, float* out_nsq) {
     const uint64_t row = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -762,14 +781,19 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const float* rows, ui
         const float4 v = *reinterpret_cast<const float4*>(src + c);
         nsq = fmaf(v.x, v.x, nsq); nsq = fmaf(v.y, v.y, nsq);
         nsq = fmaf(v.z, v.z, nsq); nsq = fmaf(v.w, v.w, nsq);
-        const f32x2v lo = {v.x, v.y}, hi = {v.z, v.w};
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
+    const float inv = norm_in_range(nsq) ? rsqrtf(nsq) : 0.f;
+    for (uint32_t c = lane * 4; c < dim; c += 256) { // second read of the row: L1/L2 hit
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        const f32x2v lo = {inv != 0.f ? v.x * inv : 0.f, inv != 0.f ? v.y * inv : 0.f};
+        const f32x2v hi = {inv != 0.f ? v.z * inv : 0.f, inv != 0.f ? v.w * inv : 0.f};
         uint2 o;
         o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
         o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
         *reinterpret_cast<uint2*>(dst + c) = o;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
     if (lane == 0) out_nsq[row] = nsq;
 }
 
