@@ -8,7 +8,7 @@ import torch
 from yams_amd.accel import Accel
 from yams_amd._lib import SCAN_COSINE
 
-n, d, nq, k = int(os.environ.get("ROWS", 12_500_000)), 768, int(os.environ.get("Q", 1024)), 100
+n, d, nq, k = int(os.environ.get("ROWS", 12_500_000)), int(os.environ.get("DIM", 768)), int(os.environ.get("Q", 1024)), 100
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 0, n, d, tc.data_ptr())
 tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 1 << 40, nq, d, tq.data_ptr())

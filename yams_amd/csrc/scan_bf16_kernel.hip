@@ -37,7 +37,8 @@ constexpr int BT_ROWS = 256, BT_QUERIES = 256, BT_THREADS = 512;
 template <int MODE, int METRIC, int ABL, int NCB, bool PRENORM = false>
 __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[NCB], float nfull,
                                               uint64_t row0, uint32_t row_in_tile, uint32_t q0,
-                                              uint32_t sel, int h, int l31) {
+                                              uint32_t sel, int h, int l31,
+                                              const float* tau_pre = nullptr /* [NCB], preloaded */) {
     if (ABL != 0) { // measurement builds: keep the accumulators alive, emit nothing
         float t = 0.f;
 #pragma unroll
@@ -130,7 +131,8 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
     } else {
         float tau[NCB];
 #pragma unroll
-        for (int u = 0; u < NCB; ++u) tau[u] = (qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff();
+        for (int u = 0; u < NCB; ++u)
+            tau[u] = tau_pre ? tau_pre[u] : ((qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff());
         // cheap reject: the maximum of a lane's 16 scores per query block (v_max3 tree); a NaN score
         // (ignored by max) can only come from a row flagged above, which forces the full scan
         uint32_t hot = 0;
@@ -193,6 +195,15 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Same, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the base moves
+// with scalar adds, so no VALU address arithmetic sits between the MFMAs.
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // ABL is a measurement knob (never set by the product path): 2 = no MFMAs (staging-only time);
@@ -609,29 +620,33 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     const int nslab = dim / SH_K; // dim % 32 == 0 is a precondition of this kernel
 
     // ---- DMA sources: every wave stages 32 rows (2 instructions) and 32 queries (2) -------------
-    const unsigned char* srcA[2];
-    const unsigned char* srcB[2];
+    // address = uniform base (tile / query-tile start + slab offset, SGPRs) + per-lane byte offset
+    uint32_t voffA[2], voffB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rowA = wid * 32 + i * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((rowA >> 2) & 3);
         uint64_t r = row0 + rowA;
-        if (r >= a.n_rows) r = a.n_rows - 1;
-        srcA[i] = reinterpret_cast<const unsigned char*>(a.rows_bf16 + r * dim + c * 8);
-        srcB[i] = reinterpret_cast<const unsigned char*>(a.q_hi + (static_cast<uint64_t>(q0 + rowA)) * 32 + c * 8);
+        if (r >= a.n_rows) r = a.n_rows - 1; // row0 < n_rows, so r - row0 >= 0
+        voffA[i] = static_cast<uint32_t>(r - row0) * dim * 2u + c * 16u;
+        voffB[i] = static_cast<uint32_t>(rowA) * 64u + c * 16u;
     }
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_bf16 + row0 * dim);
+    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_hi + static_cast<uint64_t>(q0) * 32);
     const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + wid * 2048);
     // One slab = 4 DMA pieces per wave (p = 0,1: rows; 2,3: queries).  All 32 pieces of a slab
     // issued in one burst after the barrier fill the CU's load queue and stall every wave in front
     // of its MFMAs (measured: adding the refills to an LDS-read + MFMA loop added their whole
     // stand-alone time), so the pieces are issued one at a time between MFMAs, half a slab per step.
     auto piece = [&](int s, int p) {
         if ((ABL == 1 || ABL == 3 || ABL == 4 || ABL == 5) && s >= SH_NST) return; // measurement builds, see above
-        const uint32_t st = lds0 + (s & (SH_NST - 1)) * SH_STAGE;
-        if (p < 2) lds_dma16(srcA[p] + s * (SH_K * 2), __builtin_amdgcn_readfirstlane(st + (wid * 2 + p) * 1024));
-        else lds_dma16(srcB[p - 2] + s * qslab_bytes, __builtin_amdgcn_readfirstlane(st + SH_A_BYTES + (wid * 2 + p - 2) * 1024));
+        const uint32_t st = (s & (SH_NST - 1)) * SH_STAGE;
+        if (p < 2) lds_dma16_s(baseA + s * (SH_K * 2), voffA[p], ldsA + st + p * 1024);
+        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p - 2], ldsB + st + (p - 2) * 1024);
     };
 
     f32x16 acc[2][4];
@@ -669,29 +684,51 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     auto pin = [&](ShFrags& fr) {
         asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.b[0]), "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
     };
-    // 8 MFMAs of one 16-wide step; when slab_dma >= 0, DMA pieces p0 and p0+1 of that slab go
-    // out after the 2nd and the 6th MFMA
-    auto compute = [&](const ShFrags& fr, int slab_dma, int p0) {
-        if (ABL == 2 || ABL == 3) {
-            asm volatile("" :: "v"(fr.a[0]), "v"(fr.a[1]));
+    // One 16-wide step: 8 MFMAs on `cur`, with the 6 fragment reads of the NEXT step and (when
+    // slab_dma >= 0) DMA pieces p0, p0+1 of that slab placed one per MFMA gap.  A burst of reads
+    // in front of the MFMAs leaves the matrix pipe idle when both waves of a SIMD are in it at the
+    // same time (a bare MFMA stream runs 32 cycles per instruction, micro-benchmark
+    // scripts/ubench/mfma_rate.hip; this loop ran 43); up to ~5 single-issue instructions hide in
+    // each 32-cycle gap.
+    auto step = [&](const ShFrags& cur, ShFrags& nxt, const unsigned char* nbase, int nt, bool do_load,
+                    int slab_dma, int p0) {
+        const bool rd = do_load && !((ABL == 4 || ABL == 5) && nbase != lds);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(fr.b[u]));
-            if (slab_dma >= 0) { piece(slab_dma, p0); piece(slab_dma, p0 + 1); }
-        } else {
+        for (int i = 0; i < 8; ++i) {
+            const int rb = i >> 2, u = i & 3;
+            if (ABL == 2 || ABL == 3) {
+                if (i == 0) {
+                    asm volatile("" :: "v"(cur.a[0]), "v"(cur.a[1]));
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[rb], fr.b[u], acc[rb][u], 0, 0, 0);
-                    if (u == 1 && slab_dma >= 0) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        piece(slab_dma, p0 + rb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int v = 0; v < 4; ++v) asm volatile("" :: "v"(cur.b[v]));
                 }
+            } else {
+                acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb], cur.b[u], acc[rb][u], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (rd && i < 2) nxt.a[i] = *reinterpret_cast<const bf16x8*>(nbase + offA[i][nt]);
+            if (rd && i >= 2 && i < 6) nxt.b[i - 2] = *reinterpret_cast<const bf16x8*>(nbase + offB[i - 2][nt]);
+            if (slab_dma >= 0 && (i == 3 || i == 6)) piece(slab_dma, p0 + (i == 6 ? 1 : 0));
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+
+    // epilogue inputs, requested now: a load issued at the end would sit on the critical path of
+    // every tile (rows_nsq streams from HBM), here it hides under the whole k loop
+    float nfull_pre[2], tau_pre[4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const uint64_t r = row0 + static_cast<uint32_t>(wr * 64 + rb * 32) + l31;
+        nfull_pre[rb] = r < a.n_rows ? a.rows_nsq[r] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t qi = q0 + wc * 128 + u * 32 + l31;
+        tau_pre[u] = (MODE == MODE_FILTER && ABL == 0 && qi < a.n_queries) ? a.tau[qi] : __builtin_inff();
+    }
+    // (these older loads complete before any DMA piece issued below — vmcnt retires in order — so the
+    // counted waits in the loop stay valid; the compiler waits for them at their first use, the
+    // epilogue)
 
     // ---- prologue: slabs 0..2 and the first half of slab 3 in flight, slab 0 landed ---------------
     {
@@ -718,14 +755,11 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
         constexpr int VM = decltype(vm_tag)::value;
         const unsigned char* base = lds + stage * SH_STAGE;
         stage = (stage + 1) & (SH_NST - 1);
-        // f0 was requested half an iteration ago: make the compiler place its (conservative,
-        // whole-counter) LDS wait HERE, before the next reads go out, not in front of the MFMAs
+        // f0 was requested during the previous step: make the compiler place its (conservative,
+        // whole-counter) LDS wait HERE, before the next reads go out, not in front of an MFMA
         pin(f0);
         __builtin_amdgcn_sched_barrier(0);
-        load(f1, base, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(f0, H1 ? s + 3 : -1, 2);
-        __builtin_amdgcn_sched_barrier(0);
+        step(f0, f1, base, 1, true, H1 ? s + 3 : -1, 2);
         // slab s+1 landed (VM DMA pieces of newer slabs may be in flight); all reads of slab s
         // (f1 last) complete before its stage is refilled with slab s+4
         if (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -734,10 +768,7 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
         if (ABL != 5) __builtin_amdgcn_s_barrier();
         pin(f1);
         __builtin_amdgcn_sched_barrier(0);
-        load(f0, lds + stage * SH_STAGE, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(f1, H2 ? s + 4 : -1, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        step(f1, f0, lds + stage * SH_STAGE, 0, true, H2 ? s + 4 : -1, 0);
     };
     using T = std::integral_constant<bool, true>;
     using F = std::integral_constant<bool, false>;
@@ -749,18 +780,19 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     if (s + 3 < nslab) { body(s, T{}, F{}, V8{}); ++s; }
     if (s + 2 < nslab) { body(s, F{}, F{}, V4{}); ++s; }
     if (s + 1 < nslab) { body(s, F{}, F{}, V0{}); ++s; }
-    {
-        load(f1, lds + stage * SH_STAGE, 1);
+    {   // last slab: nothing left to wait for or to prefetch after its second step
+        pin(f0);
         __builtin_amdgcn_sched_barrier(0);
-        compute(f0, -1, 0);
-        compute(f1, -1, 0);
+        step(f0, f1, lds + stage * SH_STAGE, 1, true, -1, 0);
+        pin(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(f1, f0, lds, 0, false, -1, 0);
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const uint32_t rit = static_cast<uint32_t>(wr * 64 + rb * 32);
-        const uint64_t r = row0 + rit + l31;
-        const float nfull = r < a.n_rows ? a.rows_nsq[r] : 1.f;
-        bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull, row0, rit, q0 + wc * 128, sel, h, l31);
+        bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull_pre[rb], row0, rit, q0 + wc * 128, sel, h, l31,
+                                                  MODE == MODE_FILTER ? tau_pre : nullptr);
     }
 }
 
