@@ -261,6 +261,7 @@ def main():
                 traffic = j.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    row_bytes = 2 if (tb is not None and passes == 1 and bf16) else 4   # what the filter reads per element
     roofline = {"bound": "mfma", "kernel": kname, "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s",
                 "frac": (ach_tf / peak) if ach_tf else None, "traffic": traffic,
                 "launch_ms": filt_ms, "launches": filt_n, "flops_per_launch": flops,
@@ -272,8 +273,8 @@ def main():
                 "hbm_floor_view": {"algorithmic_bytes_per_launch": filt_rows * d * (2 if tb is not None and passes == 1 and bf16 else 4),
                                    "achieved_GBps": (filt_rows * d * (2 if tb is not None and passes == 1 and bf16 else 4)) / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
                                    "peak_GBps": PEAK_HBM_GBPS},
-                "hbm_view": {"algorithmic_bytes_per_step": n * d * 4 + nq * d * 4 + nq * k * 12,
-                             "achieved_GBps": (n * d * 4 + nq * d * 4 + nq * k * 12) / (ms_per_step * 1e-3) / 1e9,
+                "hbm_view": {"algorithmic_bytes_per_step": n * d * row_bytes + nq * d * 4 + nq * k * 12,
+                             "achieved_GBps": (n * d * row_bytes + nq * d * 4 + nq * k * 12) / (ms_per_step * 1e-3) / 1e9,
                              "peak_GBps": PEAK_HBM_GBPS}}
     out = {"metric": "k-NN QPS + recall@k, 100M x 768 fp32 cosine top-100; ingest GB/s SHA-256+CDC",
            "value": qps, "unit": "QPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -17,7 +17,9 @@ for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2"
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 1 << 40, nq, d, tq.data_ptr())
     s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-    view = acc.corpus_view(tc.data_ptr(), n, d)
+    tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
+    acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr()); acc.synchronize()
+    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
     for _ in range(2):
         diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr())
     reps = 10 if n <= 1_000_000 else 4
@@ -27,8 +29,9 @@ for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2"
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     rows.append({"config": name, "rows": n, "dim": d, "Q": nq, "k": k, "metric": "l2" if metric else "cosine",
                  "ms": dt * 1e3, "QPS": nq / dt, "algorithmic_TFLOPs": 2.0 * n * d * nq / dt / 1e12,
-                 "corpus_GBps": n * d * 4 / dt / 1e9, "path": diag["path"], "fallbacks": diag["exact_fallback_queries"]})
-    del tc, tq
+                 "corpus_GBps": n * d * 4 / dt / 1e9, "path": diag["path"], "fallbacks": diag["exact_fallback_queries"], "escalated": diag["escalated_queries"],
+                 "widened": diag["widened_queries"]})
+    del tc, tq, tb, tn
     torch.cuda.empty_cache()
 for r_ in rows:
     print(json.dumps(r_))

@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 ulimit -c 0
 REPO=$PWD; OUT=$REPO/gpurun_out
 B="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ingest"
+# (bench.py builds the bf16 filter shadow before the timed region; shadow_build_kernel shows up once in the trace)
 I="python $REPO/scripts/ingest_bench.py --gib 100 --reps 2"
 rm -rf $OUT/prof_trace $OUT/prof_ingest $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_trace -o scan -- $B > $OUT/prof_trace.log 2>&1) || true

@@ -25,15 +25,16 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // passes: MFMA passes of the filter (0 = exact f32 kernel, 1 = RNE bf16, 3 = split bf16).  A looser
 // filter needs more candidates re-scored before the proof can succeed, not a different threshold.
-ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes) {
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes, int metric) {
     ScanPlan p;
     p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
     p.tile_rows = bf16 ? 256 : kTileRows;
     p.tile_queries = bf16 ? 256 : kTileQueries;
     p.n_tiles = static_cast<uint32_t>((n_rows + p.tile_rows - 1) / p.tile_rows);
     p.n_qtiles = (nq + p.tile_queries - 1) / p.tile_queries;
+    // (the L2 filter score is an upper bound carrying +E itself, so its band is 2E wide)
     p.kprime = (passes == 1)
-                   ? std::min<uint32_t>(round_up(3 * k + 64, 32), kRescoreMax)
+                   ? std::min<uint32_t>(round_up(metric == YAMS_SCAN_L2 ? 6 * k + 128 : 3 * k + 64, 32), kRescoreMax)
                    : std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
     const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 32, 8192));
     uint32_t want_tiles = static_cast<uint32_t>((s_target + p.tile_rows - 1) / p.tile_rows);
@@ -228,7 +229,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || k > 256) ? 3 : 1;
             if (pv && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
         }
-        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes);
+        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
         if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
