@@ -5,8 +5,8 @@
 // order and error behaviour, plus the CRUD subset needed to keep a device mirror of the
 // `vectors` table (insertVector, insertVectorsBatch, deleteVector, getVectorCount).  The records
 // stay on the host (chunk_id, document_hash, content, metadata are opaque to the scan); the
-// embeddings live in HBM as one dense matrix per dimension, rebuilt lazily after a mutation
-// (generation counter, the idea of sqlite_vec_backend.cpp:389-411).
+// embeddings live in HBM as one dense matrix per dimension, extended lazily after a mutation
+// (appends + tombstones; generation idea of sqlite_vec_backend.cpp:389-411).
 //
 // A patched VectorDatabase::Impl flips ONE line to use it (vector_database.cpp:56 constructs
 // SqliteVecBackend unconditionally); see INTEGRATION.md.
@@ -54,6 +54,17 @@ struct VectorSearchParams { // vector_types.h:216-227
 
 enum class VectorSearchEngine { Vec0L2, ExactScan }; // vector_types.h:31-35 (the engines served here)
 
+enum class ExactRowSelection { TopK, AllMatching }; // sqlite_vec_backend.cpp:342-371 / :4398-4400
+
+// One dense device matrix per AccelVectorIndex (one embedding dimension).  Row r of the mirror is
+// records_[r]; rows are only ever APPENDED to the device mirror:
+//   * insert of a new chunk_id      -> new row (corpus_append of the tail on the next search)
+//   * insert of an existing chunk_id -> the old row becomes a tombstone, the new value a new row
+//     (delete + insert with a new rowid inside one transaction, :1086-1226)
+//   * deleteVector                  -> tombstone
+// Tombstones are excluded through the row allow-mask of the scan; when they exceed a quarter of
+// the mirror it is compacted and re-uploaded.  The chunk_id ranking (secondary sort key) is
+// recomputed after every mutation batch.
 class AccelVectorIndex {
 public:
     AccelVectorIndex(std::shared_ptr<accel::Plugin> plugin, yams_vector_scan_v1* vt, size_t embeddingDim,
@@ -78,51 +89,87 @@ public:
             if (r.embedding.size() != dim_) return Error{ErrorCode::InvalidArgument, "embedding dimension mismatch"};
             for (float v : r.embedding) if (!std::isfinite(v)) return Error{ErrorCode::InvalidArgument, "non-finite embedding"};
         }
-        for (const auto& r : records) { // an existing chunk_id is replaced (delete + insert, :1086-1226)
+        // chunk_ids repeated inside one batch: the last write wins (:1086-1226)
+        std::unordered_map<std::string, size_t> last;
+        for (size_t i = 0; i < records.size(); ++i) last[records[i].chunk_id] = i;
+        for (size_t i = 0; i < records.size(); ++i) {
+            const auto& r = records[i];
+            if (last[r.chunk_id] != i) continue;
             auto it = byId_.find(r.chunk_id);
-            if (it != byId_.end()) { records_[it->second] = r; }
-            else { byId_[r.chunk_id] = records_.size(); records_.push_back(r); }
+            if (it != byId_.end()) kill(it->second);
+            byId_[r.chunk_id] = records_.size();
+            records_.push_back(r);
+            alive_.push_back(1);
+            zeroNorm_.push_back(isZeroNorm(r.embedding) ? 1 : 0);
         }
-        dirty_ = true;
+        ranksDirty_ = true;
         return {};
     }
     Result<void> deleteVector(const std::string& chunkId) {
         auto it = byId_.find(chunkId);
         if (it == byId_.end()) return Error{ErrorCode::NotFound, "chunk not found"};
-        records_.erase(records_.begin() + static_cast<std::ptrdiff_t>(it->second));
-        byId_.clear();
-        for (size_t i = 0; i < records_.size(); ++i) byId_[records_[i].chunk_id] = i;
-        dirty_ = true;
+        kill(it->second);
+        byId_.erase(it);
         return {};
     }
-    Result<size_t> getVectorCount() const { return records_.size(); }
+    Result<size_t> getVectorCount() const { return records_.size() - dead_; }
+    size_t mirrorRows() const { return records_.size(); }   // incl. tombstones (for tests)
+    size_t uploadedRows() const { return deviceRows_; }
 
     Result<std::vector<VectorRecord>> searchSimilar(const std::vector<float>& query, size_t k,
                                                     float similarityThreshold = 0.0f,
                                                     VectorSearchDiagnostics* diagnostics = nullptr) {
-        auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics, nullptr);
-        if (!r) return r.error();
-        return std::move(r.value().front());
+        return searchSimilar(query, k, similarityThreshold, std::nullopt, {}, {}, diagnostics);
     }
-    // The filtered form of IVectorStore::searchSimilar (vector_store.h:44-49): only rows whose
-    // document_hash equals `document_hash` (if given) AND is in `candidate_hashes` (if non-empty)
-    // take part — the SQL restriction of sqlite_vec_backend.cpp:4137-4175, as a row allow-mask.
-    // (metadata_filters need the parsed record per row and stay with the SQLite backend.)
+    // The full IVectorStore::searchSimilar (vector_store.h:44-49).  Only rows whose document_hash
+    // equals `document_hash` (if given) AND is in `candidate_hashes` (if non-empty) take part — the
+    // SQL restriction of sqlite_vec_backend.cpp:4137-4175 — and, when `metadata_filters` is not
+    // empty, whose metadata holds every (key, value) pair (:4350-4360): the host evaluates the
+    // predicates on its records, the scan gets a row allow-mask, and the record-path row rules of
+    // the reference apply (YAMS_SCAN_FLAG_RECORD_PATH).
     Result<std::vector<VectorRecord>>
     searchSimilar(const std::vector<float>& query, size_t k, float similarityThreshold,
                   const std::optional<std::string>& document_hash,
                   const std::unordered_set<std::string>& candidate_hashes,
-                  VectorSearchDiagnostics* diagnostics = nullptr) {
-        if (!document_hash && candidate_hashes.empty()) return searchSimilar(query, k, similarityThreshold, diagnostics);
+                  const std::map<std::string, std::string>& metadata_filters = {},
+                  VectorSearchDiagnostics* diagnostics = nullptr,
+                  ExactRowSelection rowSelection = ExactRowSelection::TopK) {
+        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (auto sy = syncMirror(); !sy) return sy.error(); // may compact: row numbers change BEFORE masks are built
+        const bool filtered = document_hash || !candidate_hashes.empty() || !metadata_filters.empty();
+        if (!filtered && dead_ == 0 && rowSelection == ExactRowSelection::TopK) {
+            auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics, nullptr, 0, 0, 0);
+            if (!r) return r.error();
+            return std::move(r.value().front());
+        }
         std::vector<uint32_t> mask((records_.size() + 31) / 32, 0u);
+        size_t visited = 0, evaluated = 0;
         for (size_t r = 0; r < records_.size(); ++r) {
-            const auto& h = records_[r].document_hash;
-            if (document_hash && h != *document_hash) continue;
-            if (!candidate_hashes.empty() && !candidate_hashes.count(h)) continue;
+            if (!alive_[r]) continue;
+            const auto& rec = records_[r];
+            if (document_hash && rec.document_hash != *document_hash) continue;
+            if (!candidate_hashes.empty() && !candidate_hashes.count(rec.document_hash)) continue;
+            ++visited; // rows the reference's statement steps over (:4336-4338)
+            bool match = true;
+            for (const auto& [key, value] : metadata_filters) {
+                auto it = rec.metadata.find(key);
+                if (it == rec.metadata.end() || it->second != value) { match = false; break; }
+            }
+            if (!match) continue;
             mask[r >> 5] |= 1u << (r & 31);
+            if (!zeroNorm_[r]) ++evaluated; // rows that get a score on the record path (:4365-4371)
         }
         if (mask.empty()) mask.push_back(0u);
-        auto r = searchSimilarBatchImpl({query}, k, similarityThreshold, diagnostics, mask.data());
+        const bool recordPath = !metadata_filters.empty();
+        size_t kk = k;
+        if (rowSelection == ExactRowSelection::AllMatching) {
+            kk = std::max<size_t>(visited, 1);
+            if (kk > YAMS_SCAN_MAX_K)
+                return Error{ErrorCode::NotImplemented, "AllMatching over more than YAMS_SCAN_MAX_K rows"};
+        }
+        auto r = searchSimilarBatchImpl({query}, kk, similarityThreshold, diagnostics, mask.data(),
+                                        recordPath ? YAMS_SCAN_FLAG_RECORD_PATH : 0u, visited,
+                                        recordPath ? evaluated : visited);
         if (!r) return r.error();
         return std::move(r.value().front());
     }
@@ -130,32 +177,76 @@ public:
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatch(const std::vector<std::vector<float>>& queries, size_t k,
                        float similarityThreshold = 0.0f, size_t /*num_threads*/ = 0) {
-        return searchSimilarBatchImpl(queries, k, similarityThreshold, nullptr, nullptr);
+        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (auto sy = syncMirror(); !sy) return sy.error();
+        if (dead_ == 0) return searchSimilarBatchImpl(queries, k, similarityThreshold, nullptr, nullptr, 0, 0, 0);
+        std::vector<uint32_t> mask((records_.size() + 31) / 32, 0u);
+        for (size_t r = 0; r < records_.size(); ++r) if (alive_[r]) mask[r >> 5] |= 1u << (r & 31);
+        if (mask.empty()) mask.push_back(0u);
+        return searchSimilarBatchImpl(queries, k, similarityThreshold, nullptr, mask.data(), 0, 0, 0);
     }
 
 private:
+    static bool isZeroNorm(const std::vector<float>& e) { // isZeroNormEmbedding, sqlite_vec_backend.cpp:204-211
+        double n = 0.0;
+        for (float v : e) n += static_cast<double>(v) * static_cast<double>(v);
+        return n < 1e-10;
+    }
+    void kill(size_t row) {
+        if (alive_[row]) { alive_[row] = 0; ++dead_; ranksDirty_ = true; }
+    }
+    Result<void> upload(size_t first) {
+        const size_t n = records_.size() - first;
+        if (n == 0) return {};
+        std::vector<float> flat(n * dim_);
+        for (size_t i = 0; i < n; ++i)
+            std::copy(records_[first + i].embedding.begin(), records_[first + i].embedding.end(), flat.begin() + i * dim_);
+        if (vt_->corpus_append(vt_->self, corpus_, flat.data(), n) != YAMS_OK)
+            return Error{ErrorCode::InternalError, "corpus_append failed"};
+        deviceRows_ = records_.size();
+        return {};
+    }
     Result<void> syncMirror() {
-        if (!dirty_) return {};
-        if (vt_->corpus_clear(vt_->self, corpus_) != YAMS_OK) return Error{ErrorCode::InternalError, "corpus_clear failed"};
-        const size_t n = records_.size();
-        if (n) {
-            std::vector<float> flat(n * dim_);
-            for (size_t i = 0; i < n; ++i) std::copy(records_[i].embedding.begin(), records_[i].embedding.end(), flat.begin() + i * dim_);
-            if (vt_->corpus_append(vt_->self, corpus_, flat.data(), n) != YAMS_OK) return Error{ErrorCode::InternalError, "corpus_append failed"};
-            // secondary sort key = chunk_id string order (:4218-4223)
+        if (dead_ > 1024 && dead_ * 4 > records_.size()) { // compact: drop the tombstones, re-upload
+            std::vector<VectorRecord> keep;
+            std::vector<uint8_t> zn;
+            keep.reserve(records_.size() - dead_);
+            for (size_t r = 0; r < records_.size(); ++r)
+                if (alive_[r]) { keep.push_back(std::move(records_[r])); zn.push_back(zeroNorm_[r]); }
+            records_.swap(keep); zeroNorm_.swap(zn);
+            alive_.assign(records_.size(), 1);
+            dead_ = 0;
+            byId_.clear();
+            for (size_t i = 0; i < records_.size(); ++i) byId_[records_[i].chunk_id] = i;
+            if (vt_->corpus_clear(vt_->self, corpus_) != YAMS_OK) return Error{ErrorCode::InternalError, "corpus_clear failed"};
+            deviceRows_ = 0;
+            ranksDirty_ = true;
+        }
+        const bool appended = records_.size() > deviceRows_;
+        if (appended) if (auto u = upload(deviceRows_); !u) return u.error();
+        if ((ranksDirty_ || appended) && !records_.empty()) {
+            // secondary sort key = chunk_id string order (:4218-4223); tombstones keep a rank too
+            const size_t n = records_.size();
             std::vector<uint32_t> order(n), rank(n);
             std::iota(order.begin(), order.end(), 0u);
-            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return records_[a].chunk_id < records_[b].chunk_id; });
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                const int c = records_[a].chunk_id.compare(records_[b].chunk_id);
+                return c != 0 ? c < 0 : a < b; // a replaced chunk_id exists twice (old row is dead)
+            });
             for (uint32_t r = 0; r < n; ++r) rank[order[r]] = r;
-            if (vt_->corpus_set_tie_ranks(vt_->self, corpus_, rank.data(), n) != YAMS_OK) return Error{ErrorCode::InternalError, "corpus_set_tie_ranks failed"};
+            if (vt_->corpus_set_tie_ranks(vt_->self, corpus_, rank.data(), n) != YAMS_OK)
+                return Error{ErrorCode::InternalError, "corpus_set_tie_ranks failed"};
         }
-        dirty_ = false;
+        ranksDirty_ = false;
         return {};
     }
 
+    // visited / evaluated: per-query diagnostics of a filtered search computed by the caller (0, 0 =
+    // take them from the scan)
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatchImpl(const std::vector<std::vector<float>>& queries, size_t k, float thr,
-                           VectorSearchDiagnostics* diagnostics, const uint32_t* rowMask) {
+                           VectorSearchDiagnostics* diagnostics, const uint32_t* rowMask,
+                           uint32_t flags, size_t visited, size_t evaluated) {
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
         if (queries.empty()) return std::vector<std::vector<VectorRecord>>{};
         for (const auto& q : queries) // vector_database.cpp:545-550, 626-633
@@ -167,9 +258,17 @@ private:
         for (size_t i = 0; i < queries.size(); ++i) std::copy(queries[i].begin(), queries[i].end(), flat.begin() + i * dim_);
         yams_scan_hit_t* hits = nullptr; uint32_t* counts = nullptr; yams_scan_diag_t diag{};
         const uint32_t metric = engine_ == VectorSearchEngine::Vec0L2 ? YAMS_SCAN_L2 : YAMS_SCAN_COSINE;
-        const yams_status_t st = vt_->search_batch_masked(vt_->self, corpus_, flat.data(), static_cast<uint32_t>(queries.size()),
-                                                          static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, metric,
-                                                          rowMask, &hits, &counts, &diag);
+        yams_status_t st;
+        if (flags != 0) {
+            if (!vt_->search_batch_ex) return Error{ErrorCode::NotImplemented, "plugin lacks search_batch_ex"};
+            st = vt_->search_batch_ex(vt_->self, corpus_, flat.data(), static_cast<uint32_t>(queries.size()),
+                                      static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, metric, flags,
+                                      rowMask, &hits, &counts, &diag);
+        } else {
+            st = vt_->search_batch_masked(vt_->self, corpus_, flat.data(), static_cast<uint32_t>(queries.size()),
+                                          static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, metric,
+                                          rowMask, &hits, &counts, &diag);
+        }
         if (st == YAMS_ERR_INVALID_ARG)
             return Error{ErrorCode::InvalidArgument, "Exact vector search requires a finite, non-zero query embedding"};
         if (st != YAMS_OK) return Error{accel::mapStatus(st), "vector scan failed"};
@@ -186,8 +285,9 @@ private:
         if (diagnostics) {
             diagnostics->usedExactScan = true; diagnostics->rowsVisitedObserved = true;
             diagnostics->exactDistanceEvaluationsObserved = true;
-            diagnostics->rowsVisited += diag.rows_visited;
-            diagnostics->exactDistanceEvaluations += diag.exact_distance_evaluations;
+            const bool own = rowMask != nullptr && (visited != 0 || evaluated != 0 || flags != 0);
+            diagnostics->rowsVisited += own ? visited * queries.size() : diag.rows_visited;
+            diagnostics->exactDistanceEvaluations += own ? evaluated * queries.size() : diag.exact_distance_evaluations;
             diagnostics->returnedRows = diag.returned_rows;
         }
         return out;
@@ -198,8 +298,10 @@ private:
     size_t dim_;
     VectorSearchEngine engine_;
     uint64_t corpus_ = 0;
-    bool initialized_ = false, dirty_ = false;
+    bool initialized_ = false, ranksDirty_ = false;
     std::vector<VectorRecord> records_;
+    std::vector<uint8_t> alive_, zeroNorm_;
+    size_t dead_ = 0, deviceRows_ = 0;
     std::unordered_map<std::string, size_t> byId_;
 };
 

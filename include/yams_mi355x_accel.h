@@ -141,6 +141,13 @@ typedef struct yams_scan_corpus_s {
 #define YAMS_SCAN_FLAG_F32_FILTER 4u      /* use the exact-f32 MFMA filter instead of the bf16 ones */
 #define YAMS_SCAN_FLAG_SPLIT_FILTER 8u    /* start with the split-bf16 (3-pass) filter instead of
                                              the single-pass bf16 one                            */
+#define YAMS_SCAN_FLAG_RECORD_PATH 16u    /* cosine: the reference's record path, taken when a search
+                                             carries metadata_filters (sqlite_vec_backend.cpp:
+                                             4333-4409).  Same fp64 arithmetic
+                                             (computeCosineSimilarity), but rows are dropped when
+                                             norm^2 < 1e-10 (isZeroNormEmbedding, :204-211) instead of
+                                             <= 1e-12 (:4267-4269).  The caller turns the metadata
+                                             predicate into the row allow-mask.                  */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {
@@ -351,6 +358,13 @@ typedef struct yams_vector_scan_v1 {
                                          float similarity_threshold, uint32_t metric,
                                          const uint32_t* row_mask, yams_scan_hit_t** out_hits,
                                          uint32_t** out_counts, yams_scan_diag_t* out_diag);
+    /* Same, with YAMS_SCAN_FLAG_* bits (e.g. YAMS_SCAN_FLAG_RECORD_PATH for searches that carry
+     * metadata_filters, whose predicate the host has already folded into `row_mask`). */
+    yams_status_t (*search_batch_ex)(void* self, uint64_t corpus_id, const float* queries,
+                                     uint32_t n_queries, uint32_t dim, uint32_t k,
+                                     float similarity_threshold, uint32_t metric, uint32_t flags,
+                                     const uint32_t* row_mask, yams_scan_hit_t** out_hits,
+                                     uint32_t** out_counts, yams_scan_diag_t* out_diag);
 } yams_vector_scan_v1;
 
 typedef struct yams_content_hash_v1 {

@@ -291,8 +291,54 @@ ORACLE_API long oracle_exact_scan_cosine(const float* corpus, size_t n_rows, siz
     return (long)hs;
 }
 
+/* The record path of the same function, src/vector/sqlite_vec_backend.cpp:4333-4409: taken when a
+ * search carries metadata_filters.  `allow` (nullable, one byte per row) stands for everything the
+ * reference decides before it scores a row: the SQL restriction (:4137-4175), the candidate_hashes
+ * re-check (:4339-4345) and the metadata predicate (:4350-4360).  Then: skip rows with
+ * isZeroNormEmbedding (norm^2 < 1e-10, :204-211) or a non-finite element (:4365-4367); similarity =
+ * float(computeCosineSimilarity(query, row)) (:4373-4374); skip if < threshold (:4375-4377); full
+ * sort by (similarity desc, chunk_id asc) (:4391-4396); first k (or all of them when k == 0 stands
+ * for ExactRowSelection::AllMatching, :4398-4400).  evaluations counts the rows that got a score
+ * (:4369-4371). */
+static double oracle_cosine_similarity_impl(const float* a, const float* b, size_t dim);
+typedef struct { float sim; uint64_t rank; int64_t row; } oracle_rhit;
+static int rhit_cmp(const void* pa, const void* pb) {
+    const oracle_rhit* a = (const oracle_rhit*)pa; const oracle_rhit* b = (const oracle_rhit*)pb;
+    if (a->sim != b->sim) return a->sim > b->sim ? -1 : 1;
+    if (a->rank != b->rank) return a->rank < b->rank ? -1 : 1;
+    return 0;
+}
+ORACLE_API long oracle_exact_scan_cosine_records(const float* corpus, size_t n_rows, size_t dim,
+                                                 const float* query, size_t k, int all_matching,
+                                                 float similarity_threshold,
+                                                 const uint64_t* tie_rank, const uint8_t* allow,
+                                                 int64_t* out_rows, float* out_sims,
+                                                 uint64_t* evaluations) {
+    if (evaluations) *evaluations = 0;
+    if (dim == 0 || (k == 0 && !all_matching)) return 0;   /* :4123-4126 */
+    if (oracle_query_invalid(query, dim)) return -1;       /* :4127-4130 */
+    oracle_rhit* all = (oracle_rhit*)malloc(sizeof(oracle_rhit) * (n_rows ? n_rows : 1));
+    size_t m = 0;
+    for (size_t r = 0; r < n_rows; ++r) {
+        if (allow && !allow[r]) continue;
+        const float* e = corpus + r * dim;
+        double nsq = 0.0; int finite = 1;
+        for (size_t i = 0; i < dim; ++i) { nsq += (double)e[i] * (double)e[i]; if (!isfinite(e[i])) finite = 0; }
+        if (nsq < 1e-10 || !finite) continue;              /* :4365-4367 */
+        if (evaluations) ++*evaluations;                   /* :4369-4371 */
+        float sim = (float)oracle_cosine_similarity_impl(query, e, dim); /* :4373-4374 */
+        if (sim < similarity_threshold) continue;          /* :4375-4377 */
+        all[m].sim = sim; all[m].rank = tie_rank ? tie_rank[r] : (uint64_t)r; all[m].row = (int64_t)r; ++m;
+    }
+    qsort(all, m, sizeof(oracle_rhit), rhit_cmp);          /* :4391-4396 */
+    size_t cnt = all_matching ? m : (k < m ? k : m);       /* :4398-4400 */
+    for (size_t i = 0; i < cnt; ++i) { out_rows[i] = all[i].row; out_sims[i] = all[i].sim; }
+    free(all);
+    return (long)cnt;
+}
+
 /* VectorDatabase::computeCosineSimilarity, src/vector/vector_database.cpp:1786-1810. */
-ORACLE_API double oracle_cosine_similarity(const float* a, const float* b, size_t dim) {
+static double oracle_cosine_similarity_impl(const float* a, const float* b, size_t dim) {
     double dp = 0.0, na = 0.0, nb = 0.0;
     for (size_t i = 0; i < dim; ++i) {
         dp += (double)a[i] * (double)b[i];
@@ -302,6 +348,11 @@ ORACLE_API double oracle_cosine_similarity(const float* a, const float* b, size_
     na = sqrt(na); nb = sqrt(nb);
     if (na == 0.0 || nb == 0.0) return 0.0;
     return dp / (na * nb);
+}
+
+/* VectorDatabase::computeCosineSimilarity, src/vector/vector_database.cpp:1786-1810. */
+ORACLE_API double oracle_cosine_similarity(const float* a, const float* b, size_t dim) {
+    return oracle_cosine_similarity_impl(a, b, dim);
 }
 
 /* ------------------------------------------------------------------------------------------------

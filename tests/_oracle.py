@@ -61,6 +61,9 @@ class Oracle:
         L.oracle_exact_scan_cosine.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                                C.c_float, u64p, i64p, f32p, u64p, u64p]
         L.oracle_exact_scan_cosine.restype = C.c_long
+        L.oracle_exact_scan_cosine_records.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_int,
+                                                       C.c_float, u64p, C.c_void_p, i64p, f32p, u64p]
+        L.oracle_exact_scan_cosine_records.restype = C.c_long
         L.oracle_exact_scan_l2.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                            C.c_float, u64p, i64p, f32p, f32p]
         L.oracle_exact_scan_l2.restype = C.c_long
@@ -113,6 +116,25 @@ class Oracle:
         if cnt < 0:
             return None
         return rows[:cnt].copy(), sims[:cnt].copy(), rv.value, ev.value
+
+    def scan_cosine_records(self, corpus, query, k, thr=-1.0, tie_rank=None, allow=None, all_matching=False):
+        """The reference's record path (metadata_filters), sqlite_vec_backend.cpp:4333-4409."""
+        corpus = np.ascontiguousarray(corpus, np.float32); query = np.ascontiguousarray(query, np.float32)
+        n, d = corpus.shape
+        cap = max(n if all_matching else k, 1)
+        rows = np.full(cap, -1, np.int64); sims = np.zeros(cap, np.float32)
+        ev = C.c_uint64(0)
+        tr = al = None
+        if tie_rank is not None:
+            tie_rank = np.ascontiguousarray(tie_rank, np.uint64); tr = _ptr(tie_rank, u64p)
+        if allow is not None:
+            allow = np.ascontiguousarray(allow, np.uint8); al = allow.ctypes.data_as(C.c_void_p)
+        cnt = self.L.oracle_exact_scan_cosine_records(_ptr(corpus, f32p), n, d, _ptr(query, f32p), k,
+                                                      1 if all_matching else 0, thr, tr, al,
+                                                      _ptr(rows, i64p), _ptr(sims, f32p), C.byref(ev))
+        if cnt < 0:
+            return None
+        return rows[:cnt].copy(), sims[:cnt].copy(), ev.value
 
     def scan_l2(self, corpus, query, k, thr=-1.0, tie_rank=None):
         corpus = np.ascontiguousarray(corpus, np.float32); query = np.ascontiguousarray(query, np.float32)

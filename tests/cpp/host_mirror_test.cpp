@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
         CHECK(insert("allowed_second", "allowed", {0.8f, 0.6f, 0.0f, 0.0f}).has_value());
         CHECK(insert("blocked", "blocked", {1.0f, 0.0f, 0.0f, 0.0f}).has_value());
         vector::VectorSearchDiagnostics diag;
-        auto res = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::nullopt, {"allowed"}, &diag);
+        auto res = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::nullopt, {"allowed"}, {}, &diag);
         CHECK(res.has_value() && res.value().size() == 2);
         if (res && res.value().size() == 2) {
             CHECK(res.value()[0].chunk_id == "allowed_best" && res.value()[1].chunk_id == "allowed_second");
@@ -147,6 +147,83 @@ int main(int argc, char** argv) {
         CHECK(one.has_value() && one.value().size() == 1 && one.value()[0].chunk_id == "blocked");
         auto none = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::optional<std::string>("blocked"), {"allowed"});
         CHECK(none.has_value() && none.value().empty());
+    }
+    for (auto order : {std::vector<std::string>{"tie_c", "tie_a", "tie_b"}, std::vector<std::string>{"tie_b", "tie_a", "tie_c"}}) {
+        // "breaks score ties deterministically", the useMetadataFilter arm (vector_smoke_catch2_test.cpp:304-353)
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        for (auto& id : order) {
+            vector::VectorRecord r; r.chunk_id = id; r.document_hash = "doc_" + id; r.embedding = {1, 0, 0, 0};
+            r.metadata["lane"] = "tie";
+            CHECK(db.insertVector(r).has_value());
+        }
+        auto res = db.searchSimilar({1, 0, 0, 0}, 2, -1.0f, std::nullopt, {}, {{"lane", "tie"}});
+        CHECK(res.has_value() && res.value().size() == 2 && res.value()[0].chunk_id == "tie_a" && res.value()[1].chunk_id == "tie_b");
+    }
+    {   // metadata_filters: the record path (sqlite_vec_backend.cpp:4333-4409), AllMatching (:4398-4400)
+        auto idxR = vector::createAccelVectorIndex(plugin, 4);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        auto insert = [&](const char* id, const char* lane, std::vector<float> e) {
+            vector::VectorRecord r; r.chunk_id = id; r.document_hash = "d"; r.embedding = std::move(e);
+            r.metadata["lane"] = lane; r.metadata["kind"] = "x";
+            return db.insertVector(r);
+        };
+        CHECK(insert("a_best", "a", {1.0f, 0.0f, 0.0f, 0.0f}).has_value());
+        CHECK(insert("a_second", "a", {0.8f, 0.6f, 0.0f, 0.0f}).has_value());
+        CHECK(insert("b_best", "b", {1.0f, 0.0f, 0.0f, 0.0f}).has_value());
+        CHECK(insert("a_tiny", "a", {5e-6f, 0.0f, 0.0f, 0.0f}).has_value());   // norm^2 = 2.5e-11
+        vector::VectorSearchDiagnostics diag;
+        auto res = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::nullopt, {}, {{"lane", "a"}, {"kind", "x"}}, &diag);
+        CHECK(res.has_value() && res.value().size() == 2);   // a_tiny is a zero-norm row on this path (< 1e-10)
+        if (res && res.value().size() == 2) CHECK(res.value()[0].chunk_id == "a_best" && res.value()[1].chunk_id == "a_second");
+        CHECK(diag.rowsVisited == 4 && diag.exactDistanceEvaluations == 2 && diag.returnedRows == 2);
+        auto plain = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f);       // the fast path keeps it (norm^2 > 1e-12)
+        CHECK(plain.has_value() && plain.value().size() == 4);
+        auto miss = db.searchSimilar({1, 0, 0, 0}, 4, -1.0f, std::nullopt, {}, {{"lane", "a"}, {"kind", "y"}});
+        CHECK(miss.has_value() && miss.value().empty());
+        auto all = db.searchSimilar({1, 0, 0, 0}, 1, -1.0f, std::nullopt, {}, {{"kind", "x"}}, nullptr,
+                                    vector::ExactRowSelection::AllMatching);
+        CHECK(all.has_value() && all.value().size() == 3);           // k is ignored; a_tiny dropped
+        if (all && all.value().size() == 3) CHECK(all.value()[0].chunk_id == "a_best" && all.value()[1].chunk_id == "b_best");
+    }
+    {   // incremental mirror: appends extend the device mirror, replace/delete leave tombstones
+        auto idxR = vector::createAccelVectorIndex(plugin, 8);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        auto rec = [](int i, float tilt) {
+            vector::VectorRecord r; r.chunk_id = "c" + std::to_string(1000 + i); r.document_hash = "doc";
+            r.embedding = {1.0f, tilt * static_cast<float>(i + 1), 0, 0, 0, 0, 0, 0};
+            return r;
+        };
+        std::vector<vector::VectorRecord> first;
+        for (int i = 0; i < 100; ++i) first.push_back(rec(i, 0.01f));
+        CHECK(db.insertVectorsBatch(first).has_value());
+        auto r1 = db.searchSimilar({1, 0, 0, 0, 0, 0, 0, 0}, 1, -1.0f);
+        CHECK(r1.has_value() && r1.value().front().chunk_id == "c1000" && db.uploadedRows() == 100);
+        std::vector<vector::VectorRecord> more;
+        for (int i = 100; i < 150; ++i) more.push_back(rec(i, 0.01f));
+        more.push_back(rec(0, 5.0f));                                 // replaces c1000: now far from the query
+        more.push_back(rec(0, 7.0f));                                 // same id twice in one batch: last write wins
+        CHECK(db.insertVectorsBatch(more).has_value());
+        CHECK(db.getVectorCount().value() == 150 && db.mirrorRows() == 151);
+        auto r2 = db.searchSimilar({1, 0, 0, 0, 0, 0, 0, 0}, 2, -1.0f);
+        CHECK(r2.has_value() && r2.value().size() == 2 && r2.value()[0].chunk_id == "c1001" && r2.value()[1].chunk_id == "c1002");
+        CHECK(db.uploadedRows() == 151);                              // only the 51 new rows went up
+        CHECK(db.deleteVector("c1001").has_value());
+        auto r3 = db.searchSimilarBatch({{1, 0, 0, 0, 0, 0, 0, 0}}, 1, -1.0f);
+        CHECK(r3.has_value() && r3.value()[0].front().chunk_id == "c1002" && db.uploadedRows() == 151);
+        auto gone = db.searchSimilar({1, 7.0f, 0, 0, 0, 0, 0, 0}, 1, -1.0f);
+        CHECK(gone.has_value() && gone.value().front().chunk_id == "c1000" && gone.value().front().relevance_score > 0.9999f);
+        // compaction: more than 1024 tombstones and more than a quarter of the mirror
+        std::vector<vector::VectorRecord> bulk;
+        for (int i = 200; i < 3200; ++i) bulk.push_back(rec(i, 0.001f));
+        CHECK(db.insertVectorsBatch(bulk).has_value());
+        for (int i = 200; i < 1800; ++i) CHECK(db.deleteVector("c" + std::to_string(1000 + i)).has_value());
+        auto r4 = db.searchSimilar({1, 0, 0, 0, 0, 0, 0, 0}, 1, -1.0f);
+        CHECK(r4.has_value() && r4.value().front().chunk_id == "c1002");
+        CHECK(db.mirrorRows() == db.getVectorCount().value() && db.uploadedRows() == db.mirrorRows());
     }
     {   // large finite scores (+-FLT_MAX/4) stay finite
         const float L = std::numeric_limits<float>::max() / 4.0f;

@@ -155,6 +155,34 @@ def test_scan_skips_and_cosine_helper(oracle):
     assert oracle.cosine(c[0], c[4]) == 1.0 and oracle.cosine(c[0], c[1]) == 0.0
 
 
+def test_scan_record_path(oracle):
+    """The metadata-filter path (sqlite_vec_backend.cpp:4333-4409) restated: same scores as the
+    fast path, a different zero-norm rule (1e-10 vs 1e-12), full sort, optional AllMatching."""
+    # "breaks score ties deterministically" :304-353, the useMetadataFilter = true arm
+    for ids in (["tie_c", "tie_a", "tie_b"], ["tie_b", "tie_a", "tie_c"]):
+        rank, _ = _cases.string_ranks(ids)
+        c3 = np.tile(np.array([1, 0, 0, 0], np.float32), (3, 1))
+        rows, _, ev = oracle.scan_cosine_records(c3, np.array([1, 0, 0, 0], np.float32), 2, -1.0, tie_rank=rank)
+        assert [ids[r] for r in rows] == ["tie_a", "tie_b"] and ev == 3
+    # identical to the fast path when no row norm^2 falls in [1e-12, 1e-10)
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal((500, 24)).astype(np.float32)
+    q = rng.standard_normal(24).astype(np.float32)
+    a = oracle.scan_cosine(c, q, 20, 0.1)
+    b = oracle.scan_cosine_records(c, q, 20, 0.1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # a row with norm^2 = 4e-12: kept by the fast path (> 1e-12), dropped by the record path (< 1e-10)
+    c2 = np.array([[1, 0, 0, 0], [2e-6, 0, 0, 0], [0, 1, 0, 0]], np.float32)
+    q2 = np.array([1, 0, 0, 0], np.float32)
+    assert list(oracle.scan_cosine(c2, q2, 3, -1.0)[0]) == [0, 1, 2]
+    rows, _, ev = oracle.scan_cosine_records(c2, q2, 3, -1.0)
+    assert list(rows) == [0, 2] and ev == 2
+    # allow-list (the metadata predicate) and AllMatching (:4398-4400)
+    allow = np.zeros(500, np.uint8); allow[::7] = 1
+    rows, sims, ev = oracle.scan_cosine_records(c, q, 5, -1.0, allow=allow, all_matching=True)
+    assert len(rows) == ev == int(allow.sum()) and (rows % 7 == 0).all() and (np.diff(sims) <= 0).all()
+
+
 def test_l2_known_answers(oracle):
     # sqlite_vec_c_api_smoke_catch2_test.cpp:20-43 (reference): Euclidean distance WITH sqrt
     a = np.arange(8, dtype=np.float32)

@@ -10,7 +10,8 @@ import pytest
 
 import _cases
 from yams_amd import _lib
-from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER
+from yams_amd._lib import (SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER,
+                           FLAG_RECORD_PATH)
 
 pytestmark = pytest.mark.gpu
 
@@ -356,6 +357,38 @@ def test_row_mask_dense_and_sparse(acc, oracle, metric):
     keep = np.setdiff1d(np.arange(n), best)
     _masked(acc, oracle, corpus, q, 10, keep, metric)
     _masked(acc, oracle, corpus, q, 10, [], metric)               # empty candidate set -> no results
+
+
+def test_record_path_metadata_filters(acc, oracle):
+    """YAMS_SCAN_FLAG_RECORD_PATH = the reference's metadata-filter path (:4333-4409): the host folds
+    the metadata predicate into the allow-mask; rows with norm^2 in [1e-12, 1e-10) are dropped there
+    but kept by the fast path.  Dense mask -> MFMA filter, sparse mask -> gathered fp64 path."""
+    rng = np.random.default_rng(77)
+    n, d = 50000, 64
+    corpus = oracle.synth_rows(19, 0, n, d)
+    q = oracle.synth_rows(19, 1 << 40, 4, d)
+    qu = q / np.linalg.norm(q, axis=1, keepdims=True)
+    # rows parallel to the queries with norm^2 = 2.5e-11: cosine 1.0 — winners for the fast path only
+    for i in range(4):
+        corpus[1000 + i] = (qu[i] * 5e-6).astype(np.float32)
+    rank = rng.permutation(n).astype(np.uint32)
+    inv = np.empty_like(rank); inv[rank] = np.arange(n, dtype=rank.dtype)
+    for allowed in (np.sort(np.concatenate([np.arange(1000, 1004), rng.choice(n, 30000, replace=False)])),
+                    np.sort(np.concatenate([np.arange(1000, 1004), rng.choice(n, 500, replace=False)]))):
+        allowed = np.unique(allowed)
+        bits = np.zeros((n + 31) // 32 * 32, np.uint8); bits[allowed] = 1
+        words = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+        dc, dm, dr, di = acc.to_device(corpus), acc.to_device(words), acc.to_device(rank), acc.to_device(inv)
+        view = acc.corpus_view(dc.ptr, n, d, dr.ptr, di.ptr, 0, dm.ptr, len(allowed))
+        allow8 = bits[:n]
+        fast = acc.scan_topk(view, q, 10, -1.0, SCAN_COSINE, 0)
+        rec = acc.scan_topk(view, q, 10, -1.0, SCAN_COSINE, FLAG_RECORD_PATH)
+        for qi in range(4):
+            rows, sims, _ = oracle.scan_cosine_records(corpus, q[qi], 10, -1.0, rank.astype(np.uint64), allow8)
+            assert np.array_equal(rec.rows[qi, :rec.counts[qi]], rows), (qi, rec.diag)
+            assert np.array_equal(rec.scores[qi, :rec.counts[qi]].view(np.uint32), sims.view(np.uint32))
+            assert 1000 + qi not in rec.rows[qi]            # dropped: norm^2 < 1e-10
+            assert fast.rows[qi, 0] == 1000 + qi            # kept by the fast path: norm^2 > 1e-12
 
 
 # ---- shard merge (the step after the RCCL all-gather) ---------------------------------------------

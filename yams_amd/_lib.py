@@ -18,7 +18,7 @@ YAMS_OK, YAMS_ERR_INVALID_ARG, YAMS_ERR_NOT_FOUND, YAMS_ERR_IO, YAMS_ERR_INTERNA
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NOT_FOUND", 3: "IO", 4: "INTERNAL", 5: "UNSUPPORTED"}
 SCAN_COSINE, SCAN_L2 = 0, 1
 CDC_RABIN, CDC_STREAMING = 0, 1
-FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER = 1, 2, 4, 8
+FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG_RECORD_PATH = 1, 2, 4, 8, 16
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2
 
 vp = C.c_void_p

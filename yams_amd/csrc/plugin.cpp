@@ -197,10 +197,10 @@ yams_status_t vs_corpus_size(void*, uint64_t id, uint64_t* out_rows, uint32_t* o
     return YAMS_OK;
 }
 
-yams_status_t vs_search_batch_masked(void*, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
-                                     uint32_t k, float threshold, uint32_t metric,
-                                     const uint32_t* row_mask_host, yams_scan_hit_t** out_hits,
-                                     uint32_t** out_counts, yams_scan_diag_t* out_diag) {
+yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
+                                 uint32_t k, float threshold, uint32_t metric, uint32_t flags,
+                                 const uint32_t* row_mask_host, yams_scan_hit_t** out_hits,
+                                 uint32_t** out_counts, yams_scan_diag_t* out_diag) {
     std::lock_guard<std::mutex> lk(g.mu);
     NEED_CTX();
     if (!out_hits || !out_counts) return YAMS_ERR_INVALID_ARG;
@@ -228,7 +228,8 @@ yams_status_t vs_search_batch_masked(void*, uint64_t id, const float* queries, u
         if (yams_accel_upload(g.ctx, d_mask, row_mask_host, words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
         view.row_mask = d_mask; view.row_mask_count = bits;
     }
-    yams_scan_params_t prm{k, threshold, metric, 0};
+    // only semantic flags cross the vtable; filter selection stays with the library
+    yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT)};
     const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
     std::vector<float> scores(slots), dist(slots);
     std::vector<int64_t> rows(slots);
@@ -247,6 +248,14 @@ yams_status_t vs_search_batch_masked(void*, uint64_t id, const float* queries, u
     ++g.searches;
     *out_hits = hits; *out_counts = counts;
     return YAMS_OK;
+}
+
+yams_status_t vs_search_batch_masked(void* self, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
+                                     uint32_t k, float threshold, uint32_t metric,
+                                     const uint32_t* row_mask_host, yams_scan_hit_t** out_hits,
+                                     uint32_t** out_counts, yams_scan_diag_t* out_diag) {
+    return vs_search_batch_ex(self, id, queries, nq, dim, k, threshold, metric, 0, row_mask_host, out_hits,
+                              out_counts, out_diag);
 }
 
 yams_status_t vs_search_batch(void* self, uint64_t id, const float* queries, uint32_t nq, uint32_t dim,
@@ -269,7 +278,7 @@ void vs_free_string(void*, char* s) { std::free(s); }
 yams_vector_scan_v1 g_vector_scan = {
     YAMS_IFACE_VECTOR_SCAN_V1_VERSION, nullptr, vs_corpus_create, vs_corpus_append,
     vs_corpus_set_tie_ranks, vs_corpus_clear, vs_corpus_destroy, vs_corpus_size, vs_search_batch,
-    vs_free_hits, vs_runtime_info, vs_free_string, vs_search_batch_masked};
+    vs_free_hits, vs_runtime_info, vs_free_string, vs_search_batch_masked, vs_search_batch_ex};
 
 // ---- content_hash_v1 --------------------------------------------------------------------------
 yams_status_t ch_hash(void*, const uint8_t* data, size_t n, char out_hex[65]) {

@@ -95,8 +95,8 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
             TimedRegion tr(ctx, "exact_keys");
             YA_HIP(ctx, launch_exact_keys(ctx->stream, metric, c.rows, c.n_rows, c.dim, io.queries,
                                           d_qnorm, c.tie_rank, c.row_mask, d_rows_sel, n_sel,
-                                          d_qmap + b0, nb, io.prm.similarity_threshold, d_keys,
-                                          key_stride));
+                                          d_qmap + b0, nb, io.prm.similarity_threshold, io.prm.flags,
+                                          d_keys, key_stride));
             tr.end();
         }
         const uint64_t* res; uint64_t res_stride;

@@ -541,7 +541,8 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
         const uint32_t rank = a.tie_rank ? a.tie_rank[row] : row;
         if (METRIC == YAMS_SCAN_COSINE) {
             // all elements finite <=> nsq finite (fp64 cannot overflow on fp32 squares)
-            if (!isfinite(nsq) || nsq <= 1e-12) continue;           // :4258-4269
+            // :4258-4269; the record path drops norm^2 < 1e-10 instead (isZeroNormEmbedding, :204-211)
+            if (!isfinite(nsq) || ((a.flags & YAMS_SCAN_FLAG_RECORD_PATH) ? nsq < 1e-10 : nsq <= 1e-12)) continue;
             const double denom = sqrt(nsq) * qn;                    // :4271
             const double sd = denom > 0.0 ? dot / denom : 0.0;
             if (!isfinite(sd)) continue;                            // :4273-4275
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
                                                          const uint32_t* row_mask,
                                                          const uint32_t* rows_sel, uint64_t n_sel,
                                                          const uint32_t* qmap, float threshold,
+                                                         uint32_t flags,
                                                          uint64_t* keys, uint64_t key_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sq = reinterpret_cast<float*>(smem);
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
     uint64_t key = 0;
     const uint32_t kidx = tie_rank ? tie_rank[row] : static_cast<uint32_t>(row);
     if (METRIC == YAMS_SCAN_COSINE) {
-        if (isfinite(nsq) && nsq > 1e-12) {
+        if (isfinite(nsq) && ((flags & YAMS_SCAN_FLAG_RECORD_PATH) ? nsq >= 1e-10 : nsq > 1e-12)) {
             const double denom = sqrt(nsq) * qnorm[q];
             const double sd = denom > 0.0 ? dot / denom : 0.0;
             if (isfinite(sd)) {
@@ -1062,17 +1064,18 @@ hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint
                              uint32_t dim, const float* queries, const double* qnorm,
                              const uint32_t* tie_rank, const uint32_t* row_mask,
                              const uint32_t* rows_sel, uint64_t n_sel, const uint32_t* qmap,
-                             uint32_t n_slots, float threshold, uint64_t* keys, uint64_t key_stride) {
+                             uint32_t n_slots, float threshold, uint32_t flags, uint64_t* keys,
+                             uint64_t key_stride) {
     const uint64_t n_items = rows_sel ? n_sel : n_rows;
     if (n_items == 0) return hipSuccess;
     const uint32_t gx = static_cast<uint32_t>((n_items + 255) / 256);
     const size_t sh = static_cast<size_t>(dim) * sizeof(float);
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_COSINE>), dim3(gx, n_slots), dim3(256), sh,
-                           st, rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, keys, key_stride);
+                           st, rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
     else
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2>), dim3(gx, n_slots), dim3(256), sh, st,
-                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, keys, key_stride);
+                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
     LAUNCH_CHECK();
     return hipSuccess;
 }

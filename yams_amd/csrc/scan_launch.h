@@ -68,7 +68,8 @@ hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint
                              uint32_t dim, const float* queries, const double* qnorm,
                              const uint32_t* tie_rank, const uint32_t* row_mask,
                              const uint32_t* rows_sel, uint64_t n_sel, const uint32_t* qmap,
-                             uint32_t n_slots, float threshold, uint64_t* keys, uint64_t key_stride);
+                             uint32_t n_slots, float threshold, uint32_t flags, uint64_t* keys,
+                             uint64_t key_stride);
 hipError_t launch_compact_mask(hipStream_t st, const uint32_t* row_mask, uint64_t n_rows,
                                uint32_t* rows_sel, unsigned long long* counter);
 hipError_t launch_topk_keys(hipStream_t st, const uint64_t* keys, uint64_t key_stride,
