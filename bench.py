@@ -144,6 +144,23 @@ def ingest_leg(acc, gib, seed):
            "sha256_kernel_ms": sha_ms, "cdc_candidates_kernel_ms": cdc_ms,
            "chunker": "StreamingChunker defaults (min 16 KiB, max 1 MiB, mask 0x1FFF)",
            "digests": "per-chunk + whole-blob (every byte hashed twice)"}
+    # the dedup lookup that follows in ContentStore::store (one exists() per chunk in the reference):
+    # all chunk digests of the batch against an empty device set, then again (everything known)
+    try:
+        n = int(res.n_chunks)
+        dset = acc.dedup_set(n)
+        flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+        t0 = time.perf_counter()
+        n_new, b_new, b_dup = dset.insert_device(res.chunk_digest, n, res.chunk_size, flags.data_ptr())
+        t1 = time.perf_counter()
+        n_new2, _, _ = dset.insert_device(res.chunk_digest, n, res.chunk_size, flags.data_ptr())
+        t2 = time.perf_counter()
+        out["dedup"] = {"digests": n, "new_first_pass": n_new, "new_second_pass": n_new2,
+                        "insert_ms": (t1 - t0) * 1e3, "reinsert_ms": (t2 - t1) * 1e3,
+                        "lookups_per_s": n / (t2 - t1), "bytes_new": b_new, "bytes_deduped": b_dup}
+        dset.close()
+    except Exception as e:  # the ingest number above stands on its own
+        out["dedup"] = {"error": str(e)}
     del tb
     return out
 

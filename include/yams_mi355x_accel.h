@@ -240,6 +240,16 @@ YAMS_ACCEL_API yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const
                                                       const uint64_t* offsets,
                                                       const uint64_t* lengths, uint64_t n_msgs,
                                                       uint8_t* digests);
+/* Batched integrity check (ChunkValidator::validateChunks / validateManifest,
+ * src/integrity/chunk_validator.cpp:36-120,160-212,230-262): re-hash n_chunks byte ranges of one
+ * device buffer and compare with the expected raw 32-byte digests (device, any alignment).
+ * out_valid[i] = 1 iff SHA-256(data[offsets[i] .. +lengths[i])) == expected_digests[i];
+ * *out_n_invalid = number of mismatches.  Synchronises the context's stream. */
+YAMS_ACCEL_API yams_status_t yams_verify_chunks_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                                       const uint64_t* offsets,
+                                                       const uint64_t* lengths, uint64_t n_chunks,
+                                                       const uint8_t* expected_digests,
+                                                       uint8_t* out_valid, uint64_t* out_n_invalid);
 /* One-shot over host memory: SHA256Hasher::hash(span), sha256_hasher.cpp:167-195.
  * out_hex receives 64 lower-case hex characters + NUL (bytesToHex, :19-30). */
 YAMS_ACCEL_API yams_status_t yams_sha256_host(yams_accel_ctx* ctx, const uint8_t* data_host,
@@ -310,6 +320,37 @@ YAMS_ACCEL_API yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint
                                                  uint64_t* offsets, uint64_t* sizes,
                                                  char* hex /* [cap][65] */, size_t cap,
                                                  size_t* out_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Chunk dedup lookup: a device-resident set of SHA-256 digests.
+ *
+ * Replaces the per-chunk `storage_->exists(chunk.hash)` round trips of ContentStore::store
+ * (src/api/content_store_impl.cpp:246-287).  The reference walks the chunk list in order: a chunk
+ * is stored iff its hash is neither in the store nor carried by an EARLIER chunk of the same walk;
+ * yams_dedup_insert_* answers exactly that per chunk (is_new[i]; first occurrence = lowest index)
+ * and adds the new digests to the set, so one call per ingest batch replaces n exists() calls.
+ * Digests are raw 32-byte values (the `chunk_digest` array of yams_ingest_result_t), 8-byte
+ * aligned.  The set grows by rehashing; calls synchronise the context's stream.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct yams_dedup_set yams_dedup_set;
+YAMS_ACCEL_API yams_status_t yams_dedup_set_create(yams_accel_ctx* ctx, uint64_t expected_entries,
+                                                   yams_dedup_set** out_set);
+YAMS_ACCEL_API void yams_dedup_set_destroy(yams_dedup_set* set);
+YAMS_ACCEL_API yams_status_t yams_dedup_set_size(const yams_dedup_set* set, uint64_t* out_entries);
+/* chunk_sizes (device, nullable): when given, out_bytes_new / out_bytes_deduped receive the
+ * bytesStored / bytesDeduped sums of content_store_impl.cpp:255,274. */
+YAMS_ACCEL_API yams_status_t yams_dedup_insert_device(yams_dedup_set* set, const uint8_t* digests,
+                                                      uint64_t n, const uint64_t* chunk_sizes,
+                                                      uint8_t* out_is_new, uint64_t* out_n_new,
+                                                      uint64_t* out_bytes_new,
+                                                      uint64_t* out_bytes_deduped);
+YAMS_ACCEL_API yams_status_t yams_dedup_probe_device(yams_dedup_set* set, const uint8_t* digests,
+                                                     uint64_t n, uint8_t* out_exists);
+YAMS_ACCEL_API yams_status_t yams_dedup_insert_host(yams_dedup_set* set, const uint8_t* digests_host,
+                                                    uint64_t n, uint8_t* out_is_new_host,
+                                                    uint64_t* out_n_new);
+YAMS_ACCEL_API yams_status_t yams_dedup_probe_host(yams_dedup_set* set, const uint8_t* digests_host,
+                                                   uint64_t n, uint8_t* out_exists_host);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Plugin vtables (obtained through yams_plugin_get_interface)                                  */

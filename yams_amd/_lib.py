@@ -132,7 +132,9 @@ EXPORTS = [
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device",
     "yams_scan_build_shadow_device",
     "yams_synth_rows_device", "yams_synth_bytes_device", "yams_sha256_batch_device",
-    "yams_sha256_host", "yams_sha256_many_host", "yams_cdc_default_config",
+    "yams_sha256_host", "yams_sha256_many_host", "yams_verify_chunks_device", "yams_cdc_default_config",
+    "yams_dedup_set_create", "yams_dedup_set_destroy", "yams_dedup_set_size", "yams_dedup_insert_device",
+    "yams_dedup_probe_device", "yams_dedup_insert_host", "yams_dedup_probe_host",
     "yams_cdc_chunk_device", "yams_ingest_device", "yams_cdc_chunk_host",
     "yams_plugin_get_abi_version", "yams_plugin_get_name", "yams_plugin_get_version",
     "yams_plugin_get_manifest_json", "yams_plugin_init", "yams_plugin_shutdown",
@@ -193,6 +195,15 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     L.yams_synth_bytes_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     L.yams_sha256_batch_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
+    L.yams_verify_chunks_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, u64p]
+    L.yams_dedup_set_create.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.yams_dedup_set_destroy.argtypes = [vp]
+    L.yams_dedup_set_destroy.restype = None
+    L.yams_dedup_set_size.argtypes = [vp, u64p]
+    L.yams_dedup_insert_device.argtypes = [vp, vp, C.c_uint64, vp, vp, u64p, u64p, u64p]
+    L.yams_dedup_probe_device.argtypes = [vp, vp, C.c_uint64, vp]
+    L.yams_dedup_insert_host.argtypes = [vp, vp, C.c_uint64, vp, u64p]
+    L.yams_dedup_probe_host.argtypes = [vp, vp, C.c_uint64, vp]
     L.yams_sha256_host.argtypes = [vp, vp, C.c_size_t, C.c_char_p]
     L.yams_sha256_many_host.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t,
                                         C.c_char_p]

@@ -69,6 +69,54 @@ class ScanResult:
     diag: dict
 
 
+class DedupSet:
+    """Device-resident set of SHA-256 digests (chunk dedup lookup)."""
+
+    def __init__(self, acc: "Accel", expected_entries: int = 0):
+        self.acc = acc
+        self.h = C.c_void_p()
+        acc._check(acc.L.yams_dedup_set_create(acc.ctx, expected_entries, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.acc.L.yams_dedup_set_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_uint64(0)
+        self.acc._check(self.acc.L.yams_dedup_set_size(self.h, C.byref(n)))
+        return n.value
+
+    def insert(self, digests: np.ndarray) -> np.ndarray:
+        """digests: [n][32] uint8 (host).  Returns is_new[n] (bool)."""
+        d = np.ascontiguousarray(digests, np.uint8).reshape(-1, 32)
+        out = np.zeros(d.shape[0], np.uint8)
+        nn = C.c_uint64(0)
+        self.acc._check(self.acc.L.yams_dedup_insert_host(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0],
+                                                          out.ctypes.data_as(C.c_void_p), C.byref(nn)))
+        assert nn.value == int(out.sum())
+        return out.astype(bool)
+
+    def probe(self, digests: np.ndarray) -> np.ndarray:
+        d = np.ascontiguousarray(digests, np.uint8).reshape(-1, 32)
+        out = np.zeros(d.shape[0], np.uint8)
+        self.acc._check(self.acc.L.yams_dedup_probe_host(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0],
+                                                         out.ctypes.data_as(C.c_void_p)))
+        return out.astype(bool)
+
+    def insert_device(self, digests_ptr: int, n: int, sizes_ptr: int | None, is_new_ptr: int):
+        nn, bn, bd = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.acc._check(self.acc.L.yams_dedup_insert_device(self.h, digests_ptr, n, sizes_ptr, is_new_ptr,
+                                                            C.byref(nn), C.byref(bn), C.byref(bd)))
+        return nn.value, bn.value, bd.value
+
+
 class Accel:
     def __init__(self, device: int = 0, stream: int | None = None):
         self.L = _lib.load()
@@ -213,6 +261,16 @@ class Accel:
                                                     n, digests_ptr))
 
     # ---- chunking / ingest ----------------------------------------------------------------------
+    def verify_chunks_device(self, data_ptr, offsets_ptr, lengths_ptr, n, expected_ptr, valid_ptr) -> int:
+        """Batched integrity check; returns the number of mismatching chunks."""
+        bad = C.c_uint64(0)
+        self._check(self.L.yams_verify_chunks_device(self.ctx, data_ptr, offsets_ptr, lengths_ptr, n,
+                                                     expected_ptr, valid_ptr, C.byref(bad)))
+        return bad.value
+
+    def dedup_set(self, expected_entries: int = 0) -> "DedupSet":
+        return DedupSet(self, expected_entries)
+
     def chunk(self, data, cfg: CdcConfig | None = None, with_hashes: bool = True):
         """IChunker::chunkDataLazy over host memory -> (offsets, sizes, hex hashes | None)."""
         cfg = cfg or cdc_config()

@@ -237,6 +237,28 @@ yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const uint8_t* data,
     return YAMS_OK;
 }
 
+yams_status_t yams_verify_chunks_device(yams_accel_ctx* ctx, const uint8_t* data,
+                                        const uint64_t* offsets, const uint64_t* lengths,
+                                        uint64_t n_chunks, const uint8_t* expected_digests,
+                                        uint8_t* out_valid, uint64_t* out_n_invalid) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (out_n_invalid) *out_n_invalid = 0;
+    if (n_chunks == 0) return YAMS_OK;
+    if (!expected_digests || !out_valid) return fail(ctx, YAMS_ERR_INVALID_ARG, "null expected digests / out_valid");
+    (void)hipSetDevice(ctx->device);
+    uint8_t* d_actual; unsigned long long* d_bad;
+    YA_TRY(ws_get(ctx, "verify_digests", n_chunks * 32, (void**)&d_actual));
+    YA_TRY(ws_get(ctx, "verify_count", 64, (void**)&d_bad));
+    YA_TRY(yams_sha256_batch_device(ctx, data, offsets, lengths, n_chunks, d_actual));
+    YA_HIP(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    YA_HIP(ctx, launch_digest_compare(ctx->stream, d_actual, expected_digests, n_chunks, out_valid, d_bad));
+    unsigned long long h = 0;
+    YA_HIP(ctx, hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_n_invalid) *out_n_invalid = h;
+    return YAMS_OK;
+}
+
 yams_status_t yams_sha256_many_host(yams_accel_ctx* ctx, const uint8_t* const* msgs_host,
                                     const size_t* lens, size_t n_msgs, char* out_hex) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;

@@ -781,6 +781,31 @@ __global__ __launch_bounds__(128 * LONG_PAIRS) void sha256_long_kernel(const uin
     }
 }
 
+// Batched integrity check: valid[i] = (digest_i == expected_i); counts the mismatches.
+// (ChunkValidator::validateChunkInternal compares the hex strings, src/integrity/chunk_validator.cpp:
+// 230-262; the 32 raw bytes decide the same thing.)
+__global__ __launch_bounds__(256) void digest_compare_kernel(const uint8_t* actual, const uint8_t* expected,
+                                                             uint64_t n, uint8_t* valid,
+                                                             unsigned long long* n_invalid) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(actual + i * 32);
+        const uint8_t* e = expected + i * 32; // any alignment
+        uint32_t diff = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t ew = static_cast<uint32_t>(e[4 * w]) | (static_cast<uint32_t>(e[4 * w + 1]) << 8) |
+                                (static_cast<uint32_t>(e[4 * w + 2]) << 16) | (static_cast<uint32_t>(e[4 * w + 3]) << 24);
+            diff |= a[w] ^ ew;
+        }
+        bad = diff != 0;
+        valid[i] = bad ? 0 : 1;
+    }
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_invalid, static_cast<unsigned long long>(__popcll(m)));
+}
+
 // =================================================================================================
 // Launchers
 // =================================================================================================
@@ -861,6 +886,15 @@ hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_
     if (n_msgs == 0) return hipSuccess;
     hipLaunchKernelGGL(sha256_long_kernel, dim3(static_cast<uint32_t>((n_msgs + 64 * LONG_PAIRS - 1) / (64 * LONG_PAIRS))),
                        dim3(128 * LONG_PAIRS), 0, st, data, offs, lens, out_slot, n_msgs, digests);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_digest_compare(hipStream_t st, const uint8_t* actual, const uint8_t* expected, uint64_t n,
+                                 uint8_t* valid, unsigned long long* n_invalid) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(digest_compare_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, st,
+                       actual, expected, n, valid, n_invalid);
     LAUNCH_CHECK();
     return hipSuccess;
 }

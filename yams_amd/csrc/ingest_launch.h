@@ -39,5 +39,7 @@ hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* of
 hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_t* offs,
                               const uint64_t* lens, const uint32_t* out_slot, uint64_t n_msgs,
                               uint8_t* digests);
+hipError_t launch_digest_compare(hipStream_t st, const uint8_t* actual, const uint8_t* expected, uint64_t n,
+                                 uint8_t* valid, unsigned long long* n_invalid);
 
 } // namespace yams_accel
