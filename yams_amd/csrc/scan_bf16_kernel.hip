@@ -595,8 +595,16 @@ constexpr int SH_STAGE = SH_A_BYTES + SH_B_BYTES;
 
 struct ShFrags { bf16x8 a[2]; bf16x8 b[4]; };
 
-template <int MODE, int METRIC, int ABL = 0>
-__global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArgs a) {
+// NW = waves per workgroup: 8 -> 4x2 waves of 64 rows x 128 queries (two waves per SIMD),
+//                            4 -> 2x2 waves of 128 rows x 128 queries (one wave per SIMD, 256
+//                                 accumulator registers): a third less fragment-read traffic
+//                                 (64 instead of 96 KiB per slab), twice the DMA pieces per wave.
+template <int MODE, int METRIC, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_kernel(ScanArgs a) {
+    constexpr int RB = 16 / NW;       // 32-row blocks per wave (2 or 4)
+    constexpr int PA = 16 / NW;       // DMA pieces per wave per operand per slab (2 or 4)
+    constexpr int P = 2 * PA;         // DMA pieces per wave per slab
+    constexpr int M = RB * 4;         // MFMAs per 16-wide step
     __shared__ __attribute__((aligned(16))) unsigned char lds[SH_NST * SH_STAGE];
 
     const uint32_t bid = blockIdx.x;
@@ -612,19 +620,19 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) x queries [128 wc, +128)
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [32 RB wr, +32 RB) x queries [128 wc, +128)
     const int h = lane >> 5, l31 = lane & 31;
     const uint64_t row0 = static_cast<uint64_t>(tile) * BT_ROWS;
     const uint32_t q0 = qt * BT_QUERIES;
     const uint32_t dim = a.dim;
     const int nslab = dim / SH_K; // dim % 32 == 0 is a precondition of this kernel
 
-    // ---- DMA sources: every wave stages 32 rows (2 instructions) and 32 queries (2) -------------
+    // ---- DMA sources: every wave stages 16 PA rows and 16 PA queries per slab --------------------
     // address = uniform base (tile / query-tile start + slab offset, SGPRs) + per-lane byte offset
-    uint32_t voffA[2], voffB[2];
+    uint32_t voffA[PA], voffB[PA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rowA = wid * 32 + i * 16 + (lane >> 2);
+    for (int i = 0; i < PA; ++i) {
+        const int rowA = (wid * PA + i) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((rowA >> 2) & 3);
         uint64_t r = row0 + rowA;
         if (r >= a.n_rows) r = a.n_rows - 1; // row0 < n_rows, so r - row0 >= 0
@@ -636,22 +644,22 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
-    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
-    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + wid * 2048);
-    // One slab = 4 DMA pieces per wave (p = 0,1: rows; 2,3: queries).  All 32 pieces of a slab
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * PA * 1024);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + wid * PA * 1024);
+    // One slab = P DMA pieces per wave (p < PA: rows; else queries).  All 32 pieces of a slab
     // issued in one burst after the barrier fill the CU's load queue and stall every wave in front
     // of its MFMAs (measured: adding the refills to an LDS-read + MFMA loop added their whole
     // stand-alone time), so the pieces are issued one at a time between MFMAs, half a slab per step.
     auto piece = [&](int s, int p) {
         if ((ABL == 1 || ABL == 3 || ABL == 4 || ABL == 5) && s >= SH_NST) return; // measurement builds, see above
         const uint32_t st = (s & (SH_NST - 1)) * SH_STAGE;
-        if (p < 2) lds_dma16_s(baseA + s * (SH_K * 2), voffA[p], ldsA + st + p * 1024);
-        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p - 2], ldsB + st + (p - 2) * 1024);
+        if (p < PA) lds_dma16_s(baseA + s * (SH_K * 2), voffA[p < PA ? p : 0], ldsA + st + p * 1024);
+        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= PA ? p - PA : 0], ldsB + st + (p - PA) * 1024);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[RB][4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -659,10 +667,10 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
 
     // fragment offsets inside a stage, per 16-wide step t: logical chunk 2t + h of the row / query,
     // stored at position chunk ^ ((index >> 2) & 3)
-    int offA[2][2], offB[4][2];
+    int offA[RB][2], offB[4][2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int rf = wr * 64 + rb * 32 + l31;
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rf = wr * (32 * RB) + rb * 32 + l31;
         const int f = (rf >> 2) & 3;
 #pragma unroll
         for (int t = 0; t < 2; ++t) offA[rb][t] = rf * 64 + (((2 * t + h) ^ f) << 4);
@@ -674,31 +682,37 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
 #pragma unroll
         for (int t = 0; t < 2; ++t) offB[u][t] = SH_A_BYTES + rq * 64 + (((2 * t + h) ^ f) << 4);
     }
-    auto load = [&](ShFrags& fr, const unsigned char* base, int t) {
+    struct Frags { bf16x8 a[RB]; bf16x8 b[4]; };
+    auto load = [&](Frags& fr, const unsigned char* base, int t) {
         if ((ABL == 4 || ABL == 5) && base != lds) return;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) fr.a[rb] = *reinterpret_cast<const bf16x8*>(base + offA[rb][t]);
+        for (int rb = 0; rb < RB; ++rb) fr.a[rb] = *reinterpret_cast<const bf16x8*>(base + offA[rb][t]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) fr.b[u] = *reinterpret_cast<const bf16x8*>(base + offB[u][t]);
     };
-    auto pin = [&](ShFrags& fr) {
-        asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.b[0]), "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
+    auto pin = [&](Frags& fr) {
+        if constexpr (RB == 2)
+            asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.b[0]), "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
+        else
+            asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.a[RB - 2]), "+v"(fr.a[RB - 1]), "+v"(fr.b[0]),
+                         "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
     };
-    // One 16-wide step: 8 MFMAs on `cur`, with the 6 fragment reads of the NEXT step and (when
-    // slab_dma >= 0) DMA pieces p0, p0+1 of that slab placed one per MFMA gap.  A burst of reads
-    // in front of the MFMAs leaves the matrix pipe idle when both waves of a SIMD are in it at the
-    // same time (a bare MFMA stream runs 32 cycles per instruction, micro-benchmark
+    // One 16-wide step: M MFMAs on `cur`, with the RB + 4 fragment reads of the NEXT step and (when
+    // slab_dma >= 0) DMA pieces p0 .. p0 + PA - 1 of that slab placed one per MFMA gap.  A burst of
+    // reads in front of the MFMAs leaves the matrix pipe idle when both waves of a SIMD are in it at
+    // the same time (a bare MFMA stream runs 32 cycles per instruction, micro-benchmark
     // scripts/ubench/mfma_rate.hip; this loop ran 43); up to ~5 single-issue instructions hide in
     // each 32-cycle gap.
-    auto step = [&](const ShFrags& cur, ShFrags& nxt, const unsigned char* nbase, int nt, bool do_load,
+    auto step = [&](const Frags& cur, Frags& nxt, const unsigned char* nbase, int nt, bool do_load,
                     int slab_dma, int p0) {
         const bool rd = do_load && !((ABL == 4 || ABL == 5) && nbase != lds);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < M; ++i) {
             const int rb = i >> 2, u = i & 3;
             if (ABL == 2 || ABL == 3) {
                 if (i == 0) {
-                    asm volatile("" :: "v"(cur.a[0]), "v"(cur.a[1]));
+#pragma unroll
+                    for (int v = 0; v < RB; ++v) asm volatile("" :: "v"(cur.a[v]));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) asm volatile("" :: "v"(cur.b[v]));
                 }
@@ -706,19 +720,26 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
                 acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb], cur.b[u], acc[rb][u], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (rd && i < 2) nxt.a[i] = *reinterpret_cast<const bf16x8*>(nbase + offA[i][nt]);
-            if (rd && i >= 2 && i < 6) nxt.b[i - 2] = *reinterpret_cast<const bf16x8*>(nbase + offB[i - 2][nt]);
-            if (slab_dma >= 0 && (i == 3 || i == 6)) piece(slab_dma, p0 + (i == 6 ? 1 : 0));
+            if (rd && i < RB) nxt.a[i < RB ? i : 0] = *reinterpret_cast<const bf16x8*>(nbase + offA[i < RB ? i : 0][nt]);
+            if (rd && i >= RB && i < RB + 4) nxt.b[i - RB] = *reinterpret_cast<const bf16x8*>(nbase + offB[i - RB][nt]);
+            // pieces after MFMA 3, 6 (8-MFMA steps) / 3, 7, 11, 14 (16-MFMA steps)
+            if (slab_dma >= 0) {
+                if constexpr (M == 8) {
+                    if (i == 3 || i == 6) piece(slab_dma, p0 + (i == 6 ? 1 : 0));
+                } else {
+                    if (i == 3 || i == 7 || i == 11 || i == 14) piece(slab_dma, p0 + (i == 3 ? 0 : i == 7 ? 1 : i == 11 ? 2 : 3));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // epilogue inputs, requested now: a load issued at the end would sit on the critical path of
     // every tile (rows_nsq streams from HBM), here it hides under the whole k loop
-    float nfull_pre[2], tau_pre[4];
+    float nfull_pre[RB], tau_pre[4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const uint64_t r = row0 + static_cast<uint32_t>(wr * 64 + rb * 32) + l31;
+    for (int rb = 0; rb < RB; ++rb) {
+        const uint64_t r = row0 + static_cast<uint32_t>(wr * (32 * RB) + rb * 32) + l31;
         nfull_pre[rb] = r < a.n_rows ? a.rows_nsq[r] : 1.f;
     }
 #pragma unroll
@@ -731,18 +752,20 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     // epilogue)
 
     // ---- prologue: slabs 0..2 and the first half of slab 3 in flight, slab 0 landed ---------------
+    auto wait_vm = [&](int pieces) { // s_waitcnt vmcnt(pieces) for the few values the schedule needs
+        if (pieces >= 5 * PA) { if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+        else if (pieces >= 4 * PA) { if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+        else if (pieces >= 2 * PA) { if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     {
         int issued = 0;
-        for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < 4; ++p) piece(s, p); issued += 4; }
-        if (nslab > 3) { piece(3, 0); piece(3, 1); issued += 2; }
-        const int newer = issued - 4;
-        if (newer >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (newer >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (newer >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < P; ++p) piece(s, p); issued += P; }
+        if (nslab > 3) { for (int p = 0; p < PA; ++p) piece(3, p); issued += PA; }
+        wait_vm(issued - P);
         __builtin_amdgcn_s_barrier();
     }
-    ShFrags f0, f1;
+    Frags f0, f1;
     load(f0, lds, 0);
     int stage = 0;
     // Same half-shifted pipeline as above: the barrier for slab s+1 sits between the two steps of
@@ -752,19 +775,25 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     auto body = [&](int s, auto h1_tag, auto h2_tag, auto vm_tag) {
         constexpr bool H1 = decltype(h1_tag)::value;
         constexpr bool H2 = decltype(h2_tag)::value;
-        constexpr int VM = decltype(vm_tag)::value;
+        constexpr int VM = decltype(vm_tag)::value; // in slabs: 2, 1 or 0 newer slabs may be in flight
         const unsigned char* base = lds + stage * SH_STAGE;
         stage = (stage + 1) & (SH_NST - 1);
         // f0 was requested during the previous step: make the compiler place its (conservative,
         // whole-counter) LDS wait HERE, before the next reads go out, not in front of an MFMA
         pin(f0);
         __builtin_amdgcn_sched_barrier(0);
-        step(f0, f1, base, 1, true, H1 ? s + 3 : -1, 2);
-        // slab s+1 landed (VM DMA pieces of newer slabs may be in flight); all reads of slab s
+        step(f0, f1, base, 1, true, H1 ? s + 3 : -1, PA);
+        // slab s+1 landed (VM slabs of newer DMA pieces may be in flight); all reads of slab s
         // (f1 last) complete before its stage is refilled with slab s+4
-        if (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (P == 4) {
+            if (VM == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (VM == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            if (VM == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else if (VM == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         if (ABL != 5) __builtin_amdgcn_s_barrier();
         pin(f1);
         __builtin_amdgcn_sched_barrier(0);
@@ -772,13 +801,13 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
     };
     using T = std::integral_constant<bool, true>;
     using F = std::integral_constant<bool, false>;
-    using V8 = std::integral_constant<int, 8>;
-    using V4 = std::integral_constant<int, 4>;
+    using V2 = std::integral_constant<int, 2>;
+    using V1 = std::integral_constant<int, 1>;
     using V0 = std::integral_constant<int, 0>;
     int s = 0;
-    for (; s + 4 < nslab; ++s) body(s, T{}, T{}, V8{});
-    if (s + 3 < nslab) { body(s, T{}, F{}, V8{}); ++s; }
-    if (s + 2 < nslab) { body(s, F{}, F{}, V4{}); ++s; }
+    for (; s + 4 < nslab; ++s) body(s, T{}, T{}, V2{});
+    if (s + 3 < nslab) { body(s, T{}, F{}, V2{}); ++s; }
+    if (s + 2 < nslab) { body(s, F{}, F{}, V1{}); ++s; }
     if (s + 1 < nslab) { body(s, F{}, F{}, V0{}); ++s; }
     {   // last slab: nothing left to wait for or to prefetch after its second step
         pin(f0);
@@ -789,10 +818,224 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16s_kernel(ScanArg
         step(f1, f0, lds, 0, false, -1, 0);
     }
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const uint32_t rit = static_cast<uint32_t>(wr * 64 + rb * 32);
+    for (int rb = 0; rb < RB; ++rb) {
+        const uint32_t rit = static_cast<uint32_t>(wr * (32 * RB) + rb * 32);
         bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull_pre[rb], row0, rit, q0 + wc * 128, sel, h, l31,
                                                   MODE == MODE_FILTER ? tau_pre : nullptr);
+    }
+}
+
+// =================================================================================================
+// Persistent form of the shadow kernel (FILTER mode, 8 waves).
+//
+// One workgroup per CU walks a list of (row tile, query tile) visits; the k-slab pipeline runs
+// straight through the visit boundaries: while the last four slabs of a visit are multiplied, the
+// first slabs of the next visit are already being staged, and its first fragments are read before
+// the epilogue of the current one.  What this removes (measured on the bench shard: a dim sweep at
+// constant work): one workgroup dispatch + one cold DMA prologue per tile, 3-5 us of
+// the ~23 us a tile takes.  Visit order = the block order of the non-persistent kernel (block b on
+// XCD b % 8, consecutive blocks of an XCD walk the query tiles of one row tile), so the L2 sharing
+// of a row tile between its query tiles is kept.
+// Precondition: dim % 32 == 0 and dim >= 256 (at least 8 slabs per visit).
+// =================================================================================================
+// Cosine only: with the unit-normalised shadow the epilogue needs the row norms just to flag rows
+// whose norm is out of range — and those have an all-zero shadow row, i.e. scores of exactly 0.0
+// against every query.  So nothing is preloaded per visit: a lane that sees 0.0 in all four of its
+// query blocks for some row raises a (wave-uniform, practically never taken) slow path that loads
+// the norms.  Thresholds are loaded once while the query tile stays the same.
+__global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArgs a) {
+    constexpr int METRIC = YAMS_SCAN_COSINE;
+    constexpr int RB = 2, PA = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SH_NST * SH_STAGE];
+
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t per_xcd = gridDim.x >> 3;              // gridDim.x is a multiple of 8
+    const uint32_t total_w = ((a.n_sel_tiles + 7u) / 8u) * a.n_qtiles;
+    uint32_t w = blockIdx.x >> 3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / SH_K;
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+
+    // The current and the next visit, as plain scalars (uniform: bases, row0, q0; per lane: the two
+    // row-piece offsets) — a struct handed around by pointer ends up in scratch memory.
+    const unsigned char *cA = nullptr, *cB = nullptr, *nA = nullptr, *nB = nullptr;
+    uint64_t crow0 = 0, nrow0 = 0;
+    uint32_t cq0 = 0, nq0 = 0;
+    uint32_t cvo0 = 0, cvo1 = 0, nvo0 = 0, nvo1 = 0;
+    const int rowA0 = (wid * PA + 0) * 16 + (lane >> 2), rowA1 = (wid * PA + 1) * 16 + (lane >> 2);
+    const uint32_t chk0 = ((lane & 3) ^ ((rowA0 >> 2) & 3)) * 16u, chk1 = ((lane & 3) ^ ((rowA1 >> 2) & 3)) * 16u;
+    // visit ww of this XCD -> tile coordinates and DMA bases of the NEXT slot
+    auto open_next = [&](uint32_t ww) __attribute__((always_inline)) -> bool {
+        if (ww >= total_w) return false;
+        const uint32_t qt = ww % a.n_qtiles;
+        const uint32_t sel = (ww / a.n_qtiles) * 8u + xcd;
+        if (sel >= a.n_sel_tiles) return false;           // only in the last group; nothing valid follows
+        const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+        nrow0 = static_cast<uint64_t>(tile) * BT_ROWS;
+        nq0 = qt * BT_QUERIES;
+        nA = reinterpret_cast<const unsigned char*>(a.rows_bf16 + nrow0 * dim);
+        nB = reinterpret_cast<const unsigned char*>(a.q_hi + static_cast<uint64_t>(nq0) * 32);
+        uint64_t r0 = nrow0 + rowA0, r1 = nrow0 + rowA1;
+        if (r0 >= a.n_rows) r0 = a.n_rows - 1;
+        if (r1 >= a.n_rows) r1 = a.n_rows - 1;
+        nvo0 = static_cast<uint32_t>(r0 - nrow0) * dim * 2u + chk0;
+        nvo1 = static_cast<uint32_t>(r1 - nrow0) * dim * 2u + chk1;
+        return true;
+    };
+    auto advance = [&]() __attribute__((always_inline)) { cA = nA; cB = nB; crow0 = nrow0; cq0 = nq0; cvo0 = nvo0; cvo1 = nvo1; };
+    const uint32_t voffB0 = static_cast<uint32_t>(rowA0) * 64u + chk0, voffB1 = static_cast<uint32_t>(rowA1) * 64u + chk1;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * PA * 1024);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + wid * PA * 1024);
+    // DMA piece p (0,1: rows; 2,3: queries) of slab `slab` of the current visit, or — when the slab
+    // index runs past the visit (slab >= nslab) — of the next one; ring stage `stg`.  The choice is a
+    // scalar select, so the slab loop below stays one basic block from the first slab of a visit to
+    // its last.
+    auto piece = [&](int slab, int stg, int p) __attribute__((always_inline)) {
+        const bool cross = slab >= nslab;
+        const int sl = cross ? slab - nslab : slab;
+        const uint32_t st = static_cast<uint32_t>(stg) * SH_STAGE;
+        const unsigned char* bA = cross ? nA : cA;
+        const unsigned char* bB = cross ? nB : cB;
+        if (p == 0) lds_dma16_s(bA + sl * (SH_K * 2), cross ? nvo0 : cvo0, ldsA + st);
+        else if (p == 1) lds_dma16_s(bA + sl * (SH_K * 2), cross ? nvo1 : cvo1, ldsA + st + 1024);
+        else if (p == 2) lds_dma16_s(bB + sl * qslab_bytes, voffB0, ldsB + st);
+        else lds_dma16_s(bB + sl * qslab_bytes, voffB1, ldsB + st + 1024);
+    };
+
+    f32x16 acc[RB][4];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][u][r] = 0.f;
+    };
+    zero_acc();
+
+    int offA[RB][2], offB[4][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rf = wr * 64 + rb * 32 + l31;
+        const int f = (rf >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offA[rb][t] = rf * 64 + (((2 * t + h) ^ f) << 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rq = wc * 128 + u * 32 + l31;
+        const int f = (rq >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offB[u][t] = SH_A_BYTES + rq * 64 + (((2 * t + h) ^ f) << 4);
+    }
+    struct Frags { bf16x8 a[RB]; bf16x8 b[4]; };
+    auto pin = [&](Frags& fr) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(fr.a[0]), "+v"(fr.a[1]), "+v"(fr.b[0]), "+v"(fr.b[1]), "+v"(fr.b[2]), "+v"(fr.b[3]));
+    };
+    // one 16-wide step (see scan_tiles_bf16s_kernel): 8 MFMAs on `cur`, the 6 fragment reads of the
+    // next step and 2 DMA pieces (p0, p0+1 of slab dslab into stage dstg) in the gaps
+    auto step = [&](const Frags& cur, Frags& nxt, const unsigned char* nbase, int nt, int dslab, int dstg,
+                    int p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rb = i >> 2, u = i & 3;
+            acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb], cur.b[u], acc[rb][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < RB) nxt.a[i < RB ? i : 0] = *reinterpret_cast<const bf16x8*>(nbase + offA[i < RB ? i : 0][nt]);
+            if (i >= RB && i < RB + 4) nxt.b[i - RB] = *reinterpret_cast<const bf16x8*>(nbase + offB[i - RB][nt]);
+            if (i == 3 || i == 6) piece(dslab, dstg, p0 + (i == 6 ? 1 : 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (!open_next(w)) return;
+    advance();
+    // without a next visit the "next" slot points at the current one: the tail of the slab loop then
+    // re-stages this visit's first slabs (never read) instead of branching around the DMA
+    auto alias_next = [&]() __attribute__((always_inline)) { nA = cA; nB = cB; nvo0 = cvo0; nvo1 = cvo1; };
+    bool has_next = open_next(w + per_xcd);
+    if (!has_next) alias_next();
+    float tau[4];
+    uint32_t tau_q0 = cq0;
+    auto load_tau = [&](uint32_t q0v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t qi = q0v + wc * 128 + u * 32 + l31;
+            tau[u] = qi < a.n_queries ? a.tau[qi] : __builtin_inff();
+        }
+    };
+    load_tau(tau_q0); // older than every DMA piece below: retires first, the counted waits stay valid
+
+    // ---- prologue (first visit only): slabs 0..2 and the first half of slab 3 -------------------
+    for (int sl = 0; sl < 3; ++sl)
+        for (int p = 0; p < 4; ++p) piece(sl, sl, p);
+    piece(3, 3, 0); piece(3, 3, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) f0.a[rb] = *reinterpret_cast<const bf16x8*>(lds + offA[rb][0]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f0.b[u] = *reinterpret_cast<const bf16x8*>(lds + offB[u][0]);
+    int stage = 0; // ring stage of the slab being multiplied
+
+    for (;;) {
+        // one slab per iteration: [second step requested | first step multiplied | barrier for the
+        // next slab | next slab's first step requested | second step multiplied]; DMA: second half
+        // of slab s+3, first half of slab s+4 (ring stages stage+3 and stage+4 = stage).  Slabs past
+        // the end of the visit are the first slabs of the next one, so the pipeline — DMA, the
+        // barrier, the fragment prefetch — runs straight through the visit boundary.
+        for (int s = 0; s < nslab; ++s) {
+            const unsigned char* base = lds + stage * SH_STAGE;
+            const int stg3 = (stage + 3) & (SH_NST - 1), stg4 = stage;
+            stage = (stage + 1) & (SH_NST - 1);
+            pin(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(f0, f1, base, 1, s + 3, stg3, 2);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            pin(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(f1, f0, lds + stage * SH_STAGE, 0, s + 4, stg4, 0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const uint32_t rit = static_cast<uint32_t>(wr * 64 + rb * 32);
+            bool suspicious = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                suspicious |= (acc[rb][0][r] == 0.f) & (acc[rb][1][r] == 0.f) & (acc[rb][2][r] == 0.f) & (acc[rb][3][r] == 0.f);
+            float nfull = 1.f;
+            if (__builtin_amdgcn_ballot_w64(suspicious) != 0 || crow0 + BT_ROWS > a.n_rows) {
+                const uint64_t r = crow0 + rit + l31;
+                nfull = r < a.n_rows ? a.rows_nsq[r] : 1.f;
+            }
+            bf16_epilogue<MODE_FILTER, METRIC, 0, 4, true>(a, acc[rb], nfull, crow0, rit, cq0 + wc * 128, 0u, h,
+                                                           l31, tau);
+        }
+        // stores / atomics of the epilogue may retire out of order with loads: drain, so that the
+        // counted waits of the next visit only ever see DMA pieces (by now the pieces issued during
+        // the last four slabs have landed or are about to); also the exit condition of the kernel
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!has_next) break;
+        zero_acc();
+        advance();
+        if (cq0 != tau_q0) { // query tile changed (n_qtiles does not divide the per-XCD stride)
+            tau_q0 = cq0;
+            load_tau(tau_q0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        w += per_xcd;
+        has_next = open_next(w + per_xcd);
+        if (!has_next) alias_next();
     }
 }
 
@@ -900,19 +1143,38 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
         else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
     } else if (passes == 3) LAUNCH_BF16(3);
     else if (a.rows_bf16 && bf16_slab_k(passes, L.plan.dim) == 32) {
-        const bool abl = mode == MODE_FILTER && metric == YAMS_SCAN_COSINE;
-        if (abl && version == 11) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (abl && version == 12) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (abl && version == 13) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (abl && version == 14) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 4>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (abl && version == 15) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 5>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (mode == MODE_SAMPLE) {
-            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-            else hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        } else {
-            if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-            else hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
+        if (mode == MODE_FILTER && version == 2 && L.plan.dim >= 256 && metric == YAMS_SCAN_COSINE) {
+            // persistent form: one workgroup per CU (multiple of 8 so that XCD = block % 8 holds)
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            uint32_t pg = static_cast<uint32_t>(cus) & ~7u;
+            if (pg < 8) pg = 8;
+            const uint32_t total_w = groups * a.n_qtiles * 8u;
+            if (pg > total_w) pg = (total_w + 7u) & ~7u;
+            hipLaunchKernelGGL(scan_tiles_bf16p_kernel, dim3(pg), dim3(BT_THREADS), 0, st, a);
+            LAUNCH_CHECK();
+            return hipSuccess;
         }
+        const bool abl = mode == MODE_FILTER && metric == YAMS_SCAN_COSINE;
+        const bool four = version >= 20;       // 4-wave (4x4 tiles) form; 2x = its ablations
+        const int v = four ? version - 10 : version;
+#define LAUNCH_SH(MODE_, METRIC_, ABL_) do { \
+            if (four) hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_, METRIC_, ABL_, 4>), dim3(grid), dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_, METRIC_, ABL_, 8>), dim3(grid), dim3(512), 0, st, a); } while (0)
+        if (abl && v == 11) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 1);
+        else if (abl && v == 12) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 2);
+        else if (abl && v == 13) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 3);
+        else if (abl && v == 14) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 4);
+        else if (abl && v == 15) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 5);
+        else if (mode == MODE_SAMPLE) {
+            if (metric == YAMS_SCAN_COSINE) LAUNCH_SH(MODE_SAMPLE, YAMS_SCAN_COSINE, 0);
+            else LAUNCH_SH(MODE_SAMPLE, YAMS_SCAN_L2, 0);
+        } else {
+            if (metric == YAMS_SCAN_COSINE) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 0);
+            else LAUNCH_SH(MODE_FILTER, YAMS_SCAN_L2, 0);
+        }
+#undef LAUNCH_SH
     } else if (bf16_slab_k(passes, L.plan.dim) == 32) {
         if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
             hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
