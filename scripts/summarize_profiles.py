@@ -49,13 +49,13 @@ meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py
 json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(P, f"{tag}_pmc.json"))
 
-filt = ([k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
+filt = ([k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
         or [k for k in summary if "bf16v2_kernel<1, 0" in k] or [k for k in summary if "scan_tiles_kernel<1, 0>" in k])
 if filt and "FETCH_SIZE" in summary[filt[0]]:
     fs = summary[filt[0]]["FETCH_SIZE"]["mean"]
     out = {"kernel": filt[0], "rows_per_gpu": 12_500_000, "dim": 768, "queries": 1024, "bf16": "bf16" in filt[0],
            "passes": 3 if "bf16v2_kernel<1, 0, 3" in filt[0] else (1 if "bf16" in filt[0] else 0),
-           "shadow": "bf16s_kernel" in filt[0],
+           "shadow": "bf16s_kernel" in filt[0] or "bf16p_kernel" in filt[0],
            "fetch_size_kib": fs, "hbm_bytes_per_launch": 2.0 * fs * 1024.0,
            "correction": "2x (gfx950 FETCH_SIZE halves wide coalesced reads)", "round": tag}
     k2 = summary[filt[0]]
