@@ -535,3 +535,78 @@ def test_vector_scan_vtable(accel_lib, oracle):
     vt.free_string(None, info)
     assert vt.corpus_destroy(None, cid) == 0
     L.yams_plugin_shutdown()
+
+
+# ---- randomized differential sweep ------------------------------------------------------------------
+def test_randomized_differential_sweep(acc, oracle):
+    """48 seeded random configurations (shape, k, metric, threshold, tie ranks, allow-mask, filter
+    tier, shadow on/off, record path) — every one must match the oracle bit for bit."""
+    rng = np.random.default_rng(20260925)
+    dims = [4, 8, 20, 32, 48, 64, 96, 100, 128, 256, 384]
+    for case in range(48):
+        d = int(rng.choice(dims))
+        n = int(rng.choice([1, 3, 70, 900, 4096, 5000, 20000, 66000]))
+        nq = int(rng.integers(1, 24))
+        k = int(rng.choice([1, 2, 10, 37, 100, 300]))
+        metric = SCAN_L2 if rng.random() < 0.3 else SCAN_COSINE
+        thr = float(rng.choice([-1.0, 0.0, 0.05, 0.3]))
+        corpus = oracle.synth_rows(1000 + case, 0, n, d)
+        q = oracle.synth_rows(1000 + case, 1 << 40, nq, d)
+        if rng.random() < 0.5:                                   # scaled rows, duplicates, degenerate rows
+            corpus *= rng.uniform(1e-3, 1e3, (n, 1)).astype(np.float32)
+            if n > 10:
+                corpus[rng.integers(0, n, 5)] = corpus[rng.integers(0, n)]
+                corpus[rng.integers(0, n)] = 0
+                corpus[rng.integers(0, n)] *= np.float32(1e-6)
+        rank = rng.permutation(n).astype(np.uint32) if rng.random() < 0.5 else None
+        allowed = None
+        if rng.random() < 0.4 and n > 3:
+            allowed = np.sort(rng.choice(n, int(rng.integers(1, n)), replace=False))
+        flags = int(rng.choice([0, 0, FLAG_SPLIT_FILTER, FLAG_F32_FILTER]))
+        record = metric == SCAN_COSINE and rng.random() < 0.3
+        if record:
+            flags |= FLAG_RECORD_PATH
+        shadow = bool(rng.random() < 0.7)
+        # ---- device
+        dc = acc.to_device(corpus)
+        db = dn = dm = dr = di = None
+        if shadow and d % 4 == 0:
+            db, dn = acc.alloc(corpus.size * 2), acc.alloc(n * 4)
+            acc.build_shadow_device(dc.ptr, n, d, db.ptr, dn.ptr)
+        if rank is not None:
+            inv = np.empty_like(rank); inv[rank] = np.arange(n, dtype=rank.dtype)
+            dr, di = acc.to_device(rank), acc.to_device(inv)
+        n_allowed = 0
+        if allowed is not None:
+            bits = np.zeros((n + 31) // 32 * 32, np.uint8); bits[allowed] = 1
+            words = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+            dm = acc.to_device(words); n_allowed = len(allowed)
+        view = acc.corpus_view(dc.ptr, n, d, dr.ptr if dr else None, di.ptr if di else None, 0,
+                               dm.ptr if dm else None, n_allowed,
+                               rows_bf16_ptr=db.ptr if db else None, rows_nsq_ptr=dn.ptr if dn else None)
+        r = acc.scan_topk(view, q, k, thr, metric, flags)
+        # ---- oracle
+        tr64 = None if rank is None else rank.astype(np.uint64)
+        tag = (case, n, d, nq, k, metric, thr, flags, shadow, allowed is not None, r.diag)
+        for qi in range(nq):
+            if record:
+                allow8 = None
+                if allowed is not None:
+                    allow8 = np.zeros(n, np.uint8); allow8[allowed] = 1
+                rows, sims, _ = oracle.scan_cosine_records(corpus, q[qi], k, thr, tr64, allow8)
+                dist = None
+            else:
+                sub = corpus if allowed is None else corpus[allowed]
+                sr = tr64 if (allowed is None or tr64 is None) else tr64[allowed]
+                if metric == SCAN_COSINE:
+                    rows, sims, _, _ = oracle.scan_cosine(sub, q[qi], k, thr, sr); dist = None
+                else:
+                    rows, dist, sims = oracle.scan_l2(sub, q[qi], k, thr, sr)
+                if allowed is not None:
+                    rows = np.asarray(allowed)[rows]
+            cnt = int(r.counts[qi])
+            assert cnt == len(rows), (qi, cnt, len(rows), tag)
+            assert np.array_equal(r.rows[qi, :cnt], rows), (qi, tag)
+            assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), (qi, tag)
+            if dist is not None:
+                assert np.array_equal(r.dist[qi, :cnt].view(np.uint32), dist.view(np.uint32)), (qi, tag)
