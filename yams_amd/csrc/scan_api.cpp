@@ -50,7 +50,8 @@ ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool 
     // +-50 % with overwhelming probability)
     const uint32_t need_rank = (p.kprime + p.kprime / 4 + 32 + p.sample_stride - 1) / p.sample_stride;
     p.tau_rank = std::min<uint32_t>(std::max<uint32_t>(32, round_up(need_rank, 32)), kRescoreMax);
-    uint64_t cap = std::max<uint64_t>(4096, 8ull * p.tau_rank * p.sample_stride);
+    // expected list length tau_rank * stride (relative spread ~1/sqrt(tau_rank)): 4x is > 15 sigma
+    uint64_t cap = std::max<uint64_t>(4096, 4ull * p.tau_rank * p.sample_stride);
     if (p.n_groups < p.tau_rank) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
     cap = std::min<uint64_t>(cap, std::max<uint64_t>(n_rows, 4096));
     p.list_cap = round_up(static_cast<uint32_t>(cap), 256);

@@ -488,36 +488,105 @@ struct RescoreArgs {
 };
 
 constexpr int RS_MAX = 2048; // max candidates per query per launch
+constexpr int RS_STAGE_STRIDE = 36; // floats per staged row chunk (32 + 4 pad: b128 reads of 16 lanes hit 16 bank groups)
 
 template <int METRIC>
 __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);              // [RS_MAX]
-    uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + RS_MAX);     // [RS_MAX] candidate slot
-    float* saux = reinterpret_cast<float*>(sidx + RS_MAX);           // [RS_MAX] cosine (L2 mode)
-    float* sq = saux + RS_MAX;                                       // [dim]
+    // rs = slots the block sorts = next power of two >= n_cand (384 candidates sort as 512)
+    int rs = 64;
+    while (rs < static_cast<int>(a.n_cand)) rs <<= 1;
+    if (rs > RS_MAX) rs = RS_MAX;
+    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);              // [rs]
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + rs);         // [rs] candidate slot
+    float* saux = reinterpret_cast<float*>(sidx + rs);               // [rs] cosine (L2 mode)
+    float* sq = saux + rs;                                           // [dim]
+    float* sstage = sq + ((a.dim + 3u) & ~3u);                       // [4 waves][64 rows][RS_STAGE_STRIDE] (staged walk)
 
     const uint32_t slot = blockIdx.x;
     const uint32_t q = a.qmap ? a.qmap[slot] : slot;
     const uint32_t dim = a.dim;
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
         sq[i] = a.queries[static_cast<uint64_t>(q) * dim + i];
-    for (int i = threadIdx.x; i < RS_MAX; i += blockDim.x) { skey[i] = 0; sidx[i] = 0; saux[i] = 0.f; }
+    for (int i = threadIdx.x; i < rs; i += blockDim.x) { skey[i] = 0; sidx[i] = 0; saux[i] = 0.f; }
     __syncthreads();
     const double qn = a.qnorm[q];
     const uint64_t* cand = a.cand + static_cast<uint64_t>(slot) * a.cand_stride;
 
     uint32_t local_rescored = 0;
-    for (uint32_t c = threadIdx.x; c < a.n_cand; c += blockDim.x) {
-        const uint64_t ck = cand[c];
-        if (ck == 0) continue;
-        const uint32_t row = a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck);
+    // Staged walk (dim % 32 == 0, 16-byte aligned rows): a lane still walks its own row in the
+    // reference's summation order, but the bytes arrive line by line: the wave fetches one 128-byte
+    // line of each of its 64 candidate rows with 8 coalesced instructions (8 rows x 8 lanes x 16 B
+    // each — every line is requested exactly once), parks them in LDS, and every lane then reads its
+    // own row's 32 floats back.  The lane-per-row loads of the plain walk fetch each line in eight
+    // 16-byte pieces from 64 different lines per instruction: 4-8x the traffic between L1, L2 and HBM.
+    const bool staged = (dim & 31u) == 0 && ((reinterpret_cast<uintptr_t>(a.rows) & 15u) == 0);
+    const uint32_t n_rounds = (a.n_cand + blockDim.x - 1) / blockDim.x;
+    for (uint32_t round = 0; round < n_rounds; ++round) {
+        const uint32_t c = round * blockDim.x + threadIdx.x;
+        const uint64_t ck = c < a.n_cand ? cand[c] : 0;
+        const bool live = ck != 0;
+        const uint32_t row = live ? (a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck)) : 0u;
         const float* x = a.rows + static_cast<uint64_t>(row) * dim;
-        ++local_rescored;
+        if (live) ++local_rescored;
         double nsq = 0.0, dot = 0.0, dsq = 0.0;
         const bool vec4 = (dim & 3u) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
-        if (vec4) {
-            for (uint32_t i = 0; i < dim; i += 4) {
+        if (staged) {
+            const int lane = threadIdx.x & 63;
+            float* stg = sstage + (threadIdx.x >> 6) * (64 * RS_STAGE_STRIDE);
+            if (__builtin_amdgcn_ballot_w64(live) != 0) { // whole wave idle in a partial round: skip
+                for (uint32_t ch = 0; ch < dim; ch += 32) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int src = 8 * j + (lane >> 3);
+                        const uint32_t r = static_cast<uint32_t>(__shfl(static_cast<int>(row), src));
+                        const float4 v = *reinterpret_cast<const float4*>(a.rows + static_cast<uint64_t>(r) * dim + ch + (lane & 7) * 4);
+                        *reinterpret_cast<float4*>(stg + src * RS_STAGE_STRIDE + (lane & 7) * 4) = v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const float4 v = *reinterpret_cast<const float4*>(stg + lane * RS_STAGE_STRIDE + 4 * m);
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double sv = static_cast<double>(vv[e]);
+                            const double qv = static_cast<double>(sq[ch + 4 * m + e]);
+                            nsq = fma(sv, sv, nsq);
+                            dot = fma(sv, qv, dot);
+                            if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier(); // the next chunk overwrites the staging rows
+                }
+            }
+            if (!live) continue;
+        } else if (!live) {
+            continue;
+        } else if (vec4) {
+            // A lane walks its own row (the summation order is the reference's, so a row cannot be
+            // split across lanes): fetch a whole 128-byte line (8 x float4) before consuming it,
+            // otherwise every 16 bytes pay a full memory latency.
+            uint32_t i = 0;
+            for (; i + 32 <= dim; i += 32) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(x + i + 4 * j);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double sv = static_cast<double>(vv[e]);
+                        const double qv = static_cast<double>(sq[i + 4 * j + e]);
+                        nsq = fma(sv, sv, nsq);
+                        dot = fma(sv, qv, dot);
+                        if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+                    }
+                }
+            }
+            for (; i < dim; i += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(x + i);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -566,10 +635,10 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
     if (a.stat_rescored && local_rescored) atomicAdd(a.stat_rescored, (unsigned long long)local_rescored);
     __syncthreads();
 
-    // bitonic sort (key desc) of RS_MAX pairs
-    for (int kk = 2; kk <= RS_MAX; kk <<= 1) {
+    // bitonic sort (key desc) of rs pairs
+    for (int kk = 2; kk <= rs; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < RS_MAX; i += blockDim.x) {
+            for (int i = threadIdx.x; i < rs; i += blockDim.x) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const uint64_t x = skey[i], y = skey[ixj];
@@ -594,7 +663,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
     if (threadIdx.x == 0) {
         uint32_t nv = 0;
         // count valid (non-zero) keys by binary search on the sorted array
-        uint32_t lo = 0, hi = RS_MAX;
+        uint32_t lo = 0, hi = static_cast<uint32_t>(rs);
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skey[mid] != 0) lo = mid + 1; else hi = mid; }
         nv = lo;
         s_nvalid = nv;
@@ -1108,8 +1177,12 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     a.err_bound = R.err_bound; a.out_scores = R.out_scores; a.out_rows = R.out_rows;
     a.out_counts = R.out_counts; a.out_dist = R.out_dist; a.out_ranks = R.out_ranks;
     a.out_status = R.out_status; a.stat_rescored = R.stat_rescored;
-    const size_t sh = RS_MAX * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
-                      static_cast<size_t>(R.dim) * sizeof(float);
+    size_t rs = 64;
+    while (rs < R.n_cand) rs <<= 1;
+    if (rs > static_cast<size_t>(RS_MAX)) rs = RS_MAX;
+    const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
+                      ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
+                      4 * 64 * RS_STAGE_STRIDE * sizeof(float);
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(256),
                            sh, st, a);
