@@ -44,6 +44,15 @@ __host__ __device__ inline float key_score(uint64_t k) {
     return ord2f(static_cast<uint32_t>(k >> 32));
 }
 
+// ---- dense sample scores ---------------------------------------------------------------------------
+// Layout [sample_row / 4][query][4]: in the MFMA accumulator layout a lane owns ONE query and four
+// consecutive rows per register quad, so the 32 lanes of a half wave store 32 consecutive queries x
+// 16 bytes = 512 contiguous bytes (query-major rows would scatter every lane 4 * sample_rows bytes
+// apart).  sample_row is a multiple of 4 at every store / load site.
+__host__ __device__ inline uint64_t dense_index(uint32_t q, uint64_t sample_row, uint32_t n_queries) {
+    return ((sample_row >> 2) * n_queries + q) * 4ull + (sample_row & 3ull);
+}
+
 // ---- scan geometry (shared by kernels and host planner) ----------------------------------------
 constexpr int kTileRows = 128;    // corpus rows per workgroup tile
 constexpr int kTileQueries = 128; // queries per workgroup tile

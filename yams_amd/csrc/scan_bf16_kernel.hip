@@ -120,7 +120,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
                 bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
                 if (qok[u]) {
                     const uint64_t srow = static_cast<uint64_t>(sel) * BT_ROWS + row_in_tile + 8 * g4 + 4 * h;
-                    *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
+                    *reinterpret_cast<float4*>(a.dense + dense_index(qidx[u], srow, a.n_queries)) = v;
                 }
             }
             if (qok[u]) {

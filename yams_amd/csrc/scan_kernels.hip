@@ -12,6 +12,8 @@
 // reference's own summation order.  A per-query verification proves that no discarded row could
 // have entered the result; queries that fail it are widened and finally scored exhaustively in
 // fp64 — on the device, never on the CPU.
+#include <algorithm>
+
 #include "common.h"
 #include "scan_args.h"
 
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
                     if (qok[u]) {
                         const uint64_t srow = static_cast<uint64_t>(sel) * kTileRows + wr * 64 +
                                               t * 32 + 8 * g4 + 4 * h;
-                        *reinterpret_cast<float4*>(a.dense + qidx[u] * a.sample_rows + srow) = v;
+                        *reinterpret_cast<float4*>(a.dense + dense_index(qidx[u], srow, a.n_queries)) = v;
                     }
                 }
                 if (qok[u]) {
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const uint32_t* gmax, u
 // Group gid covers rows  32 * (gid >> 1) + 4 * (gid & 1) + {0..3} + 8 * {0..3}  of the sample
 // (the MFMA accumulator layout of both sample kernels).
 __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense, const uint32_t* gmax,
-                                                             uint32_t n_groups,
+                                                             uint32_t n_groups, uint32_t n_queries,
                                                              uint64_t sample_rows, uint32_t tile_rows,
                                                              uint32_t stride,
                                                              uint64_t n_rows, const float* tau,
@@ -424,7 +426,6 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
                                                              uint32_t list_cap) {
     const uint32_t q = blockIdx.y;
     const float t = tau[q];
-    const float* src = dense + static_cast<uint64_t>(q) * sample_rows;
     const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
         const float m = ord2f(gm[g]); // 0xffffffff decodes to NaN
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
         const uint64_t s0 = static_cast<uint64_t>(g >> 1) * 32 + 4 * (g & 1);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(src + s0 + 8 * g4);
+            const float4 v4 = *reinterpret_cast<const float4*>(dense + dense_index(q, s0 + 8 * g4, n_queries));
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -491,7 +492,7 @@ constexpr int RS_MAX = 2048; // max candidates per query per launch
 constexpr int RS_STAGE_STRIDE = 36; // floats per staged row chunk (32 + 4 pad: b128 reads of 16 lanes hit 16 bank groups)
 
 template <int METRIC>
-__global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
+__global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // rs = slots the block sorts = next power of two >= n_cand (384 candidates sort as 512)
     int rs = 64;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
     uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + rs);         // [rs] candidate slot
     float* saux = reinterpret_cast<float*>(sidx + rs);               // [rs] cosine (L2 mode)
     float* sq = saux + rs;                                           // [dim]
-    float* sstage = sq + ((a.dim + 3u) & ~3u);                       // [4 waves][64 rows][RS_STAGE_STRIDE] (staged walk)
+    float* sstage = sq + ((a.dim + 3u) & ~3u);                       // [waves][64 rows][RS_STAGE_STRIDE] (staged walk)
 
     const uint32_t slot = blockIdx.x;
     const uint32_t q = a.qmap ? a.qmap[slot] : slot;
@@ -1115,7 +1116,7 @@ hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L) {
     uint32_t gx = (L.plan.n_groups + 255) / 256;
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.dense,
-                       L.gmax, L.plan.n_groups, L.plan.sample_rows, L.plan.tile_rows,
+                       L.gmax, L.plan.n_groups, L.plan.n_queries, L.plan.sample_rows, L.plan.tile_rows,
                        L.plan.sample_stride, L.plan.n_rows, L.tau, L.list_count, L.list, L.plan.list_cap);
     LAUNCH_CHECK();
     return hipSuccess;
@@ -1180,14 +1181,16 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     size_t rs = 64;
     while (rs < R.n_cand) rs <<= 1;
     if (rs > static_cast<size_t>(RS_MAX)) rs = RS_MAX;
+    // one round of the candidate walk when the candidates fit a block (384 candidates: 6 waves)
+    uint32_t threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
                       ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
-                      4 * 64 * RS_STAGE_STRIDE * sizeof(float);
+                      (threads / 64) * 64 * RS_STAGE_STRIDE * sizeof(float);
     if (metric == YAMS_SCAN_COSINE)
-        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(256),
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(threads),
                            sh, st, a);
     else
-        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2>), dim3(R.n_slots), dim3(256), sh,
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2>), dim3(R.n_slots), dim3(threads), sh,
                            st, a);
     LAUNCH_CHECK();
     return hipSuccess;
