@@ -255,7 +255,7 @@ def main():
     filt_rows = min(n, (n_tiles - n_sample) * tr)
     flops = 2.0 * nq * d * filt_rows            # ALGORITHMIC flops of the contraction per launch
     ach_tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms else None
-    passes = 3 if (a.split_filter or k > 256) else 1
+    passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
     if bf16 and passes == 3:
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"
         peak = PEAK_BF16_MFMA_TFLOPS / BF16_PASSES  # each algorithmic multiply-add costs 3 bf16 MFMA passes

@@ -150,7 +150,9 @@ def test_empty_and_degenerate(acc):
     (150000, 384, 130, 100, SCAN_COSINE, -1.0),   # sample + filter passes, 2 query tiles
     (150000, 384, 40, 100, SCAN_COSINE, 0.16),    # threshold cuts the result short
     (150000, 256, 16, 100, SCAN_L2, 0.05),        # vec0: top-k by distance, then cosine threshold
-    (60000, 128, 8, 1000, SCAN_COSINE, -1.0),     # large k
+    (60000, 128, 8, 1000, SCAN_COSINE, -1.0),     # large k: split filter
+    (60000, 128, 8, 500, SCAN_COSINE, -1.0),      # k = 500: still the single-pass filter (1564 candidates)
+    (50000, 96, 5, 300, SCAN_L2, -1.0),           # L2 k = 300: single pass (1928 candidates)
     (33000, 1024, 3, 1, SCAN_COSINE, -1.0),
 ])
 def test_parity_sweep(acc, oracle, n, d, nq, k, metric, thr):

@@ -219,7 +219,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // bf16 matrix-core filter unless the caller asks for exact f32.  One RNE-bf16 pass is the
         // default: a third of the matrix work of the split filter for a looser bound (2^-7 |x||q|),
         // paid for by re-scoring ~3k instead of ~1.25k candidates per query.  Large k (where the
-        // extra candidates would not fit the re-score stage) and escalation runs use the split filter.
+        // extra candidates would not fit the re-score stage: k > 661, L2 k > 319) and escalation runs
+        // use the split filter.
         const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 15u) == 0;
         // measurement knobs (never set by the product path)
         const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL");
@@ -227,7 +228,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES");
         int passes = 0;
         if (bf16) {
-            passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || k > 256) ? 3 : 1;
+            // the single-pass tier needs 3k + 64 (L2: 6k + 128) candidates re-scored in stage 1
+            const uint32_t need1 = (metric == YAMS_SCAN_L2) ? 6 * k + 128 : 3 * k + 64;
+            passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || need1 > kRescoreMax) ? 3 : 1;
             if (pv && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
         }
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
