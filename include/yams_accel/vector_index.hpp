@@ -312,4 +312,80 @@ inline Result<std::unique_ptr<AccelVectorIndex>> createAccelVectorIndex(std::sha
     return std::make_unique<AccelVectorIndex>(std::move(plugin), vt.value(), dim, engine);
 }
 
+// The `vectors` table holds rows of ANY dimension; a search only sees the rows whose embedding_dim
+// equals the query's (`WHERE embedding_dim = ?`, sqlite_vec_backend.cpp:4147).  One dense mirror per
+// dimension, created on first use; a query of a dimension that has no rows returns no results.
+class AccelVectorTable {
+public:
+    explicit AccelVectorTable(std::shared_ptr<accel::Plugin> plugin,
+                              VectorSearchEngine engine = VectorSearchEngine::ExactScan)
+        : plugin_(std::move(plugin)), engine_(engine) {}
+
+    Result<void> insertVectorsBatch(const std::vector<VectorRecord>& records) {
+        std::map<size_t, std::vector<VectorRecord>> byDim;
+        for (const auto& r : records) {
+            if (r.embedding.empty()) return Error{ErrorCode::InvalidArgument, "empty embedding"};
+            byDim[r.embedding.size()].push_back(r);
+        }
+        for (auto& [dim, recs] : byDim) {
+            // a chunk_id lives in one dimension only: re-inserting it with another size moves it
+            for (const auto& r : recs) {
+                auto it = dimOf_.find(r.chunk_id);
+                if (it != dimOf_.end() && it->second != dim) (void)byDim_[it->second]->deleteVector(r.chunk_id);
+                dimOf_[r.chunk_id] = dim;
+            }
+            auto idx = indexFor(dim);
+            if (!idx) return idx.error();
+            if (auto s = idx.value()->insertVectorsBatch(recs); !s) return s;
+        }
+        return {};
+    }
+    Result<void> insertVector(const VectorRecord& record) { return insertVectorsBatch({record}); }
+    Result<void> deleteVector(const std::string& chunkId) {
+        auto it = dimOf_.find(chunkId);
+        if (it == dimOf_.end()) return Error{ErrorCode::NotFound, "chunk not found"};
+        auto s = byDim_[it->second]->deleteVector(chunkId);
+        dimOf_.erase(it);
+        return s;
+    }
+    Result<size_t> getVectorCount() const {
+        size_t n = 0;
+        for (const auto& [dim, idx] : byDim_) n += idx->getVectorCount().value();
+        return n;
+    }
+    Result<std::vector<VectorRecord>>
+    searchSimilar(const std::vector<float>& query, size_t k, float similarityThreshold = 0.0f,
+                  const std::optional<std::string>& document_hash = std::nullopt,
+                  const std::unordered_set<std::string>& candidate_hashes = {},
+                  const std::map<std::string, std::string>& metadata_filters = {},
+                  VectorSearchDiagnostics* diagnostics = nullptr) {
+        auto it = byDim_.find(query.size());
+        if (it == byDim_.end()) { // no row of this dimension: the statement steps over nothing
+            if (query.empty() || k == 0) return std::vector<VectorRecord>{};
+            for (float v : query)
+                if (!std::isfinite(v)) return Error{ErrorCode::InvalidArgument, "Exact vector search requires a finite, non-zero query embedding"};
+            if (diagnostics) { diagnostics->usedExactScan = true; diagnostics->rowsVisitedObserved = true; }
+            return std::vector<VectorRecord>{};
+        }
+        return it->second->searchSimilar(query, k, similarityThreshold, document_hash, candidate_hashes,
+                                         metadata_filters, diagnostics);
+    }
+
+private:
+    Result<AccelVectorIndex*> indexFor(size_t dim) {
+        auto it = byDim_.find(dim);
+        if (it != byDim_.end()) return it->second.get();
+        auto made = createAccelVectorIndex(plugin_, dim, engine_);
+        if (!made) return made.error();
+        if (auto s = made.value()->initialize(); !s) return s.error();
+        auto* raw = made.value().get();
+        byDim_[dim] = std::move(made.value());
+        return raw;
+    }
+    std::shared_ptr<accel::Plugin> plugin_;
+    VectorSearchEngine engine_;
+    std::map<size_t, std::unique_ptr<AccelVectorIndex>> byDim_;
+    std::unordered_map<std::string, size_t> dimOf_;
+};
+
 } // namespace yams::vector

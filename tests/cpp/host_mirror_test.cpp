@@ -225,6 +225,23 @@ int main(int argc, char** argv) {
         CHECK(r4.has_value() && r4.value().front().chunk_id == "c1002");
         CHECK(db.mirrorRows() == db.getVectorCount().value() && db.uploadedRows() == db.mirrorRows());
     }
+    {   // mixed dimensions in one table: a search only sees rows of the query's dimension (:4147)
+        vector::AccelVectorTable table(plugin);
+        auto rec = [](const char* id, std::vector<float> e) { vector::VectorRecord r; r.chunk_id = id; r.document_hash = "d"; r.embedding = std::move(e); return r; };
+        CHECK(table.insertVectorsBatch({rec("a4", {1, 0, 0, 0}), rec("b8", {1, 0, 0, 0, 0, 0, 0, 0}), rec("c4", {0.6f, 0.8f, 0, 0})}).has_value());
+        CHECK(table.getVectorCount().value() == 3);
+        auto r4 = table.searchSimilar({1, 0, 0, 0}, 5, -1.0f);
+        CHECK(r4.has_value() && r4.value().size() == 2 && r4.value()[0].chunk_id == "a4" && r4.value()[1].chunk_id == "c4");
+        auto r8 = table.searchSimilar({1, 0, 0, 0, 0, 0, 0, 0}, 5, -1.0f);
+        CHECK(r8.has_value() && r8.value().size() == 1 && r8.value()[0].chunk_id == "b8");
+        auto r3 = table.searchSimilar({1, 0, 0}, 5, -1.0f);
+        CHECK(r3.has_value() && r3.value().empty());
+        CHECK(table.insertVector(rec("a4", {0, 1, 0, 0, 0, 0, 0, 0})).has_value());   // a4 moves to dimension 8
+        CHECK(table.getVectorCount().value() == 3);
+        auto again = table.searchSimilar({1, 0, 0, 0}, 5, -1.0f);
+        CHECK(again.has_value() && again.value().size() == 1 && again.value()[0].chunk_id == "c4");
+        CHECK(table.deleteVector("b8").has_value() && !table.deleteVector("b8").has_value());
+    }
     {   // large finite scores (+-FLT_MAX/4) stay finite
         const float L = std::numeric_limits<float>::max() / 4.0f;
         auto idxR = vector::createAccelVectorIndex(plugin, 4);
