@@ -57,4 +57,9 @@ def gather_and_merge(local, k: int, merge_fn):
             else:
                 dist.all_gather_into_tensor(out, t)
             gathered[name] = out
+    if world > 1 and torch.cuda.is_available() and dist.get_backend() != "gloo":
+        # the merge kernel runs on the accelerator context's stream, which need not be torch's
+        # current stream (a context created on the default stream owns a private one): make the
+        # gathered tensors visible to it
+        torch.cuda.current_stream().synchronize()
     return merge_fn(gathered, world)
