@@ -237,6 +237,13 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+    merge_ok = None
+    if world > 1:
+        # the merged list must start with the best hit any shard found, be sorted, and stay in range
+        mx = s_loc[:, 0].clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        merge_ok = bool(torch.equal(mx, s_out[:, 0]) and bool((s_out[:, 1:] <= s_out[:, :-1]).all())
+                        and bool(((r_out >= 0) & (r_out < total_rows)).all()) and bool((c_out == k).all()))
     filt_ms, filt_n = acc.kernel_ms("scan_filter")
     samp_ms, samp_n = acc.kernel_ms("scan_sample")
     acc.enable_timing(False)
@@ -307,6 +314,8 @@ def main():
            "row_queries_per_s": total_rows * nq * a.steps / dt,
            "exact_fallback_queries": fallbacks,
            "roofline": roofline}
+    if merge_ok is not None:
+        out["merged_topk_consistent"] = merge_ok
     if not a.no_cpu_baseline:
         cb, recall, exact = cpu_baseline_scan(acc, tc, tq, n, d, k)
         out["cpu_baseline"] = cb
