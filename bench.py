@@ -267,7 +267,7 @@ def main():
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"
         peak = PEAK_BF16_MFMA_TFLOPS / BF16_PASSES  # each algorithmic multiply-add costs 3 bf16 MFMA passes
     elif bf16:
-        kname = ((("scan_tiles_bf16p_kernel (persistent)" if d >= 256 else "scan_tiles_bf16s_kernel<FILTER,COSINE>")
+        kname = ((("scan_tiles_bf16p_kernel (persistent)" if 256 <= d <= 512 else "scan_tiles_bf16s_kernel<FILTER,COSINE>")
                   if tb is not None else "scan_tiles_bf16k32_kernel<FILTER,COSINE>")
                  if d % 32 == 0 else "scan_tiles_bf16v2_kernel<FILTER,COSINE,1>") \
             + " (v_mfma_f32_32x32x16_bf16, RNE bf16 operands, one pass" + (", bf16 corpus shadow)" if tb is not None else ")")

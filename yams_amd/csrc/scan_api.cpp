@@ -284,7 +284,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
 
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 20) { // ablated measurement kernels produce no candidates: stop here
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20) { // ablated measurement kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;

@@ -1143,7 +1143,10 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
         else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
     } else if (passes == 3) LAUNCH_BF16(3);
     else if (a.rows_bf16 && bf16_slab_k(passes, L.plan.dim) == 32) {
-        if (mode == MODE_FILTER && version == 2 && L.plan.dim >= 256 && metric == YAMS_SCAN_COSINE) {
+        // persistent form where tiles are short (many visits per CU): measured -3 % at dim 384,
+        // equal at 768, +5 % (worse) at 1536; version 4 forces it, 3 forces the per-tile form
+        const bool persistent = (version == 4) || (version == 2 && L.plan.dim <= 512);
+        if (mode == MODE_FILTER && persistent && L.plan.dim >= 256 && metric == YAMS_SCAN_COSINE) {
             // persistent form: one workgroup per CU (multiple of 8 so that XCD = block % 8 holds)
             int dev = 0, cus = 256;
             (void)hipGetDevice(&dev);
