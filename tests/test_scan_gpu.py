@@ -612,3 +612,22 @@ def test_randomized_differential_sweep(acc, oracle):
             assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), (qi, tag)
             if dist is not None:
                 assert np.array_equal(r.dist[qi, :cnt].view(np.uint32), dist.view(np.uint32)), (qi, tag)
+
+
+def test_clustered_corpus_stays_exact(acc, oracle):
+    """A near-duplicate-heavy corpus (40 tight clusters of ~3000 rows, queries at cluster centres): thousands of
+    rows within the single-pass bound of every top-k boundary.  Whatever mix of widening, escalation
+    and exhaustive scoring the tiers choose, the answer is the oracle's, bit for bit."""
+    rng = np.random.default_rng(404)
+    n, d, nc = 120000, 64, 40
+    centres = rng.standard_normal((nc, d)).astype(np.float32)
+    assign = rng.integers(0, nc, n)
+    corpus = (centres[assign] + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    corpus *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    q = (centres[:6] + 0.01 * rng.standard_normal((6, d))).astype(np.float32)
+    rank = rng.permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 100, metric=SCAN_COSINE, tie_rank=rank, expect_path=0)
+    # ~3000 cluster members within 1e-4 of each other: neither filter tier can prove a top-100
+    assert r.diag["widened_queries"] >= 6 and r.diag["escalated_queries"] == 6 and r.diag["exact_fallback_queries"] == 6, r.diag
+    # L2: the random row scales spread the distances, the filter separates them easily
+    check(acc, oracle, corpus, q, 100, metric=SCAN_L2, tie_rank=rank, expect_path=0)
