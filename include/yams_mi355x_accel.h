@@ -423,6 +423,23 @@ typedef struct yams_content_hash_v1 {
     yams_status_t (*stream_update)(void* self, void* stream, const uint8_t* data, size_t n);
     yams_status_t (*stream_finalize)(void* self, void* stream, char out_hex[65]);
     void (*stream_destroy)(void* self, void* stream);
+    /* Batched integrity check (ChunkValidator::validateChunks, src/integrity/chunk_validator.cpp:
+     * 160-212): out_valid[i] = 1 iff SHA-256(msgs[i]) == expected_hex[i] (64 hex chars, either case;
+     * a malformed expectation is simply a mismatch). */
+    yams_status_t (*verify_many)(void* self, const uint8_t* const* msgs, const size_t* lens,
+                                 const char* expected_hex /* [n_msgs][65] */, size_t n_msgs,
+                                 uint8_t* out_valid);
+    /* Device-resident set of known chunk hashes (the batched `storage_->exists` of
+     * ContentStore::store, src/api/content_store_impl.cpp:246-287).  dedup_insert answers, per hash
+     * and in order, "is this one new?" (neither in the set nor earlier in the same call) and adds
+     * the new ones; dedup_contains only looks. */
+    yams_status_t (*dedup_create)(void* self, uint64_t expected_entries, uint64_t* out_set_id);
+    yams_status_t (*dedup_insert)(void* self, uint64_t set_id, const char* hashes_hex /* [n][65] */,
+                                  size_t n, uint8_t* out_is_new);
+    yams_status_t (*dedup_contains)(void* self, uint64_t set_id, const char* hashes_hex, size_t n,
+                                    uint8_t* out_exists);
+    yams_status_t (*dedup_size)(void* self, uint64_t set_id, uint64_t* out_entries);
+    yams_status_t (*dedup_destroy)(void* self, uint64_t set_id);
 } yams_content_hash_v1;
 
 typedef struct yams_chunk_ref_s { /* ChunkRef, chunker.h:32-41 (hash as hex) */

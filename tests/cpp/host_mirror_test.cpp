@@ -13,6 +13,7 @@
 #include "yams_accel/chunker.hpp"
 #include "yams_accel/hasher.hpp"
 #include "yams_accel/vector_index.hpp"
+#include "yams_accel/integrity.hpp"
 
 static int failures = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
@@ -83,6 +84,28 @@ int main(int argc, char** argv) {
             CHECK(chunks[i].hash == hasher.hash(bytes(data).subspan(chunks[i].offset, chunks[i].size)));
         auto lazy = chunker.chunkDataLazy(bytes(data));
         CHECK(lazy.size() == chunks.size() && lazy.back().hash == chunks.back().hash && lazy.front().data.empty());
+    }
+
+    // ---- integrity check + dedup lookup (the callers either side of the hash path) -----------------
+    {
+        auto* hvt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, 1).value();
+        integrity::AccelChunkValidator validator(plugin, hvt);
+        std::string a(5000, 'a'), b(70000, 'b'), c;
+        const std::string ha = hasher.hash(bytes(a)), hb = hasher.hash(bytes(b)), hc = hasher.hash(bytes(c));
+        auto one = validator.validateChunk(bytes(a), ha);
+        CHECK(one.isValid && one.errorMessage.empty() && one.chunkSize == 5000 && one.chunkHash == ha);
+        auto res = validator.validateChunks({{bytes(a), ha}, {bytes(b), ha}, {bytes(c), hc}, {bytes(b), "short"}});
+        CHECK(res.size() == 4 && res[0].isValid && !res[1].isValid && res[2].isValid && !res[3].isValid);
+        CHECK(res[1].errorMessage == "Hash mismatch: expected " + ha.substr(0, 8) + ", got " + hb.substr(0, 8));
+        integrity::AccelDedupIndex known(plugin, hvt);
+        auto first = known.insertAndClassify({ha, hb, ha, hc, hb});
+        CHECK(first.has_value() && first.value() == std::vector<bool>({true, true, false, true, false}));
+        auto again = known.insertAndClassify({hc, ha});
+        CHECK(again.has_value() && again.value() == std::vector<bool>({false, false}) && known.size().value() == 3);
+        const std::string hd = hasher.hash(bytes(std::string("d")));
+        auto look = known.contains({hd, hb});
+        CHECK(look.has_value() && look.value() == std::vector<bool>({false, true}) && known.size().value() == 3);
+        CHECK(!known.insertAndClassify({"nothex"}).has_value());
     }
 
     // ---- vector ----------------------------------------------------------------------------

@@ -402,9 +402,93 @@ yams_status_t ch_stream_finalize(void*, void* s, char out_hex[65]) {
 }
 void ch_stream_destroy(void*, void* s) { delete static_cast<HashStream*>(s); }
 
+// hex (either case) -> 32 raw bytes; false on anything that is not 64 hex digits
+bool parse_hex32(const char* hex, uint8_t out[32]) {
+    for (int i = 0; i < 32; ++i) {
+        int v = 0;
+        for (int j = 0; j < 2; ++j) {
+            const char c = hex[2 * i + j];
+            int d;
+            if (c >= '0' && c <= '9') d = c - '0';
+            else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+            else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+            else return false;
+            v = v * 16 + d;
+        }
+        out[i] = static_cast<uint8_t>(v);
+    }
+    return hex[64] == 0;
+}
+
+yams_status_t ch_verify_many(void*, const uint8_t* const* msgs, const size_t* lens, const char* expected_hex,
+                             size_t n, uint8_t* out_valid) {
+    if (n == 0) return YAMS_OK;
+    if (!msgs || !lens || !expected_hex || !out_valid) return YAMS_ERR_INVALID_ARG;
+    std::vector<char> hex(n * 65);
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        NEED_CTX();
+        g.hashes += n;
+        yams_status_t s = yams_sha256_many_host(g.ctx, msgs, lens, n, hex.data());
+        if (s != YAMS_OK) return s;
+    }
+    for (size_t i = 0; i < n; ++i) { // the reference compares the lower-case hex strings (:243-249)
+        uint8_t a[32], b[32];
+        out_valid[i] = (parse_hex32(hex.data() + 65 * i, a) && parse_hex32(expected_hex + 65 * i, b) &&
+                        std::memcmp(a, b, 32) == 0) ? 1 : 0;
+    }
+    return YAMS_OK;
+}
+
+std::map<uint64_t, yams_dedup_set*> g_dedup;
+uint64_t g_next_dedup = 1;
+
+yams_status_t ch_dedup_create(void*, uint64_t expected, uint64_t* out_id) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    NEED_CTX();
+    if (!out_id) return YAMS_ERR_INVALID_ARG;
+    yams_dedup_set* s = nullptr;
+    yams_status_t st = yams_dedup_set_create(g.ctx, expected, &s);
+    if (st != YAMS_OK) return st;
+    *out_id = g_next_dedup++;
+    g_dedup[*out_id] = s;
+    return YAMS_OK;
+}
+yams_status_t dedup_call(uint64_t id, const char* hashes_hex, size_t n, uint8_t* out, bool insert) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    NEED_CTX();
+    auto it = g_dedup.find(id);
+    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
+    if (n == 0) return YAMS_OK;
+    if (!hashes_hex || !out) return YAMS_ERR_INVALID_ARG;
+    std::vector<uint8_t> raw(n * 32);
+    for (size_t i = 0; i < n; ++i)
+        if (!parse_hex32(hashes_hex + 65 * i, raw.data() + 32 * i)) return YAMS_ERR_INVALID_ARG;
+    return insert ? yams_dedup_insert_host(it->second, raw.data(), n, out, nullptr)
+                  : yams_dedup_probe_host(it->second, raw.data(), n, out);
+}
+yams_status_t ch_dedup_insert(void*, uint64_t id, const char* hex, size_t n, uint8_t* out) { return dedup_call(id, hex, n, out, true); }
+yams_status_t ch_dedup_contains(void*, uint64_t id, const char* hex, size_t n, uint8_t* out) { return dedup_call(id, hex, n, out, false); }
+yams_status_t ch_dedup_size(void*, uint64_t id, uint64_t* out_entries) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g_dedup.find(id);
+    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
+    return yams_dedup_set_size(it->second, out_entries);
+}
+yams_status_t ch_dedup_destroy(void*, uint64_t id) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g_dedup.find(id);
+    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
+    yams_dedup_set_destroy(it->second);
+    g_dedup.erase(it);
+    return YAMS_OK;
+}
+
 yams_content_hash_v1 g_content_hash = {YAMS_IFACE_CONTENT_HASH_V1_VERSION, nullptr, ch_hash,
                                        ch_hash_many, ch_stream_create, ch_stream_init,
-                                       ch_stream_update, ch_stream_finalize, ch_stream_destroy};
+                                       ch_stream_update, ch_stream_finalize, ch_stream_destroy,
+                                       ch_verify_many, ch_dedup_create, ch_dedup_insert,
+                                       ch_dedup_contains, ch_dedup_size, ch_dedup_destroy};
 
 // ---- chunker_v1 -------------------------------------------------------------------------------
 yams_status_t ck_default_config(void*, uint32_t mode, yams_cdc_config_t* out_cfg) {
@@ -476,6 +560,8 @@ YAMS_PLUGIN_API void yams_plugin_shutdown(void) {
         (void)hipStreamSynchronize(g.ctx->stream);
         for (auto& kv : g.corpora) free_corpus(kv.second);
         g.corpora.clear();
+        for (auto& kv : g_dedup) yams_dedup_set_destroy(kv.second);
+        g_dedup.clear();
         yams_accel_ctx_destroy(g.ctx);
         g.ctx = nullptr;
     }
