@@ -7,6 +7,8 @@
 #include <cstddef>
 #include <filesystem>
 #include <fstream>
+#include <functional>
+#include <future>
 #include <memory>
 #include <span>
 #include <string>
@@ -23,6 +25,10 @@ public:
     virtual void update(std::span<const std::byte> data) = 0;
     virtual std::string finalize() = 0;
     virtual std::string hashFile(const std::filesystem::path& path) = 0;
+    // hasher.h:41-46
+    virtual std::future<Result<std::string>> hashFileAsync(const std::filesystem::path& path) = 0;
+    using ProgressCallback = std::function<void(uint64_t, uint64_t)>;
+    virtual void setProgressCallback(ProgressCallback callback) = 0;
 };
 
 class AccelSHA256Hasher final : public IContentHasher {
@@ -51,13 +57,27 @@ public:
         if (!file) throw std::runtime_error("Failed to open file: " + path.string());
         init();
         std::vector<std::byte> buffer(1 << 20); // larger reads than the reference's 64 KiB: one launch each
+        const uint64_t fileSize = std::filesystem::file_size(path);
+        uint64_t processed = 0;
         while (file) {
             file.read(reinterpret_cast<char*>(buffer.data()), static_cast<std::streamsize>(buffer.size()));
             const auto n = file.gcount();
-            if (n > 0) update(std::span<const std::byte>(buffer.data(), static_cast<size_t>(n)));
+            if (n > 0) {
+                update(std::span<const std::byte>(buffer.data(), static_cast<size_t>(n)));
+                processed += static_cast<uint64_t>(n);
+                if (progress_) progress_(processed, fileSize); // sha256_hasher.cpp:136-138
+            }
         }
         return finalize();
     }
+    // sha256_hasher.cpp:152-161: any failure becomes ErrorCode::FileNotFound
+    std::future<Result<std::string>> hashFileAsync(const std::filesystem::path& path) override {
+        return std::async(std::launch::async, [this, path]() -> Result<std::string> {
+            try { return hashFile(path); }
+            catch (const std::exception&) { return Error{ErrorCode::FileNotFound, "hashFileAsync failed"}; }
+        });
+    }
+    void setProgressCallback(ProgressCallback callback) override { progress_ = std::move(callback); }
     // SHA256Hasher::hash(span) one-shot, sha256_hasher.cpp:167-195
     std::string hash(std::span<const std::byte> data) {
         char hex[65];
@@ -80,6 +100,7 @@ private:
     std::shared_ptr<accel::Plugin> plugin_;
     yams_content_hash_v1* vt_;
     void* stream_ = nullptr;
+    ProgressCallback progress_;
 };
 
 inline Result<std::unique_ptr<AccelSHA256Hasher>> createAccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin) {

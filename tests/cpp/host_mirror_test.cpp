@@ -6,6 +6,7 @@
 // Usage: host_mirror_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu]
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <limits>
 #include <random>
 #include <string>
@@ -84,6 +85,24 @@ int main(int argc, char** argv) {
             CHECK(chunks[i].hash == hasher.hash(bytes(data).subspan(chunks[i].offset, chunks[i].size)));
         auto lazy = chunker.chunkDataLazy(bytes(data));
         CHECK(lazy.size() == chunks.size() && lazy.back().hash == chunks.back().hash && lazy.front().data.empty());
+    }
+
+    {   // hashFile / hashFileAsync / progress callback (sha256_hasher.cpp:111-165)
+        const std::string path = "/tmp/yams_accel_hashfile_test.bin";
+        std::string payload(3 * (1 << 20) + 12345, 'x');
+        for (size_t i = 0; i < payload.size(); i += 997) payload[i] = static_cast<char>(i);
+        { std::ofstream f(path, std::ios::binary); f.write(payload.data(), static_cast<std::streamsize>(payload.size())); }
+        uint64_t lastDone = 0, lastTotal = 0; int calls = 0;
+        hasher.setProgressCallback([&](uint64_t d, uint64_t t) { lastDone = d; lastTotal = t; ++calls; });
+        CHECK(hasher.hashFile(path) == hasher.hash(bytes(payload)));
+        CHECK(calls >= 3 && lastDone == payload.size() && lastTotal == payload.size());
+        auto fut = hasher.hashFileAsync(path);
+        auto r = fut.get();
+        CHECK(r.has_value() && r.value() == hasher.hash(bytes(payload)));
+        auto missing = hasher.hashFileAsync("/tmp/yams_accel_no_such_file").get();
+        CHECK(!missing.has_value() && missing.error().code == ErrorCode::FileNotFound);
+        hasher.setProgressCallback(nullptr);
+        std::remove(path.c_str());
     }
 
     // ---- integrity check + dedup lookup (the callers either side of the hash path) -----------------
