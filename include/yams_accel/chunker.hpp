@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <filesystem>
 #include <fstream>
+#include <functional>
+#include <future>
 #include <memory>
 #include <span>
 #include <string>
@@ -42,6 +44,9 @@ public:
     virtual std::vector<Chunk> chunkFile(const std::filesystem::path& path) = 0;
     virtual std::vector<Chunk> chunkData(std::span<const std::byte> data) = 0;
     virtual std::vector<Chunk> chunkDataLazy(std::span<const std::byte> data) { return chunkData(data); }
+    virtual std::future<Result<std::vector<Chunk>>> chunkFileAsync(const std::filesystem::path& path) = 0;
+    using ProgressCallback = std::function<void(uint64_t, uint64_t)>;
+    virtual void setProgressCallback(ProgressCallback callback) = 0;
 };
 
 enum class AccelChunkerKind { Rabin, Streaming };
@@ -68,6 +73,17 @@ public:
         if (!file && !data.empty()) throw std::runtime_error("Failed to read file");
         return chunkData(data);
     }
+    // rabin_chunker.cpp:182-192 / streaming_chunker.cpp:139-150: any failure -> FileNotFound
+    std::future<Result<std::vector<Chunk>>> chunkFileAsync(const std::filesystem::path& path) override {
+        return std::async(std::launch::async, [this, path]() -> Result<std::vector<Chunk>> {
+            try { return chunkFile(path); }
+            catch (const std::exception&) { return Error{ErrorCode::FileNotFound, "chunkFileAsync failed"}; }
+        });
+    }
+    // Called with (end offset of the chunk, total bytes) once per emitted chunk, in order — the
+    // sequence RabinChunker produces (rabin_chunker.cpp:144-147); the boundaries all come back from
+    // one device call, so the calls happen after it.
+    void setProgressCallback(ProgressCallback callback) override { progress_ = std::move(callback); }
 private:
     std::vector<Chunk> run(std::span<const std::byte> data, bool lazy) {
         yams_cdc_config_t cfg{};
@@ -86,12 +102,15 @@ private:
             if (!lazy) { auto s = data.subspan(chunks[i].offset, chunks[i].size); chunks[i].data.assign(s.begin(), s.end()); }
         }
         vt_->free_chunks(vt_->self, refs, n); // paired free, never host free() (model_provider_v1.h:46-49)
+        if (progress_)
+            for (const auto& c : chunks) progress_(c.offset + c.size, data.size());
         return chunks;
     }
     std::shared_ptr<accel::Plugin> plugin_;
     yams_chunker_v1* vt_;
     AccelChunkerKind kind_;
     ChunkingConfig config_;
+    ProgressCallback progress_;
 };
 
 inline Result<std::unique_ptr<IChunker>> createAccelChunker(std::shared_ptr<accel::Plugin> plugin,

@@ -83,6 +83,20 @@ int main(int argc, char** argv) {
         CHECK(pos == data.size());
         for (size_t i = 0; i < chunks.size(); i += 5)          // chunk hash == SHA-256 of the slice
             CHECK(chunks[i].hash == hasher.hash(bytes(data).subspan(chunks[i].offset, chunks[i].size)));
+        {   // progress callback + async file chunking (rabin_chunker.cpp:144-147, 182-192)
+            uint64_t last = 0, total = 0; size_t calls = 0;
+            chunker.setProgressCallback([&](uint64_t p, uint64_t t) { CHECK(p > last); last = p; total = t; ++calls; });
+            auto again = chunker.chunkDataLazy(bytes(data));
+            CHECK(calls == again.size() && last == data.size() && total == data.size());
+            chunker.setProgressCallback(nullptr);
+            const std::string path = "/tmp/yams_accel_chunkfile_test.bin";
+            { std::ofstream f(path, std::ios::binary); f.write(data.data(), static_cast<std::streamsize>(data.size())); }
+            auto viaFile = chunker.chunkFileAsync(path).get();
+            CHECK(viaFile.has_value() && viaFile.value().size() == chunks.size() && viaFile.value().back().hash == chunks.back().hash);
+            auto missing = chunker.chunkFileAsync("/tmp/yams_accel_no_such_file").get();
+            CHECK(!missing.has_value() && missing.error().code == ErrorCode::FileNotFound);
+            std::remove(path.c_str());
+        }
         auto lazy = chunker.chunkDataLazy(bytes(data));
         CHECK(lazy.size() == chunks.size() && lazy.back().hash == chunks.back().hash && lazy.front().data.empty());
     }
