@@ -112,6 +112,35 @@ public:
         byId_.erase(it);
         return {};
     }
+    // updateVector replaces the row of chunk_id (it must exist, sqlite_vec_backend.cpp CRUD contract)
+    Result<void> updateVector(const std::string& chunkId, const VectorRecord& record) {
+        if (byId_.find(chunkId) == byId_.end()) return Error{ErrorCode::NotFound, "chunk not found"};
+        VectorRecord r = record;
+        r.chunk_id = chunkId;
+        return insertVectorsBatch({r});
+    }
+    Result<void> deleteVectorsByDocument(const std::string& documentHash) {
+        std::vector<std::string> ids;
+        for (const auto& [id, row] : byId_) if (records_[row].document_hash == documentHash) ids.push_back(id);
+        for (const auto& id : ids) (void)deleteVector(id);
+        return {};
+    }
+    Result<std::optional<VectorRecord>> getVector(const std::string& chunkId) const {
+        auto it = byId_.find(chunkId);
+        if (it == byId_.end()) return std::optional<VectorRecord>{};
+        return std::optional<VectorRecord>{records_[it->second]};
+    }
+    Result<std::vector<VectorRecord>> getVectorsByDocument(const std::string& documentHash) const {
+        std::vector<VectorRecord> out;
+        for (size_t r = 0; r < records_.size(); ++r)
+            if (alive_[r] && records_[r].document_hash == documentHash) out.push_back(records_[r]);
+        return out;
+    }
+    Result<bool> hasEmbedding(const std::string& documentHash) const {
+        for (size_t r = 0; r < records_.size(); ++r)
+            if (alive_[r] && records_[r].document_hash == documentHash) return true;
+        return false;
+    }
     Result<size_t> getVectorCount() const { return records_.size() - dead_; }
     size_t mirrorRows() const { return records_.size(); }   // incl. tombstones (for tests)
     size_t uploadedRows() const { return deviceRows_; }

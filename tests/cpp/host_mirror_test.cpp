@@ -172,6 +172,17 @@ int main(int argc, char** argv) {
         CHECK(db.deleteVector("exact_0").has_value());
         auto after = db.searchSimilar({1, 0, 0, 0}, 1, -1.0f);
         CHECK(after.has_value() && after.value().front().chunk_id == "exact_1");
+        // retrieval / update / delete-by-document on the mirror
+        CHECK(db.getVector("exact_3").value().has_value() && !db.getVector("exact_0").value().has_value());
+        CHECK(db.hasEmbedding("doc_2").value() && !db.hasEmbedding("doc_0").value());
+        vector::VectorRecord up; up.document_hash = "doc_5"; up.embedding = {1.0f, 0.0f, 0.0f, 0.0f};
+        CHECK(db.updateVector("exact_5", up).has_value() && !db.updateVector("nope", up).has_value());
+        auto upd = db.searchSimilar({1, 0, 0, 0}, 1, -1.0f);
+        CHECK(upd.has_value() && upd.value().front().chunk_id == "exact_5" && upd.value().front().relevance_score == 1.0f);
+        CHECK(db.deleteVectorsByDocument("doc_5").has_value() && db.getVectorsByDocument("doc_5").value().empty());
+        CHECK(db.getVectorCount().value() == 4);
+        auto gone5 = db.searchSimilar({1, 0, 0, 0}, 1, -1.0f);
+        CHECK(gone5.has_value() && gone5.value().front().chunk_id == "exact_1");
     }
     for (auto order : {std::vector<std::string>{"tie_c", "tie_a", "tie_b"}, std::vector<std::string>{"tie_b", "tie_a", "tie_c"}}) {
         auto idxR = vector::createAccelVectorIndex(plugin, 4);
