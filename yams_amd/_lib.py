@@ -96,6 +96,10 @@ class VectorScanV1(C.Structure):
                                             C.c_uint32, C.c_float, C.c_uint32, u32p,
                                             C.POINTER(C.POINTER(ScanHit)), C.POINTER(u32p),
                                             C.POINTER(ScanDiag))),
+        ("search_batch_ex", C.CFUNCTYPE(ST, vp, C.c_uint64, f32p, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, u32p,
+                                        C.POINTER(C.POINTER(ScanHit)), C.POINTER(u32p),
+                                        C.POINTER(ScanDiag))),
     ]
 
 
@@ -110,6 +114,12 @@ class ContentHashV1(C.Structure):
         ("stream_update", C.CFUNCTYPE(ST, vp, vp, u8p, C.c_size_t)),
         ("stream_finalize", C.CFUNCTYPE(ST, vp, vp, C.c_char_p)),
         ("stream_destroy", C.CFUNCTYPE(None, vp, vp)),
+        ("verify_many", C.CFUNCTYPE(ST, vp, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, u8p)),
+        ("dedup_create", C.CFUNCTYPE(ST, vp, C.c_uint64, u64p)),
+        ("dedup_insert", C.CFUNCTYPE(ST, vp, C.c_uint64, C.c_char_p, C.c_size_t, u8p)),
+        ("dedup_contains", C.CFUNCTYPE(ST, vp, C.c_uint64, C.c_char_p, C.c_size_t, u8p)),
+        ("dedup_size", C.CFUNCTYPE(ST, vp, C.c_uint64, u64p)),
+        ("dedup_destroy", C.CFUNCTYPE(ST, vp, C.c_uint64)),
     ]
 
 
