@@ -256,7 +256,7 @@ def main():
     bf16 = (not a.f32_filter) and d % 16 == 0
     tr = 256 if bf16 else 128
     n_tiles = (n + tr - 1) // tr
-    s_target = min(n, max(n // 32, 8192))
+    s_target = min(n, max(n // 64, 8192))
     stride = max(1, n_tiles // ((s_target + tr - 1) // tr))
     n_sample = (n_tiles + stride - 1) // stride
     filt_rows = min(n, (n_tiles - n_sample) * tr)

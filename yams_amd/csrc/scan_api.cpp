@@ -36,7 +36,7 @@ ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool 
     p.kprime = (passes == 1)
                    ? std::min<uint32_t>(round_up(metric == YAMS_SCAN_L2 ? 6 * k + 128 : 3 * k + 64, 32), kRescoreMax)
                    : std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
-    const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 32, 8192));
+    const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 64, 8192));
     uint32_t want_tiles = static_cast<uint32_t>((s_target + p.tile_rows - 1) / p.tile_rows);
     if (want_tiles == 0) want_tiles = 1;
     p.sample_stride = std::max<uint32_t>(1, p.n_tiles / want_tiles);
@@ -46,10 +46,10 @@ ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool 
     p.n_groups = static_cast<uint32_t>(p.sample_rows / kGroupRows);
     // tau = the tau_rank-th best sample value, i.e. about the (tau_rank * stride)-th best overall:
     // the lists must hold comfortably more than the kprime candidates stage 1 wants
-    // (expected list size tau_rank * stride, relative spread ~1/sqrt(tau_rank): 32 keeps it within
-    // +-50 % with overwhelming probability)
-    const uint32_t need_rank = (p.kprime + p.kprime / 4 + 32 + p.sample_stride - 1) / p.sample_stride;
-    p.tau_rank = std::min<uint32_t>(std::max<uint32_t>(32, round_up(need_rank, 32)), kRescoreMax);
+    // (list size ~ Gamma(tau_rank) scaled to tau_rank * stride: with rank 16 and an expectation of
+    // 2.7x what the proof needs, the chance of a list too short to prove is ~1e-7 per query)
+    const uint32_t need_rank = (2 * p.kprime + p.kprime / 2 + 32 + p.sample_stride - 1) / p.sample_stride;
+    p.tau_rank = std::min<uint32_t>(std::max<uint32_t>(16, round_up(need_rank, 16)), kRescoreMax);
     // expected list length tau_rank * stride (relative spread ~1/sqrt(tau_rank)): 4x is > 15 sigma
     uint64_t cap = std::max<uint64_t>(4096, 4ull * p.tau_rank * p.sample_stride);
     if (p.n_groups < p.tau_rank) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
