@@ -15,3 +15,8 @@ rm -rf $OUT/prof_trace $OUT/prof_ingest $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_pmc1 -o scan -- $B > $OUT/prof_pmc1.log 2>&1) || true
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU --kernel-trace -f csv -d $OUT/prof_pmc2 -o scan -- $B > $OUT/prof_pmc2.log 2>&1) || true
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum --kernel-trace -f csv -d $OUT/prof_pmc3 -o scan -- $B > $OUT/prof_pmc3.log 2>&1) || true
+# small batches: the narrow (HBM-bound) filter at Q = 64
+S="python $REPO/scripts/small_batch.py"
+rm -rf $OUT/prof_small $OUT/prof_small_pmc
+(cd /tmp && QS=64 FORMS=default timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_small -o small -- $S > $OUT/small_batch_prof.jsonl 2> $OUT/prof_small.log) || true
+(cd /tmp && QS=64 FORMS=default timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_small_pmc -o small -- $S > /dev/null 2> $OUT/prof_small_pmc.log) || true

@@ -277,6 +277,28 @@ def test_all_filters_agree_with_the_oracle(acc, oracle, metric):
     assert a.diag["exact_fallback_queries"] == 0 and b.diag["exact_fallback_queries"] == 0
 
 
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+@pytest.mark.parametrize("nq", [1, 33, 64, 65, 128, 129])
+def test_small_batches_take_the_narrow_filter_and_agree(acc, oracle, metric, nq, monkeypatch):
+    """Batches of <= 64 / <= 128 queries run the narrow (HBM-bound) form of the shadow filter; 129
+    falls back to the 256-query tile.  Same result as the oracle and, bit for bit, as the wide form
+    (YAMS_ACCEL_BF16_KERNEL=3); ragged row tail, zero-norm and huge-norm rows, thresholds."""
+    n, d, k = 40000 + 77, 192, 30
+    corpus = oracle.synth_rows(21, 0, n, d)
+    corpus[5] = 0.0
+    corpus[n - 1] = 0.0
+    corpus[777] *= 1e18          # out-of-range norm: NaN filter score, exact re-score decides
+    q = oracle.synth_rows(21, 1 << 40, nq, d)
+    thr = 0.05 if metric == SCAN_COSINE else -1.0
+    a = check(acc, oracle, corpus, q, k, thr=thr, metric=metric, max_queries=5, expect_path=0)
+    monkeypatch.setenv("YAMS_ACCEL_BF16_KERNEL", "3")
+    b = run(acc, corpus, q, k, thr, metric)
+    monkeypatch.delenv("YAMS_ACCEL_BF16_KERNEL")
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.counts, b.counts)
+    assert np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
+    assert a.diag["exact_fallback_queries"] == 0
+
+
 def test_forced_exact_equals_filter_path(acc, oracle):
     corpus = oracle.synth_rows(12, 0, 50000, 128)
     q = oracle.synth_rows(12, 1 << 40, 6, 128)

@@ -1039,6 +1039,135 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArg
     }
 }
 
+// =================================================================================================
+// Narrow form of the shadow kernel (FILTER mode) for batches of at most 32 NQB queries (64 or 128).
+//
+// With one query tile the pass streams the shadow once and the 256-query tile of the kernels above
+// multiplies mostly padding: a 12.5M x 768 shard took 4.3 ms whether 1 or 256 queries rode along
+// (4.5 TB/s).  Here a workgroup still owns 256 rows, but only 32 NQB query columns: a wave
+// multiplies ITS OWN 32 rows (staged by itself, two 1 KiB DMA pieces per 32-wide k-slab — no other
+// wave reads them) against the query slab the workgroup shares (2 NQB pieces, one per wave for the
+// first 2 NQB waves).  4 NQB MFMAs per wave per slab leave the matrix pipe mostly idle; what
+// matters is bytes in flight: a 3-stage ring of 20 / 24 KiB per workgroup, TWO workgroups per CU
+// (<= 128 VGPRs), i.e. 4 row slabs = 64 KiB of HBM reads in flight per CU at all times, and one
+// workgroup's prologue / epilogue overlaps the other's stream.
+// Precondition: dim % 32 == 0, n_queries <= 32 NQB, shadow present.
+// =================================================================================================
+template <int METRIC, int NQB>
+__global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArgs a) {
+    constexpr int NST = 3;
+    constexpr int Q_BYTES = NQB * 32 * SH_K * 2;   // query part of a stage (2 KiB per 32 queries)
+    constexpr int STAGE = SH_A_BYTES + Q_BYTES;
+    constexpr int QPIECES = Q_BYTES / 1024;        // 4 or 8
+    static_assert(QPIECES <= 8, "one query piece per wave at most");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
+
+    const uint32_t sel = blockIdx.x;
+    const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const uint64_t row0 = static_cast<uint64_t>(tile) * BT_ROWS;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / SH_K;
+
+    uint32_t voffA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rowA = wid * 32 + i * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((rowA >> 2) & 3);
+        uint64_t r = row0 + rowA;
+        if (r >= a.n_rows) r = a.n_rows - 1;
+        voffA[i] = static_cast<uint32_t>(r - row0) * dim * 2u + c * 16u;
+    }
+    const int rowQ = (wid & (QPIECES - 1)) * 16 + (lane >> 2);
+    const uint32_t voffQ = static_cast<uint32_t>(rowQ) * 64u + (((lane & 3) ^ ((rowQ >> 2) & 3)) * 16u);
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_bf16 + row0 * dim);
+    const unsigned char* baseQ = reinterpret_cast<const unsigned char*>(a.q_hi);
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
+    const uint32_t ldsQ = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + (wid & (QPIECES - 1)) * 1024);
+
+    const int rf = wid * 32 + l31;
+    int offA[2], offB[NQB][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) offA[t] = rf * 64 + (((2 * t + h) ^ ((rf >> 2) & 3)) << 4);
+#pragma unroll
+    for (int u = 0; u < NQB; ++u) {
+        const int rq = u * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offB[u][t] = SH_A_BYTES + rq * 64 + (((2 * t + h) ^ ((rq >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[NQB];
+#pragma unroll
+    for (int u = 0; u < NQB; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    // epilogue inputs first: older than every DMA piece, so the counted waits below stay valid
+    float tau_pre[NQB];
+    const uint64_t rme = row0 + static_cast<uint32_t>(rf);
+    const float nfull = rme < a.n_rows ? a.rows_nsq[rme] : 1.f;
+#pragma unroll
+    for (int u = 0; u < NQB; ++u) {
+        const uint32_t qi = u * 32 + l31;
+        tau_pre[u] = qi < a.n_queries ? a.tau[qi] : __builtin_inff();
+    }
+
+    // HASQ: this wave also stages one piece of the shared query slab (3 pieces per slab, else 2)
+    auto run = [&](auto hasq_tag) __attribute__((always_inline)) {
+        constexpr bool HASQ = decltype(hasq_tag)::value;
+        auto issue = [&](int sl, int stg) __attribute__((always_inline)) {
+            const uint32_t st = static_cast<uint32_t>(stg) * STAGE;
+            lds_dma16_s(baseA + sl * (SH_K * 2), voffA[0], ldsA + st);
+            lds_dma16_s(baseA + sl * (SH_K * 2), voffA[1], ldsA + st + 1024);
+            if (HASQ) lds_dma16_s(baseQ + sl * qslab_bytes, voffQ, ldsQ + st);
+        };
+        issue(0, 0);
+        if (nslab > 1) issue(1, 1);
+        int stage = 0;
+        for (int sl = 0; sl < nslab; ++sl) {
+            // slab sl landed (the one after it may still be in flight); every wave is past its reads
+            // of slab sl-1, whose stage the refill below reuses
+            if (sl + 1 < nslab) {
+                if (HASQ) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            const int nstage = stage == 0 ? NST - 1 : stage - 1; // (sl + 2) % NST
+            if (sl + 2 < nslab) issue(sl + 2, nstage);
+            const unsigned char* base = lds + stage * STAGE;
+            stage = stage + 1 == NST ? 0 : stage + 1;
+            bf16x8 fa[2], fb[NQB][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *reinterpret_cast<const bf16x8*>(base + offA[t]);
+#pragma unroll
+                for (int u = 0; u < NQB; ++u) fb[u][t] = *reinterpret_cast<const bf16x8*>(base + offB[u][t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < NQB; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t], fb[u][t], acc[u], 0, 0, 0);
+        }
+    };
+    if constexpr (QPIECES == 8) {
+        run(std::integral_constant<bool, true>{});
+    } else {
+        if (wid < QPIECES) run(std::integral_constant<bool, true>{});
+        else run(std::integral_constant<bool, false>{});
+    }
+    bf16_epilogue<MODE_FILTER, METRIC, 0, NQB, true>(a, acc, nfull, row0, static_cast<uint32_t>(wid) * 32u, 0u, sel, h, l31,
+                                                     tau_pre);
+}
+
 // The shadow: bf16 (RNE) of the UNIT-NORMALISED rows + their fp32 squared norms; one wave per row.
 // Rows whose squared norm is outside (1e-30, 1e30) or not finite get an all-zero shadow row; the
 // filter epilogue turns their scores into NaN (= always a candidate) from the stored norm.
@@ -1156,6 +1285,19 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
             const uint32_t total_w = groups * a.n_qtiles * 8u;
             if (pg > total_w) pg = (total_w + 7u) & ~7u;
             hipLaunchKernelGGL(scan_tiles_bf16p_kernel, dim3(pg), dim3(BT_THREADS), 0, st, a);
+            LAUNCH_CHECK();
+            return hipSuccess;
+        }
+        // small batches: the narrow form (HBM-bound; see the kernel).  version 3 keeps the 256-query form
+        if (mode == MODE_FILTER && version == 2 && a.n_queries <= 128 && L.plan.dim >= 64) {
+            const uint32_t ng = a.n_sel_tiles;
+            if (a.n_queries <= 64) {
+                if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+                else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+            } else {
+                if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+                else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+            }
             LAUNCH_CHECK();
             return hipSuccess;
         }
