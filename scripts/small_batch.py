@@ -38,7 +38,7 @@ for nq in [int(x) for x in os.environ.get("QS", "1,16,64,128,256").split(",")]:
         acc.enable_timing(False)
         res = (r.cpu().numpy().copy(), s.cpu().numpy().view("uint32").copy())
         same = None
-        if form == "wide" and nq in keep:
+        if form != "default" and nq in keep:
             same = bool((keep[nq][0] == res[0]).all() and (keep[nq][1] == res[1]).all())
         elif form == "default":
             keep[nq] = res

@@ -1050,16 +1050,21 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArg
 // first 2 NQB waves).  4 NQB MFMAs per wave per slab leave the matrix pipe mostly idle; what
 // matters is bytes in flight: a 3-stage ring of 20 / 24 KiB per workgroup, TWO workgroups per CU
 // (<= 128 VGPRs), i.e. 4 row slabs = 64 KiB of HBM reads in flight per CU at all times, and one
-// workgroup's prologue / epilogue overlaps the other's stream.
+// workgroup's prologue / epilogue overlaps the other's stream.  Measured on a 12.5M x 768 shard:
+// 3.10 ms (6.1 TB/s, 0.76 of the HBM peak) up to 64 queries, 3.39 ms at 128, against 4.1-4.5 ms of
+// the 256-query form.  The same structure stretched to a whole 256-query tile (NQB = 8, one
+// workgroup per CU, 4-stage ring) was measured too and loses to the interleaved kernel above
+// (5.4 vs 4.7 ms): from 129 queries on the matrix pipe matters again.
 // Precondition: dim % 32 == 0, n_queries <= 32 NQB, shadow present.
 // =================================================================================================
 template <int METRIC, int NQB>
 __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArgs a) {
-    constexpr int NST = 3;
+    static_assert(NQB == 2 || NQB == 4, "64 or 128 queries");
+    constexpr int NST = 3;                         // ring stages
     constexpr int Q_BYTES = NQB * 32 * SH_K * 2;   // query part of a stage (2 KiB per 32 queries)
     constexpr int STAGE = SH_A_BYTES + Q_BYTES;
-    constexpr int QPIECES = Q_BYTES / 1024;        // 4 or 8
-    static_assert(QPIECES <= 8, "one query piece per wave at most");
+    constexpr int QPIECES = Q_BYTES / 1024;        // 4 or 8 query pieces per slab
+    constexpr int QPW = QPIECES >= 8 ? QPIECES / 8 : 1; // ... per staging wave
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
 
     const uint32_t sel = blockIdx.x;
@@ -1072,7 +1077,7 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
     const uint32_t dim = a.dim;
     const int nslab = dim / SH_K;
 
-    uint32_t voffA[2];
+    uint32_t voffA[2], voffQ[QPW];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rowA = wid * 32 + i * 16 + (lane >> 2);
@@ -1081,25 +1086,27 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
         if (r >= a.n_rows) r = a.n_rows - 1;
         voffA[i] = static_cast<uint32_t>(r - row0) * dim * 2u + c * 16u;
     }
-    const int rowQ = (wid & (QPIECES - 1)) * 16 + (lane >> 2);
-    const uint32_t voffQ = static_cast<uint32_t>(rowQ) * 64u + (((lane & 3) ^ ((rowQ >> 2) & 3)) * 16u);
+    const int qpiece0 = QPIECES >= 8 ? wid * QPW : (wid & (QPIECES - 1));
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        const int rowQ = (qpiece0 + j) * 16 + (lane >> 2);
+        voffQ[j] = static_cast<uint32_t>(rowQ) * 64u + (((lane & 3) ^ ((rowQ >> 2) & 3)) * 16u);
+    }
     const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_bf16 + row0 * dim);
     const unsigned char* baseQ = reinterpret_cast<const unsigned char*>(a.q_hi);
     const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
     const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
-    const uint32_t ldsQ = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + (wid & (QPIECES - 1)) * 1024);
+    const uint32_t ldsQ = __builtin_amdgcn_readfirstlane(lds0 + SH_A_BYTES + qpiece0 * 1024);
 
     const int rf = wid * 32 + l31;
-    int offA[2], offB[NQB][2];
+    // query block u sits 2 KiB further (same swizzle: 32 | 16), an immediate offset of the read
+    int offA[2], offB[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) offA[t] = rf * 64 + (((2 * t + h) ^ ((rf >> 2) & 3)) << 4);
-#pragma unroll
-    for (int u = 0; u < NQB; ++u) {
-        const int rq = u * 32 + l31;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) offB[u][t] = SH_A_BYTES + rq * 64 + (((2 * t + h) ^ ((rq >> 2) & 3)) << 4);
+    for (int t = 0; t < 2; ++t) {
+        offA[t] = rf * 64 + (((2 * t + h) ^ ((rf >> 2) & 3)) << 4);
+        offB[t] = SH_A_BYTES + l31 * 64 + (((2 * t + h) ^ ((l31 >> 2) & 3)) << 4);
     }
 
     f32x16 acc[NQB];
@@ -1118,30 +1125,39 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
         tau_pre[u] = qi < a.n_queries ? a.tau[qi] : __builtin_inff();
     }
 
-    // HASQ: this wave also stages one piece of the shared query slab (3 pieces per slab, else 2)
+    // HASQ: this wave also stages QPW pieces of the shared query slab (2 + QPW pieces per slab, else 2)
     auto run = [&](auto hasq_tag) __attribute__((always_inline)) {
         constexpr bool HASQ = decltype(hasq_tag)::value;
+        constexpr int PPW = 2 + (HASQ ? QPW : 0);
         auto issue = [&](int sl, int stg) __attribute__((always_inline)) {
             const uint32_t st = static_cast<uint32_t>(stg) * STAGE;
             lds_dma16_s(baseA + sl * (SH_K * 2), voffA[0], ldsA + st);
             lds_dma16_s(baseA + sl * (SH_K * 2), voffA[1], ldsA + st + 1024);
-            if (HASQ) lds_dma16_s(baseQ + sl * qslab_bytes, voffQ, ldsQ + st);
+            if (HASQ) {
+#pragma unroll
+                for (int j = 0; j < QPW; ++j) lds_dma16_s(baseQ + sl * qslab_bytes, voffQ[j], ldsQ + st + j * 1024);
+            }
         };
-        issue(0, 0);
-        if (nslab > 1) issue(1, 1);
+        // s_waitcnt for "at most `newer` slabs younger than the one needed are still in flight"
+        auto wait_newer = [&](int newer) __attribute__((always_inline)) {
+            const int c = newer * PPW;
+            if (c >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (c >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (c >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (c >= 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else if (c >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        };
+        for (int sl = 0; sl < NST - 1 && sl < nslab; ++sl) issue(sl, sl);
         int stage = 0;
         for (int sl = 0; sl < nslab; ++sl) {
-            // slab sl landed (the one after it may still be in flight); every wave is past its reads
-            // of slab sl-1, whose stage the refill below reuses
-            if (sl + 1 < nslab) {
-                if (HASQ) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
+            // slab sl landed (up to NST-2 younger ones may still be in flight); every wave is past
+            // its reads of slab sl-1, whose stage the refill below reuses
+            const int left = nslab - 1 - sl;
+            wait_newer(left < NST - 2 ? left : NST - 2);
             __builtin_amdgcn_s_barrier();
-            const int nstage = stage == 0 ? NST - 1 : stage - 1; // (sl + 2) % NST
-            if (sl + 2 < nslab) issue(sl + 2, nstage);
+            const int nstage = stage == 0 ? NST - 1 : stage - 1; // (sl + NST - 1) % NST
+            if (sl + NST - 1 < nslab) issue(sl + NST - 1, nstage);
             const unsigned char* base = lds + stage * STAGE;
             stage = stage + 1 == NST ? 0 : stage + 1;
             bf16x8 fa[2], fb[NQB][2];
@@ -1149,7 +1165,7 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
             for (int t = 0; t < 2; ++t) {
                 fa[t] = *reinterpret_cast<const bf16x8*>(base + offA[t]);
 #pragma unroll
-                for (int u = 0; u < NQB; ++u) fb[u][t] = *reinterpret_cast<const bf16x8*>(base + offB[u][t]);
+                for (int u = 0; u < NQB; ++u) fb[u][t] = *reinterpret_cast<const bf16x8*>(base + offB[t] + u * 2048);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1158,7 +1174,7 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t], fb[u][t], acc[u], 0, 0, 0);
         }
     };
-    if constexpr (QPIECES == 8) {
+    if constexpr (QPIECES >= 8) {
         run(std::integral_constant<bool, true>{});
     } else {
         if (wid < QPIECES) run(std::integral_constant<bool, true>{});
@@ -1288,16 +1304,15 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
             LAUNCH_CHECK();
             return hipSuccess;
         }
-        // small batches: the narrow form (HBM-bound; see the kernel).  version 3 keeps the 256-query form
-        if (mode == MODE_FILTER && version == 2 && a.n_queries <= 128 && L.plan.dim >= 64) {
+        // small batches: the narrow form (HBM-bound; see the kernel).  version 3 keeps the 256-query form.
+        // (L2 with 128 queries would need more than the 128 VGPRs two workgroups per CU leave a wave —
+        // its epilogue rescales every score by the row norm — so L2 goes narrow up to 64 queries only.)
+        if (mode == MODE_FILTER && version == 2 && L.plan.dim >= 64 &&
+            a.n_queries <= (metric == YAMS_SCAN_COSINE ? 128u : 64u)) {
             const uint32_t ng = a.n_sel_tiles;
-            if (a.n_queries <= 64) {
-                if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-                else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-            } else {
-                if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-                else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-            }
+            if (metric != YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+            else if (a.n_queries <= 64) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
             LAUNCH_CHECK();
             return hipSuccess;
         }
