@@ -61,7 +61,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_queries=8):
+def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_queries=16):
     """The oracle (scalar fp64 restatement of sqlite_vec_backend.cpp:4204-4331) timed on this
     box's host cores on a bounded sample of the same workload; also the recall check."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -89,7 +89,7 @@ def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_qu
             "host_cores_available": os.cpu_count()}, recall, exact
 
 
-def ingest_cpu_baseline(seed, blen, n_sample=16):
+def ingest_cpu_baseline(seed, blen, n_sample=384):
     """The reference's own translation units (oracle/_ref: StreamingChunker::chunkData incl. the
     per-chunk SHA-256, + SHA256Hasher::hash of the whole blob) on one host core, on a bounded
     sample of the same Philox blobs; falls back to the plain-C port when _ref did not travel."""

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArg
 }
 
 // =================================================================================================
-// Narrow form of the shadow kernel (FILTER mode) for batches of at most 32 NQB queries (64 or 128).
+// Narrow form of the shadow kernel for batches of at most 32 NQB queries (64 or 128).
 //
 // With one query tile the pass streams the shadow once and the 256-query tile of the kernels above
 // multiplies mostly padding: a 12.5M x 768 shard took 4.3 ms whether 1 or 256 queries rode along
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArg
 // (5.4 vs 4.7 ms): from 129 queries on the matrix pipe matters again.
 // Precondition: dim % 32 == 0, n_queries <= 32 NQB, shadow present.
 // =================================================================================================
-template <int METRIC, int NQB>
+template <int MODE, int METRIC, int NQB>
 __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArgs a) {
     static_assert(NQB == 2 || NQB == 4, "64 or 128 queries");
     constexpr int NST = 3;                         // ring stages
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
 
     const uint32_t sel = blockIdx.x;
-    const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+    const uint32_t tile = MODE == MODE_SAMPLE ? sel * a.stride : sel + sel / (a.stride - 1u) + 1u;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
 #pragma unroll
     for (int u = 0; u < NQB; ++u) {
         const uint32_t qi = u * 32 + l31;
-        tau_pre[u] = qi < a.n_queries ? a.tau[qi] : __builtin_inff();
+        tau_pre[u] = (MODE == MODE_FILTER && qi < a.n_queries) ? a.tau[qi] : __builtin_inff();
     }
 
     // HASQ: this wave also stages QPW pieces of the shared query slab (2 + QPW pieces per slab, else 2)
@@ -1180,8 +1180,8 @@ __global__ __launch_bounds__(BT_THREADS, 4) void scan_tiles_bf16n_kernel(ScanArg
         if (wid < QPIECES) run(std::integral_constant<bool, true>{});
         else run(std::integral_constant<bool, false>{});
     }
-    bf16_epilogue<MODE_FILTER, METRIC, 0, NQB, true>(a, acc, nfull, row0, static_cast<uint32_t>(wid) * 32u, 0u, sel, h, l31,
-                                                     tau_pre);
+    bf16_epilogue<MODE, METRIC, 0, NQB, true>(a, acc, nfull, row0, static_cast<uint32_t>(wid) * 32u, 0u, sel, h, l31,
+                                              MODE == MODE_FILTER ? tau_pre : nullptr);
 }
 
 // The shadow: bf16 (RNE) of the UNIT-NORMALISED rows + their fp32 squared norms; one wave per row.
@@ -1307,12 +1307,21 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
         // small batches: the narrow form (HBM-bound; see the kernel).  version 3 keeps the 256-query form.
         // (L2 with 128 queries would need more than the 128 VGPRs two workgroups per CU leave a wave —
         // its epilogue rescales every score by the row norm — so L2 goes narrow up to 64 queries only.)
-        if (mode == MODE_FILTER && version == 2 && L.plan.dim >= 64 &&
-            a.n_queries <= (metric == YAMS_SCAN_COSINE ? 128u : 64u)) {
-            const uint32_t ng = a.n_sel_tiles;
-            if (metric != YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_L2, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-            else if (a.n_queries <= 64) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 2>), dim3(ng), dim3(BT_THREADS), 0, st, a);
-            else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<YAMS_SCAN_COSINE, 4>), dim3(ng), dim3(BT_THREADS), 0, st, a);
+        // (the sample epilogue of a 128-query block does not fit 128 VGPRs either: the sample pass
+        // of 65..128-query batches stays on the 256-query form)
+        const uint32_t narrow_max = (metric == YAMS_SCAN_COSINE && mode == MODE_FILTER) ? 128u : 64u;
+        if (version == 2 && L.plan.dim >= 64 && a.n_queries <= narrow_max) {
+            const dim3 ng(a.n_sel_tiles), nt(BT_THREADS);
+            if (mode == MODE_SAMPLE) {
+                if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16n_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE, 2>), ng, nt, 0, st, a);
+                else hipLaunchKernelGGL((scan_tiles_bf16n_kernel<MODE_SAMPLE, YAMS_SCAN_L2, 2>), ng, nt, 0, st, a);
+            } else if (metric != YAMS_SCAN_COSINE) {
+                hipLaunchKernelGGL((scan_tiles_bf16n_kernel<MODE_FILTER, YAMS_SCAN_L2, 2>), ng, nt, 0, st, a);
+            } else if (a.n_queries <= 64) {
+                hipLaunchKernelGGL((scan_tiles_bf16n_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), ng, nt, 0, st, a);
+            } else {
+                hipLaunchKernelGGL((scan_tiles_bf16n_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 4>), ng, nt, 0, st, a);
+            }
             LAUNCH_CHECK();
             return hipSuccess;
         }
