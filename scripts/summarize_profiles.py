@@ -32,7 +32,7 @@ copy(os.path.join(G, "prof_small", "small_kernel_stats.csv"), os.path.join(P, f"
 f = os.path.join(G, "prof_small_pmc", "small_counter_collection.csv")
 if os.path.exists(f):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-         if "bf16n_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+         if "bf16n_kernel<1," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
     if v:
         fs = sum(v) / len(v)
         out = {"kernel": "scan_tiles_bf16n_kernel<COSINE, 2> (narrow filter, Q <= 64)", "rows_per_gpu": 12_500_000,
