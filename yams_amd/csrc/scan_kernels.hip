@@ -265,20 +265,39 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
 // -------------------------------------------------------------------------------------------------
 __global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t dim, int metric,
                                     float* qprep, double* qnorm, float* qnorm_up,
-                                    uint32_t* qflags) {
+                                    uint32_t* qflags, int staged) {
     const uint32_t qi = blockIdx.x;
     __shared__ double s_norm;
     __shared__ uint32_t s_flag;
+    extern __shared__ float s_stage[]; // dim floats when the launch provides them (staged != 0)
     const float* src = q + static_cast<uint64_t>(qi) * dim;
+    if (staged) {
+        // the norm below is ONE sequential fp64 chain (reference order): feed it from LDS, not from
+        // dependent global loads (40 us -> a few us for a lone 768-wide query)
+        for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) s_stage[i] = src[i];
+        __syncthreads();
+        src = s_stage;
+    }
     if (threadIdx.x == 0) {
         double acc = 0.0;
-        bool finite = true;
-        for (uint32_t i = 0; i < dim; ++i) {
-            const float v = src[i];
-            if (!isfinite(v)) finite = false;
-            const double d = static_cast<double>(v);
-            acc = fma(d, d, acc); // v*v is exact in fp64, so fma == mul then add
+        // one sequential chain in the reference's order; fp64 cannot overflow on fp32 squares, so
+        // "every element finite" <=> "the sum is finite" (inf*inf = inf, NaN propagates)
+        uint32_t i = 0;
+        for (; i + 8 <= dim; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[i + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double d = static_cast<double>(v[e]);
+                acc = fma(d, d, acc); // v*v is exact in fp64, so fma == mul then add
+            }
         }
+        for (; i < dim; ++i) {
+            const double d = static_cast<double>(src[i]);
+            acc = fma(d, d, acc);
+        }
+        const bool finite = isfinite(acc);
         uint32_t f = 0;
         if (!finite) f |= 1u;
         if (!(acc >= 1e-10)) f |= 2u;
@@ -310,17 +329,18 @@ __global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t dim, i
 // Block top-k by bitonic sort in LDS.  Grid (n_chunks, n_queries).  Sorts one chunk of up to CAP
 // keys of one query in descending order and writes its best `keep` keys (0-padded).
 // -------------------------------------------------------------------------------------------------
+// Sorts s[0, m) in descending order; m is a power of two <= CAP (the same for the whole block).
+// One compare-exchange per thread per step: pair t is (i, i + j) with i = 2t - (t & (j - 1)).
 template <typename K, int CAP, int NT>
-__device__ __forceinline__ void bitonic_desc(K* s) {
-    for (int k = 2; k <= CAP; k <<= 1) {
+__device__ __forceinline__ void bitonic_desc(K* s, int m = CAP) {
+    for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < CAP; i += NT) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const K x = s[i], y = s[ixj];
-                    const bool up = (i & k) == 0; // descending overall
-                    if (up ? (x < y) : (x > y)) { s[i] = y; s[ixj] = x; }
-                }
+            for (int t = threadIdx.x; t < (m >> 1); t += NT) {
+                const int i = 2 * t - (t & (j - 1));
+                const int ixj = i + j;
+                const K x = s[i], y = s[ixj];
+                const bool up = (i & k) == 0; // descending overall
+                if (up ? (x < y) : (x > y)) { s[i] = y; s[ixj] = x; }
             }
             __syncthreads();
         }
@@ -345,13 +365,17 @@ __global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint
         for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = K(0);
         return;
     }
-    for (int i = threadIdx.x; i < CAP; i += 256) {
+    // only the occupied part of the chunk is sorted (keys are non-zero, the 0 padding sorts last)
+    const uint64_t left = n - c0;
+    int m = 2;
+    while (m < CAP && static_cast<uint64_t>(m) < left) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 256) {
         const uint64_t e = c0 + i;
         s[i] = (e < n) ? src[e] : K(0);
     }
     __syncthreads();
-    bitonic_desc<K, CAP, 256>(s);
-    for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = (i < CAP) ? s[i] : K(0);
+    bitonic_desc<K, CAP, 256>(s, m);
+    for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = (i < static_cast<uint32_t>(m)) ? s[i] : K(0);
 }
 
 // tau[q] = score of the rank-th best group maximum (or -inf when there are fewer groups).
@@ -536,16 +560,29 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             const int lane = threadIdx.x & 63;
             float* stg = sstage + (threadIdx.x >> 6) * (64 * RS_STAGE_STRIDE);
             if (__builtin_amdgcn_ballot_w64(live) != 0) { // whole wave idle in a partial round: skip
+                // The lines of chunk c+1 are requested before chunk c is summed: a lone query has
+                // nothing else to hide the miss latency of its dim/32 dependent chunk rounds behind.
+                // (No fence between the staging stores and the reads: DS operations of one wave
+                // execute in order, and a release fence would drain the prefetch as well.)
+                const float* lrow[8];
+                typedef float rs_f4 __attribute__((ext_vector_type(4))); // (HIP's float4 struct keeps the array in scratch)
+                rs_f4 nx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t r = static_cast<uint32_t>(__shfl(static_cast<int>(row), 8 * j + (lane >> 3)));
+                    lrow[j] = a.rows + static_cast<uint64_t>(r) * dim + (lane & 7) * 4;
+                    nx[j] = *reinterpret_cast<const rs_f4*>(lrow[j]);
+                }
                 for (uint32_t ch = 0; ch < dim; ch += 32) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int src = 8 * j + (lane >> 3);
-                        const uint32_t r = static_cast<uint32_t>(__shfl(static_cast<int>(row), src));
-                        const float4 v = *reinterpret_cast<const float4*>(a.rows + static_cast<uint64_t>(r) * dim + ch + (lane & 7) * 4);
-                        *reinterpret_cast<float4*>(stg + src * RS_STAGE_STRIDE + (lane & 7) * 4) = v;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    for (int j = 0; j < 8; ++j)
+                        *reinterpret_cast<rs_f4*>(stg + (8 * j + (lane >> 3)) * RS_STAGE_STRIDE + (lane & 7) * 4) = nx[j];
+                    asm volatile("" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
+                    if (ch + 32 < dim) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) nx[j] = *reinterpret_cast<const rs_f4*>(lrow[j] + ch + 32);
+                    }
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
                         const float4 v = *reinterpret_cast<const float4*>(stg + lane * RS_STAGE_STRIDE + 4 * m);
@@ -559,6 +596,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                             if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
                         }
                     }
+                    asm volatile("" ::: "memory");
                     __builtin_amdgcn_wave_barrier(); // the next chunk overwrites the staging rows
                 }
             }
@@ -639,15 +677,14 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     // bitonic sort (key desc) of rs pairs
     for (int kk = 2; kk <= rs; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < rs; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t x = skey[i], y = skey[ixj];
-                    const bool up = (i & kk) == 0;
-                    if (up ? (x < y) : (x > y)) {
-                        skey[i] = y; skey[ixj] = x;
-                        const uint32_t t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t;
-                    }
+            for (int t = threadIdx.x; t < (rs >> 1); t += blockDim.x) { // pair t = (i, i + j)
+                const int i = 2 * t - (t & (j - 1));
+                const int ixj = i + j;
+                const uint64_t x = skey[i], y = skey[ixj];
+                const bool up = (i & kk) == 0;
+                if (up ? (x < y) : (x > y)) {
+                    skey[i] = y; skey[ixj] = x;
+                    const uint32_t tt = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = tt;
                 }
             }
             __syncthreads();
@@ -1013,8 +1050,9 @@ namespace yams_accel {
 hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
                                uint32_t* qflags) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq), dim3(128), 0, st, q, nq, dim, metric, qprep,
-                       qnorm, qnorm_up, qflags);
+    const bool staged = static_cast<size_t>(dim) * 4 <= 48 * 1024;
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq), dim3(128), staged ? static_cast<size_t>(dim) * 4 : 0, st, q,
+                       nq, dim, metric, qprep, qnorm, qnorm_up, qflags, staged ? 1 : 0);
     LAUNCH_CHECK();
     return hipSuccess;
 }
