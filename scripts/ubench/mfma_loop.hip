@@ -180,7 +180,9 @@ __global__ void fill_bf16(unsigned short* p, unsigned long long n) {
         p[i + j] = static_cast<unsigned short>(__float_as_uint(f) >> 16);
     }
 }
-template <bool BLOCKED>
+// NODMA: after four warm-up slabs (the ring holds random data) no further DMA is issued — what the
+// loop costs with the same operand bits but no data movement.
+template <bool BLOCKED, bool NODMA = false>
 __global__ __launch_bounds__(512, 2) void k67(float* out, int iters, unsigned long long* cyc, const unsigned char* rows,
                                               unsigned long long n_tiles, const unsigned char* qimg) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[131072];
@@ -206,14 +208,16 @@ __global__ __launch_bounds__(512, 2) void k67(float* out, int iters, unsigned lo
     for (int it = 0; it < iters; ++it) {
         const unsigned st = lds0 + (it & 3) * 32768u + wid * 2048u;
         const unsigned char* tb = rows + (tile % n_tiles) * 393216ull;
+        if (!NODMA || it < 4) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned blk = wid * 2 + p;
-            lds_dma16_s(BLOCKED ? tb + blk * 24576u + slab * 1024u : tb + blk * 24576u + slab * 64u, vo_rows, st + p * 1024u);
+            for (int p = 0; p < 2; ++p) {
+                const unsigned blk = wid * 2 + p;
+                lds_dma16_s(BLOCKED ? tb + blk * 24576u + slab * 1024u : tb + blk * 24576u + slab * 64u, vo_rows, st + p * 1024u);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                lds_dma16_s(qimg + qt * 393216u + slab * 16384u + (wid * 2 + p) * 1024u, lane * 16u, st + 16384u + p * 1024u);
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            lds_dma16_s(qimg + qt * 393216u + slab * 16384u + (wid * 2 + p) * 1024u, lane * 16u, st + 16384u + p * 1024u);
         if (++slab == 24) { slab = 0; tile += 64; }
         const unsigned char* rbase = lds + ((it + 2) & 3) * 32768;
 #pragma unroll
@@ -226,7 +230,11 @@ __global__ __launch_bounds__(512, 2) void k67(float* out, int iters, unsigned lo
                 else if (i < 6) fb[s ^ 1][i - 2] = *reinterpret_cast<const bf16x8*>(rbase + offB[i - 2][s ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (s == 0) { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            if (s == 0) {
+                if (NODMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -235,15 +243,15 @@ __global__ __launch_bounds__(512, 2) void k67(float* out, int iters, unsigned lo
     if (sum == 123.456f) out[0] = sum;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <bool BLOCKED> void run67(int iters, const char* tag) {
+template <bool BLOCKED, bool NODMA = false> void run67(int iters, const char* tag, unsigned long long n_tiles = 48000) {
     float* out; unsigned long long* cyc; (void)hipMalloc(&out, 4); (void)hipMalloc(&cyc, 8);
-    const unsigned long long n_tiles = 48000; // 18.9 GB of rows: every tile is a first touch
+    // n_tiles = 48000: 18.9 GB of rows, every tile a first touch; n_tiles = 64: 25 MB, L2 / MALL resident
     unsigned char *rows, *q; (void)hipMalloc(&rows, n_tiles * 393216ull); (void)hipMalloc(&q, 4u * 393216u);
     hipLaunchKernelGGL(fill_bf16, dim3(static_cast<unsigned>(n_tiles * 393216ull / 2 / 8 / 256)), dim3(256), 0, 0, reinterpret_cast<unsigned short*>(rows), n_tiles * 393216ull / 2);
     hipLaunchKernelGGL(fill_bf16, dim3(4u * 393216u / 2 / 8 / 256), dim3(256), 0, 0, reinterpret_cast<unsigned short*>(q), 4ull * 393216u / 2);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k67<BLOCKED>, dim3(256), dim3(512), 0, 0, out, 480, cyc, rows, n_tiles, q); (void)hipDeviceSynchronize();
-    (void)hipEventRecord(e0); hipLaunchKernelGGL(k67<BLOCKED>, dim3(256), dim3(512), 0, 0, out, iters, cyc, rows, n_tiles, q); (void)hipEventRecord(e1);
+    hipLaunchKernelGGL((k67<BLOCKED, NODMA>), dim3(256), dim3(512), 0, 0, out, 480, cyc, rows, n_tiles, q); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); hipLaunchKernelGGL((k67<BLOCKED, NODMA>), dim3(256), dim3(512), 0, 0, out, iters, cyc, rows, n_tiles, q); (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     (void)hipFree(rows); (void)hipFree(q);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -275,10 +283,13 @@ int main() {
     run<4>(100000, "+ 4 contiguous pieces 2MiB", 2ull << 20);
     run<4>(100000, "+ 4 contiguous pieces 64M ", 64ull << 20);
     run<4>(100000, "+ 4 contiguous pieces 24G ", 24ull << 30);
-    run67<false>(17160, "product pattern, row-major rows ");
-    run67<true>(17160, "product pattern, blocked rows   ");
-    run67<false>(17160, "product pattern, row-major rows ");
-    run67<true>(17160, "product pattern, blocked rows   ");
+    run67<false, true>(17160, "product loop, random operands, NO DMA   ");
+    run67<false>(17160, "product pattern, rows L2/MALL-resident  ", 64);
+    run67<false>(17160, "product pattern, rows from HBM          ");
+    run67<true>(17160, "product pattern, blocked rows from HBM  ");
+    run67<false, true>(17160, "product loop, random operands, NO DMA   ");
+    run67<false>(17160, "product pattern, rows L2/MALL-resident  ", 64);
+    run67<false>(17160, "product pattern, rows from HBM          ");
     if (0) run5(100000, "2 DMA + 8 global q-frag loads, 2 MiB ", 2ull << 20);
 
     return 0;
