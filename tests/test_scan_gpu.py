@@ -340,6 +340,17 @@ def _masked(acc, oracle, corpus, queries, k, allowed, metric=SCAN_COSINE, thr=-1
         dr, di = acc.to_device(tie_rank), acc.to_device(inv)
     view = acc.corpus_view(dc.ptr, n, d, dr.ptr if dr else None, di.ptr if di else None, 0, dm.ptr, len(allowed))
     r = acc.scan_topk(view, queries, k, thr, metric)
+    if d % 32 == 0 and n >= 4096:
+        # the same search over a mirror that carries the bf16 shadow (as the plugin's always does):
+        # small batches then take the narrow filter, whose epilogue applies the same mask
+        db, dn = acc.alloc(corpus.size * 2), acc.alloc(n * 4)
+        acc.build_shadow_device(dc.ptr, n, d, db.ptr, dn.ptr)
+        view_s = acc.corpus_view(dc.ptr, n, d, dr.ptr if dr else None, di.ptr if di else None, 0, dm.ptr,
+                                 len(allowed), rows_bf16_ptr=db.ptr, rows_nsq_ptr=dn.ptr)
+        rs = acc.scan_topk(view_s, queries, k, thr, metric)
+        assert np.array_equal(rs.rows, r.rows) and np.array_equal(rs.counts, r.counts)
+        assert np.array_equal(rs.scores.view(np.uint32), r.scores.view(np.uint32))
+        assert rs.diag["path"] == r.diag["path"] and rs.diag["rows_visited"] == r.diag["rows_visited"]
     sub = corpus[allowed]
     sub_rank = None if tie_rank is None else tie_rank[allowed].astype(np.uint64)
     for qi in range(queries.shape[0]):
