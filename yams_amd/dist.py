@@ -32,32 +32,51 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+def _layout(local):
+    """Byte layout of one rank's record: the given tensors back to back, 16-byte aligned."""
+    off, lay = 0, []
+    for name, t in local.items():
+        if t is None:
+            continue
+        nb = t.numel() * t.element_size()
+        lay.append((name, off, nb))
+        off += (nb + 15) & ~15
+    return lay, off
+
+
 def gather_and_merge(local, k: int, merge_fn):
     """local = dict(scores [Q,k] f32, rows [Q,k] i64 (global ids), counts [Q] i32, optional
     dist [Q,k] f32, ranks [Q,k] i32) as torch tensors.  Returns merge_fn(gathered, world) where
-    gathered[name] has shape [world, ...].  With world == 1 no collective is issued."""
+    gathered[name] has shape [world, ...].  With world == 1 no collective is issued; otherwise the
+    tensors are packed into one byte record per rank and ONE all-gather moves them (a few small
+    collectives would each pay the launch + ring latency)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
-    gathered = {}
-    for name, t in local.items():
-        if t is None:
-            gathered[name] = None
-            continue
-        t = t.contiguous()
-        if world == 1:
-            gathered[name] = t.unsqueeze(0)
-        else:
-            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            if dist.get_backend() == "gloo":   # CPU tests / single-GPU dry runs: no flat all-gather
-                src = t.cpu() if t.is_cuda else t
-                parts = [torch.empty_like(src) for _ in range(world)]
-                dist.all_gather(parts, src)
-                out = torch.stack(parts, 0).to(t.device)
-            else:
-                dist.all_gather_into_tensor(out, t)
-            gathered[name] = out
-    if world > 1 and torch.cuda.is_available() and dist.get_backend() != "gloo":
+    gathered = {name: None for name in local}
+    if world == 1:
+        for name, t in local.items():
+            if t is not None:
+                gathered[name] = t.contiguous().unsqueeze(0)
+        return merge_fn(gathered, world)
+    lay, total = _layout(local)
+    dev = next(t.device for t in local.values() if t is not None)
+    rec = torch.empty(total, dtype=torch.uint8, device=dev)
+    for name, off, nb in lay:
+        t = local[name].contiguous()
+        rec[off:off + nb].view(t.dtype).view(t.shape).copy_(t)
+    if dist.get_backend() == "gloo":       # CPU tests / single-GPU dry runs: the collective runs on the host
+        src = rec.cpu()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        out = torch.stack(parts, 0).to(dev)
+    else:
+        out = torch.empty((world, total), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, rec)
+    for name, off, nb in lay:
+        t = local[name]
+        gathered[name] = out[:, off:off + nb].contiguous().view(t.dtype).view((world,) + tuple(t.shape))
+    if torch.cuda.is_available() and dist.get_backend() != "gloo":
         # the merge kernel runs on the accelerator context's stream, which need not be torch's
         # current stream (a context created on the default stream owns a private one): make the
         # gathered tensors visible to it
