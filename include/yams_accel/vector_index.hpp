@@ -97,7 +97,12 @@ public:
             if (last[r.chunk_id] != i) continue;
             auto it = byId_.find(r.chunk_id);
             if (it != byId_.end()) kill(it->second);
+            // rows appended in ascending chunk_id order need no rank table: row order IS the
+            // secondary sort key (the scan's default when no tie ranks are set)
+            if (idOrdered_ && (records_.empty() || r.chunk_id > maxId_)) maxId_ = r.chunk_id;
+            else idOrdered_ = false;
             byId_[r.chunk_id] = records_.size();
+            byDoc_[r.document_hash].push_back(static_cast<uint32_t>(records_.size()));
             records_.push_back(r);
             alive_.push_back(1);
             zeroNorm_.push_back(isZeroNorm(r.embedding) ? 1 : 0);
@@ -120,9 +125,10 @@ public:
         return insertVectorsBatch({r});
     }
     Result<void> deleteVectorsByDocument(const std::string& documentHash) {
-        std::vector<std::string> ids;
-        for (const auto& [id, row] : byId_) if (records_[row].document_hash == documentHash) ids.push_back(id);
-        for (const auto& id : ids) (void)deleteVector(id);
+        auto it = byDoc_.find(documentHash);
+        if (it == byDoc_.end()) return {};
+        for (uint32_t row : it->second)
+            if (alive_[row]) (void)deleteVector(records_[row].chunk_id);
         return {};
     }
     Result<std::optional<VectorRecord>> getVector(const std::string& chunkId) const {
@@ -132,13 +138,13 @@ public:
     }
     Result<std::vector<VectorRecord>> getVectorsByDocument(const std::string& documentHash) const {
         std::vector<VectorRecord> out;
-        for (size_t r = 0; r < records_.size(); ++r)
-            if (alive_[r] && records_[r].document_hash == documentHash) out.push_back(records_[r]);
+        if (auto it = byDoc_.find(documentHash); it != byDoc_.end())
+            for (uint32_t r : it->second) if (alive_[r]) out.push_back(records_[r]);
         return out;
     }
     Result<bool> hasEmbedding(const std::string& documentHash) const {
-        for (size_t r = 0; r < records_.size(); ++r)
-            if (alive_[r] && records_[r].document_hash == documentHash) return true;
+        if (auto it = byDoc_.find(documentHash); it != byDoc_.end())
+            for (uint32_t r : it->second) if (alive_[r]) return true;
         return false;
     }
     Result<size_t> getVectorCount() const { return records_.size() - dead_; }
@@ -173,20 +179,30 @@ public:
         }
         std::vector<uint32_t> mask((records_.size() + 31) / 32, 0u);
         size_t visited = 0, evaluated = 0;
-        for (size_t r = 0; r < records_.size(); ++r) {
-            if (!alive_[r]) continue;
+        // `r` passed the document restriction (the SQL WHERE of :4137-4175)
+        auto consider = [&](size_t r) {
+            if (!alive_[r]) return;
             const auto& rec = records_[r];
-            if (document_hash && rec.document_hash != *document_hash) continue;
-            if (!candidate_hashes.empty() && !candidate_hashes.count(rec.document_hash)) continue;
             ++visited; // rows the reference's statement steps over (:4336-4338)
-            bool match = true;
             for (const auto& [key, value] : metadata_filters) {
                 auto it = rec.metadata.find(key);
-                if (it == rec.metadata.end() || it->second != value) { match = false; break; }
+                if (it == rec.metadata.end() || it->second != value) return;
             }
-            if (!match) continue;
             mask[r >> 5] |= 1u << (r & 31);
             if (!zeroNorm_[r]) ++evaluated; // rows that get a score on the record path (:4365-4371)
+        };
+        // document restrictions go through the document_hash index (the reference's statement is an
+        // indexed lookup too), only a pure metadata filter walks every record
+        auto considerDoc = [&](const std::string& h) {
+            if (auto it = byDoc_.find(h); it != byDoc_.end())
+                for (uint32_t r : it->second) consider(r);
+        };
+        if (document_hash) {
+            if (candidate_hashes.empty() || candidate_hashes.count(*document_hash)) considerDoc(*document_hash);
+        } else if (!candidate_hashes.empty()) {
+            for (const auto& h : candidate_hashes) considerDoc(h);
+        } else {
+            for (size_t r = 0; r < records_.size(); ++r) consider(r);
         }
         if (mask.empty()) mask.push_back(0u);
         const bool recordPath = !metadata_filters.empty();
@@ -245,15 +261,18 @@ private:
             records_.swap(keep); zeroNorm_.swap(zn);
             alive_.assign(records_.size(), 1);
             dead_ = 0;
-            byId_.clear();
-            for (size_t i = 0; i < records_.size(); ++i) byId_[records_[i].chunk_id] = i;
+            byId_.clear(); byDoc_.clear();
+            for (size_t i = 0; i < records_.size(); ++i) {
+                byId_[records_[i].chunk_id] = i;
+                byDoc_[records_[i].document_hash].push_back(static_cast<uint32_t>(i));
+            }
             if (vt_->corpus_clear(vt_->self, corpus_) != YAMS_OK) return Error{ErrorCode::InternalError, "corpus_clear failed"};
             deviceRows_ = 0;
             ranksDirty_ = true;
         }
         const bool appended = records_.size() > deviceRows_;
         if (appended) if (auto u = upload(deviceRows_); !u) return u.error();
-        if ((ranksDirty_ || appended) && !records_.empty()) {
+        if ((ranksDirty_ || appended) && !records_.empty() && !idOrdered_) {
             // secondary sort key = chunk_id string order (:4218-4223); tombstones keep a rank too
             const size_t n = records_.size();
             std::vector<uint32_t> order(n), rank(n);
@@ -332,6 +351,9 @@ private:
     std::vector<uint8_t> alive_, zeroNorm_;
     size_t dead_ = 0, deviceRows_ = 0;
     std::unordered_map<std::string, size_t> byId_;
+    std::unordered_map<std::string, std::vector<uint32_t>> byDoc_; // document_hash -> rows (incl. tombstones)
+    bool idOrdered_ = true;   // every row was appended with a chunk_id above all earlier ones
+    std::string maxId_;
 };
 
 inline Result<std::unique_ptr<AccelVectorIndex>> createAccelVectorIndex(std::shared_ptr<accel::Plugin> plugin, size_t dim,

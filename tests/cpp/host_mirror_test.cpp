@@ -309,6 +309,65 @@ int main(int argc, char** argv) {
         CHECK(again.has_value() && again.value().size() == 1 && again.value()[0].chunk_id == "c4");
         CHECK(table.deleteVector("b8").has_value() && !table.deleteVector("b8").has_value());
     }
+    {   // document restrictions over a larger mirror: the document_hash index must select exactly
+        // the rows a second index holding ONLY those rows would score; ids arrive in ascending
+        // order (no rank table is uploaded: row order is the tie order) until one does not
+        const int N = 6000, DOCS = 40;
+        auto a = vector::createAccelVectorIndex(plugin, 32), b = vector::createAccelVectorIndex(plugin, 32);
+        auto &all = *a.value(), &only = *b.value();
+        CHECK(all.initialize().has_value() && only.initialize().has_value());
+        uint32_t x = 12345u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return static_cast<float>((x >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        std::vector<vector::VectorRecord> recs, sub;
+        const std::unordered_set<std::string> want = {"doc_3", "doc_17", "doc_39", "doc_none"};
+        char id[32];
+        for (int i = 0; i < N; ++i) {
+            vector::VectorRecord r;
+            std::snprintf(id, sizeof id, "chunk_%06d", i);
+            r.chunk_id = id; r.document_hash = "doc_" + std::to_string(i % DOCS);
+            r.embedding.resize(32);
+            for (auto& v : r.embedding) v = rnd();
+            if (i % 500 == 7) r.embedding = recs[i - 7].embedding;        // exact ties, broken by chunk_id
+            recs.push_back(r);
+            if (want.count(r.document_hash)) sub.push_back(r);
+        }
+        CHECK(all.insertVectorsBatch(recs).has_value() && only.insertVectorsBatch(sub).has_value());
+        auto same = [&](const std::vector<vector::VectorRecord>& p, const std::vector<vector::VectorRecord>& q) {
+            if (p.size() != q.size()) return false;
+            for (size_t i = 0; i < p.size(); ++i)
+                if (p[i].chunk_id != q[i].chunk_id || p[i].relevance_score != q[i].relevance_score) return false;
+            return true;
+        };
+        for (int t = 0; t < 3; ++t) {
+            std::vector<float> qv(32);
+            for (auto& v : qv) v = rnd();
+            if (t == 2) qv = recs[500].embedding;                         // a query sitting on a tie pair
+            vector::VectorSearchDiagnostics d1, d2;
+            auto f = all.searchSimilar(qv, 25, -1.0f, std::nullopt, want, {}, &d1);
+            auto g = only.searchSimilar(qv, 25, -1.0f, &d2);
+            CHECK(f.has_value() && g.has_value() && same(f.value(), g.value()));
+            CHECK(d1.rowsVisited == sub.size() && d1.exactDistanceEvaluations == sub.size() && d2.rowsVisited == sub.size());
+            auto one = all.searchSimilar(qv, 10, -1.0f, std::optional<std::string>("doc_17"), want);
+            CHECK(one.has_value() && one.value().size() == 10);
+            if (one) for (const auto& r : one.value()) CHECK(r.document_hash == "doc_17");
+            auto excl = all.searchSimilar(qv, 10, -1.0f, std::optional<std::string>("doc_5"), want); // doc_5 not a candidate
+            CHECK(excl.has_value() && excl.value().empty());
+        }
+        auto ties = all.searchSimilar(recs[500].embedding, 2, -1.0f);
+        CHECK(ties.has_value() && ties.value().size() == 2 && ties.value()[0].chunk_id == "chunk_000500" && ties.value()[1].chunk_id == "chunk_000507");
+        // an id below the current maximum ends the append-order shortcut: ranks are uploaded and the
+        // new row sorts in front of its twins
+        vector::VectorRecord early = recs[500];
+        early.chunk_id = "chunk_000000_b"; early.document_hash = "doc_17";
+        CHECK(all.insertVector(early).has_value());
+        auto ties2 = all.searchSimilar(recs[500].embedding, 3, -1.0f);
+        CHECK(ties2.has_value() && ties2.value().size() == 3 && ties2.value()[0].chunk_id == "chunk_000000_b" &&
+              ties2.value()[1].chunk_id == "chunk_000500");
+        CHECK(all.deleteVectorsByDocument("doc_17").has_value() && !all.hasEmbedding("doc_17").value());
+        CHECK(all.getVectorsByDocument("doc_3").value().size() == static_cast<size_t>(N / DOCS));
+        auto gone = all.searchSimilar(recs[17].embedding, 5, -1.0f, std::optional<std::string>("doc_17"), {});
+        CHECK(gone.has_value() && gone.value().empty());
+    }
     {   // large finite scores (+-FLT_MAX/4) stay finite
         const float L = std::numeric_limits<float>::max() / 4.0f;
         auto idxR = vector::createAccelVectorIndex(plugin, 4);
