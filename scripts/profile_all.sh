@@ -20,3 +20,7 @@ S="python $REPO/scripts/small_batch.py"
 rm -rf $OUT/prof_small $OUT/prof_small_pmc
 (cd /tmp && QS=64 FORMS=default timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_small -o small -- $S > $OUT/small_batch_prof.jsonl 2> $OUT/prof_small.log) || true
 (cd /tmp && QS=64 FORMS=default timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_small_pmc -o small -- $S > /dev/null 2> $OUT/prof_small_pmc.log) || true
+# ingest: VALU issue counters of the SHA-256 / CDC kernels (their roofline is integer VALU throughput), and HBM reads
+rm -rf $OUT/prof_ingest_pmc1 $OUT/prof_ingest_pmc2
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -f csv -d $OUT/prof_ingest_pmc1 -o ingest -- $I > $OUT/prof_ingest_pmc1.log 2>&1) || true
+(cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_ingest_pmc2 -o ingest -- $I > $OUT/prof_ingest_pmc2.log 2>&1) || true

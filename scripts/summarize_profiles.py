@@ -42,6 +42,36 @@ if os.path.exists(f):
         json.dump(out, open(os.path.join(P, f"{tag}_small_batch_pmc.json"), "w"), indent=1)
         print(out)
 
+ipmc = {}
+for d in ("prof_ingest_pmc1", "prof_ingest_pmc2"):
+    f = os.path.join(G, d, "ingest_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        ipmc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if ipmc:
+    isum = {}
+    for k_, cs in ipmc.items():
+        e = {c: sum(v) / len(v) for c, v in cs.items()}
+        e["launches"] = max(len(v) for v in cs.values())
+        if "SQ_INSTS_VALU" in e and "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"] > 0:
+            # a wave64 VALU instruction holds its SIMD's 16-lane ALU for 4 cycles; 1024 SIMDs; GRBM summed over 8 XCDs
+            e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * 4.0 / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if "FETCH_SIZE" in e:
+            e["hbm_read_bytes"] = 2.0 * e["FETCH_SIZE"] * 1024.0
+        isum[k_] = e
+    json.dump({"meta": {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python scripts/ingest_bench.py --gib 100 --reps 2",
+                        "notes": ["valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (kernel cycles x 1024 SIMDs): the share of the "
+                                  "chip's integer VALU issue slots the kernel used while it ran (concurrent kernels share them)",
+                                  "FETCH_SIZE in KiB; hbm_read_bytes applies the x2 gfx950 correction, which is calibrated for wide "
+                                  "coalesced streams (cdc_candidates_w48: 108 GB for 107 GB of blobs) and over-counts the "
+                                  "lane-per-message 16-byte loads of sha256_batch_kernel (198 GB reported for 107 GB read)",
+                                  "kernels are serialised under counter collection; in the product the blob-digest kernel "
+                                  "runs beside CDC + chunk hashing on a second stream"]},
+               "kernels": isum}, open(os.path.join(P, f"{tag}_ingest_pmc.json"), "w"), indent=1)
+    print("wrote", os.path.join(P, f"{tag}_ingest_pmc.json"))
+
 pmc = {}
 for d in ("prof_pmc1", "prof_pmc2", "prof_pmc3"):
     f = os.path.join(G, d, "scan_counter_collection.csv")
