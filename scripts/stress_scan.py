@@ -1,0 +1,83 @@
+"""Randomised self-consistency stress of the scan paths on the GPU (no CPU oracle in the loop, so it
+covers far more shapes per second than the parity tests): for random (rows, dim, batch, k, metric,
+threshold, allow-mask) the default path — narrow filter for small batches, 256-query tile above —
+must return bit-identical rows / scores / counts to the exhaustive fp64 path
+(YAMS_SCAN_FLAG_FORCE_EXACT), which shares no filter code with it, and to the wide form
+(YAMS_ACCEL_BF16_KERNEL=3).  Prints one summary line; exit code 1 on any mismatch.
+
+    python scripts/stress_scan.py [--cases 60] [--seed 1]
+"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from yams_amd.accel import Accel
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+acc = Accel(0, torch.cuda.current_stream().cuda_stream)
+bad, done, paths = [], 0, {}
+for case in range(a.cases):
+    d = int(rng.choice([64, 96, 128, 160, 256, 384, 768, 1024]))
+    n = int(rng.integers(4096, 120_000 if d <= 256 else 40_000))
+    nq = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200]))
+    k = int(rng.choice([1, 5, 10, 50, 100, 200]))
+    metric = SCAN_L2 if rng.random() < 0.3 else SCAN_COSINE
+    thr = float(rng.choice([-1.0, 0.0, 0.1])) if metric == SCAN_COSINE else -1.0
+    tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 0, n, d, tc.data_ptr())
+    tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 1 << 40, nq, d, tq.data_ptr())
+    if rng.random() < 0.5:      # clustered: a few hundred near-copies of query 0 -> crowded top
+        m = int(rng.integers(50, 600))
+        idx = torch.from_numpy(rng.choice(n, m, replace=False)).cuda()
+        tc[idx] = tq[0] * float(rng.uniform(0.5, 2.0)) + 1e-3 * torch.randn((m, d), device="cuda")
+    if rng.random() < 0.3:
+        tc[int(rng.integers(0, n))] = 0.0
+    if rng.random() < 0.3:
+        tc[n - 1] *= 1e17
+    tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
+    acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
+    mask_t, mask_n = None, 0
+    if rng.random() < 0.35:
+        keep = rng.random(n) < float(rng.uniform(0.3, 0.95))
+        bits = np.zeros((n + 31) // 32 * 32, np.uint8); bits[:n] = keep
+        words = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+        mask_t = torch.from_numpy(words.view(np.int32)).cuda(); mask_n = int(keep.sum())
+    view = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
+                           rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
+    out = {}
+    for form in ("default", "wide", "exact"):
+        s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        if form == "wide":
+            os.environ["YAMS_ACCEL_BF16_KERNEL"] = "3"
+        else:
+            os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)
+        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
+                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else 0)
+        torch.cuda.synchronize()
+        cn = c.cpu().numpy()
+        sel = np.arange(k)[None, :] < cn[:, None]        # only the returned prefix is defined
+        out[form] = (cn, np.where(sel, r.cpu().numpy(), -1), np.where(sel, s.cpu().numpy().view(np.uint32), 0),
+                     np.where(sel, dist.cpu().numpy().view(np.uint32), 0) if metric == SCAN_L2 else None, diag)
+    os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)
+    ref = out["exact"]
+    for form in ("default", "wide"):
+        o = out[form]
+        ok = (o[0] == ref[0]).all() and (o[1] == ref[1]).all() and (o[2] == ref[2]).all()
+        if metric == SCAN_L2:
+            ok = ok and (o[3] == ref[3]).all()
+        if not ok:
+            bad.append({"case": case, "form": form, "n": n, "d": d, "nq": nq, "k": k, "metric": int(metric), "thr": thr,
+                        "mask": mask_n, "diag": {kk: int(v) for kk, v in o[4].items()}})
+    dg = out["default"][4]
+    key = f"path{dg['path']}/widened{int(dg['widened_queries'] > 0)}/escalated{int(dg['escalated_queries'] > 0)}/fallback{int(dg['exact_fallback_queries'] > 0)}"
+    paths[key] = paths.get(key, 0) + 1
+    done += 1
+    del tc, tq, tb, tn
+print(json.dumps({"cases": done, "mismatches": len(bad), "paths": paths, "first_bad": bad[:3]}))
+sys.exit(1 if bad else 0)

@@ -664,3 +664,19 @@ def test_clustered_corpus_stays_exact(acc, oracle):
     assert r.diag["widened_queries"] >= 6 and r.diag["escalated_queries"] == 6 and r.diag["exact_fallback_queries"] == 6, r.diag
     # L2: the random row scales spread the distances, the filter separates them easily
     check(acc, oracle, corpus, q, 100, metric=SCAN_L2, tie_rank=rank, expect_path=0)
+
+
+def test_randomised_self_consistency_of_all_scan_paths():
+    """scripts/stress_scan.py: 150 random shapes (rows, dim, batch 1..200, k, metric, threshold,
+    allow-mask, clustered tops, zero / huge rows); the default path (narrow or 256-query filter,
+    widening, escalation, fallback) must equal the exhaustive fp64 path and the wide form bit for
+    bit.  (1680 further cases were run by hand with seeds 1-5: no mismatch.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_scan.py"), "--cases", "150", "--seed", "7"],
+                       capture_output=True, text=True, timeout=280)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res["cases"] == 150 and res["mismatches"] == 0, res
+    assert any("widened1" in p for p in res["paths"]) and any(p.startswith("path1") for p in res["paths"]), res
