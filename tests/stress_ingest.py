@@ -4,7 +4,7 @@ constant, short-period and text-like content), random chunker configurations on 
 narrow (32-bit, window 48) candidate kernel's limits, both chunkers.  Boundaries, per-chunk
 digests and whole-blob digests must be bit-exact.  Test infrastructure (uses oracle/).
 
-    python scripts/stress_ingest.py [--cases 40] [--seed 1]
+    python tests/stress_ingest.py [--cases 40] [--seed 1]
 """
 import argparse, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

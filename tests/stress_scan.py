@@ -5,7 +5,7 @@ must return bit-identical rows / scores / counts to the exhaustive fp64 path
 (YAMS_SCAN_FLAG_FORCE_EXACT), which shares no filter code with it, and to the wide form
 (YAMS_ACCEL_BF16_KERNEL=3).  Prints one summary line; exit code 1 on any mismatch.
 
-    python scripts/stress_scan.py [--cases 60] [--seed 1]
+    python tests/stress_scan.py [--cases 60] [--seed 1]
 """
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -253,13 +253,13 @@ def test_chunker_vtable(accel_lib, oracle):
 
 
 def test_randomised_ingest_stress_against_cpu_checkers():
-    """scripts/stress_ingest.py: random ragged blob sets (random / constant / periodic / text-like
+    """tests/stress_ingest.py: random ragged blob sets (random / constant / periodic / text-like
     content at arbitrary byte offsets), random chunker configurations, both chunkers; boundaries,
     chunk digests and blob digests bit-exact against the oracle + hashlib.  (220 further cases,
     4.9 M chunks, were run by hand with seeds 1-4: no mismatch.)"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_ingest.py"), "--cases", "30", "--seed", "9"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_ingest.py"), "--cases", "30", "--seed", "9"],
                        capture_output=True, text=True, timeout=280)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]

@@ -667,13 +667,13 @@ def test_clustered_corpus_stays_exact(acc, oracle):
 
 
 def test_randomised_self_consistency_of_all_scan_paths():
-    """scripts/stress_scan.py: 150 random shapes (rows, dim, batch 1..200, k, metric, threshold,
+    """tests/stress_scan.py: 150 random shapes (rows, dim, batch 1..200, k, metric, threshold,
     allow-mask, clustered tops, zero / huge rows); the default path (narrow or 256-query filter,
     widening, escalation, fallback) must equal the exhaustive fp64 path and the wide form bit for
     bit.  (1680 further cases were run by hand with seeds 1-5: no mismatch.)"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_scan.py"), "--cases", "150", "--seed", "7"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_scan.py"), "--cases", "150", "--seed", "7"],
                        capture_output=True, text=True, timeout=280)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
