@@ -328,12 +328,14 @@ def main():
            "roofline": roofline}
     if merge_ok is not None:
         out["merged_topk_consistent"] = merge_ok
-    if not a.no_cpu_baseline:
+    # CPU baseline and the ingest leg: rank 0 at N = 1 only (at N > 1 the other ranks would sit in the
+    # final barrier for their ~25 s; the merged result is checked by `merged_topk_consistent` there)
+    if not a.no_cpu_baseline and world == 1:
         cb, recall, exact = cpu_baseline_scan(acc, tc, tq, n, d, k)
         out["cpu_baseline"] = cb
         out["recall_at_k"] = recall
         out["bit_exact_vs_oracle_sample"] = exact
-    if not a.no_ingest:
+    if not a.no_ingest and world == 1:
         del tc
         acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg
         acc.ctx = None
