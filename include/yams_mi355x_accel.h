@@ -182,7 +182,8 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, 
                                                            uint16_t* out_rows_bf16,
                                                            float* out_rows_nsq);
 
-/* Batched exact top-k, everything device-resident.
+/* Batched exact top-k, everything device-resident.  Any batch size: more than 4096 queries run as
+ * slices of 4096 (the per-batch workspace grows with the query count); diagnostics are summed.
  *   queries      device [n_queries][dim] fp32 (raw)
  *   out_scores   device [n_queries][k] fp32: cosine similarity (relevance_score, :4323-4326),
  *                best first; unused slots hold -inf

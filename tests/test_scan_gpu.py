@@ -666,6 +666,25 @@ def test_clustered_corpus_stays_exact(acc, oracle):
     check(acc, oracle, corpus, q, 100, metric=SCAN_L2, tie_rank=rank, expect_path=0)
 
 
+def test_batches_above_4096_queries_run_as_slices(acc, oracle):
+    """yams_scan_topk_device slices batches of more than 4096 queries; results, counts and the
+    summed diagnostics are those of one batch; an invalid query anywhere still fails the call."""
+    n, d, k = 9000, 64, 7
+    corpus = oracle.synth_rows(31, 0, n, d)
+    q = oracle.synth_rows(31, 1 << 40, 4096 + 333, d)
+    r = run(acc, corpus, q, k)
+    assert r.diag["rows_visited"] == q.shape[0] * n and r.diag["returned_rows"] == q.shape[0] * k
+    for qi in (0, 4095, 4096, 4097, q.shape[0] - 1):
+        rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, -1.0)
+        assert np.array_equal(r.rows[qi], rows) and np.array_equal(r.scores[qi].view(np.uint32), sims.view(np.uint32))
+    a = run(acc, corpus, q[4000:4200], k)          # the same queries inside one slice
+    assert np.array_equal(a.rows, r.rows[4000:4200]) and np.array_equal(a.scores.view(np.uint32), r.scores[4000:4200].view(np.uint32))
+    q[4200] = 0.0
+    with pytest.raises(_lib.AccelError) as e:
+        run(acc, corpus, q, k)
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+
+
 def test_randomised_self_consistency_of_all_scan_paths():
     """tests/stress_scan.py: 150 random shapes (rows, dim, batch 1..200, k, metric, threshold,
     allow-mask, clustered tops, zero / huge rows); the default path (narrow or 256-query filter,

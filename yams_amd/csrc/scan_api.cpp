@@ -422,8 +422,37 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
                                                int64_t* out_rows, uint32_t* out_counts,
                                                float* out_dist, uint32_t* out_ranks,
                                                yams_scan_diag_t* diag) {
-    return scan_impl(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts,
-                     out_dist, out_ranks, diag, false);
+    // Very large batches run as slices: the per-batch workspace (sample scores, candidate lists)
+    // grows with the query count, and one corpus pass already amortises over 4096 queries.
+    constexpr uint32_t kBatchMax = 4096;
+    if (n_queries <= kBatchMax || !ctx || !corpus || !params || !queries)
+        return scan_impl(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts,
+                         out_dist, out_ranks, diag, false);
+    yams_scan_diag_t total{};
+    const size_t k = params->k, dim = corpus->dim;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += kBatchMax) {
+        const uint32_t nq = std::min(kBatchMax, n_queries - q0);
+        yams_scan_diag_t d{};
+        const yams_status_t s = scan_impl(ctx, corpus, queries + static_cast<size_t>(q0) * dim, nq, params,
+                                          out_scores ? out_scores + q0 * k : nullptr,
+                                          out_rows ? out_rows + q0 * k : nullptr,
+                                          out_counts ? out_counts + q0 : nullptr,
+                                          out_dist ? out_dist + q0 * k : nullptr,
+                                          out_ranks ? out_ranks + q0 * k : nullptr, diag ? &d : nullptr, false);
+        if (s != YAMS_OK) return s; // a batch fails as a whole (:1635-1647)
+        total.used_exact_scan = 1; total.rows_visited_observed = 1;
+        total.rows_visited += d.rows_visited;
+        total.exact_distance_evaluations += d.exact_distance_evaluations;
+        total.returned_rows += d.returned_rows;
+        total.filter_candidates += d.filter_candidates;
+        total.rescored_rows += d.rescored_rows;
+        total.widened_queries += d.widened_queries;
+        total.exact_fallback_queries += d.exact_fallback_queries;
+        total.escalated_queries += d.escalated_queries;
+        total.path = std::max(total.path, d.path);
+    }
+    if (diag) *diag = total;
+    return YAMS_OK;
 }
 
 extern "C" yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, const float* rows,
