@@ -1047,8 +1047,10 @@ __global__ __launch_bounds__(BT_THREADS, 2) void scan_tiles_bf16p_kernel(ScanArg
 // (4.5 TB/s).  Here a workgroup still owns 256 rows, but only 32 NQB query columns: a wave
 // multiplies ITS OWN 32 rows (staged by itself, two 1 KiB DMA pieces per 32-wide k-slab — no other
 // wave reads them) against the query slab the workgroup shares (2 NQB pieces, one per wave for the
-// first 2 NQB waves).  4 NQB MFMAs per wave per slab leave the matrix pipe mostly idle; what
-// matters is bytes in flight: a 3-stage ring of 20 / 24 KiB per workgroup, TWO workgroups per CU
+// first 2 NQB waves).  4 NQB MFMAs per wave per slab leave the matrix pipe mostly idle.
+// (The non-temporal policy on the row pieces, `global_load_lds_dwordx4 ... nt`, was measured:
+// 4.5 ms instead of 3.1 — the default policy stays.)
+// What matters is bytes in flight: a 3-stage ring of 20 / 24 KiB per workgroup, TWO workgroups per CU
 // (<= 128 VGPRs), i.e. 4 row slabs = 64 KiB of HBM reads in flight per CU at all times, and one
 // workgroup's prologue / epilogue overlaps the other's stream.  Measured on a 12.5M x 768 shard:
 // 3.10 ms (6.1 TB/s, 0.76 of the HBM peak) up to 64 queries, 3.39 ms at 128, against 4.1-4.5 ms of
