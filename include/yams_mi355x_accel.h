@@ -166,7 +166,7 @@ typedef struct yams_scan_diag_s {
     uint64_t rows_visited;                /* per query: n_rows (summed over the batch)           */
     uint64_t exact_distance_evaluations;  /* per query: n_rows (summed over the batch)           */
     uint64_t returned_rows;
-    uint64_t filter_candidates;           /* rows that passed the fp32 MFMA filter               */
+    uint64_t filter_candidates;           /* rows that passed the MFMA filter (any tier)           */
     uint64_t rescored_rows;               /* rows re-scored in fp64                              */
     uint32_t widened_queries;             /* queries whose candidate set had to be widened       */
     uint32_t exact_fallback_queries;      /* queries that took the full fp64 scan                */
