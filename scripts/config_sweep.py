@@ -10,9 +10,12 @@ from yams_amd._lib import SCAN_COSINE, SCAN_L2
 
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 rows = []
+only = os.environ.get("ONLY")   # e.g. ONLY=C2
 for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2", 1_000_000, 384, 256, 100, SCAN_COSINE),
                                   ("C3", 10_000_000, 768, 1024, 100, SCAN_L2), ("C4/8 Q=64", 12_500_000, 768, 64, 100, SCAN_COSINE),
                                   ("C4/8 Q=256", 12_500_000, 768, 256, 100, SCAN_COSINE), ("C4/8 Q=1024", 12_500_000, 768, 1024, 100, SCAN_COSINE)]:
+    if only and not name.startswith(only):
+        continue
     tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 0, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 1 << 40, nq, d, tq.data_ptr())
     s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
