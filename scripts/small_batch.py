@@ -9,7 +9,7 @@ import torch
 from yams_amd.accel import Accel
 from yams_amd._lib import SCAN_COSINE
 
-n, d, k = int(os.environ.get("ROWS", 12_500_000)), 768, 100
+n, d, k = int(os.environ.get("ROWS", 12_500_000)), int(os.environ.get("DIM", 768)), 100
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 0, n, d, tc.data_ptr())
 tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
