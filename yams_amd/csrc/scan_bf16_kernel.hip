@@ -34,11 +34,17 @@ constexpr int BT_ROWS = 256, BT_QUERIES = 256, BT_THREADS = 512;
 // PRENORM: the A operand was the unit-normalised shadow row, so a cosine score needs no scaling
 // (rows whose norm is out of range still turn into NaN = "always a candidate"); L2 scales the dot
 // back by the row norm.
-template <int MODE, int METRIC, int ABL, int NCB, bool PRENORM = false>
+// PHASE (FILTER mode): 0 = everything; 1 = up to the list reservations (survivor masks and reserved
+// positions are returned in pend_pass / pend_base); 2 = only the stores of a call that ran phase 1.
+// A wave that holds several row blocks runs phase 1 for all of them before the first phase 2, so
+// their reservation round trips overlap.
+template <int MODE, int METRIC, int ABL, int NCB, bool PRENORM = false, int PHASE = 0>
 __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[NCB], float nfull,
                                               uint64_t row0, uint32_t row_in_tile, uint32_t q0,
                                               uint32_t sel, int h, int l31,
-                                              const float* tau_pre = nullptr /* [NCB], preloaded */) {
+                                              const float* tau_pre = nullptr /* [NCB], preloaded */,
+                                              uint32_t* pend_pass = nullptr, uint32_t* pend_base = nullptr) {
+    static_assert(PHASE == 0 || MODE == MODE_FILTER, "phases exist for the filter epilogue only");
     if (ABL != 0) { // measurement builds: keep the accumulators alive, emit nothing
         float t = 0.f;
 #pragma unroll
@@ -60,7 +66,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
     }
     const bool ok = norm_in_range(nfull);
     const bool any_bad = __builtin_amdgcn_ballot_w64(!ok) != 0; // wave-uniform
-    if (!(PRENORM && METRIC == YAMS_SCAN_COSINE) || any_bad) {
+    if (PHASE != 2 && (!(PRENORM && METRIC == YAMS_SCAN_COSINE) || any_bad)) {
         float p0, p1 = 0.f, ps = 1.f;
         if (METRIC == YAMS_SCAN_COSINE) {
             p0 = ok ? (PRENORM ? 1.f : rsqrtf(nfull)) : __builtin_nanf("");
@@ -91,7 +97,7 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
     }
 
     const uint64_t wave_row0 = row0 + row_in_tile;
-    if (a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
+    if (PHASE != 2 && a.row_mask) { // rows outside the allow-mask never score (they are not part of the scan)
         const uint32_t mw = mask_word(a.row_mask, wave_row0, a.n_rows);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -129,37 +135,64 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
             }
         }
     } else {
-        float tau[NCB];
+        uint32_t pass[NCB], base[NCB];
+        if (PHASE == 2) {
 #pragma unroll
-        for (int u = 0; u < NCB; ++u)
-            tau[u] = tau_pre ? tau_pre[u] : ((qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff());
-        // cheap reject: the maximum of a lane's 16 scores per query block (v_max3 tree); a NaN score
-        // (ignored by max) can only come from a row flagged above, which forces the full scan
-        uint32_t hot = 0;
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) {
-            float m = acc[u][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
-            if (!(m < tau[u]) || any_bad) hot |= 1u << u;
-        }
-        if (hot) {
+            for (int u = 0; u < NCB; ++u) { pass[u] = pend_pass[u]; base[u] = pend_base[u]; }
+        } else {
+            float tau[NCB];
 #pragma unroll
             for (int u = 0; u < NCB; ++u)
+                tau[u] = tau_pre ? tau_pre[u] : ((qok[u] && ABL == 0) ? a.tau[qidx[u]] : __builtin_inff());
+            // cheap reject: the maximum of a lane's 16 scores per query block (v_max3 tree); a NaN score
+            // (ignored by max) can only come from a row flagged above, which forces the full scan
+            uint32_t hot = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (!((hot >> u) & 1u)) continue;
-                    const float sc = acc[u][r];
-                    if (!(sc < tau[u])) {
+            for (int u = 0; u < NCB; ++u) {
+                float m = acc[u][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+                if (!(m < tau[u]) || any_bad) hot |= 1u << u;
+            }
+            // A lane reserves room for ALL its survivors of a query block with one atomic, and the
+            // reservations of its NCB blocks are issued back to back before the first one is
+            // needed: one memory round trip per call instead of one per survivor.  (Small corpora
+            // have the same ~1000 survivors per query spread over far fewer tiles: with one
+            // round trip per survivor the epilogue was 2/3 of a 1M-row scan.)
+#pragma unroll
+            for (int u = 0; u < NCB; ++u) {
+                pass[u] = 0u;
+                if (((hot >> u) & 1u) && qok[u]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
                         const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < a.n_rows && qok[u]) {
-                            const uint32_t pos = atomicAdd(&a.list_count[qidx[u]], 1u);
-                            if (pos < a.list_cap)
-                                a.list[static_cast<uint64_t>(qidx[u]) * a.list_cap + pos] =
-                                    pack_key(sc, static_cast<uint32_t>(row));
-                        }
+                        if (!(acc[u][r] < tau[u]) && row < a.n_rows) pass[u] |= 1u << r;
                     }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < NCB; ++u) {
+                base[u] = 0u;
+                if (pass[u]) base[u] = atomicAdd(&a.list_count[qidx[u]], static_cast<uint32_t>(__builtin_popcount(pass[u])));
+            }
+            if (PHASE == 1) {
+#pragma unroll
+                for (int u = 0; u < NCB; ++u) { pend_pass[u] = pass[u]; pend_base[u] = base[u]; }
+                return;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) {
+            if (!pass[u]) continue;
+            uint32_t pos = base[u];
+            uint64_t* lst = a.list + static_cast<uint64_t>(qidx[u]) * a.list_cap;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!((pass[u] >> r) & 1u)) continue;
+                const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (pos < a.list_cap) lst[pos] = pack_key(acc[u][r], static_cast<uint32_t>(row));
+                ++pos;
+            }
         }
     }
 }
@@ -817,11 +850,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
         __builtin_amdgcn_sched_barrier(0);
         step(f1, f0, lds, 0, false, -1, 0);
     }
+    if constexpr (MODE == MODE_FILTER && ABL == 0 && METRIC == YAMS_SCAN_COSINE) {
+        // reservations of all row blocks first, then their stores (overlapping round trips); the L2
+        // epilogue has no registers to spare for the pending masks and keeps one round trip per block
+        uint32_t ppass[RB][4], pbase[RB][4];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const uint32_t rit = static_cast<uint32_t>(wr * (32 * RB) + rb * 32);
-        bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull_pre[rb], row0, rit, q0 + wc * 128, sel, h, l31,
-                                                  MODE == MODE_FILTER ? tau_pre : nullptr);
+        for (int rb = 0; rb < RB; ++rb)
+            bf16_epilogue<MODE, METRIC, ABL, 4, true, 1>(a, acc[rb], nfull_pre[rb], row0, static_cast<uint32_t>(wr * (32 * RB) + rb * 32),
+                                                         q0 + wc * 128, sel, h, l31, tau_pre, ppass[rb], pbase[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            bf16_epilogue<MODE, METRIC, ABL, 4, true, 2>(a, acc[rb], nfull_pre[rb], row0, static_cast<uint32_t>(wr * (32 * RB) + rb * 32),
+                                                         q0 + wc * 128, sel, h, l31, tau_pre, ppass[rb], pbase[rb]);
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const uint32_t rit = static_cast<uint32_t>(wr * (32 * RB) + rb * 32);
+            bf16_epilogue<MODE, METRIC, ABL, 4, true>(a, acc[rb], nfull_pre[rb], row0, rit, q0 + wc * 128, sel, h, l31,
+                                                      MODE == MODE_FILTER ? tau_pre : nullptr);
+        }
     }
 }
 
