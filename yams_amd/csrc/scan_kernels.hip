@@ -236,24 +236,42 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) any |= !(acc[t][u][r] < tau[u]);
         if (any) {
+            // one list reservation per (lane, query block) for all 32 rows of the two row blocks,
+            // both reservations issued before the first is needed (see bf16_epilogue)
+            uint32_t pass[2], base[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int u = 0; u < 2; ++u) {
+                pass[u] = 0u;
+                if (qok[u]) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint64_t row = wave_row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (!(acc[t][u][r] < tau[u]) && row < a.n_rows) pass[u] |= 1u << (t * 16 + r);
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                base[u] = 0u;
+                if (pass[u]) base[u] = atomicAdd(&a.list_count[qidx[u]], static_cast<uint32_t>(__builtin_popcount(pass[u])));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!pass[u]) continue;
+                uint32_t pos = base[u];
+                uint64_t* lst = a.list + static_cast<uint64_t>(qidx[u]) * a.list_cap;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float s = acc[t][u][r];
-                        if (!(s < tau[u])) {
-                            const uint64_t row =
-                                wave_row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if (row < a.n_rows && qok[u]) {
-                                const uint32_t pos = atomicAdd(&a.list_count[qidx[u]], 1u);
-                                if (pos < a.list_cap)
-                                    a.list[static_cast<uint64_t>(qidx[u]) * a.list_cap + pos] =
-                                        pack_key(s, static_cast<uint32_t>(row));
-                            }
-                        }
+                        if (!((pass[u] >> (t * 16 + r)) & 1u)) continue;
+                        const uint64_t row = wave_row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (pos < a.list_cap) lst[pos] = pack_key(acc[t][u][r], static_cast<uint32_t>(row));
+                        ++pos;
                     }
+            }
         }
     }
 }
