@@ -148,6 +148,9 @@ typedef struct yams_scan_corpus_s {
                                              norm^2 < 1e-10 (isZeroNormEmbedding, :204-211) instead of
                                              <= 1e-12 (:4267-4269).  The caller turns the metadata
                                              predicate into the row allow-mask.                  */
+#define YAMS_SCAN_FLAG_WIDE_TILE 32u      /* keep the 256-query MFMA tile for batches of <= 128
+                                             queries (default: the narrow, HBM-bound kernel form);
+                                             results are identical, only the kernel form differs  */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {
@@ -279,8 +282,12 @@ typedef struct yams_cdc_config_s {
     uint64_t polynomial;
     uint64_t mask;
     uint32_t mode;        /* yams_cdc_mode_t */
-    uint32_t reserved;
+    uint32_t flags;       /* YAMS_CDC_FLAG_*; 0 = defaults */
 } yams_cdc_config_t;
+/* Boundary detection has two kernel forms with identical results: a narrow one for window 48 and
+ * masks below 2^31 (the product defaults) and a generic one (any window 1..48, any 64-bit mask).
+ * This flag selects the generic form even where the narrow one applies (parity tests use it). */
+#define YAMS_CDC_FLAG_GENERIC_KERNEL 1u
 
 YAMS_ACCEL_API void yams_cdc_default_config(yams_cdc_config_t* cfg, uint32_t mode);
 

@@ -1,7 +1,9 @@
 """Filter-kernel ablations (measurement only): times the FILTER launch alone under
 YAMS_ACCEL_BF16_KERNEL = 2 (product), 11 (no refills), 12 (no MFMA), 13 (no refills, no MFMA),
-14 (no refills, no fragment reads)."""
+14 (no refills, no fragment reads).  Needs the measurement build of the library
+(`python -m yams_amd.build --measure`): the product .so has neither the knob nor the ablation kernels."""
 import json, os, sys
+os.environ["YAMS_ACCEL_MEASURE_LIB"] = "1"   # the measurement build: python -m yams_amd.build --measure
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,5 +1,5 @@
 """Small query batches on one C4 shard (12.5M x 768 cosine, k = 100): the narrow form of the shadow
-filter (Q <= 64 / <= 128, HBM-bound) next to the 256-query tile (YAMS_ACCEL_BF16_KERNEL=3).
+filter (Q <= 64 / <= 128, HBM-bound) next to the 256-query tile (YAMS_SCAN_FLAG_WIDE_TILE).
 One JSON line per (Q, form): whole-step ms, filter-kernel ms (HIP events on the context's stream),
 achieved shadow-read GB/s of the filter kernel against the 8 TB/s HBM peak."""
 import json, os, sys, time
@@ -21,11 +21,8 @@ for nq in [int(x) for x in os.environ.get("QS", "1,16,64,128,256").split(",")]:
     s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     for form in os.environ.get("FORMS", "default,wide").split(","):
-        if form == "wide":
-            os.environ["YAMS_ACCEL_BF16_KERNEL"] = "3"
-        else:
-            os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)
-        args = (view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr())
+        args = (view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr(),
+                None, 32 if form == "wide" else 0)   # YAMS_SCAN_FLAG_WIDE_TILE
         for _ in range(2):
             diag = acc.scan_topk_device(*args)
         reps = 6
@@ -49,4 +46,3 @@ for nq in [int(x) for x in os.environ.get("QS", "1,16,64,128,256").split(",")]:
                           "frac_of_8TBps": filt_bytes / (filt_ms * 1e-3) / 8e12 if filt_ms else None,
                           "path": diag["path"], "fallbacks": diag["exact_fallback_queries"],
                           "identical_to_default": same}), flush=True)
-os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)

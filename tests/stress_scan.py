@@ -3,7 +3,7 @@ covers far more shapes per second than the parity tests): for random (rows, dim,
 threshold, allow-mask) the default path — narrow filter for small batches, 256-query tile above —
 must return bit-identical rows / scores / counts to the exhaustive fp64 path
 (YAMS_SCAN_FLAG_FORCE_EXACT), which shares no filter code with it, and to the wide form
-(YAMS_ACCEL_BF16_KERNEL=3).  Prints one summary line; exit code 1 on any mismatch.
+(YAMS_SCAN_FLAG_WIDE_TILE).  Prints one summary line; exit code 1 on any mismatch.
 
     python tests/stress_scan.py [--cases 60] [--seed 1]
 """
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from yams_amd.accel import Accel
-from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_WIDE_TILE
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
@@ -53,18 +53,13 @@ for case in range(a.cases):
     for form in ("default", "wide", "exact"):
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        if form == "wide":
-            os.environ["YAMS_ACCEL_BF16_KERNEL"] = "3"
-        else:
-            os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)
         diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
-                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else 0)
+                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else (FLAG_WIDE_TILE if form == "wide" else 0))
         torch.cuda.synchronize()
         cn = c.cpu().numpy()
         sel = np.arange(k)[None, :] < cn[:, None]        # only the returned prefix is defined
         out[form] = (cn, np.where(sel, r.cpu().numpy(), -1), np.where(sel, s.cpu().numpy().view(np.uint32), 0),
                      np.where(sel, dist.cpu().numpy().view(np.uint32), 0) if metric == SCAN_L2 else None, diag)
-    os.environ.pop("YAMS_ACCEL_BF16_KERNEL", None)
     ref = out["exact"]
     for form in ("default", "wide"):
         o = out[form]

@@ -43,6 +43,20 @@ def test_library_has_no_oracle_or_torch_dependency():
     assert "oracle_" not in syms and "ref_sha256" not in syms
 
 
+def test_product_library_reads_no_environment():
+    """Kernel-form / ablation selection from the environment exists only in the measurement build
+    (-DYAMS_ACCEL_MEASURE); the product library does not even import getenv."""
+    import subprocess
+    from yams_amd import _lib
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    for name in os.listdir(os.path.join(ROOT, "yams_amd", "csrc")):
+        src = open(os.path.join(ROOT, "yams_amd", "csrc", name)).read()
+        for m in re.finditer(r"getenv", src):
+            guard = src.rfind("#ifdef YAMS_ACCEL_MEASURE", 0, m.start())
+            assert guard >= 0 and src.find("#endif", guard, m.start()) < 0, f"unguarded getenv in {name}"
+
+
 def test_plugin_identity_and_manifest(accel_lib):
     L = accel_lib
     assert L.yams_plugin_get_abi_version() == 1  # YAMS_PLUGIN_ABI_VERSION, abi.h:18

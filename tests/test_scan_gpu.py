@@ -11,7 +11,7 @@ import pytest
 import _cases
 from yams_amd import _lib
 from yams_amd._lib import (SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER,
-                           FLAG_RECORD_PATH)
+                           FLAG_RECORD_PATH, FLAG_WIDE_TILE)
 
 pytestmark = pytest.mark.gpu
 
@@ -234,6 +234,43 @@ def test_crowded_top_escalates_to_the_split_filter(acc, oracle):
     check(acc, oracle, corpus, q, 50, metric=SCAN_L2, expect_path=0)
 
 
+def test_escalation_and_list_overflow_in_one_batch(acc, oracle):
+    """One batch holding a list-overflow query at index 0 AND a crowded-top query: the crowded one is
+    re-run through the split filter as a nested one-query batch (slot 0 of ITS workspace) before
+    the overflowed one takes the exhaustive fp64 pass with the outer call's query norms.  The two
+    queries have different norms, so a nested run that shared the outer workspace would score query
+    0 with the wrong norm (round-1 advisor finding)."""
+    n, d = 20000, 64
+    rng = np.random.default_rng(92)
+    corpus = oracle.synth_rows(13, 0, n, d)
+    q = oracle.synth_rows(13, 1 << 40, 5, d)
+    q[0] *= np.float32(3.0)
+    corpus[1::4] = q[0] * np.float32(0.5)                   # 5000 exact ties: query 0's list overflows
+    qu = (q[2] / np.linalg.norm(q[2])).astype(np.float64)
+    pool = np.setdiff1d(np.arange(n), np.arange(1, n, 4))
+    crowd = rng.choice(pool, 3000, replace=False)
+    for r_, s_ in zip(crowd, np.linspace(0.990, 0.999, 3000)):
+        v = rng.standard_normal(d)
+        v -= (v @ qu) * qu
+        v /= np.linalg.norm(v)
+        corpus[r_] = (s_ * qu + np.sqrt(1.0 - s_ * s_) * v).astype(np.float32) * np.float32(rng.uniform(0.5, 2.0))
+    rank = np.random.default_rng(34).permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0)
+    assert r.diag["escalated_queries"] >= 1 and r.diag["exact_fallback_queries"] >= 1, r.diag
+
+
+def test_product_library_ignores_measurement_environment(acc, oracle, monkeypatch):
+    """YAMS_ACCEL_BF16_KERNEL / _PASSES select ablation kernels in the measurement build only
+    (-DYAMS_ACCEL_MEASURE, scripts/); the product library must not read them."""
+    monkeypatch.setenv("YAMS_ACCEL_BF16_KERNEL", "12")
+    monkeypatch.setenv("YAMS_ACCEL_BF16_PASSES", "3")
+    monkeypatch.setenv("YAMS_ACCEL_CDC_GENERIC", "1")
+    corpus = oracle.synth_rows(18, 0, 30000, 128)
+    q = oracle.synth_rows(18, 1 << 40, 4, 128)
+    r = check(acc, oracle, corpus, q, 20, expect_path=0)
+    assert r.diag["escalated_queries"] == 0 and (r.counts == 20).all()
+
+
 def test_massive_ties_take_the_exhaustive_fp64_path(acc, oracle):
     """More identical rows than the candidate list can hold: the list overflows, the query is
     scored exhaustively in fp64 on the device — results stay exact, other queries stay fast."""
@@ -279,10 +316,10 @@ def test_all_filters_agree_with_the_oracle(acc, oracle, metric):
 
 @pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
 @pytest.mark.parametrize("nq", [1, 33, 64, 65, 128, 129])
-def test_small_batches_take_the_narrow_filter_and_agree(acc, oracle, metric, nq, monkeypatch):
+def test_small_batches_take_the_narrow_filter_and_agree(acc, oracle, metric, nq):
     """Batches of <= 64 / <= 128 queries run the narrow (HBM-bound) form of the shadow filter; 129
     falls back to the 256-query tile.  Same result as the oracle and, bit for bit, as the wide form
-    (YAMS_ACCEL_BF16_KERNEL=3); ragged row tail, zero-norm and huge-norm rows, thresholds."""
+    (YAMS_SCAN_FLAG_WIDE_TILE); ragged row tail, zero-norm and huge-norm rows, thresholds."""
     n, d, k = 40000 + 77, 192, 30
     corpus = oracle.synth_rows(21, 0, n, d)
     corpus[5] = 0.0
@@ -291,9 +328,7 @@ def test_small_batches_take_the_narrow_filter_and_agree(acc, oracle, metric, nq,
     q = oracle.synth_rows(21, 1 << 40, nq, d)
     thr = 0.05 if metric == SCAN_COSINE else -1.0
     a = check(acc, oracle, corpus, q, k, thr=thr, metric=metric, max_queries=5, expect_path=0)
-    monkeypatch.setenv("YAMS_ACCEL_BF16_KERNEL", "3")
-    b = run(acc, corpus, q, k, thr, metric)
-    monkeypatch.delenv("YAMS_ACCEL_BF16_KERNEL")
+    b = run(acc, corpus, q, k, thr, metric, flags=FLAG_WIDE_TILE)
     assert np.array_equal(a.rows, b.rows) and np.array_equal(a.counts, b.counts)
     assert np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
     assert a.diag["exact_fallback_queries"] == 0

@@ -19,6 +19,8 @@ STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NOT_FOUND", 3: "IO", 4: "INTERNAL
 SCAN_COSINE, SCAN_L2 = 0, 1
 CDC_RABIN, CDC_STREAMING = 0, 1
 FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG_RECORD_PATH = 1, 2, 4, 8, 16
+FLAG_WIDE_TILE = 32
+CDC_FLAG_GENERIC_KERNEL = 1
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2
 
 vp = C.c_void_p
@@ -56,7 +58,7 @@ class ScanDiag(C.Structure):
 class CdcConfig(C.Structure):
     _fields_ = [("window_size", C.c_uint64), ("min_size", C.c_uint64), ("max_size", C.c_uint64),
                 ("polynomial", C.c_uint64), ("mask", C.c_uint64), ("mode", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32)]
 
 
 class IngestResult(C.Structure):
@@ -165,6 +167,11 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    if os.environ.get("YAMS_ACCEL_MEASURE_LIB"):
+        # scripts/ only: the measurement build (ablation kernels + environment knobs), same ABI.
+        # This is the Python loader choosing a file; the product library itself reads no environment.
+        LIB_PATH = os.path.join(HERE, "lib", "libyams_mi355x_accel_measure.so")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m yams_amd.build` "

@@ -19,9 +19,10 @@ DEFAULT_POLY = 0x3DA3358B4DC173
 
 
 def cdc_config(mode="streaming", window=48, min_size=16 * 1024, max_size=1024 * 1024,
-               polynomial=DEFAULT_POLY, mask=0x1FFF) -> CdcConfig:
+               polynomial=DEFAULT_POLY, mask=0x1FFF, generic_kernel=False) -> CdcConfig:
     m = CDC_STREAMING if mode in ("streaming", CDC_STREAMING) else CDC_RABIN
-    return CdcConfig(window, min_size, max_size, polynomial, mask, m, 0)
+    return CdcConfig(window, min_size, max_size, polynomial, mask, m,
+                     _lib.CDC_FLAG_GENERIC_KERNEL if generic_kernel else 0)
 
 
 class DeviceArray:

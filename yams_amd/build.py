@@ -35,9 +35,16 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+MEASURE_LIB = os.path.join(LIBDIR, "libyams_mi355x_accel_measure.so")
+
+
+def build(force: bool = False, verbose: bool = False, measure: bool = False) -> str:
+    """measure=True builds libyams_mi355x_accel_measure.so (-DYAMS_ACCEL_MEASURE): the same sources
+    plus the ablation kernels and the YAMS_ACCEL_BF16_KERNEL / _PASSES environment knobs that
+    scripts/ uses.  The product library contains neither and never reads the environment."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp_file = os.path.join(LIBDIR, ".stamp")
+    LIB = MEASURE_LIB if measure else globals()["LIB"]
+    stamp_file = os.path.join(LIBDIR, ".stamp_measure" if measure else ".stamp")
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) \
             and open(stamp_file).read() == stamp:
@@ -49,8 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src + ".o")
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(LIBDIR, src + (".measure.o" if measure else ".o"))
+        cmd = [HIPCC, *FLAGS, *(["-DYAMS_ACCEL_MEASURE"] if measure else []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -72,7 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, measure="--measure" in sys.argv))
 
 
 def build_host_tests() -> str:

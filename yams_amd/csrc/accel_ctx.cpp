@@ -21,7 +21,7 @@ yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what) {
 }
 
 yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out) {
-    auto& b = ctx->bufs[name];
+    auto& b = ctx->ws_ns.empty() ? ctx->bufs[name] : ctx->bufs[ctx->ws_ns + name];
     if (bytes == 0) bytes = 16;
     if (b.cap < bytes) {
         if (b.p) {

@@ -20,6 +20,9 @@ struct yams_accel_ctx {
     // growable named device buffers (workspace); never shrinks
     struct Buf { void* p = nullptr; size_t cap = 0; };
     std::map<std::string, Buf> bufs;
+    // name prefix of ws_get: a nested scan (the split-filter escalation of a batch) works in its
+    // own namespace, so the buffers of the call that is still in flight around it stay intact
+    std::string ws_ns;
     // pinned host staging
     void* pinned = nullptr;
     size_t pinned_cap = 0;

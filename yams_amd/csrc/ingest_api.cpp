@@ -25,6 +25,7 @@ yams_status_t make_params(yams_accel_ctx* ctx, const yams_cdc_config_t* cfg, Cdc
     cp->min_size = cfg->min_size;
     cp->max_size = cfg->max_size;
     cp->streaming = cfg->mode == YAMS_CDC_STREAMING;
+    cp->generic = (cfg->flags & YAMS_CDC_FLAG_GENERIC_KERNEL) ? 1u : 0u;
     uint64_t w = cfg->window_size;
     if (cp->streaming) { // streaming_chunker.cpp:44-49 clamps the ring
         if (w == 0) w = 1; else if (w > 48) w = 48;
@@ -201,7 +202,7 @@ void yams_cdc_default_config(yams_cdc_config_t* cfg, uint32_t mode) {
     cfg->polynomial = kDefaultPoly;     // chunker.h:49
     cfg->mask = 0x1FFF;                 // chunker.h:50
     cfg->mode = mode;
-    cfg->reserved = 0;
+    cfg->flags = 0;
 }
 
 yams_status_t yams_cdc_chunk_device(yams_accel_ctx* ctx, const uint8_t* data,

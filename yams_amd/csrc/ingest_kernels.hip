@@ -816,8 +816,7 @@ hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint
                                  uint32_t n_blobs, uint64_t n_pieces, const CdcParams& cp,
                                  uint32_t* bitmap) {
     if (n_pieces == 0) return hipSuccess;
-    static const bool force_generic = getenv("YAMS_ACCEL_CDC_GENERIC") != nullptr;
-    if (cp.window == 48 && cp.mask < (1ull << 31) && !force_generic)
+    if (cp.window == 48 && cp.mask < (1ull << 31) && !cp.generic)
         hipLaunchKernelGGL(cdc_candidates_w48_kernel, dim3(static_cast<uint32_t>(n_pieces)),
                            dim3(CDC_THREADS), 0, st, data, blob_off, blob_len, piece_prefix, n_blobs,
                            cp, bitmap);

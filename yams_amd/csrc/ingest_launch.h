@@ -13,6 +13,7 @@ struct CdcParams {
     uint64_t max_size;
     uint32_t window;    // effective ring size (1..48)
     uint32_t streaming; // 1 = StreamingChunker semantics, 0 = RabinChunker
+    uint32_t generic;   // 1 = use the any-window candidates kernel even where the narrow one applies
 };
 
 hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint64_t* blob_off,

@@ -222,17 +222,21 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // extra candidates would not fit the re-score stage: k > 661, L2 k > 319) and escalation runs
         // use the split filter.
         const bool bf16 = !(params->flags & YAMS_SCAN_FLAG_F32_FILTER) && (dim & 15u) == 0;
-        // measurement knobs (never set by the product path)
-        const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL");
-        const int bf16_version = kv ? std::atoi(kv) : 2; // 12 = staging-only ablation (perf measurement only)
-        const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES");
+        // 2 = the library's own choice of kernel form; 3 = keep the 256-query tile for small batches
+        int bf16_version = (params->flags & YAMS_SCAN_FLAG_WIDE_TILE) ? 3 : 2;
         int passes = 0;
         if (bf16) {
             // the single-pass tier needs 3k + 64 (L2: 6k + 128) candidates re-scored in stage 1
             const uint32_t need1 = (metric == YAMS_SCAN_L2) ? 6 * k + 128 : 3 * k + 64;
             passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || need1 > kRescoreMax) ? 3 : 1;
-            if (pv && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
         }
+#ifdef YAMS_ACCEL_MEASURE
+        // Measurement build only (libyams_mi355x_accel_measure.so, scripts/): kernel-form and
+        // ablation selection from the environment.  The product library never reads it.
+        if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
+        if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
+            if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
+#endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
@@ -284,11 +288,13 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
 
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20) { // ablated measurement kernels produce no candidates: stop here
+#ifdef YAMS_ACCEL_MEASURE
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20) { // ablated kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;
         }
+#endif
         // stage 1: re-score the best kprime filter survivors of every query
         // cosine: |s32 - cos| <= dot_rel + norm (dim/2 u) + rsqrt/product/unit-query rounding
         const double err_bound = (metric == YAMS_SCAN_COSINE)
@@ -360,8 +366,15 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_HIP(ctx, launch_gather_queries(st, queries, d_submap, escalated, dim, s_q));
             YA_HIP(ctx, hipStreamSynchronize(st)); // `failed` is pageable
             yams_scan_diag_t sub{};
-            YA_TRY(scan_impl(ctx, corpus, s_q, escalated, params, s_scores, s_rows, s_counts, s_dist,
-                             s_ranks, &sub, true));
+            {   // the nested run gets its own workspace namespace: this call's qnorm / status /
+                // candidate lists are still needed by the exhaustive pass below
+                const std::string outer_ns = ctx->ws_ns;
+                ctx->ws_ns = outer_ns + "esc/";
+                const yams_status_t ns_st = scan_impl(ctx, corpus, s_q, escalated, params, s_scores, s_rows,
+                                                      s_counts, s_dist, s_ranks, &sub, true);
+                ctx->ws_ns = outer_ns;
+                YA_TRY(ns_st);
+            }
             YA_HIP(ctx, launch_scatter_results(st, d_submap, escalated, k, s_scores, s_rows, s_counts,
                                                s_dist, s_ranks, out_scores, out_rows, out_counts,
                                                out_dist, out_ranks));
@@ -371,7 +384,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             widened += sub.widened_queries;
             exact_fb += sub.exact_fallback_queries;
             failed.clear();
-            // the nested call reused the workspace: d_stat now counts only its rows (added above)
+            // d_stat was read into rescored_nested above; the nested call counted in its own buffer
             YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
         }
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());

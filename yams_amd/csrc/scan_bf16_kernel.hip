@@ -1325,17 +1325,25 @@ hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_row
         else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_L2, PASSES>), dim3(grid), dim3(BT_THREADS), 0, st, a); \
     } } while (0)
 
-// passes: 1 or 3 (see the kernel).  version 12 = staging-only ablation (measurement only).
+// passes: 1 or 3 (see the kernel).  version: 2 = default forms, 3 = wide tile for small batches
+// (YAMS_SCAN_FLAG_WIDE_TILE); other values exist in the measurement build only (ablations, -DYAMS_ACCEL_MEASURE).
 hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int passes, int version) {
     ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
     const uint32_t grid = groups * a.n_qtiles * 8;
+#ifdef YAMS_ACCEL_MEASURE
     if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE && bf16_slab_k(passes, L.plan.dim) == 16) {
         if (passes == 3) hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
         else hipLaunchKernelGGL((scan_tiles_bf16v2_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 1, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-    } else if (passes == 3) LAUNCH_BF16(3);
+        LAUNCH_CHECK();
+        return hipSuccess;
+    }
+#else
+    if (version != 3) version = 2; // the product library knows two forms: its own choice, or the wide tile
+#endif
+    if (passes == 3) LAUNCH_BF16(3);
     else if (a.rows_bf16 && bf16_slab_k(passes, L.plan.dim) == 32) {
         // persistent form where tiles are short (many visits per CU): measured -3 % at dim 384,
         // equal at 768, +5 % (worse) at 1536; version 4 forces it, 3 forces the per-tile form
@@ -1374,6 +1382,7 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
             LAUNCH_CHECK();
             return hipSuccess;
         }
+#ifdef YAMS_ACCEL_MEASURE
         const bool abl = mode == MODE_FILTER && metric == YAMS_SCAN_COSINE;
         const bool four = version >= 20;       // 4-wave (4x4 tiles) form; 2x = its ablations
         const int v = four ? version - 10 : version;
@@ -1385,7 +1394,12 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
         else if (abl && v == 13) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 3);
         else if (abl && v == 14) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 4);
         else if (abl && v == 15) LAUNCH_SH(MODE_FILTER, YAMS_SCAN_COSINE, 5);
-        else if (mode == MODE_SAMPLE) {
+        else
+#else
+#define LAUNCH_SH(MODE_, METRIC_, ABL_) \
+            hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_, METRIC_, ABL_, 8>), dim3(grid), dim3(512), 0, st, a)
+#endif
+        if (mode == MODE_SAMPLE) {
             if (metric == YAMS_SCAN_COSINE) LAUNCH_SH(MODE_SAMPLE, YAMS_SCAN_COSINE, 0);
             else LAUNCH_SH(MODE_SAMPLE, YAMS_SCAN_L2, 0);
         } else {
@@ -1394,6 +1408,7 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
         }
 #undef LAUNCH_SH
     } else if (bf16_slab_k(passes, L.plan.dim) == 32) {
+#ifdef YAMS_ACCEL_MEASURE
         if (version == 12 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
             hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
         else if (version == 11 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
@@ -1402,7 +1417,9 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
             hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 3>), dim3(grid), dim3(BT_THREADS), 0, st, a);
         else if (version == 14 && mode == MODE_FILTER && metric == YAMS_SCAN_COSINE)
             hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 4>), dim3(grid), dim3(BT_THREADS), 0, st, a);
-        else if (mode == MODE_SAMPLE) {
+        else
+#endif
+        if (mode == MODE_SAMPLE) {
             if (metric == YAMS_SCAN_COSINE) hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE>), dim3(grid), dim3(BT_THREADS), 0, st, a);
             else hipLaunchKernelGGL((scan_tiles_bf16k32_kernel<MODE_SAMPLE, YAMS_SCAN_L2>), dim3(grid), dim3(BT_THREADS), 0, st, a);
         } else {
