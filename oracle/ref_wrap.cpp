@@ -7,8 +7,10 @@
 #include <yams/chunking/streaming_chunker.h>
 #include <yams/crypto/hasher.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <span>
 #include <vector>
 
@@ -77,5 +79,24 @@ ref_chunk_streaming(const uint8_t* data, size_t n, uint64_t window, uint64_t min
     auto chunks = chunker.chunkData(
         std::span<const std::byte>(reinterpret_cast<const std::byte*>(data), n));
     return emit(chunks, offsets, sizes, hex, cap);
+}
+// The reference's synthetic-embedding recipe drawn with the REAL std::mt19937 and
+// std::uniform_real_distribution<float> of this toolchain's libstdc++ (the classes
+// tests/benchmarks/vector_backend_engine_compare.cpp:83-107 uses); pins oracle_mt19937_rows.
+__attribute__((visibility("default"))) void ref_mt19937_rows(uint32_t seed, size_t count, size_t dim,
+                                                             float* out) {
+    std::mt19937 rng(seed);
+    for (size_t r = 0; r < count; ++r) {
+        std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+        float* v = out + r * dim;
+        float norm_sq = 0.0f;
+        for (size_t j = 0; j < dim; ++j) {
+            v[j] = dist(rng);
+            norm_sq += v[j] * v[j];
+        }
+        const float norm = std::sqrt(norm_sq);
+        if (norm > 0.0f)
+            for (size_t j = 0; j < dim; ++j) v[j] /= norm;
+    }
 }
 }

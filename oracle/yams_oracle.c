@@ -462,3 +462,61 @@ ORACLE_API void oracle_synth_bytes(uint64_t seed, uint64_t blob_id, uint64_t off
         for (; b < 16 && i < n; ++b, ++i) out[i] = (uint8_t)(w[b / 4] >> (8 * (b % 4)));
     }
 }
+
+/* ================================================================================================
+ * The reference's own synthetic-vector recipe (tests/benchmarks/vector_backend_engine_compare.cpp:
+ * 83-107, 251-253; fixture tests/unit/vector/sqlite_vec_backend_comprehensive_catch2_test.cpp:
+ * 84-101): std::mt19937 rng(seed); every component uniform_real_distribution<float>(-1, 1); then an
+ * fp32 L2-normalisation with norm_sq accumulated in float; the corpus is drawn first, the queries
+ * after it from the same stream.  Restated here so BASELINE config 1 (10k x 384, seed 42) can be
+ * regenerated on the GPU box: MT19937 (Matsumoto & Nishimura 1998, the parameters std::mt19937 is
+ * specified with, [rand.predef]) and libstdc++'s uniform_real_distribution<float> =
+ * generate_canonical<float, 24>: one 32-bit draw, float(draw) * 2^-32, a result that rounds to
+ * 1.0f is replaced by nextafter(1, 0); value = canonical * (b - a) + a.
+ * Pinned by tests/golden/mt_recipe.json (made with the real std:: classes, oracle/ref_wrap.cpp).
+ * ============================================================================================== */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_state;
+
+static void mt19937_seed(mt19937_state* s, uint32_t seed) {
+    s->mt[0] = seed;
+    for (int i = 1; i < 624; ++i)
+        s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->idx = 624;
+}
+static uint32_t mt19937_next(mt19937_state* s) {
+    if (s->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            const uint32_t y = (s->mt[i] & 0x80000000u) | (s->mt[(i + 1) % 624] & 0x7fffffffu);
+            s->mt[i] = s->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        s->idx = 0;
+    }
+    uint32_t y = s->mt[s->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* `count` normalised vectors drawn consecutively from mt19937(seed) after skipping `skip_vectors`
+ * vectors of the same dimension (the queries follow the corpus in the stream). */
+ORACLE_API void oracle_mt19937_rows(uint32_t seed, size_t skip_vectors, size_t count, size_t dim, float* out) {
+    mt19937_state st;
+    mt19937_seed(&st, seed);
+    for (size_t i = 0; i < skip_vectors * dim; ++i) (void)mt19937_next(&st);
+    for (size_t r = 0; r < count; ++r) {
+        float* v = out + r * dim;
+        float norm_sq = 0.0f;
+        for (size_t j = 0; j < dim; ++j) {
+            float canon = (float)mt19937_next(&st) * 2.3283064365386963e-10f; /* / 2^32 (exact scaling) */
+            if (canon >= 1.0f) canon = 0.99999994f;                            /* nextafterf(1, 0) */
+            const float value = canon * 2.0f + -1.0f;                          /* * (b - a) + a */
+            v[j] = value;
+            norm_sq += value * value;
+        }
+        const float norm = sqrtf(norm_sq);
+        if (norm > 0.0f)
+            for (size_t j = 0; j < dim; ++j) v[j] /= norm;
+    }
+}

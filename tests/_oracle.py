@@ -72,6 +72,7 @@ class Oracle:
         L.oracle_philox4x32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         L.oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, f32p]
         L.oracle_synth_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, u8p]
+        L.oracle_mt19937_rows.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
 
     # --- SHA-256 ---
     def sha256_hex(self, data: bytes | np.ndarray) -> str:
@@ -158,6 +159,13 @@ class Oracle:
         self.L.oracle_synth_rows(seed, row0, n, dim, _ptr(out, f32p))
         return out
 
+    def mt19937_rows(self, seed, skip_vectors, n, dim):
+        """The reference's own recipe (vector_backend_engine_compare.cpp:83-107): std::mt19937(seed),
+        U(-1,1) floats, fp32 normalise; `skip_vectors` vectors of the stream are skipped first."""
+        out = np.empty((n, dim), np.float32)
+        self.L.oracle_mt19937_rows(seed, skip_vectors, n, dim, _ptr(out, f32p))
+        return out
+
     def synth_bytes(self, seed, blob, off, n):
         out = np.empty(n, np.uint8)
         if n:
@@ -186,6 +194,12 @@ class Ref:
             f.argtypes = [u8p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                           C.c_uint64, u64p, u64p, C.c_char_p, C.c_size_t]
             f.restype = C.c_size_t
+
+    def mt19937_rows(self, seed, n, dim):
+        out = np.empty((n, dim), np.float32)
+        self.L.ref_mt19937_rows.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, f32p]
+        self.L.ref_mt19937_rows(seed, n, dim, _ptr(out, f32p))
+        return out
 
     def sha256_hex(self, data) -> str:
         a = np.ascontiguousarray(data if isinstance(data, np.ndarray)
@@ -239,3 +253,64 @@ def ref():
         except (FileNotFoundError, OSError):
             _ref = False
     return _ref or None
+
+
+# ---- the oracle over all host cores ------------------------------------------------------------------
+def host_threads(limit: int | None = None) -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, limit) if limit else n)
+
+
+def scan_threaded(get_slice, n_rows, queries, k, metric="cosine", thr=-1.0, slice_rows=65536,
+                  threads=None, stats=None):
+    """The scalar oracle scan of every query over a corpus that need not fit in host memory:
+    `get_slice(lo, hi)` returns rows [lo, hi) as a float32 array (a device-to-host copy of the very
+    tensor the GPU scanned, or a regenerated Philox slice).  One task = one row slice x all queries
+    (ctypes calls release the GIL, so the tasks run on all host cores); per-slice top-k lists are
+    merged with the reference comparator (similarity desc / distance asc, then row id asc) — the
+    exact top-k of a union is the top-k of the per-part top-k lists.  Returns one
+    (rows, sims[, dist]) tuple per query, identical to a single oracle call over the whole corpus."""
+    from concurrent.futures import ThreadPoolExecutor
+    import time
+    o = oracle()
+    queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
+    nq = queries.shape[0]
+    threads = threads or host_threads()
+    bounds = [(lo, min(lo + slice_rows, n_rows)) for lo in range(0, n_rows, slice_rows)]
+
+    def task(b):
+        lo, hi = b
+        t0 = time.perf_counter()
+        part = np.ascontiguousarray(get_slice(lo, hi), np.float32)
+        t1 = time.perf_counter()
+        out = []
+        for qi in range(nq):
+            if metric == "cosine":
+                rows, sims, _, _ = o.scan_cosine(part, queries[qi], k, thr)
+                out.append((rows + lo, sims, None))
+            else:
+                rows, dist, sims = o.scan_l2(part, queries[qi], k, -1.0)   # threshold after the merge
+                out.append((rows + lo, sims, dist))
+        return out, t1 - t0, time.perf_counter() - t1
+
+    t_start = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(task, bounds))
+    wall = time.perf_counter() - t_start
+    if stats is not None:
+        stats.update({"threads": threads, "slices": len(bounds), "wall_s": wall,
+                      "fetch_thread_s": sum(p[1] for p in parts), "scan_thread_s": sum(p[2] for p in parts)})
+    res = []
+    for qi in range(nq):
+        rows = np.concatenate([p[0][qi][0] for p in parts])
+        sims = np.concatenate([p[0][qi][1] for p in parts])
+        if metric == "cosine":
+            order = np.lexsort((rows, -sims.astype(np.float64)))[:k]
+            res.append((rows[order], sims[order]))
+        else:
+            dist = np.concatenate([p[0][qi][2] for p in parts])
+            order = np.lexsort((rows, dist.astype(np.float64)))[:k]
+            rows, sims, dist = rows[order], sims[order], dist[order]
+            keep = ~(sims < np.float32(thr))      # vec0: k nearest, THEN the cosine threshold (:4506-4510)
+            res.append((rows[keep], sims[keep], dist[keep]))
+    return res

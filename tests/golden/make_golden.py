@@ -82,7 +82,21 @@ def main():
     with open(os.path.join(HERE, "cdc.json"), "w") as f:
         json.dump({"source": "reference src/chunking/{rabin,streaming}_chunker.cpp via oracle/_ref",
                    "cases": cdc}, f)
-    print("wrote", len(sha), "sha cases and", len(cdc), "cdc cases")
+    # the reference's synthetic-embedding recipe (vector_backend_engine_compare.cpp:83-107) drawn
+    # with the real std::mt19937 / std::uniform_real_distribution<float> (oracle/ref_wrap.cpp)
+    import hashlib
+    small = r.mt19937_rows(7, 5, 6)
+    c1 = r.mt19937_rows(42, 10_000 + 16, 384)      # BASELINE config 1: corpus, then the queries
+    mt = {"source": "std::mt19937 + std::uniform_real_distribution<float>(-1,1) + fp32 normalise, libstdc++ "
+                    "of the dev container, via oracle/_ref (ref_mt19937_rows)",
+          "small": {"seed": 7, "count": 5, "dim": 6, "values_u32": [int(x) for x in small.view(np.uint32).ravel()]},
+          "config1": {"seed": 42, "count": 10_016, "dim": 384,
+                      "sha256_of_float32_bytes": hashlib.sha256(c1.tobytes()).hexdigest(),
+                      "first_row_head_u32": [int(x) for x in c1[0, :8].view(np.uint32)],
+                      "first_query_head_u32": [int(x) for x in c1[10_000, :8].view(np.uint32)]}}
+    with open(os.path.join(HERE, "mt_recipe.json"), "w") as f:
+        json.dump(mt, f, indent=1)
+    print("wrote", len(sha), "sha cases and", len(cdc), "cdc cases + the mt19937 recipe")
 
 
 if __name__ == "__main__":

@@ -231,6 +231,52 @@ def test_ingest_full_size_properties(acc, oracle):
     assert np.array_equal(out2["chunk_digest"], out["chunk_digest"])
 
 
+def test_ingest_config5_8GiB_every_blob_verified(acc, oracle):
+    """8 GiB of BASELINE config 5 (2048 Philox blobs x 4 MiB, product-default StreamingChunker),
+    EVERY blob checked on the host cores: the blob is regenerated from the Philox recipe on the CPU
+    (so the device generator is checked too), chunked by the reference's own StreamingChunker
+    (oracle/_ref) or its C restatement, and all chunk digests + the blob digest are compared with
+    hashlib (OpenSSL, what the reference links)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    import _oracle
+    n_blobs, blen = 2048, 4 << 20
+    tb = torch.empty(n_blobs * blen, dtype=torch.uint8, device="cuda")
+    acc.synth_bytes(42, 0, n_blobs, blen, tb.data_ptr())
+    offs = [i * blen for i in range(n_blobs)]
+    res = acc.ingest_device(tb.data_ptr(), offs, [blen] * n_blobs, cdc_config("streaming"), flags=3)
+    out = acc.fetch_ingest(res, n_blobs)
+    first, co, cs = out["blob_first"], out["chunk_offset"], out["chunk_size"]
+    cd, bd = out["chunk_digest"], out["blob_digest"]
+    ref = _oracle.ref()
+
+    def verify(bi):
+        blob = oracle.synth_bytes(42, bi, 0, blen)
+        ref_hashes = None
+        if ref is not None and bi % 8 == 0:         # the reference's TUs (slower: per-byte push_back)
+            ooff, osz, ref_hashes = ref.chunks(blob, "streaming", with_hashes=True)
+        else:
+            ooff, osz = oracle.chunks(blob, "streaming")
+        lo, hi = int(first[bi]), int(first[bi + 1])
+        if hi - lo != len(ooff) or not (np.array_equal(co[lo:hi], ooff) and np.array_equal(cs[lo:hi], osz)):
+            return f"blob {bi}: boundaries differ"
+        mv = memoryview(blob)
+        if bd[bi].tobytes() != hashlib.sha256(mv).digest():
+            return f"blob {bi}: blob digest differs"
+        for j in range(lo, hi):
+            o, sz = int(co[j]), int(cs[j])
+            if cd[j].tobytes() != hashlib.sha256(mv[o:o + sz]).digest():
+                return f"blob {bi}: chunk {j - lo} digest differs"
+            if ref_hashes is not None and cd[j].tobytes().hex() != ref_hashes[j - lo]:
+                return f"blob {bi}: chunk {j - lo} differs from the reference's Chunk::hash"
+        return None
+
+    with ThreadPoolExecutor(max_workers=_oracle.host_threads(128)) as ex:
+        bad = [m for m in ex.map(verify, range(n_blobs)) if m]
+    assert not bad, bad[:5]
+    assert int(first[-1]) == out["n_chunks"] and 300_000 < out["n_chunks"] < 400_000
+
+
 def test_chunker_vtable(accel_lib, oracle):
     L = accel_lib
     assert L.yams_plugin_init(b"{}", None) == 0

@@ -6,11 +6,14 @@
   * live against oracle/_ref when it is present (dev container).
 """
 import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
 
 import _cases
+import _oracle
 
 
 # ---- SHA-256 ------------------------------------------------------------------------------------
@@ -188,3 +191,47 @@ def test_l2_known_answers(oracle):
     a = np.arange(8, dtype=np.float32)
     rows, dist, sims = oracle.scan_l2(np.stack([a, a + 1]), a, 2, -1.0)
     assert list(rows) == [0, 1] and dist[0] == 0.0 and abs(dist[1] - np.sqrt(8)) < 1e-5
+
+
+def test_mt19937_recipe_matches_the_std_library_golden(oracle):
+    """The reference's synthetic-embedding recipe (vector_backend_engine_compare.cpp:83-107):
+    the C restatement against a fixture drawn with the real std::mt19937 /
+    std::uniform_real_distribution<float> (tests/golden/make_golden.py), and against those classes
+    directly when oracle/_ref is present."""
+    import hashlib
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mt_recipe.json")))
+    sm = g["small"]
+    got = oracle.mt19937_rows(sm["seed"], 0, sm["count"], sm["dim"])
+    assert [int(x) for x in got.view(np.uint32).ravel()] == sm["values_u32"]
+    c1 = g["config1"]
+    full = oracle.mt19937_rows(c1["seed"], 0, c1["count"], c1["dim"])
+    assert hashlib.sha256(full.tobytes()).hexdigest() == c1["sha256_of_float32_bytes"]
+    assert [int(x) for x in full[0, :8].view(np.uint32)] == c1["first_row_head_u32"]
+    # queries follow the corpus in the same stream
+    q = oracle.mt19937_rows(c1["seed"], 10_000, 16, c1["dim"])
+    assert np.array_equal(q.view(np.uint32), full[10_000:].view(np.uint32))
+    assert [int(x) for x in q[0, :8].view(np.uint32)] == c1["first_query_head_u32"]
+    r = _oracle.ref()
+    if r is not None:
+        assert np.array_equal(r.mt19937_rows(9, 300, 48).view(np.uint32), oracle.mt19937_rows(9, 0, 300, 48).view(np.uint32))
+
+
+def test_threaded_scan_equals_one_oracle_call(oracle):
+    """_oracle.scan_threaded (slices on all host cores + comparator merge) is the oracle, not an
+    approximation of it: identical rows, order and bits, ties across slice boundaries included."""
+    n, d, k = 5000, 24, 40
+    corpus = oracle.synth_rows(3, 0, n, d)
+    corpus[999] = corpus[1000] = corpus[4321] = corpus[17]          # exact ties straddling slices
+    q = oracle.synth_rows(3, 1 << 40, 3, d)
+    q[0] = corpus[17]
+    stats = {}
+    got = _oracle.scan_threaded(lambda lo, hi: corpus[lo:hi], n, q, k, slice_rows=1000, threads=4, stats=stats)
+    assert stats["slices"] == 5
+    for qi in range(3):
+        rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, -1.0)
+        assert np.array_equal(got[qi][0], rows) and np.array_equal(got[qi][1].view(np.uint32), sims.view(np.uint32))
+    got = _oracle.scan_threaded(lambda lo, hi: corpus[lo:hi], n, q, k, metric="l2", thr=0.1, slice_rows=700, threads=3)
+    for qi in range(3):
+        rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, 0.1)
+        assert np.array_equal(got[qi][0], rows) and np.array_equal(got[qi][2].view(np.uint32), dist.view(np.uint32))
+        assert np.array_equal(got[qi][1].view(np.uint32), sims.view(np.uint32))

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import _cases
+import _oracle
 from yams_amd import _lib
 from yams_amd._lib import (SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER,
                            FLAG_RECORD_PATH, FLAG_WIDE_TILE)
@@ -551,14 +552,22 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     acc.scan_topk_device(view, tq2.data_ptr(), len(qsel), k, -1.0, metric, s2.data_ptr(), r2.data_ptr(),
                          c2.data_ptr(), None, None, flags=FLAG_FORCE_EXACT)
     assert torch.equal(r2, r[qsel]) and torch.equal(s2, s[qsel])
-    # and against the CPU oracle on a regenerated corpus for a few queries
+    # and against the CPU oracle (all host cores, row slices of the very tensor the GPU scanned,
+    # comparator merge: tests/_oracle.py scan_threaded == one oracle call over the whole corpus)
     if n_oracle_queries:
-        corpus = oracle.synth_rows(42, 0, n, d)
-        queries = oracle.synth_rows(42, n, nq, d)
-        for qi in list(range(nq))[:n_oracle_queries]:
-            rows_o, sims_o, _, _ = oracle.scan_cosine(corpus, queries[qi], k, -1.0)
-            assert np.array_equal(r[qi].cpu().numpy(), rows_o)
-            assert np.array_equal(s[qi].cpu().numpy().view(np.uint32), sims_o.view(np.uint32))
+        qsel_o = [int(x) for x in np.linspace(0, nq - 1, n_oracle_queries).round()]
+        queries = tq[qsel_o].cpu().numpy()
+        # the device generator is the oracle's Philox recipe: spot-check a slice at the far end
+        lo = max(0, n - 1000)
+        assert np.array_equal(tc[lo:n].cpu().numpy().view(np.uint32), oracle.synth_rows(42, lo, n - lo, d).view(np.uint32))
+        ref = _oracle.scan_threaded(lambda a, b: tc[a:b].cpu().numpy(), n, queries, k,
+                                    metric="l2" if metric == SCAN_L2 else "cosine", thr=-1.0)
+        rr, ss, dd = r.cpu().numpy(), s.cpu().numpy(), dist.cpu().numpy()
+        for j, qi in enumerate(qsel_o):
+            assert np.array_equal(rr[qi], ref[j][0]), (qi, rr[qi][:8], ref[j][0][:8])
+            assert np.array_equal(ss[qi].view(np.uint32), ref[j][1].view(np.uint32)), qi
+            if metric == SCAN_L2:
+                assert np.array_equal(dd[qi].view(np.uint32), ref[j][2].view(np.uint32)), qi
 
 
 def test_full_size_config2_1Mx384_cosine_top100_q256(acc, oracle):
@@ -566,7 +575,28 @@ def test_full_size_config2_1Mx384_cosine_top100_q256(acc, oracle):
 
 
 def test_full_size_config3_10Mx768_l2_top100_q1024(acc, oracle):
-    _full_size(acc, oracle, 10_000_000, 768, 1024, 100, SCAN_L2, n_oracle_queries=0)
+    _full_size(acc, oracle, 10_000_000, 768, 1024, 100, SCAN_L2, n_oracle_queries=2)
+
+
+def test_full_size_config4_shard_12p5Mx768_cosine_top100_q1024(acc, oracle):
+    """One row shard of BASELINE config 4 (100M x 768 over 8 GPUs) = the bench.py workload: the
+    bf16-shadow filter at Q = 1024 over 12.5M rows, three queries against the oracle over the full shard."""
+    _full_size(acc, oracle, 12_500_000, 768, 1024, 100, SCAN_COSINE, n_oracle_queries=3)
+
+
+def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle):
+    """BASELINE config 1: the reference's own CPU-runnable case — 10 000 x 384, k = 10, one query
+    per call, data from ITS recipe (std::mt19937(42), U(-1,1), fp32 normalise; corpus first, then
+    the queries from the same stream: tests/benchmarks/vector_backend_engine_compare.cpp:83-107,
+    251-253), here through the device path: every query as its own batch, then all in one batch."""
+    n, d, k, nq = 10_000, 384, 10, 16
+    corpus = oracle.mt19937_rows(42, 0, n, d)
+    queries = oracle.mt19937_rows(42, n, nq, d)
+    for qi in range(nq):
+        r = check(acc, oracle, corpus, queries[qi], k, thr=0.0, expect_path=0)   # the reference bench passes 0.0
+        assert r.counts[0] == k and r.diag["exact_fallback_queries"] == 0
+    check(acc, oracle, corpus, queries, k, thr=-1.0, expect_path=0)
+    check(acc, oracle, corpus, queries[:1], k, thr=-1.0, flags=FLAG_FORCE_EXACT, expect_path=1)
 
 
 # ---- the plugin vtable door ------------------------------------------------------------------------
