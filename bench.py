@@ -7,15 +7,16 @@ row-sharded over the GPUs of one node; ingest GB/s (SHA-256 + CDC) reported alon
 Workload per GPU (weak scaling in corpus size): one 12.5M x 768 fp32 row shard of
 BASELINE config 4 (100M x 768 cosine top-100 over 8 GPUs), query batch 1024 — at N GPUs the job
 searches N x 12.5M rows; N = 8 is the headline configuration.  A "step" = one query batch: every
-rank scans its shard, one RCCL all-gather moves the per-shard top-k, every rank merges.
+rank scans its shard, one RCCL all-gather moves the per-shard top-k, every rank merges (collective +
+merge of batch i run on a side stream under the sweep of batch i+1).
 `value` is the whole-job rate in the unit of the metric — queries/s against the 100M x 768 headline
 corpus: (rows scored x queries) / s / 1e8.  At N = 8 the job holds exactly those 100M rows and
 `value` is its measured QPS (batch / step time); at N < 8 the GPUs hold N/8 of the corpus and the
 same aggregate rate counts for N/8 of a headline query, so `value` grows with N when per-GPU work
 is fixed (weak scaling).  `qps_on_resident_corpus` is batch / step time on the rows actually
-resident (59 k at every N: the searched corpus grows N-fold instead).
+resident.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE: starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -29,17 +30,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from yams_amd import dist as ydist  # noqa: E402
-from yams_amd.accel import Accel, cdc_config  # noqa: E402
-from yams_amd._lib import SCAN_COSINE  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak (NOT the 2:1-sparse 5 PF)
 BF16_PASSES = 3                # hi*hi + hi*lo + lo*hi per algorithmic multiply-add
 PEAK_HBM_GBPS = 8000.0
+INT_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one 32-bit integer wave-instruction per 4 cycles
 HEADLINE_ROWS = 100_000_000     # BASELINE.json metric: 100M x 768 (= 8 shards of the default --rows-per-gpu)
 
 
@@ -54,6 +49,8 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-hbm-leg", action="store_true")
+    ap.add_argument("--oracle-queries", type=int, default=None, help="queries checked against the oracle over the whole resident corpus (default 4 at N=1, 2 at N>1; 0 = skip)")
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
@@ -65,46 +62,61 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_scan(acc, tc, tq, rows_total, dim, k, seed_rows=1_250_000, n_queries=16):
-    """The oracle (scalar fp64 restatement of sqlite_vec_backend.cpp:4204-4331) timed on this
-    box's host cores on a bounded sample of the same workload; also the recall check."""
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: start N ranks (one per GPU) under
+    torch.distributed.run on this node and pass their output through; rank 0 prints the JSON line."""
+    from yams_amd import dist as ydist
+    return ydist.launch_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]).returncode
+
+
+def oracle_mod():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
+    return _oracle
+
+
+def cpu_baseline_scan(tc, tq, rows_total, k, seed_rows=1_250_000):
+    """The oracle (scalar fp64 restatement of sqlite_vec_backend.cpp:4204-4331) timed on this box's
+    host cores on a bounded, host-resident sample of the same workload: single-thread (how the
+    reference runs a query) and one query per thread on all cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    _oracle = oracle_mod()
     o = _oracle.oracle()
     n_s = min(seed_rows, rows_total)
     corpus = tc[:n_s].cpu().numpy()
-    queries = tq[:n_queries].cpu().numpy()
+    threads = min(_oracle.host_threads(), tq.shape[0])
+    queries = tq[:max(threads, 4)].cpu().numpy()
+    n1 = 4
     t0 = time.perf_counter()
-    ref = [o.scan_cosine(corpus, queries[i], k, -1.0) for i in range(n_queries)]
-    dt = time.perf_counter() - t0
-    qps_slice = n_queries / dt
-    qps_full = qps_slice * n_s / HEADLINE_ROWS             # same unit as `value`: queries/s over 100M rows
-    # recall@k of the device path against the oracle on the same slice (outside the timed region)
-    r = acc.scan_topk(acc.corpus_view(tc.data_ptr(), n_s, dim), queries, k, -1.0, SCAN_COSINE)
-    inter = sum(len(set(r.rows[i, :k].tolist()) & set(ref[i][0].tolist())) for i in range(n_queries))
-    recall = inter / float(n_queries * k)
-    exact = all(np.array_equal(r.rows[i], ref[i][0]) and
-                np.array_equal(r.scores[i].view(np.uint32), ref[i][1].view(np.uint32))
-                for i in range(n_queries))
-    return {"value": qps_full, "unit": "QPS", "cores": 1, "kind": "port",
-            "sample": f"{n_queries} queries x first {n_s} rows of the same shard, scalar fp64 "
-                      f"oracle scan, 1 thread, {dt:.1f} s; scaled by {n_s}/{HEADLINE_ROWS} to queries/s over "
-                      f"the 100M-row headline corpus, the unit of `value` ({qps_slice * n_s / rows_total:.4f} QPS on "
-                      f"one {rows_total}-row shard; SQLite row fetch of the real reference excluded: upper bound)",
-            "host_cores_available": os.cpu_count()}, recall, exact
+    for i in range(n1):
+        o.scan_cosine(corpus, queries[i], k, -1.0)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda i: o.scan_cosine(corpus, queries[i], k, -1.0), range(threads)))
+    dtn = time.perf_counter() - t0
+    scale = n_s / HEADLINE_ROWS                        # same unit as `value`: queries/s over 100M rows
+    return {"value": threads / dtn * scale, "unit": "QPS", "cores": threads, "kind": "port",
+            "sample": f"one query per thread x first {n_s} rows of the same shard (host-resident), scalar fp64 oracle "
+                      f"scan, {threads} threads, {dtn:.1f} s; scaled by {n_s}/{HEADLINE_ROWS}",
+            "sample_rows": n_s, "sample_queries": threads, "sample_seconds": dtn, "scaled_by": scale,
+            "qps_on_one_shard": threads / dtn * n_s / rows_total,
+            "single_thread": {"value": n1 / dt1 * scale, "cores": 1, "sample_queries": n1, "sample_seconds": dt1,
+                              "qps_on_one_shard": n1 / dt1 * n_s / rows_total},
+            "host_cores_available": os.cpu_count(),
+            "note": "SQLite row fetch of the real reference excluded (sqlite_vec_backend.cpp cannot be built here): upper bound"}
 
 
-def ingest_cpu_baseline(seed, blen, n_sample=384):
+def ingest_cpu_baseline(seed, blen, n_sample=96):
     """The reference's own translation units (oracle/_ref: StreamingChunker::chunkData incl. the
-    per-chunk SHA-256, + SHA256Hasher::hash of the whole blob) on one host core, on a bounded
-    sample of the same Philox blobs; falls back to the plain-C port when _ref did not travel."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _oracle
+    per-chunk SHA-256, + SHA256Hasher::hash of the whole blob), one blob per call: single-thread and
+    one blob per thread on all host cores; falls back to the plain-C port when _ref did not travel."""
+    from concurrent.futures import ThreadPoolExecutor
+    _oracle = oracle_mod()
     o = _oracle.oracle()
     r = _oracle.ref()
-    blobs = [o.synth_bytes(seed, b, 0, blen) for b in range(n_sample)]
-    t0 = time.perf_counter()
-    for b in blobs:
+
+    def one(b):
         if r is not None:
             r.chunks(b, "streaming", with_hashes=True)
             r.sha256_hex(b)
@@ -113,15 +125,30 @@ def ingest_cpu_baseline(seed, blen, n_sample=384):
             for x, y in zip(off, sz):
                 o.sha256_hex(b[int(x):int(x + y)])
             o.sha256_hex(b)
-    dt = time.perf_counter() - t0
-    return {"value": n_sample * blen / dt / 1e9, "unit": "GB/s", "cores": 1,
+
+    threads = _oracle.host_threads()
+    blobs = [o.synth_bytes(seed, b, 0, blen) for b in range(min(n_sample, 32))]
+    t0 = time.perf_counter()
+    for b in blobs:
+        one(b)
+    dt1 = time.perf_counter() - t0
+    n_all = max(threads * 2, 32)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda i: one(blobs[i % len(blobs)]), range(n_all)))
+    dtn = time.perf_counter() - t0
+    return {"value": n_all * blen / dtn / 1e9, "unit": "GB/s", "cores": threads,
             "kind": "reference" if r is not None else "port",
-            "sample": f"{n_sample} x {blen >> 20} MiB Philox blobs, StreamingChunker defaults + per-chunk and "
-                      f"whole-blob SHA-256, 1 thread, {dt:.1f} s"}
+            "sample": f"{n_all} x {blen >> 20} MiB Philox blobs, StreamingChunker defaults + per-chunk and "
+                      f"whole-blob SHA-256, one blob per thread, {threads} threads, {dtn:.1f} s",
+            "sample_seconds": dtn,
+            "single_thread": {"value": len(blobs) * blen / dt1 / 1e9, "cores": 1, "sample_blobs": len(blobs),
+                              "sample_seconds": dt1}}
 
 
-def ingest_leg(acc, gib, seed):
+def ingest_leg(acc, torch, gib, seed):
     """SHA-256 + CDC over device-resident Philox blobs (4 MiB each, product-default chunker)."""
+    from yams_amd.accel import cdc_config
     blen = 4 << 20
     free_b, _ = torch.cuda.mem_get_info()
     gib = min(gib, max(1.0, (free_b * 0.70) / (1 << 30) / 1.2))   # blobs + bitmap/slot workspace
@@ -143,16 +170,35 @@ def ingest_leg(acc, gib, seed):
     cdc_ms, _ = acc.kernel_ms("cdc_candidates")
     acc.enable_timing(False)
     total = n_blobs * blen
+    # bit-exactness of the timed call's own output on a spread of blobs (all host cores)
+    verified = verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check=64)
     cpu = ingest_cpu_baseline(seed, blen)
+    n_chunks = int(res.n_chunks)
+    # Roofline: the call is bound by 32-bit integer VALU issue, not by HBM.
+    # Instruction model per wave-instruction (64 lanes): one SHA-256 block per lane = 1400 VALU
+    # (sha256_batch_kernel; every byte is hashed twice: chunk digest + blob digest, plus one padding
+    # block per message), CDC candidates = 9 VALU per byte per lane-unit of 32 B -> 9/64 per byte.
+    blocks = 2.0 * total / 64.0 + n_chunks + n_blobs
+    wave_instr = blocks / 64.0 * 1400.0 + total * 9.0 / 64.0
+    floor_s = wave_instr / INT_VALU_WAVE_INSTR_PER_S
     out = {"value": total / dt / 1e9, "unit": "GB/s", "bytes": total, "blobs": n_blobs, "cpu_baseline": cpu,
-           "blob_bytes": blen, "chunks": int(res.n_chunks), "ms": dt * 1e3,
+           "blob_bytes": blen, "chunks": n_chunks, "ms": dt * 1e3,
            "sha256_kernel_ms": sha_ms, "cdc_candidates_kernel_ms": cdc_ms,
            "chunker": "StreamingChunker defaults (min 16 KiB, max 1 MiB, mask 0x1FFF)",
-           "digests": "per-chunk + whole-blob (every byte hashed twice)"}
+           "digests": "per-chunk + whole-blob (every byte hashed twice)",
+           "bit_exact_vs_cpu_sample": verified,
+           "roofline": {"bound": "valu-issue (int32)", "achieved": total / dt / 1e9, "peak": total / floor_s / 1e9,
+                        "unit": "GB/s", "frac": floor_s / dt,
+                        "model": "wave-instructions = SHA blocks/64 x 1400 + bytes x 9/64; floor = that x 4 cycles / "
+                                 "(1024 SIMDs x 2.4 GHz)", "model_wave_instructions": wave_instr,
+                        "pmc_cross_check": "profiles/r01_ingest_pmc.json (SQ_INSTS_VALU 1.016e11 for the same call: "
+                                           "0.79 of the issue roof; builder run)",
+                        "hbm_view": {"bytes_read_per_call_est": 3.0 * total, "achieved_GBps": 3.0 * total / dt / 1e9,
+                                     "peak_GBps": PEAK_HBM_GBPS}}}
     # the dedup lookup that follows in ContentStore::store (one exists() per chunk in the reference):
     # all chunk digests of the batch against an empty device set, then again (everything known)
     try:
-        n = int(res.n_chunks)
+        n = n_chunks
         dset = acc.dedup_set(n)
         flags = torch.empty(n, dtype=torch.uint8, device="cuda")
         t0 = time.perf_counter()
@@ -170,12 +216,52 @@ def ingest_leg(acc, gib, seed):
     return out
 
 
+def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check):
+    """Blobs spread over the timed call's result, each regenerated on the CPU (Philox), chunked by
+    the oracle and hashed with hashlib; returns {"blobs": n, "ok": bool}."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    _oracle = oracle_mod()
+    o = _oracle.oracle()
+    out = acc.fetch_ingest(res, n_blobs)
+    first, co, cs, cd, bd = out["blob_first"], out["chunk_offset"], out["chunk_size"], out["chunk_digest"], out["blob_digest"]
+    pick = sorted(set(int(x) for x in np.linspace(0, n_blobs - 1, min(n_check, n_blobs)).round()))
+
+    def verify(bi):
+        blob = o.synth_bytes(seed, bi, 0, blen)
+        ooff, osz = o.chunks(blob, "streaming")
+        lo, hi = int(first[bi]), int(first[bi + 1])
+        if hi - lo != len(ooff) or not (np.array_equal(co[lo:hi], ooff) and np.array_equal(cs[lo:hi], osz)):
+            return False
+        mv = memoryview(blob)
+        if bd[bi].tobytes() != hashlib.sha256(mv).digest():
+            return False
+        return all(cd[j].tobytes() == hashlib.sha256(mv[int(co[j]):int(co[j] + cs[j])]).digest() for j in range(lo, hi))
+
+    with ThreadPoolExecutor(max_workers=_oracle.host_threads(64)) as ex:
+        ok = all(ex.map(verify, pick))
+    return {"blobs": len(pick), "ok": bool(ok)}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import numpy as np
+    import torch
+    from yams_amd import dist as ydist
+    from yams_amd.accel import Accel
+    from yams_amd._lib import SCAN_COSINE
+
     if a.single_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = ydist.init_from_env(a.dist_backend)
     assert world == max(1, a.gpus) or world == 1, (world, a.gpus)
+    if not a.single_device and local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({torch.cuda.device_count()} visible); "
+                         "one rank per GPU (use --single-device --dist-backend gloo for a dry run)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     acc = Accel(local, torch.cuda.current_stream().cuda_stream)
@@ -188,12 +274,6 @@ def main():
     acc.synth_rows(a.seed, row_base, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device=dev)
     acc.synth_rows(a.seed, 1 << 40, nq, d, tq.data_ptr())        # same queries on every rank
-    s_loc = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    r_loc = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    c_loc = torch.empty(nq, dtype=torch.int32, device=dev)
-    s_out = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    r_out = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    c_out = torch.empty(nq, dtype=torch.int32, device=dev)
     # the filter shadow of the mirror (bf16 copy + squared norms), built once when rows are uploaded
     # (plugin.cpp corpus_append does the same); part of the resident index, not of the timed step
     tb = tn = None
@@ -209,50 +289,99 @@ def main():
                            rows_nsq_ptr=tn.data_ptr() if tn is not None else None)
     acc.synchronize()
 
-    def merge_fn(g, w):
-        acc.merge_topk_device(w, nq, k, -1.0, SCAN_COSINE, g["scores"].data_ptr(), g["rows"].data_ptr(),
-                              g["counts"].data_ptr(), None, None, s_out.data_ptr(), r_out.data_ptr(),
-                              c_out.data_ptr(), None)
-        return s_out, r_out, c_out
+    # the step after the scan: all-gather + merge, two batches in flight (yams_amd/dist.py)
+    pipe = ydist.GatherPipeline(nq, k, dev, depth=2)
+    if world > 1:
+        acc_merge = Accel(local, pipe.side_stream_ptr())        # merge kernel on the side stream
+
+        def merge_fn(g, out):
+            acc_merge.merge_topk_device(world, nq, k, -1.0, SCAN_COSINE, g["scores"].data_ptr(), g["rows"].data_ptr(),
+                                        g["counts"].data_ptr(), None, None, out["scores"].data_ptr(),
+                                        out["rows"].data_ptr(), out["counts"].data_ptr(), None)
+        pipe.merge_fn = merge_fn
 
     scan_flags = 4 if a.f32_filter else (8 if a.split_filter else 0)   # YAMS_SCAN_FLAG_F32_FILTER / _SPLIT_FILTER
+    batch_no = [0]
 
     def step(want_diag=False):
+        slot = batch_no[0] % pipe.depth
+        batch_no[0] += 1
+        pipe.wait(slot)                 # the merge of batch i-2 has long finished: its record is free
+        loc = pipe.local(slot)
         # (the call returns after its own host sync on the query status words: results are complete)
-        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s_loc.data_ptr(),
-                                    r_loc.data_ptr(), c_loc.data_ptr(), flags=scan_flags, want_diag=want_diag)
-        if world > 1:
-            ydist.gather_and_merge({"scores": s_loc, "rows": r_loc, "counts": c_loc}, k, merge_fn)
-        return diag
+        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
+                                    loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
+                                    want_diag=want_diag)
+        pipe.launch(slot)               # collective + merge on the side stream, under the next sweep
+        return diag, slot
 
     def fence():
+        pipe.drain()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
+    fence()
     acc.enable_timing(True)
     fence(); t0 = time.perf_counter()
+    last_slot = 0
     for _ in range(a.steps):
-        step()
+        _, last_slot = step()
     fence(); dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    merge_ok = None
-    if world > 1:
-        # the merged list must start with the best hit any shard found, be sorted, and stay in range
-        mx = s_loc[:, 0].clone()
-        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-        merge_ok = bool(torch.equal(mx, s_out[:, 0]) and bool((s_out[:, 1:] <= s_out[:, :-1]).all())
-                        and bool(((r_out >= 0) & (r_out < total_rows)).all()) and bool((c_out == k).all()))
     filt_ms, filt_n = acc.kernel_ms("scan_filter")
     samp_ms, samp_n = acc.kernel_ms("scan_sample")
     acc.enable_timing(False)
+    res = pipe.result(last_slot)          # the merged top-k of the LAST TIMED step
+    r_timed = res["rows"].cpu().numpy().copy()
+    s_timed = res["scores"].cpu().numpy().copy()
+    c_timed = res["counts"].cpu().numpy().copy()
+
+    # ---- the timed configuration against the oracle over the whole resident corpus ----------------
+    n_oq = a.oracle_queries if a.oracle_queries is not None else (4 if world == 1 else 2)
+    n_oq = min(n_oq, nq)
+    check = None
+    if n_oq > 0:
+        _oracle = oracle_mod()
+        qsel = [int(x) for x in np.linspace(0, nq - 1, n_oq).round()]
+        qh = tq[qsel].cpu().numpy()
+        stats = {}
+        threads = max(1, _oracle.host_threads() // world)
+        t_or = time.perf_counter()
+        part = _oracle.scan_threaded(lambda lo, hi: tc[lo:hi].cpu().numpy(), n, qh, k, slice_rows=32768,
+                                     threads=min(threads, 96), stats=stats)
+        t_or = time.perf_counter() - t_or
+        mine = [(rows + row_base, sims) for rows, sims in part]
+        if world > 1:
+            allp = [None] * world
+            torch.distributed.all_gather_object(allp, mine)
+        else:
+            allp = [mine]
+        if rank == 0:
+            inter, exact = 0, True
+            for j, qi in enumerate(qsel):
+                rows = np.concatenate([p[j][0] for p in allp]); sims = np.concatenate([p[j][1] for p in allp])
+                order = np.lexsort((rows, -sims.astype(np.float64)))[:k]      # (similarity desc, row id asc)
+                rows, sims = rows[order], sims[order]
+                inter += len(set(r_timed[qi, :k].tolist()) & set(rows.tolist()))
+                exact &= bool(c_timed[qi] == len(rows) and np.array_equal(r_timed[qi, :len(rows)], rows)
+                              and np.array_equal(s_timed[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+            check = {"recall_at_k": inter / float(n_oq * k), "bit_exact_vs_oracle": exact,
+                     "recall_checked_on": "timed configuration: the merged top-k of the last timed step "
+                                          f"({'bf16-shadow' if tb is not None else 'fp32-view'} filter, {total_rows} rows, "
+                                          f"Q={nq}) vs the scalar fp64 oracle over all {total_rows} resident rows",
+                     "oracle_queries": n_oq, "oracle_query_ids": qsel, "oracle_seconds": t_or,
+                     "oracle_threads_per_rank": stats.get("threads"), "oracle_scan_thread_seconds": stats.get("scan_thread_s")}
+
     # diagnostics of the same batch, outside the timed region (every step scans the same inputs)
-    fallbacks = step(want_diag=True)["exact_fallback_queries"] * a.steps
+    diag, _ = step(want_diag=True)
+    fence()
+    fallbacks = diag["exact_fallback_queries"] * a.steps
     ms_per_step = dt / a.steps * 1e3
     qps_resident = nq * a.steps / dt                       # queries/s against the rows resident on the N GPUs
     # `value`: queries/s against the 100M-row headline corpus = aggregate (rows x queries)/s / 1e8.
@@ -260,9 +389,8 @@ def main():
     # aggregate rate covers N/8 of the corpus, so the whole-job number grows with N (weak scaling).
     qps = qps_resident * (total_rows / HEADLINE_ROWS)
 
-    if rank != 0:
-        return
-    # ---- roofline of the dominant kernel (the FILTER pass of the scan) -----------------------------
+    # ---- second roofline leg: the HBM-bound regime (Q = 64, narrow kernel form), N = 1 ------------
+    hbm_leg = None
     bf16 = (not a.f32_filter) and d % 16 == 0
     tr = 256 if bf16 else 128
     n_tiles = (n + tr - 1) // tr
@@ -270,6 +398,36 @@ def main():
     stride = max(1, n_tiles // ((s_target + tr - 1) // tr))
     n_sample = (n_tiles + stride - 1) // stride
     filt_rows = min(n, (n_tiles - n_sample) * tr)
+    if world == 1 and not a.no_hbm_leg and tb is not None and bf16 and nq >= 64:
+        q64 = 64
+        s64 = torch.empty((q64, k), dtype=torch.float32, device=dev)
+        r64 = torch.empty((q64, k), dtype=torch.int64, device=dev)
+        c64 = torch.empty(q64, dtype=torch.int32, device=dev)
+
+        def step64():
+            acc.scan_topk_device(view, tq.data_ptr(), q64, k, -1.0, SCAN_COSINE, s64.data_ptr(), r64.data_ptr(),
+                                 c64.data_ptr(), flags=scan_flags, want_diag=False)
+        for _ in range(max(2, a.warmup)):
+            step64()
+        acc.enable_timing(True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step64()
+        torch.cuda.synchronize(); dt64 = (time.perf_counter() - t1) / a.steps
+        f64_ms, f64_n = acc.kernel_ms("scan_filter")
+        acc.enable_timing(False)
+        byts = filt_rows * d * 2 + filt_rows * 4 + q64 * d * 2
+        same = bool(torch.equal(r64, res["rows"][:q64]) and torch.equal(s64, res["scores"][:q64]))
+        hbm_leg = {"bound": "hbm", "kernel": "scan_tiles_bf16n_kernel<FILTER,COSINE,2> (narrow form, Q <= 64)",
+                   "queries": q64, "achieved": byts / (f64_ms * 1e-3) / 1e9 if f64_ms else None, "peak": PEAK_HBM_GBPS,
+                   "unit": "GB/s", "frac": byts / (f64_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if f64_ms else None,
+                   "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n, "traffic": None,
+                   "ms_per_step": dt64 * 1e3, "qps_on_resident_corpus": q64 / dt64,
+                   "results_identical_to_the_q1024_run": same}
+
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel (the FILTER pass of the scan) -----------------------------
     flops = 2.0 * nq * d * filt_rows            # ALGORITHMIC flops of the contraction per launch
     ach_tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms else None
     passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
@@ -286,6 +444,7 @@ def main():
         kname = "scan_tiles_kernel<FILTER,COSINE> (v_mfma_f32_32x32x2_f32)"
         peak = PEAK_F32_MFMA_TFLOPS
     traffic = None
+    traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "scan_filter_pmc.json")
     if os.path.exists(pmc):
         try:
@@ -294,19 +453,21 @@ def main():
                     and j.get("bf16", False) == bf16 and j.get("passes", 3) == (passes if bf16 else 0) \
                     and j.get("shadow", False) == (tb is not None):
                 traffic = j.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/scan_filter_pmc.json ({j.get('round', '?')}, builder run: rocprofv3 --pmc FETCH_SIZE x2 " \
+                                 "gfx950 correction; NOT measured in this run)"
         except Exception:
             traffic = None
     row_bytes = 2 if (tb is not None and passes == 1 and bf16) else 4   # what the filter reads per element
     roofline = {"bound": "mfma", "kernel": kname, "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": (ach_tf / peak) if ach_tf else None, "traffic": traffic,
+                "frac": (ach_tf / peak) if ach_tf else None, "traffic": traffic, "traffic_source": traffic_source,
                 "launch_ms": filt_ms, "launches": filt_n, "flops_per_launch": flops,
                 "executed_mfma_tflops": (ach_tf * passes if bf16 else ach_tf) if ach_tf else None,
                 "mfma_peak_for_executed": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS,
                 "sample_pass_ms": samp_ms,
-                # the other floor of this kernel: one read of the filter rows from HBM per launch
                 "shadow_build_ms": shadow_ms,
-                "hbm_floor_view": {"algorithmic_bytes_per_launch": filt_rows * d * (2 if tb is not None and passes == 1 and bf16 else 4),
-                                   "achieved_GBps": (filt_rows * d * (2 if tb is not None and passes == 1 and bf16 else 4)) / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
+                # the other floor of this kernel: one read of the filter rows from HBM per launch
+                "hbm_floor_view": {"algorithmic_bytes_per_launch": filt_rows * d * row_bytes,
+                                   "achieved_GBps": (filt_rows * d * row_bytes) / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
                                    "peak_GBps": PEAK_HBM_GBPS},
                 "hbm_view": {"algorithmic_bytes_per_step": n * d * row_bytes + nq * d * 4 + nq * k * 12,
                              "achieved_GBps": (n * d * row_bytes + nq * d * 4 + nq * k * 12) / (ms_per_step * 1e-3) / 1e9,
@@ -320,34 +481,37 @@ def main():
            "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: "
                                   f"100Mx768 over 8 GPUs), query batch {nq}",
                       "rows_per_gpu": n, "corpus_rows": total_rows, "dim": d, "k": k, "query_batch": nq,
-                      "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge" if world > 1 else "single shard"},
+                      "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge (overlapped with the next sweep)" if world > 1 else "single shard"},
            "value_definition": "queries/s against the 100M x 768 headline corpus = (rows scored x queries)/s / 1e8; "
                                "equals qps_on_resident_corpus x corpus_rows / 1e8 (identical at N = 8)",
            "qps_on_resident_corpus": qps_resident,
            "row_queries_per_s": total_rows * nq * a.steps / dt,
            "exact_fallback_queries": fallbacks,
            "roofline": roofline}
-    if merge_ok is not None:
-        out["merged_topk_consistent"] = merge_ok
+    if hbm_leg is not None:
+        out["roofline_hbm_leg"] = hbm_leg
+    if check is not None:
+        out.update(check)
+    if world > 1:
+        out["collective"] = {"backend": torch.distributed.get_backend(), "bytes_per_rank": pipe.rec_bytes,
+                             "overlapped": pipe.side is not None and torch.distributed.get_backend() != "gloo"}
     # CPU baseline and the ingest leg: rank 0 at N = 1 only (at N > 1 the other ranks would sit in the
-    # final barrier for their ~25 s; the merged result is checked by `merged_topk_consistent` there)
+    # final barrier meanwhile)
     if not a.no_cpu_baseline and world == 1:
-        cb, recall, exact = cpu_baseline_scan(acc, tc, tq, n, d, k)
-        out["cpu_baseline"] = cb
-        out["recall_at_k"] = recall
-        out["bit_exact_vs_oracle_sample"] = exact
+        out["cpu_baseline"] = cpu_baseline_scan(tc, tq, n, k)
     if not a.no_ingest and world == 1:
-        del tc
+        del tc, tb, tn, view, pipe, res
         acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg
         acc.ctx = None
         acc = Accel(local, torch.cuda.current_stream().cuda_stream)
         torch.cuda.empty_cache()
-        out["ingest"] = ingest_leg(acc, a.ingest_gib, a.seed)
+        out["ingest"] = ingest_leg(acc, torch, a.ingest_gib, a.seed)
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
     main()
+    import torch
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

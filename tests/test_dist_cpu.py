@@ -1,9 +1,10 @@
-"""N>1 path on CPU: world_size-2 gloo job through yams_amd/dist.py (shard bounds, rendezvous from
-the torchrun environment, all-gather of per-shard top-k, merge == single-shard oracle)."""
+"""N>1 path on CPU: world_size-2 and -4 gloo jobs through yams_amd/dist.py — shard bounds, the rank
+launcher bench.py uses for `--gpus N`, rendezvous from the torchrun environment, the two-slot
+all-gather + merge pipeline; merged result == single-shard oracle."""
 import json
 import os
-import subprocess
-import sys
+
+import pytest
 
 from yams_amd import dist as ydist
 
@@ -20,13 +21,11 @@ def test_shard_bounds_partition_rows():
     assert ydist.shard_bounds(100_000_000, 8)[1] == 12_500_000      # BASELINE config 4
 
 
-def test_world_size_2_gloo_sharded_search_matches_oracle():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611",
-           os.path.join(ROOT, "tests", "_dist_worker.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharded_search_matches_oracle(world, monkeypatch):
+    monkeypatch.setenv("YAMS_DIST_TEST_CPU", "1")
+    r = ydist.launch_ranks(os.path.join(ROOT, "tests", "_dist_worker.py"), world, [], capture=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["ok"] and out["world"] == 2 and out["bounds"] == [0, 1500, 3000]
+    assert out["ok"] and out["world"] == world and out["bounds"] == [3000 * g // world for g in range(world + 1)]

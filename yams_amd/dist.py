@@ -2,8 +2,10 @@
 
 The corpus never crosses xGMI: rank g owns rows [bounds[g], bounds[g+1]); every rank scores the
 same query batch against its shard (fp64-exact per-shard top-k), then ONE all-gather moves
-Q*k*(4+8+4) bytes per rank and every rank merges the gathered lists on its own device
-(yams_scan_merge_topk_device).  torch is plumbing here: tensors + the collective."""
+Q*k*(4+8)+4Q bytes per rank and every rank merges the gathered lists on its own device
+(yams_scan_merge_topk_device).  The collective and the merge of batch i run on a side stream while
+the sweep of batch i+1 runs on the scan stream (`GatherPipeline`).  torch is plumbing here:
+tensors, streams and the collective."""
 from __future__ import annotations
 
 import os
@@ -32,53 +34,125 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
-def _layout(local):
-    """Byte layout of one rank's record: the given tensors back to back, 16-byte aligned."""
+def launch_ranks(script: str, nproc: int, argv: list[str], capture: bool = False, timeout: float | None = None):
+    """Start `nproc` ranks of `script` on this node under torch.distributed.run (one rank per GPU;
+    rendezvous on 127.0.0.1 and a free port).  bench.py uses it when `--gpus N` is given without a
+    torchrun environment; the CPU tests use it for the gloo jobs.  Returns the CompletedProcess."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    return subprocess.run(cmd, env=env, capture_output=capture, text=capture, timeout=timeout)
+
+
+def _layout(spec):
+    """Byte layout of one rank's record: the (name, nbytes) parts back to back, 16-byte aligned."""
     off, lay = 0, []
-    for name, t in local.items():
-        if t is None:
-            continue
-        nb = t.numel() * t.element_size()
+    for name, nb in spec:
         lay.append((name, off, nb))
         off += (nb + 15) & ~15
     return lay, off
 
 
-def gather_and_merge(local, k: int, merge_fn):
-    """local = dict(scores [Q,k] f32, rows [Q,k] i64 (global ids), counts [Q] i32, optional
-    dist [Q,k] f32, ranks [Q,k] i32) as torch tensors.  Returns merge_fn(gathered, world) where
-    gathered[name] has shape [world, ...].  With world == 1 no collective is issued; otherwise the
-    tensors are packed into one byte record per rank and ONE all-gather moves them (a few small
-    collectives would each pay the launch + ring latency)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    gathered = {name: None for name in local}
-    if world == 1:
-        for name, t in local.items():
-            if t is not None:
-                gathered[name] = t.contiguous().unsqueeze(0)
-        return merge_fn(gathered, world)
-    lay, total = _layout(local)
-    dev = next(t.device for t in local.values() if t is not None)
-    rec = torch.empty(total, dtype=torch.uint8, device=dev)
-    for name, off, nb in lay:
-        t = local[name].contiguous()
-        rec[off:off + nb].view(t.dtype).view(t.shape).copy_(t)
-    if dist.get_backend() == "gloo":       # CPU tests / single-GPU dry runs: the collective runs on the host
-        src = rec.cpu()
-        parts = [torch.empty_like(src) for _ in range(world)]
-        dist.all_gather(parts, src)
-        out = torch.stack(parts, 0).to(dev)
-    else:
-        out = torch.empty((world, total), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, rec)
-    for name, off, nb in lay:
-        t = local[name]
-        gathered[name] = out[:, off:off + nb].contiguous().view(t.dtype).view((world,) + tuple(t.shape))
-    if torch.cuda.is_available() and dist.get_backend() != "gloo":
-        # the merge kernel runs on the accelerator context's stream, which need not be torch's
-        # current stream (a context created on the default stream owns a private one): make the
-        # gathered tensors visible to it
-        torch.cuda.current_stream().synchronize()
-    return merge_fn(gathered, world)
+class GatherPipeline:
+    """The step after the per-shard scan, `depth` batches in flight.
+
+    Slot s = batch i % depth owns one packed record per rank — [scores f32 [Q,k] | rows i64 [Q,k] |
+    counts i32 [Q] (| dist f32 [Q,k])] — that the scan writes IN PLACE (`local(s)` hands out the
+    views), so nothing is copied before the collective.  `launch(s)` issues, on a side stream,
+    ONE all-gather of the record (RCCL: all_gather_into_tensor; gloo dry runs: the same call on a
+    host copy) and then `merge_fn(gathered views, merged views)` — the k-way merge kernel on a
+    context bound to that side stream.  The caller's next sweep runs meanwhile on its own stream;
+    `wait(s)` blocks the host until slot s is merged (before its record is reused, or to read it).
+    With world == 1 there is no collective and no merge: the merged views ARE the local views."""
+
+    def __init__(self, nq: int, k: int, device, with_dist: bool = False, depth: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        self.nq, self.k, self.depth, self.device = nq, k, depth, device
+        spec = [("scores", nq * k * 4), ("rows", nq * k * 8), ("counts", nq * 4)]
+        if with_dist:
+            spec.append(("dist", nq * k * 4))
+        self.lay, self.rec_bytes = _layout(spec)
+        self.dtypes = {"scores": torch.float32, "rows": torch.int64, "counts": torch.int32, "dist": torch.float32}
+        self.shapes = {"scores": (nq, k), "rows": (nq, k), "counts": (nq,), "dist": (nq, k)}
+        self.rec = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        on_gpu = device.type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if on_gpu and self.world > 1 else None
+        if self.world > 1:
+            self.gathered = [torch.zeros((self.world, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.merged = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.done = [torch.cuda.Event() if on_gpu else None for _ in range(depth)]
+            self.busy = [False] * depth
+        self.merge_fn = None
+
+    # -- views ---------------------------------------------------------------------------------------
+    def _views(self, buf, lead=()):
+        out = {}
+        for name, off, nb in self.lay:
+            t = buf[..., off:off + nb]
+            out[name] = t.view(self.dtypes[name]).view(tuple(lead) + self.shapes[name])
+        return out
+
+    def local(self, slot):
+        """Tensors the scan of this slot's batch writes (views into the slot's record)."""
+        return self._views(self.rec[slot])
+
+    def result(self, slot):
+        """Merged top-k of the slot's batch (valid after wait(slot))."""
+        return self.local(slot) if self.world == 1 else self._views(self.merged[slot])
+
+    def side_stream_ptr(self):
+        return self.side.cuda_stream if self.side is not None else None
+
+    # -- the step -------------------------------------------------------------------------------------
+    def launch(self, slot):
+        """Collective + merge of the slot's batch.  The scan that filled the record has completed on
+        the host's view (yams_scan_topk_device synchronises its stream before returning)."""
+        if self.world == 1:
+            return
+        torch, dist = self.torch, self.dist
+        rec, out = self.rec[slot], self.gathered[slot]
+        if self.backend == "gloo":      # CPU tests / single-GPU dry runs: the collective runs on the host
+            src = rec.cpu()
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src)
+            out.copy_(torch.stack(parts, 0))
+            if self.side is not None:
+                torch.cuda.current_stream().synchronize()
+            self.merge_fn(self._views(out, (self.world,)), self._views(self.merged[slot]))
+            if self.done[slot] is not None:
+                self.done[slot].record(self.side)
+            self.busy[slot] = True
+            return
+        with torch.cuda.stream(self.side):
+            work = dist.all_gather_into_tensor(out, rec, async_op=True)
+            work.wait()                 # the side stream waits for RCCL's stream; the host does not
+            self.merge_fn(self._views(out, (self.world,)), self._views(self.merged[slot]))
+            self.done[slot].record(self.side)
+        self.busy[slot] = True
+
+    def wait(self, slot):
+        if self.world == 1 or not self.busy[slot]:
+            return
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()
+        self.busy[slot] = False
+
+    def drain(self):
+        for s in range(self.depth):
+            self.wait(s)
+        if self.side is not None:
+            self.side.synchronize()
