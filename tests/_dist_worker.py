@@ -40,6 +40,7 @@ if use_gpu:
     acc = Accel(local, torch.cuda.current_stream().cuda_stream)
     acc_merge = Accel(local, pipe.side_stream_ptr()) if world > 1 else acc
     tc = torch.from_numpy(corpus[lo:hi]).to(dev)
+    torch.cuda.synchronize()                   # the contexts run on their own (non-blocking) streams
     view = acc.corpus_view(tc.data_ptr(), hi - lo, d, row_base=lo)
 
     def merge_fn(g, out):                      # the product's merge kernel behind the collective
@@ -59,7 +60,22 @@ else:
 pipe.merge_fn = merge_fn
 
 ok = True
+bad = []
 batches = []
+
+
+def compare(bi, res, queries):
+    global ok
+    for qi in range(nq):
+        r, s, _, _ = o.scan_cosine(corpus, queries[qi], k, -1.0)
+        c = int(res["counts"][qi])
+        got_r = res["rows"][qi, :c].cpu().numpy(); got_s = res["scores"][qi, :c].cpu().numpy()
+        good = c == len(r) and np.array_equal(got_r, r) and np.array_equal(got_s.view(np.uint32), s.view(np.uint32))
+        if not good:
+            ok = False
+            bad.append({"rank": rank, "batch": bi, "query": qi, "count": c, "want_count": len(r),
+                        "got": got_r[:6].tolist(), "want": r[:6].tolist()})
+
 for bi in range(n_batches):                    # several batches in flight: slots are reused
     queries = o.synth_rows(5, (1 << 40) + bi * nq, nq, d)
     if bi == 0:
@@ -70,6 +86,7 @@ for bi in range(n_batches):                    # several batches in flight: slot
     loc = pipe.local(slot)
     if use_gpu:
         tq = torch.from_numpy(queries).to(dev)
+        torch.cuda.synchronize()
         acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
                              loc["rows"].data_ptr(), loc["counts"].data_ptr(), want_diag=False)
     else:
@@ -84,23 +101,16 @@ for bi in range(n_batches):                    # several batches in flight: slot
         pipe.wait(slot)
     res = pipe.result(slot)
     if bi % 2 == 0:
-        for qi in range(nq):
-            r, s, _, _ = o.scan_cosine(corpus, queries[qi], k, -1.0)
-            c = int(res["counts"][qi])
-            ok &= c == len(r) and np.array_equal(res["rows"][qi, :c].cpu().numpy(), r)
-            ok &= np.array_equal(res["scores"][qi, :c].cpu().numpy().view(np.uint32), s.view(np.uint32))
+        compare(bi, res, queries)
 pipe.drain()
 for bi in range(n_batches - pipe.depth, n_batches):   # the batches still resident in their slots
     if bi % 2 == 0 or bi < 0:
         continue
-    res = pipe.result(bi % pipe.depth)
-    for qi in range(nq):
-        r, s, _, _ = o.scan_cosine(corpus, batches[bi][qi], k, -1.0)
-        c = int(res["counts"][qi])
-        ok &= c == len(r) and np.array_equal(res["rows"][qi, :c].cpu().numpy(), r)
-        ok &= np.array_equal(res["scores"][qi, :c].cpu().numpy().view(np.uint32), s.view(np.uint32))
+    compare(bi, pipe.result(bi % pipe.depth), batches[bi])
 t = torch.tensor([1.0 if ok else 0.0])
 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+if bad:
+    print("MISMATCH " + json.dumps(bad[:4]), file=sys.stderr, flush=True)
 if rank == 0:
     print(json.dumps({"ok": bool(t.item() == 1.0), "world": world, "bounds": b, "gpu": bool(use_gpu),
                       "backend": backend, "merge": "merge_topk_kernel" if use_gpu else "python (test fallback)"}))

@@ -257,7 +257,21 @@ def ref():
 
 # ---- the oracle over all host cores ------------------------------------------------------------------
 def host_threads(limit: int | None = None) -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a
+    container that shows 256 CPUs may be allowed 16 CPU-seconds per second)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
     return max(1, min(n, limit) if limit else n)
 
 

@@ -20,7 +20,7 @@ def test_sharded_search_with_the_merge_kernel_behind_the_collective(world):
     r = ydist.launch_ranks(os.path.join(ROOT, "tests", "_dist_worker.py"), world, [], capture=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["ok"] and out["world"] == world and out["gpu"] and out["merge"] == "merge_topk_kernel"
+    assert out["ok"] and out["world"] == world and out["gpu"] and out["merge"] == "merge_topk_kernel", r.stderr[-3000:]
 
 
 def test_bench_self_launches_n_ranks_and_checks_the_merge_against_the_oracle():

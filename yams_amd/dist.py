@@ -96,6 +96,7 @@ class GatherPipeline:
             self.merged = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.done = [torch.cuda.Event() if on_gpu else None for _ in range(depth)]
             self.busy = [False] * depth
+            self._keep = [None] * depth
         self.merge_fn = None
 
     # -- views ---------------------------------------------------------------------------------------
@@ -103,6 +104,8 @@ class GatherPipeline:
         out = {}
         for name, off, nb in self.lay:
             t = buf[..., off:off + nb]
+            if lead:                # [world][record] -> dense [world][...] per field (the merge ABI's layout)
+                t = t.contiguous()
             out[name] = t.view(self.dtypes[name]).view(tuple(lead) + self.shapes[name])
         return out
 
@@ -130,9 +133,11 @@ class GatherPipeline:
             parts = [torch.empty_like(src) for _ in range(self.world)]
             dist.all_gather(parts, src)
             out.copy_(torch.stack(parts, 0))
+            g = self._views(out, (self.world,))
             if self.side is not None:
                 torch.cuda.current_stream().synchronize()
-            self.merge_fn(self._views(out, (self.world,)), self._views(self.merged[slot]))
+            self.merge_fn(g, self._views(self.merged[slot]))
+            self._keep[slot] = g        # (allocated on the current stream, read on the side stream)
             if self.done[slot] is not None:
                 self.done[slot].record(self.side)
             self.busy[slot] = True
