@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA dense peak (NOT the 2:1-sparse 5 PF)
+PEAK_I8_MFMA_TOPS = 5000.0     # int8 MFMA dense = 2x the bf16 rate (MI355X_MICROARCH.md: "I8 ... ~2x bf16 rate"; 10 POPS is the sparse figure)
 BF16_PASSES = 3                # hi*hi + hi*lo + lo*hi per algorithmic multiply-add
 PEAK_HBM_GBPS = 8000.0
 INT_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one 32-bit integer wave-instruction per 4 cycles
@@ -55,6 +56,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
     ap.add_argument("--no-shadow", action="store_true", help="bare fp32 corpus view: the single-pass filter converts rows in its loop")
+    ap.add_argument("--no-i8", action="store_true", help="no int8 shadow: the bf16 tier filters the large batches too")
     ap.add_argument("--split-filter", action="store_true", help="start with the split-bf16 (3-pass) filter instead of the single-pass bf16 one")
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
     ap.add_argument("--dist-backend", default=None, help="override the collective backend (gloo for dry runs)")
@@ -284,9 +286,20 @@ def main():
         acc.synchronize(); t_sh = time.perf_counter()
         acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
         acc.synchronize(); shadow_ms = (time.perf_counter() - t_sh) * 1e3
+    # the INT8 shadow (first filter tier of cosine batches > 128 queries), also built at upload time
+    t8 = tm8 = None
+    shadow_i8_ms = i8_mean_err = None
+    if tb is not None and not a.no_i8 and d % 64 == 0 and not a.f32_filter and not a.split_filter:
+        t8 = torch.empty((n, d), dtype=torch.int8, device=dev)
+        tm8 = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        acc.synchronize(); t_sh = time.perf_counter()
+        i8_mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
+        shadow_i8_ms = (time.perf_counter() - t_sh) * 1e3
     view = acc.corpus_view(tc.data_ptr(), n, d, row_base=row_base,
                            rows_bf16_ptr=tb.data_ptr() if tb is not None else None,
-                           rows_nsq_ptr=tn.data_ptr() if tn is not None else None)
+                           rows_nsq_ptr=tn.data_ptr() if tn is not None else None,
+                           rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
+                           rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
     acc.synchronize()
 
     # the step after the scan: all-gather + merge, two batches in flight (yams_amd/dist.py)
@@ -373,7 +386,7 @@ def main():
                               and np.array_equal(s_timed[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
             check = {"recall_at_k": inter / float(n_oq * k), "bit_exact_vs_oracle": exact,
                      "recall_checked_on": "timed configuration: the merged top-k of the last timed step "
-                                          f"({'bf16-shadow' if tb is not None else 'fp32-view'} filter, {total_rows} rows, "
+                                          f"({'int8-shadow' if t8 is not None and nq > 128 else ('bf16-shadow' if tb is not None else 'fp32-view')} filter, {total_rows} rows, "
                                           f"Q={nq}) vs the scalar fp64 oracle over all {total_rows} resident rows",
                      "oracle_queries": n_oq, "oracle_query_ids": qsel, "oracle_seconds": t_or,
                      "oracle_threads_per_rank": stats.get("threads"), "oracle_scan_thread_seconds": stats.get("scan_thread_s")}
@@ -431,7 +444,11 @@ def main():
     flops = 2.0 * nq * d * filt_rows            # ALGORITHMIC flops of the contraction per launch
     ach_tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms else None
     passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
-    if bf16 and passes == 3:
+    i8 = t8 is not None and nq > 128 and passes == 1 and diag.get("filter_tier") == 1
+    if i8:
+        kname = "scan_tiles_bf16s_kernel<FILTER,COSINE,I8> (v_mfma_i32_32x32x32_i8 over the int8 shadow, exact integer accumulate)"
+        peak = PEAK_I8_MFMA_TOPS
+    elif bf16 and passes == 3:
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"
         peak = PEAK_BF16_MFMA_TFLOPS / BF16_PASSES  # each algorithmic multiply-add costs 3 bf16 MFMA passes
     elif bf16:
@@ -451,20 +468,21 @@ def main():
             j = json.load(open(pmc))
             if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq \
                     and j.get("bf16", False) == bf16 and j.get("passes", 3) == (passes if bf16 else 0) \
-                    and j.get("shadow", False) == (tb is not None):
+                    and j.get("shadow", False) == (tb is not None) and j.get("i8", False) == i8:
                 traffic = j.get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/scan_filter_pmc.json ({j.get('round', '?')}, builder run: rocprofv3 --pmc FETCH_SIZE x2 " \
                                  "gfx950 correction; NOT measured in this run)"
         except Exception:
             traffic = None
-    row_bytes = 2 if (tb is not None and passes == 1 and bf16) else 4   # what the filter reads per element
-    roofline = {"bound": "mfma", "kernel": kname, "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s",
+    row_bytes = 1 if i8 else (2 if (tb is not None and passes == 1 and bf16) else 4)   # what the filter reads per element
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": ach_tf, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                 "frac": (ach_tf / peak) if ach_tf else None, "traffic": traffic, "traffic_source": traffic_source,
                 "launch_ms": filt_ms, "launches": filt_n, "flops_per_launch": flops,
                 "executed_mfma_tflops": (ach_tf * passes if bf16 else ach_tf) if ach_tf else None,
-                "mfma_peak_for_executed": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS,
+                "mfma_peak_for_executed": PEAK_I8_MFMA_TOPS if i8 else (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
+                "frac_of_bf16_peak": (ach_tf / PEAK_BF16_MFMA_TFLOPS) if ach_tf else None,
                 "sample_pass_ms": samp_ms,
-                "shadow_build_ms": shadow_ms,
+                "shadow_build_ms": shadow_ms, "shadow_i8_build_ms": shadow_i8_ms, "shadow_i8_mean_residue": i8_mean_err,
                 # the other floor of this kernel: one read of the filter rows from HBM per launch
                 "hbm_floor_view": {"algorithmic_bytes_per_launch": filt_rows * d * row_bytes,
                                    "achieved_GBps": (filt_rows * d * row_bytes) / (filt_ms * 1e-3) / 1e9 if filt_ms else None,
@@ -476,7 +494,8 @@ def main():
            "value": qps, "unit": "QPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
-           "dtype": (("bf16" if passes == 1 else "bf16x3 split-f32") + " (MFMA filter) + f64 (exact re-score)" if bf16 else "f32 (MFMA filter) + f64 (exact re-score)"),
+           "dtype": ("i8 (MFMA filter, exact i32 accumulate) + f64 (exact re-score)" if i8 else
+                     (("bf16" if passes == 1 else "bf16x3 split-f32") + " (MFMA filter) + f64 (exact re-score)" if bf16 else "f32 (MFMA filter) + f64 (exact re-score)")),
            "data": "synthetic",
            "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: "
                                   f"100Mx768 over 8 GPUs), query batch {nq}",
@@ -500,7 +519,7 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_scan(tc, tq, n, k)
     if not a.no_ingest and world == 1:
-        del tc, tb, tn, view, pipe, res
+        del tc, tb, tn, t8, tm8, view, pipe, res
         acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg
         acc.ctx = None
         acc = Accel(local, torch.cuda.current_stream().cuda_stream)

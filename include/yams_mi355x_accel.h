@@ -133,6 +133,16 @@ typedef struct yams_scan_corpus_s {
                                   that decides the result always reads `rows`.  Results are
                                   bit-identical with and without it.                              */
     const float* rows_nsq;     /* device, nullable iff rows_bf16 is: [n_rows] fp32 squared norms  */
+    const int8_t* rows_i8;     /* device, nullable: the INT8 SHADOW built by
+                                  yams_scan_build_shadow_i8_device — [n_rows][dim] int8 =
+                                  round(unit-normalised row / s_r), 16-byte aligned, dim % 64 == 0.
+                                  Read by the first filter tier of cosine searches (half the bytes
+                                  of the bf16 shadow, twice its matrix rate); like every filter
+                                  tier it only proposes candidates, the fp64 re-score over `rows`
+                                  decides: results are bit-identical with and without it.         */
+    const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [n_rows][2] = {s_r, e_r}: the
+                                  row's quantisation scale and a bound of its quantisation
+                                  residue |x/|x| - s_r * int8 row| (measured per row)              */
 } yams_scan_corpus_t;
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
@@ -151,6 +161,7 @@ typedef struct yams_scan_corpus_s {
 #define YAMS_SCAN_FLAG_WIDE_TILE 32u      /* keep the 256-query MFMA tile for batches of <= 128
                                              queries (default: the narrow, HBM-bound kernel form);
                                              results are identical, only the kernel form differs  */
+#define YAMS_SCAN_FLAG_NO_I8_FILTER 64u   /* do not use the int8 shadow even when the view carries one */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {
@@ -175,6 +186,9 @@ typedef struct yams_scan_diag_s {
     uint32_t exact_fallback_queries;      /* queries that took the full fp64 scan                */
     uint32_t path;                        /* 0 = mfma filter + fp64 re-score, 1 = full fp64 scan */
     uint32_t escalated_queries;           /* queries re-filtered with the split (3-pass) filter  */
+    uint32_t filter_tier;                 /* first filter tier of the call: 0 none (fp64 scan),
+                                             1 int8, 2 bf16, 3 split bf16, 4 f32                  */
+    uint32_t reserved;
 } yams_scan_diag_t;
 
 /* Builds the filter shadow of `n_rows` rows (call it when rows are uploaded or appended; pass
@@ -184,6 +198,16 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, 
                                                            uint64_t n_rows, uint32_t dim,
                                                            uint16_t* out_rows_bf16,
                                                            float* out_rows_nsq);
+
+/* Builds the INT8 shadow of `n_rows` rows (same call pattern as yams_scan_build_shadow_device; dim
+ * must be a multiple of 64, rows 16-byte aligned).  out_rows_i8: [n_rows][dim] int8; out_meta:
+ * [n_rows][2] fp32.  out_mean_err (host, nullable): mean e_r over the rows with a usable norm — a
+ * host that sees a large value (say > 0.02: heavy-tailed rows quantise badly) may leave the int8
+ * shadow out of the view and keep the bf16 one; asking for it synchronises the stream. */
+YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, const float* rows,
+                                                              uint64_t n_rows, uint32_t dim,
+                                                              int8_t* out_rows_i8, float* out_meta,
+                                                              double* out_mean_err);
 
 /* Batched exact top-k, everything device-resident.  Any batch size: more than 4096 queries run as
  * slices of 4096 (the per-batch workspace grows with the query count); diagnostics are summed.

@@ -49,11 +49,19 @@ for case in range(a.cases):
         mask_t = torch.from_numpy(words.view(np.int32)).cuda(); mask_n = int(keep.sum())
     view = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
                            rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
+    forms = ["default", "wide", "exact"]
+    view8 = None
+    if metric == SCAN_COSINE and d % 64 == 0:   # the int8 tier: a view that carries only the int8 shadow
+        t8 = torch.empty((n, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+        acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr())
+        view8 = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
+                                rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
+        forms.insert(0, "i8")
     out = {}
-    for form in ("default", "wide", "exact"):
+    for form in forms:
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
+        diag = acc.scan_topk_device(view8 if form == "i8" else view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
                                     dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else (FLAG_WIDE_TILE if form == "wide" else 0))
         torch.cuda.synchronize()
         cn = c.cpu().numpy()
@@ -61,7 +69,7 @@ for case in range(a.cases):
         out[form] = (cn, np.where(sel, r.cpu().numpy(), -1), np.where(sel, s.cpu().numpy().view(np.uint32), 0),
                      np.where(sel, dist.cpu().numpy().view(np.uint32), 0) if metric == SCAN_L2 else None, diag)
     ref = out["exact"]
-    for form in ("default", "wide"):
+    for form in [f for f in forms if f != "exact"]:
         o = out[form]
         ok = (o[0] == ref[0]).all() and (o[1] == ref[1]).all() and (o[2] == ref[2]).all()
         if metric == SCAN_L2:

@@ -20,15 +20,27 @@ TOL = 0.0  # similarities must be bit-identical; the north_star tolerance would 
 
 
 def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0,
-        shadow=True):
+        shadow=True, mask=None):
     """shadow=True: the corpus view carries the bf16 filter shadow, as the plugin's device mirror
-    always does (plugin.cpp corpus_append); shadow=False: a bare fp32 view (flat C-ABI callers)."""
+    always does (plugin.cpp corpus_append); shadow=False: a bare fp32 view (flat C-ABI callers);
+    shadow="i8": only the INT8 shadow (every batch size takes the int8 tier); shadow="both": both
+    (batches above 128 queries take the int8 tier, smaller ones the narrow bf16 form).
+    mask: optional boolean allow-mask over the rows."""
     corpus = np.ascontiguousarray(corpus, np.float32)
     dc = acc.to_device(corpus) if corpus.size else None
-    db = dn = None
-    if shadow and corpus.size and corpus.shape[1] % 4 == 0:
+    db = dn = d8 = dm8 = None
+    if shadow in (True, "both") and corpus.size and corpus.shape[1] % 4 == 0:
         db, dn = acc.alloc(corpus.size * 2), acc.alloc(corpus.shape[0] * 4)
         acc.build_shadow_device(dc.ptr, corpus.shape[0], corpus.shape[1], db.ptr, dn.ptr)
+    if shadow in ("i8", "both") and corpus.size and corpus.shape[1] % 64 == 0:
+        d8, dm8 = acc.alloc(corpus.size), acc.alloc(corpus.shape[0] * 8)
+        acc.build_shadow_i8_device(dc.ptr, corpus.shape[0], corpus.shape[1], d8.ptr, dm8.ptr)
+    dmask, n_allowed = None, 0
+    if mask is not None:
+        n = corpus.shape[0]
+        bits = np.zeros((n + 31) // 32 * 32, np.uint8); bits[:n] = mask
+        words = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+        dmask = acc.to_device(words); n_allowed = int(np.count_nonzero(mask))
     dr = di = None
     if tie_rank is not None:
         inv = np.empty_like(tie_rank)
@@ -36,16 +48,20 @@ def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank
         dr, di = acc.to_device(tie_rank.astype(np.uint32)), acc.to_device(inv.astype(np.uint32))
     view = acc.corpus_view(dc.ptr if dc else None, corpus.shape[0], corpus.shape[1],
                            dr.ptr if dr else None, di.ptr if di else None, row_base,
-                           rows_bf16_ptr=db.ptr if db else None, rows_nsq_ptr=dn.ptr if dn else None)
+                           dmask.ptr if dmask else None, n_allowed,
+                           rows_bf16_ptr=db.ptr if db else None, rows_nsq_ptr=dn.ptr if dn else None,
+                           rows_i8_ptr=d8.ptr if d8 else None, rows_i8_meta_ptr=dm8.ptr if dm8 else None)
     return acc.scan_topk(view, queries, k, thr, metric, flags)
 
 
 def check(acc, oracle, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None,
-          max_queries=None, expect_path=None, shadow=True):
+          max_queries=None, expect_path=None, shadow=True, expect_tier=None):
     queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
     r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank, shadow=shadow)
     if expect_path is not None:
         assert r.diag["path"] == expect_path, r.diag
+    if expect_tier is not None:
+        assert r.diag["filter_tier"] == expect_tier, r.diag
     tr64 = None if tie_rank is None else tie_rank.astype(np.uint64)
     nq = queries.shape[0]
     for qi in range(nq if max_queries is None else min(nq, max_queries)):
@@ -524,10 +540,27 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     assert torch.allclose(tn[:4096], n64.float(), rtol=1e-5)
     unit = (tc[:4096].double() / n64.sqrt()[:, None]).float()
     assert (tb[:4096].float() - unit).abs().max().item() <= 2.0 ** -8 * unit.abs().max().item() * 1.01
-    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
+    t8 = tm8 = None
+    if metric == SCAN_COSINE and d % 64 == 0:   # the int8 shadow: first filter tier of cosine batches > 128 queries
+        t8 = torch.empty((n, d), dtype=torch.int8, device="cuda")
+        tm8 = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+        mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
+        assert 0.0 < mean_err < 0.006                      # uniform components: ~ sqrt(3) / (127 sqrt(12)) = 0.0039
+        unit8 = (tc[:4096].double() / n64.sqrt()[:, None])
+        recon = t8[:4096].double() * tm8[:4096, 0:1].double()
+        assert ((unit8 - recon).norm(dim=-1) <= tm8[:4096, 1].double()).all()   # e_r bounds the measured residue
+    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                           rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
+                           rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
     diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(),
                                 c.data_ptr(), dist.data_ptr())
     assert diag["path"] == 0 and diag["exact_fallback_queries"] == 0
+    assert diag["filter_tier"] == (_lib.TIER_I8 if t8 is not None else _lib.TIER_BF16)
+    if t8 is not None:                                     # the bf16 tier gives the same bits
+        sb = torch.empty_like(s); rb_ = torch.empty_like(r); cb = torch.empty_like(c)
+        dg = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, sb.data_ptr(), rb_.data_ptr(),
+                                  cb.data_ptr(), None, None, flags=_lib.FLAG_NO_I8_FILTER)
+        assert dg["filter_tier"] == _lib.TIER_BF16 and torch.equal(rb_, r) and torch.equal(sb, s) and torch.equal(cb, c)
     assert (c == k).all()
     key = dist if metric == SCAN_L2 else -s
     assert (key[:, 1:] >= key[:, :-1]).all()                                 # sortedness
@@ -597,6 +630,84 @@ def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle)
         assert r.counts[0] == k and r.diag["exact_fallback_queries"] == 0
     check(acc, oracle, corpus, queries, k, thr=-1.0, expect_path=0)
     check(acc, oracle, corpus, queries[:1], k, thr=-1.0, flags=FLAG_FORCE_EXACT, expect_path=1)
+
+
+
+# ---- the INT8 filter tier ----------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k,thr", [
+    (20000, 64, 1, 10, -1.0), (20000, 64, 5, 50, 0.1), (50000, 128, 130, 100, -1.0),
+    (70001, 256, 300, 50, -1.0), (33333, 768, 40, 100, 0.05), (150000, 384, 260, 100, -1.0),
+    (9000, 1024, 7, 20, -1.0), (4096, 64, 3, 200, -1.0),
+])
+def test_int8_tier_matches_the_oracle(acc, oracle, n, d, nq, k, thr):
+    """The int8 tier (v_mfma_i32_32x32x32_i8 over the int8 shadow; filter score = a rigorous upper
+    bound from the measured quantisation residues) in front of the same fp64 re-score + proof:
+    bit-identical to the oracle; ragged row tails, several query tiles, thresholds."""
+    corpus = oracle.synth_rows(31, 0, n, d)
+    q = oracle.synth_rows(31, 1 << 40, nq, d)
+    r = check(acc, oracle, corpus, q, k, thr=thr, max_queries=10, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    assert r.diag["exact_fallback_queries"] == 0
+    # both shadows: the int8 tier from 129 queries on, the narrow bf16 form below; NO_I8 switches it off
+    r2 = check(acc, oracle, corpus, q, k, thr=thr, max_queries=4, expect_path=0, shadow="both",
+               expect_tier=_lib.TIER_I8 if nq > 128 else _lib.TIER_BF16)
+    r3 = run(acc, corpus, q, k, thr, flags=_lib.FLAG_NO_I8_FILTER, shadow="both")
+    assert r3.diag["filter_tier"] == _lib.TIER_BF16
+    for other in (r2, r3):
+        assert np.array_equal(r.rows, other.rows) and np.array_equal(r.counts, other.counts)
+        assert np.array_equal(r.scores.view(np.uint32), other.scores.view(np.uint32))
+
+
+def test_int8_tier_on_hostile_rows(acc, oracle):
+    """Rows that quantise badly or not at all: zero rows, rows far outside the fp32 comfort zone
+    (no usable norm: e_r = inf, always a candidate), a NaN row, one-hot rows (scale = the whole
+    row), heavy-tailed rows (a few huge components: large measured residue), scaled duplicates
+    (exact ties), rows equal to a query; plus an allow-mask.  Correctness never depends on the
+    quantisation quality — only the number of candidates does."""
+    n, d, k = 30000, 128, 40
+    rng = np.random.default_rng(77)
+    corpus = oracle.synth_rows(32, 0, n, d)
+    q = oracle.synth_rows(32, 1 << 40, 9, d)
+    corpus[5] = 0.0; corpus[n - 1] = 0.0
+    corpus[777] *= np.float32(1e18); corpus[778] *= np.float32(1e-18)
+    corpus[900, 3] = np.nan
+    corpus[1000:1064] = np.eye(64, d, dtype=np.float32) * np.float32(3.0)
+    heavy = rng.choice(n, 2000, replace=False)
+    corpus[heavy, rng.integers(0, d, 2000)] *= np.float32(40.0)
+    corpus[2000:2040] = q[1] * rng.uniform(0.1, 10.0, (40, 1)).astype(np.float32)   # 40 exact ties at 1.0
+    corpus[3000] = q[2]; q[3] = corpus[1003]
+    rank = rng.permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, k, tie_rank=rank, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    assert r.diag["exact_fallback_queries"] == 0
+    # allow-mask: masked rows are not part of the scan
+    mask = rng.random(n) < 0.6
+    got = run(acc, corpus, q, k, -1.0, tie_rank=rank, shadow="i8", mask=mask)
+    assert got.diag["filter_tier"] == _lib.TIER_I8
+    allowed = np.flatnonzero(mask)
+    for qi in range(len(q)):
+        rows, sims, _, _ = oracle.scan_cosine(corpus[allowed], q[qi], k, -1.0, rank.astype(np.uint64)[allowed])
+        assert np.array_equal(got.rows[qi, :len(rows)], allowed[rows]) and got.counts[qi] == len(rows)
+        assert np.array_equal(got.scores[qi, :len(rows)].view(np.uint32), sims.view(np.uint32))
+
+
+def test_int8_tier_widens_escalates_and_falls_back(acc, oracle):
+    """The int8 tier's unproven queries take the same road as the bf16 tier's: widen to the whole
+    list, then the split filter as a nested batch, then the exhaustive fp64 pass."""
+    n, d = 20000, 64
+    rng = np.random.default_rng(93)
+    corpus = oracle.synth_rows(33, 0, n, d)
+    q = oracle.synth_rows(33, 1 << 40, 5, d)
+    q[0] *= np.float32(3.0)
+    corpus[1::4] = q[0] * np.float32(0.5)                   # 5000 exact ties: list overflow -> exhaustive
+    qu = (q[2] / np.linalg.norm(q[2])).astype(np.float64)
+    pool = np.setdiff1d(np.arange(n), np.arange(1, n, 4))
+    crowd = rng.choice(pool, 3000, replace=False)
+    for r_, s_ in zip(crowd, np.linspace(0.990, 0.999, 3000)):  # crowded top: escalates to the split filter
+        v = rng.standard_normal(d); v -= (v @ qu) * qu; v /= np.linalg.norm(v)
+        corpus[r_] = (s_ * qu + np.sqrt(1.0 - s_ * s_) * v).astype(np.float32) * np.float32(rng.uniform(0.5, 2.0))
+    corpus[pool[100:100 + 300]] = q[4]                       # 300 ties: more than k' = 214, fewer than the list: widened
+    rank = np.random.default_rng(35).permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    assert r.diag["escalated_queries"] >= 1 and r.diag["exact_fallback_queries"] >= 1 and r.diag["widened_queries"] >= 1, r.diag
 
 
 # ---- the plugin vtable door ------------------------------------------------------------------------

@@ -20,6 +20,8 @@ SCAN_COSINE, SCAN_L2 = 0, 1
 CDC_RABIN, CDC_STREAMING = 0, 1
 FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG_RECORD_PATH = 1, 2, 4, 8, 16
 FLAG_WIDE_TILE = 32
+FLAG_NO_I8_FILTER = 64
+TIER_NONE, TIER_I8, TIER_BF16, TIER_SPLIT, TIER_F32 = range(5)
 CDC_FLAG_GENERIC_KERNEL = 1
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2
 
@@ -35,7 +37,7 @@ class ScanCorpus(C.Structure):
     _fields_ = [("rows", vp), ("n_rows", C.c_uint64), ("dim", C.c_uint32), ("reserved", C.c_uint32),
                 ("tie_rank", vp), ("rank_row", vp), ("row_base", C.c_int64),
                 ("row_mask", vp), ("row_mask_count", C.c_uint64),
-                ("rows_bf16", vp), ("rows_nsq", vp)]
+                ("rows_bf16", vp), ("rows_nsq", vp), ("rows_i8", vp), ("rows_i8_meta", vp)]
 
 
 class ScanParams(C.Structure):
@@ -49,7 +51,7 @@ class ScanDiag(C.Structure):
                 ("returned_rows", C.c_uint64), ("filter_candidates", C.c_uint64),
                 ("rescored_rows", C.c_uint64), ("widened_queries", C.c_uint32),
                 ("exact_fallback_queries", C.c_uint32), ("path", C.c_uint32),
-                ("escalated_queries", C.c_uint32)]
+                ("escalated_queries", C.c_uint32), ("filter_tier", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -142,7 +144,7 @@ EXPORTS = [
     "yams_accel_free_string", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device",
-    "yams_scan_build_shadow_device",
+    "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device",
     "yams_synth_rows_device", "yams_synth_bytes_device", "yams_sha256_batch_device",
     "yams_sha256_host", "yams_sha256_many_host", "yams_verify_chunks_device", "yams_cdc_default_config",
     "yams_dedup_set_create", "yams_dedup_set_destroy", "yams_dedup_set_size", "yams_dedup_insert_device",
@@ -207,6 +209,7 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_scan_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32,
                                       C.POINTER(ScanParams), vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_scan_build_shadow_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
+    L.yams_scan_build_shadow_i8_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
     L.yams_scan_merge_topk_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]

@@ -181,15 +181,26 @@ class Accel:
     def corpus_view(self, rows_ptr: int, n_rows: int, dim: int, tie_rank_ptr: int | None = None,
                     rank_row_ptr: int | None = None, row_base: int = 0,
                     row_mask_ptr: int | None = None, row_mask_count: int = 0,
-                    rows_bf16_ptr: int | None = None, rows_nsq_ptr: int | None = None) -> ScanCorpus:
+                    rows_bf16_ptr: int | None = None, rows_nsq_ptr: int | None = None,
+                    rows_i8_ptr: int | None = None, rows_i8_meta_ptr: int | None = None) -> ScanCorpus:
         return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base,
-                          row_mask_ptr, row_mask_count, rows_bf16_ptr, rows_nsq_ptr)
+                          row_mask_ptr, row_mask_count, rows_bf16_ptr, rows_nsq_ptr,
+                          rows_i8_ptr, rows_i8_meta_ptr)
 
     def build_shadow_device(self, rows_ptr: int, n_rows: int, dim: int, out_bf16_ptr: int,
                             out_nsq_ptr: int) -> None:
         """Filter shadow of the rows (bf16 RNE copy + fp32 squared norms); asynchronous."""
         self._check(self.L.yams_scan_build_shadow_device(self.ctx, rows_ptr, n_rows, dim,
                                                          out_bf16_ptr, out_nsq_ptr))
+
+    def build_shadow_i8_device(self, rows_ptr: int, n_rows: int, dim: int, out_i8_ptr: int,
+                               out_meta_ptr: int, want_mean_err: bool = False):
+        """INT8 filter shadow (int8 rows + {scale, residue bound} per row).  Asynchronous unless the
+        mean residue bound is asked for."""
+        me = C.c_double(0.0)
+        self._check(self.L.yams_scan_build_shadow_i8_device(self.ctx, rows_ptr, n_rows, dim, out_i8_ptr,
+                                                            out_meta_ptr, C.byref(me) if want_mean_err else None))
+        return me.value if want_mean_err else None
 
     def scan_topk_device(self, corpus: ScanCorpus, queries_ptr: int, nq: int, k: int,
                          threshold: float, metric: int, out_scores: int, out_rows: int,

@@ -149,6 +149,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         return fail(ctx, YAMS_ERR_INVALID_ARG, "tie_rank and rank_row must be given together");
     if ((corpus->rows_bf16 == nullptr) != (corpus->rows_nsq == nullptr))
         return fail(ctx, YAMS_ERR_INVALID_ARG, "rows_bf16 and rows_nsq must be given together");
+    if ((corpus->rows_i8 == nullptr) != (corpus->rows_i8_meta == nullptr))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "rows_i8 and rows_i8_meta must be given together");
     if (corpus->row_mask && corpus->row_mask_count > corpus->n_rows)
         return fail(ctx, YAMS_ERR_INVALID_ARG, "row_mask_count exceeds n_rows");
     (void)hipSetDevice(ctx->device);
@@ -195,7 +197,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     }
 
     uint64_t filter_candidates = 0, rescored_nested = 0;
-    uint32_t widened = 0, exact_fb = 0, escalated = 0;
+    uint32_t widened = 0, exact_fb = 0, escalated = 0, filter_tier = 0;
     std::vector<uint32_t> flags_keep; // h_flags survives a nested (escalation) call through this copy
     if (!use_mfma) {
         const uint32_t* d_rows_sel = nullptr;
@@ -230,19 +232,30 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             const uint32_t need1 = (metric == YAMS_SCAN_L2) ? 6 * k + 128 : 3 * k + 64;
             passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || need1 > kRescoreMax) ? 3 : 1;
         }
+        // The INT8 tier (cosine, dim % 64 == 0, int8 shadow in the view): the same tile loop on
+        // v_mfma_i32_32x32x32_i8 — twice the matrix rate, half the shadow bytes, exact integer
+        // accumulation; its filter score is an upper bound of the similarity built from the
+        // MEASURED quantisation residues, so the proof needs no extra error term.
+        // Batches of <= 128 queries stay on the narrow bf16 form when a bf16 shadow is there too.
+        bool i8 = bf16 && passes == 1 && metric == YAMS_SCAN_COSINE && (dim & 63u) == 0 && corpus->rows_i8 &&
+                  corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
+                  !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER) && (nq > 128 || !corpus->rows_bf16);
 #ifdef YAMS_ACCEL_MEASURE
         // Measurement build only (libyams_mi355x_accel_measure.so, scripts/): kernel-form and
         // ablation selection from the environment.  The product library never reads it.
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3)) i8 = false;
 #endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
         if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
             L.rows_bf16 = corpus->rows_bf16; L.rows_nsq = corpus->rows_nsq; // used by the single-pass kernel
-        } L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
+        }
+        if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
+        L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
         //   split bf16: 3*dim fp32 accumulations (x2 safety for the MFMA adder tree) + the split residue:
@@ -257,7 +270,14 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         const bool use_shadow = passes == 1 && L.rows_bf16 && bf16_slab_k(passes, dim) == 32;
         const double norm_rel = (dim + 32.0) * u24;
         L.err_coef = static_cast<float>((dot_rel + (use_shadow ? norm_rel : 0.0)) * 1.01);
-        if (bf16) {
+        if (i8) {
+            int8_t* d_qi8; float* d_qmeta;
+            const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
+            YA_TRY(ws_get(ctx, "q_i8", static_cast<size_t>(q_pad) * dim, (void**)&d_qi8));
+            YA_TRY(ws_get(ctx, "q_meta", static_cast<size_t>(q_pad) * 16, (void**)&d_qmeta));
+            YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, q_pad, dim, d_qi8, d_qmeta));
+            L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_pad = q_pad;
+        } else if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
             YA_TRY(ws_get(ctx, "q_hi", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qhi));
@@ -280,12 +300,14 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
 
         { TimedRegion tr(ctx, "scan_sample");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
+          if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 0, bf16_version));
+          else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         YA_HIP(ctx, launch_collect_sample(st, L));
         { TimedRegion tr(ctx, "scan_filter");
-          if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
+          if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));
+          else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
 
 #ifdef YAMS_ACCEL_MEASURE
@@ -297,8 +319,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
 #endif
         // stage 1: re-score the best kprime filter survivors of every query
         // cosine: |s32 - cos| <= dot_rel + norm (dim/2 u) + rsqrt/product/unit-query rounding
-        const double err_bound = (metric == YAMS_SCAN_COSINE)
+        // (the int8 tier's filter score already is an upper bound of the similarity)
+        const double err_bound = (metric == YAMS_SCAN_COSINE && !i8)
                                      ? dot_rel + (dim + 24.0) * u24 + (use_shadow ? norm_rel : 0.0) : 0.0;
+        filter_tier = i8 ? 1u : (!bf16 ? 4u : (passes == 3 ? 3u : 2u));
         auto rescore_stage = [&](uint32_t n_slots, const uint32_t* d_qmap, uint32_t n_cand) -> yams_status_t {
             const uint64_t* res; uint64_t res_stride;
             YA_HIP(ctx, launch_select_lists(st, d_list, d_lcount, plan.list_cap, n_slots, d_qmap,
@@ -422,6 +446,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         diag->widened_queries = widened;
         diag->exact_fallback_queries = exact_fb;
         diag->escalated_queries = escalated;
+        diag->filter_tier = filter_tier;
     }
     return YAMS_OK;
 }
@@ -463,6 +488,7 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
         total.exact_fallback_queries += d.exact_fallback_queries;
         total.escalated_queries += d.escalated_queries;
         total.path = std::max(total.path, d.path);
+        total.filter_tier = d.filter_tier;
     }
     if (diag) *diag = total;
     return YAMS_OK;
@@ -481,6 +507,37 @@ extern "C" yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, cons
     TimedRegion tr(ctx, "shadow_build");
     YA_HIP(ctx, launch_shadow_build(ctx->stream, rows, n_rows, dim, out_rows_bf16, out_rows_nsq));
     tr.end();
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, const float* rows,
+                                                          uint64_t n_rows, uint32_t dim,
+                                                          int8_t* out_rows_i8, float* out_meta,
+                                                          double* out_mean_err) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (out_mean_err) *out_mean_err = 0.0;
+    if (n_rows == 0) return YAMS_OK;
+    if (!rows || !out_rows_i8 || !out_meta) return fail(ctx, YAMS_ERR_INVALID_ARG, "null shadow buffers");
+    if (dim == 0 || (dim & 63u) || (reinterpret_cast<uintptr_t>(rows) & 15u) ||
+        (reinterpret_cast<uintptr_t>(out_rows_i8) & 3u) || (reinterpret_cast<uintptr_t>(out_meta) & 7u))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "the int8 shadow needs dim % 64 == 0 and 16-byte aligned rows");
+    (void)hipSetDevice(ctx->device);
+    double* d_stats = nullptr;
+    if (out_mean_err) {
+        YA_TRY(ws_get(ctx, "i8_stats", 16, (void**)&d_stats));
+        YA_HIP(ctx, hipMemsetAsync(d_stats, 0, 16, ctx->stream));
+    }
+    TimedRegion tr(ctx, "shadow_build_i8");
+    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, n_rows, dim, out_rows_i8, out_meta, d_stats));
+    tr.end();
+    if (out_mean_err) {
+        double h[2] = {0.0, 0.0};
+        YA_HIP(ctx, hipMemcpyAsync(h, d_stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+        YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long cnt;
+        std::memcpy(&cnt, &h[1], 8);
+        *out_mean_err = cnt ? h[0] / static_cast<double>(cnt) : 0.0;
+    }
     return YAMS_OK;
 }
 

@@ -9,6 +9,10 @@ struct ScanLaunch {
     const float* rows = nullptr;
     const uint16_t* rows_bf16 = nullptr; // nullable shadow (with rows_nsq)
     const float* rows_nsq = nullptr;
+    const int8_t* rows_i8 = nullptr;     // nullable INT8 shadow (with rows_i8_meta)
+    const float* rows_i8_meta = nullptr;
+    const int8_t* q_i8 = nullptr;
+    const float* q_meta = nullptr;
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
     const uint16_t* q_hi = nullptr;
@@ -54,6 +58,14 @@ hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint32_t nq, ui
 // the single-pass kernel uses 32-wide slabs when the dimension allows it.
 inline uint32_t bf16_slab_k(int passes, uint32_t dim) { return (passes == 1 && (dim & 31u) == 0) ? 32u : 16u; }
 hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int mode, int passes, int version);
+// The INT8 tier (cosine, dim % 64 == 0, int8 shadow present): sample (mode 0) or filter (mode 1) pass.
+hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version);
+// Quantises the prepared (unit) queries of a batch: k-slab-major int8 plane + {t_q, c_q, f_q} per query.
+hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
+                          int8_t* q_i8, float* q_meta);
+// The INT8 shadow of `n_rows` rows; stats (nullable) = {sum of finite e_r (double), rows counted (u64 bits)}.
+hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
+                                  int8_t* out_i8, float* out_meta, double* stats);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32);
