@@ -289,9 +289,9 @@ def main():
     # the INT8 shadow (first filter tier of cosine batches > 128 queries), also built at upload time
     t8 = tm8 = None
     shadow_i8_ms = i8_mean_err = None
-    if tb is not None and not a.no_i8 and d % 64 == 0 and not a.f32_filter and not a.split_filter:
+    if tb is not None and not a.no_i8 and d % 64 == 0 and d >= 256 and not a.f32_filter and not a.split_filter:
         t8 = torch.empty((n, d), dtype=torch.int8, device=dev)
-        tm8 = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
         acc.synchronize(); t_sh = time.perf_counter()
         i8_mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
         shadow_i8_ms = (time.perf_counter() - t_sh) * 1e3
@@ -446,7 +446,7 @@ def main():
     passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
     i8 = t8 is not None and nq > 128 and passes == 1 and diag.get("filter_tier") == 1
     if i8:
-        kname = "scan_tiles_bf16s_kernel<FILTER,COSINE,I8> (v_mfma_i32_32x32x32_i8 over the int8 shadow, exact integer accumulate)"
+        kname = "scan_tiles_i8_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, exact integer accumulate)"
         peak = PEAK_I8_MFMA_TOPS
     elif bf16 and passes == 3:
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"

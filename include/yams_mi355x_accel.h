@@ -135,14 +135,15 @@ typedef struct yams_scan_corpus_s {
     const float* rows_nsq;     /* device, nullable iff rows_bf16 is: [n_rows] fp32 squared norms  */
     const int8_t* rows_i8;     /* device, nullable: the INT8 SHADOW built by
                                   yams_scan_build_shadow_i8_device — [n_rows][dim] int8 =
-                                  round(unit-normalised row / s_r), 16-byte aligned, dim % 64 == 0.
+                                  round(unit-normalised row / s_b), 16-byte aligned, dim % 64 == 0, dim >= 256.
                                   Read by the first filter tier of cosine searches (half the bytes
                                   of the bf16 shadow, twice its matrix rate); like every filter
                                   tier it only proposes candidates, the fp64 re-score over `rows`
                                   decides: results are bit-identical with and without it.         */
-    const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [n_rows][2] = {s_r, e_r}: the
-                                  row's quantisation scale and a bound of its quantisation
-                                  residue |x/|x| - s_r * int8 row| (measured per row)              */
+    const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [ceil(n_rows / 16)][2] =
+                                  {s_b, e_b} per block of 16 rows: the block's quantisation scale
+                                  and the largest measured residue |x/|x| - s_b * int8 row| of
+                                  its rows                                                         */
 } yams_scan_corpus_t;
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
@@ -199,15 +200,19 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, 
                                                            uint16_t* out_rows_bf16,
                                                            float* out_rows_nsq);
 
-/* Builds the INT8 shadow of `n_rows` rows (same call pattern as yams_scan_build_shadow_device; dim
- * must be a multiple of 64, rows 16-byte aligned).  out_rows_i8: [n_rows][dim] int8; out_meta:
- * [n_rows][2] fp32.  out_mean_err (host, nullable): mean e_r over the rows with a usable norm — a
- * host that sees a large value (say > 0.02: heavy-tailed rows quantise badly) may leave the int8
- * shadow out of the view and keep the bf16 one; asking for it synchronises the stream. */
+/* (Re)builds the INT8 shadow of the mirror at `rows` for every block of 16 rows that intersects
+ * [first_row, first_row + n_rows) — call it when those rows were uploaded or appended (the rows of a
+ * block share one quantisation scale, so an append that starts inside a block re-quantises that
+ * block's earlier rows too; all pointers are the BASES of the mirror's arrays, not offset ones).
+ * dim must be a multiple of 64 and at least 256, rows 16-byte aligned.  out_rows_i8: [n][dim] int8; out_meta:
+ * [ceil(n / 16)][2] fp32 for a mirror of n rows.  out_mean_err (host, nullable): mean residue bound
+ * over the rebuilt blocks — a host that sees a large value (say > 0.02: heavy-tailed rows quantise
+ * badly) may leave the int8 shadow out of the view and keep the bf16 one; asking for it
+ * synchronises the stream. */
 YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, const float* rows,
-                                                              uint64_t n_rows, uint32_t dim,
-                                                              int8_t* out_rows_i8, float* out_meta,
-                                                              double* out_mean_err);
+                                                              uint64_t first_row, uint64_t n_rows,
+                                                              uint32_t dim, int8_t* out_rows_i8,
+                                                              float* out_meta, double* out_mean_err);
 
 /* Batched exact top-k, everything device-resident.  Any batch size: more than 4096 queries run as
  * slices of 4096 (the per-batch workspace grows with the query count); diagnostics are summed.

@@ -18,13 +18,20 @@ s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((n
 c = torch.empty(nq, dtype=torch.int32, device="cuda")
 tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
 acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr()); acc.synchronize()
+t8 = torch.empty((n, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
+acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr()); acc.synchronize()
 view = acc.corpus_view(tc.data_ptr(), n, d) if os.environ.get("NO_SHADOW") else \
     acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
+view8 = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                        rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
 out = {}
 for v in sys.argv[1:]:
     os.environ["YAMS_ACCEL_BF16_KERNEL"] = v
     acc.enable_timing(True)   # (the host returns right after the filter launch for ablated kernels)
-    acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), flags=0, want_diag=False)
+    i8v = v.startswith("i8:")          # "i8:2" = the int8 tier's product kernel, "i8:31/32/37" its ablations
+    if i8v:
+        os.environ["YAMS_ACCEL_BF16_KERNEL"] = v[3:]
+    acc.scan_topk_device(view8 if i8v else view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), flags=0, want_diag=False)
     out[v] = acc.kernel_ms("scan_filter")[0]
     acc.enable_timing(False)
 print(json.dumps(out))

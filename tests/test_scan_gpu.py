@@ -32,8 +32,8 @@ def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank
     if shadow in (True, "both") and corpus.size and corpus.shape[1] % 4 == 0:
         db, dn = acc.alloc(corpus.size * 2), acc.alloc(corpus.shape[0] * 4)
         acc.build_shadow_device(dc.ptr, corpus.shape[0], corpus.shape[1], db.ptr, dn.ptr)
-    if shadow in ("i8", "both") and corpus.size and corpus.shape[1] % 64 == 0:
-        d8, dm8 = acc.alloc(corpus.size), acc.alloc(corpus.shape[0] * 8)
+    if shadow in ("i8", "both") and corpus.size and corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256:
+        d8, dm8 = acc.alloc(corpus.size), acc.alloc((corpus.shape[0] + 15) // 16 * 8)
         acc.build_shadow_i8_device(dc.ptr, corpus.shape[0], corpus.shape[1], d8.ptr, dm8.ptr)
     dmask, n_allowed = None, 0
     if mask is not None:
@@ -541,14 +541,15 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     unit = (tc[:4096].double() / n64.sqrt()[:, None]).float()
     assert (tb[:4096].float() - unit).abs().max().item() <= 2.0 ** -8 * unit.abs().max().item() * 1.01
     t8 = tm8 = None
-    if metric == SCAN_COSINE and d % 64 == 0:   # the int8 shadow: first filter tier of cosine batches > 128 queries
+    if metric == SCAN_COSINE and d % 64 == 0 and d >= 256:   # the int8 shadow: first filter tier of cosine batches > 128 queries
         t8 = torch.empty((n, d), dtype=torch.int8, device="cuda")
-        tm8 = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+        tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
         mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
         assert 0.0 < mean_err < 0.006                      # uniform components: ~ sqrt(3) / (127 sqrt(12)) = 0.0039
         unit8 = (tc[:4096].double() / n64.sqrt()[:, None])
-        recon = t8[:4096].double() * tm8[:4096, 0:1].double()
-        assert ((unit8 - recon).norm(dim=-1) <= tm8[:4096, 1].double()).all()   # e_r bounds the measured residue
+        sc8 = tm8[:256, 0].double().repeat_interleave(16)[:, None]       # one scale per block of 16 rows
+        recon = t8[:4096].double() * sc8
+        assert ((unit8 - recon).norm(dim=-1) <= tm8[:256, 1].double().repeat_interleave(16)).all()   # e_b bounds the measured residues
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
                            rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
                            rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
@@ -635,9 +636,9 @@ def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle)
 
 # ---- the INT8 filter tier ----------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,nq,k,thr", [
-    (20000, 64, 1, 10, -1.0), (20000, 64, 5, 50, 0.1), (50000, 128, 130, 100, -1.0),
+    (20000, 256, 1, 10, -1.0), (20007, 320, 5, 50, 0.1), (50000, 256, 130, 100, -1.0),
     (70001, 256, 300, 50, -1.0), (33333, 768, 40, 100, 0.05), (150000, 384, 260, 100, -1.0),
-    (9000, 1024, 7, 20, -1.0), (4096, 64, 3, 200, -1.0),
+    (9000, 1024, 7, 20, -1.0), (4096, 448, 3, 200, -1.0), (30011, 1536, 33, 10, -1.0),
 ])
 def test_int8_tier_matches_the_oracle(acc, oracle, n, d, nq, k, thr):
     """The int8 tier (v_mfma_i32_32x32x32_i8 over the int8 shadow; filter score = a rigorous upper
@@ -663,13 +664,14 @@ def test_int8_tier_on_hostile_rows(acc, oracle):
     row), heavy-tailed rows (a few huge components: large measured residue), scaled duplicates
     (exact ties), rows equal to a query; plus an allow-mask.  Correctness never depends on the
     quantisation quality — only the number of candidates does."""
-    n, d, k = 30000, 128, 40
+    n, d, k = 30000, 256, 40
     rng = np.random.default_rng(77)
     corpus = oracle.synth_rows(32, 0, n, d)
     q = oracle.synth_rows(32, 1 << 40, 9, d)
-    corpus[5] = 0.0; corpus[n - 1] = 0.0
+    corpus[5] = 0.0; corpus[n - 1] = 0.0; corpus[4000:4016] = 0.0     # a whole block of zero rows
     corpus[777] *= np.float32(1e18); corpus[778] *= np.float32(1e-18)
-    corpus[900, 3] = np.nan
+    corpus[779] *= np.float32(3e-21)                                   # norm^2 below 1e-12 in fp64 too: skipped by the reference
+    corpus[900, 3] = np.nan; corpus[901, 7] = np.inf
     corpus[1000:1064] = np.eye(64, d, dtype=np.float32) * np.float32(3.0)
     heavy = rng.choice(n, 2000, replace=False)
     corpus[heavy, rng.integers(0, d, 2000)] *= np.float32(40.0)
@@ -689,10 +691,35 @@ def test_int8_tier_on_hostile_rows(acc, oracle):
         assert np.array_equal(got.scores[qi, :len(rows)].view(np.uint32), sims.view(np.uint32))
 
 
+def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
+    """The rows of a 16-row block share one scale, so an append that starts inside a block must
+    re-quantise that block's earlier rows: building in ragged appends == building once."""
+    import torch
+    n, d = 5003, 320
+    corpus = oracle.synth_rows(34, 0, n, d)
+    corpus[1001] *= np.float32(7.0)                     # a row with a different largest component
+    tc = torch.from_numpy(corpus).cuda()
+    nb = (n + 15) // 16
+    a8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); am = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    b8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); bm = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    acc.build_shadow_i8_device(tc.data_ptr(), n, d, a8.data_ptr(), am.data_ptr())
+    first = 0
+    for step in (1000, 1, 7, 2995, 1000):               # 1000 and 1001 fall inside a block
+        acc.build_shadow_i8_device(tc.data_ptr(), step, d, b8.data_ptr(), bm.data_ptr(), first_row=first)
+        first += step
+    assert first == n
+    acc.synchronize()
+    assert torch.equal(a8, b8) and torch.equal(am, bm)
+    unit = tc.double() / tc.double().norm(dim=-1, keepdim=True)
+    sc = am[:, 0].double().repeat_interleave(16)[:n, None]
+    assert ((unit - a8.double() * sc).norm(dim=-1) <= am[:, 1].double().repeat_interleave(16)[:n]).all()
+    assert (a8.abs().amax(dim=-1).view(-1)[:16 * (n // 16)].view(-1, 16).amax(dim=-1) == 127).all()   # every block uses its full range
+
+
 def test_int8_tier_widens_escalates_and_falls_back(acc, oracle):
     """The int8 tier's unproven queries take the same road as the bf16 tier's: widen to the whole
     list, then the split filter as a nested batch, then the exhaustive fp64 pass."""
-    n, d = 20000, 64
+    n, d = 20000, 256
     rng = np.random.default_rng(93)
     corpus = oracle.synth_rows(33, 0, n, d)
     q = oracle.synth_rows(33, 1 << 40, 5, d)

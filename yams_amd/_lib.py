@@ -209,7 +209,7 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_scan_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32,
                                       C.POINTER(ScanParams), vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_scan_build_shadow_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
-    L.yams_scan_build_shadow_i8_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
+    L.yams_scan_build_shadow_i8_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
     L.yams_scan_merge_topk_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]

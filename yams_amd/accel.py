@@ -194,11 +194,12 @@ class Accel:
                                                          out_bf16_ptr, out_nsq_ptr))
 
     def build_shadow_i8_device(self, rows_ptr: int, n_rows: int, dim: int, out_i8_ptr: int,
-                               out_meta_ptr: int, want_mean_err: bool = False):
-        """INT8 filter shadow (int8 rows + {scale, residue bound} per row).  Asynchronous unless the
-        mean residue bound is asked for."""
+                               out_meta_ptr: int, want_mean_err: bool = False, first_row: int = 0):
+        """INT8 filter shadow of rows [first_row, first_row + n_rows) of the mirror whose arrays start
+        at the given BASE pointers: int8 rows [n][dim] + {scale, residue bound} per block of 16 rows
+        ([ceil(n / 16)][2] fp32).  Asynchronous unless the mean residue bound is asked for."""
         me = C.c_double(0.0)
-        self._check(self.L.yams_scan_build_shadow_i8_device(self.ctx, rows_ptr, n_rows, dim, out_i8_ptr,
+        self._check(self.L.yams_scan_build_shadow_i8_device(self.ctx, rows_ptr, first_row, n_rows, dim, out_i8_ptr,
                                                             out_meta_ptr, C.byref(me) if want_mean_err else None))
         return me.value if want_mean_err else None
 

@@ -232,12 +232,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             const uint32_t need1 = (metric == YAMS_SCAN_L2) ? 6 * k + 128 : 3 * k + 64;
             passes = (split_only || (params->flags & YAMS_SCAN_FLAG_SPLIT_FILTER) || need1 > kRescoreMax) ? 3 : 1;
         }
-        // The INT8 tier (cosine, dim % 64 == 0, int8 shadow in the view): the same tile loop on
-        // v_mfma_i32_32x32x32_i8 — twice the matrix rate, half the shadow bytes, exact integer
-        // accumulation; its filter score is an upper bound of the similarity built from the
-        // MEASURED quantisation residues, so the proof needs no extra error term.
+        // The INT8 tier (cosine, dim % 64 == 0, dim >= 256, int8 shadow in the view): the tile loop on
+        // v_mfma_i32_16x16x64_i8 (scan_i8_kernel.hip) — more than twice the sustained matrix rate,
+        // half the shadow bytes, exact integer accumulation; its filter score is an upper bound of the
+        // similarity built from the MEASURED quantisation residues, so the proof needs no extra error term.
         // Batches of <= 128 queries stay on the narrow bf16 form when a bf16 shadow is there too.
-        bool i8 = bf16 && passes == 1 && metric == YAMS_SCAN_COSINE && (dim & 63u) == 0 && corpus->rows_i8 &&
+        bool i8 = bf16 && passes == 1 && metric == YAMS_SCAN_COSINE && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                   !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER) && (nq > 128 || !corpus->rows_bf16);
 #ifdef YAMS_ACCEL_MEASURE
@@ -246,7 +246,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3)) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37)) i8 = false;
 #endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
@@ -275,8 +275,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
             YA_TRY(ws_get(ctx, "q_i8", static_cast<size_t>(q_pad) * dim, (void**)&d_qi8));
             YA_TRY(ws_get(ctx, "q_meta", static_cast<size_t>(q_pad) * 16, (void**)&d_qmeta));
+            float* d_qthr;
+            YA_TRY(ws_get(ctx, "q_thr", static_cast<size_t>(q_pad) * 8, (void**)&d_qthr));
             YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, q_pad, dim, d_qi8, d_qmeta));
-            L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_pad = q_pad;
+            L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_thr = d_qthr; L.q_pad = q_pad; L.sample_layout = 1;
         } else if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
@@ -304,6 +306,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
+        if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
         YA_HIP(ctx, launch_collect_sample(st, L));
         { TimedRegion tr(ctx, "scan_filter");
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));
@@ -511,16 +514,16 @@ extern "C" yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, cons
 }
 
 extern "C" yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, const float* rows,
-                                                          uint64_t n_rows, uint32_t dim,
+                                                          uint64_t first_row, uint64_t n_rows, uint32_t dim,
                                                           int8_t* out_rows_i8, float* out_meta,
                                                           double* out_mean_err) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
     if (out_mean_err) *out_mean_err = 0.0;
     if (n_rows == 0) return YAMS_OK;
     if (!rows || !out_rows_i8 || !out_meta) return fail(ctx, YAMS_ERR_INVALID_ARG, "null shadow buffers");
-    if (dim == 0 || (dim & 63u) || (reinterpret_cast<uintptr_t>(rows) & 15u) ||
-        (reinterpret_cast<uintptr_t>(out_rows_i8) & 3u) || (reinterpret_cast<uintptr_t>(out_meta) & 7u))
-        return fail(ctx, YAMS_ERR_INVALID_ARG, "the int8 shadow needs dim % 64 == 0 and 16-byte aligned rows");
+    if (dim < 256 || (dim & 63u) || (reinterpret_cast<uintptr_t>(rows) & 15u) ||
+        (reinterpret_cast<uintptr_t>(out_rows_i8) & 15u) || (reinterpret_cast<uintptr_t>(out_meta) & 7u))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "the int8 shadow needs dim % 64 == 0, dim >= 256 and 16-byte aligned rows");
     (void)hipSetDevice(ctx->device);
     double* d_stats = nullptr;
     if (out_mean_err) {
@@ -528,7 +531,7 @@ extern "C" yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, c
         YA_HIP(ctx, hipMemsetAsync(d_stats, 0, 16, ctx->stream));
     }
     TimedRegion tr(ctx, "shadow_build_i8");
-    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, n_rows, dim, out_rows_i8, out_meta, d_stats));
+    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, first_row, n_rows, dim, out_rows_i8, out_meta, d_stats));
     tr.end();
     if (out_mean_err) {
         double h[2] = {0.0, 0.0};

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "scan_args.h"
+#include "lds_dma.h"
 
 namespace yams_accel {
 
@@ -365,22 +366,6 @@ constexpr int V2_B_BYTES = BT_QUERIES * V2_K * 2;       // one bf16 plane: 32 B 
 constexpr int v2_stage_bytes(int passes) { return V2_A_BYTES + (passes == 3 ? 2 : 1) * V2_B_BYTES; }
 static_assert(v2_stage_bytes(3) == 32768 && v2_stage_bytes(1) == 24576, "stage size");
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-
-__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// Same, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the base moves
-// with scalar adds, so no VALU address arithmetic sits between the MFMAs.
-__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
 
 // ABL is a measurement knob (never set by the product path): 2 = no MFMAs (staging-only time);
 // the epilogue then appends nothing.
@@ -775,20 +760,13 @@ struct ShFrags { bf16x8 a[2]; bf16x8 b[4]; };
 //                            4 -> 2x2 waves of 128 rows x 128 queries (one wave per SIMD, 256
 //                                 accumulator registers): a third less fragment-read traffic
 //                                 (64 instead of 96 KiB per slab), twice the DMA pieces per wave.
-// I8: the INT8 tier — the same loop, byte for byte (a 64-byte row slab is 64 int8 k-values instead
-// of 32 bf16 ones; v_mfma_i32_32x32x32_i8 takes its 16-byte operand from the same lanes as
-// v_mfma_f32_32x32x16_bf16 and retires twice the multiply-adds in the same 32 cycles), exact integer
-// accumulation, per-row / per-query scales applied in the epilogue (i8_epilogue).  Cosine only.
-template <int MODE, int METRIC, int ABL = 0, int NW = 8, bool I8 = false>
+template <int MODE, int METRIC, int ABL = 0, int NW = 8>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_kernel(ScanArgs a) {
-    static_assert(!I8 || (METRIC == YAMS_SCAN_COSINE && ABL == 0 && NW == 8), "the int8 tier is cosine-only");
-    using acc_t = std::conditional_t<I8, i32x16, f32x16>;
     constexpr int RB = 16 / NW;       // 32-row blocks per wave (2 or 4)
     constexpr int PA = 16 / NW;       // DMA pieces per wave per operand per slab (2 or 4)
     constexpr int P = 2 * PA;         // DMA pieces per wave per slab
     constexpr int M = RB * 4;         // MFMAs per 16-wide step
     __shared__ __attribute__((aligned(16))) unsigned char lds[SH_NST * SH_STAGE];
-    __shared__ float2 lds_meta[I8 ? BT_ROWS : 1]; // int8 tier: {s_r, e_r} of the tile's rows (epilogue)
 
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
@@ -808,8 +786,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
     const uint64_t row0 = static_cast<uint64_t>(tile) * BT_ROWS;
     const uint32_t q0 = qt * BT_QUERIES;
     const uint32_t dim = a.dim;
-    constexpr int EB = I8 ? 1 : 2;                 // bytes per corpus / query element
-    const int nslab = dim / (I8 ? 2 * SH_K : SH_K); // dim % 32 == 0 (int8: % 64) is a precondition of this kernel
+    const int nslab = dim / SH_K; // dim % 32 == 0 is a precondition of this kernel
 
     // ---- DMA sources: every wave stages 16 PA rows and 16 PA queries per slab --------------------
     // address = uniform base (tile / query-tile start + slab offset, SGPRs) + per-lane byte offset
@@ -820,13 +797,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
         const int c = (lane & 3) ^ ((rowA >> 2) & 3);
         uint64_t r = row0 + rowA;
         if (r >= a.n_rows) r = a.n_rows - 1; // row0 < n_rows, so r - row0 >= 0
-        voffA[i] = static_cast<uint32_t>(r - row0) * dim * EB + c * 16u;
+        voffA[i] = static_cast<uint32_t>(r - row0) * dim * 2u + c * 16u;
         voffB[i] = static_cast<uint32_t>(rowA) * 64u + c * 16u;
     }
-    const unsigned char* baseA = I8 ? reinterpret_cast<const unsigned char*>(a.rows_i8 + row0 * dim)
-                                    : reinterpret_cast<const unsigned char*>(a.rows_bf16 + row0 * dim);
-    const unsigned char* baseB = (I8 ? reinterpret_cast<const unsigned char*>(a.q_i8)
-                                     : reinterpret_cast<const unsigned char*>(a.q_hi)) + static_cast<uint64_t>(q0) * 64;
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_bf16 + row0 * dim);
+    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_hi + static_cast<uint64_t>(q0) * 32);
     const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
@@ -843,13 +818,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
         else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= PA ? p - PA : 0], ldsB + st + (p - PA) * 1024);
     };
 
-    acc_t acc[RB][4];
+    f32x16 acc[RB][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][u][r] = 0;
+            for (int r = 0; r < 16; ++r) acc[rb][u][r] = 0.f;
 
     // fragment offsets inside a stage, per 16-wide step t: logical chunk 2t + h of the row / query,
     // stored at position chunk ^ ((index >> 2) & 3)
@@ -902,9 +877,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
 #pragma unroll
                     for (int v = 0; v < 4; ++v) asm volatile("" :: "v"(cur.b[v]));
                 }
-            } else if constexpr (I8) {
-                acc[rb][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, cur.a[rb]),
-                                                                   __builtin_bit_cast(i32x4v, cur.b[u]), acc[rb][u], 0, 0, 0);
             } else {
                 acc[rb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb], cur.b[u], acc[rb][u], 0, 0, 0);
             }
@@ -926,26 +898,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
     // epilogue inputs, requested now: a load issued at the end would sit on the critical path of
     // every tile (rows_nsq streams from HBM), here it hides under the whole k loop
     float nfull_pre[RB], tau_pre[4];
-    float2 meta_pre[RB];                      // int8 tier: {s_r, e_r} of row (lane & 31) of each row block
-    float q_t[4], q_c[4], q_f[4];             // int8 tier: per-query scale, |quantised q|, residue bound
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const uint64_t r = row0 + static_cast<uint32_t>(wr * (32 * RB) + rb * 32) + l31;
-        if constexpr (I8) {
-            meta_pre[rb] = r < a.n_rows ? reinterpret_cast<const float2*>(a.rows_i8_meta)[r] : make_float2(1.f, 0.f);
-            nfull_pre[rb] = 1.f;
-        } else {
-            nfull_pre[rb] = r < a.n_rows ? a.rows_nsq[r] : 1.f;
-        }
+        nfull_pre[rb] = r < a.n_rows ? a.rows_nsq[r] : 1.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t qi = q0 + wc * 128 + u * 32 + l31;
         tau_pre[u] = (MODE == MODE_FILTER && ABL == 0 && qi < a.n_queries) ? a.tau[qi] : __builtin_inff();
-        if constexpr (I8) {
-            const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // [q_pad][4]: padded, always readable
-            q_t[u] = qm.x; q_c[u] = qm.y; q_f[u] = qm.z;
-        }
     }
     // (these older loads complete before any DMA piece issued below — vmcnt retires in order — so the
     // counted waits in the loop stay valid; the compiler waits for them at their first use, the
@@ -1017,32 +978,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void scan_tiles_bf16s_ker
         __builtin_amdgcn_sched_barrier(0);
         step(f1, f0, lds, 0, false, -1, 0);
     }
-    if constexpr (I8) {
-        // the row factors of this wave's rows go to LDS (wave-private slots; DS operations of one wave
-        // execute in order, so no barrier): hot lanes of the epilogue read them per element
-        if (h == 0) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) lds_meta[wr * (32 * RB) + rb * 32 + l31] = meta_pre[rb];
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if constexpr (MODE == MODE_FILTER) {
-            uint32_t ppass[RB][4], pbase[RB][4];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                i8_epilogue<MODE, 4, 1>(a, acc[rb], meta_pre[rb].x, meta_pre[rb].y, row0, static_cast<uint32_t>(wr * (32 * RB) + rb * 32),
-                                        q0 + wc * 128, sel, h, l31, lds_meta, q_t, q_c, q_f, tau_pre, ppass[rb], pbase[rb]);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                i8_epilogue<MODE, 4, 2>(a, acc[rb], meta_pre[rb].x, meta_pre[rb].y, row0, static_cast<uint32_t>(wr * (32 * RB) + rb * 32),
-                                        q0 + wc * 128, sel, h, l31, lds_meta, q_t, q_c, q_f, tau_pre, ppass[rb], pbase[rb]);
-        } else {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                i8_epilogue<MODE, 4>(a, acc[rb], meta_pre[rb].x, meta_pre[rb].y, row0, static_cast<uint32_t>(wr * (32 * RB) + rb * 32),
-                                     q0 + wc * 128, sel, h, l31, lds_meta, q_t, q_c, q_f, tau_pre);
-        }
-    } else if constexpr (MODE == MODE_FILTER && ABL == 0 && METRIC == YAMS_SCAN_COSINE) {
+    if constexpr (MODE == MODE_FILTER && ABL == 0 && METRIC == YAMS_SCAN_COSINE) {
         // reservations of all row blocks first, then their stores (overlapping round trips); the L2
         // epilogue has no registers to spare for the pending masks and keeps one round trip per block
         uint32_t ppass[RB][4], pbase[RB][4];
@@ -1458,128 +1394,6 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const float* rows, ui
     if (lane == 0) out_nsq[row] = nsq;
 }
 
-// The INT8 shadow: round-to-nearest int8 of the UNIT-NORMALISED row divided by its own scale
-// s_r = max|x~_i| / 127, plus {s_r, e_r} per row, e_r >= |x~ - s_r xi| — the MEASURED quantisation
-// residue of this row (not a worst-case figure), inflated by the fp32 rounding of its own
-// evaluation and by the error of the fp32 normalisation ((dim + 32) 2^-24).  One wave per row, three
-// passes over the row (the second and third hit L1/L2).  Rows whose squared norm is outside
-// (1e-30, 1e30) or not finite get an all-zero int8 row, s_r = 1 and e_r = +inf (always a candidate).
-// stats (nullable): [0] += e_r of every usable row (double), [1] += 1 per usable row (as uint64).
-__global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows, uint64_t n_rows, uint32_t dim,
-                                                              int8_t* out_i8, float* out_meta, double* stats) {
-    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const int lane = threadIdx.x & 63;
-    const float* src = rows + row * dim;
-    int8_t* dst = out_i8 + row * dim;
-    float nsq = 0.f, amax = 0.f;
-    for (uint32_t c = lane * 4; c < dim; c += 256) { // dim % 64 == 0
-        const float4 v = *reinterpret_cast<const float4*>(src + c);
-        nsq = fmaf(v.x, v.x, nsq); nsq = fmaf(v.y, v.y, nsq);
-        nsq = fmaf(v.z, v.z, nsq); nsq = fmaf(v.w, v.w, nsq);
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { nsq += __shfl_xor(nsq, d); amax = fmaxf(amax, __shfl_xor(amax, d)); }
-    const bool ok = norm_in_range(nsq) && amax > 0.f && amax < __builtin_inff();
-    const float inv = ok ? rsqrtf(nsq) : 0.f;
-    const float umax = amax * inv;                       // largest |x~_i| (the products below are monotone in |v|)
-    const float sc = ok ? umax / 127.0f : 1.0f;          // s_r
-    const float isc = ok ? 127.0f / umax : 0.f;
-    float esq = 0.f;
-    for (uint32_t c = lane * 4; c < dim; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(src + c);
-        const float x[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
-        uint32_t packed = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float qf = rintf(x[e] * isc);
-            qf = fminf(fmaxf(qf, -127.f), 127.f);
-            const float d = fmaf(-sc, qf, x[e]);         // residue of this element
-            esq = fmaf(d, d, esq);
-            packed |= (static_cast<uint32_t>(static_cast<int>(qf)) & 0xffu) << (8 * e);
-        }
-        *reinterpret_cast<uint32_t*>(dst + c) = ok ? packed : 0u;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) esq += __shfl_xor(esq, d);
-    if (lane == 0) {
-        // |d| up: the fp32 sum of squares (relative 2^-24 per term, dim terms) and sqrt; then the
-        // distance between the fp32-normalised row and the true unit row
-        const float e = ok ? sqrtf(esq) * (1.0f + (static_cast<float>(dim) + 16.f) * 5.9604645e-8f) +
-                                 (static_cast<float>(dim) + 32.f) * 5.9604645e-8f
-                           : __builtin_inff();
-        out_meta[2 * row] = sc;
-        out_meta[2 * row + 1] = e;
-        if (stats && ok) {
-            atomicAdd(stats, static_cast<double>(e));
-            atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, 1ull);
-        }
-    }
-}
-
-// Quantises the prepared (unit-norm) queries of a batch for the INT8 tier.  One workgroup per padded
-// query: qi = rint(q~ / t_q), t_q = max|q~_i| / 127, written k-slab-major ([dim/64][q_pad][64] int8,
-// the layout the filter's DMA pieces expect); meta[q] = {t_q, c_q, f_q, 0} with c_q >= |t_q qi| and
-// f_q >= |q~ - t_q qi| + 1e-6 (the absolute slop covers the fp32 evaluation of the score bound and the
-// final fp64 -> fp32 rounding of the exact similarity).  Padding queries are zero with t_q = 1.
-__global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                                                      int8_t* q_i8, float* q_meta) {
-    const uint32_t q = blockIdx.x;
-    __shared__ float red[256];
-    __shared__ float s_amax;
-    const bool live = q < nq;
-    const float* src = qprep + static_cast<uint64_t>(q) * dim;
-    float amax = 0.f;
-    if (live)
-        for (uint32_t i = threadIdx.x; i < dim; i += 256) amax = fmaxf(amax, fabsf(src[i]));
-    red[threadIdx.x] = amax;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) s_amax = red[0];
-    __syncthreads();
-    const float am = s_amax;
-    const bool ok = live && am > 0.f && am < __builtin_inff(); // an invalid query was zeroed by prep_queries
-    const float t = ok ? am / 127.0f : 1.0f;
-    const float it = ok ? 127.0f / am : 0.f;
-    float csq = 0.f, fsq = 0.f;
-    for (uint32_t i = threadIdx.x; i < dim; i += 256) {
-        const float x = live ? src[i] : 0.f;
-        float qf = rintf(x * it);
-        qf = fminf(fmaxf(qf, -127.f), 127.f);
-        const float qq = t * qf;
-        const float d = fmaf(-t, qf, x);
-        csq = fmaf(qq, qq, csq);
-        fsq = fmaf(d, d, fsq);
-        q_i8[(static_cast<uint64_t>(i >> 6) * q_pad + q) * 64 + (i & 63)] = ok ? static_cast<int8_t>(static_cast<int>(qf)) : int8_t(0);
-    }
-    __syncthreads();
-    red[threadIdx.x] = csq;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    const float csum = red[0];
-    __syncthreads();
-    red[threadIdx.x] = fsq;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float up = 1.0f + (static_cast<float>(dim) + 16.f) * 5.9604645e-8f;
-        q_meta[4 * q + 0] = t;
-        q_meta[4 * q + 1] = ok ? sqrtf(csum) * up : 0.f;
-        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + (static_cast<float>(dim) + 32.f) * 5.9604645e-8f + 1e-6f : 0.f;
-        q_meta[4 * q + 3] = 0.f;
-    }
-}
-
 // Split the prepared fp32 queries into bf16 head + tail planes, k-slab-major with slabs of
 // `slab` (16 or 32) k-values: plane[(k / slab) * q_pad + q][k % slab]; rows q >= n_queries are zero.
 __global__ void prep_split_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
@@ -1628,37 +1442,6 @@ hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_row
                        rows, n_rows, dim, out_bf16, out_nsq);
     hipError_t e_ = hipGetLastError();
     return e_;
-}
-
-hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
-                                  int8_t* out_i8, float* out_meta, double* stats) {
-    if (n_rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(shadow_build_i8_kernel, dim3(static_cast<uint32_t>((n_rows + 3) / 4)), dim3(256), 0, st,
-                       rows, n_rows, dim, out_i8, out_meta, stats);
-    return hipGetLastError();
-}
-
-hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta) {
-    if (q_pad == 0) return hipSuccess;
-    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta);
-    return hipGetLastError();
-}
-
-// The INT8 tier: 256 x 256 tiles of scan_tiles_bf16s_kernel<..., I8 = true> (XCD-aware block -> tile
-// map as for the bf16 tier).  version: see launch_scan_bf16.
-hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version) {
-    (void)version;
-    ScanArgs a = make_scan_args(L);
-    a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
-    if (a.n_sel_tiles == 0) return hipSuccess;
-    const uint32_t groups = (a.n_sel_tiles + 7) / 8;
-    const uint32_t grid = groups * a.n_qtiles * 8;
-    if (mode == MODE_SAMPLE)
-        hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_SAMPLE, YAMS_SCAN_COSINE, 0, 8, true>), dim3(grid), dim3(512), 0, st, a);
-    else
-        hipLaunchKernelGGL((scan_tiles_bf16s_kernel<MODE_FILTER, YAMS_SCAN_COSINE, 0, 8, true>), dim3(grid), dim3(512), 0, st, a);
-    return hipGetLastError();
 }
 
 #define LAUNCH_BF16(PASSES) do { \

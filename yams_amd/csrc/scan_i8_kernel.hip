@@ -1,0 +1,573 @@
+// scan_i8_kernel.hip — the INT8 tier of the filter pass (cosine).
+//
+// Same contract as the bf16 tiers (scan_bf16_kernel.hip): score every (row, query) pair with a
+// rigorous bound, keep what can reach the top k; the fp64 re-score + proof that follow make the
+// result bit-identical to the reference (sqlite_vec_backend.cpp:4204-4331).  What changes is the
+// arithmetic of the contraction: the rows and the queries are quantised to int8 and multiplied on
+// v_mfma_i32_16x16x64_i8 — exact integer accumulation, half the operand bytes of bf16, and the
+// highest sustained matrix rate this part offers (scripts/ubench/mfma_i8_rate.hip, random operands,
+// two waves per SIMD: 4.4 POP/s, against 3.6 for v_mfma_i32_32x32x32_i8 and 1.77 PFLOP/s for
+// v_mfma_f32_32x32x16_bf16 — the 16 x 16 shape moves a quarter of the accumulator registers per
+// multiply-add and sustains a higher clock).
+//
+// Quantisation (shadow_build_i8_kernel): the unit-normalised row x~ is stored as int8 xi with ONE
+// scale per block of 16 rows, s_b = max |x~_i| over the block / 127, together with e_b = the largest
+// MEASURED residue |x~ - s_b xi| of the block's rows (not a worst-case figure).  Queries get their own
+// scale t_q per batch (prep_i8_kernel), with c_q >= |t_q qi| and f_q >= |q~ - t_q qi| + slop.  Then
+//     cos(x, q) = x~ . q~ = s_b t_q (xi . qi) + d . (t_q qi) + x~ . p   <=   s_b t_q I + e_b c_q + f_q =: u
+// (Cauchy-Schwarz; I = xi . qi exactly).  The filter score of this tier IS the upper bound u, so the
+// completeness proof of the re-score needs no further error term.  A row survives iff u >= tau_q, i.e.
+//     I >= (tau_q - f_q) / t_q * (1 / s_b) - (c_q / t_q) * (e_b / s_b) = A_q IS_b - B_q G_b,
+// an INTEGER threshold per (16-row block, query): the epilogue is one v_max tree per query block
+// against the smallest threshold of the wave's four row blocks, and only lanes that can hold a
+// survivor (~1 %) look at single elements.
+#include <type_traits>
+
+#include "lds_dma.h"
+#include "scan_args.h"
+
+namespace yams_accel {
+
+using i32x4v = __attribute__((ext_vector_type(4))) int;
+
+constexpr int I8_ROWS = 256, I8_QUERIES = 256, I8_THREADS = 512;
+constexpr int I8_SLAB = 64;                        // bytes (= int8 k-values) per row per ring stage
+constexpr int I8_NST = 4;
+constexpr int I8_A_BYTES = I8_ROWS * I8_SLAB;      // 16 KiB
+constexpr int I8_B_BYTES = I8_QUERIES * I8_SLAB;   // 16 KiB
+constexpr int I8_STAGE = I8_A_BYTES + I8_B_BYTES;
+constexpr int I8_BLOCK_ROWS = 16;                  // rows that share one quantisation scale
+
+// LDS image of a 64-byte row slab: four 16-byte chunks; logical chunk c of row R sits at position
+// c ^ g((R >> 2) & 3), g = {0, 2, 3, 1}.  A v_mfma_i32_16x16x64_i8 operand is "row (lane & 15),
+// chunk (lane >> 4)"; ds_read_b128 serves a wave in four fixed 16-lane groups ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, ...): with this g every group touches each of the 16 bank quads exactly once.
+__device__ __forceinline__ int i8_swz(int row) {
+    const int j = (row >> 2) & 3;
+    return (((j ^ (j >> 1)) & 1) << 1) | (j >> 1);
+}
+
+// per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
+// MODE_SAMPLE writes dense upper bounds + group maxima (groups of 16 rows: the rows one lane holds
+// for a query block — 4 row blocks x 4 consecutive rows — see collect_sample_kernel, layout 1).
+template <int MODE, int ABL = 0>
+__global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[I8_NST * I8_STAGE];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t w = bid >> 3;
+    const uint32_t qt = w % a.n_qtiles;
+    const uint32_t sel = (w / a.n_qtiles) * 8u + xcd;
+    if (sel >= a.n_sel_tiles) return;
+    uint32_t tile;
+    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
+    else tile = sel + sel / (a.stride - 1u) + 1u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) x queries [128 wc, +128)
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint64_t row0 = static_cast<uint64_t>(tile) * I8_ROWS;
+    const uint32_t q0 = qt * I8_QUERIES;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
+
+    // ---- DMA sources: every wave stages 32 rows and 32 queries per slab (4 pieces of 1 KiB) -------
+    uint32_t voffA[2], voffB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ i8_swz(rowA);
+        uint64_t r = row0 + rowA;
+        if (r >= a.n_rows) r = a.n_rows - 1; // row0 < n_rows
+        voffA[i] = static_cast<uint32_t>(r - row0) * dim + c * 16u;
+        voffB[i] = static_cast<uint32_t>(rowA) * 64u + c * 16u;
+    }
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + row0 * dim);
+    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + I8_A_BYTES + wid * 2048);
+    auto piece = [&](int s, int p) __attribute__((always_inline)) {
+        if ((ABL == 1) && s >= I8_NST) return; // measurement build: no refills after the prologue
+        const uint32_t st = (s & (I8_NST - 1)) * I8_STAGE;
+        if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + st + p * 1024);
+        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + st + (p - 2) * 1024);
+    };
+
+    i32x4v acc[4][8];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
+
+    // fragment offsets inside a stage: row block rb adds rb * 1 KiB, query block cb adds cb * 1 KiB
+    // (block starts are multiples of 16 rows, so the swizzle term depends on the lane only)
+    const int offA = (wr * 64 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+    const int offB = I8_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+
+    // epilogue inputs, requested now (older than every DMA piece, so the counted waits stay valid;
+    // the compiler waits for them at their first use, after the loop)
+    float2 qthr[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        const uint32_t qi = q0 + wc * 128 + cb * 16 + l15; // < q_pad: the threshold table is padded
+        qthr[cb] = (MODE == MODE_FILTER && ABL == 0) ? reinterpret_cast<const float2*>(a.q_thr)[qi] : make_float2(0.f, 0.f);
+    }
+
+    auto wait_vm = [&](int pieces) __attribute__((always_inline)) {
+        if (pieces >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (pieces >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (pieces >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    {   // prologue: slabs 0..2 and the first half of slab 3 in flight, slab 0 landed
+        int issued = 0;
+        for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < 4; ++p) piece(s, p); issued += 4; }
+        if (nslab > 3) { piece(3, 0); piece(3, 1); issued += 2; }
+        wait_vm(issued - 4);
+        __builtin_amdgcn_s_barrier();
+    }
+    // Fragments: A (4 row blocks) double-buffered across slabs, B in two halves of 4 query blocks.
+    i32x4v fa[2][4], fb[2][4];
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(lds, offA + rb * 1024);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offB + cb * 1024);
+    int stage = 0;
+
+    // One slab = two halves of 16 MFMAs (all four row blocks x four query blocks each).
+    //   half 1: multiplies fa[cur] x fb[0]; requests the other four query blocks of THIS slab (fb[1])
+    //           and issues the second half of slab s+3's DMA pieces (its stage was released by the
+    //           barrier of the previous iteration);
+    //   barrier: slab s+1 has landed, every wave is done reading slab s;
+    //   half 2: multiplies fa[cur] x fb[1]; requests slab s+1's row blocks (fa[nxt]) and first four
+    //           query blocks (fb[0]) and issues the first half of slab s+4's pieces.
+    // Loads and DMA pieces sit one per MFMA gap; the steady-state body is one basic block.
+    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rb = i >> 2, c = i & 3;
+            if (ABL != 2)
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+            else if (i == 0)
+                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            filler(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // REM = slabs left including this one (5 = five or more): decides which DMA halves are still to be
+    // issued, how many newer slabs may be in flight at the barrier, and whether a next slab exists.
+    // CUR = which of the two row-fragment buffers this slab uses (compile time: a runtime index would
+    // push the fragment arrays into scratch memory).
+    auto body = [&](int s, auto cur_tag, auto rem_tag) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr int REM = decltype(rem_tag)::value;
+        constexpr bool H1 = REM >= 4;                  // slab s+3 exists: issue its second half
+        constexpr bool H2 = REM >= 5;                  // slab s+4 exists: issue its first half
+        constexpr int VM = REM >= 4 ? 2 : (REM == 3 ? 1 : 0);
+        constexpr bool MORE = REM >= 2;
+        const unsigned char* base = lds + stage * I8_STAGE;
+        stage = (stage + 1) & (I8_NST - 1);
+        const unsigned char* nbase = lds + stage * I8_STAGE;
+        pin4(fa[CUR]); pin4(fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[0], 0, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[1][i < 4 ? i : 0] = ld(base, offB + (4 + (i < 4 ? i : 0)) * 1024);
+            if (H1 && (i == 6 || i == 12)) piece(s + 3, i == 6 ? 2 : 3);
+        });
+        if (VM == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (VM == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[1], 4, [&](int i) __attribute__((always_inline)) {
+            if (MORE && i < 4) fa[CUR ^ 1][i < 4 ? i : 0] = ld(nbase, offA + (i < 4 ? i : 0) * 1024);
+            if (MORE && i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(nbase, offB + ((i - 4) & 3) * 1024);
+            if (H2 && (i == 9 || i == 13)) piece(s + 4, i == 9 ? 0 : 1);
+        });
+    };
+    using R5 = std::integral_constant<int, 5>;
+    using R4 = std::integral_constant<int, 4>;
+    using R3 = std::integral_constant<int, 3>;
+    using R2 = std::integral_constant<int, 2>;
+    using R1 = std::integral_constant<int, 1>;
+    // nslab >= 4 (dim >= 256, checked by the host).  The last four slabs have their own bodies; the
+    // nslab - 4 steady-state slabs run two per trip with the buffer parity fixed at compile time.  An
+    // odd count runs one steady body first and then renames the prefetched row fragments into buffer
+    // 0, so that a single code path leads into the pair loop and the tail (several alternative paths
+    // of unrolled bodies made the register allocator spill the accumulators).
+    const int n_steady = nslab - 4;
+    int s = 0;
+    if (n_steady & 1) {
+        body(0, C0{}, R5{});
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) fa[0][rb] = fa[1][rb];
+        s = 1;
+    }
+    for (; s < n_steady; s += 2) { body(s, C0{}, R5{}); body(s + 1, C1{}, R5{}); }
+    body(s, C0{}, R4{}); body(s + 1, C1{}, R3{}); body(s + 2, C0{}, R2{}); body(s + 3, C1{}, R1{});
+
+    if (ABL != 0) { // measurement builds: keep the accumulators alive, emit nothing
+        int t = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
+        if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        return;
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
+    const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
+    const uint32_t qb = q0 + wc * 128;
+    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    float sb[4], eb[4];                 // wave-uniform: scale and residue bound of the four row blocks
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const uint64_t blk = strip / I8_BLOCK_ROWS + rb;
+        const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
+        sb[rb] = m.x; eb[rb] = m.y;
+    }
+    if (MODE == MODE_SAMPLE) {
+        const float ninf = -__builtin_inff();
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const uint32_t qi = qb + cb * 16 + l15;
+            const bool qok = qi < a.n_queries;
+            const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
+            float m = ninf;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float S = sb[rb] * qm.x, K = fmaf(eb[rb], qm.y, qm.z);
+                const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                    v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
+                    m = fmaxf(m, v[r]);
+                }
+                if (qok) {
+                    const uint64_t srow = static_cast<uint64_t>(sel) * I8_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
+                    *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            if (qok) {
+                const uint32_t gid = (sel * I8_ROWS + static_cast<uint32_t>(wr * 64)) / 16u + lq;
+                a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
+            }
+        }
+        return;
+    }
+    // FILTER: integer thresholds.  T(rb, cb) = A_lo IS_rb - B_hi G_rb - 2, truncated towards zero
+    // (A_lo / B_hi carry the relative slack for the fp32 evaluation, the 2 covers the truncation).
+    float IS[4], G[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) { IS[rb] = 1.0f / sb[rb]; G[rb] = eb[rb] * IS[rb]; }
+    const float is_min = fminf(fminf(IS[0], IS[1]), fminf(IS[2], IS[3]));
+    const float is_max = fmaxf(fmaxf(IS[0], IS[1]), fmaxf(IS[2], IS[3]));
+    const float g_max = fmaxf(fmaxf(G[0], G[1]), fmaxf(G[2], G[3]));
+    auto thr_int = [](float A, float is, float B, float g) -> int {
+        const float t = fmaf(A, is, fmaf(-B, g, -2.0f));
+        if (t != t) return static_cast<int>(0x80000000u);          // NaN: keep everything
+        return t >= 2.0e9f ? 0x7fffffff : (t <= -2.0e9f ? static_cast<int>(0x80000000u) : static_cast<int>(t));
+    };
+    uint32_t hot = 0;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        int m = acc[0][cb][0];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
+        const float A = qthr[cb].x, B = qthr[cb].y;
+        const int tmin = thr_int(A, A >= 0.f ? is_min : is_max, B, g_max);
+        if (m >= tmin && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+    }
+    if (hot == 0) return; // ~99 % of the lanes
+    // the lane may hold survivors: exact integer test per (row block, query block), one reservation per
+    // query block (all of them issued before the first store), then the stores
+    uint32_t pass[8], base[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        pass[cb] = 0u;
+        if ((hot >> cb) & 1u) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const int ti = thr_int(qthr[cb].x, IS[rb], qthr[cb].y, G[rb]);
+                const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (acc[rb][cb][r] >= ti && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        base[cb] = 0u;
+        if (pass[cb]) base[cb] = atomicAdd(&a.list_count[qb + cb * 16 + l15], static_cast<uint32_t>(__builtin_popcount(pass[cb])));
+    }
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        if (!pass[cb]) continue;
+        const uint32_t qi = qb + cb * 16 + l15;
+        const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi];
+        uint32_t pos = base[cb];
+        uint64_t* lst = a.list + static_cast<uint64_t>(qi) * a.list_cap;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const float S = sb[rb] * qm.x, K = fmaf(eb[rb], qm.y, qm.z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
+                const uint64_t row = strip + 16 * rb + 4 * lq + r;
+                if (pos < a.list_cap)
+                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r]), S, K), static_cast<uint32_t>(row));
+                ++pos;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The INT8 shadow.  One wave per block of 16 rows.  A row is first scaled by its own largest
+// component (so tiny and huge rows normalise without under- or overflow), normalised in fp32, and
+// the block's scale is s_b = max |x~_i| / 127 over its usable rows.  e_b = the largest measured
+// residue |x~ - s_b xi| of those rows, inflated for the fp32 evaluation of the sum of squares and for
+// the distance between the fp32-normalised row and the true unit row.  Rows that are all zero or
+// hold a non-finite component get an all-zero int8 row: the reference never returns them
+// (:4258-4269), so they need no score.
+// `first_row` / `n_rows` name the rows that changed: every 16-row block that intersects
+// [first_row, first_row + n_rows) is rebuilt from its first row on (an append that starts inside a
+// block re-quantises that block's earlier rows with the new common scale).
+// stats (nullable): [0] += e_b of every block with a usable row (double), [1] += 1 per such block.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows, uint64_t first_block, uint64_t end_row,
+                                                              uint32_t dim, int8_t* out_i8, float* out_meta, double* stats) {
+    const uint64_t blk = first_block + static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const uint64_t r0 = blk * I8_BLOCK_ROWS;
+    if (r0 >= end_row) return;
+    const int lane = threadIdx.x & 63;
+    const int nr = static_cast<int>(end_row - r0 < I8_BLOCK_ROWS ? end_row - r0 : I8_BLOCK_ROWS);
+    float rinv[I8_BLOCK_ROWS];          // per row: 1 / (amax |x / amax|) or 0 for an unusable row
+    float umax = 0.f;                   // largest |x~_i| of the block
+    for (int rr = 0; rr < nr; ++rr) {
+        const float* src = rows + (r0 + rr) * dim;
+        float amax = 0.f; bool bad = false;
+        for (uint32_t c = lane * 4; c < dim; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            bad = bad || !(m <= 3.4e38f) || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w; // inf or NaN component
+            amax = fmaxf(amax, m);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+        bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        const bool ok = !bad && amax > 0.f;
+        const float ia = ok ? 1.0f / amax : 0.f;
+        float nsq = 0.f;
+        for (uint32_t c = lane * 4; c < dim; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            const float x0 = v.x * ia, x1 = v.y * ia, x2 = v.z * ia, x3 = v.w * ia;
+            nsq = fmaf(x0, x0, nsq); nsq = fmaf(x1, x1, nsq); nsq = fmaf(x2, x2, nsq); nsq = fmaf(x3, x3, nsq);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
+        const float inv = ok ? ia * rsqrtf(nsq) : 0.f;  // x~ = x * inv (nsq in [1, dim]: no range trouble)
+        rinv[rr] = inv;
+        if (ok) umax = fmaxf(umax, rsqrtf(nsq));         // |x~|_max = (amax * ia) * rsqrt(nsq)
+    }
+    const bool any = umax > 0.f;
+    const float sc = any ? umax / 127.0f : 1.0f;
+    const float isc = any ? 127.0f / umax : 0.f;
+    float emax = 0.f;
+    for (int rr = 0; rr < nr; ++rr) {
+        const float* src = rows + (r0 + rr) * dim;
+        int8_t* dst = out_i8 + (r0 + rr) * dim;
+        const float inv = rinv[rr];
+        float esq = 0.f;
+        for (uint32_t c = lane * 4; c < dim; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            const float x[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float qf = rintf(x[e] * isc);
+                qf = fminf(fmaxf(qf, -127.f), 127.f);
+                const float d = fmaf(-sc, qf, x[e]);
+                esq = fmaf(d, d, esq);
+                packed |= (static_cast<uint32_t>(static_cast<int>(qf)) & 0xffu) << (8 * e);
+            }
+            *reinterpret_cast<uint32_t*>(dst + c) = inv != 0.f ? packed : 0u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) esq += __shfl_xor(esq, d);
+        if (inv != 0.f) emax = fmaxf(emax, esq);
+    }
+    if (lane == 0) {
+        const float fd = static_cast<float>(dim);
+        const float e = any ? sqrtf(emax) * (1.0f + (fd + 16.f) * 5.9604645e-8f) + (fd + 64.f) * 5.9604645e-8f : 0.f;
+        out_meta[2 * blk] = sc;
+        out_meta[2 * blk + 1] = e;
+        if (stats && any) {
+            atomicAdd(stats, static_cast<double>(e));
+            atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, 1ull);
+        }
+    }
+}
+
+// Quantises the prepared (unit-norm) queries of a batch.  One workgroup per padded query:
+// qi = rint(q~ / t_q), t_q = max |q~_i| / 127, written k-slab-major ([dim/64][q_pad][64] int8, the
+// layout the filter's DMA pieces expect); meta[q] = {t_q, c_q, f_q, 0} with c_q >= |t_q qi| and
+// f_q >= |q~ - t_q qi| + 1e-6 (the absolute slop covers the fp32 evaluation of the score bound and the
+// fp64 -> fp32 rounding of the exact similarity).  Padding queries are zero with t_q = 1.
+__global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
+                                                      int8_t* q_i8, float* q_meta) {
+    const uint32_t q = blockIdx.x;
+    __shared__ float red[256];
+    const bool live = q < nq;
+    const float* src = qprep + static_cast<uint64_t>(q) * dim;
+    float amax = 0.f;
+    if (live)
+        for (uint32_t i = threadIdx.x; i < dim; i += 256) amax = fmaxf(amax, fabsf(src[i]));
+    red[threadIdx.x] = amax;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    const float am = red[0];
+    __syncthreads();
+    const bool ok = live && am > 0.f && am < __builtin_inff(); // an invalid query was zeroed by prep_queries
+    const float t = ok ? am / 127.0f : 1.0f;
+    const float it = ok ? 127.0f / am : 0.f;
+    float csq = 0.f, fsq = 0.f;
+    for (uint32_t i = threadIdx.x; i < dim; i += 256) {
+        const float x = live ? src[i] : 0.f;
+        float qf = rintf(x * it);
+        qf = fminf(fmaxf(qf, -127.f), 127.f);
+        const float qq = t * qf;
+        const float d = fmaf(-t, qf, x);
+        csq = fmaf(qq, qq, csq);
+        fsq = fmaf(d, d, fsq);
+        q_i8[(static_cast<uint64_t>(i >> 6) * q_pad + q) * 64 + (i & 63)] = ok ? static_cast<int8_t>(static_cast<int>(qf)) : int8_t(0);
+    }
+    red[threadIdx.x] = csq;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    const float csum = red[0];
+    __syncthreads();
+    red[threadIdx.x] = fsq;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float fd = static_cast<float>(dim);
+        const float up = 1.0f + (fd + 16.f) * 5.9604645e-8f;
+        q_meta[4 * q + 0] = t;
+        q_meta[4 * q + 1] = ok ? sqrtf(csum) * up : 0.f;
+        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + (fd + 32.f) * 5.9604645e-8f + 1e-6f : 0.f;
+        q_meta[4 * q + 3] = 0.f;
+    }
+}
+
+// After the sample pass: the per-query halves of the integer thresholds of the filter pass,
+//   A_lo <= (tau_q - f_q) / t_q,  B_hi >= c_q / t_q   (relative slack 2^-19 for the fp32 products the
+// kernel forms with them).  No threshold (tau = -inf or NaN) keeps everything; padding queries keep
+// nothing.
+__global__ void i8_query_thresholds_kernel(const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad, float* q_thr) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q_pad) return;
+    float A = __builtin_inff(), B = 0.f;
+    if (q < nq) {
+        const float t = q_meta[4 * q], c = q_meta[4 * q + 1], f = q_meta[4 * q + 2], ta = tau[q];
+        if (ta != ta) A = -__builtin_inff();
+        else {
+            A = (ta - f) / t;
+            A -= fabsf(A) * 1.9073486e-6f;
+        }
+        B = (c / t) * (1.0f + 1.9073486e-6f);
+    }
+    q_thr[2 * q] = A;
+    q_thr[2 * q + 1] = B;
+}
+
+} // namespace yams_accel
+
+#include "scan_launch.h"
+
+namespace yams_accel {
+
+ScanArgs make_scan_args(const ScanLaunch& L); // scan_kernels.hip
+
+hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
+                                  int8_t* out_i8, float* out_meta, double* stats) {
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t first_block = first_row / I8_BLOCK_ROWS;
+    const uint64_t end_row = first_row + n_rows;
+    const uint64_t n_blocks = (end_row + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS - first_block;
+    hipLaunchKernelGGL(shadow_build_i8_kernel, dim3(static_cast<uint32_t>((n_blocks + 3) / 4)), dim3(256), 0, st,
+                       rows, first_block, end_row, dim, out_i8, out_meta, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
+                          int8_t* q_i8, float* q_meta) {
+    if (q_pad == 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta);
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
+                                float* q_thr) {
+    if (q_pad == 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_query_thresholds_kernel, dim3((q_pad + 255) / 256), dim3(256), 0, st, tau, q_meta, nq, q_pad, q_thr);
+    return hipGetLastError();
+}
+
+// 256 x 256 tiles, XCD-aware block -> tile map as for the bf16 tier.  version: measurement build only
+// (31 = no DMA refills after the prologue, 32 = no MFMAs, 37 = the whole loop but no epilogue).
+hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version) {
+    (void)version;
+    ScanArgs a = make_scan_args(L);
+    a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
+    if (a.n_sel_tiles == 0) return hipSuccess;
+    const uint32_t groups = (a.n_sel_tiles + 7) / 8;
+    const uint32_t grid = groups * a.n_qtiles * 8;
+#ifdef YAMS_ACCEL_MEASURE
+    if (mode == MODE_FILTER && (version == 31 || version == 32 || version == 37)) {
+        if (version == 31) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 1>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        else if (version == 32) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 2>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 7>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+#endif
+    if (mode == MODE_SAMPLE) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_SAMPLE>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace yams_accel

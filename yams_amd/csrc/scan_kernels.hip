@@ -458,30 +458,32 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const uint32_t* gmax, u
 // Sample rows that reach the threshold join the candidate lists.  Driven by the group maxima:
 // only groups whose maximum reaches tau (a NaN group always does) have their 16 dense scores read.
 // Group gid covers rows  32 * (gid >> 1) + 4 * (gid & 1) + {0..3} + 8 * {0..3}  of the sample
-// (the MFMA accumulator layout of both sample kernels).
+// (the 32x32 MFMA accumulator layout of the f32 / bf16 sample kernels; layout16 == 0), or rows
+// 64 * (gid >> 2) + 4 * (gid & 3) + {0..3} + 16 * {0..3}  (the int8 tier's 16x16 layout).
 __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense, const uint32_t* gmax,
                                                              uint32_t n_groups, uint32_t n_queries,
                                                              uint64_t sample_rows, uint32_t tile_rows,
                                                              uint32_t stride,
                                                              uint64_t n_rows, const float* tau,
                                                              uint32_t* list_count, uint64_t* list,
-                                                             uint32_t list_cap) {
+                                                             uint32_t list_cap, int layout16) {
     const uint32_t q = blockIdx.y;
     const float t = tau[q];
     const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
         const float m = ord2f(gm[g]); // 0xffffffff decodes to NaN
         if (m < t) continue;
-        const uint64_t s0 = static_cast<uint64_t>(g >> 1) * 32 + 4 * (g & 1);
+        const uint64_t s0 = layout16 ? static_cast<uint64_t>(g >> 2) * 64 + 4 * (g & 3) : static_cast<uint64_t>(g >> 1) * 32 + 4 * (g & 1);
+        const uint32_t gstep = layout16 ? 16u : 8u;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(dense + dense_index(q, s0 + 8 * g4, n_queries));
+            const float4 v4 = *reinterpret_cast<const float4*>(dense + dense_index(q, s0 + gstep * g4, n_queries));
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = vv[e];
                 if (!(v < t)) {
-                    const uint64_t sidx = s0 + 8 * g4 + e;
+                    const uint64_t sidx = s0 + gstep * g4 + e;
                     const uint64_t row = (sidx / tile_rows) * stride * tile_rows + (sidx % tile_rows);
                     if (row < n_rows) {
                         const uint32_t pos = atomicAdd(&list_count[q], 1u);
@@ -898,6 +900,11 @@ struct MergeArgs {
     float threshold;
     const float* in_scores; const int64_t* in_rows; const uint32_t* in_counts;
     const float* in_dist; const uint32_t* in_ranks;
+    // distance between consecutive shards of each input, in ELEMENTS of that input (dense arrays:
+    // n_queries * k resp. n_queries; packed per-shard records: record bytes / element size)
+    uint64_t st_scores, st_rows, st_counts, st_dist, st_ranks;
+    const uint32_t* rank_of_row; // nullable: global tie rank of global row id (row - rank_row_base)
+    int64_t rank_row_base;
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
 };
 
@@ -912,30 +919,33 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
     auto valid = [&](uint32_t e) -> bool {
         if (e >= total) return false;
         const uint32_t sh = e / a.k, i = e % a.k;
-        return i < a.in_counts[static_cast<uint64_t>(sh) * a.n_queries + q];
+        return i < a.in_counts[static_cast<uint64_t>(sh) * a.st_counts + q];
     };
-    auto off = [&](uint32_t e) -> uint64_t {
-        const uint32_t sh = e / a.k, i = e % a.k;
-        return (static_cast<uint64_t>(sh) * a.n_queries + q) * a.k + i;
-    };
+    // element e = (shard, i) of query q: offset inside its shard's [n_queries][k] array
+    auto within = [&](uint32_t e) -> uint64_t { return static_cast<uint64_t>(q) * a.k + e % a.k; };
+    auto score_of = [&](uint32_t e) -> float { return a.in_scores[(e / a.k) * a.st_scores + within(e)]; };
+    auto dist_of = [&](uint32_t e) -> float { return a.in_dist[(e / a.k) * a.st_dist + within(e)]; };
+    auto row_of = [&](uint32_t e) -> int64_t { return a.in_rows[(e / a.k) * a.st_rows + within(e)]; };
     // better(x, y): x sorts before y
     auto better = [&](uint32_t x, uint32_t y) -> bool {
         const bool vx = valid(x), vy = valid(y);
         if (vx != vy) return vx;
         if (!vx) return x < y;
-        const uint64_t ox = off(x), oy = off(y);
         if (a.metric == YAMS_SCAN_L2) {
-            const float dx = a.in_dist[ox], dy = a.in_dist[oy];
+            const float dx = dist_of(x), dy = dist_of(y);
             if (dx != dy) return dx < dy;
         } else {
-            const float sx = a.in_scores[ox], sy = a.in_scores[oy];
+            const float sx = score_of(x), sy = score_of(y);
             if (sx != sy) return sx > sy;
         }
-        if (a.in_ranks) {
-            const uint32_t rx = a.in_ranks[ox], ry = a.in_ranks[oy];
+        const int64_t ix = row_of(x), iy = row_of(y);
+        if (a.in_ranks) { // ranks the caller guarantees to be comparable across shards
+            const uint32_t rx = a.in_ranks[(x / a.k) * a.st_ranks + within(x)], ry = a.in_ranks[(y / a.k) * a.st_ranks + within(y)];
+            if (rx != ry) return rx < ry;
+        } else if (a.rank_of_row) { // the corpus-wide chunk_id ranking, looked up by global row id
+            const uint32_t rx = a.rank_of_row[ix - a.rank_row_base], ry = a.rank_of_row[iy - a.rank_row_base];
             if (rx != ry) return rx < ry;
         }
-        const int64_t ix = a.in_rows[ox], iy = a.in_rows[oy];
         if (ix != iy) return ix < iy;
         return x < y;
     };
@@ -962,12 +972,12 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
         for (uint32_t i = 0; i < a.k && i < cap; ++i) {
             const uint32_t e = sidx[i];
             if (!valid(e)) break;
-            const uint64_t o = off(e);
-            if (a.metric == YAMS_SCAN_L2 && a.in_scores[o] < a.threshold) continue; // :4508-4510
+            const float sc = score_of(e);
+            if (a.metric == YAMS_SCAN_L2 && sc < a.threshold) continue; // :4508-4510
             const uint64_t d = static_cast<uint64_t>(q) * a.k + outn;
-            a.out_scores[d] = a.in_scores[o];
-            a.out_rows[d] = a.in_rows[o];
-            if (a.out_dist) a.out_dist[d] = a.in_dist ? a.in_dist[o] : 1.0f - a.in_scores[o];
+            a.out_scores[d] = sc;
+            a.out_rows[d] = row_of(e);
+            if (a.out_dist) a.out_dist[d] = a.in_dist ? dist_of(e) : 1.0f - sc;
             ++outn;
         }
         s_outn = outn;
@@ -1078,7 +1088,7 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
 ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
     a.rows = L.rows; a.rows_bf16 = L.rows_bf16; a.rows_nsq = L.rows_nsq;
-    a.rows_i8 = L.rows_i8; a.rows_i8_meta = L.rows_i8_meta; a.q_i8 = L.q_i8; a.q_meta = L.q_meta; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.rows_i8 = L.rows_i8; a.rows_i8_meta = L.rows_i8_meta; a.q_i8 = L.q_i8; a.q_meta = L.q_meta; a.q_thr = L.q_thr; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
@@ -1174,7 +1184,8 @@ hipError_t launch_collect_sample(hipStream_t st, const ScanLaunch& L) {
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.dense,
                        L.gmax, L.plan.n_groups, L.plan.n_queries, L.plan.sample_rows, L.plan.tile_rows,
-                       L.plan.sample_stride, L.plan.n_rows, L.tau, L.list_count, L.list, L.plan.list_cap);
+                       L.plan.sample_stride, L.plan.n_rows, L.tau, L.list_count, L.list, L.plan.list_cap,
+                       L.sample_layout);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1308,6 +1319,11 @@ hipError_t launch_merge(hipStream_t st, const MergeLaunch& M) {
     a.n_shards = M.n_shards; a.n_queries = M.n_queries; a.k = M.k; a.metric = M.metric;
     a.threshold = M.threshold; a.in_scores = M.in_scores; a.in_rows = M.in_rows;
     a.in_counts = M.in_counts; a.in_dist = M.in_dist; a.in_ranks = M.in_ranks;
+    const uint64_t dense = static_cast<uint64_t>(M.n_queries) * M.k;
+    a.st_scores = M.st_scores ? M.st_scores : dense; a.st_rows = M.st_rows ? M.st_rows : dense;
+    a.st_counts = M.st_counts ? M.st_counts : M.n_queries; a.st_dist = M.st_dist ? M.st_dist : dense;
+    a.st_ranks = M.st_ranks ? M.st_ranks : dense;
+    a.rank_of_row = M.rank_of_row; a.rank_row_base = M.rank_row_base;
     a.out_scores = M.out_scores; a.out_rows = M.out_rows; a.out_counts = M.out_counts;
     a.out_dist = M.out_dist;
     uint32_t cap = 1;

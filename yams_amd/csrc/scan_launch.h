@@ -13,6 +13,8 @@ struct ScanLaunch {
     const float* rows_i8_meta = nullptr;
     const int8_t* q_i8 = nullptr;
     const float* q_meta = nullptr;
+    const float* q_thr = nullptr;
+    int sample_layout = 0;               // rows of a sample group: 0 = 32x32 accumulator layout, 1 = 16x16 (int8 tier)
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
     const uint16_t* q_hi = nullptr;
@@ -45,6 +47,9 @@ struct MergeLaunch {
     const float* in_scores; const int64_t* in_rows; const uint32_t* in_counts;
     const float* in_dist; const uint32_t* in_ranks;
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
+    // 0 = dense arrays; else the distance between consecutive shards in elements of each input
+    uint64_t st_scores = 0, st_rows = 0, st_counts = 0, st_dist = 0, st_ranks = 0;
+    const uint32_t* rank_of_row = nullptr; int64_t rank_row_base = 0;
 };
 
 constexpr uint32_t kRescoreMax = 2047; // + 1 boundary key == kSelectCap / 2 (select convergence)
@@ -63,9 +68,13 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
 // Quantises the prepared (unit) queries of a batch: k-slab-major int8 plane + {t_q, c_q, f_q} per query.
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
                           int8_t* q_i8, float* q_meta);
-// The INT8 shadow of `n_rows` rows; stats (nullable) = {sum of finite e_r (double), rows counted (u64 bits)}.
-hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
+// (Re)builds the INT8 shadow of every 16-row block that intersects rows [first_row, first_row + n_rows)
+// of the mirror at `rows`; stats (nullable) = {sum of e_b (double), blocks counted (u64 bits)}.
+hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
                                   int8_t* out_i8, float* out_meta, double* stats);
+// After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
+hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
+                                float* q_thr);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_scan_filter(hipStream_t st, const ScanLaunch& L, int metric);
 hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* work32);
