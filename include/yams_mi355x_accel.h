@@ -144,6 +144,16 @@ typedef struct yams_scan_corpus_s {
                                   {s_b, e_b} per block of 16 rows: the block's quantisation scale
                                   and the largest measured residue |x/|x| - s_b * int8 row| of
                                   its rows                                                         */
+    uint32_t stripe_rows;      /* 0: a contiguous shard, global id = row_base + local row.  Else the
+                                  corpus is dealt to n_stripes shards in stripes of stripe_rows
+                                  rows (how a growing mirror stays balanced over devices): local
+                                  row L of this shard is global row  row_base +
+                                  ((L / stripe_rows) * n_stripes + stripe_index) * stripe_rows +
+                                  L % stripe_rows.  Local order == global order within a shard,
+                                  so the default tie-break (row id) stays the reference's.        */
+    uint32_t n_stripes;
+    uint32_t stripe_index;
+    uint32_t reserved2;
 } yams_scan_corpus_t;
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
@@ -252,6 +262,48 @@ YAMS_ACCEL_API yams_status_t yams_scan_merge_topk_device(
     const float* in_scores, const int64_t* in_rows, const uint32_t* in_counts,
     const float* in_dist, const uint32_t* in_ranks, float* out_scores, int64_t* out_rows,
     uint32_t* out_counts, float* out_dist);
+
+/* The packed per-shard result record: what one shard's search writes and what travels between
+ * devices (RCCL all-gather in the one-process-per-GPU form, peer copies in the in-process form):
+ *   scores f32 [n_queries][k] | rows i64 [n_queries][k] | counts u32 [n_queries]
+ *   (| dist f32 [n_queries][k]) (| ranks u32 [n_queries][k]),   every part 16-byte aligned.
+ * An absent part has offset UINT64_MAX. */
+typedef struct yams_scan_record_layout_s {
+    uint64_t scores_off, rows_off, counts_off, dist_off, ranks_off, bytes;
+} yams_scan_record_layout_t;
+YAMS_ACCEL_API void yams_scan_record_layout(uint32_t n_queries, uint32_t k, int with_dist,
+                                            int with_ranks, yams_scan_record_layout_t* out);
+
+/* k-way merge of `n_shards` records lying `record_stride` bytes apart in device memory (e.g. the
+ * output of one all-gather, untouched).  Order: similarity desc / distance asc, then the tie rank:
+ * the records' own ranks if present, else rank_of_row[row - rank_row_base] if given (device; the
+ * corpus-wide chunk_id ranking, :4218-4223), else the global row id. */
+YAMS_ACCEL_API yams_status_t yams_scan_merge_records_device(
+    yams_accel_ctx* ctx, uint32_t n_shards, uint32_t n_queries, const yams_scan_params_t* params,
+    const void* records, uint64_t record_stride, const yams_scan_record_layout_t* layout,
+    const uint32_t* rank_of_row, int64_t rank_row_base, float* out_scores, int64_t* out_rows,
+    uint32_t* out_counts, float* out_dist);
+
+/* One search over a corpus row-sharded across several devices of this node, behind one call: a
+ * context + host thread per shard, per-shard exact top-k, records copied device-to-device to the
+ * first shard's device, merged there.  `devices[i]` is the HIP device of shard i (shards may share
+ * a device).  shards[i] is shard i's view (device pointers valid on devices[i]; row_base / stripe
+ * fields give global ids); upload and build shadows through yams_scan_sharded_ctx(s, i).
+ * rank_of_row (nullable): device array on devices[0], the global tie ranking — needed only when
+ * the shards carry tie_rank arrays (then each shard's tie_rank must be a local permutation that
+ * preserves the global order).  A handle serves one call at a time. */
+typedef struct yams_scan_sharded yams_scan_sharded;
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards,
+                                                      yams_scan_sharded** out);
+YAMS_ACCEL_API void yams_scan_sharded_destroy(yams_scan_sharded* s);
+YAMS_ACCEL_API uint32_t yams_scan_sharded_count(const yams_scan_sharded* s);
+YAMS_ACCEL_API yams_accel_ctx* yams_scan_sharded_ctx(yams_scan_sharded* s, uint32_t shard);
+YAMS_ACCEL_API const char* yams_scan_sharded_last_error(const yams_scan_sharded* s);
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_topk_host(
+    yams_scan_sharded* s, const yams_scan_corpus_t* shards, const float* queries_host,
+    uint32_t n_queries, const yams_scan_params_t* params, const uint32_t* rank_of_row,
+    int64_t rank_row_base, float* out_scores_host, int64_t* out_rows_host,
+    uint32_t* out_counts_host, float* out_dist_host, yams_scan_diag_t* diag);
 
 /* Fill a device matrix with the synthetic embedding recipe: Philox4x32-10
  * (seed, row, col/4) -> U[-1,1) -> fp32 L2-normalise.  Used by bench.py and tests so that a

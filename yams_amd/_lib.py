@@ -37,7 +37,14 @@ class ScanCorpus(C.Structure):
     _fields_ = [("rows", vp), ("n_rows", C.c_uint64), ("dim", C.c_uint32), ("reserved", C.c_uint32),
                 ("tie_rank", vp), ("rank_row", vp), ("row_base", C.c_int64),
                 ("row_mask", vp), ("row_mask_count", C.c_uint64),
-                ("rows_bf16", vp), ("rows_nsq", vp), ("rows_i8", vp), ("rows_i8_meta", vp)]
+                ("rows_bf16", vp), ("rows_nsq", vp), ("rows_i8", vp), ("rows_i8_meta", vp),
+                ("stripe_rows", C.c_uint32), ("n_stripes", C.c_uint32), ("stripe_index", C.c_uint32),
+                ("reserved2", C.c_uint32)]
+
+
+class RecordLayout(C.Structure):
+    _fields_ = [("scores_off", C.c_uint64), ("rows_off", C.c_uint64), ("counts_off", C.c_uint64),
+                ("dist_off", C.c_uint64), ("ranks_off", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 class ScanParams(C.Structure):
@@ -145,6 +152,9 @@ EXPORTS = [
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device",
     "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device",
+    "yams_scan_record_layout", "yams_scan_merge_records_device", "yams_scan_sharded_create",
+    "yams_scan_sharded_destroy", "yams_scan_sharded_count", "yams_scan_sharded_ctx",
+    "yams_scan_sharded_last_error", "yams_scan_sharded_topk_host",
     "yams_synth_rows_device", "yams_synth_bytes_device", "yams_sha256_batch_device",
     "yams_sha256_host", "yams_sha256_many_host", "yams_verify_chunks_device", "yams_cdc_default_config",
     "yams_dedup_set_create", "yams_dedup_set_destroy", "yams_dedup_set_size", "yams_dedup_insert_device",
@@ -212,6 +222,21 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_scan_build_shadow_i8_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
     L.yams_scan_merge_topk_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.yams_scan_record_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(RecordLayout)]
+    L.yams_scan_record_layout.restype = None
+    L.yams_scan_merge_records_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams), vp, C.c_uint64,
+                                                 C.POINTER(RecordLayout), vp, C.c_int64, vp, vp, vp, vp]
+    L.yams_scan_sharded_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.yams_scan_sharded_destroy.argtypes = [vp]
+    L.yams_scan_sharded_destroy.restype = None
+    L.yams_scan_sharded_count.argtypes = [vp]
+    L.yams_scan_sharded_count.restype = C.c_uint32
+    L.yams_scan_sharded_ctx.argtypes = [vp, C.c_uint32]
+    L.yams_scan_sharded_ctx.restype = vp
+    L.yams_scan_sharded_last_error.argtypes = [vp]
+    L.yams_scan_sharded_last_error.restype = C.c_char_p
+    L.yams_scan_sharded_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32, C.POINTER(ScanParams), vp,
+                                              C.c_int64, vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     L.yams_synth_bytes_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     L.yams_sha256_batch_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]

@@ -182,10 +182,11 @@ class Accel:
                     rank_row_ptr: int | None = None, row_base: int = 0,
                     row_mask_ptr: int | None = None, row_mask_count: int = 0,
                     rows_bf16_ptr: int | None = None, rows_nsq_ptr: int | None = None,
-                    rows_i8_ptr: int | None = None, rows_i8_meta_ptr: int | None = None) -> ScanCorpus:
+                    rows_i8_ptr: int | None = None, rows_i8_meta_ptr: int | None = None,
+                    stripe_rows: int = 0, n_stripes: int = 0, stripe_index: int = 0) -> ScanCorpus:
         return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base,
                           row_mask_ptr, row_mask_count, rows_bf16_ptr, rows_nsq_ptr,
-                          rows_i8_ptr, rows_i8_meta_ptr)
+                          rows_i8_ptr, rows_i8_meta_ptr, stripe_rows, n_stripes, stripe_index, 0)
 
     def build_shadow_device(self, rows_ptr: int, n_rows: int, dim: int, out_bf16_ptr: int,
                             out_nsq_ptr: int) -> None:

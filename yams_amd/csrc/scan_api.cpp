@@ -107,6 +107,7 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
         RescoreLaunch R{};
         R.rows = c.rows; R.n_rows = c.n_rows; R.dim = c.dim; R.queries = io.queries; R.qnorm = d_qnorm;
         R.tie_rank = c.tie_rank; R.rank_row = c.tie_rank ? c.rank_row : nullptr; R.row_base = c.row_base;
+        R.stripe_rows = c.stripe_rows; R.n_stripes = c.n_stripes; R.stripe_index = c.stripe_index;
         R.cand = res; R.cand_stride = res_stride; R.n_cand = std::min<uint32_t>(keep, kRescoreMax);
         R.tau = nullptr; R.list_count = nullptr; R.list_cap = 0; R.all_rows_listed = 1;
         R.qmap = d_qmap + b0; R.n_slots = nb; R.k = io.prm.k; R.threshold = io.prm.similarity_threshold;
@@ -153,6 +154,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         return fail(ctx, YAMS_ERR_INVALID_ARG, "rows_i8 and rows_i8_meta must be given together");
     if (corpus->row_mask && corpus->row_mask_count > corpus->n_rows)
         return fail(ctx, YAMS_ERR_INVALID_ARG, "row_mask_count exceeds n_rows");
+    if (corpus->stripe_rows && (corpus->n_stripes == 0 || corpus->stripe_index >= corpus->n_stripes))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "striped shard needs stripe_index < n_stripes");
     (void)hipSetDevice(ctx->device);
 
     const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
@@ -333,7 +336,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             RescoreLaunch R{};
             R.rows = corpus->rows; R.n_rows = corpus->n_rows; R.dim = dim; R.queries = queries;
             R.qnorm = d_qnorm; R.tie_rank = corpus->tie_rank; R.rank_row = nullptr;
-            R.row_base = corpus->row_base; R.cand = res; R.cand_stride = res_stride;
+            R.row_base = corpus->row_base; R.stripe_rows = corpus->stripe_rows;
+            R.n_stripes = corpus->n_stripes; R.stripe_index = corpus->stripe_index; R.cand = res; R.cand_stride = res_stride;
             R.n_cand = n_cand; R.tau = d_tau; R.list_count = d_lcount; R.list_cap = plan.list_cap;
             R.all_rows_listed = 0; R.qmap = d_qmap; R.n_slots = n_slots; R.k = k;
             R.threshold = params->similarity_threshold; R.flags = params->flags;

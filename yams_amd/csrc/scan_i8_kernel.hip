@@ -113,7 +113,19 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     const int offB = I8_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
 
     // epilogue inputs, requested now (older than every DMA piece, so the counted waits stay valid;
-    // the compiler waits for them at their first use, after the loop)
+    // the compiler waits for them at their first use, after the loop): a load issued at the end would
+    // sit on the critical path of every tile — the block scales stream from HBM
+    const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
+    float sb[4], eb[4];                 // wave-uniform: scale and residue bound of the four row blocks
+    {
+        const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const uint64_t blk = strip / I8_BLOCK_ROWS + rb;
+            const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
+            sb[rb] = m.x; eb[rb] = m.y;
+        }
+    }
     float2 qthr[8];
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
@@ -234,16 +246,7 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
 
     // ---- epilogue ----------------------------------------------------------------------------------
     // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
-    const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
     const uint32_t qb = q0 + wc * 128;
-    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
-    float sb[4], eb[4];                 // wave-uniform: scale and residue bound of the four row blocks
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        const uint64_t blk = strip / I8_BLOCK_ROWS + rb;
-        const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
-        sb[rb] = m.x; eb[rb] = m.y;
-    }
     if (MODE == MODE_SAMPLE) {
         const float ninf = -__builtin_inff();
 #pragma unroll
@@ -320,6 +323,12 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
             }
         }
     }
+    // the query factors of the surviving blocks and the list reservations go out back to back (one
+    // memory round trip for both), then the stores
+    float4 qm[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+        qm[cb] = pass[cb] ? reinterpret_cast<const float4*>(a.q_meta)[qb + cb * 16 + l15] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
         base[cb] = 0u;
@@ -329,12 +338,11 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     for (int cb = 0; cb < 8; ++cb) {
         if (!pass[cb]) continue;
         const uint32_t qi = qb + cb * 16 + l15;
-        const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi];
         uint32_t pos = base[cb];
         uint64_t* lst = a.list + static_cast<uint64_t>(qi) * a.list_cap;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-            const float S = sb[rb] * qm.x, K = fmaf(eb[rb], qm.y, qm.z);
+            const float S = sb[rb] * qm[cb].x, K = fmaf(eb[rb], qm[cb].y, qm[cb].z);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;

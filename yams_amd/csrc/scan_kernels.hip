@@ -514,6 +514,7 @@ struct RescoreArgs {
     const uint32_t* tie_rank;   // nullable
     const uint32_t* rank_row;   // nullable: candidate keys carry ranks, not rows (exact path)
     int64_t row_base;
+    uint32_t stripe_rows, n_stripes, stripe_index; // striped shard: local row -> global id (0 = contiguous)
     const uint64_t* cand;       // [slots][cand_stride] keys sorted best-first (0 = empty)
     uint64_t cand_stride;
     uint32_t n_cand;            // candidates to re-score per query
@@ -531,6 +532,13 @@ struct RescoreArgs {
     uint32_t* out_status;       // [nq]: 0 verified, 1 needs widening
     unsigned long long* stat_rescored;
 };
+
+// local row ordinal -> the id the caller sees (yams_scan_corpus_t: row_base, stripes)
+__device__ __forceinline__ int64_t global_row(const RescoreArgs& a, uint32_t row) {
+    if (a.stripe_rows == 0) return a.row_base + static_cast<int64_t>(row);
+    const uint64_t t = row / a.stripe_rows, w = row % a.stripe_rows;
+    return a.row_base + static_cast<int64_t>((t * a.n_stripes + a.stripe_index) * a.stripe_rows + w);
+}
 
 constexpr int RS_MAX = 2048; // max candidates per query per launch
 constexpr int RS_STAGE_STRIDE = 36; // floats per staged row chunk (32 + 4 pad: b128 reads of 16 lanes hit 16 bank groups)
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             if (i < take) {
                 const uint32_t row = a.rank_row ? a.rank_row[key_idx(cand[sidx[i]])] : key_idx(cand[sidx[i]]);
                 a.out_scores[o] = key_score(skey[i]);
-                a.out_rows[o] = a.row_base + static_cast<int64_t>(row);
+                a.out_rows[o] = global_row(a, row);
                 if (a.out_ranks) a.out_ranks[o] = key_idx(skey[i]);
             } else {
                 a.out_scores[o] = -__builtin_inff();
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                 const uint64_t o = static_cast<uint64_t>(q) * a.k + outn;
                 const uint32_t row = a.rank_row ? a.rank_row[key_idx(cand[sidx[i]])] : key_idx(cand[sidx[i]]);
                 a.out_scores[o] = cs;
-                a.out_rows[o] = a.row_base + static_cast<int64_t>(row);
+                a.out_rows[o] = global_row(a, row);
                 if (a.out_dist) a.out_dist[o] = -key_score(skey[i]);
                 if (a.out_ranks) a.out_ranks[o] = key_idx(skey[i]);
                 ++outn;
@@ -1240,6 +1248,7 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     RescoreArgs a{};
     a.rows = R.rows; a.n_rows = R.n_rows; a.dim = R.dim; a.queries = R.queries; a.qnorm = R.qnorm;
     a.tie_rank = R.tie_rank; a.rank_row = R.rank_row; a.row_base = R.row_base; a.cand = R.cand;
+    a.stripe_rows = R.stripe_rows; a.n_stripes = R.n_stripes; a.stripe_index = R.stripe_index;
     a.cand_stride = R.cand_stride; a.n_cand = R.n_cand; a.tau = R.tau;
     a.list_count = R.list_count; a.list_cap = R.list_cap; a.all_rows_listed = R.all_rows_listed;
     a.qmap = R.qmap; a.k = R.k; a.threshold = R.threshold; a.flags = R.flags;

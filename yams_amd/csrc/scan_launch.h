@@ -34,6 +34,7 @@ struct RescoreLaunch {
     const float* rows; uint64_t n_rows; uint32_t dim;
     const float* queries; const double* qnorm;
     const uint32_t* tie_rank; const uint32_t* rank_row; int64_t row_base;
+    uint32_t stripe_rows, n_stripes, stripe_index;
     const uint64_t* cand; uint64_t cand_stride; uint32_t n_cand;
     const float* tau; const uint32_t* list_count; uint32_t list_cap; uint32_t all_rows_listed;
     const uint32_t* qmap; uint32_t n_slots;
