@@ -520,6 +520,71 @@ def test_sharded_merge_equals_single_device_and_oracle(acc, oracle, n_shards, me
         assert np.array_equal(os_[qi, :c].cpu().numpy().view(np.uint32), sims.view(np.uint32))
 
 
+# ---- sharding behind the C ABI (yams_scan_sharded_*) -------------------------------------------------
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+@pytest.mark.parametrize("n_shards,layout", [(1, "contiguous"), (2, "contiguous"), (3, "contiguous"), (2, "striped"), (4, "striped")])
+def test_sharded_search_behind_one_c_call(oracle, n_shards, layout, metric):
+    """One yams_scan_sharded_topk_host call over shards that each have their own context (here all
+    on device 0): contiguous row ranges or stripes, cross-shard exact ties, a corpus-wide chunk_id
+    ranking through the rank_of_row table; merged result == the oracle over the whole corpus."""
+    from yams_amd.accel import ShardedScan
+    n, d, nq, k = 30011, 256, 7, 25
+    corpus = oracle.synth_rows(41, 0, n, d)
+    q = oracle.synth_rows(41, 1 << 40, nq, d)
+    corpus[5] = corpus[n - 7] = corpus[n // 2 + 3]        # exact ties across shards
+    q[0] = corpus[5]
+    rng = np.random.default_rng(5)
+    rank = rng.permutation(n).astype(np.uint32)            # the corpus-wide chunk_id ranking
+    stripe = 4096
+    sh = ShardedScan([0] * n_shards)
+    keep, views = [], []
+    for i in range(n_shards):
+        if layout == "contiguous":
+            lo, hi = n * i // n_shards, n * (i + 1) // n_shards
+            glob = np.arange(lo, hi)
+            extra = dict(row_base=lo)
+        else:
+            t = np.arange(n) // stripe
+            glob = np.flatnonzero(t % n_shards == i)
+            extra = dict(stripe_rows=stripe, n_stripes=n_shards, stripe_index=i)
+        a = sh.ctx(i)
+        part = np.ascontiguousarray(corpus[glob])
+        dc = a.to_device(part)
+        # local tie ranks: a permutation of 0..n_local-1 that preserves the global order
+        order = np.argsort(rank[glob], kind="stable")
+        local_rank = np.empty(len(glob), np.uint32); local_rank[order] = np.arange(len(glob), dtype=np.uint32)
+        inv = np.empty_like(local_rank); inv[local_rank] = np.arange(len(glob), dtype=np.uint32)
+        dr, di = a.to_device(local_rank), a.to_device(inv)
+        d8 = dm8 = None
+        if metric == SCAN_COSINE:
+            d8, dm8 = a.alloc(part.size), a.alloc((len(glob) + 15) // 16 * 8)
+            a.build_shadow_i8_device(dc.ptr, len(glob), d, d8.ptr, dm8.ptr)
+        keep += [dc, dr, di, d8, dm8]
+        views.append(a.corpus_view(dc.ptr, len(glob), d, dr.ptr, di.ptr, rows_i8_ptr=d8.ptr if d8 else None,
+                                   rows_i8_meta_ptr=dm8.ptr if dm8 else None, **extra))
+    drank = sh.ctx(0).to_device(rank)
+    thr = 0.05 if metric == SCAN_L2 else -1.0
+    r = sh.topk(views, q, k, thr, metric, rank_of_row_ptr=drank.ptr)
+    for qi in range(nq):
+        if metric == SCAN_COSINE:
+            rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, thr, rank.astype(np.uint64))
+            dist = None
+        else:
+            rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, thr, rank.astype(np.uint64))
+        c = int(r.counts[qi])
+        assert c == len(rows) and np.array_equal(r.rows[qi, :c], rows), (qi, r.rows[qi, :8], rows[:8])
+        assert np.array_equal(r.scores[qi, :c].view(np.uint32), sims.view(np.uint32))
+        if dist is not None:
+            assert np.array_equal(r.dist[qi, :c].view(np.uint32), dist.view(np.uint32))
+    assert r.diag["rows_visited"] == nq * n
+    # invalid query: the batch fails as a whole
+    bad = q.copy(); bad[3, 1] = np.nan                  # (a zero query is invalid for cosine only: vec0 accepts it)
+    with pytest.raises(_lib.AccelError) as e:
+        sh.topk(views, bad, k, thr, metric, rank_of_row_ptr=drank.ptr)
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    sh.close()
+
+
 # ---- BASELINE.json full sizes: size-independent properties ----------------------------------------
 def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     import torch

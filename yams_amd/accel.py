@@ -118,6 +118,64 @@ class DedupSet:
         return nn.value, bn.value, bd.value
 
 
+class ShardedScan:
+    """yams_scan_sharded_*: one search over a corpus row-sharded across several devices (shards may
+    share a device), behind one C call.  `ctx(i)` is an Accel bound to shard i's context — upload the
+    shard's rows and build its shadows through it."""
+
+    def __init__(self, devices):
+        self.L = _lib.load()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        st = self.L.yams_scan_sharded_create(arr, len(devices), C.byref(h))
+        if st != 0:
+            raise AccelError(st, "yams_scan_sharded_create failed")
+        self.h = h
+        self.n = len(devices)
+        self._views = []
+        for i in range(self.n):
+            a = Accel.__new__(Accel)
+            a.L = self.L; a.ctx = C.c_void_p(self.L.yams_scan_sharded_ctx(self.h, i)); a.device = devices[i]
+            a._borrowed = True
+            self._views.append(a)
+
+    def ctx(self, i: int) -> "Accel":
+        return self._views[i]
+
+    def close(self):
+        if getattr(self, "h", None):
+            for a in self._views:
+                a.ctx = None
+            self.L.yams_scan_sharded_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def topk(self, shards, queries: np.ndarray, k: int, threshold: float = 0.0, metric: int = SCAN_COSINE,
+             flags: int = 0, rank_of_row_ptr: int | None = None, rank_row_base: int = 0) -> ScanResult:
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, kk = q.shape[0], max(k, 1)
+        scores = np.full((nq, kk), -np.inf, np.float32)
+        rows = np.full((nq, kk), -1, np.int64)
+        counts = np.zeros(nq, np.uint32)
+        dist = np.full((nq, kk), np.inf, np.float32)
+        prm = ScanParams(k, threshold, metric, flags)
+        diag = ScanDiag()
+        arr = (ScanCorpus * self.n)(*shards)
+        st = self.L.yams_scan_sharded_topk_host(self.h, arr, q.ctypes.data, nq, C.byref(prm), rank_of_row_ptr,
+                                                rank_row_base, scores.ctypes.data, rows.ctypes.data,
+                                                counts.ctypes.data, dist.ctypes.data, C.byref(diag))
+        if st != 0:
+            raise AccelError(st, self.L.yams_scan_sharded_last_error(self.h).decode())
+        return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
+
+
 class Accel:
     def __init__(self, device: int = 0, stream: int | None = None):
         self.L = _lib.load()
@@ -133,9 +191,9 @@ class Accel:
         self.device = device
 
     def close(self):
-        if getattr(self, "ctx", None):
+        if getattr(self, "ctx", None) and not getattr(self, "_borrowed", False):
             self.L.yams_accel_ctx_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def __del__(self):
         try:
