@@ -18,8 +18,14 @@
 
 #include "plugin.hpp"
 
+#ifdef YAMS_ACCEL_USE_HOST_TYPES
+#include <yams/chunking/chunker.h> // the host's own Chunk / ChunkRef / ChunkingConfig / IChunker (chunker.h:18-92)
+#endif
+
 namespace yams::chunking {
 
+#ifndef YAMS_ACCEL_USE_HOST_TYPES
+// restated for builds outside the YAMS tree
 struct Chunk { // chunker.h:18-30
     std::vector<std::byte> data;
     Hash hash;
@@ -48,6 +54,8 @@ public:
     using ProgressCallback = std::function<void(uint64_t, uint64_t)>;
     virtual void setProgressCallback(ProgressCallback callback) = 0;
 };
+
+#endif
 
 enum class AccelChunkerKind { Rabin, Streaming };
 

@@ -4,6 +4,7 @@
 // (src/api/content_store_builder.cpp:433-441).  Instances are single-threaded objects, like the
 // reference's (src/crypto/sha256_hasher.cpp:34).
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <filesystem>
 #include <fstream>
@@ -16,9 +17,14 @@
 
 #include "plugin.hpp"
 
+#ifdef YAMS_ACCEL_USE_HOST_TYPES
+#include <yams/crypto/hasher.h> // the host's own yams::crypto::IContentHasher (hasher.h:14-47)
+#endif
+
 namespace yams::crypto {
 
-class IContentHasher { // hasher.h:14-47 (reference)
+#ifndef YAMS_ACCEL_USE_HOST_TYPES
+class IContentHasher { // hasher.h:14-47 (reference), restated for builds outside the YAMS tree
 public:
     virtual ~IContentHasher() = default;
     virtual void init() = 0;
@@ -30,6 +36,7 @@ public:
     using ProgressCallback = std::function<void(uint64_t, uint64_t)>;
     virtual void setProgressCallback(ProgressCallback callback) = 0;
 };
+#endif
 
 class AccelSHA256Hasher final : public IContentHasher {
 public:
@@ -52,23 +59,41 @@ public:
         check(vt_->stream_finalize(vt_->self, stream_, hex), "Failed to finalize SHA256");
         return std::string(hex, 64);
     }
-    std::string hashFile(const std::filesystem::path& path) override { // sha256_hasher.cpp:111-150
+    // sha256_hasher.cpp:111-150.  The reference streams 64 KiB reads through update(); a device has
+    // nothing to gain from a launch per read, so the file is read whole and hashed with ONE upload
+    // and ONE kernel (content_hash_v1.hash).  A single SHA-256 chain is sequential by definition: one
+    // file at a time is a job for the host's hasher — the device pays off on batches (hashMany,
+    // hashFiles, chunker_v1, yams_ingest_device); see INTEGRATION.md.
+    std::string hashFile(const std::filesystem::path& path) override {
         std::ifstream file(path, std::ios::binary);
         if (!file) throw std::runtime_error("Failed to open file: " + path.string());
-        init();
-        std::vector<std::byte> buffer(1 << 20); // larger reads than the reference's 64 KiB: one launch each
         const uint64_t fileSize = std::filesystem::file_size(path);
+        std::vector<std::byte> data(static_cast<size_t>(fileSize));
         uint64_t processed = 0;
-        while (file) {
-            file.read(reinterpret_cast<char*>(buffer.data()), static_cast<std::streamsize>(buffer.size()));
+        while (file && processed < fileSize) {
+            const size_t want = static_cast<size_t>(std::min<uint64_t>(fileSize - processed, 8u << 20));
+            file.read(reinterpret_cast<char*>(data.data() + processed), static_cast<std::streamsize>(want));
             const auto n = file.gcount();
-            if (n > 0) {
-                update(std::span<const std::byte>(buffer.data(), static_cast<size_t>(n)));
-                processed += static_cast<uint64_t>(n);
-                if (progress_) progress_(processed, fileSize); // sha256_hasher.cpp:136-138
-            }
+            if (n <= 0) break;
+            processed += static_cast<uint64_t>(n);
+            if (progress_) progress_(processed, fileSize); // sha256_hasher.cpp:136-138
         }
-        return finalize();
+        data.resize(static_cast<size_t>(processed));
+        return hash(std::span<const std::byte>(data.data(), data.size()));
+    }
+    // Many files per call: read them all, one device call for all digests.
+    std::vector<std::string> hashFiles(const std::vector<std::filesystem::path>& paths) {
+        std::vector<std::vector<std::byte>> bufs(paths.size());
+        std::vector<std::span<const std::byte>> spans;
+        for (size_t i = 0; i < paths.size(); ++i) {
+            std::ifstream file(paths[i], std::ios::binary);
+            if (!file) throw std::runtime_error("Failed to open file: " + paths[i].string());
+            bufs[i].resize(static_cast<size_t>(std::filesystem::file_size(paths[i])));
+            file.read(reinterpret_cast<char*>(bufs[i].data()), static_cast<std::streamsize>(bufs[i].size()));
+            bufs[i].resize(static_cast<size_t>(file.gcount()));
+            spans.emplace_back(bufs[i].data(), bufs[i].size());
+        }
+        return hashMany(spans);
     }
     // sha256_hasher.cpp:152-161: any failure becomes ErrorCode::FileNotFound
     std::future<Result<std::string>> hashFileAsync(const std::filesystem::path& path) override {

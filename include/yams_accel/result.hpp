@@ -20,7 +20,7 @@ enum class ErrorCode {
     InternalError, NotFound, NotSupported, CompressionError, Timeout, TransactionAborted,
     ResourceExhausted, SystemShutdown, ValidationError, WriteError, NotInitialized,
     NotImplemented, InvalidPath, ResourceBusy, IOError, SerializationError, DataCorruption,
-    RateLimited, Unknown
+    RateLimited, Unauthorized, Unknown
 };
 
 struct Error {
@@ -59,4 +59,6 @@ private:
 };
 
 } // namespace yams
+#else
+#include <yams/core/types.h> // the host's own ErrorCode / Error / Result<T> / Hash
 #endif

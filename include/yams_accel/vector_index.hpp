@@ -24,8 +24,14 @@
 
 #include "plugin.hpp"
 
+#ifdef YAMS_ACCEL_USE_HOST_TYPES
+#include <yams/vector/vector_store.h> // the host's own VectorRecord / VectorSearchDiagnostics / ... / IVectorStore
+#endif
+
 namespace yams::vector {
 
+#ifndef YAMS_ACCEL_USE_HOST_TYPES
+// restated for builds outside the YAMS tree (the subset of vector_types.h the scan path touches)
 struct VectorRecord { // the fields of vector_types.h:104-138 the scan path reads or fills
     std::string chunk_id;
     std::string document_hash;
@@ -39,11 +45,13 @@ struct VectorRecord { // the fields of vector_types.h:104-138 the scan path read
 struct VectorSearchDiagnostics { // vector_types.h:181-204 (exact-scan subset)
     bool usedAnn = false;
     bool usedExactScan = false;
+    bool collectVisitedDocumentHashes = false;
     bool rowsVisitedObserved = false;
     bool exactDistanceEvaluationsObserved = false;
     size_t rowsVisited = 0;
     size_t exactDistanceEvaluations = 0;
     size_t returnedRows = 0;
+    std::unordered_set<std::string> visitedDocumentHashes;
 };
 
 struct VectorSearchParams { // vector_types.h:216-227
@@ -53,6 +61,8 @@ struct VectorSearchParams { // vector_types.h:216-227
 };
 
 enum class VectorSearchEngine { Vec0L2, ExactScan }; // vector_types.h:31-35 (the engines served here)
+
+#endif
 
 enum class ExactRowSelection { TopK, AllMatching }; // sqlite_vec_backend.cpp:342-371 / :4398-4400
 
@@ -209,14 +219,20 @@ public:
         size_t kk = k;
         if (rowSelection == ExactRowSelection::AllMatching) {
             kk = std::max<size_t>(visited, 1);
-            if (kk > YAMS_SCAN_MAX_K)
-                return Error{ErrorCode::NotImplemented, "AllMatching over more than YAMS_SCAN_MAX_K rows"};
+            if (kk > YAMS_SCAN_MAX_K) return allMatchingSliced(query, similarityThreshold, mask, recordPath, visited, evaluated, diagnostics);
         }
+        if (diagnostics && diagnostics->collectVisitedDocumentHashes) // (:4189-4197)
+            for (size_t r = 0; r < records_.size(); ++r)
+                if ((mask[r >> 5] >> (r & 31)) & 1u) diagnostics->visitedDocumentHashes.insert(records_[r].document_hash);
         auto r = searchSimilarBatchImpl({query}, kk, similarityThreshold, diagnostics, mask.data(),
                                         recordPath ? YAMS_SCAN_FLAG_RECORD_PATH : 0u, visited,
                                         recordPath ? evaluated : visited);
         if (!r) return r.error();
         return std::move(r.value().front());
+    }
+    // Every live record, in mirror order (retrieval methods of a backend built on this index).
+    template <typename Fn> void forEachRecord(Fn&& fn) const {
+        for (size_t r = 0; r < records_.size(); ++r) if (alive_[r]) fn(records_[r]);
     }
     // num_threads is accepted and ignored, exactly like the reference (:1627)
     Result<std::vector<std::vector<VectorRecord>>>
@@ -232,6 +248,47 @@ public:
     }
 
 private:
+    // ExactRowSelection::AllMatching over more rows than one device call returns (YAMS_SCAN_MAX_K):
+    // the allowed rows are cut into slices of at most YAMS_SCAN_MAX_K, every slice returns ALL of its
+    // matching rows, and the slices are merged with the reference's comparator (similarity desc,
+    // chunk_id asc, sqlite_vec_backend.cpp:4218-4223) — exact, because nothing is ever dropped.
+    Result<std::vector<VectorRecord>> allMatchingSliced(const std::vector<float>& query, float thr,
+                                                        const std::vector<uint32_t>& mask, bool recordPath,
+                                                        size_t visited, size_t evaluated,
+                                                        VectorSearchDiagnostics* diagnostics) {
+        std::vector<VectorRecord> all;
+        std::vector<uint32_t> part(mask.size(), 0u);
+        size_t inPart = 0;
+        auto flush = [&]() -> Result<void> {
+            if (inPart == 0) return {};
+            auto r = searchSimilarBatchImpl({query}, inPart, thr, nullptr, part.data(),
+                                            recordPath ? YAMS_SCAN_FLAG_RECORD_PATH : 0u, 0, 0);
+            if (!r) return r.error();
+            for (auto& rec : r.value().front()) all.push_back(std::move(rec));
+            std::fill(part.begin(), part.end(), 0u);
+            inPart = 0;
+            return {};
+        };
+        for (size_t r = 0; r < records_.size(); ++r) {
+            if (!((mask[r >> 5] >> (r & 31)) & 1u)) continue;
+            part[r >> 5] |= 1u << (r & 31);
+            if (++inPart == YAMS_SCAN_MAX_K)
+                if (auto f = flush(); !f) return f.error();
+        }
+        if (auto f = flush(); !f) return f.error();
+        std::stable_sort(all.begin(), all.end(), [](const VectorRecord& x, const VectorRecord& y) {
+            if (x.relevance_score != y.relevance_score) return x.relevance_score > y.relevance_score;
+            return x.chunk_id < y.chunk_id;
+        });
+        if (diagnostics) {
+            diagnostics->usedExactScan = true; diagnostics->rowsVisitedObserved = true;
+            diagnostics->exactDistanceEvaluationsObserved = true;
+            diagnostics->rowsVisited += visited;
+            diagnostics->exactDistanceEvaluations += recordPath ? evaluated : visited;
+            diagnostics->returnedRows = all.size();
+        }
+        return all;
+    }
     static bool isZeroNorm(const std::vector<float>& e) { // isZeroNormEmbedding, sqlite_vec_backend.cpp:204-211
         double n = 0.0;
         for (float v : e) n += static_cast<double>(v) * static_cast<double>(v);
@@ -420,6 +477,52 @@ public:
         }
         return it->second->searchSimilar(query, k, similarityThreshold, document_hash, candidate_hashes,
                                          metadata_filters, diagnostics);
+    }
+
+    // all queries of a batch share one dimension (:1619-1626); num_threads is ignored (:1627)
+    Result<std::vector<std::vector<VectorRecord>>>
+    searchSimilarBatch(const std::vector<std::vector<float>>& queries, size_t k, float similarityThreshold = 0.0f,
+                       size_t num_threads = 0) {
+        if (queries.empty()) return std::vector<std::vector<VectorRecord>>{};
+        const size_t dim = queries.front().size();
+        for (const auto& q : queries)
+            if (q.size() != dim) return Error{ErrorCode::InvalidArgument, "All query embeddings in a batch must share one dimension"};
+        auto it = byDim_.find(dim);
+        if (it == byDim_.end()) {
+            std::vector<std::vector<VectorRecord>> out;
+            for (const auto& q : queries) {
+                auto one = searchSimilar(q, k, similarityThreshold);
+                if (!one) return one.error();
+                out.push_back(std::move(one.value()));
+            }
+            return out;
+        }
+        return it->second->searchSimilarBatch(queries, k, similarityThreshold, num_threads);
+    }
+    Result<std::vector<VectorRecord>>
+    searchSimilarRows(const std::vector<float>& query, size_t k, float similarityThreshold,
+                      const std::unordered_set<std::string>& candidate_hashes, VectorSearchDiagnostics* diagnostics,
+                      ExactRowSelection selection) {
+        auto it = byDim_.find(query.size());
+        if (it == byDim_.end()) return searchSimilar(query, selection == ExactRowSelection::AllMatching ? 1 : k,
+                                                     similarityThreshold, std::nullopt, candidate_hashes, {}, diagnostics);
+        return it->second->searchSimilar(query, k, similarityThreshold, std::nullopt, candidate_hashes, {}, diagnostics, selection);
+    }
+    template <typename Fn> void forEachRecord(Fn&& fn) const {
+        for (const auto& [dim, idx] : byDim_) idx->forEachRecord(fn);
+    }
+    Result<std::optional<VectorRecord>> getVector(const std::string& chunkId) const {
+        auto it = dimOf_.find(chunkId);
+        if (it == dimOf_.end()) return std::optional<VectorRecord>{};
+        return byDim_.at(it->second)->getVector(chunkId);
+    }
+    Result<void> deleteVectorsByDocument(const std::string& documentHash) {
+        for (auto& [dim, idx] : byDim_) {
+            auto recs = idx->getVectorsByDocument(documentHash);
+            if (recs) for (const auto& r : recs.value()) dimOf_.erase(r.chunk_id);
+            if (auto s = idx->deleteVectorsByDocument(documentHash); !s) return s;
+        }
+        return {};
     }
 
 private:

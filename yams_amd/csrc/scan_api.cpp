@@ -249,7 +249,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37)) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38)) i8 = false;
 #endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;

@@ -18,9 +18,10 @@
 // (Cauchy-Schwarz; I = xi . qi exactly).  The filter score of this tier IS the upper bound u, so the
 // completeness proof of the re-score needs no further error term.  A row survives iff u >= tau_q, i.e.
 //     I >= (tau_q - f_q) / t_q * (1 / s_b) - (c_q / t_q) * (e_b / s_b) = A_q IS_b - B_q G_b,
-// an INTEGER threshold per (16-row block, query): the epilogue is one v_max tree per query block
-// against the smallest threshold of the wave's four row blocks, and only lanes that can hold a
-// survivor (~1 %) look at single elements.
+// an INTEGER threshold T per (16-row block, query).  The accumulators START at -T (computed while the
+// first k-slabs are still on their way from HBM), so after the k loop "survives" is a sign bit: the
+// epilogue is one v_max3 tree per query block, and only lanes that hold a survivor (~1 %) look at
+// single elements.
 #include <type_traits>
 
 #include "lds_dma.h"
@@ -45,6 +46,15 @@ constexpr int I8_BLOCK_ROWS = 16;                  // rows that share one quanti
 __device__ __forceinline__ int i8_swz(int row) {
     const int j = (row >> 2) & 3;
     return (((j ^ (j >> 1)) & 1) << 1) | (j >> 1);
+}
+
+// T(row block, query) = A_lo IS_b - B_hi G_b - 2, truncated towards zero and clamped to +-2^30 (A_lo /
+// B_hi carry the relative slack for this fp32 evaluation, the 2 covers the truncation; +2^30 = nothing
+// survives, -2^30 = everything does — |xi . qi| <= 127^2 dim stays far below either).
+__device__ __forceinline__ int i8_threshold(float A, float is, float B, float g) {
+    const float t = fmaf(A, is, fmaf(-B, g, -2.0f));
+    if (t != t) return -(1 << 30);                                  // NaN: keep everything
+    return t >= 1.0e9f ? (1 << 30) : (t <= -1.0e9f ? -(1 << 30) : static_cast<int>(t));
 }
 
 // per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
@@ -126,11 +136,18 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
             sb[rb] = m.x; eb[rb] = m.y;
         }
     }
-    float2 qthr[8];
+    // The per-query threshold halves {A_lo, B_hi}: loaded from inline asm so that the compiler does
+    // not wait for them with a conservative vmcnt(0) (it cannot see the DMA pieces that follow); they
+    // are older than every piece, so "at most 14 younger operations outstanding" means they landed.
+    typedef float qthr_t __attribute__((ext_vector_type(2)));
+    qthr_t qthr[8];
+    constexpr bool THR = MODE == MODE_FILTER && (ABL == 0 || ABL == 8);
+    if (THR) {
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        const uint32_t qi = q0 + wc * 128 + cb * 16 + l15; // < q_pad: the threshold table is padded
-        qthr[cb] = (MODE == MODE_FILTER && ABL == 0) ? reinterpret_cast<const float2*>(a.q_thr)[qi] : make_float2(0.f, 0.f);
+        for (int cb = 0; cb < 8; ++cb) {
+            const float* p = a.q_thr + 2ull * (q0 + wc * 128 + cb * 16 + l15); // < q_pad: the table is padded
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[cb]) : "v"(p) : "memory");
+        }
     }
 
     auto wait_vm = [&](int pieces) __attribute__((always_inline)) {
@@ -143,6 +160,21 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
         int issued = 0;
         for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < 4; ++p) piece(s, p); issued += 4; }
         if (nslab > 3) { piece(3, 0); piece(3, 1); issued += 2; }
+        if (THR) {
+            // accumulators start at -T(row block, query block) while the slabs are in flight
+            asm volatile("s_waitcnt vmcnt(14)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                 "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float is = 1.0f / sb[rb], g = eb[rb] * is;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const int ti = i8_threshold(qthr[cb][0], is, qthr[cb][1], g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = -ti;
+                }
+            }
+        }
         wait_vm(issued - 4);
         __builtin_amdgcn_s_barrier();
     }
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     for (; s < n_steady; s += 2) { body(s, C0{}, R5{}); body(s + 1, C1{}, R5{}); }
     body(s, C0{}, R4{}); body(s + 1, C1{}, R3{}); body(s + 2, C0{}, R2{}); body(s + 3, C1{}, R1{});
 
-    if (ABL != 0) { // measurement builds: keep the accumulators alive, emit nothing
+    if (ABL != 0 && ABL != 8) { // measurement builds: keep the accumulators alive, emit nothing
         int t = 0;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -279,19 +311,7 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
         }
         return;
     }
-    // FILTER: integer thresholds.  T(rb, cb) = A_lo IS_rb - B_hi G_rb - 2, truncated towards zero
-    // (A_lo / B_hi carry the relative slack for the fp32 evaluation, the 2 covers the truncation).
-    float IS[4], G[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) { IS[rb] = 1.0f / sb[rb]; G[rb] = eb[rb] * IS[rb]; }
-    const float is_min = fminf(fminf(IS[0], IS[1]), fminf(IS[2], IS[3]));
-    const float is_max = fmaxf(fmaxf(IS[0], IS[1]), fmaxf(IS[2], IS[3]));
-    const float g_max = fmaxf(fmaxf(G[0], G[1]), fmaxf(G[2], G[3]));
-    auto thr_int = [](float A, float is, float B, float g) -> int {
-        const float t = fmaf(A, is, fmaf(-B, g, -2.0f));
-        if (t != t) return static_cast<int>(0x80000000u);          // NaN: keep everything
-        return t >= 2.0e9f ? 0x7fffffff : (t <= -2.0e9f ? static_cast<int>(0x80000000u) : static_cast<int>(t));
-    };
+    // FILTER: the accumulators hold I - T, a survivor is a non-negative one
     uint32_t hot = 0;
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
@@ -300,13 +320,11 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-        const float A = qthr[cb].x, B = qthr[cb].y;
-        const int tmin = thr_int(A, A >= 0.f ? is_min : is_max, B, g_max);
-        if (m >= tmin && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+        if (m >= 0 && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
     }
     if (hot == 0) return; // ~99 % of the lanes
-    // the lane may hold survivors: exact integer test per (row block, query block), one reservation per
-    // query block (all of them issued before the first store), then the stores
+    // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
+    // per query block (all of them issued before the first store), then the stores
     uint32_t pass[8], base[8];
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
@@ -314,21 +332,30 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
         if ((hot >> cb) & 1u) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const int ti = thr_int(qthr[cb].x, IS[rb], qthr[cb].y, G[rb]);
                 const uint64_t rbase = strip + 16 * rb + 4 * lq;
                 const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (acc[rb][cb][r] >= ti && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
+                    if (acc[rb][cb][r] >= 0 && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
             }
         }
+    }
+    if (ABL == 8) { // measurement build: the whole epilogue up to here, but no reservations and no stores
+        uint32_t t = 0;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
+        if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        return;
     }
     // the query factors of the surviving blocks and the list reservations go out back to back (one
     // memory round trip for both), then the stores
     float4 qm[8];
+    float2 qth[8];  // (the threshold halves are re-read here instead of living in 16 registers through the k loop)
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < 8; ++cb) {
         qm[cb] = pass[cb] ? reinterpret_cast<const float4*>(a.q_meta)[qb + cb * 16 + l15] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qth[cb] = pass[cb] ? reinterpret_cast<const float2*>(a.q_thr)[qb + cb * 16 + l15] : make_float2(0.f, 0.f);
+    }
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
         base[cb] = 0u;
@@ -343,12 +370,14 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const float S = sb[rb] * qm[cb].x, K = fmaf(eb[rb], qm[cb].y, qm[cb].z);
+            const float is = 1.0f / sb[rb];
+            const int ti = i8_threshold(qth[cb].x, is, qth[cb].y, eb[rb] * is); // I = accumulator + T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
                 const uint64_t row = strip + 16 * rb + 4 * lq + r;
                 if (pos < a.list_cap)
-                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r]), S, K), static_cast<uint32_t>(row));
+                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r] + ti), S, K), static_cast<uint32_t>(row));
                 ++pos;
             }
         }
@@ -566,6 +595,10 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
     const uint32_t grid = groups * a.n_qtiles * 8;
 #ifdef YAMS_ACCEL_MEASURE
+    if (mode == MODE_FILTER && version == 38) { // the epilogue without its reservations and stores
+        hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 8>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
     if (mode == MODE_FILTER && (version == 31 || version == 32 || version == 37)) {
         if (version == 31) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 1>), dim3(grid), dim3(I8_THREADS), 0, st, a);
         else if (version == 32) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 2>), dim3(grid), dim3(I8_THREADS), 0, st, a);
