@@ -140,8 +140,8 @@ typedef struct yams_scan_corpus_s {
                                   of the bf16 shadow, twice its matrix rate); like every filter
                                   tier it only proposes candidates, the fp64 re-score over `rows`
                                   decides: results are bit-identical with and without it.         */
-    const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [ceil(n_rows / 16)][2] =
-                                  {s_b, e_b} per block of 16 rows: the block's quantisation scale
+    const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [ceil(n_rows / 64)][2] =
+                                  {s_b, e_b} per block of 64 rows: the block's quantisation scale
                                   and the largest measured residue |x/|x| - s_b * int8 row| of
                                   its rows                                                         */
     uint32_t stripe_rows;      /* 0: a contiguous shard, global id = row_base + local row.  Else the
@@ -210,12 +210,12 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, 
                                                            uint16_t* out_rows_bf16,
                                                            float* out_rows_nsq);
 
-/* (Re)builds the INT8 shadow of the mirror at `rows` for every block of 16 rows that intersects
+/* (Re)builds the INT8 shadow of the mirror at `rows` for every block of 64 rows that intersects
  * [first_row, first_row + n_rows) — call it when those rows were uploaded or appended (the rows of a
  * block share one quantisation scale, so an append that starts inside a block re-quantises that
  * block's earlier rows too; all pointers are the BASES of the mirror's arrays, not offset ones).
  * dim must be a multiple of 64 and at least 256, rows 16-byte aligned.  out_rows_i8: [n][dim] int8; out_meta:
- * [ceil(n / 16)][2] fp32 for a mirror of n rows.  out_mean_err (host, nullable): mean residue bound
+ * [ceil(n / 64)][2] fp32 for a mirror of n rows.  out_mean_err (host, nullable): mean residue bound
  * over the rebuilt blocks — a host that sees a large value (say > 0.02: heavy-tailed rows quantise
  * badly) may leave the int8 shadow out of the view and keep the bf16 one; asking for it
  * synchronises the stream. */

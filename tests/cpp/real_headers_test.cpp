@@ -1,0 +1,221 @@
+// real_headers_test.cpp — the adapters compiled against the REFERENCE's own headers
+// (-DYAMS_ACCEL_USE_HOST_TYPES -I/root/reference/include) and used only through the reference's
+// own base classes: yams::crypto::IContentHasher (hasher.h:14-47), yams::chunking::IChunker
+// (chunker.h:65-92), yams::vector::IVectorStore + the four capability seams found by dynamic_cast
+// exactly as VectorDatabase::Impl does (vector_database.cpp:553-609).  Linked with the reference's
+// OWN translation units (sha256_hasher.cpp, rabin_chunker.cpp, streaming_chunker.cpp — the recipe
+// of oracle/Makefile), so every accelerated result is compared with the reference class next to it.
+// Built only where /root/reference exists (tests/test_cpp_host.py); the binary travels to the GPU box.
+// Usage: real_headers_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu]
+#include <yams/chunking/chunker.h>
+#include <yams/chunking/streaming_chunker.h>
+#include <yams/crypto/hasher.h>
+#include <yams/vector/vector_store.h>
+
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <random>
+
+#include "yams_accel/chunker.hpp"
+#include "yams_accel/exact_scan_backend.hpp"
+#include "yams_accel/hasher.hpp"
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+using namespace yams;
+
+static std::vector<float> unit(std::mt19937& rng, size_t dim) {
+    std::uniform_real_distribution<float> d(-1.f, 1.f);
+    std::vector<float> v(dim);
+    float n = 0.f;
+    for (auto& x : v) { x = d(rng); n += x * x; }
+    n = std::sqrt(n);
+    for (auto& x : v) x /= n;
+    return v;
+}
+// the reference's exact arithmetic (sqlite_vec_backend.cpp:4253-4276): fp64 accumulate, cast to float
+static float refCosine(const std::vector<float>& q, const std::vector<float>& x) {
+    double dot = 0.0, nsq = 0.0, qsq = 0.0;
+    for (size_t i = 0; i < q.size(); ++i) { nsq += double(x[i]) * x[i]; dot += double(x[i]) * q[i]; }
+    for (float v : q) qsq += double(v) * v;
+    return static_cast<float>(dot / (std::sqrt(nsq) * std::sqrt(qsq)));
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("usage: %s <plugin.so> [--expect-no-gpu]\n", argv[0]); return 2; }
+    const bool expectNoGpu = argc > 2 && std::strcmp(argv[2], "--expect-no-gpu") == 0;
+    auto loaded = accel::Plugin::load(argv[1], "{\"device\":0}");
+    if (expectNoGpu) {
+        CHECK(!loaded.has_value());
+        std::printf("%s\n", failures ? "FAILED" : "OK (refused without a GPU)");
+        return failures ? 1 : 0;
+    }
+    if (!loaded) { std::printf("load failed: %s\n", loaded.error().message.c_str()); return 1; }
+    auto plugin = loaded.value();
+    static_assert(static_cast<int>(ErrorCode::Unknown) == 36, "the host's ErrorCode (core/types.h:25-63)");
+
+    // ---- IContentHasher: the accelerator next to the reference's SHA256Hasher -----------------------------
+    {
+        auto made = crypto::createAccelSHA256Hasher(plugin);
+        CHECK(made.has_value());
+        std::unique_ptr<crypto::IContentHasher> acc = std::move(made.value());
+        std::unique_ptr<crypto::IContentHasher> ref = std::make_unique<crypto::SHA256Hasher>();
+        std::mt19937 rng(3);
+        for (size_t n : {size_t(0), size_t(1), size_t(55), size_t(56), size_t(64), size_t(1000), size_t(70001), size_t(3 << 20)}) {
+            std::vector<std::byte> data(n);
+            for (auto& b : data) b = static_cast<std::byte>(rng());
+            acc->init(); ref->init();
+            size_t pos = 0;
+            while (pos < n) { // ragged updates
+                const size_t take = std::min<size_t>(n - pos, 1 + rng() % 50000);
+                acc->update({data.data() + pos, take}); ref->update({data.data() + pos, take});
+                pos += take;
+            }
+            CHECK(acc->finalize() == ref->finalize());
+            CHECK(acc->hash(data) == crypto::SHA256Hasher::hash(std::span<const std::byte>(data)));   // the HashableData template of the base
+        }
+        const auto path = std::filesystem::temp_directory_path() / "yams_accel_real_headers.bin";
+        { std::ofstream f(path, std::ios::binary); std::vector<char> d(5 * 1000 * 1000 + 3); for (auto& c : d) c = static_cast<char>(rng()); f.write(d.data(), d.size()); }
+        uint64_t seen = 0;
+        acc->setProgressCallback([&](uint64_t done, uint64_t total) { seen = done; CHECK(total == 5 * 1000 * 1000 + 3); });
+        CHECK(acc->hashFile(path) == ref->hashFile(path));
+        CHECK(seen == 5 * 1000 * 1000 + 3);
+        auto fut = acc->hashFileAsync(path);
+        CHECK(fut.get().value() == ref->hashFile(path));
+        auto bad = acc->hashFileAsync(path.string() + ".missing").get();
+        CHECK(!bad.has_value() && bad.error().code == ErrorCode::FileNotFound);   // sha256_hasher.cpp:152-161
+        std::filesystem::remove(path);
+    }
+
+    // ---- IChunker: both chunkers next to the reference's ---------------------------------------------------
+    for (int kind = 0; kind < 2; ++kind) {
+        chunking::ChunkingConfig cfg;
+        cfg.minChunkSize = 2048; cfg.maxChunkSize = 65536;
+        auto made = chunking::createAccelChunker(plugin, kind ? chunking::AccelChunkerKind::Streaming : chunking::AccelChunkerKind::Rabin, cfg);
+        CHECK(made.has_value());
+        std::unique_ptr<chunking::IChunker> acc = std::move(made.value());
+        std::unique_ptr<chunking::IChunker> ref;
+        if (kind) ref = std::make_unique<chunking::StreamingChunker>(cfg); else ref = std::make_unique<chunking::RabinChunker>(cfg);
+        std::mt19937 rng(17 + kind);
+        std::vector<std::byte> data((3 << 20) + 12345);
+        for (auto& b : data) b = static_cast<std::byte>(rng());
+        for (size_t n : {size_t(0), size_t(47), size_t(2048), size_t(2049), size_t(100000), data.size()}) {
+            auto a = acc->chunkData({data.data(), n});
+            auto r = ref->chunkData({data.data(), n});
+            CHECK(a.size() == r.size());
+            for (size_t i = 0; i < a.size() && i < r.size(); ++i) CHECK(a[i] == r[i]);   // Chunk::operator== : data, hash, offset, size
+            auto lazy = acc->chunkDataLazy({data.data(), n});
+            CHECK(lazy.size() == r.size());
+            for (size_t i = 0; i < lazy.size() && i < r.size(); ++i)
+                CHECK(lazy[i].data.empty() && lazy[i].hash == r[i].hash && lazy[i].offset == r[i].offset && lazy[i].size == r[i].size);
+        }
+        CHECK(acc->getConfig().minChunkSize == 2048 && acc->getConfig().chunkMask == 0x1FFF);
+    }
+
+    // ---- IVectorStore + capability seams ---------------------------------------------------------------------
+    {
+        std::unique_ptr<vector::IVectorStore> backend = vector::createAccelExactScanBackend(plugin);
+        CHECK(backend->initialize(":memory:").has_value());
+        CHECK(backend->createTables(256).has_value() && backend->tablesExist() && backend->isInitialized());
+        auto* diagnosticStore = dynamic_cast<vector::IDiagnosticVectorStore*>(backend.get());
+        auto* exactStore = dynamic_cast<vector::IExactCandidateVectorStore*>(backend.get());
+        auto* allRowsStore = dynamic_cast<vector::IAllExactCandidateVectorStore*>(backend.get());
+        auto* documentStore = dynamic_cast<vector::IDocumentCandidateVectorStore*>(backend.get());
+        CHECK(diagnosticStore && exactStore && allRowsStore && documentStore);
+
+        const size_t dim = 256, n = 6000, perDoc = 4;   // doc_<i/4>, chunk_%09zu: string order == row order
+        std::mt19937 rng(42);
+        std::vector<vector::VectorRecord> recs;
+        for (size_t i = 0; i < n; ++i) {
+            char id[32], doc[32];
+            std::snprintf(id, sizeof id, "chunk_%09zu", i);
+            std::snprintf(doc, sizeof doc, "doc_%06zu", i / perDoc);
+            vector::VectorRecord r(id, doc, unit(rng, dim), "content");
+            r.metadata["lang"] = (i % 3 == 0) ? "en" : "de";
+            r.level = (i % perDoc == 0) ? vector::EmbeddingLevel::DOCUMENT : vector::EmbeddingLevel::CHUNK;
+            recs.push_back(std::move(r));
+        }
+        CHECK(backend->insertVectorsBatch(recs).has_value());
+        CHECK(backend->getVectorCount().value() == n);
+        const auto q = unit(rng, dim);
+
+        // plain top-k against the reference arithmetic, order (similarity desc, chunk_id asc)
+        std::vector<std::pair<float, size_t>> exact;
+        for (size_t i = 0; i < n; ++i) exact.emplace_back(refCosine(q, recs[i].embedding), i);
+        std::sort(exact.begin(), exact.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+        auto top = backend->searchSimilar(q, 25, -1.0f);
+        CHECK(top.has_value() && top.value().size() == 25);
+        for (size_t i = 0; i < 25 && i < top.value().size(); ++i) {
+            CHECK(top.value()[i].chunk_id == recs[exact[i].second].chunk_id);
+            CHECK(top.value()[i].relevance_score == exact[i].first);   // bit-identical fp32
+        }
+        // diagnostics seam: the collect flag survives the reset (:4650-4661)
+        vector::VectorSearchDiagnostics diag;
+        diag.collectVisitedDocumentHashes = true; diag.rowsVisited = 999;
+        std::unordered_set<std::string> cands = {"doc_000003", "doc_000700", "doc_001499"};
+        auto viaDiag = diagnosticStore->searchSimilarWithDiagnostics(q, 5, -1.0f, std::nullopt, cands, {}, diag);
+        CHECK(viaDiag.has_value() && viaDiag.value().size() == 5);
+        CHECK(diag.usedExactScan && diag.rowsVisitedObserved && diag.rowsVisited == 12 && diag.exactDistanceEvaluations == 12);
+        CHECK(diag.collectVisitedDocumentHashes && diag.visitedDocumentHashes == cands);
+        // exact candidates (:1578-1593) and the InvalidArgument rule
+        auto noCands = exactStore->searchExactCandidatesWithDiagnostics(q, 5, -1.0f, {}, diag);
+        CHECK(!noCands.has_value() && noCands.error().code == ErrorCode::InvalidArgument);
+        auto ex = exactStore->searchExactCandidatesWithDiagnostics(q, 3, -1.0f, cands, diag);
+        CHECK(ex.has_value() && ex.value().size() == 3 && diag.returnedRows == 3);
+        for (const auto& r : ex.value()) CHECK(cands.count(r.document_hash) == 1);
+        // all rows of MANY candidate documents: more than one device call returns (no cap, :1595-1610)
+        std::unordered_set<std::string> many;
+        for (size_t dd = 0; dd < 400; ++dd) { char doc[32]; std::snprintf(doc, sizeof doc, "doc_%06zu", dd * 3); many.insert(doc); }
+        auto all = allRowsStore->searchAllExactCandidateRowsWithDiagnostics(q, -1.0f, many, diag);
+        CHECK(all.has_value() && all.value().size() == 400 * perDoc && diag.rowsVisited == 400 * perDoc);
+        for (size_t i = 1; i < all.value().size(); ++i) {
+            const auto &a = all.value()[i - 1], &b = all.value()[i];
+            CHECK(a.relevance_score > b.relevance_score || (a.relevance_score == b.relevance_score && a.chunk_id < b.chunk_id));
+        }
+        // one best row per document (:86-125), k documents
+        auto docs = documentStore->searchDocumentCandidatesWithDiagnostics(q, 7, -1.0f, many, diag);
+        CHECK(docs.has_value() && docs.value().size() == 7);
+        {
+            std::unordered_map<std::string, float> best;
+            for (const auto& r : all.value()) { auto it = best.find(r.document_hash); if (it == best.end() || r.relevance_score > it->second) best[r.document_hash] = r.relevance_score; }
+            std::unordered_set<std::string> seen;
+            float prev = 2.f;
+            for (const auto& r : docs.value()) {
+                CHECK(seen.insert(r.document_hash).second && r.relevance_score == best[r.document_hash] && r.relevance_score <= prev);
+                prev = r.relevance_score;
+            }
+        }
+        // metadata filters take the record path (:4333-4409); threshold; batch; invalid query; k = 0
+        auto en = backend->searchSimilar(q, 10, -1.0f, std::nullopt, {}, {{"lang", "en"}});
+        CHECK(en.has_value() && en.value().size() == 10);
+        for (const auto& r : en.value()) CHECK(r.metadata.at("lang") == "en");
+        CHECK(backend->searchSimilar(q, 0, -1.0f).value().empty());
+        auto zero = backend->searchSimilar(std::vector<float>(dim, 0.f), 5, -1.0f);
+        CHECK(!zero.has_value() && zero.error().code == ErrorCode::InvalidArgument);
+        auto batch = backend->searchSimilarBatch({q, recs[17].embedding}, 4, -1.0f, 0);
+        CHECK(batch.has_value() && batch.value().size() == 2 && batch.value()[1].front().chunk_id == "chunk_000000017");
+        // CRUD through the base class: replace, delete, document delete; retrieval methods
+        vector::VectorRecord repl = recs[17]; repl.embedding = q;
+        CHECK(backend->updateVector("chunk_000000017", repl).has_value());
+        CHECK(backend->searchSimilar(q, 1, -1.0f).value().front().chunk_id == "chunk_000000017");
+        CHECK(backend->deleteVector("chunk_000000017").has_value());
+        CHECK(backend->searchSimilar(q, 1, -1.0f).value().front().chunk_id == recs[exact[0].second].chunk_id);
+        CHECK(backend->deleteVectorsByDocument("doc_000001").has_value());
+        CHECK(!backend->hasEmbedding("doc_000001").value() && backend->hasEmbedding("doc_000002").value());
+        CHECK(backend->getVectorCount().value() == n - 1 - perDoc);
+        CHECK(backend->getVector("chunk_000000020").value().has_value() && !backend->getVector("chunk_000000017").value().has_value());
+        CHECK(backend->getVectorsByDocument("doc_000002").value().size() == perDoc);
+        CHECK(backend->getDocumentLevelVectorsAll().value().size() == n / perDoc - 1);
+        CHECK(backend->getEmbeddedDocumentHashes().value().size() == n / perDoc - 1);
+        CHECK(backend->getStats().value().total_vectors == n - 1 - perDoc);
+        CHECK(backend->beginTransaction().has_value() && backend->commitTransaction().has_value());
+        backend->close();
+        CHECK(!backend->isInitialized());
+        CHECK(backend->searchSimilar(q, 1, -1.0f).error().code == ErrorCode::NotInitialized);
+    }
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
+    return failures ? 1 : 0;
+}

@@ -26,3 +26,32 @@ def test_host_mirror_reference_style_suite():
     r = subprocess.run([exe, lib], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (0 failures)" in r.stdout
+
+
+def test_adapters_compile_against_the_reference_headers(accel_lib):
+    """AccelSHA256Hasher / AccelChunker / AccelExactScanBackend built with -DYAMS_ACCEL_USE_HOST_TYPES
+    -I/root/reference/include: they derive from the reference's OWN IContentHasher, IChunker,
+    IVectorStore and capability seams (dev container only: the reference tree must be there)."""
+    from yams_amd import build as b
+    exe = b.build_real_headers_test()
+    if exe is None:
+        pytest.skip("/root/reference is not present and no prebuilt real_headers_test travelled")
+    if accel_lib.yams_accel_device_count() > 0:
+        pytest.skip("GPU present: covered by the gpu-marked run")
+    r = subprocess.run([exe, b.LIB, "--expect-no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_adapters_through_the_reference_base_classes():
+    """The same binary on the GPU: every accelerated result next to the reference's own SHA256Hasher /
+    RabinChunker / StreamingChunker (linked in), the backend used only through IVectorStore* and the
+    dynamic_cast capability seams of vector_database.cpp:553-609."""
+    from yams_amd import build as b
+    b.build()
+    exe = b.build_real_headers_test()
+    if exe is None:
+        pytest.skip("no real_headers_test binary (built only where /root/reference exists)")
+    r = subprocess.run([exe, b.LIB], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "OK (0 failures)" in r.stdout

@@ -608,13 +608,13 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     t8 = tm8 = None
     if metric == SCAN_COSINE and d % 64 == 0 and d >= 256:   # the int8 shadow: first filter tier of cosine batches > 128 queries
         t8 = torch.empty((n, d), dtype=torch.int8, device="cuda")
-        tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
+        tm8 = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
         mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
         assert 0.0 < mean_err < 0.006                      # uniform components: ~ sqrt(3) / (127 sqrt(12)) = 0.0039
         unit8 = (tc[:4096].double() / n64.sqrt()[:, None])
-        sc8 = tm8[:256, 0].double().repeat_interleave(16)[:, None]       # one scale per block of 16 rows
+        sc8 = tm8[:64, 0].double().repeat_interleave(64)[:, None]        # one scale per block of 64 rows
         recon = t8[:4096].double() * sc8
-        assert ((unit8 - recon).norm(dim=-1) <= tm8[:256, 1].double().repeat_interleave(16)).all()   # e_b bounds the measured residues
+        assert ((unit8 - recon).norm(dim=-1) <= tm8[:64, 1].double().repeat_interleave(64)).all()    # e_b bounds the measured residues
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
                            rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
                            rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
@@ -757,14 +757,14 @@ def test_int8_tier_on_hostile_rows(acc, oracle):
 
 
 def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
-    """The rows of a 16-row block share one scale, so an append that starts inside a block must
+    """The rows of a 64-row block share one scale, so an append that starts inside a block must
     re-quantise that block's earlier rows: building in ragged appends == building once."""
     import torch
     n, d = 5003, 320
     corpus = oracle.synth_rows(34, 0, n, d)
     corpus[1001] *= np.float32(7.0)                     # a row with a different largest component
     tc = torch.from_numpy(corpus).cuda()
-    nb = (n + 15) // 16
+    nb = (n + 63) // 64
     a8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); am = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
     b8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); bm = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
     acc.build_shadow_i8_device(tc.data_ptr(), n, d, a8.data_ptr(), am.data_ptr())
@@ -776,9 +776,9 @@ def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
     acc.synchronize()
     assert torch.equal(a8, b8) and torch.equal(am, bm)
     unit = tc.double() / tc.double().norm(dim=-1, keepdim=True)
-    sc = am[:, 0].double().repeat_interleave(16)[:n, None]
-    assert ((unit - a8.double() * sc).norm(dim=-1) <= am[:, 1].double().repeat_interleave(16)[:n]).all()
-    assert (a8.abs().amax(dim=-1).view(-1)[:16 * (n // 16)].view(-1, 16).amax(dim=-1) == 127).all()   # every block uses its full range
+    sc = am[:, 0].double().repeat_interleave(64)[:n, None]
+    assert ((unit - a8.double() * sc).norm(dim=-1) <= am[:, 1].double().repeat_interleave(64)[:n]).all()
+    assert (a8.abs().amax(dim=-1).view(-1)[:64 * (n // 64)].view(-1, 64).amax(dim=-1) == 127).all()   # every block uses its full range
 
 
 def test_int8_tier_widens_escalates_and_falls_back(acc, oracle):

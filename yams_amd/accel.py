@@ -255,8 +255,8 @@ class Accel:
     def build_shadow_i8_device(self, rows_ptr: int, n_rows: int, dim: int, out_i8_ptr: int,
                                out_meta_ptr: int, want_mean_err: bool = False, first_row: int = 0):
         """INT8 filter shadow of rows [first_row, first_row + n_rows) of the mirror whose arrays start
-        at the given BASE pointers: int8 rows [n][dim] + {scale, residue bound} per block of 16 rows
-        ([ceil(n / 16)][2] fp32).  Asynchronous unless the mean residue bound is asked for."""
+        at the given BASE pointers: int8 rows [n][dim] + {scale, residue bound} per block of 64 rows
+        ([ceil(n / 64)][2] fp32).  Asynchronous unless the mean residue bound is asked for."""
         me = C.c_double(0.0)
         self._check(self.L.yams_scan_build_shadow_i8_device(self.ctx, rows_ptr, first_row, n_rows, dim, out_i8_ptr,
                                                             out_meta_ptr, C.byref(me) if want_mean_err else None))

@@ -11,14 +11,15 @@
 // multiply-add and sustains a higher clock).
 //
 // Quantisation (shadow_build_i8_kernel): the unit-normalised row x~ is stored as int8 xi with ONE
-// scale per block of 16 rows, s_b = max |x~_i| over the block / 127, together with e_b = the largest
+// scale per block of 64 rows, s_b = max |x~_i| over the block / 127, together with e_b = the largest
 // MEASURED residue |x~ - s_b xi| of the block's rows (not a worst-case figure).  Queries get their own
 // scale t_q per batch (prep_i8_kernel), with c_q >= |t_q qi| and f_q >= |q~ - t_q qi| + slop.  Then
 //     cos(x, q) = x~ . q~ = s_b t_q (xi . qi) + d . (t_q qi) + x~ . p   <=   s_b t_q I + e_b c_q + f_q =: u
 // (Cauchy-Schwarz; I = xi . qi exactly).  The filter score of this tier IS the upper bound u, so the
 // completeness proof of the re-score needs no further error term.  A row survives iff u >= tau_q, i.e.
 //     I >= (tau_q - f_q) / t_q * (1 / s_b) - (c_q / t_q) * (e_b / s_b) = A_q IS_b - B_q G_b,
-// an INTEGER threshold T per (16-row block, query).  The accumulators START at -T (computed while the
+// an INTEGER threshold T per (64-row block = the rows of one wave, query): eight per lane.  The
+// accumulators START at -T (computed while the
 // first k-slabs are still on their way from HBM), so after the k loop "survives" is a sign bit: the
 // epilogue is one v_max3 tree per query block, and only lanes that hold a survivor (~1 %) look at
 // single elements.
@@ -37,7 +38,7 @@ constexpr int I8_NST = 4;
 constexpr int I8_A_BYTES = I8_ROWS * I8_SLAB;      // 16 KiB
 constexpr int I8_B_BYTES = I8_QUERIES * I8_SLAB;   // 16 KiB
 constexpr int I8_STAGE = I8_A_BYTES + I8_B_BYTES;
-constexpr int I8_BLOCK_ROWS = 16;                  // rows that share one quantisation scale
+constexpr int I8_BLOCK_ROWS = 64;                  // rows that share one quantisation scale (= a wave's rows of a tile)
 
 // LDS image of a 64-byte row slab: four 16-byte chunks; logical chunk c of row R sits at position
 // c ^ g((R >> 2) & 3), g = {0, 2, 3, 1}.  A v_mfma_i32_16x16x64_i8 operand is "row (lane & 15),
@@ -48,13 +49,13 @@ __device__ __forceinline__ int i8_swz(int row) {
     return (((j ^ (j >> 1)) & 1) << 1) | (j >> 1);
 }
 
-// T(row block, query) = A_lo IS_b - B_hi G_b - 2, truncated towards zero and clamped to +-2^30 (A_lo /
-// B_hi carry the relative slack for this fp32 evaluation, the 2 covers the truncation; +2^30 = nothing
-// survives, -2^30 = everything does — |xi . qi| <= 127^2 dim stays far below either).
-__device__ __forceinline__ int i8_threshold(float A, float is, float B, float g) {
-    const float t = fmaf(A, is, fmaf(-B, g, -2.0f));
-    if (t != t) return -(1 << 30);                                  // NaN: keep everything
-    return t >= 1.0e9f ? (1 << 30) : (t <= -1.0e9f ? -(1 << 30) : static_cast<int>(t));
+// -T(row block, query) for T = A_lo IS_b - B_hi G_b - 2: what an accumulator starts at.  A_lo / B_hi
+// carry the relative slack for this fp32 evaluation, the 2 covers the truncation towards zero of the
+// conversion; clamped to +-2^30 (-2^30 = nothing survives, +2^30 = everything does — |xi . qi| <=
+// 127^2 dim stays far below either).  A_lo is never NaN (i8_query_thresholds_kernel), G_b is finite.
+__device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, float g) {
+    const float t = fmaf(-A, is, fmaf(B, g, 2.0f));
+    return static_cast<int>(__builtin_amdgcn_fmed3f(t, -1.0737418e9f, 1.0737418e9f));
 }
 
 // per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
@@ -126,15 +127,12 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     // the compiler waits for them at their first use, after the loop): a load issued at the end would
     // sit on the critical path of every tile — the block scales stream from HBM
     const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
-    float sb[4], eb[4];                 // wave-uniform: scale and residue bound of the four row blocks
+    float sb, eb;                       // wave-uniform: scale and residue bound of this wave's 64 rows
     {
         const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const uint64_t blk = strip / I8_BLOCK_ROWS + rb;
-            const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
-            sb[rb] = m.x; eb[rb] = m.y;
-        }
+        const uint64_t blk = strip / I8_BLOCK_ROWS;
+        const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
+        sb = m.x; eb = m.y;
     }
     // The per-query threshold halves {A_lo, B_hi}: loaded from inline asm so that the compiler does
     // not wait for them with a conservative vmcnt(0) (it cannot see the DMA pieces that follow); they
@@ -164,15 +162,14 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
             // accumulators start at -T(row block, query block) while the slabs are in flight
             asm volatile("s_waitcnt vmcnt(14)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
                                                  "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+            const float is = 1.0f / sb, g = eb * is;
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const float is = 1.0f / sb[rb], g = eb[rb] * is;
+            for (int cb = 0; cb < 8; ++cb) {
+                const int nt = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) {
-                    const int ti = i8_threshold(qthr[cb][0], is, qthr[cb][1], g);
+                for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = -ti;
-                }
+                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
             }
         }
         wait_vm(issued - 4);
@@ -287,9 +284,9 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
             const bool qok = qi < a.n_queries;
             const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
             float m = ninf;
+            const float S = sb * qm.x, K = fmaf(eb, qm.y, qm.z);
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const float S = sb[rb] * qm.x, K = fmaf(eb[rb], qm.y, qm.z);
                 const uint64_t rbase = strip + 16 * rb + 4 * lq;
                 const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
                 float v[4];
@@ -367,17 +364,17 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
         const uint32_t qi = qb + cb * 16 + l15;
         uint32_t pos = base[cb];
         uint64_t* lst = a.list + static_cast<uint64_t>(qi) * a.list_cap;
+        const float S = sb * qm[cb].x, K = fmaf(eb, qm[cb].y, qm[cb].z);
+        const float is = 1.0f / sb;
+        const int nt = i8_neg_threshold(qth[cb].x, is, qth[cb].y, eb * is); // I = accumulator - (-T)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-            const float S = sb[rb] * qm[cb].x, K = fmaf(eb[rb], qm[cb].y, qm[cb].z);
-            const float is = 1.0f / sb[rb];
-            const int ti = i8_threshold(qth[cb].x, is, qth[cb].y, eb[rb] * is); // I = accumulator + T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
                 const uint64_t row = strip + 16 * rb + 4 * lq + r;
                 if (pos < a.list_cap)
-                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r] + ti), S, K), static_cast<uint32_t>(row));
+                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r] - nt), S, K), static_cast<uint32_t>(row));
                 ++pos;
             }
         }
@@ -385,26 +382,26 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
 }
 
 // -------------------------------------------------------------------------------------------------
-// The INT8 shadow.  One wave per block of 16 rows.  A row is first scaled by its own largest
+// The INT8 shadow.  One wave per block of 64 rows.  A row is first scaled by its own largest
 // component (so tiny and huge rows normalise without under- or overflow), normalised in fp32, and
 // the block's scale is s_b = max |x~_i| / 127 over its usable rows.  e_b = the largest measured
 // residue |x~ - s_b xi| of those rows, inflated for the fp32 evaluation of the sum of squares and for
 // the distance between the fp32-normalised row and the true unit row.  Rows that are all zero or
 // hold a non-finite component get an all-zero int8 row: the reference never returns them
 // (:4258-4269), so they need no score.
-// `first_row` / `n_rows` name the rows that changed: every 16-row block that intersects
+// `first_row` / `n_rows` name the rows that changed: every 64-row block that intersects
 // [first_row, first_row + n_rows) is rebuilt from its first row on (an append that starts inside a
 // block re-quantises that block's earlier rows with the new common scale).
-// stats (nullable): [0] += e_b of every block with a usable row (double), [1] += 1 per such block.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows, uint64_t first_block, uint64_t end_row,
-                                                              uint32_t dim, int8_t* out_i8, float* out_meta, double* stats) {
+                                                              uint32_t dim, int8_t* out_i8, float* out_meta) {
+    __shared__ float rinv_s[4][I8_BLOCK_ROWS]; // per wave, per row: the normalising factor, 0 for an unusable row
     const uint64_t blk = first_block + static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const uint64_t r0 = blk * I8_BLOCK_ROWS;
     if (r0 >= end_row) return;
     const int lane = threadIdx.x & 63;
     const int nr = static_cast<int>(end_row - r0 < I8_BLOCK_ROWS ? end_row - r0 : I8_BLOCK_ROWS);
-    float rinv[I8_BLOCK_ROWS];          // per row: 1 / (amax |x / amax|) or 0 for an unusable row
+    float* rinv = rinv_s[threadIdx.x >> 6];  // (wave-private; written and read by the same wave in program order)
     float umax = 0.f;                   // largest |x~_i| of the block
     for (int rr = 0; rr < nr; ++rr) {
         const float* src = rows + (r0 + rr) * dim;
@@ -429,7 +426,7 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
         const float inv = ok ? ia * rsqrtf(nsq) : 0.f;  // x~ = x * inv (nsq in [1, dim]: no range trouble)
-        rinv[rr] = inv;
+        if (lane == 0) rinv[rr] = inv;
         if (ok) umax = fmaxf(umax, rsqrtf(nsq));         // |x~|_max = (amax * ia) * rsqrt(nsq)
     }
     const bool any = umax > 0.f;
@@ -464,10 +461,29 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
         const float e = any ? sqrtf(emax) * (1.0f + (fd + 16.f) * 5.9604645e-8f) + (fd + 64.f) * 5.9604645e-8f : 0.f;
         out_meta[2 * blk] = sc;
         out_meta[2 * blk + 1] = e;
-        if (stats && any) {
-            atomicAdd(stats, static_cast<double>(e));
-            atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, 1ull);
-        }
+    }
+}
+
+// stats[0] += sum of e_b, stats[1] (as uint64) += number of blocks, over blocks [first_block, end_block)
+// (one atomic pair per workgroup: a per-block atomic on one address serialises the whole build)
+__global__ __launch_bounds__(256) void i8_meta_stats_kernel(const float* meta, uint64_t first_block, uint64_t end_block,
+                                                            double* stats) {
+    __shared__ double ssum[256];
+    __shared__ unsigned int scnt[256];
+    double sum = 0.0; unsigned int cnt = 0;
+    for (uint64_t b = first_block + blockIdx.x * 256ull + threadIdx.x; b < end_block; b += 256ull * gridDim.x) {
+        const float e = meta[2 * b + 1];
+        if (e > 0.f) { sum += static_cast<double>(e); ++cnt; }
+    }
+    ssum[threadIdx.x] = sum; scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) { ssum[threadIdx.x] += ssum[threadIdx.x + st]; scnt[threadIdx.x] += scnt[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && scnt[0]) {
+        atomicAdd(stats, ssum[0]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, static_cast<unsigned long long>(scnt[0]));
     }
 }
 
@@ -567,7 +583,12 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
     const uint64_t end_row = first_row + n_rows;
     const uint64_t n_blocks = (end_row + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS - first_block;
     hipLaunchKernelGGL(shadow_build_i8_kernel, dim3(static_cast<uint32_t>((n_blocks + 3) / 4)), dim3(256), 0, st,
-                       rows, first_block, end_row, dim, out_i8, out_meta, stats);
+                       rows, first_block, end_row, dim, out_i8, out_meta);
+    if (stats) {
+        uint32_t g = static_cast<uint32_t>((n_blocks + 255) / 256);
+        if (g > 256) g = 256;
+        hipLaunchKernelGGL(i8_meta_stats_kernel, dim3(g), dim3(256), 0, st, out_meta, first_block, first_block + n_blocks, stats);
+    }
     return hipGetLastError();
 }
 
