@@ -71,7 +71,7 @@ public:
         std::vector<std::byte> data(static_cast<size_t>(fileSize));
         uint64_t processed = 0;
         while (file && processed < fileSize) {
-            const size_t want = static_cast<size_t>(std::min<uint64_t>(fileSize - processed, 8u << 20));
+            const size_t want = static_cast<size_t>(std::min<uint64_t>(fileSize - processed, 64u << 10)); // the reference's read size (:120)
             file.read(reinterpret_cast<char*>(data.data() + processed), static_cast<std::streamsize>(want));
             const auto n = file.gcount();
             if (n <= 0) break;

@@ -451,6 +451,28 @@ YAMS_ACCEL_API yams_status_t yams_dedup_probe_host(yams_dedup_set* set, const ui
 #define YAMS_IFACE_CHUNKER_V1 "chunker_v1"
 #define YAMS_IFACE_CHUNKER_V1_VERSION 1u
 
+/* The YAMS plugin entry points (include/yams/plugins/abi.h:18-34 in the reference; the declarations
+ * are identical, so this header and the reference's can be included together). */
+#ifndef YAMS_PLUGIN_ABI_VERSION
+#define YAMS_PLUGIN_ABI_VERSION 1
+#define YAMS_PLUGIN_OK 0
+#define YAMS_PLUGIN_ERR_INCOMPATIBLE -1
+#define YAMS_PLUGIN_ERR_NOT_FOUND -2
+#define YAMS_PLUGIN_ERR_INIT_FAILED -3
+#define YAMS_PLUGIN_ERR_INVALID -4
+#endif
+YAMS_ACCEL_API int yams_plugin_get_abi_version(void);
+YAMS_ACCEL_API const char* yams_plugin_get_name(void);
+YAMS_ACCEL_API const char* yams_plugin_get_version(void);
+YAMS_ACCEL_API const char* yams_plugin_get_manifest_json(void);
+/* config_json: {"device": n} | {"devices": [..]} (a corpus is dealt to all of them in stripes and
+ * searched behind one call), "search_slots": n (concurrent searches, default 2),
+ * "shadows": "both" | "bf16" | "i8" | "none". */
+YAMS_ACCEL_API int yams_plugin_init(const char* config_json, const void* host_context);
+YAMS_ACCEL_API void yams_plugin_shutdown(void);
+YAMS_ACCEL_API int yams_plugin_get_interface(const char* iface_id, uint32_t version, void** out_iface);
+YAMS_ACCEL_API int yams_plugin_get_health_json(char** out_json);
+
 typedef struct yams_scan_hit_s {
     int64_t row;      /* row ordinal in the mirror (host maps it to its VectorRecord)            */
     float similarity; /* relevance_score */

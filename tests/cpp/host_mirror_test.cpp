@@ -3,7 +3,9 @@
 //   tests/unit/vector/vector_smoke_catch2_test.cpp:188-353   (exact-scan contract, ties, invalid queries)
 //   tests/unit/crypto/crypto_test.cpp:92-99,134-228          (SHA-256 known answers, split updates)
 //   tests/unit/chunking/chunking_test.cpp:146-228            (chunk invariants, hash == SHA-256 of slice)
-// Usage: host_mirror_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu]
+// Usage: host_mirror_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu | --config '<init json>']
+// (e.g. --config '{"devices":[0,0],"stripe_rows":64}': every corpus dealt to two shards — two contexts
+// on one device — in stripes of 64 rows; the suite must pass unchanged, bit for bit)
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -26,9 +28,10 @@ static std::span<const std::byte> bytes(const std::string& s) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::printf("usage: %s <plugin.so> [--expect-no-gpu]\n", argv[0]); return 2; }
+    if (argc < 2) { std::printf("usage: %s <plugin.so> [--expect-no-gpu | --config <json>]\n", argv[0]); return 2; }
     const bool expectNoGpu = argc > 2 && std::strcmp(argv[2], "--expect-no-gpu") == 0;
-    auto loaded = accel::Plugin::load(argv[1], "{\"device\":0}");
+    const std::string config = (argc > 3 && std::strcmp(argv[2], "--config") == 0) ? argv[3] : "{\"device\":0}";
+    auto loaded = accel::Plugin::load(argv[1], config);
     if (expectNoGpu) {
         CHECK(!loaded.has_value());
         if (!loaded.has_value()) CHECK(loaded.error().code == ErrorCode::NotInitialized);

@@ -21,9 +21,13 @@ def test_host_mirror_compiles_and_refuses_without_gpu(accel_lib):
 
 
 @pytest.mark.gpu
-def test_host_mirror_reference_style_suite():
+@pytest.mark.parametrize("config", ['{"device":0}', '{"devices":[0,0],"stripe_rows":64}',
+                                    '{"devices":[0,0,0],"stripe_rows":128,"search_slots":3,"shadows":"bf16"}'])
+def test_host_mirror_reference_style_suite(config):
+    """The reference-style suite through the plugin, with the corpus on one shard and dealt to two / three
+    shards (contexts on one device, stripes of 64 / 128 rows): same assertions, bit for bit."""
     exe, lib = _exe()
-    r = subprocess.run([exe, lib], capture_output=True, text=True, timeout=280)
+    r = subprocess.run([exe, lib, "--config", config], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (0 failures)" in r.stdout
 
@@ -33,7 +37,8 @@ def test_adapters_compile_against_the_reference_headers(accel_lib):
     -I/root/reference/include: they derive from the reference's OWN IContentHasher, IChunker,
     IVectorStore and capability seams (dev container only: the reference tree must be there)."""
     from yams_amd import build as b
-    exe = b.build_real_headers_test()
+    import _cpp_build
+    exe = _cpp_build.build_real_headers_test()
     if exe is None:
         pytest.skip("/root/reference is not present and no prebuilt real_headers_test travelled")
     if accel_lib.yams_accel_device_count() > 0:
@@ -48,8 +53,9 @@ def test_adapters_through_the_reference_base_classes():
     RabinChunker / StreamingChunker (linked in), the backend used only through IVectorStore* and the
     dynamic_cast capability seams of vector_database.cpp:553-609."""
     from yams_amd import build as b
+    import _cpp_build
     b.build()
-    exe = b.build_real_headers_test()
+    exe = _cpp_build.build_real_headers_test()
     if exe is None:
         pytest.skip("no real_headers_test binary (built only where /root/reference exists)")
     r = subprocess.run([exe, b.LIB], capture_output=True, text=True, timeout=280)

@@ -840,6 +840,137 @@ def test_vector_scan_vtable(accel_lib, oracle):
     L.yams_plugin_shutdown()
 
 
+def _vt(L, config):
+    assert L.yams_plugin_init(config, None) == 0
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"vector_scan_v1", 1, C.byref(p)) == 0
+    return C.cast(p, C.POINTER(_lib.VectorScanV1)).contents
+
+
+def _vt_search(vt, cid, q, k, thr=-1.0, metric=0, mask=None, flags=0):
+    nq, d = q.shape
+    hits = C.POINTER(_lib.ScanHit)(); counts = _lib.u32p(); diag = _lib.ScanDiag()
+    mp = mask.ctypes.data_as(_lib.u32p) if mask is not None else None
+    st = vt.search_batch_ex(None, cid, q.ctypes.data_as(_lib.f32p), nq, d, k, thr, metric, flags, mp,
+                            C.byref(hits), C.byref(counts), C.byref(diag))
+    assert st == 0, st
+    rows = [[hits[qi * k + i].row for i in range(counts[qi])] for qi in range(nq)]
+    sims = [np.array([hits[qi * k + i].similarity for i in range(counts[qi])], np.float32) for qi in range(nq)]
+    vt.free_hits(None, hits, counts)
+    return rows, sims, diag.as_dict()
+
+
+@pytest.mark.parametrize("config", [b'{"device": 0}', b'{"devices": [0, 0, 0], "stripe_rows": 4096, "search_slots": 2}'])
+def test_plugin_mirror_grows_in_place_and_is_dealt_to_shards(accel_lib, oracle, config):
+    """vector_scan_v1 with the corpus on one shard or dealt to three (contexts on one device, stripes of
+    4096 rows): ragged appends that straddle stripes (the mirror grows in place, nothing is re-uploaded),
+    a corpus-wide chunk_id ranking, an allow-mask, batches on both sides of the int8 tier's threshold —
+    every answer equals the oracle over the whole corpus."""
+    L = accel_lib
+    vt = _vt(L, config)
+    n, d, k = 70_001, 256, 20
+    corpus = oracle.synth_rows(51, 0, n, d)
+    corpus[100] = corpus[9000] = corpus[50_000]                 # exact ties on different shards
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, d, C.byref(cid)) == 0
+    pos = 0
+    for step in (1, 4095, 4096, 10_000, 3, 40_000, n):          # ragged appends
+        step = min(step, n - pos)
+        if step == 0:
+            break
+        part = np.ascontiguousarray(corpus[pos:pos + step])
+        assert vt.corpus_append(None, cid, part.ctypes.data_as(_lib.f32p), step) == 0
+        pos += step
+    nn = C.c_uint64(); dd = C.c_uint32()
+    assert vt.corpus_size(None, cid, C.byref(nn), C.byref(dd)) == 0 and (nn.value, dd.value) == (n, d)
+    q = oracle.synth_rows(51, 1 << 40, 140, d)
+    q[0] = corpus[100]
+    rank = np.random.default_rng(8).permutation(n).astype(np.uint32)
+    for use_rank in (False, True):
+        if use_rank:
+            assert vt.corpus_set_tie_ranks(None, cid, rank.ctypes.data_as(_lib.u32p), n) == 0
+        tr = rank.astype(np.uint64) if use_rank else None
+        for nq in (3, 140):                                      # narrow bf16 form / int8 tier
+            rows, sims, diag = _vt_search(vt, cid, np.ascontiguousarray(q[:nq]), k)
+            assert diag["filter_tier"] == (_lib.TIER_I8 if nq > 128 else _lib.TIER_BF16), diag
+            for qi in list(range(nq))[:6]:
+                orow, osim, _, _ = oracle.scan_cosine(corpus, q[qi], k, -1.0, tr)
+                assert rows[qi] == list(orow), (config, use_rank, nq, qi, rows[qi][:6], orow[:6])
+                assert np.array_equal(sims[qi].view(np.uint32), osim.view(np.uint32))
+    # allow-mask over global rows (document_hash / candidate_hashes restriction)
+    allow = np.random.default_rng(9).random(n) < 0.5
+    bits = np.zeros((n + 31) // 32 * 32, np.uint8); bits[:n] = allow
+    words = np.ascontiguousarray(np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel())
+    rows, sims, _ = _vt_search(vt, cid, np.ascontiguousarray(q[:4]), k, mask=words)
+    idx = np.flatnonzero(allow)
+    for qi in range(4):
+        orow, osim, _, _ = oracle.scan_cosine(corpus[idx], q[qi], k, -1.0, rank.astype(np.uint64)[idx])
+        assert rows[qi] == list(idx[orow]) and np.array_equal(sims[qi].view(np.uint32), osim.view(np.uint32))
+    # L2 (vec0 semantics) through the same mirror
+    rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q[:3]), k, thr=-1.0, metric=1)
+    for qi in range(3):
+        orow, _, _ = oracle.scan_l2(corpus, q[qi], k, -1.0, rank.astype(np.uint64))
+        assert rows[qi] == list(orow)
+    assert vt.corpus_clear(None, cid) == 0 and vt.corpus_size(None, cid, C.byref(nn), None) == 0 and nn.value == 0
+    assert vt.corpus_append(None, cid, corpus[:5000].ctypes.data_as(_lib.f32p), 5000) == 0    # reusable after clear
+    rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q[1:2]), 5)
+    assert rows[0] == list(oracle.scan_cosine(corpus[:5000], q[1], 5, -1.0)[0])
+    assert vt.corpus_destroy(None, cid) == 0
+    L.yams_plugin_shutdown()
+
+
+def test_plugin_serves_concurrent_calls(accel_lib, oracle):
+    """The reference serves searches under a shared lock (vector_database.cpp:539,618).  Here every call
+    leases its own contexts: 8 threads searching + 1 thread chunking finish sooner than the same calls
+    one after the other, and every result is still exact."""
+    import threading, time
+    L = accel_lib
+    vt = _vt(L, b'{"device": 0, "search_slots": 4}')
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"chunker_v1", 1, C.byref(p)) == 0
+    ck = C.cast(p, C.POINTER(_lib.ChunkerV1)).contents
+    n, d, k, nq = 400_000, 256, 10, 8
+    corpus = oracle.synth_rows(52, 0, n, d)
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, d, C.byref(cid)) == 0
+    assert vt.corpus_append(None, cid, corpus.ctypes.data_as(_lib.f32p), n) == 0
+    qs = [oracle.synth_rows(52, (1 << 40) + 100 * t, nq, d) for t in range(8)]
+    blob = np.random.default_rng(3).integers(0, 256, 48 << 20, dtype=np.uint8)
+    cfg = _lib.CdcConfig(); ck.get_default_config(None, _lib.CDC_STREAMING, C.byref(cfg))
+    out = {}
+
+    def search(t, reps=6):
+        for _ in range(reps):
+            out[t] = _vt_search(vt, cid, qs[t], k)[0]
+
+    def chunk():
+        chunks = C.POINTER(_lib.ChunkRef)(); cnt = C.c_size_t()
+        assert ck.chunk_data(None, blob.ctypes.data_as(_lib.u8p), blob.size, C.byref(cfg), C.byref(chunks), C.byref(cnt)) == 0
+        out["chunks"] = cnt.value
+        ck.free_chunks(None, chunks, cnt)
+
+    search(0, 1); chunk()                                        # warm-up (workspaces)
+    t0 = time.perf_counter()
+    for t in range(8):
+        search(t)
+    chunk()
+    serial = time.perf_counter() - t0
+    th = [threading.Thread(target=search, args=(t,)) for t in range(8)] + [threading.Thread(target=chunk)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    conc = time.perf_counter() - t0
+    for t in range(8):
+        for qi in range(2):
+            assert out[t][qi] == list(oracle.scan_cosine(corpus, qs[t][qi], k, -1.0)[0])
+    assert out["chunks"] > 1000
+    assert conc < 0.9 * serial, (conc, serial)
+    assert vt.corpus_destroy(None, cid) == 0
+    L.yams_plugin_shutdown()
+
+
 # ---- randomized differential sweep ------------------------------------------------------------------
 def test_randomized_differential_sweep(acc, oracle):
     """48 seeded random configurations (shape, k, metric, threshold, tie ranks, allow-mask, filter

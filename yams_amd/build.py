@@ -101,34 +101,3 @@ def build_host_tests() -> str:
         raise RuntimeError("host mirror test failed to compile:\n" + r.stdout.decode())
     return exe
 
-
-def build_real_headers_test(reference: str = "/root/reference"):
-    """Compiles tests/cpp/real_headers_test.cpp against the REFERENCE's own headers
-    (-DYAMS_ACCEL_USE_HOST_TYPES -I<reference>/include) and links the reference's own translation
-    units next to it (sha256_hasher.cpp, rabin_chunker.cpp, streaming_chunker.cpp with the no-op spdlog
-    shim of oracle/shim — the recipe of oracle/Makefile).  Only possible where the reference tree
-    exists (the dev container); the binary is git-ignored and travels to the GPU box.  Returns the path
-    of the executable, or None when neither the sources nor a prebuilt binary are there."""
-    root = os.path.dirname(HERE)
-    out_dir = os.path.join(root, "tests", "cpp", "_build")
-    exe = os.path.join(out_dir, "real_headers_test")
-    src = os.path.join(root, "tests", "cpp", "real_headers_test.cpp")
-    if not os.path.isdir(os.path.join(reference, "include", "yams")):
-        return exe if os.path.exists(exe) else None
-    os.makedirs(out_dir, exist_ok=True)
-    deps = [src, os.path.join(root, "include", "yams_mi355x_accel.h")] + \
-        [os.path.join(root, "include", "yams_accel", f) for f in os.listdir(os.path.join(root, "include", "yams_accel"))]
-    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
-        return exe
-    ref_srcs = [os.path.join(reference, "src", "crypto", "sha256_hasher.cpp"),
-                os.path.join(reference, "src", "chunking", "rabin_chunker.cpp"),
-                os.path.join(reference, "src", "chunking", "streaming_chunker.cpp")]
-    cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++20", "-O1", "-Wall", "-Wno-unused-variable", "-DYAMS_ACCEL_USE_HOST_TYPES",
-           "-I" + os.path.join(root, "oracle", "shim"), "-I" + os.path.join(reference, "include"),
-           "-I" + os.path.join(reference, "src", "chunking"), "-I" + os.path.join(root, "include"),
-           "-o", exe, src, *ref_srcs, "-lcrypto", "-lpthread", "-ldl"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("real_headers_test failed to compile against the reference headers:\n" + r.stdout.decode())
-    return exe

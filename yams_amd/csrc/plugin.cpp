@@ -6,45 +6,159 @@
 // this file is AbiPluginLoader::load / getInterface (src/daemon/resource/abi_plugin_loader.cpp:
 // 270-442, 657-681): dlopen(RTLD_LAZY|RTLD_LOCAL), yams_plugin_init(config_json, host_context),
 // yams_plugin_get_manifest_json, then yams_plugin_get_interface(id, version, &vtable).
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <numeric>
+#include <shared_mutex>
 #include <sstream>
 #include <string>
 #include <vector>
 
 #include "accel_ctx.h"
 
-#define YAMS_PLUGIN_API __attribute__((visibility("default")))
-#define YAMS_PLUGIN_ABI_VERSION 1          // abi.h:18
-#define YAMS_PLUGIN_OK 0                   // abi.h:20-24
-#define YAMS_PLUGIN_ERR_INCOMPATIBLE -1
-#define YAMS_PLUGIN_ERR_NOT_FOUND -2
-#define YAMS_PLUGIN_ERR_INIT_FAILED -3
-#define YAMS_PLUGIN_ERR_INVALID -4
+// The eight entry points and their return codes are declared in include/yams_mi355x_accel.h exactly as
+// the reference's include/yams/plugins/abi.h:18-34 declares them (no local restatement here).
 
 namespace {
 
+// ------------------------------------------------------------------------------------------------
+// A device buffer that grows IN PLACE: one virtual range reserved up front, physical chunks mapped
+// behind it as rows arrive (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess).
+// Appending to a 38 GB mirror maps a few more chunks; nothing is reallocated or copied, pointers
+// handed to running searches stay valid.  (Probed on MI355X: scripts/ubench/vmm_probe.hip.)  Falls
+// back to allocate-copy-free growth only if the driver refuses the virtual-memory calls.
+// ------------------------------------------------------------------------------------------------
+struct GrowBuf {
+    int device = 0;
+    unsigned char* base = nullptr;
+    size_t reserved = 0, mapped = 0;
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
+    bool plain = false; // fallback mode: `base` is a hipMalloc allocation of `mapped` bytes
+
+    static constexpr size_t kGran = 2ull << 20;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(base); }
+
+    bool ensure(size_t bytes, size_t reserve_hint) {
+        if (bytes <= mapped) return true;
+        (void)hipSetDevice(device);
+        if (!plain && !base) {
+            size_t want = std::max(reserve_hint, bytes);
+            want = (want + kGran - 1) / kGran * kGran;
+            void* va = nullptr;
+            if (hipMemAddressReserve(&va, want, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); plain = true; }
+            else { base = static_cast<unsigned char*>(va); reserved = want; }
+        }
+        if (!plain && bytes > reserved) return false; // beyond the reservation (sized to the device's memory)
+        if (!plain) {
+            // geometric chunks: at least 32 MiB, at least a quarter of what is mapped
+            size_t add = std::max<size_t>(bytes - mapped, std::max<size_t>(32ull << 20, mapped / 4));
+            add = (add + kGran - 1) / kGran * kGran;
+            if (mapped + add > reserved) add = reserved - mapped;
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = device;
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            hipMemAccessDesc acc{};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            if (hipMemMap(base + mapped, add, 0, h, 0) != hipSuccess ||
+                hipMemSetAccess(base + mapped, add, &acc, 1) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipMemRelease(h); return false;
+            }
+            chunks.emplace_back(h, add);
+            mapped += add;
+            return true;
+        }
+        // fallback: allocate, copy, free
+        const size_t want = std::max(bytes, mapped + mapped / 2);
+        void* nd = nullptr;
+        if (hipMalloc(&nd, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (mapped && hipMemcpy(nd, base, mapped, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nd); return false; }
+        if (base) (void)hipFree(base);
+        base = static_cast<unsigned char*>(nd);
+        mapped = want;
+        return true;
+    }
+    void release() {
+        (void)hipSetDevice(device);
+        if (plain) { if (base) (void)hipFree(base); }
+        else if (base) {
+            size_t off = 0;
+            for (auto& c : chunks) { (void)hipMemUnmap(base + off, c.second); (void)hipMemRelease(c.first); off += c.second; }
+            (void)hipMemAddressFree(base, reserved);
+        }
+        base = nullptr; reserved = mapped = 0; chunks.clear(); plain = false;
+    }
+};
+
+// One shard of a corpus: the rows dealt to one device, plus their filter shadows.
+struct ShardStore {
+    int device = 0;
+    uint64_t n_rows = 0;
+    GrowBuf rows, bf16, nsq, i8, i8meta, tie, inv;
+    bool has_tie = false;
+    void release() { rows.release(); bf16.release(); nsq.release(); i8.release(); i8meta.release(); tie.release(); inv.release(); n_rows = 0; has_tie = false; }
+};
+
 struct Corpus {
     uint32_t dim = 0;
-    uint64_t n_rows = 0, cap_rows = 0;
-    float* d_rows = nullptr;
-    uint16_t* d_bf16 = nullptr; // filter shadow of d_rows (same capacity), kept in step by corpus_append
-    float* d_nsq = nullptr;
-    uint32_t* d_tie = nullptr;
-    uint32_t* d_inv = nullptr;
+    uint64_t n_rows = 0;
+    std::vector<ShardStore> sh;      // one per plugin device
+    GrowBuf rank_of_row;             // device 0: the corpus-wide chunk_id ranking (cross-shard ties)
+    bool has_ranks = false;
+    std::shared_mutex mu;            // searches share, mutations exclude (vector_database.cpp:539,618)
+};
+
+// rows of a stripe when a corpus is dealt to several devices (config "stripe_rows", a multiple of 64;
+// fixed at init: it is part of every corpus's row -> shard map)
+uint32_t kStripeRows = 65536;
+
+// A pool of N identical resources handed out to concurrent calls.
+template <typename T> class Pool {
+public:
+    void add(T v) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(v); all_.push_back(v); }
+    T acquire() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !free_.empty(); });
+        T v = free_.back(); free_.pop_back();
+        return v;
+    }
+    void release(T v) { { std::lock_guard<std::mutex> lk(mu_); free_.push_back(v); } cv_.notify_one(); }
+    std::vector<T> drain() { std::lock_guard<std::mutex> lk(mu_); auto a = all_; all_.clear(); free_.clear(); return a; }
+    size_t size() const { return all_.size(); }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<T> free_, all_;
+};
+template <typename T> struct Lease {
+    Pool<T>& pool; T v;
+    explicit Lease(Pool<T>& p) : pool(p), v(p.acquire()) {}
+    ~Lease() { pool.release(v); }
 };
 
 struct PluginState {
-    std::mutex mu; // vtable functions must be thread-safe (model_provider_v1.h:45); one stream
-    yams_accel_ctx* ctx = nullptr;
-    int device = 0;
+    std::shared_mutex mu;            // init / shutdown exclude everything else; calls share
     bool initialised = false;
+    std::vector<int> devices;        // config "devices": [..] (or "device": n); rows are striped over them
+    bool want_bf16 = true, want_i8 = true;
     std::string init_error;
-    std::map<uint64_t, Corpus> corpora;
+    Pool<yams_scan_sharded*> search_slots;   // concurrent searches: one sharded handle (a context per device) each
+    Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
+    std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
+    std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
+    std::mutex corpora_mu;
+    std::map<uint64_t, std::shared_ptr<Corpus>> corpora;
     uint64_t next_id = 1;
-    uint64_t searches = 0, hashes = 0, chunk_calls = 0;
+    std::atomic<uint64_t> searches{0}, hashes{0}, chunk_calls{0};
 };
 PluginState g;
 
@@ -54,146 +168,212 @@ const char kManifest[] =
     "\"interfaces\":[{\"id\":\"vector_scan_v1\",\"version\":1},"
     "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":1}]}";
 
-int parse_device(const char* json) {
-    if (!json) return 0;
-    const char* p = std::strstr(json, "\"device\"");
-    if (!p) return 0;
+// Minimal readers for the init config: {"device": 0} | {"devices": [0,1,...], "search_slots": 2,
+// "shadows": "both" | "bf16" | "i8" | "none"}
+long json_int(const char* json, const char* key, long dflt) {
+    if (!json) return dflt;
+    const char* p = std::strstr(json, key);
+    if (!p) return dflt;
     p = std::strchr(p, ':');
-    if (!p) return 0;
-    return std::atoi(p + 1);
+    return p ? std::atol(p + 1) : dflt;
+}
+std::vector<int> json_devices(const char* json) {
+    std::vector<int> out;
+    const char* p = json ? std::strstr(json, "\"devices\"") : nullptr;
+    if (p && (p = std::strchr(p, '['))) {
+        ++p;
+        while (*p && *p != ']') {
+            while (*p == ' ' || *p == ',') ++p;
+            if (*p == ']' || !*p) break;
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            out.push_back(static_cast<int>(v));
+            p = end;
+        }
+    }
+    if (out.empty()) out.push_back(static_cast<int>(json_int(json, "\"device\"", 0)));
+    return out;
 }
 
-void free_corpus(Corpus& c) {
-    if (c.d_rows) (void)hipFree(c.d_rows);
-    if (c.d_bf16) (void)hipFree(c.d_bf16);
-    if (c.d_nsq) (void)hipFree(c.d_nsq);
-    if (c.d_tie) (void)hipFree(c.d_tie);
-    if (c.d_inv) (void)hipFree(c.d_inv);
-    c = Corpus{};
+std::shared_ptr<Corpus> find_corpus(uint64_t id) {
+    std::lock_guard<std::mutex> lk(g.corpora_mu);
+    auto it = g.corpora.find(id);
+    return it == g.corpora.end() ? nullptr : it->second;
 }
 
-#define NEED_CTX() do { if (!g.ctx) return YAMS_ERR_UNSUPPORTED; } while (0)
+#define NEED_INIT() std::shared_lock<std::shared_mutex> init_lk__(g.mu); do { if (!g.initialised) return YAMS_ERR_UNSUPPORTED; } while (0)
+
+// global row -> (shard, local row) under the stripe dealing
+inline uint32_t shard_of(uint64_t row, uint32_t n_sh) { return n_sh == 1 ? 0u : static_cast<uint32_t>((row / kStripeRows) % n_sh); }
+inline uint64_t local_of(uint64_t row, uint32_t n_sh) {
+    return n_sh == 1 ? row : (row / kStripeRows / n_sh) * kStripeRows + row % kStripeRows;
+}
+// rows of a corpus of n rows that live on shard i
+inline uint64_t shard_rows(uint64_t n, uint32_t n_sh, uint32_t i) {
+    if (n_sh == 1) return n;
+    const uint64_t full = n / kStripeRows, rem = n % kStripeRows;
+    uint64_t r = (full / n_sh) * kStripeRows + ((full % n_sh) > i ? kStripeRows : 0);
+    if (full % n_sh == i) r += rem;
+    return r;
+}
 
 // ---- vector_scan_v1 ---------------------------------------------------------------------------
 yams_status_t vs_corpus_create(void*, uint32_t dim, uint64_t* out_id) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!out_id || dim == 0) return YAMS_ERR_INVALID_ARG;
-    Corpus c; c.dim = dim;
-    const uint64_t id = g.next_id++;
-    g.corpora[id] = c;
-    *out_id = id;
+    auto c = std::make_shared<Corpus>();
+    c->dim = dim;
+    c->sh.resize(g.devices.size());
+    for (size_t i = 0; i < g.devices.size(); ++i) {
+        auto& s = c->sh[i];
+        s.device = g.devices[i];
+        for (GrowBuf* b : {&s.rows, &s.bf16, &s.nsq, &s.i8, &s.i8meta, &s.tie, &s.inv}) b->device = s.device;
+    }
+    c->rank_of_row.device = g.devices[0];
+    std::lock_guard<std::mutex> lk(g.corpora_mu);
+    *out_id = g.next_id++;
+    g.corpora[*out_id] = c;
     return YAMS_OK;
 }
 
+// Appends rows: they take the next global ids, are dealt to the devices in stripes, copied to the end of
+// each shard's growing mirror, and the shadows of the touched local ranges are (re)built.
 yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n_rows) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
+    NEED_INIT();
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
     if (n_rows == 0) return YAMS_OK;
     if (!rows) return YAMS_ERR_INVALID_ARG;
-    Corpus& c = it->second;
-    (void)hipSetDevice(g.ctx->device);
-    (void)hipStreamSynchronize(g.ctx->stream);
-    const uint64_t need = c.n_rows + n_rows;
-    if (need > c.cap_rows) {
-        uint64_t cap = std::max<uint64_t>(need, c.cap_rows + c.cap_rows / 2);
-        float* nd = nullptr;
-        if (hipMalloc(&nd, cap * c.dim * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
-        if (c.n_rows && hipMemcpy(nd, c.d_rows, c.n_rows * c.dim * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
-            (void)hipGetLastError(); (void)hipFree(nd); return YAMS_ERR_INTERNAL;
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    std::lock_guard<std::mutex> up(g.upload_mu);
+    const uint32_t n_sh = static_cast<uint32_t>(c->sh.size());
+    const uint64_t n0 = c->n_rows, n1 = n0 + n_rows;
+    if (shard_rows(n1, n_sh, 0) >= (1ull << 32)) return YAMS_ERR_UNSUPPORTED;
+    const size_t rb = static_cast<size_t>(c->dim) * 4;
+    const bool bf16 = g.want_bf16 && (c->dim & 3u) == 0;
+    const bool i8 = g.want_i8 && (c->dim & 63u) == 0 && c->dim >= 256;
+    size_t dev_total = 0, dev_free = 0;
+    for (uint32_t i = 0; i < n_sh; ++i) {
+        ShardStore& s = c->sh[i];
+        const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
+        if (now == old) continue;
+        (void)hipSetDevice(s.device);
+        (void)hipMemGetInfo(&dev_free, &dev_total);
+        const size_t hint_rows = dev_total / (rb + (bf16 ? rb / 2 + 4 : 0) + (i8 ? rb / 4 + 1 : 0) + 8) + 1; // a device full of this corpus
+        if (!s.rows.ensure(now * rb, hint_rows * rb)) return YAMS_ERR_INTERNAL;
+        if (bf16 && (!s.bf16.ensure(now * rb / 2, hint_rows * rb / 2) || !s.nsq.ensure(now * 4, hint_rows * 4))) return YAMS_ERR_INTERNAL;
+        if (i8 && (!s.i8.ensure(now * rb / 4, hint_rows * rb / 4) || !s.i8meta.ensure(((now + 63) / 64) * 8, (hint_rows / 64 + 1) * 8))) return YAMS_ERR_INTERNAL;
+    }
+    // copy: runs of consecutive global rows inside one stripe are consecutive local rows
+    for (uint64_t r = n0; r < n1;) {
+        const uint64_t run = std::min<uint64_t>(n1 - r, n_sh == 1 ? n1 - r : kStripeRows - r % kStripeRows);
+        ShardStore& s = c->sh[shard_of(r, n_sh)];
+        yams_accel_ctx* uc = g.upload_ctx[shard_of(r, n_sh)];
+        (void)hipSetDevice(s.device);
+        if (hipMemcpyAsync(s.rows.as<float>() + local_of(r, n_sh) * c->dim, rows + (r - n0) * c->dim, run * rb,
+                           hipMemcpyHostToDevice, uc->stream) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
+        r += run;
+    }
+    for (uint32_t i = 0; i < n_sh; ++i) {
+        ShardStore& s = c->sh[i];
+        const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
+        yams_accel_ctx* uc = g.upload_ctx[i];
+        if (now != old) {
+            if (bf16 && yams_scan_build_shadow_device(uc, s.rows.as<float>() + old * c->dim, now - old, c->dim,
+                                                      s.bf16.as<uint16_t>() + old * c->dim, s.nsq.as<float>() + old) != YAMS_OK)
+                return YAMS_ERR_INTERNAL;
+            if (i8 && yams_scan_build_shadow_i8_device(uc, s.rows.as<float>(), old, now - old, c->dim, s.i8.as<int8_t>(),
+                                                       s.i8meta.as<float>(), nullptr) != YAMS_OK)
+                return YAMS_ERR_INTERNAL;
         }
-        if (c.d_rows) (void)hipFree(c.d_rows);
-        c.d_rows = nd;
-        if ((c.dim & 3u) == 0) { // the shadow grows with the mirror
-            uint16_t* nb = nullptr; float* nn = nullptr;
-            if (hipMalloc(&nb, cap * c.dim * sizeof(uint16_t)) != hipSuccess || hipMalloc(&nn, cap * sizeof(float)) != hipSuccess) {
-                (void)hipGetLastError(); if (nb) (void)hipFree(nb); return YAMS_ERR_INTERNAL;
-            }
-            if (c.n_rows && (hipMemcpy(nb, c.d_bf16, c.n_rows * c.dim * sizeof(uint16_t), hipMemcpyDeviceToDevice) != hipSuccess ||
-                             hipMemcpy(nn, c.d_nsq, c.n_rows * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess)) {
-                (void)hipGetLastError(); (void)hipFree(nb); (void)hipFree(nn); return YAMS_ERR_INTERNAL;
-            }
-            if (c.d_bf16) (void)hipFree(c.d_bf16);
-            if (c.d_nsq) (void)hipFree(c.d_nsq);
-            c.d_bf16 = nb; c.d_nsq = nn;
-        }
-        c.cap_rows = cap;
+        if (yams_accel_ctx_synchronize(uc) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        s.n_rows = now;
+        s.has_tie = false; // appended rows invalidate a previously supplied chunk_id ranking
     }
-    if (hipMemcpy(c.d_rows + c.n_rows * c.dim, rows, n_rows * c.dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipGetLastError(); return YAMS_ERR_INTERNAL;
-    }
-    if (c.d_bf16) {
-        if (yams_scan_build_shadow_device(g.ctx, c.d_rows + c.n_rows * c.dim, n_rows, c.dim,
-                                          c.d_bf16 + c.n_rows * c.dim, c.d_nsq + c.n_rows) != YAMS_OK ||
-            yams_accel_ctx_synchronize(g.ctx) != YAMS_OK)
-            return YAMS_ERR_INTERNAL;
-    }
-    c.n_rows = need;
-    // appended rows invalidate a previously supplied chunk_id ranking
-    if (c.d_tie) { (void)hipFree(c.d_tie); c.d_tie = nullptr; }
-    if (c.d_inv) { (void)hipFree(c.d_inv); c.d_inv = nullptr; }
+    c->n_rows = n1;
+    c->has_ranks = false;
     return YAMS_OK;
 }
 
 yams_status_t vs_corpus_set_tie_ranks(void*, uint64_t id, const uint32_t* ranks, uint64_t n_rows) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
-    Corpus& c = it->second;
-    if (n_rows != c.n_rows || (!ranks && n_rows)) return YAMS_ERR_INVALID_ARG;
-    std::vector<uint32_t> inv(n_rows, 0xffffffffu);
-    for (uint64_t r = 0; r < n_rows; ++r) {
-        if (ranks[r] >= n_rows || inv[ranks[r]] != 0xffffffffu) return YAMS_ERR_INVALID_ARG; // not a permutation
-        inv[ranks[r]] = static_cast<uint32_t>(r);
+    NEED_INIT();
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (n_rows != c->n_rows || (!ranks && n_rows)) return YAMS_ERR_INVALID_ARG;
+    {
+        std::vector<uint8_t> seen(n_rows, 0);
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            if (ranks[r] >= n_rows || seen[ranks[r]]) return YAMS_ERR_INVALID_ARG; // not a permutation
+            seen[ranks[r]] = 1;
+        }
     }
-    (void)hipSetDevice(g.ctx->device);
-    (void)hipStreamSynchronize(g.ctx->stream);
-    if (c.d_tie) { (void)hipFree(c.d_tie); c.d_tie = nullptr; }
-    if (c.d_inv) { (void)hipFree(c.d_inv); c.d_inv = nullptr; }
     if (n_rows == 0) return YAMS_OK;
-    if (hipMalloc(&c.d_tie, n_rows * 4) != hipSuccess || hipMalloc(&c.d_inv, n_rows * 4) != hipSuccess) {
-        (void)hipGetLastError(); return YAMS_ERR_INTERNAL;
+    std::lock_guard<std::mutex> up(g.upload_mu);
+    const uint32_t n_sh = static_cast<uint32_t>(c->sh.size());
+    for (uint32_t i = 0; i < n_sh; ++i) {
+        ShardStore& s = c->sh[i];
+        const uint64_t nl = s.n_rows;
+        if (nl == 0) continue;
+        // local tie ranks: a permutation of 0..nl-1 that preserves the global order (the scan sorts ties
+        // by it inside the shard; the merge compares the global ranks through rank_of_row)
+        std::vector<uint32_t> glob(nl), order(nl), lrank(nl), linv(nl);
+        for (uint64_t l = 0; l < nl; ++l)
+            glob[l] = ranks[n_sh == 1 ? l : ((l / kStripeRows) * n_sh + i) * kStripeRows + l % kStripeRows];
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return glob[x] < glob[y]; });
+        for (uint32_t p = 0; p < nl; ++p) { lrank[order[p]] = p; linv[p] = order[p]; }
+        if (!s.tie.ensure(nl * 4, s.rows.reserved / c->dim + 4) || !s.inv.ensure(nl * 4, s.rows.reserved / c->dim + 4)) return YAMS_ERR_INTERNAL;
+        if (yams_accel_upload(g.upload_ctx[i], s.tie.base, lrank.data(), nl * 4) != YAMS_OK ||
+            yams_accel_upload(g.upload_ctx[i], s.inv.base, linv.data(), nl * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        s.has_tie = true;
     }
-    if (hipMemcpy(c.d_tie, ranks, n_rows * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c.d_inv, inv.data(), n_rows * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipGetLastError(); return YAMS_ERR_INTERNAL;
+    if (n_sh > 1) {
+        if (!c->rank_of_row.ensure(n_rows * 4, n_rows * 8) ||
+            yams_accel_upload(g.upload_ctx[0], c->rank_of_row.base, ranks, n_rows * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
     }
+    c->has_ranks = true;
     return YAMS_OK;
 }
 
+void release_corpus(Corpus& c) {
+    for (auto& s : c.sh) s.release();
+    c.rank_of_row.release();
+    c.n_rows = 0; c.has_ranks = false;
+}
+
 yams_status_t vs_corpus_clear(void*, uint64_t id) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
-    (void)hipStreamSynchronize(g.ctx->stream);
-    const uint32_t dim = it->second.dim;
-    free_corpus(it->second);
-    it->second.dim = dim;
+    NEED_INIT();
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    release_corpus(*c);
     return YAMS_OK;
 }
 
 yams_status_t vs_corpus_destroy(void*, uint64_t id) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
-    (void)hipStreamSynchronize(g.ctx->stream);
-    free_corpus(it->second);
-    g.corpora.erase(it);
+    NEED_INIT();
+    std::shared_ptr<Corpus> c;
+    {
+        std::lock_guard<std::mutex> lk(g.corpora_mu);
+        auto it = g.corpora.find(id);
+        if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
+        c = it->second;
+        g.corpora.erase(it);
+    }
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    release_corpus(*c);
     return YAMS_OK;
 }
 
 yams_status_t vs_corpus_size(void*, uint64_t id, uint64_t* out_rows, uint32_t* out_dim) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
-    if (out_rows) *out_rows = it->second.n_rows;
-    if (out_dim) *out_dim = it->second.dim;
+    NEED_INIT();
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (out_rows) *out_rows = c->n_rows;
+    if (out_dim) *out_dim = c->dim;
     return YAMS_OK;
 }
 
@@ -201,32 +381,46 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
                                  uint32_t k, float threshold, uint32_t metric, uint32_t flags,
                                  const uint32_t* row_mask_host, yams_scan_hit_t** out_hits,
                                  uint32_t** out_counts, yams_scan_diag_t* out_diag) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!out_hits || !out_counts) return YAMS_ERR_INVALID_ARG;
     *out_hits = nullptr; *out_counts = nullptr;
-    auto it = g.corpora.find(id);
-    if (it == g.corpora.end()) return YAMS_ERR_NOT_FOUND;
-    const Corpus& c = it->second;
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
     // dimension mismatch -> InvalidArgument (vector_database.cpp:545-550, 626-633)
-    if (dim != c.dim) return YAMS_ERR_INVALID_ARG;
+    if (dim != c->dim) return YAMS_ERR_INVALID_ARG;
     if (nq && !queries) return YAMS_ERR_INVALID_ARG;
-    yams_scan_corpus_t view{};
-    view.rows = c.d_rows; view.n_rows = c.n_rows; view.dim = c.dim;
-    view.tie_rank = c.d_tie; view.rank_row = c.d_inv; view.row_base = 0;
-    view.rows_bf16 = c.d_bf16; view.rows_nsq = c.d_bf16 ? c.d_nsq : nullptr;
-    if (row_mask_host && c.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175)
-        const size_t words = (c.n_rows + 31) / 32;
-        uint64_t bits = 0;
-        for (size_t i = 0; i < words; ++i) {
-            uint32_t w = row_mask_host[i];
-            if (i == words - 1 && (c.n_rows & 31)) w &= (1u << (c.n_rows & 31)) - 1u;
-            bits += static_cast<uint64_t>(__builtin_popcount(w));
+    std::shared_lock<std::shared_mutex> lk(c->mu);      // concurrent searches share the corpus
+    Lease<yams_scan_sharded*> slot(g.search_slots);     // ... and each runs on its own contexts / streams
+    const uint32_t n_sh = static_cast<uint32_t>(c->sh.size());
+    std::vector<yams_scan_corpus_t> views(n_sh);
+    for (uint32_t i = 0; i < n_sh; ++i) {
+        const ShardStore& s = c->sh[i];
+        yams_scan_corpus_t& v = views[i];
+        std::memset(&v, 0, sizeof v);
+        v.rows = s.rows.as<float>(); v.n_rows = s.n_rows; v.dim = c->dim;
+        if (s.has_tie) { v.tie_rank = s.tie.as<uint32_t>(); v.rank_row = s.inv.as<uint32_t>(); }
+        if (s.bf16.base && s.n_rows) { v.rows_bf16 = s.bf16.as<uint16_t>(); v.rows_nsq = s.nsq.as<float>(); }
+        if (s.i8.base && s.n_rows) { v.rows_i8 = s.i8.as<int8_t>(); v.rows_i8_meta = s.i8meta.as<float>(); }
+        if (n_sh > 1) { v.stripe_rows = kStripeRows; v.n_stripes = n_sh; v.stripe_index = i; }
+        if (row_mask_host && s.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175), dealt like the rows
+            const size_t words = (s.n_rows + 31) / 32;
+            std::vector<uint32_t> local(words, 0u);
+            uint64_t bits = 0;
+            for (size_t w = 0; w < words; ++w) {
+                const uint64_t l0 = static_cast<uint64_t>(w) * 32;  // kStripeRows % 32 == 0: a local word is a global word
+                const uint64_t g0 = n_sh == 1 ? l0 : ((l0 / kStripeRows) * n_sh + i) * kStripeRows + l0 % kStripeRows;
+                uint32_t m = row_mask_host[g0 >> 5];
+                const uint64_t left = s.n_rows - l0;
+                if (left < 32) m &= (1u << left) - 1u;
+                local[w] = m;
+                bits += static_cast<uint64_t>(__builtin_popcount(m));
+            }
+            yams_accel_ctx* sc = yams_scan_sharded_ctx(slot.v, i);
+            uint32_t* d_mask = nullptr;
+            if (yams_accel::ws_get(sc, "plugin_row_mask", words * 4, (void**)&d_mask) != YAMS_OK) return YAMS_ERR_INTERNAL;
+            if (yams_accel_upload(sc, d_mask, local.data(), words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
+            v.row_mask = d_mask; v.row_mask_count = bits;
         }
-        uint32_t* d_mask = nullptr;
-        if (yams_accel::ws_get(g.ctx, "plugin_row_mask", words * 4, (void**)&d_mask) != YAMS_OK) return YAMS_ERR_INTERNAL;
-        if (yams_accel_upload(g.ctx, d_mask, row_mask_host, words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
-        view.row_mask = d_mask; view.row_mask_count = bits;
     }
     // only semantic flags cross the vtable; filter selection stays with the library
     yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT)};
@@ -236,8 +430,9 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
     auto* counts = static_cast<uint32_t*>(std::calloc(std::max<uint32_t>(nq, 1), sizeof(uint32_t)));
     auto* hits = static_cast<yams_scan_hit_t*>(std::calloc(std::max<size_t>(slots, 1), sizeof(yams_scan_hit_t)));
     if (!counts || !hits) { std::free(counts); std::free(hits); return YAMS_ERR_INTERNAL; }
-    yams_status_t s = yams_scan_topk_host(g.ctx, &view, queries, nq, &prm, scores.data(), rows.data(),
-                                          counts, dist.data(), out_diag);
+    const yams_status_t s = yams_scan_sharded_topk_host(slot.v, views.data(), queries, nq, &prm,
+                                                        c->has_ranks && n_sh > 1 ? c->rank_of_row.as<uint32_t>() : nullptr, 0,
+                                                        scores.data(), rows.data(), counts, dist.data(), out_diag);
     if (s != YAMS_OK) { std::free(counts); std::free(hits); return s; }
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t i = 0; i < k; ++i) {
@@ -269,9 +464,9 @@ yams_status_t vs_search_batch(void* self, uint64_t id, const float* queries, uin
 void vs_free_hits(void*, yams_scan_hit_t* hits, uint32_t* counts) { std::free(hits); std::free(counts); }
 
 yams_status_t vs_runtime_info(void*, char** out_json) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    return yams_accel_device_info_json(g.ctx, out_json);
+    NEED_INIT();
+    Lease<yams_accel_ctx*> w(g.work_ctx);
+    return yams_accel_device_info_json(w.v, out_json);
 }
 void vs_free_string(void*, char* s) { std::free(s); }
 
@@ -281,27 +476,32 @@ yams_vector_scan_v1 g_vector_scan = {
     vs_free_hits, vs_runtime_info, vs_free_string, vs_search_batch_masked, vs_search_batch_ex};
 
 // ---- content_hash_v1 --------------------------------------------------------------------------
+// Every call leases one of the plugin's work contexts (own stream, own workspace), so hashing, chunking
+// and searches of different host threads overlap on the device instead of queueing on one mutex.
 yams_status_t ch_hash(void*, const uint8_t* data, size_t n, char out_hex[65]) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
+    Lease<yams_accel_ctx*> w(g.work_ctx);
     ++g.hashes;
-    return yams_sha256_host(g.ctx, data, n, out_hex);
+    return yams_sha256_host(w.v, data, n, out_hex);
 }
 yams_status_t ch_hash_many(void*, const uint8_t* const* msgs, const size_t* lens, size_t n, char* out_hex) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
+    Lease<yams_accel_ctx*> w(g.work_ctx);
     g.hashes += n;
-    return yams_sha256_many_host(g.ctx, msgs, lens, n, out_hex);
+    return yams_sha256_many_host(w.v, msgs, lens, n, out_hex);
 }
 
-// Streaming state (sha256_hasher.cpp:81-109): the compression function runs on the device over
-// whole 64-byte blocks; the host only buffers the partial block and builds the FIPS 180-4 padding.
+// Streaming state (sha256_hasher.cpp:81-109).  update() only BUFFERS on the host: one SHA-256 chain is
+// sequential, a launch + sync per update would cost more than the hashing.  Whole 64-byte blocks are
+// pushed through the device in pieces of kStreamFlush bytes (one upload + one kernel each), the tail
+// and the FIPS 180-4 padding at finalize().  A handle is a single-threaded object, like the reference's
+// hasher (sha256_hasher.cpp:34).
 struct HashStream {
     uint32_t state[8];
-    uint8_t partial[64];
-    size_t partial_len = 0;
-    uint64_t total = 0;
+    std::vector<uint8_t> pending; // bytes not yet compressed
+    uint64_t total = 0;           // bytes compressed so far + pending
 };
+constexpr size_t kStreamFlush = 64u << 20;
 const uint32_t kShaInit[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
                               0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
 }  // namespace
@@ -315,10 +515,9 @@ hipError_t launch_sha256(hipStream_t st, const uint8_t* data, const uint64_t* of
 
 namespace {
 // Runs the compression function over `n` bytes (a multiple of 64) starting from hs->state.
-yams_status_t stream_blocks(HashStream* hs, const uint8_t* bytes, size_t n) {
+yams_status_t stream_blocks(yams_accel_ctx* ctx, HashStream* hs, const uint8_t* bytes, size_t n) {
     using namespace yams_accel;
     if (n == 0) return YAMS_OK;
-    yams_accel_ctx* ctx = g.ctx;
     (void)hipSetDevice(ctx->device);
     uint8_t* d_data; uint64_t* d_tab; uint32_t* d_state; unsigned long long* d_head;
     YA_TRY(ws_get(ctx, "hs_data", n + 64, (void**)&d_data));
@@ -326,19 +525,28 @@ yams_status_t stream_blocks(HashStream* hs, const uint8_t* bytes, size_t n) {
     YA_TRY(ws_get(ctx, "hs_state", 64, (void**)&d_state));
     YA_TRY(ws_get(ctx, "ing_queue", 64, (void**)&d_head));
     const uint64_t tab[2] = {0, n};
+    uint32_t out[8];
     YA_HIP(ctx, hipMemcpyAsync(d_data, bytes, n, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, hipMemcpyAsync(d_tab, tab, 16, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, hipMemcpyAsync(d_state, hs->state, 32, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, launch_sha256(ctx->stream, d_data, d_tab, d_tab + 1, 0, 1, nullptr, d_head, d_state,
                               d_state + 8, 1, 1, 1));
-    YA_HIP(ctx, hipMemcpyAsync(hs->state, d_state + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    YA_HIP(ctx, hipMemcpyAsync(out, d_state + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(hs->state, out, 32); // the handle changes only after the device call succeeded
+    return YAMS_OK;
+}
+yams_status_t flush_whole_blocks(HashStream* hs) {
+    const size_t whole = hs->pending.size() / 64 * 64;
+    if (whole == 0) return YAMS_OK;
+    Lease<yams_accel_ctx*> w(g.work_ctx);
+    YA_TRY(stream_blocks(w.v, hs, hs->pending.data(), whole));
+    hs->pending.erase(hs->pending.begin(), hs->pending.begin() + static_cast<std::ptrdiff_t>(whole));
     return YAMS_OK;
 }
 
 yams_status_t ch_stream_create(void*, void** out) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!out) return YAMS_ERR_INVALID_ARG;
     auto* hs = new HashStream();
     std::memcpy(hs->state, kShaInit, 32);
@@ -346,47 +554,41 @@ yams_status_t ch_stream_create(void*, void** out) {
     return YAMS_OK;
 }
 yams_status_t ch_stream_init(void*, void* s) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!s) return YAMS_ERR_INVALID_ARG;
     auto* hs = static_cast<HashStream*>(s);
     std::memcpy(hs->state, kShaInit, 32);
-    hs->partial_len = 0; hs->total = 0;
+    hs->pending.clear(); hs->total = 0;
     return YAMS_OK;
 }
 yams_status_t ch_stream_update(void*, void* s, const uint8_t* data, size_t n) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!s || (n && !data)) return YAMS_ERR_INVALID_ARG;
     auto* hs = static_cast<HashStream*>(s);
-    hs->total += n;
     size_t pos = 0;
-    if (hs->partial_len) {
-        const size_t take = std::min(n, 64 - hs->partial_len);
-        std::memcpy(hs->partial + hs->partial_len, data, take);
-        hs->partial_len += take; pos = take;
-        if (hs->partial_len < 64) return YAMS_OK;
-        YA_TRY(stream_blocks(hs, hs->partial, 64));
-        hs->partial_len = 0;
+    while (pos < n) { // bounded host buffer: flush whole blocks every kStreamFlush bytes
+        const size_t take = std::min(n - pos, kStreamFlush - std::min(kStreamFlush, hs->pending.size()) + 64);
+        hs->pending.insert(hs->pending.end(), data + pos, data + pos + take);
+        hs->total += take;
+        pos += take;
+        if (hs->pending.size() >= kStreamFlush) {
+            const yams_status_t st = flush_whole_blocks(hs);
+            if (st != YAMS_OK) return st;
+        }
     }
-    const size_t whole = (n - pos) / 64 * 64;
-    if (whole) { YA_TRY(stream_blocks(hs, data + pos, whole)); pos += whole; }
-    if (pos < n) { std::memcpy(hs->partial, data + pos, n - pos); hs->partial_len = n - pos; }
     return YAMS_OK;
 }
 yams_status_t ch_stream_finalize(void*, void* s, char out_hex[65]) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!s || !out_hex) return YAMS_ERR_INVALID_ARG;
     auto* hs = static_cast<HashStream*>(s);
-    uint8_t tail[128];
-    std::memset(tail, 0, sizeof tail);
-    std::memcpy(tail, hs->partial, hs->partial_len);
-    tail[hs->partial_len] = 0x80;
-    const size_t tl = hs->partial_len < 56 ? 64 : 128;
+    // padding: 0x80, zeros, the bit length as a big-endian 64-bit word
     const uint64_t bits = hs->total * 8;
-    for (int i = 0; i < 8; ++i) tail[tl - 1 - i] = static_cast<uint8_t>(bits >> (8 * i));
-    YA_TRY(stream_blocks(hs, tail, tl));
+    hs->pending.push_back(0x80);
+    while (hs->pending.size() % 64 != 56) hs->pending.push_back(0);
+    for (int i = 7; i >= 0; --i) hs->pending.push_back(static_cast<uint8_t>(bits >> (8 * i)));
+    const yams_status_t st = flush_whole_blocks(hs);
+    if (st != YAMS_OK) return st;
     static const char kHex[] = "0123456789abcdef";
     for (int i = 0; i < 8; ++i)
         for (int b = 0; b < 4; ++b) {
@@ -396,7 +598,7 @@ yams_status_t ch_stream_finalize(void*, void* s, char out_hex[65]) {
     out_hex[64] = 0;
     // "Reset for potential reuse" (sha256_hasher.cpp:103-106)
     std::memcpy(hs->state, kShaInit, 32);
-    hs->partial_len = 0; hs->total = 0;
+    hs->pending.clear(); hs->total = 0;
     ++g.hashes;
     return YAMS_OK;
 }
@@ -426,10 +628,10 @@ yams_status_t ch_verify_many(void*, const uint8_t* const* msgs, const size_t* le
     if (!msgs || !lens || !expected_hex || !out_valid) return YAMS_ERR_INVALID_ARG;
     std::vector<char> hex(n * 65);
     {
-        std::lock_guard<std::mutex> lk(g.mu);
-        NEED_CTX();
+        NEED_INIT();
+        Lease<yams_accel_ctx*> w(g.work_ctx);
         g.hashes += n;
-        yams_status_t s = yams_sha256_many_host(g.ctx, msgs, lens, n, hex.data());
+        yams_status_t s = yams_sha256_many_host(w.v, msgs, lens, n, hex.data());
         if (s != YAMS_OK) return s;
     }
     for (size_t i = 0; i < n; ++i) { // the reference compares the lower-case hex strings (:243-249)
@@ -440,47 +642,72 @@ yams_status_t ch_verify_many(void*, const uint8_t* const* msgs, const size_t* le
     return YAMS_OK;
 }
 
-std::map<uint64_t, yams_dedup_set*> g_dedup;
+// Dedup sets: each owns a context (its table lives in that context's device memory) and a mutex.
+struct DedupEntry { yams_accel_ctx* ctx = nullptr; yams_dedup_set* set = nullptr; std::mutex mu; };
+std::mutex g_dedup_mu;
+std::map<uint64_t, std::shared_ptr<DedupEntry>> g_dedup;
 uint64_t g_next_dedup = 1;
 
+std::shared_ptr<DedupEntry> find_dedup(uint64_t id) {
+    std::lock_guard<std::mutex> lk(g_dedup_mu);
+    auto it = g_dedup.find(id);
+    return it == g_dedup.end() ? nullptr : it->second;
+}
+void destroy_dedup(DedupEntry& e) {
+    if (e.set) yams_dedup_set_destroy(e.set);
+    if (e.ctx) yams_accel_ctx_destroy(e.ctx);
+    e.set = nullptr; e.ctx = nullptr;
+}
+
 yams_status_t ch_dedup_create(void*, uint64_t expected, uint64_t* out_id) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!out_id) return YAMS_ERR_INVALID_ARG;
-    yams_dedup_set* s = nullptr;
-    yams_status_t st = yams_dedup_set_create(g.ctx, expected, &s);
+    auto e = std::make_shared<DedupEntry>();
+    yams_status_t st = yams_accel_ctx_create(g.devices[0], nullptr, &e->ctx);
     if (st != YAMS_OK) return st;
+    st = yams_dedup_set_create(e->ctx, expected, &e->set);
+    if (st != YAMS_OK) { destroy_dedup(*e); return st; }
+    std::lock_guard<std::mutex> lk(g_dedup_mu);
     *out_id = g_next_dedup++;
-    g_dedup[*out_id] = s;
+    g_dedup[*out_id] = e;
     return YAMS_OK;
 }
 yams_status_t dedup_call(uint64_t id, const char* hashes_hex, size_t n, uint8_t* out, bool insert) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
-    auto it = g_dedup.find(id);
-    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
+    NEED_INIT();
+    auto e = find_dedup(id);
+    if (!e) return YAMS_ERR_NOT_FOUND;
     if (n == 0) return YAMS_OK;
     if (!hashes_hex || !out) return YAMS_ERR_INVALID_ARG;
     std::vector<uint8_t> raw(n * 32);
     for (size_t i = 0; i < n; ++i)
         if (!parse_hex32(hashes_hex + 65 * i, raw.data() + 32 * i)) return YAMS_ERR_INVALID_ARG;
-    return insert ? yams_dedup_insert_host(it->second, raw.data(), n, out, nullptr)
-                  : yams_dedup_probe_host(it->second, raw.data(), n, out);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->set) return YAMS_ERR_NOT_FOUND;
+    return insert ? yams_dedup_insert_host(e->set, raw.data(), n, out, nullptr)
+                  : yams_dedup_probe_host(e->set, raw.data(), n, out);
 }
 yams_status_t ch_dedup_insert(void*, uint64_t id, const char* hex, size_t n, uint8_t* out) { return dedup_call(id, hex, n, out, true); }
 yams_status_t ch_dedup_contains(void*, uint64_t id, const char* hex, size_t n, uint8_t* out) { return dedup_call(id, hex, n, out, false); }
 yams_status_t ch_dedup_size(void*, uint64_t id, uint64_t* out_entries) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto it = g_dedup.find(id);
-    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
-    return yams_dedup_set_size(it->second, out_entries);
+    NEED_INIT();
+    auto e = find_dedup(id);
+    if (!e) return YAMS_ERR_NOT_FOUND;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->set) return YAMS_ERR_NOT_FOUND;
+    return yams_dedup_set_size(e->set, out_entries);
 }
 yams_status_t ch_dedup_destroy(void*, uint64_t id) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto it = g_dedup.find(id);
-    if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
-    yams_dedup_set_destroy(it->second);
-    g_dedup.erase(it);
+    NEED_INIT();
+    std::shared_ptr<DedupEntry> e;
+    {
+        std::lock_guard<std::mutex> lk(g_dedup_mu);
+        auto it = g_dedup.find(id);
+        if (it == g_dedup.end()) return YAMS_ERR_NOT_FOUND;
+        e = it->second;
+        g_dedup.erase(it);
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    destroy_dedup(*e);
     return YAMS_OK;
 }
 
@@ -496,10 +723,10 @@ yams_status_t ck_default_config(void*, uint32_t mode, yams_cdc_config_t* out_cfg
     yams_cdc_default_config(out_cfg, mode);
     return YAMS_OK;
 }
+// re-entrant: ContentStore shares one chunker across its workers (content_store_impl.cpp:1412)
 yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc_config_t* cfg,
                             yams_chunk_ref_t** out_chunks, size_t* out_count) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    NEED_CTX();
+    NEED_INIT();
     if (!out_chunks || !out_count || !cfg) return YAMS_ERR_INVALID_ARG;
     *out_chunks = nullptr; *out_count = 0;
     const uint64_t floor = std::max<uint64_t>(1, cfg->min_size);
@@ -507,7 +734,11 @@ yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc
     std::vector<uint64_t> off(cap), sz(cap);
     std::vector<char> hex(cap * 65);
     size_t cnt = 0;
-    yams_status_t s = yams_cdc_chunk_host(g.ctx, data, n, cfg, off.data(), sz.data(), hex.data(), cap, &cnt);
+    yams_status_t s;
+    {
+        Lease<yams_accel_ctx*> w(g.work_ctx);
+        s = yams_cdc_chunk_host(w.v, data, n, cfg, off.data(), sz.data(), hex.data(), cap, &cnt);
+    }
     if (s != YAMS_OK) return s;
     auto* chunks = static_cast<yams_chunk_ref_t*>(std::calloc(std::max<size_t>(cnt, 1), sizeof(yams_chunk_ref_t)));
     if (!chunks) return YAMS_ERR_INTERNAL;
@@ -524,53 +755,89 @@ void ck_free_chunks(void*, yams_chunk_ref_t* chunks, size_t) { std::free(chunks)
 yams_chunker_v1 g_chunker = {YAMS_IFACE_CHUNKER_V1_VERSION, nullptr, ck_default_config,
                              ck_chunk_data, ck_free_chunks};
 
+void teardown_locked() { // g.mu held exclusively
+    {
+        std::lock_guard<std::mutex> lk(g.corpora_mu);
+        for (auto& kv : g.corpora) { std::unique_lock<std::shared_mutex> cl(kv.second->mu); release_corpus(*kv.second); }
+        g.corpora.clear();
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_dedup_mu);
+        for (auto& kv : g_dedup) { std::lock_guard<std::mutex> el(kv.second->mu); destroy_dedup(*kv.second); }
+        g_dedup.clear();
+    }
+    for (auto* s : g.search_slots.drain()) yams_scan_sharded_destroy(s);
+    for (auto* c : g.work_ctx.drain()) yams_accel_ctx_destroy(c);
+    for (auto* c : g.upload_ctx) yams_accel_ctx_destroy(c);
+    g.upload_ctx.clear();
+    g.initialised = false;
+}
+
 } // namespace
 
 extern "C" {
 
-YAMS_PLUGIN_API int yams_plugin_get_abi_version(void) { return YAMS_PLUGIN_ABI_VERSION; }
-YAMS_PLUGIN_API const char* yams_plugin_get_name(void) { return "yams_mi355x_accel"; }
-YAMS_PLUGIN_API const char* yams_plugin_get_version(void) { return YAMS_ACCEL_VERSION_STRING; }
-YAMS_PLUGIN_API const char* yams_plugin_get_manifest_json(void) { return kManifest; }
+int yams_plugin_get_abi_version(void) { return YAMS_PLUGIN_ABI_VERSION; }
+const char* yams_plugin_get_name(void) { return "yams_mi355x_accel"; }
+const char* yams_plugin_get_version(void) { return YAMS_ACCEL_VERSION_STRING; }
+const char* yams_plugin_get_manifest_json(void) { return kManifest; }
 
 // host_context is a yams_plugin_host_context_v1* (host_services_v1.h:19-26); unused here.  The
 // legacy one-argument form (abi_plugin_loader.cpp:329-357) is tolerated: the second argument is
-// never dereferenced.
-YAMS_PLUGIN_API int yams_plugin_init(const char* config_json, const void* host_context) {
+// never dereferenced.  config_json: {"device": n} or {"devices": [..]} (a corpus is dealt to all of
+// them in stripes and searched behind one call), "search_slots": concurrent searches (default 2),
+// "shadows": "both" (default) | "bf16" | "i8" | "none".
+int yams_plugin_init(const char* config_json, const void* host_context) {
     (void)host_context;
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::unique_lock<std::shared_mutex> lk(g.mu);
     if (g.initialised) return YAMS_PLUGIN_OK;
-    g.device = parse_device(config_json);
-    yams_accel_ctx* ctx = nullptr;
-    const yams_status_t s = yams_accel_ctx_create(g.device, nullptr, &ctx);
-    if (s != YAMS_OK) {
-        g.init_error = (s == YAMS_ERR_UNSUPPORTED) ? "no gfx950 device visible" : "context creation failed";
-        return YAMS_PLUGIN_ERR_INIT_FAILED; // the host keeps its built-in CPU backends
+    g.devices = json_devices(config_json);
+    const long slots = std::max<long>(1, std::min<long>(16, json_int(config_json, "\"search_slots\"", 2)));
+    {
+        const long sr = json_int(config_json, "\"stripe_rows\"", 65536);
+        kStripeRows = static_cast<uint32_t>(std::max<long>(64, std::min<long>(1 << 24, sr)) / 64 * 64);
     }
-    g.ctx = ctx;
+    g.want_bf16 = g.want_i8 = true;
+    if (config_json && std::strstr(config_json, "\"shadows\"")) {
+        const char* p = std::strstr(config_json, "\"shadows\"");
+        g.want_bf16 = std::strstr(p, "\"both\"") || std::strstr(p, "\"bf16\"");
+        g.want_i8 = std::strstr(p, "\"both\"") || std::strstr(p, "\"i8\"");
+    }
+    auto failed = [&](const char* why) {
+        g.init_error = why;
+        teardown_locked();
+        return YAMS_PLUGIN_ERR_INIT_FAILED; // the host keeps its built-in CPU backends
+    };
+    for (size_t i = 0; i < g.devices.size(); ++i) {
+        yams_accel_ctx* c = nullptr;
+        const yams_status_t s = yams_accel_ctx_create(g.devices[i], nullptr, &c);
+        if (s != YAMS_OK) return failed(s == YAMS_ERR_UNSUPPORTED ? "no gfx950 device visible" : "context creation failed");
+        g.upload_ctx.push_back(c);
+    }
+    for (long i = 0; i < slots; ++i) {
+        yams_scan_sharded* sh = nullptr;
+        if (yams_scan_sharded_create(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &sh) != YAMS_OK)
+            return failed("search slot creation failed");
+        g.search_slots.add(sh);
+    }
+    for (long i = 0; i < std::max<long>(2, slots); ++i) {
+        yams_accel_ctx* c = nullptr;
+        if (yams_accel_ctx_create(g.devices[0], nullptr, &c) != YAMS_OK) return failed("work context creation failed");
+        g.work_ctx.add(c);
+    }
     g.initialised = true;
     g.init_error.clear();
     return YAMS_PLUGIN_OK;
 }
 
-YAMS_PLUGIN_API void yams_plugin_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.ctx) {
-        (void)hipSetDevice(g.ctx->device);
-        (void)hipStreamSynchronize(g.ctx->stream);
-        for (auto& kv : g.corpora) free_corpus(kv.second);
-        g.corpora.clear();
-        for (auto& kv : g_dedup) yams_dedup_set_destroy(kv.second);
-        g_dedup.clear();
-        yams_accel_ctx_destroy(g.ctx);
-        g.ctx = nullptr;
-    }
-    g.initialised = false;
+void yams_plugin_shutdown(void) {
+    std::unique_lock<std::shared_mutex> lk(g.mu);
+    if (g.initialised) teardown_locked();
 }
 
 // Returns a pointer to a static vtable; unknown id or version -> NOT_FOUND, null args -> INVALID
 // (plugins/glint/plugin.cpp:338-359, tools/fuzzing/fuzz_abi_test_plugin.c:48-60).
-YAMS_PLUGIN_API int yams_plugin_get_interface(const char* iface_id, uint32_t version, void** out_iface) {
+int yams_plugin_get_interface(const char* iface_id, uint32_t version, void** out_iface) {
     if (!iface_id || !out_iface) return YAMS_PLUGIN_ERR_INVALID;
     *out_iface = nullptr;
     if (std::strcmp(iface_id, YAMS_IFACE_VECTOR_SCAN_V1) == 0) {
@@ -589,14 +856,17 @@ YAMS_PLUGIN_API int yams_plugin_get_interface(const char* iface_id, uint32_t ver
 }
 
 // malloc'd; the host free()s it (abi_plugin_loader.cpp:481-500).
-YAMS_PLUGIN_API int yams_plugin_get_health_json(char** out_json) {
+int yams_plugin_get_health_json(char** out_json) {
     if (!out_json) return YAMS_PLUGIN_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::shared_lock<std::shared_mutex> lk(g.mu);
     std::ostringstream os;
-    os << "{\"status\":\"" << (g.ctx ? "ok" : (g.initialised ? "degraded" : "not_initialised"))
-       << "\",\"device\":" << g.device << ",\"corpora\":" << g.corpora.size()
-       << ",\"searches\":" << g.searches << ",\"hashes\":" << g.hashes
-       << ",\"chunk_calls\":" << g.chunk_calls;
+    size_t n_corpora;
+    { std::lock_guard<std::mutex> cl(g.corpora_mu); n_corpora = g.corpora.size(); }
+    os << "{\"status\":\"" << (g.initialised ? "ok" : "not_initialised") << "\",\"devices\":[";
+    for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
+    os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots.size()
+       << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
+       << ",\"chunk_calls\":" << g.chunk_calls.load();
     if (!g.init_error.empty()) os << ",\"error\":\"" << g.init_error << "\"";
     os << "}";
     const std::string s = os.str();
