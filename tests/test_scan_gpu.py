@@ -841,6 +841,7 @@ def test_vector_scan_vtable(accel_lib, oracle):
 
 
 def _vt(L, config):
+    L.yams_plugin_shutdown()                  # (a test that failed half-way leaves the plugin initialised)
     assert L.yams_plugin_init(config, None) == 0
     p = C.c_void_p()
     assert L.yams_plugin_get_interface(b"vector_scan_v1", 1, C.byref(p)) == 0

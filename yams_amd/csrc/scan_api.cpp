@@ -303,6 +303,18 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_TRY(ws_get(ctx, "work64", static_cast<size_t>(2) * nq * lchunks * keep_max * 8, (void**)&d_work64));
         L.tau = d_tau; L.tau_out = d_tau; L.list_count = d_lcount; L.list = d_list;
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
+        uint32_t* d_qover = nullptr;
+        if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip); 16 entries per (workgroup, wave)
+            const uint64_t regions = static_cast<uint64_t>(i8_filter_grid(L)) * 8u;
+            L.log_cap = 16;
+            YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * 8, (void**)&L.log_key));
+            YA_TRY(ws_get(ctx, "i8_log_q", static_cast<size_t>(regions) * L.log_cap * 4, (void**)&L.log_q));
+            YA_TRY(ws_get(ctx, "i8_log_cnt", static_cast<size_t>(regions) * 4, (void**)&L.log_cnt));
+            YA_TRY(ws_get(ctx, "q_over", static_cast<size_t>(nq) * 4, (void**)&d_qover));
+            YA_HIP(ctx, hipMemsetAsync(L.log_cnt, 0, static_cast<size_t>(regions) * 4, st));
+            YA_HIP(ctx, hipMemsetAsync(d_qover, 0, static_cast<size_t>(nq) * 4, st));
+            L.q_over = d_qover;
+        }
 
         { TimedRegion tr(ctx, "scan_sample");
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 0, bf16_version));
@@ -315,6 +327,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
           tr.end(); }
+        if (i8) YA_HIP(ctx, launch_i8_log_gather(st, L));
 
 #ifdef YAMS_ACCEL_MEASURE
         if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20) { // ablated kernels produce no candidates: stop here
@@ -343,7 +356,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             R.threshold = params->similarity_threshold; R.flags = params->flags;
             R.err_bound = err_bound; R.out_scores = out_scores; R.out_rows = out_rows;
             R.out_counts = out_counts; R.out_dist = out_dist; R.out_ranks = out_ranks;
-            R.out_status = d_status; R.stat_rescored = d_stat;
+            R.out_status = d_status; R.stat_rescored = d_stat; R.q_over = d_qover;
             YA_HIP(ctx, launch_rescore(st, metric, R));
             return YAMS_OK;
         };

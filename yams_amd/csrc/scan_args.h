@@ -15,6 +15,13 @@ struct ScanArgs {
     const int8_t* q_i8;        // [dim/64][q_pad][64] int8 queries of the batch (int8 tier, k-slab-major)
     const float* q_meta;       // [q_pad][4] = {t_q, c_q, f_q, 0}
     const float* q_thr;        // [q_pad][2] = {A_lo, B_hi}: per-query halves of the integer thresholds
+    // int8 tier, filter pass: survivors go to a per-(workgroup, wave) log instead of reserving list slots
+    // with returning global atomics (whose round trip sat on the critical path of every tile)
+    uint64_t* log_key;         // [grid * 8][log_cap] candidate keys
+    uint32_t* log_q;           // [grid * 8][log_cap] their queries
+    uint32_t* log_cnt;         // [grid * 8] entries written (zeroed before the launch)
+    uint32_t log_cap;
+    uint32_t* q_over;          // [n_queries] set when a log region was too small for a query's survivors
     const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
     const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
     const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)

@@ -64,6 +64,7 @@ __device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, floa
 template <int MODE, int ABL = 0>
 __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[I8_NST * I8_STAGE];
+    __shared__ uint32_t wave_log[8]; // survivors each wave has logged (wave-private slots)
 
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     const uint32_t q0 = qt * I8_QUERIES;
     const uint32_t dim = a.dim;
     const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
+    if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
 
     // ---- DMA sources: every wave stages 32 rows and 32 queries per slab (4 pieces of 1 KiB) -------
     uint32_t voffA[2], voffB[2];
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     if (hot == 0) return; // ~99 % of the lanes
     // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
     // per query block (all of them issued before the first store), then the stores
-    uint32_t pass[8], base[8];
+    uint32_t pass[8];
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
         pass[cb] = 0u;
@@ -337,47 +339,76 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
             }
         }
     }
-    if (ABL == 8) { // measurement build: the whole epilogue up to here, but no reservations and no stores
+    if (ABL == 8) { // measurement build: the whole epilogue up to here, but nothing is emitted
         uint32_t t = 0;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
         if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
         return;
     }
-    // the query factors of the surviving blocks and the list reservations go out back to back (one
-    // memory round trip for both), then the stores
-    float4 qm[8];
-    float2 qth[8];  // (the threshold halves are re-read here instead of living in 16 registers through the k loop)
+    // Survivors go to this wave's region of the log: slots come from an LDS counter (a ~100-cycle round
+    // trip; a returning GLOBAL atomic per query block took microseconds at the end of every tile), the
+    // stores are fire-and-forget.  i8_log_gather_kernel moves the log into the per-query lists.
+    uint32_t mine = 0;
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        qm[cb] = pass[cb] ? reinterpret_cast<const float4*>(a.q_meta)[qb + cb * 16 + l15] : make_float4(0.f, 0.f, 0.f, 0.f);
-        qth[cb] = pass[cb] ? reinterpret_cast<const float2*>(a.q_thr)[qb + cb * 16 + l15] : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        base[cb] = 0u;
-        if (pass[cb]) base[cb] = atomicAdd(&a.list_count[qb + cb * 16 + l15], static_cast<uint32_t>(__builtin_popcount(pass[cb])));
-    }
+    for (int cb = 0; cb < 8; ++cb) mine += static_cast<uint32_t>(__builtin_popcount(pass[cb]));
+    uint32_t pos = mine ? atomicAdd(&wave_log[wid], mine) : 0u;
+    const uint64_t region = (static_cast<uint64_t>(bid) * 8u + static_cast<uint32_t>(wid)) * a.log_cap;
+    // An entry is (accumulator, row) + the query: no global load sits between the k loop and the end of
+    // the tile; the gather kernel turns the accumulator back into the score bound u.
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
         if (!pass[cb]) continue;
         const uint32_t qi = qb + cb * 16 + l15;
-        uint32_t pos = base[cb];
-        uint64_t* lst = a.list + static_cast<uint64_t>(qi) * a.list_cap;
-        const float S = sb * qm[cb].x, K = fmaf(eb, qm[cb].y, qm[cb].z);
-        const float is = 1.0f / sb;
-        const int nt = i8_neg_threshold(qth[cb].x, is, qth[cb].y, eb * is); // I = accumulator - (-T)
+        bool lost = false;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
                 const uint64_t row = strip + 16 * rb + 4 * lq + r;
-                if (pos < a.list_cap)
-                    lst[pos] = pack_key(fmaf(static_cast<float>(acc[rb][cb][r] - nt), S, K), static_cast<uint32_t>(row));
+                if (pos < a.log_cap) {
+                    a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(acc[rb][cb][r])) << 32) | static_cast<uint32_t>(row);
+                    a.log_q[region + pos] = qi;
+                } else {
+                    lost = true;
+                }
                 ++pos;
             }
         }
+        if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path (no return value used)
+    }
+    // the wave's total (all hot lanes ran the LDS add in the same instruction): one lane publishes it
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    if (lane == static_cast<int>(__builtin_ctzll(act))) {
+        const uint32_t total = wave_log[wid];
+        a.log_cnt[static_cast<uint64_t>(bid) * 8u + static_cast<uint32_t>(wid)] = total < a.log_cap ? total : a.log_cap;
+    }
+}
+
+// Log -> per-query candidate lists.  One thread per log region.  An entry carries the accumulator
+// I - T of a survivor; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
+// filter kernel derived it (same inputs, same instructions).
+__global__ __launch_bounds__(256) void i8_log_gather_kernel(const uint64_t* log_key, const uint32_t* log_q, const uint32_t* log_cnt,
+                                                            uint32_t log_cap, uint64_t n_regions, const float* rows_meta,
+                                                            const float* q_meta, const float* q_thr, uint32_t* list_count,
+                                                            uint64_t* list, uint32_t list_cap) {
+    const uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    const uint32_t n = log_cnt[r];
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t e = log_key[r * log_cap + i];
+        const uint32_t q = log_q[r * log_cap + i];
+        const uint32_t row = static_cast<uint32_t>(e);
+        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
+        const float2 m = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
+        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
+        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
+        const float is = 1.0f / m.x;
+        const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
+        const float u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        const uint32_t pos = atomicAdd(&list_count[q], 1u);
+        if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
 }
 
@@ -603,6 +634,19 @@ hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q
                                 float* q_thr) {
     if (q_pad == 0) return hipSuccess;
     hipLaunchKernelGGL(i8_query_thresholds_kernel, dim3((q_pad + 255) / 256), dim3(256), 0, st, tau, q_meta, nq, q_pad, q_thr);
+    return hipGetLastError();
+}
+
+uint32_t i8_filter_grid(const ScanLaunch& L) {
+    return ((L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8;
+}
+
+hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
+    const uint64_t regions = static_cast<uint64_t>(i8_filter_grid(L)) * 8u;
+    if (regions == 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_log_gather_kernel, dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
+                       L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
+                       L.plan.list_cap);
     return hipGetLastError();
 }
 

@@ -531,6 +531,7 @@ struct RescoreArgs {
     uint32_t* out_ranks;
     uint32_t* out_status;       // [nq]: 0 verified, 1 needs widening
     unsigned long long* stat_rescored;
+    const uint32_t* q_over;     // nullable: != 0 -> the list of this query is incomplete
 };
 
 // local row ordinal -> the id the caller sees (yams_scan_corpus_t: row_base, stripes)
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
         s_nvalid = nv;
         uint32_t status = 0;
         if (!a.all_rows_listed) {
-            const bool overflow = a.list_count && a.list_count[q] > a.list_cap;
+            const bool overflow = (a.list_count && a.list_count[q] > a.list_cap) || (a.q_over && a.q_over[q] != 0);
             const float ninf = -__builtin_inff();
             double ob = 0.0;
             bool has_outside = false;
@@ -1096,7 +1097,8 @@ hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint
 ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
     a.rows = L.rows; a.rows_bf16 = L.rows_bf16; a.rows_nsq = L.rows_nsq;
-    a.rows_i8 = L.rows_i8; a.rows_i8_meta = L.rows_i8_meta; a.q_i8 = L.q_i8; a.q_meta = L.q_meta; a.q_thr = L.q_thr; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.rows_i8 = L.rows_i8; a.rows_i8_meta = L.rows_i8_meta; a.q_i8 = L.q_i8; a.q_meta = L.q_meta; a.q_thr = L.q_thr;
+    a.log_key = L.log_key; a.log_q = L.log_q; a.log_cnt = L.log_cnt; a.log_cap = L.log_cap; a.q_over = L.q_over; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;
@@ -1254,7 +1256,7 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     a.qmap = R.qmap; a.k = R.k; a.threshold = R.threshold; a.flags = R.flags;
     a.err_bound = R.err_bound; a.out_scores = R.out_scores; a.out_rows = R.out_rows;
     a.out_counts = R.out_counts; a.out_dist = R.out_dist; a.out_ranks = R.out_ranks;
-    a.out_status = R.out_status; a.stat_rescored = R.stat_rescored;
+    a.out_status = R.out_status; a.stat_rescored = R.stat_rescored; a.q_over = R.q_over;
     size_t rs = 64;
     while (rs < R.n_cand) rs <<= 1;
     if (rs > static_cast<size_t>(RS_MAX)) rs = RS_MAX;

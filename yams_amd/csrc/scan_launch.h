@@ -14,6 +14,8 @@ struct ScanLaunch {
     const int8_t* q_i8 = nullptr;
     const float* q_meta = nullptr;
     const float* q_thr = nullptr;
+    uint64_t* log_key = nullptr; uint32_t* log_q = nullptr; uint32_t* log_cnt = nullptr; uint32_t log_cap = 0;
+    uint32_t* q_over = nullptr;
     int sample_layout = 0;               // rows of a sample group: 0 = 32x32 accumulator layout, 1 = 16x16 (int8 tier)
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
@@ -41,6 +43,7 @@ struct RescoreLaunch {
     uint32_t k; float threshold; uint32_t flags; double err_bound;
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
     uint32_t* out_ranks; uint32_t* out_status; unsigned long long* stat_rescored;
+    const uint32_t* q_over = nullptr; // nullable: queries whose candidate list is known to be incomplete
 };
 
 struct MergeLaunch {
@@ -74,6 +77,11 @@ hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint3
 hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
                                   int8_t* out_i8, float* out_meta, double* stats);
 // After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
+// int8 tier: workgroups of the filter launch (the survivor log has 8 regions of log_cap entries per group)
+uint32_t i8_filter_grid(const ScanLaunch& L);
+// after the filter pass: log entries -> per-query candidate lists (the returning atomics live here, where
+// thousands of independent threads hide their latency)
+hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L);
 hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
                                 float* q_thr);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);

@@ -148,6 +148,12 @@ extern "C" yams_status_t yams_scan_sharded_topk_host(
     if (n_queries == 0) return YAMS_OK;
     if (!queries_host || !out_counts_host) return failed(YAMS_ERR_INVALID_ARG, "null queries/out_counts");
     const uint32_t n = static_cast<uint32_t>(s->ctx.size());
+    if (n == 1) { // one shard: its own ordering (tie ranks included) is final, nothing to merge
+        const yams_status_t st1 = yams_scan_topk_host(s->ctx[0], &shards[0], queries_host, n_queries, params, out_scores_host,
+                                                      out_rows_host, out_counts_host, out_dist_host, diag);
+        if (st1 != YAMS_OK) s->last_error = yams_accel_last_error(s->ctx[0]);
+        return st1;
+    }
     const uint32_t dim = shards[0].dim;
     for (uint32_t i = 1; i < n; ++i)
         if (shards[i].dim != dim) return failed(YAMS_ERR_INVALID_ARG, "shards disagree on the dimension");
