@@ -506,6 +506,8 @@ def main():
            "qps_on_resident_corpus": qps_resident,
            "row_queries_per_s": total_rows * nq * a.steps / dt,
            "exact_fallback_queries": fallbacks,
+           "scan_diag_per_batch": {kk: diag[kk] for kk in ("filter_tier", "filter_candidates", "rescored_rows", "widened_queries",
+                                                             "escalated_queries", "exact_fallback_queries")},
            "roofline": roofline}
     if hbm_leg is not None:
         out["roofline_hbm_leg"] = hbm_leg

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -31,33 +32,48 @@ namespace {
 // A device buffer that grows IN PLACE: one virtual range reserved up front, physical chunks mapped
 // behind it as rows arrive (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess).
 // Appending to a 38 GB mirror maps a few more chunks; nothing is reallocated or copied, pointers
-// handed to running searches stay valid.  (Probed on MI355X: scripts/ubench/vmm_probe.hip.)  Falls
-// back to allocate-copy-free growth only if the driver refuses the virtual-memory calls.
+// handed to running searches stay valid.  (Probed on MI355X: scripts/ubench/vmm_probe.hip.)
+//
+// A virtual address is NEVER reused for a different mapping: scripts/ubench/vmm_stale.hip shows that
+// after hipMemUnmap + a new hipMemMap at the same address, kernels read through stale translations
+// (wrong data in 1-60 % of the trials, even on the stream that did the copy), while re-filling a range
+// that stays mapped is always seen.  So a buffer whose corpus is destroyed is PARKED, mapping intact,
+// and handed to the next corpus on that device (park / unpark below); physical memory goes back to the
+// driver only when the process exits.
+// Falls back to allocate-copy-free growth if the driver refuses the virtual-memory calls.
 // ------------------------------------------------------------------------------------------------
+#ifdef YAMS_ACCEL_MEASURE
+#define GROW_TRACE(what, err) std::fprintf(stderr, "[yams_mi355x_accel] GrowBuf role %d: %s failed (%s); want %zu mapped %zu reserved %zu\n", role, what, hipGetErrorString(err), bytes, mapped, reserved)
+#else
+#define GROW_TRACE(what, err) ((void)0)
+#endif
 struct GrowBuf {
     int device = 0;
+    int role = 0;               // which array of a shard this is (buffers are parked and reused per role)
     unsigned char* base = nullptr;
     size_t reserved = 0, mapped = 0;
-    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
     bool plain = false; // fallback mode: `base` is a hipMalloc allocation of `mapped` bytes
+    std::vector<size_t> chunk_end; // end offset of every physical chunk mapped so far
 
     static constexpr size_t kGran = 2ull << 20;
     template <typename T> T* as() const { return reinterpret_cast<T*>(base); }
 
-    bool ensure(size_t bytes, size_t reserve_hint) {
+    // reserve_bytes: the size of the virtual range if this is the buffer's first use (per role: a fixed
+    // fraction of the device's memory, so parked buffers fit every later corpus)
+    bool ensure(size_t bytes, size_t reserve_bytes) {
         if (bytes <= mapped) return true;
         (void)hipSetDevice(device);
         if (!plain && !base) {
-            size_t want = std::max(reserve_hint, bytes);
+            size_t want = std::max(reserve_bytes, bytes);
             want = (want + kGran - 1) / kGran * kGran;
             void* va = nullptr;
             if (hipMemAddressReserve(&va, want, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); plain = true; }
             else { base = static_cast<unsigned char*>(va); reserved = want; }
         }
-        if (!plain && bytes > reserved) return false; // beyond the reservation (sized to the device's memory)
+        if (!plain && bytes > reserved) { GROW_TRACE("beyond reservation", hipSuccess); return false; } // (sized to the device's memory)
         if (!plain) {
-            // geometric chunks: at least 32 MiB, at least a quarter of what is mapped
-            size_t add = std::max<size_t>(bytes - mapped, std::max<size_t>(32ull << 20, mapped / 4));
+            // geometric chunks: at least 32 MiB (small side arrays: 2 MiB), at least a quarter of what is mapped
+            size_t add = std::max<size_t>(bytes - mapped, std::max<size_t>(reserved >= (1ull << 30) ? 32ull << 20 : kGran, mapped / 4));
             add = (add + kGran - 1) / kGran * kGran;
             if (mapped + add > reserved) add = reserved - mapped;
             hipMemAllocationProp prop{};
@@ -65,16 +81,21 @@ struct GrowBuf {
             prop.location.type = hipMemLocationTypeDevice;
             prop.location.id = device;
             hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            hipError_t e = hipMemCreate(&h, add, &prop, 0);
+            if (e != hipSuccess) { GROW_TRACE("hipMemCreate", e); (void)hipGetLastError(); return false; }
             hipMemAccessDesc acc{};
             acc.location = prop.location;
             acc.flags = hipMemAccessFlagsProtReadWrite;
-            if (hipMemMap(base + mapped, add, 0, h, 0) != hipSuccess ||
-                hipMemSetAccess(base + mapped, add, &acc, 1) != hipSuccess) {
-                (void)hipGetLastError(); (void)hipMemRelease(h); return false;
-            }
-            chunks.emplace_back(h, add);
+            e = hipMemMap(base + mapped, add, 0, h, 0);
+            // access is set over the WHOLE mapped range: on a sub-range that starts at a later chunk the call
+            // returns "invalid argument" as soon as chunk sizes differ (scripts/ubench/vmm_map.hip)
+            const bool was_mapped = e == hipSuccess;
+            if (e == hipSuccess) e = hipMemSetAccess(base, mapped + add, &acc, 1);
+            if (e != hipSuccess && was_mapped) (void)hipMemUnmap(base + mapped, add); // never touched: safe to unmap
+            if (e != hipSuccess) { GROW_TRACE("hipMemMap/SetAccess", e); (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+            (void)hipMemRelease(h); // the mapping keeps the memory alive; it is never unmapped (see above)
             mapped += add;
+            chunk_end.push_back(mapped);
             return true;
         }
         // fallback: allocate, copy, free
@@ -87,17 +108,50 @@ struct GrowBuf {
         mapped = want;
         return true;
     }
-    void release() {
-        (void)hipSetDevice(device);
-        if (plain) { if (base) (void)hipFree(base); }
-        else if (base) {
-            size_t off = 0;
-            for (auto& c : chunks) { (void)hipMemUnmap(base + off, c.second); (void)hipMemRelease(c.first); off += c.second; }
-            (void)hipMemAddressFree(base, reserved);
+    // Host -> device copy into [off, off+bytes).  The runtime's copy wants its destination inside ONE
+    // allocation, so a range that crosses physical chunks goes as one copy per chunk.
+    bool h2d(size_t off, const void* src, size_t bytes, hipStream_t stream) const {
+        if (off + bytes > mapped) return false;
+        const unsigned char* sp = static_cast<const unsigned char*>(src);
+        size_t ci = 0;
+        while (bytes) {
+            size_t end = off + bytes;
+            if (!plain) {
+                while (ci < chunk_end.size() && chunk_end[ci] <= off) ++ci;
+                if (ci < chunk_end.size()) end = std::min(end, chunk_end[ci]);
+            }
+            if (hipMemcpyAsync(base + off, sp, end - off, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+            sp += end - off; bytes -= end - off; off = end;
         }
-        base = nullptr; reserved = mapped = 0; chunks.clear(); plain = false;
+        return true;
     }
+    void release(); // parks the mapping for the next corpus (or frees a fallback allocation)
+    void adopt();   // takes a parked mapping of the same (device, role), if there is one
 };
+
+// parked mappings, per (device, role); they outlive yams_plugin_shutdown (a re-initialised plugin reuses them)
+std::mutex g_park_mu;
+std::map<std::pair<int, int>, std::vector<GrowBuf>> g_parked;
+
+void GrowBuf::release() {
+    if (plain) { (void)hipSetDevice(device); if (base) (void)hipFree(base); }
+    else if (base) {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        g_parked[{device, role}].push_back(*this);
+    }
+    base = nullptr; reserved = mapped = 0; plain = false; chunk_end.clear();
+}
+void GrowBuf::adopt() {
+    if (base) return;
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    auto& v = g_parked[{device, role}];
+    if (v.empty()) return;
+    // the largest mapping first: it needs the fewest new chunks
+    size_t best = 0;
+    for (size_t i = 1; i < v.size(); ++i) if (v[i].mapped > v[best].mapped) best = i;
+    base = v[best].base; reserved = v[best].reserved; mapped = v[best].mapped; chunk_end = std::move(v[best].chunk_end);
+    v.erase(v.begin() + static_cast<std::ptrdiff_t>(best));
+}
 
 // One shard of a corpus: the rows dealt to one device, plus their filter shadows.
 struct ShardStore {
@@ -106,6 +160,17 @@ struct ShardStore {
     GrowBuf rows, bf16, nsq, i8, i8meta, tie, inv;
     bool has_tie = false;
     void release() { rows.release(); bf16.release(); nsq.release(); i8.release(); i8meta.release(); tie.release(); inv.release(); n_rows = 0; has_tie = false; }
+    // virtual range per array if freshly reserved: a fixed share of the device's memory per role
+    static size_t share(size_t dev_total, int role) {
+        switch (role) {
+            case 0: return dev_total;            // rows (fp32)
+            case 1: return dev_total / 2;        // bf16 shadow
+            case 2: return dev_total / 4;        // int8 shadow
+            case 3: return dev_total / 16;       // squared norms
+            case 4: return dev_total / 256;      // int8 block scales
+            default: return dev_total / 16;      // tie ranks, inverse, corpus-wide ranking
+        }
+    }
 };
 
 struct Corpus {
@@ -228,9 +293,10 @@ yams_status_t vs_corpus_create(void*, uint32_t dim, uint64_t* out_id) {
     for (size_t i = 0; i < g.devices.size(); ++i) {
         auto& s = c->sh[i];
         s.device = g.devices[i];
-        for (GrowBuf* b : {&s.rows, &s.bf16, &s.nsq, &s.i8, &s.i8meta, &s.tie, &s.inv}) b->device = s.device;
+        int role = 0;
+        for (GrowBuf* b : {&s.rows, &s.bf16, &s.i8, &s.nsq, &s.i8meta, &s.tie, &s.inv}) { b->device = s.device; b->role = role++; b->adopt(); }
     }
-    c->rank_of_row.device = g.devices[0];
+    c->rank_of_row.device = g.devices[0]; c->rank_of_row.role = 7; c->rank_of_row.adopt();
     std::lock_guard<std::mutex> lk(g.corpora_mu);
     *out_id = g.next_id++;
     g.corpora[*out_id] = c;
@@ -239,6 +305,16 @@ yams_status_t vs_corpus_create(void*, uint32_t dim, uint64_t* out_id) {
 
 // Appends rows: they take the next global ids, are dealt to the devices in stripes, copied to the end of
 // each shard's growing mirror, and the shadows of the touched local ranges are (re)built.
+// measure builds say where an internal error came from
+inline yams_status_t internal_error(const char* where) {
+#ifdef YAMS_ACCEL_MEASURE
+    std::fprintf(stderr, "[yams_mi355x_accel] internal error at %s (hip: %s)\n", where, hipGetErrorString(hipGetLastError()));
+#else
+    (void)where;
+#endif
+    return YAMS_ERR_INTERNAL;
+}
+
 yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n_rows) {
     NEED_INIT();
     auto c = find_corpus(id);
@@ -260,10 +336,9 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         if (now == old) continue;
         (void)hipSetDevice(s.device);
         (void)hipMemGetInfo(&dev_free, &dev_total);
-        const size_t hint_rows = dev_total / (rb + (bf16 ? rb / 2 + 4 : 0) + (i8 ? rb / 4 + 1 : 0) + 8) + 1; // a device full of this corpus
-        if (!s.rows.ensure(now * rb, hint_rows * rb)) return YAMS_ERR_INTERNAL;
-        if (bf16 && (!s.bf16.ensure(now * rb / 2, hint_rows * rb / 2) || !s.nsq.ensure(now * 4, hint_rows * 4))) return YAMS_ERR_INTERNAL;
-        if (i8 && (!s.i8.ensure(now * rb / 4, hint_rows * rb / 4) || !s.i8meta.ensure(((now + 63) / 64) * 8, (hint_rows / 64 + 1) * 8))) return YAMS_ERR_INTERNAL;
+        if (!s.rows.ensure(now * rb, ShardStore::share(dev_total, 0))) return internal_error("append:1");
+        if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) return internal_error("append:2");
+        if (i8 && (!s.i8.ensure(now * rb / 4, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
     }
     // copy: runs of consecutive global rows inside one stripe are consecutive local rows
     for (uint64_t r = n0; r < n1;) {
@@ -271,8 +346,7 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         ShardStore& s = c->sh[shard_of(r, n_sh)];
         yams_accel_ctx* uc = g.upload_ctx[shard_of(r, n_sh)];
         (void)hipSetDevice(s.device);
-        if (hipMemcpyAsync(s.rows.as<float>() + local_of(r, n_sh) * c->dim, rows + (r - n0) * c->dim, run * rb,
-                           hipMemcpyHostToDevice, uc->stream) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
+        if (!s.rows.h2d(local_of(r, n_sh) * rb, rows + (r - n0) * c->dim, run * rb, uc->stream)) return internal_error("append:4");
         r += run;
     }
     for (uint32_t i = 0; i < n_sh; ++i) {
@@ -282,12 +356,12 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         if (now != old) {
             if (bf16 && yams_scan_build_shadow_device(uc, s.rows.as<float>() + old * c->dim, now - old, c->dim,
                                                       s.bf16.as<uint16_t>() + old * c->dim, s.nsq.as<float>() + old) != YAMS_OK)
-                return YAMS_ERR_INTERNAL;
+                return internal_error("append:5");
             if (i8 && yams_scan_build_shadow_i8_device(uc, s.rows.as<float>(), old, now - old, c->dim, s.i8.as<int8_t>(),
                                                        s.i8meta.as<float>(), nullptr) != YAMS_OK)
-                return YAMS_ERR_INTERNAL;
+                return internal_error("append:6");
         }
-        if (yams_accel_ctx_synchronize(uc) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        if (yams_accel_ctx_synchronize(uc) != YAMS_OK) return internal_error("append:7");
         s.n_rows = now;
         s.has_tie = false; // appended rows invalidate a previously supplied chunk_id ranking
     }
@@ -324,14 +398,17 @@ yams_status_t vs_corpus_set_tie_ranks(void*, uint64_t id, const uint32_t* ranks,
         std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return glob[x] < glob[y]; });
         for (uint32_t p = 0; p < nl; ++p) { lrank[order[p]] = p; linv[p] = order[p]; }
-        if (!s.tie.ensure(nl * 4, s.rows.reserved / c->dim + 4) || !s.inv.ensure(nl * 4, s.rows.reserved / c->dim + 4)) return YAMS_ERR_INTERNAL;
-        if (yams_accel_upload(g.upload_ctx[i], s.tie.base, lrank.data(), nl * 4) != YAMS_OK ||
-            yams_accel_upload(g.upload_ctx[i], s.inv.base, linv.data(), nl * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        if (!s.tie.ensure(nl * 4, s.rows.reserved / 16) || !s.inv.ensure(nl * 4, s.rows.reserved / 16)) return YAMS_ERR_INTERNAL;
+        (void)hipSetDevice(s.device);
+        if (!s.tie.h2d(0, lrank.data(), nl * 4, g.upload_ctx[i]->stream) || !s.inv.h2d(0, linv.data(), nl * 4, g.upload_ctx[i]->stream) ||
+            yams_accel_ctx_synchronize(g.upload_ctx[i]) != YAMS_OK) return YAMS_ERR_INTERNAL;
         s.has_tie = true;
     }
     if (n_sh > 1) {
-        if (!c->rank_of_row.ensure(n_rows * 4, n_rows * 8) ||
-            yams_accel_upload(g.upload_ctx[0], c->rank_of_row.base, ranks, n_rows * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
+        (void)hipSetDevice(c->rank_of_row.device);
+        if (!c->rank_of_row.ensure(n_rows * 4, c->sh[0].rows.reserved / 16) ||
+            !c->rank_of_row.h2d(0, ranks, n_rows * 4, g.upload_ctx[0]->stream) ||
+            yams_accel_ctx_synchronize(g.upload_ctx[0]) != YAMS_OK) return YAMS_ERR_INTERNAL;
     }
     c->has_ranks = true;
     return YAMS_OK;
@@ -343,12 +420,14 @@ void release_corpus(Corpus& c) {
     c.n_rows = 0; c.has_ranks = false;
 }
 
+// The rows are gone, the mirror's memory stays mapped for the re-upload that usually follows (compaction).
 yams_status_t vs_corpus_clear(void*, uint64_t id) {
     NEED_INIT();
     auto c = find_corpus(id);
     if (!c) return YAMS_ERR_NOT_FOUND;
     std::unique_lock<std::shared_mutex> lk(c->mu);
-    release_corpus(*c);
+    for (auto& s : c->sh) { s.n_rows = 0; s.has_tie = false; }
+    c->n_rows = 0; c->has_ranks = false;
     return YAMS_OK;
 }
 
@@ -399,8 +478,8 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
         std::memset(&v, 0, sizeof v);
         v.rows = s.rows.as<float>(); v.n_rows = s.n_rows; v.dim = c->dim;
         if (s.has_tie) { v.tie_rank = s.tie.as<uint32_t>(); v.rank_row = s.inv.as<uint32_t>(); }
-        if (s.bf16.base && s.n_rows) { v.rows_bf16 = s.bf16.as<uint16_t>(); v.rows_nsq = s.nsq.as<float>(); }
-        if (s.i8.base && s.n_rows) { v.rows_i8 = s.i8.as<int8_t>(); v.rows_i8_meta = s.i8meta.as<float>(); }
+        if (g.want_bf16 && (c->dim & 3u) == 0 && s.n_rows) { v.rows_bf16 = s.bf16.as<uint16_t>(); v.rows_nsq = s.nsq.as<float>(); }
+        if (g.want_i8 && (c->dim & 63u) == 0 && c->dim >= 256 && s.n_rows) { v.rows_i8 = s.i8.as<int8_t>(); v.rows_i8_meta = s.i8meta.as<float>(); }
         if (n_sh > 1) { v.stripe_rows = kStripeRows; v.n_stripes = n_sh; v.stripe_index = i; }
         if (row_mask_host && s.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175), dealt like the rows
             const size_t words = (s.n_rows + 31) / 32;
