@@ -723,6 +723,17 @@ def test_int8_tier_matches_the_oracle(acc, oracle, n, d, nq, k, thr):
         assert np.array_equal(r.scores.view(np.uint32), other.scores.view(np.uint32))
 
 
+def test_int8_tier_proves_small_dense_shards_without_escalating(acc, oracle):
+    """A 300k-row shard admits ~16 survivors per wave tile (a 12.5M-row one: 0.6): the survivor log is
+    sized from the plan, so the int8 tier proves these queries itself instead of escalating all of them."""
+    n, d, nq, k = 300_000, 256, 300, 50
+    corpus = oracle.synth_rows(61, 0, n, d)
+    queries = oracle.synth_rows(61, 1 << 40, nq, d)
+    diag = check(acc, oracle, corpus, queries, k, shadow="i8", max_queries=6, expect_tier=_lib.TIER_I8).diag
+    assert diag["escalated_queries"] == 0 and diag["exact_fallback_queries"] == 0, diag
+    assert diag["widened_queries"] <= nq // 10, diag
+
+
 def test_int8_tier_on_hostile_rows(acc, oracle):
     """Rows that quantise badly or not at all: zero rows, rows far outside the fp32 comfort zone
     (no usable norm: e_r = inf, always a candidate), a NaN row, one-hot rows (scale = the whole

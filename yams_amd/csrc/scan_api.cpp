@@ -304,9 +304,13 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         L.tau = d_tau; L.tau_out = d_tau; L.list_count = d_lcount; L.list = d_list;
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
         uint32_t* d_qover = nullptr;
-        if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip); 16 entries per (workgroup, wave)
+        if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip), one region per (workgroup, wave)
             const uint64_t regions = static_cast<uint64_t>(i8_filter_grid(L)) * 8u;
-            L.log_cap = 16;
+            // a wave tile is 64 rows x 128 queries; the threshold admits ~tau_rank * stride rows per query.
+            // 4x the expectation + 16 (at 12.5M rows: 0.6 expected, 16 slots; a 300k-row shard: 16 expected, 80).
+            // A region that still overflows marks its queries (q_over) and they take the exhaustive path.
+            const double per_wave = 8192.0 * plan.tau_rank * plan.sample_stride / static_cast<double>(std::max<uint64_t>(1, plan.n_rows));
+            L.log_cap = std::min<uint32_t>(8192, round_up(static_cast<uint32_t>(std::min(8192.0, 4.0 * per_wave)) + 16, 16));
             YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * 8, (void**)&L.log_key));
             YA_TRY(ws_get(ctx, "i8_log_q", static_cast<size_t>(regions) * L.log_cap * 4, (void**)&L.log_q));
             YA_TRY(ws_get(ctx, "i8_log_cnt", static_cast<size_t>(regions) * 4, (void**)&L.log_cnt));
