@@ -89,17 +89,18 @@ meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py
                   "(MI355X_MICROARCH.md, HBM section): hbm_bytes = 2 * FETCH_SIZE * 1024",
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs",
                   "SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16 (64 per "
-                  "v_mfma_f32_32x32x2_f32), summed over 1024 SIMDs"]}
+                  "v_mfma_f32_32x32x2_f32, 16 per v_mfma_i32_16x16x64_i8), summed over 1024 SIMDs"]}
 json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(P, f"{tag}_pmc.json"))
 
-filt = ([k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
+filt = ([k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
         or [k for k in summary if "bf16v2_kernel<1, 0" in k] or [k for k in summary if "scan_tiles_kernel<1, 0>" in k])
 if filt and "FETCH_SIZE" in summary[filt[0]]:
     fs = summary[filt[0]]["FETCH_SIZE"]["mean"]
-    out = {"kernel": filt[0], "rows_per_gpu": 12_500_000, "dim": 768, "queries": 1024, "bf16": "bf16" in filt[0],
-           "passes": 3 if "bf16v2_kernel<1, 0, 3" in filt[0] else (1 if "bf16" in filt[0] else 0),
-           "shadow": "bf16s_kernel" in filt[0] or "bf16p_kernel" in filt[0],
+    is_i8 = "scan_tiles_i8_kernel" in filt[0]
+    out = {"kernel": filt[0], "rows_per_gpu": 12_500_000, "dim": 768, "queries": 1024, "bf16": is_i8 or "bf16" in filt[0],
+           "passes": 3 if "bf16v2_kernel<1, 0, 3" in filt[0] else (1 if (is_i8 or "bf16" in filt[0]) else 0),
+           "shadow": is_i8 or "bf16s_kernel" in filt[0] or "bf16p_kernel" in filt[0], "i8": is_i8,
            "fetch_size_kib": fs, "hbm_bytes_per_launch": 2.0 * fs * 1024.0,
            "correction": "2x (gfx950 FETCH_SIZE halves wide coalesced reads)", "round": tag}
     k2 = summary[filt[0]]
