@@ -446,7 +446,7 @@ def main():
     passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
     i8 = t8 is not None and nq > 128 and passes == 1 and diag.get("filter_tier") == 1
     if i8:
-        kname = "scan_tiles_i8_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, exact integer accumulate)"
+        kname = "scan_tiles_i8h_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, 128 x 256 half tiles, two workgroups per CU, exact integer accumulate)"
         peak = PEAK_I8_MFMA_TOPS
     elif bf16 and passes == 3:
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"

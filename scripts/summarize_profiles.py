@@ -93,11 +93,11 @@ meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py
 json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(P, f"{tag}_pmc.json"))
 
-filt = ([k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
+filt = ([k for k in summary if "scan_tiles_i8h_kernel<1" in k] or [k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
         or [k for k in summary if "bf16v2_kernel<1, 0" in k] or [k for k in summary if "scan_tiles_kernel<1, 0>" in k])
 if filt and "FETCH_SIZE" in summary[filt[0]]:
     fs = summary[filt[0]]["FETCH_SIZE"]["mean"]
-    is_i8 = "scan_tiles_i8_kernel" in filt[0]
+    is_i8 = "scan_tiles_i8" in filt[0]
     out = {"kernel": filt[0], "rows_per_gpu": 12_500_000, "dim": 768, "queries": 1024, "bf16": is_i8 or "bf16" in filt[0],
            "passes": 3 if "bf16v2_kernel<1, 0, 3" in filt[0] else (1 if (is_i8 or "bf16" in filt[0]) else 0),
            "shadow": is_i8 or "bf16s_kernel" in filt[0] or "bf16p_kernel" in filt[0], "i8": is_i8,

@@ -249,7 +249,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38)) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 41 && bf16_version <= 48))) i8 = false;
 #endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
@@ -305,7 +305,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
         uint32_t* d_qover = nullptr;
         if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip), one region per (workgroup, wave)
-            const uint64_t regions = static_cast<uint64_t>(i8_filter_grid(L)) * 8u;
+            const uint64_t regions = i8_log_regions(L);
             // a wave tile is 64 rows x 128 queries; the threshold admits ~tau_rank * stride rows per query.
             // 4x the expectation + 16 (at 12.5M rows: 0.6 expected, 16 slots; a 300k-row shard: 16 expected, 80).
             // A region that still overflows marks its queries (q_over) and they take the exhaustive path.
@@ -334,7 +334,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (i8) YA_HIP(ctx, launch_i8_log_gather(st, L));
 
 #ifdef YAMS_ACCEL_MEASURE
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20) { // ablated kernels produce no candidates: stop here
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30) { // ablated kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;

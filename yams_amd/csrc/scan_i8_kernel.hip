@@ -58,6 +58,10 @@ __device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, floa
     return static_cast<int>(__builtin_amdgcn_fmed3f(t, -1.0737418e9f, 1.0737418e9f));
 }
 
+#ifdef YAMS_ACCEL_MEASURE
+// The first form of this kernel (whole 256 x 256 tiles, eight waves, one workgroup per CU): kept in the
+// measurement build for A/B runs (scripts/filter_ablation.py i8:30); the product launches the half-tile
+// form below.
 // per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
 // MODE_SAMPLE writes dense upper bounds + group maxima (groups of 16 rows: the rows one lane holds
 // for a query block — 4 row blocks x 4 consecutive rows — see collect_sample_kernel, layout 1).
@@ -386,6 +390,349 @@ __global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a
     }
 }
 
+#endif // YAMS_ACCEL_MEASURE
+
+// -------------------------------------------------------------------------------------------------
+// The filter on HALF tiles: 128 rows x 256 queries per workgroup of FOUR waves (wave tile still
+// 64 x 128, 3-stage ring of 24 KiB), two workgroups per CU.  r02 counters of the 8-wave kernel: MFMA
+// pipe 43 % busy, wave slots 17 % empty (one workgroup per CU: nothing runs while it turns over) and
+// both waves of a SIMD meet at the same barrier.  Two independent workgroups per CU overlap one's
+// barrier / epilogue / prologue with the other's k loop.
+// -------------------------------------------------------------------------------------------------
+constexpr int H_ROWS = 128, H_THREADS = 256, H_NST = 3;
+constexpr int H_A_BYTES = H_ROWS * I8_SLAB;        // 8 KiB
+constexpr int H_STAGE = H_A_BYTES + I8_B_BYTES;    // 24 KiB
+
+// per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
+// MODE_SAMPLE writes dense upper bounds + group maxima (groups of 16 rows: the rows one lane holds
+// for a query block — 4 row blocks x 4 consecutive rows — see collect_sample_kernel, layout 1).
+template <int MODE, int ABL = 0>
+__global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
+    __shared__ uint32_t wave_log[4]; // survivors each wave has logged (wave-private slots)
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t w = bid >> 3;
+    const uint32_t qt = w % a.n_qtiles;
+    const uint32_t sel2 = (w / a.n_qtiles) * 8u + xcd; // (selected 256-row tile, which half of it)
+    const uint32_t sel = sel2 >> 1, hf = sel2 & 1u;
+    if (sel >= a.n_sel_tiles) return;
+    uint32_t tile;
+    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
+    else tile = sel + sel / (a.stride - 1u) + 1u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) of this half x queries [128 wc, +128)
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint64_t row0 = static_cast<uint64_t>(tile) * I8_ROWS + hf * H_ROWS; // may lie past the end (ragged last tile)
+    const uint32_t q0 = qt * I8_QUERIES;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
+    if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
+
+    // ---- DMA sources: every wave stages 32 rows (2 pieces of 1 KiB) and 64 queries (4 pieces) per slab ----
+    const uint64_t rowb = row0 < a.n_rows ? row0 : a.n_rows - 1; // loads of rows past the end read the last row
+    uint32_t voffA[2], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ i8_swz(rowA);
+        uint64_t r = row0 + rowA;
+        if (r >= a.n_rows) r = a.n_rows - 1;
+        voffA[i] = static_cast<uint32_t>(r - rowb) * dim + c * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowB = (wid * 4 + i) * 16 + (lane >> 2);
+        voffB[i] = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(rowB)) * 16u;
+    }
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + rowb * dim);
+    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + H_A_BYTES + wid * 4096);
+    // piece p of slab s into ring stage `st` (0..2): p = 0, 1 rows, p = 2..5 queries
+    auto piece = [&](int s, int st, int p) __attribute__((always_inline)) {
+        if ((ABL == 1) && s >= H_NST) return; // measurement build: no refills after the prologue
+        const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
+        if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
+        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
+    };
+
+    i32x4v acc[4][8];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
+
+    // fragment offsets inside a stage: row block rb adds rb * 1 KiB, query block cb adds cb * 1 KiB
+    // (block starts are multiples of 16 rows, so the swizzle term depends on the lane only)
+    const int offA = (wr * 64 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+    const int offB = H_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+
+    // epilogue inputs, requested now (older than every DMA piece, so the counted waits stay valid;
+    // the compiler waits for them at their first use, after the loop): a load issued at the end would
+    // sit on the critical path of every tile — the block scales stream from HBM
+    const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
+    float sb, eb;                       // wave-uniform: scale and residue bound of this wave's 64 rows
+    {
+        const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+        const uint64_t blk = strip / I8_BLOCK_ROWS;
+        const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
+        sb = m.x; eb = m.y;
+    }
+    // The per-query threshold halves {A_lo, B_hi}: loaded from inline asm so that the compiler does
+    // not wait for them with a conservative vmcnt(0) (it cannot see the DMA pieces that follow); they
+    // are older than every piece, so "at most 14 younger operations outstanding" means they landed.
+    typedef float qthr_t __attribute__((ext_vector_type(2)));
+    qthr_t qthr[8];
+    constexpr bool THR = MODE == MODE_FILTER && (ABL == 0 || ABL == 8);
+    if (THR) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const float* p = a.q_thr + 2ull * (q0 + wc * 128 + cb * 16 + l15); // < q_pad: the table is padded
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[cb]) : "v"(p) : "memory");
+        }
+    }
+
+    {   // prologue: slabs 0 and 1 and the first half of slab 2 in flight (nslab >= 4), slab 0 landed
+        for (int s = 0; s < 2; ++s) for (int p = 0; p < 6; ++p) piece(s, s, p);
+        piece(2, 2, 0); piece(2, 2, 1); piece(2, 2, 2);
+        if (THR) {
+            // accumulators start at -T(row block, query block) while the slabs are in flight
+            asm volatile("s_waitcnt vmcnt(15)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                 "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+            const float is = 1.0f / sb, g = eb * is;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int nt = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); // 15 pieces issued, slab 0's six have landed
+        __builtin_amdgcn_s_barrier();
+    }
+    // Fragments: A (4 row blocks) double-buffered across slabs, B in two halves of 4 query blocks.
+    i32x4v fa[2][4], fb[2][4];
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(lds, offA + rb * 1024);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offB + cb * 1024);
+    int stage = 0;
+
+    // One slab = two halves of 16 MFMAs (all four row blocks x four query blocks each).
+    //   half 1: multiplies fa[cur] x fb[0]; requests the other four query blocks of THIS slab (fb[1])
+    //           and issues the second half of slab s+2's DMA pieces (its stage was released by the
+    //           barrier of the previous iteration);
+    //   barrier: slab s+1 has landed, every wave is done reading slab s;
+    //   half 2: multiplies fa[cur] x fb[1]; requests slab s+1's row blocks (fa[nxt]) and first four
+    //           query blocks (fb[0]) and issues the first half of slab s+3's pieces into the stage
+    //           slab s just left.
+    // Two workgroups of four waves share a CU (72 KiB of LDS and 256 VGPRs each): while one sits at
+    // its barrier, in its epilogue or in the prologue of its next tile, the other keeps the MFMA pipe fed.
+    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rb = i >> 2, c = i & 3;
+            if (ABL != 2)
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+            else if (i == 0)
+                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            filler(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // REM = slabs left including this one (4 = four or more): decides which DMA halves are still to be
+    // issued, how many newer pieces may be in flight at the barrier, and whether a next slab exists.
+    // CUR = which of the two row-fragment buffers this slab uses (compile time: a runtime index would
+    // push the fragment arrays into scratch memory).
+    auto body = [&](int s, auto cur_tag, auto rem_tag) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr int REM = decltype(rem_tag)::value;
+        constexpr bool H1 = REM >= 3;                  // slab s+2 exists: issue its second half
+        constexpr bool H2 = REM >= 4;                  // slab s+3 exists: issue its first half
+        constexpr bool MORE = REM >= 2;
+        const int st0 = stage;                                   // slab s (and, after the barrier, slab s+3)
+        const int st1 = stage == 2 ? 0 : stage + 1;              // slab s+1
+        const int st2 = st1 == 2 ? 0 : st1 + 1;                  // slab s+2
+        const unsigned char* base = lds + st0 * H_STAGE;
+        const unsigned char* nbase = lds + st1 * H_STAGE;
+        stage = st1;
+        pin4(fa[CUR]); pin4(fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[0], 0, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[1][i < 4 ? i : 0] = ld(base, offB + (4 + (i < 4 ? i : 0)) * 1024);
+            if (H1 && (i == 5 || i == 9 || i == 13)) piece(s + 2, st2, i == 5 ? 3 : (i == 9 ? 4 : 5));
+        });
+        // slab s+1 is older than slab s+2's six pieces
+        if (H1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[1], 4, [&](int i) __attribute__((always_inline)) {
+            if (MORE && i < 4) fa[CUR ^ 1][i < 4 ? i : 0] = ld(nbase, offA + (i < 4 ? i : 0) * 1024);
+            if (MORE && i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(nbase, offB + ((i - 4) & 3) * 1024);
+            if (H2 && (i == 9 || i == 11 || i == 13)) piece(s + 3, st0, i == 9 ? 0 : (i == 11 ? 1 : 2));
+        });
+    };
+    using R4 = std::integral_constant<int, 4>;
+    using R3 = std::integral_constant<int, 3>;
+    using R2 = std::integral_constant<int, 2>;
+    using R1 = std::integral_constant<int, 1>;
+    // nslab >= 4 (dim >= 256, checked by the host).  The last three slabs have their own bodies; the
+    // nslab - 3 steady-state slabs run two per trip with the buffer parity fixed at compile time.  An
+    // odd count runs one steady body first and then renames the prefetched row fragments into buffer
+    // 0, so that a single code path leads into the pair loop and the tail.
+    const int n_steady = nslab - 3;
+    int s = 0;
+    if (n_steady & 1) {
+        body(0, C0{}, R4{});
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) fa[0][rb] = fa[1][rb];
+        s = 1;
+    }
+    for (; s < n_steady; s += 2) { body(s, C0{}, R4{}); body(s + 1, C1{}, R4{}); }
+    body(s, C0{}, R3{}); body(s + 1, C1{}, R2{}); body(s + 2, C0{}, R1{});
+
+    if (ABL != 0 && ABL != 8) { // measurement builds: keep the accumulators alive, emit nothing
+        int t = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
+        if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        return;
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
+    const uint32_t qb = q0 + wc * 128;
+    if (MODE == MODE_SAMPLE) {
+        const float ninf = -__builtin_inff();
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const uint32_t qi = qb + cb * 16 + l15;
+            const bool qok = qi < a.n_queries;
+            const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
+            float m = ninf;
+            const float S = sb * qm.x, K = fmaf(eb, qm.y, qm.z);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                    v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
+                    m = fmaxf(m, v[r]);
+                }
+                if (qok) {
+                    const uint64_t srow = static_cast<uint64_t>(sel) * I8_ROWS + hf * H_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
+                    *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            if (qok) {
+                const uint32_t gid = (sel * I8_ROWS + hf * H_ROWS + static_cast<uint32_t>(wr * 64)) / 16u + lq;
+                a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
+            }
+        }
+        return;
+    }
+    // FILTER: the accumulators hold I - T, a survivor is a non-negative one
+    uint32_t hot = 0;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        int m = acc[0][cb][0];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
+        if (m >= 0 && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+    }
+    if (hot == 0) return; // ~99 % of the lanes
+    // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
+    // per query block (all of them issued before the first store), then the stores
+    uint32_t pass[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        pass[cb] = 0u;
+        if ((hot >> cb) & 1u) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (acc[rb][cb][r] >= 0 && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
+            }
+        }
+    }
+    if (ABL == 8) { // measurement build: the whole epilogue up to here, but nothing is emitted
+        uint32_t t = 0;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
+        if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        return;
+    }
+    // Survivors go to this wave's region of the log: slots come from an LDS counter (a ~100-cycle round
+    // trip; a returning GLOBAL atomic per query block took microseconds at the end of every tile), the
+    // stores are fire-and-forget.  i8_log_gather_kernel moves the log into the per-query lists.
+    uint32_t mine = 0;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) mine += static_cast<uint32_t>(__builtin_popcount(pass[cb]));
+    uint32_t pos = mine ? atomicAdd(&wave_log[wid], mine) : 0u;
+    const uint64_t region = (static_cast<uint64_t>(bid) * 4u + static_cast<uint32_t>(wid)) * a.log_cap;
+    // An entry is (accumulator, row) + the query: no global load sits between the k loop and the end of
+    // the tile; the gather kernel turns the accumulator back into the score bound u.
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        if (!pass[cb]) continue;
+        const uint32_t qi = qb + cb * 16 + l15;
+        bool lost = false;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
+                const uint64_t row = strip + 16 * rb + 4 * lq + r;
+                if (pos < a.log_cap) {
+                    a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(acc[rb][cb][r])) << 32) | static_cast<uint32_t>(row);
+                    a.log_q[region + pos] = qi;
+                } else {
+                    lost = true;
+                }
+                ++pos;
+            }
+        }
+        if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path (no return value used)
+    }
+    // the wave's total (all hot lanes ran the LDS add in the same instruction): one lane publishes it
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    if (lane == static_cast<int>(__builtin_ctzll(act))) {
+        const uint32_t total = wave_log[wid];
+        a.log_cnt[static_cast<uint64_t>(bid) * 4u + static_cast<uint32_t>(wid)] = total < a.log_cap ? total : a.log_cap;
+    }
+}
+
 // Log -> per-query candidate lists.  One thread per log region.  An entry carries the accumulator
 // I - T of a survivor; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
 // filter kernel derived it (same inputs, same instructions).
@@ -637,12 +984,13 @@ hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q
     return hipGetLastError();
 }
 
-uint32_t i8_filter_grid(const ScanLaunch& L) {
-    return ((L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8;
+// survivor-log regions of the filter launch: one per (workgroup, wave) of the half-tile kernel
+uint64_t i8_log_regions(const ScanLaunch& L) {
+    return static_cast<uint64_t>((2u * L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8u * 4u;
 }
 
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
-    const uint64_t regions = static_cast<uint64_t>(i8_filter_grid(L)) * 8u;
+    const uint64_t regions = i8_log_regions(L);
     if (regions == 0) return hipSuccess;
     hipLaunchKernelGGL(i8_log_gather_kernel, dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
                        L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
@@ -650,18 +998,31 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     return hipGetLastError();
 }
 
-// 256 x 256 tiles, XCD-aware block -> tile map as for the bf16 tier.  version: measurement build only
-// (31 = no DMA refills after the prologue, 32 = no MFMAs, 37 = the whole loop but no epilogue).
+// Half tiles (128 rows x 256 queries), XCD-aware block -> tile map as for the bf16 tier.  version:
+// measurement build only (30 = the 8-wave whole-tile kernel, 31/32/37/38 its ablations; 41 = no DMA
+// refills after the prologue, 42 = no MFMAs, 47 = the whole loop but no epilogue, 48 = no emission).
 hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version) {
     (void)version;
     ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
+#ifdef YAMS_ACCEL_MEASURE
     const uint32_t groups = (a.n_sel_tiles + 7) / 8;
     const uint32_t grid = groups * a.n_qtiles * 8;
-#ifdef YAMS_ACCEL_MEASURE
     if (mode == MODE_FILTER && version == 38) { // the epilogue without its reservations and stores
         hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 8>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+    if (mode == MODE_FILTER && version == 30) { // the 8-wave, whole-tile form (same log layout: 8 regions per tile)
+        hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 0>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+    if (mode == MODE_FILTER && version >= 41 && version <= 48) { // ablations of the half-tile kernel
+        const uint32_t hg = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
+        if (version == 41) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 1>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 42) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 2>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 48) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 8>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hg), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
     if (mode == MODE_FILTER && (version == 31 || version == 32 || version == 37)) {
@@ -671,8 +1032,9 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
 #endif
-    if (mode == MODE_SAMPLE) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_SAMPLE>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER>), dim3(grid), dim3(I8_THREADS), 0, st, a);
+    const uint32_t hgrid = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
+    if (mode == MODE_SAMPLE) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
 }
 

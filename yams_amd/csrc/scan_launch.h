@@ -78,7 +78,7 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
                                   int8_t* out_i8, float* out_meta, double* stats);
 // After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
 // int8 tier: workgroups of the filter launch (the survivor log has 8 regions of log_cap entries per group)
-uint32_t i8_filter_grid(const ScanLaunch& L);
+uint64_t i8_log_regions(const ScanLaunch& L);
 // after the filter pass: log entries -> per-query candidate lists (the returning atomics live here, where
 // thousands of independent threads hide their latency)
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L);
