@@ -458,7 +458,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
     const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + H_A_BYTES + wid * 4096);
     // piece p of slab s into ring stage `st` (0..2): p = 0, 1 rows, p = 2..5 queries
     auto piece = [&](int s, int st, int p) __attribute__((always_inline)) {
-        if ((ABL == 1) && s >= H_NST) return; // measurement build: no refills after the prologue
+        if ((ABL == 1 || ABL == 3) && s >= H_NST) return; // measurement build: no refills after the prologue
         const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
         if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
         else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
@@ -524,7 +524,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
     }
     // Fragments: A (4 row blocks) double-buffered across slabs, B in two halves of 4 query blocks.
     i32x4v fa[2][4], fb[2][4];
-    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v {
+        if (ABL == 4) { i32x4v z = {off, 0, 0, 0}; return z; } // measurement build: no fragment reads
+        return *reinterpret_cast<const i32x4v*>(base + off);
+    };
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(lds, offA + rb * 1024);
 #pragma unroll
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rb = i >> 2, c = i & 3;
-            if (ABL != 2)
+            if (ABL != 2 && ABL != 3 && ABL != 4)
                 acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
             else if (i == 0)
                 asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
@@ -732,6 +735,373 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
         a.log_cnt[static_cast<uint64_t>(bid) * 4u + static_cast<uint32_t>(wid)] = total < a.log_cap ? total : a.log_cap;
     }
 }
+
+#ifdef YAMS_ACCEL_MEASURE
+// -------------------------------------------------------------------------------------------------
+// The PERSISTENT form of the half-tile filter: 2 workgroups per CU stay resident and walk the virtual
+// block ids bid, bid + grid, ...  The 3-stage ring runs straight through the tile boundaries: while
+// the last three slabs of a tile are multiplied, their DMA slots already carry the first slabs of the
+// NEXT tile (and its thresholds and block scale), so a tile no longer starts with an empty ring and
+// a trip to HBM — the only thing between two k loops is the epilogue.
+//   issue order around a boundary (n = next tile):  ... | n0a | n0b | n1a | n1b | thr x8, meta | n2a |
+//   tile start: s_waitcnt vmcnt(3) = everything but n2a has landed, barrier, first fragments.
+// MEASUREMENT BUILD ONLY (scripts/filter_ablation.py i8:50): on MI355X it runs the 12.5M x 768 x 1024 launch in
+// 8.87 ms against 8.90 ms for the plain half-tile kernel — with two workgroups per CU the other workgroup
+// already covers a tile's start, so the product keeps the simpler kernel.
+// Stores of the epilogue also count in vmcnt; they only make the counted waits conservative (a count
+// of N leaves at most N LOADS outstanding, and loads complete in order).
+// -------------------------------------------------------------------------------------------------
+template <int MODE, int ABL = 0>
+__global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8p_kernel(ScanArgs a, uint32_t n_virtual) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
+    __shared__ uint32_t wave_log[4]; // survivors each wave has logged in the current tile (wave-private slots)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) of the half tile x queries [128 wc, +128)
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
+    if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
+
+    // ---- where a virtual block lives ----------------------------------------------------------------
+    struct Geo {
+        uint32_t vb, sel, hf, q0;
+        uint64_t row0;
+        const unsigned char* baseA;
+        const unsigned char* baseB;
+        uint32_t voffA[2];
+        bool valid;
+    };
+    auto locate = [&](uint32_t vb, Geo& g, const Geo& fallback) __attribute__((always_inline)) {
+        const uint32_t xcd = vb & 7u, w = vb >> 3;
+        const uint32_t qt = w % a.n_qtiles;
+        const uint32_t sel2 = (w / a.n_qtiles) * 8u + xcd; // (selected 256-row tile, which half of it)
+        const uint32_t sel = sel2 >> 1;
+        if (vb >= n_virtual || sel >= a.n_sel_tiles) { g = fallback; g.valid = false; return; } // (its DMA slots re-read the fallback tile)
+        g.vb = vb; g.sel = sel; g.hf = sel2 & 1u; g.q0 = qt * I8_QUERIES; g.valid = true;
+        const uint32_t tile = MODE == MODE_SAMPLE ? sel * a.stride : sel + sel / (a.stride - 1u) + 1u;
+        g.row0 = static_cast<uint64_t>(tile) * I8_ROWS + g.hf * H_ROWS; // may lie past the end (ragged last tile)
+        const uint64_t rowb = g.row0 < a.n_rows ? g.row0 : a.n_rows - 1; // loads of rows past the end read the last row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ i8_swz(rowA);
+            uint64_t r = g.row0 + rowA;
+            if (r >= a.n_rows) r = a.n_rows - 1;
+            g.voffA[i] = static_cast<uint32_t>(r - rowb) * dim + c * 16u;
+        }
+        g.baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + rowb * dim);
+        g.baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(g.q0) * 64;
+    };
+
+    // ---- DMA: every wave stages 32 rows (2 pieces of 1 KiB) and 64 queries (4 pieces) per slab --------
+    uint32_t voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowB = (wid * 4 + i) * 16 + (lane >> 2);
+        voffB[i] = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(rowB)) * 16u;
+    }
+    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
+    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + H_A_BYTES + wid * 4096);
+    // piece p of slab s of tile g into ring stage `st` (0..2): p = 0, 1 rows, p = 2..5 queries
+    auto piece = [&](const Geo& g, int s, int st, int p) __attribute__((always_inline)) {
+        const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
+        if (p < 2) lds_dma16_s(g.baseA + s * I8_SLAB, g.voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
+        else lds_dma16_s(g.baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
+    };
+    // the thresholds {A_lo, B_hi} of this lane's eight queries and the block scale {s_b, e_b} of the wave's
+    // 64 rows: loaded from inline asm (the compiler would wait for them with a vmcnt(0) that drains the ring)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t qthr[8], meta;
+    constexpr bool THR = MODE == MODE_FILTER && (ABL == 0 || ABL == 8);
+    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    auto thr_load = [&](const Geo& g, int i) __attribute__((always_inline)) {
+        if (i < 8) {
+            if (!THR) return;
+            const float* p = a.q_thr + 2ull * (g.q0 + wc * 128 + i * 16 + l15); // < q_pad: the table is padded
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[i < 8 ? i : 0]) : "v"(p) : "memory");
+        } else {
+            uint64_t blk = (g.row0 + static_cast<uint32_t>(wr * 64)) / I8_BLOCK_ROWS;
+            if (blk >= n_blocks) blk = n_blocks - 1; // a strip past the end: nothing of it is ever emitted
+            const float* p = a.rows_i8_meta + 2ull * blk;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(meta) : "v"(p) : "memory");
+        }
+    };
+
+    // fragment offsets inside a stage: row block rb adds rb * 1 KiB, query block cb adds cb * 1 KiB
+    // (block starts are multiples of 16 rows, so the swizzle term depends on the lane only)
+    const int offA = (wr * 64 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+    const int offB = H_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
+
+    i32x4v acc[4][8];
+    i32x4v fa[2][4], fb[2][4];
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
+    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rb = i >> 2, c = i & 3;
+            if (ABL != 2)
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+            else if (i == 0)
+                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            filler(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using R4 = std::integral_constant<int, 4>;
+    using R3 = std::integral_constant<int, 3>;
+    using R2 = std::integral_constant<int, 2>;
+    using R1 = std::integral_constant<int, 1>;
+
+    Geo cur, nxt;
+    locate(blockIdx.x, cur, cur);
+    if (!cur.valid) return; // (grid <= n_virtual; a padded id can only be a workgroup's first)
+    int stage = 0;
+    {   // first tile: thresholds, block scale, slabs 0 and 1 and the first half of slab 2
+        for (int i = 0; i < 9; ++i) thr_load(cur, i);
+        for (int s = 0; s < 2; ++s) for (int p = 0; p < 6; ++p) piece(cur, s, s, p);
+        piece(cur, 2, 2, 0); piece(cur, 2, 2, 1); piece(cur, 2, 2, 2);
+    }
+
+    // One slab = two halves of 16 MFMAs (all four row blocks x four query blocks each).
+    //   half 1: multiplies fa[cur] x fb[0]; requests the other four query blocks of THIS slab (fb[1])
+    //           and issues the second half of the DMA pieces of the slab two ahead (its stage was
+    //           released by the barrier of the previous slab);
+    //   barrier: the next slab has landed (it is older than the six pieces of the one after it),
+    //           every wave is done reading this one;
+    //   half 2: multiplies fa[cur] x fb[1]; requests the next slab's row blocks (fa[nxt]) and first four
+    //           query blocks (fb[0]) and issues the first half of the pieces of the slab three ahead
+    //           into the stage this slab just left.
+    // REM = slabs of this tile left including this one (4 = four or more).  "Two / three ahead" run on
+    // into the next tile: REM 3 issues n0a in half 2, REM 2 n0b | n1a, REM 1 n1b | thresholds, scale, n2a.
+    // CUR = which of the two row-fragment buffers this slab uses (compile time: a runtime index would
+    // push the fragment arrays into scratch memory).
+    auto body = [&](int s, auto cur_tag, auto rem_tag) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr int REM = decltype(rem_tag)::value;
+        constexpr bool MORE = REM >= 2;
+        const int st0 = stage;                                   // this slab (and, after the barrier, the slab three ahead)
+        const int st1 = stage == 2 ? 0 : stage + 1;              // the next slab
+        const int st2 = st1 == 2 ? 0 : st1 + 1;                  // two ahead
+        const unsigned char* base = lds + st0 * H_STAGE;
+        const unsigned char* nbase = lds + st1 * H_STAGE;
+        stage = st1;
+        pin4(fa[CUR]); pin4(fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[0], 0, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[1][i < 4 ? i : 0] = ld(base, offB + (4 + (i < 4 ? i : 0)) * 1024);
+            if (i == 5 || i == 9 || i == 13) {
+                const int p = i == 5 ? 3 : (i == 9 ? 4 : 5);
+                if (REM >= 3) piece(cur, s + 2, st2, p); else piece(nxt, 2 - REM, st2, p);
+            }
+        });
+        if (MORE) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[CUR], fb[1], 4, [&](int i) __attribute__((always_inline)) {
+            if (MORE && i < 4) fa[CUR ^ 1][i < 4 ? i : 0] = ld(nbase, offA + (i < 4 ? i : 0) * 1024);
+            if (MORE && i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(nbase, offB + ((i - 4) & 3) * 1024);
+            if (!MORE && i < 9) thr_load(nxt, i);
+            if (i == 9 || i == 11 || i == 13) {
+                const int p = i == 9 ? 0 : (i == 11 ? 1 : 2);
+                if (REM >= 4) piece(cur, s + 3, st0, p); else piece(nxt, 3 - REM, st0, p);
+            }
+        });
+    };
+
+    for (;;) {
+        // ---- tile start: everything but the three youngest pieces has landed ---------------------------
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                            "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]), "+v"(meta) :: "memory");
+        const uint64_t strip = cur.row0 + static_cast<uint32_t>(wr * 64);
+        const bool strip_ok = strip / I8_BLOCK_ROWS < n_blocks;
+        const float sb = strip_ok ? meta[0] : 1.0f, eb = strip_ok ? meta[1] : 0.0f; // wave-uniform
+        if (THR) {
+            // accumulators start at -T(row block, query block)
+            const float is = 1.0f / sb, g = eb * is;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int nt = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
+        }
+        __builtin_amdgcn_s_barrier();
+        {
+            const unsigned char* base = lds + stage * H_STAGE;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(base, offA + rb * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(base, offB + cb * 1024);
+        }
+        locate(cur.vb + gridDim.x, nxt, cur);
+
+        // nslab >= 4 (dim >= 256, checked by the host).  The last three slabs have their own bodies; the
+        // nslab - 3 before them run two per trip with the buffer parity fixed at compile time.  An odd
+        // count runs one body first and then renames the prefetched row fragments into buffer 0, so that
+        // a single code path leads into the pair loop and the tail.
+        const int n_steady = nslab - 3;
+        int s = 0;
+        if (n_steady & 1) {
+            body(0, C0{}, R4{});
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) fa[0][rb] = fa[1][rb];
+            s = 1;
+        }
+        for (; s < n_steady; s += 2) { body(s, C0{}, R4{}); body(s + 1, C1{}, R4{}); }
+        body(s, C0{}, R3{}); body(s + 1, C1{}, R2{}); body(s + 2, C0{}, R1{});
+
+        // ---- epilogue ------------------------------------------------------------------------------
+        // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
+        [&]() __attribute__((always_inline)) {
+            if (ABL != 0 && ABL != 8) { // measurement builds: keep the accumulators alive, emit nothing
+                int t = 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
+                if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+                return;
+            }
+            const uint32_t qb = cur.q0 + wc * 128;
+            if (MODE == MODE_SAMPLE) {
+                const float ninf = -__builtin_inff();
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const uint32_t qi = qb + cb * 16 + l15;
+                    const bool qok = qi < a.n_queries;
+                    const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
+                    float m = ninf;
+                    const float S = sb * qm.x, K = fmaf(eb, qm.y, qm.z);
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                        const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                            v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
+                            m = fmaxf(m, v[r]);
+                        }
+                        if (qok) {
+                            const uint64_t srow = static_cast<uint64_t>(cur.sel) * I8_ROWS + cur.hf * H_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
+                            *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    if (qok) {
+                        const uint32_t gid = (cur.sel * I8_ROWS + cur.hf * H_ROWS + static_cast<uint32_t>(wr * 64)) / 16u + lq;
+                        a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
+                    }
+                }
+                return;
+            }
+            // FILTER: the accumulators hold I - T, a survivor is a non-negative one
+            uint32_t hot = 0;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                int m = acc[0][cb][0];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
+                if (m >= 0 && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+            }
+            if (hot == 0) return; // ~99 % of the lanes
+            // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
+            // for all of them, then the stores
+            uint32_t pass[8];
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                pass[cb] = 0u;
+                if ((hot >> cb) & 1u) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const uint64_t rbase = strip + 16 * rb + 4 * lq;
+                        const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (acc[rb][cb][r] >= 0 && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
+                    }
+                }
+            }
+            if (ABL == 8) { // measurement build: the whole epilogue up to here, but nothing is emitted
+                uint32_t t = 0;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
+                if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+                return;
+            }
+            // Survivors go to this wave's region of the log: slots come from an LDS counter (a ~100-cycle round
+            // trip), the stores are fire-and-forget.  i8_log_gather_kernel moves the log into the per-query lists.
+            uint32_t mine = 0;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) mine += static_cast<uint32_t>(__builtin_popcount(pass[cb]));
+            uint32_t pos = mine ? atomicAdd(&wave_log[wid], mine) : 0u;
+            const uint64_t rix = static_cast<uint64_t>(cur.vb) * 4u + static_cast<uint32_t>(wid);
+            const uint64_t region = rix * a.log_cap;
+            // An entry is (accumulator, row) + the query; the gather kernel turns the accumulator back into the
+            // score bound u.
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                if (!pass[cb]) continue;
+                const uint32_t qi = qb + cb * 16 + l15;
+                bool lost = false;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
+                        const uint64_t row = strip + 16 * rb + 4 * lq + r;
+                        if (pos < a.log_cap) {
+                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(acc[rb][cb][r])) << 32) | static_cast<uint32_t>(row);
+                            a.log_q[region + pos] = qi;
+                        } else {
+                            lost = true;
+                        }
+                        ++pos;
+                    }
+                }
+                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+            }
+            // the wave's total (all hot lanes ran the LDS add in the same instruction): one lane publishes it
+            // and clears the counter for the next tile
+            const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+            if (lane == static_cast<int>(__builtin_ctzll(act))) {
+                const uint32_t total = wave_log[wid];
+                a.log_cnt[rix] = total < a.log_cap ? total : a.log_cap;
+                wave_log[wid] = 0u;
+            }
+        }();
+        if (!nxt.valid) break;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
+}
+
+#endif // YAMS_ACCEL_MEASURE
 
 // Log -> per-query candidate lists.  One thread per log region.  An entry carries the accumulator
 // I - T of a survivor; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
@@ -1021,6 +1391,8 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         const uint32_t hg = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
         if (version == 41) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 1>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else if (version == 42) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 2>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 43) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 3>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 44) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 4>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else if (version == 48) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 8>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hg), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
@@ -1033,6 +1405,16 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     }
 #endif
     const uint32_t hgrid = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
+#ifdef YAMS_ACCEL_MEASURE
+    if (mode == MODE_FILTER && version >= 50 && version <= 58) { // the persistent form and its ablations
+        const uint32_t pg = hgrid < 512u ? hgrid : 512u;
+        if (version == 50) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 0>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
+        else if (version == 52) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 2>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
+        else if (version == 58) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 8>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
+        else hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 7>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
+        return hipGetLastError();
+    }
+#endif
     if (mode == MODE_SAMPLE) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
