@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
     ap.add_argument("--no-shadow", action="store_true", help="bare fp32 corpus view: the single-pass filter converts rows in its loop")
+    ap.add_argument("--lanes", type=int, default=2, help="search lanes: batches in flight, each on its own context / stream / host thread")
     ap.add_argument("--no-i8", action="store_true", help="no int8 shadow: the bf16 tier filters the large batches too")
     ap.add_argument("--split-filter", action="store_true", help="start with the split-bf16 (3-pass) filter instead of the single-pass bf16 one")
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
@@ -303,7 +304,8 @@ def main():
     acc.synchronize()
 
     # the step after the scan: all-gather + merge, two batches in flight (yams_amd/dist.py)
-    pipe = ydist.GatherPipeline(nq, k, dev, depth=2)
+    lanes = max(1, a.lanes)
+    pipe = ydist.GatherPipeline(nq, k, dev, depth=lanes)
     if world > 1:
         acc_merge = Accel(local, pipe.side_stream_ptr())        # merge kernel on the side stream
 
@@ -314,19 +316,70 @@ def main():
         pipe.merge_fn = merge_fn
 
     scan_flags = 4 if a.f32_filter else (8 if a.split_filter else 0)   # YAMS_SCAN_FLAG_F32_FILTER / _SPLIT_FILTER
+    # Search lanes: every lane is its own context (stream + workspace) driven by its own host thread, as the
+    # plugin serves concurrent search calls from its pool of contexts (plugin.cpp, "search_slots").  While
+    # one lane's batch is in its serial tail (candidate selection, fp64 re-score, the host's look at the
+    # proof words) the other lane's filter sweep has the GPU.  Batch i runs on lane i % lanes and owns
+    # pipeline slot i % lanes; the collectives are issued in batch order on every rank (a turnstile).
+    import threading
+    lane_streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+    accs = [acc] + [Accel(local, st.cuda_stream) for st in lane_streams[1:]]
+    gate = None
+    if lanes > 1 and dev.type == "cuda":
+        from yams_amd.accel import SweepGate
+        gate = SweepGate(local)         # the lanes' filter sweeps run one after the other, the rest overlaps
+        for c in accs:
+            c.set_gate(gate)
+    turn = [0]
+    turn_cv = threading.Condition()
     batch_no = [0]
 
-    def step(want_diag=False):
-        slot = batch_no[0] % pipe.depth
-        batch_no[0] += 1
-        pipe.wait(slot)                 # the merge of batch i-2 has long finished: its record is free
+    def step(i, want_diag=False):
+        lane = slot = i % lanes
+        pipe.wait(slot)                 # the merge of batch i - lanes has long finished: its record is free
         loc = pipe.local(slot)
         # (the call returns after its own host sync on the query status words: results are complete)
-        diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
-                                    loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
-                                    want_diag=want_diag)
-        pipe.launch(slot)               # collective + merge on the side stream, under the next sweep
+        diag = accs[lane].scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
+                                           loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
+                                           want_diag=want_diag)
+        with turn_cv:
+            while turn[0] != i:
+                turn_cv.wait()
+            pipe.launch(slot)           # collective + merge on the side stream, under the next sweeps
+            turn[0] += 1
+            turn_cv.notify_all()
         return diag, slot
+
+    def run_steps(count):
+        """`count` batches, `lanes` at a time; returns the slot of the last one."""
+        first = batch_no[0]
+        batch_no[0] += count
+        errs = []
+
+        def lane_fn(lane):
+            try:
+                if dev.type == "cuda":
+                    torch.cuda.set_device(dev)
+                for i in range(first, first + count):
+                    if i % lanes == lane:
+                        step(i)
+            except BaseException as e:       # noqa: BLE001 - re-raised on the main thread
+                errs.append(e)
+                with turn_cv:
+                    turn[0] = 1 << 60
+                    turn_cv.notify_all()
+        if lanes == 1 or count == 1:
+            for i in range(first, first + count):
+                step(i)
+        else:
+            th = [threading.Thread(target=lane_fn, args=(l,)) for l in range(lanes)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+        return (first + count - 1) % lanes
 
     def fence():
         pipe.drain()
@@ -334,22 +387,29 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    if a.warmup:
+        run_steps(a.warmup)
     fence()
-    acc.enable_timing(True)
+    for c in accs:
+        c.enable_timing(True)
     fence(); t0 = time.perf_counter()
-    last_slot = 0
-    for _ in range(a.steps):
-        _, last_slot = step()
+    last_slot = run_steps(a.steps)
     fence(); dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    filt_ms, filt_n = acc.kernel_ms("scan_filter")
-    samp_ms, samp_n = acc.kernel_ms("scan_sample")
-    acc.enable_timing(False)
+    def lane_kernel_ms(name):
+        tot, cnt = 0.0, 0
+        for c in accs:
+            ms, n_ = c.kernel_ms(name)
+            if ms is not None and n_:
+                tot += ms * n_; cnt += n_
+        return (tot / cnt if cnt else None), cnt
+    filt_ms, filt_n = lane_kernel_ms("scan_filter")
+    samp_ms, samp_n = lane_kernel_ms("scan_sample")
+    for c in accs:
+        c.enable_timing(False)
     res = pipe.result(last_slot)          # the merged top-k of the LAST TIMED step
     r_timed = res["rows"].cpu().numpy().copy()
     s_timed = res["scores"].cpu().numpy().copy()
@@ -392,7 +452,8 @@ def main():
                      "oracle_threads_per_rank": stats.get("threads"), "oracle_scan_thread_seconds": stats.get("scan_thread_s")}
 
     # diagnostics of the same batch, outside the timed region (every step scans the same inputs)
-    diag, _ = step(want_diag=True)
+    diag, _ = step(batch_no[0], want_diag=True)
+    batch_no[0] += 1
     fence()
     fallbacks = diag["exact_fallback_queries"] * a.steps
     ms_per_step = dt / a.steps * 1e3
@@ -500,7 +561,8 @@ def main():
            "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: "
                                   f"100Mx768 over 8 GPUs), query batch {nq}",
                       "rows_per_gpu": n, "corpus_rows": total_rows, "dim": d, "k": k, "query_batch": nq,
-                      "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge (overlapped with the next sweep)" if world > 1 else "single shard"},
+                      "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge (overlapped with the next sweep)" if world > 1 else "single shard",
+                      "search_lanes": lanes},
            "value_definition": "queries/s against the 100M x 768 headline corpus = (rows scored x queries)/s / 1e8; "
                                "equals qps_on_resident_corpus x corpus_rows / 1e8 (identical at N = 8)",
            "qps_on_resident_corpus": qps_resident,

@@ -80,6 +80,17 @@ YAMS_ACCEL_API yams_status_t yams_accel_ctx_create(int device, void* hip_stream,
                                                    yams_accel_ctx** out_ctx);
 YAMS_ACCEL_API void yams_accel_ctx_destroy(yams_accel_ctx* ctx);
 YAMS_ACCEL_API yams_status_t yams_accel_ctx_synchronize(yams_accel_ctx* ctx);
+/* Sweep gate: contexts of ONE device that serve concurrent search calls share a gate, and their big filter
+ * sweeps then run one after the other on the GPU (stream-ordered: the host never waits) while everything
+ * around them — query preparation, candidate selection, the fp64 re-score — overlaps the other context's
+ * sweep.  Without a gate two concurrent sweeps interleave workgroup by workgroup and evict each other's
+ * tiles from L2.  The plugin's pool of search contexts shares one gate per device (plugin.cpp); the
+ * reference serves concurrent searches under a shared lock (vector_database.cpp:539,618).
+ * A gate must outlive the contexts attached to it; attach with NULL to detach. */
+typedef struct yams_accel_gate yams_accel_gate;
+YAMS_ACCEL_API yams_status_t yams_accel_gate_create(int device, yams_accel_gate** out_gate);
+YAMS_ACCEL_API void yams_accel_gate_destroy(yams_accel_gate* gate);
+YAMS_ACCEL_API yams_status_t yams_accel_ctx_set_gate(yams_accel_ctx* ctx, yams_accel_gate* gate);
 /* Human-readable description of the last failure on this context (static storage, never NULL). */
 YAMS_ACCEL_API const char* yams_accel_last_error(const yams_accel_ctx* ctx);
 /* Device properties as a JSON string (malloc'd; release with yams_accel_free_string). */

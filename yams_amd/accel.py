@@ -176,6 +176,24 @@ class ShardedScan:
         return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
 
 
+class SweepGate:
+    """Shared by the contexts of one device that search concurrently: their filter sweeps run one after the
+    other on the GPU, everything around them overlaps (yams_accel_gate_create in the header)."""
+
+    def __init__(self, device: int = 0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        st = self.L.yams_accel_gate_create(device, C.byref(h))
+        if st != 0:
+            raise AccelError(st, "yams_accel_gate_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.yams_accel_gate_destroy(self.h)
+        self.h = None
+
+
 class Accel:
     def __init__(self, device: int = 0, stream: int | None = None):
         self.L = _lib.load()
@@ -204,6 +222,11 @@ class Accel:
     def _check(self, st: int):
         if st != 0:
             raise AccelError(st, self.L.yams_accel_last_error(self.ctx).decode())
+
+    def set_gate(self, gate: "SweepGate | None"):
+        """Attach this context to a sweep gate (None detaches).  The gate must outlive the context."""
+        self._check(self.L.yams_accel_ctx_set_gate(self.ctx, gate.h if gate is not None else None))
+        self._gate = gate
 
     # ---- misc ---------------------------------------------------------------------------------
     def device_info(self) -> dict:

@@ -148,6 +148,33 @@ void yams_accel_ctx_destroy(yams_accel_ctx* ctx) {
     delete ctx;
 }
 
+yams_status_t yams_accel_gate_create(int device, yams_accel_gate** out_gate) {
+    if (!out_gate) return YAMS_ERR_INVALID_ARG;
+    *out_gate = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return YAMS_ERR_UNSUPPORTED; }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return YAMS_ERR_INTERNAL; }
+    auto* g = new yams_accel_gate();
+    g->device = device;
+    if (hipEventCreateWithFlags(&g->last, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); delete g; return YAMS_ERR_INTERNAL; }
+    *out_gate = g;
+    return YAMS_OK;
+}
+
+void yams_accel_gate_destroy(yams_accel_gate* gate) {
+    if (!gate) return;
+    (void)hipSetDevice(gate->device);
+    if (gate->last) (void)hipEventDestroy(gate->last);
+    delete gate;
+}
+
+yams_status_t yams_accel_ctx_set_gate(yams_accel_ctx* ctx, yams_accel_gate* gate) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (gate && gate->device != ctx->device) return yams_accel::fail(ctx, YAMS_ERR_INVALID_ARG, "gate and context are on different devices");
+    ctx->gate = gate;
+    return YAMS_OK;
+}
+
 yams_status_t yams_accel_ctx_synchronize(yams_accel_ctx* ctx) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));

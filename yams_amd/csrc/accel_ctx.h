@@ -4,13 +4,23 @@
 
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/yams_mi355x_accel.h"
 
+// Orders the filter sweeps of the contexts that share it (see yams_accel_gate_create).
+struct yams_accel_gate {
+    int device = 0;
+    std::mutex mu;
+    hipEvent_t last = nullptr; // end of the most recently enqueued sweep
+    bool armed = false;
+};
+
 struct yams_accel_ctx {
     int device = 0;
+    yams_accel_gate* gate = nullptr;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;   // high-priority side stream (whole-blob digest chains)
@@ -45,6 +55,24 @@ yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what);
 // Workspace: returns a device pointer of at least `bytes` (contents undefined).
 yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out);
 yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
+
+// Brackets a filter sweep: the stream waits for the previous sweep of the gate, the sweep's end becomes the
+// gate's new tail.  The gate's mutex is held from enter() to leave() (launches only, no host waits).
+struct GatedSweep {
+    yams_accel_ctx* ctx; hipStream_t st; bool held = false;
+    GatedSweep(yams_accel_ctx* c, hipStream_t s) : ctx(c), st(s) {
+        if (!ctx->gate) return;
+        ctx->gate->mu.lock(); held = true;
+        if (ctx->gate->armed) (void)hipStreamWaitEvent(st, ctx->gate->last, 0);
+    }
+    void leave() {
+        if (!held) return;
+        (void)hipEventRecord(ctx->gate->last, st);
+        ctx->gate->armed = true;
+        ctx->gate->mu.unlock(); held = false;
+    }
+    ~GatedSweep() { leave(); }
+};
 
 struct TimedRegion { // RAII-less helper: begin/end record events when timing is enabled
     yams_accel_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;

@@ -217,6 +217,7 @@ struct PluginState {
     bool want_bf16 = true, want_i8 = true;
     std::string init_error;
     Pool<yams_scan_sharded*> search_slots;   // concurrent searches: one sharded handle (a context per device) each
+    std::map<int, yams_accel_gate*> gates;   // one per device: the search contexts' filter sweeps run one after the other
     Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
     std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
     std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
@@ -846,6 +847,8 @@ void teardown_locked() { // g.mu held exclusively
         g_dedup.clear();
     }
     for (auto* s : g.search_slots.drain()) yams_scan_sharded_destroy(s);
+    for (auto& kv : g.gates) yams_accel_gate_destroy(kv.second);
+    g.gates.clear();
     for (auto* c : g.work_ctx.drain()) yams_accel_ctx_destroy(c);
     for (auto* c : g.upload_ctx) yams_accel_ctx_destroy(c);
     g.upload_ctx.clear();
@@ -898,6 +901,11 @@ int yams_plugin_init(const char* config_json, const void* host_context) {
         if (yams_scan_sharded_create(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &sh) != YAMS_OK)
             return failed("search slot creation failed");
         g.search_slots.add(sh);
+        for (uint32_t d = 0; d < g.devices.size(); ++d) {
+            yams_accel_gate*& gate = g.gates[g.devices[d]];
+            if (!gate && yams_accel_gate_create(g.devices[d], &gate) != YAMS_OK) return failed("sweep gate creation failed");
+            (void)yams_accel_ctx_set_gate(yams_scan_sharded_ctx(sh, d), gate);
+        }
     }
     for (long i = 0; i < std::max<long>(2, slots); ++i) {
         yams_accel_ctx* c = nullptr;

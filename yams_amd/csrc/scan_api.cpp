@@ -327,10 +327,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
         YA_HIP(ctx, launch_collect_sample(st, L));
-        { TimedRegion tr(ctx, "scan_filter");
+        { GatedSweep gs(ctx, st); // sweeps of contexts that share a gate run one after the other
+          TimedRegion tr(ctx, "scan_filter");
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 1, passes, bf16_version)); else YA_HIP(ctx, launch_scan_filter(st, L, metric));
-          tr.end(); }
+          tr.end();
+          gs.leave(); }
         if (i8) YA_HIP(ctx, launch_i8_log_gather(st, L));
 
 #ifdef YAMS_ACCEL_MEASURE
