@@ -184,6 +184,11 @@ typedef struct yams_scan_corpus_s {
                                              queries (default: the narrow, HBM-bound kernel form);
                                              results are identical, only the kernel form differs  */
 #define YAMS_SCAN_FLAG_NO_I8_FILTER 64u   /* do not use the int8 shadow even when the view carries one */
+#define YAMS_SCAN_FLAG_RESIDENT_QUERIES 128u /* int8 tier: take the resident-query kernel form whenever its
+                                             preconditions hold (dim % 128 == 0, dim <= 768), also on shards
+                                             too small for it to balance (default: the library chooses);
+                                             with YAMS_SCAN_FLAG_WIDE_TILE: never take it.  Results are
+                                             identical, only the kernel form differs              */
 #define YAMS_SCAN_MAX_K 1024u
 
 typedef struct yams_scan_params_s {

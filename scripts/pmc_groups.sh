@@ -9,7 +9,10 @@ GROUPS_=(
  "TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP_PENDING_STALL_CYCLES TA_TA_BUSY GRBM_GUI_ACTIVE"
  "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"
  "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+ "FETCH_SIZE GRBM_GUI_ACTIVE"
+ "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
 )
+if [ -n "$PMC_ONLY" ]; then GROUPS_=("${GROUPS_[$PMC_ONLY]}"); fi
 i=0
 for g in "${GROUPS_[@]}"; do
   rm -rf $OUT/pmcg$i
@@ -30,7 +33,7 @@ for G in sorted(glob.glob(os.path.join(R,"pmcg[0-9]"))):
     except Exception as e:
         print(G, "failed", e); continue
     for d,(n,ns) in dur.items():
-        if "scan_tiles_i8" in n and "<1" in n:
+        if ("scan_tiles_i8" in n and "<1" in n) or "scan_tiles_i8r" in n:
             v=vals.get(d,{})
             cyc=v.get("GRBM_GUI_ACTIVE",0)/8.0
             print(os.path.basename(G), n[17:50], "ms=%.2f cyc=%.3g"%(ns/1e6,cyc), {k: "%.4g (%.3f/cyc)"%(x, x/cyc if cyc else 0) for k,x in v.items() if k!="GRBM_GUI_ACTIVE"})

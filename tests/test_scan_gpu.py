@@ -723,6 +723,36 @@ def test_int8_tier_matches_the_oracle(acc, oracle, n, d, nq, k, thr):
         assert np.array_equal(r.scores.view(np.uint32), other.scores.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,nq,k,thr", [
+    (20000, 256, 1, 10, -1.0), (50000, 256, 130, 100, -1.0), (70001, 256, 300, 50, 0.02),
+    (33333, 768, 40, 100, 0.05), (150001, 384, 260, 100, -1.0), (40449, 512, 700, 30, -1.0),
+    (4500, 640, 129, 20, -1.0), (90000, 768, 1024, 100, -1.0), (25000, 768, 2100, 10, -1.0),
+])
+def test_int8_resident_query_form_matches_the_oracle_and_the_half_tile_form(acc, oracle, n, d, nq, k, thr):
+    """The resident-query form of the int8 filter (scan_tiles_i8r_kernel: a 128-query tile stays in LDS,
+    persistent workgroups stream 512-row units past it, wave-private row rings) forced on shards far
+    smaller than the ones the library picks it for: ragged last units, odd tile counts, streams without
+    work, one to seventeen query tiles, thresholds, an allow-mask — bit-identical to the oracle and to the
+    half-tile form (YAMS_SCAN_FLAG_WIDE_TILE keeps the per-tile kernels)."""
+    corpus = oracle.synth_rows(35, 0, n, d)
+    q = oracle.synth_rows(35, 1 << 40, nq, d)
+    r = check(acc, oracle, corpus, q, k, thr=thr, max_queries=8, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8,
+              flags=_lib.FLAG_RESIDENT_QUERIES)
+    assert r.diag["exact_fallback_queries"] == 0
+    h = run(acc, corpus, q, k, thr, flags=FLAG_WIDE_TILE, shadow="i8")
+    assert h.diag["filter_tier"] == _lib.TIER_I8
+    assert np.array_equal(r.rows, h.rows) and np.array_equal(r.counts, h.counts)
+    assert np.array_equal(r.scores.view(np.uint32), h.scores.view(np.uint32))
+    assert r.diag["filter_candidates"] == h.diag["filter_candidates"]     # the same survivors, not just the same top k
+    rng = np.random.default_rng(n)
+    mask = rng.random(n) < 0.5
+    a = run(acc, corpus, q, k, thr, flags=_lib.FLAG_RESIDENT_QUERIES, shadow="i8", mask=mask)
+    b = run(acc, corpus, q, k, thr, flags=FLAG_WIDE_TILE, shadow="i8", mask=mask)
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.counts, b.counts)
+    assert np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
+    assert a.diag["filter_candidates"] == b.diag["filter_candidates"]
+
+
 def test_int8_tier_proves_small_dense_shards_without_escalating(acc, oracle):
     """A 300k-row shard admits ~16 survivors per wave tile (a 12.5M-row one: 0.6): the survivor log is
     sized from the plan, so the int8 tier proves these queries itself instead of escalating all of them."""

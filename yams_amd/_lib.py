@@ -21,6 +21,7 @@ CDC_RABIN, CDC_STREAMING = 0, 1
 FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG_RECORD_PATH = 1, 2, 4, 8, 16
 FLAG_WIDE_TILE = 32
 FLAG_NO_I8_FILTER = 64
+FLAG_RESIDENT_QUERIES = 128
 TIER_NONE, TIER_I8, TIER_BF16, TIER_SPLIT, TIER_F32 = range(5)
 CDC_FLAG_GENERIC_KERNEL = 1
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2

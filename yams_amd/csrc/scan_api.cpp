@@ -7,6 +7,7 @@
 //   -> per-query candidate select -> fp64 re-score + verification (-> widen -> exhaustive fp64).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -249,7 +250,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 41 && bf16_version <= 58))) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 68))) i8 = false;
 #endif
         const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
         ScanLaunch L;
@@ -258,6 +259,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             L.rows_bf16 = corpus->rows_bf16; L.rows_nsq = corpus->rows_nsq; // used by the single-pass kernel
         }
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
+        L.i8_form = (params->flags & YAMS_SCAN_FLAG_WIDE_TILE) ? 1 : ((params->flags & YAMS_SCAN_FLAG_RESIDENT_QUERIES) ? 2 : 0);
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
@@ -318,6 +320,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_HIP(ctx, hipMemsetAsync(L.log_cnt, 0, static_cast<size_t>(regions) * 4, st));
             YA_HIP(ctx, hipMemsetAsync(d_qover, 0, static_cast<size_t>(nq) * 4, st));
             L.q_over = d_qover;
+            if (const uint64_t sync_words = i8_sync_words(L)) {
+                YA_TRY(ws_get(ctx, "i8_sync", static_cast<size_t>(sync_words) * 4, (void**)&L.i8_sync));
+                YA_HIP(ctx, hipMemsetAsync(L.i8_sync, 0, static_cast<size_t>(sync_words) * 4, st));
+            }
         }
 
         { TimedRegion tr(ctx, "scan_sample");
@@ -334,9 +340,17 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           tr.end();
           gs.leave(); }
         if (i8) YA_HIP(ctx, launch_i8_log_gather(st, L));
+#ifdef YAMS_ACCEL_MEASURE
+        if (i8 && L.i8_sync) if (const char* dump = std::getenv("YAMS_ACCEL_DUMP_SYNC")) { // per-wave begin / end ticks of the resident-query kernel
+            std::vector<uint32_t> h(i8_sync_words(L));
+            YA_HIP(ctx, hipMemcpyAsync(h.data(), L.i8_sync, h.size() * 4, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 4, h.size(), f); std::fclose(f); }
+        }
+#endif
 
 #ifdef YAMS_ACCEL_MEASURE
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 50) { // ablated kernels produce no candidates: stop here
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 40 && bf16_version != 50) { // ablated kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;

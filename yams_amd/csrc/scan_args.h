@@ -22,6 +22,7 @@ struct ScanArgs {
     uint32_t* log_cnt;         // [grid * 8] entries written (zeroed before the launch)
     uint32_t log_cap;
     uint32_t* q_over;          // [n_queries] set when a log region was too small for a query's survivors
+    uint32_t* i8_sync;         // resident-query form: [n_streams][4 wave pairs][32 query tiles] strips drawn so far (zeroed before the launch)
     const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
     const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
     const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)

@@ -459,6 +459,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
     // piece p of slab s into ring stage `st` (0..2): p = 0, 1 rows, p = 2..5 queries
     auto piece = [&](int s, int st, int p) __attribute__((always_inline)) {
         if ((ABL == 1 || ABL == 3) && s >= H_NST) return; // measurement build: no refills after the prologue
+        if (ABL == 5 && s >= H_NST && p >= 2) return;     // measurement build: row pieces only (queries "resident")
+        if (ABL == 6 && s >= H_NST && p < 2) return;      // measurement build: query pieces only
         const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
         if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
         else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
@@ -583,7 +585,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
             if (H1 && (i == 5 || i == 9 || i == 13)) piece(s + 2, st2, i == 5 ? 3 : (i == 9 ? 4 : 5));
         });
         // slab s+1 is older than slab s+2's six pieces
-        if (H1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if (H1 && ABL == 5 && s >= 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if (H1 && ABL == 6 && s >= 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (H1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         pin4(fb[1]);
@@ -734,6 +738,411 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
         const uint32_t total = wave_log[wid];
         a.log_cnt[static_cast<uint64_t>(bid) * 4u + static_cast<uint32_t>(wid)] = total < a.log_cap ? total : a.log_cap;
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The filter with the QUERY TILE RESIDENT in LDS (dim <= 768, dim % 128 == 0): one workgroup of eight
+// waves per CU stays for the whole launch, holds 128 queries x dim int8 (<= 96 KiB) and streams row
+// strips past them.  Ablations of the half-tile kernel on the bench shard (12.5M x 768, 1024 queries):
+// 8.9 ms as shipped, 7.1 ms with the query pieces of the ring left out, 6.1 ms without any refill —
+// two thirds of its LDS-DMA pieces (and of its L2 -> LDS bytes) re-stage queries that never change.
+// Here
+//   * a query slab is staged ONCE per workgroup; the only steady-state DMA traffic is the rows: 1/128
+//     byte per multiply-add instead of 1/128 + 1/256, four pieces per wave and slab instead of six;
+//   * every wave stages and multiplies its OWN 64 rows (a ring of two 4 KiB slabs in LDS plus a
+//     register double buffer), so there is no workgroup barrier after the prologue, no shared ring to
+//     drain at a tile boundary and no tile prologue: the row stream runs straight through the units;
+//   * the eight workgroups that hold the eight query tiles of a batch sit on the same XCD and walk the
+//     same row units in the same order, so a row comes from HBM once and seven times from that L2.
+// A unit = 512 rows (two consecutive filter tiles; wave w owns strip w & 3 of tile w >> 2), the
+// accumulator layout, thresholds, survivor log and epilogue are those of the half-tile kernel.
+// -------------------------------------------------------------------------------------------------
+constexpr int R_QUERIES = 128, R_THREADS = 512, R_MAX_SLABS = 12;
+constexpr int R_B_SLAB = R_QUERIES * I8_SLAB;      // 8 KiB of queries per k-slab
+constexpr int R_RING = 2 * 64 * I8_SLAB;           // per wave: two slabs of its 64 rows
+constexpr int R_LDS = R_MAX_SLABS * R_B_SLAB + 8 * R_RING; // 160 KiB: everything a CU has
+
+template <int ABL = 0>
+__global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, slot = bid >> 3;       // workgroup b runs on XCD b % 8
+    const uint32_t qt = slot % n_qt, st = slot / n_qt;    // the query tile it holds, its row stream on this XCD
+    if (st >= (n_streams >> 3)) return;
+    const uint32_t stream = st * 8u + xcd;
+    if (stream >= n_units) return;
+
+#ifdef YAMS_ACCEL_MEASURE
+    const uint64_t t_begin = wall_clock64();
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / I8_SLAB; // even, 4..12 (checked by the host)
+    const uint32_t q0 = qt * R_QUERIES;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ringW = __builtin_amdgcn_readfirstlane(lds0 + R_MAX_SLABS * R_B_SLAB + wid * R_RING);
+    const unsigned char* ring = lds + R_MAX_SLABS * R_B_SLAB + wid * R_RING;
+    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    const uint64_t past_end = n_blocks * I8_BLOCK_ROWS;
+
+    // ---- where this wave's strip of a unit lives ----------------------------------------------------
+    // A DMA piece = 16 rows x 64 bytes; lane i fetches 16 bytes of row i >> 2.  Byte offset of that
+    // row from the strip's base: (16 rb + prow) dim, clamped so that rows past the end of the shard read
+    // its last row (only the last unit can be ragged): ONE per-lane register for all pieces and units
+    // plus one clamp value per unit.
+    struct Geo {
+        uint64_t row0;               // first row of the strip; >= n_rows when the strip does not exist
+        const unsigned char* base;   // DMA source base (uniform): the strip's first row (or the shard's last)
+        uint32_t limp;               // per lane: largest admissible offset + the lane's chunk offset
+    };
+    const int prow = lane >> 2;
+    const uint32_t pchunk = ((lane & 3) ^ i8_swz(prow)) * 16u;
+    const uint32_t vlin0p = static_cast<uint32_t>(prow) * dim + pchunk;
+    const uint32_t dim16 = dim * 16u;
+    // Strip k of this wave's PAIR (waves w and w + 4 share a SIMD and a strip sequence, see "work sharing"
+    // below): unit (k >> 1) of the stream, tile (k & 1) of that unit, rows [64 (w & 3), +64) of the tile.
+    auto unit_of = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t { return stream + (k >> 1) * n_streams; };
+    auto locate = [&](uint32_t k, Geo& g) __attribute__((always_inline)) {
+        const uint32_t un_ = unit_of(k);
+        const uint32_t sel = un_ < n_units ? 2u * un_ + (k & 1u) : 0xffffffffu;
+        uint64_t row0 = past_end;
+        if (sel < a.n_sel_tiles) {
+            const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+            row0 = static_cast<uint64_t>(tile) * I8_ROWS + static_cast<uint32_t>((wid & 3) * 64);
+        }
+        g.row0 = row0;
+        const uint64_t rowb = row0 < a.n_rows ? row0 : a.n_rows - 1;
+        const uint64_t room = a.n_rows - 1 - rowb;                         // rows after the base row
+        g.limp = static_cast<uint32_t>(room < 63 ? room : 63) * dim + pchunk;
+        g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + rowb * dim;
+    };
+    // row piece rb of slab ss of the strip at `src` into ring stage P
+    auto piece = [&](const unsigned char* sbase, uint32_t limp, int ss, int P, int rb) __attribute__((always_inline)) {
+        uint32_t off = vlin0p + static_cast<uint32_t>(rb) * dim16;
+        off = off < limp ? off : limp;
+        lds_dma16_s(sbase + ss * I8_SLAB, off, ringW + P * 4096 + rb * 1024);
+    };
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    auto meta_ptr = [&](uint64_t row0) __attribute__((always_inline)) -> const float* {
+        uint64_t blk = row0 / I8_BLOCK_ROWS;
+        if (blk >= n_blocks) blk = n_blocks - 1; // a strip past the end: nothing of it is ever emitted
+        return a.rows_i8_meta + 2ull * blk;
+    };
+    // {A_lo, B_hi} of this lane's eight queries: requested from inline asm (the compiler would drain the
+    // ring with a vmcnt(0) of its own at a place of its choosing) at the end of a unit, when the second
+    // set of query fragments is dead — sixteen registers that are free exactly then
+    f2_t qthr[8];
+    const float* qthr_p = a.q_thr + 2ull * (q0 + l15); // < q_pad: the table is padded
+    auto qthr_request = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+            asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(qthr[cb]) : "v"(qthr_p), "n"(cb * 128) : "memory");
+    };
+    auto qthr_wait = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                            "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+    };
+
+    // ---- prologue: the resident query tile (wave w stages 16 queries of every slab), the first two
+    //      slabs of the first unit, its thresholds ---------------------------------------------------
+    {
+        const int rowB = wid * 16 + prow;
+        const uint32_t voffB = static_cast<uint32_t>(rowB) * 64u + pchunk; // i8_swz(rowB) == i8_swz(prow)
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
+        const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+        for (int s = 0; s < nslab; ++s)
+            lds_dma16_s(baseB + s * qslab_bytes, voffB, __builtin_amdgcn_readfirstlane(lds0 + s * R_B_SLAB + wid * 1024));
+    }
+    // ---- work sharing ----------------------------------------------------------------------------------
+    // The two waves of a SIMD do not run at the same speed: the arbiter favours the older one, which then
+    // moves at the pace its own DMA latency allows while the younger one gets what is left.  With a fixed
+    // strip per wave, waves 0-3 finished their streams 20 % ahead of waves 4-7 and every launch ended with
+    // one wave per SIMD (alternating s_setprio made both slower).  So a pair (w, w + 4) draws its strips
+    // from ONE counter in global memory (there is no LDS left): a returning atomic, requested two strips
+    // before its value is needed and completed by a drain that is there anyway.  The same counters pace
+    // the query tiles of a stream (below).
+    uint32_t* const pair_cnt = a.i8_sync + (static_cast<uint64_t>(stream) * 4u + static_cast<uint32_t>(wid & 3)) * 32u;
+    uint32_t take_v; // lane 0: the counter's value before this wave's increment
+    auto take_request = [&]() __attribute__((always_inline)) {
+        unsigned long long keep;
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                     : "=&v"(take_v), "=&s"(keep) : "v"(pair_cnt + qt), "v"(1u) : "memory");
+    };
+    auto take_result = [&]() __attribute__((always_inline)) -> uint32_t { // after a vmcnt(0)
+        asm volatile("" : "+v"(take_v));
+        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(take_v)));
+    };
+    uint32_t k_cur, k_nxt, k_fut; // the strip in the accumulators, the one whose first slabs are on their way, the one after
+    take_request(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k_cur = take_result();
+    take_request(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k_nxt = take_result();
+    take_request(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k_fut = take_result();
+    Geo cur, nxt;
+    locate(k_cur, cur);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) piece(cur.base, cur.limp, s, s, rb);
+    qthr_request();
+    float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
+    {
+        const float* mp = meta_ptr(cur.row0);
+        const float m0 = mp[0], m1 = mp[1];
+        sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m0)));
+        eb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m1)));
+    }
+    qthr_wait();
+    __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
+
+    // fragment offsets: row block rb adds rb * 1 KiB inside a ring slab, query block cb adds cb * 1 KiB
+    const int offF = l15 * 64 + ((lq ^ i8_swz(l15)) << 4);
+    i32x4v acc[4][8];
+    i32x4v fa[2][4], fb[2][4];
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v {
+        if (ABL == 4) { i32x4v z = {off, 0, 0, 0}; return z; } // measurement build: no fragment reads
+        return *reinterpret_cast<const i32x4v*>(base + off);
+    };
+    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rb = i >> 2, c = i & 3;
+            if (ABL != 2 && ABL != 4)
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+            else if (i == 0)
+                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            filler(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+
+    // One slab (parity P = slab & 1 = its ring stage) of the current unit:
+    //   half 1: fa[P] x query blocks 0-3; requests query blocks 4-7 of this slab and issues the four row
+    //           pieces of the slab two ahead into stage P (its fragments went to fa[P] during the previous
+    //           slab, and those reads have completed: the MFMAs of this half consume them);
+    //   wait:   the slab one ahead has landed (only the four pieces just issued are younger);
+    //   half 2: fa[P] x query blocks 4-7; requests the next slab's row fragments (fa[P ^ 1]) and its query
+    //           blocks 0-3.
+    // `sbase` / `slimp` / `ss` name the strip and slab the DMA pieces belong to, `sn` the next slab of the query tile.
+    auto body = [&](int s, int sn, const unsigned char* sbase, uint32_t slimp, int ss, auto par_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_tag)::value;
+        const unsigned char* bq = lds + s * R_B_SLAB;
+        const unsigned char* bqn = lds + sn * R_B_SLAB;
+        pin4(fa[P]); pin4(fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[P], fb[0], 0, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
+            if (ABL != 1 && (i == 5 || i == 8 || i == 11 || i == 14)) piece(sbase, slimp, ss, P, ((i - 5) / 3) & 3);
+        });
+        // (slab 0 of a unit waits for no DMA: slabs 0 and 1 landed before the unit began — the drain in front
+        // of the thresholds — and the survivor stores of the previous unit's epilogue, which sit in the same
+        // in-order counter, get a whole slab to complete before a counted wait looks at them)
+        if (ABL != 1) {
+            if (P == 1) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                int so = s;
+                asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for this)
+                if (so != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[P], fb[1], 4, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fa[P ^ 1][i < 4 ? i : 0] = ld(ring, (P ^ 1) * 4096 + offF + (i < 4 ? i : 0) * 1024);
+            if (i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(bqn, offF + ((i - 4) & 3) * 1024);
+        });
+    };
+
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
+
+    // ---- pacing ------------------------------------------------------------------------------------------
+    // Pair p of the n_qt workgroups of a row stream reads the same strips in the same order; they come from
+    // HBM once only while those pairs stay within what this XCD's L2 keeps of the stream (4 MiB for four
+    // streams: two to three units each).  Nothing else couples them — a survivor here, a slow store there —
+    // and measured without pacing they drift apart until most strips are fetched again: 34 GB from HBM per
+    // launch instead of 9.4.  So a wave looks at its siblings' strip counters at the end of a strip (the
+    // load rides on the drain that is there anyway) and lets the slowest one come within R_WINDOW strips of
+    // the one it just drew before it goes on.  Best effort: a bounded number of polls, no correctness
+    // depends on it, no workgroup waits for one that is not resident.
+    constexpr uint32_t R_WINDOW = 4, R_POLLS = 4096;
+    const uint32_t* sync_sib = pair_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
+#ifdef YAMS_ACCEL_MEASURE
+    uint32_t units_read = 0;
+#endif
+
+    constexpr bool THR = ABL == 0 || ABL == 8 || ABL == 9;
+    int nt[8]; // -T(this strip, query block cb): what the accumulators of the unit start at
+    auto thresholds = [&]() __attribute__((always_inline)) {
+        const float is = 1.0f / sb, g = eb * is; // (the same expressions as in i8_log_gather_kernel)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) nt[cb] = THR ? i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g) : 0;
+    };
+    thresholds();
+
+    if (unit_of(k_cur) < n_units) for (;;) {
+        const uint32_t u = unit_of(k_cur);
+        const bool more = unit_of(k_nxt) < n_units;
+        locate(k_nxt, nxt); // (past the end of the stream: the spare DMA slots read the shard's last row; nobody consumes them)
+        take_request();             // the strip after the next two; older than every piece of this strip
+        unsigned long long meta_n;  // the next strip's block scale, on its way through the scalar cache
+        {
+            const float* mp = meta_ptr(nxt.row0);
+            asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(meta_n) : "s"(mp) : "memory");
+        }
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt[cb];
+        // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the
+        // last trip already belong to the next unit: a uniform select, not a second copy of the loop body
+        // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the
+        // last trip already belong to the next unit: a uniform select, not a second copy of the loop body
+        int s = 0;
+        do { // (nslab >= 4: a loop the compiler knows to run at least once keeps one register assignment)
+            const bool last = s + 2 >= nslab;
+            const unsigned char* dbase = last ? nxt.base : cur.base;
+            const uint32_t dlimp = last ? nxt.limp : cur.limp;
+            const int ss = last ? 0 : s + 2;
+            body(s, s + 1, dbase, dlimp, ss, C0{});
+            body(s + 1, ss, dbase, dlimp, ss + 1, C1{});
+            s += 2;
+        } while (s < nslab);
+        asm volatile("" : "+s"(meta_n)); // (every slab waits lgkmcnt(0): the scalar load has long returned)
+#ifdef YAMS_ACCEL_MEASURE
+        ++units_read;
+#endif
+        uint32_t sib = 0; // pacing: the siblings' strip counters
+        if (THR && n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+        if (THR) qthr_request();         // for the NEXT unit's thresholds; in flight under the sign test below
+
+        // ---- epilogue of the unit: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
+        //      the accumulators hold I - T, a survivor is a non-negative one ---------------------------------
+        const uint64_t strip = cur.row0;
+        const float sb_cur = sb, eb_cur = eb;
+        (void)sb_cur; (void)eb_cur;
+        uint32_t hot = 0, k_new;
+        if (THR) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                int m = acc[0][cb][0];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
+                if (m >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+            }
+            if (strip >= a.n_rows) hot = 0;
+            // the next unit's thresholds (needs nothing of this unit's accumulators: eight registers)
+            sb = __uint_as_float(static_cast<uint32_t>(meta_n));
+            eb = __uint_as_float(static_cast<uint32_t>(meta_n >> 32));
+            qthr_wait();
+            thresholds();
+            k_new = take_result(); // (landed with the drain above, like the siblings' counters)
+            if (n_qt > 1 && more) {
+                asm volatile("" : "+v"(sib));
+                for (uint32_t polls = 0; polls < R_POLLS; ++polls) {
+                    if (__builtin_amdgcn_ballot_w64(sib + R_WINDOW < k_new) == 0) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sib) : "v"(sync_sib) : "memory");
+                }
+            }
+        } else { // measurement builds: keep the accumulators alive, emit nothing
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            k_new = take_result();
+            int t = 0;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
+            if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        }
+        if (THR && __builtin_amdgcn_ballot_w64(hot != 0) != 0) { // about half of the strips hold a survivor somewhere
+            // One pass over the query blocks that hold a survivor in some lane (one, typically): every element
+            // is tested by the whole wave at once, a ballot hands out the slots of this strip's log region (no
+            // LDS is left for a counter) and the lanes that hold a survivor store it.  An entry is
+            // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
+            // bound u and moves the entry into its query's candidate list.
+            const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
+            const uint64_t rid = (static_cast<uint64_t>(u) * n_qt + qt) * 8u + static_cast<uint32_t>((wid & 3) + 4 * (k_cur & 1u));
+            const uint64_t region = rid * a.log_cap;
+            uint32_t base = 0; // entries of this strip so far (wave-uniform)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const bool hot_cb = (hot >> cb) & 1u;
+                if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
+                const uint32_t qi = q0 + cb * 16 + l15;
+                // this lane's 16 elements of the block that survive (straight-line code) ...
+                uint32_t pm = 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const uint32_t off0 = 16 * rb + 4 * lq; // row of element r of this lane: strip + off0 + r
+                    uint32_t mw = 0xfu;
+                    if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pm |= (acc[rb][cb][r] >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                }
+                if (!hot_cb) pm = 0;
+                // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
+                // unrolled form (a store block per element, 35 KB of it) ran from a cold instruction cache every time
+                bool lost = false;
+                for (;;) {
+                    const bool p = pm != 0;
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                    if (m == 0) break;
+                    const int e = p ? __builtin_ctz(pm) : 0;
+                    int val = acc[0][cb][0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
+                    const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                    base += static_cast<uint32_t>(__builtin_popcountll(m));
+                    if (p && ABL != 8) {
+                        const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
+                        if (ABL == 9) { // measurement build: slots, but no stores
+                            if (pos == 0x7fffffffu && val == 1) a.list_count[0] = 1;
+                        } else if (pos < a.log_cap) {
+                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
+                            a.log_q[region + pos] = qi;
+                        } else {
+                            lost = true;
+                        }
+                    }
+                    pm &= pm - 1u;
+                }
+                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+            }
+            if (lane == 0 && ABL != 8 && ABL != 9) a.log_cnt[rid] = base < a.log_cap ? base : a.log_cap;
+            if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        }
+        if (!more) break;
+        cur = nxt;
+        k_cur = k_nxt; k_nxt = k_fut; k_fut = k_new;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
+#ifdef YAMS_ACCEL_MEASURE
+    if (lane == 0 && n_qt <= 8) { // measurement build: when each wave started and ended (100 MHz ticks) and how many strips it took
+        uint32_t* const dbg = a.i8_sync + (static_cast<uint64_t>(n_streams) * 4u + static_cast<uint64_t>(stream) * 8u + static_cast<uint32_t>(wid)) * 32u;
+        dbg[8 + qt] = static_cast<uint32_t>(t_begin);
+        dbg[16 + qt] = static_cast<uint32_t>(wall_clock64());
+        dbg[24 + qt] = units_read;
+    }
+#endif
 }
 
 #ifdef YAMS_ACCEL_MEASURE
@@ -1354,9 +1763,47 @@ hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q
     return hipGetLastError();
 }
 
-// survivor-log regions of the filter launch: one per (workgroup, wave) of the half-tile kernel
+// Does the filter pass of this launch run with the query tile resident (scan_tiles_i8r_kernel)?
+// Needs the whole 128-query tile in LDS next to the row rings (dim <= 768), an even slab count, at most
+// one query tile per CU of an XCD, and enough 512-row units per row stream that the streams end together.
+struct ResidentPlan { bool use; uint32_t n_units, n_qt, n_streams, grid; };
+static ResidentPlan i8_resident_plan(const ScanLaunch& L) {
+    static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    ResidentPlan r{false, 0, 0, 0, 0};
+    const uint32_t dim = L.plan.dim, nq = L.plan.n_queries;
+    if (n_cu < 8 || (dim & 127u) || dim < 256 || dim > static_cast<uint32_t>(R_MAX_SLABS * I8_SLAB)) return r;
+    const uint32_t per_xcd = static_cast<uint32_t>(n_cu) / 8u;
+    r.n_qt = (nq + R_QUERIES - 1) / R_QUERIES;
+    if (r.n_qt == 0 || r.n_qt > per_xcd) return r;
+    if (L.i8_form == 1) return r;                                  // the caller keeps the per-tile kernels
+    const uint32_t streams_x = per_xcd / r.n_qt;
+    r.n_streams = streams_x * 8u;
+    r.n_units = (L.plan.n_filter_tiles + 1u) / 2u;
+    if (r.n_units == 0) return r;
+    if (L.i8_form != 2) { // the library's choice (the caller's RESIDENT_QUERIES flag skips these two)
+        if (streams_x * r.n_qt * 10u < per_xcd * 9u) return r;   // more than a tenth of the CUs would idle
+        if (r.n_units < 12u * r.n_streams) return r;              // short streams: the half-tile kernel balances better
+    }
+    r.grid = per_xcd * 8u;
+    r.use = true;
+    return r;
+}
+
+// survivor-log regions of the filter launch: one per (workgroup, wave) of the half-tile kernel, one per
+// (unit, query tile, wave) of the resident-query kernel — a 64 x 128 wave tile either way
 uint64_t i8_log_regions(const ScanLaunch& L) {
+    const ResidentPlan r = i8_resident_plan(L);
+    if (r.use) return static_cast<uint64_t>(r.n_units) * r.n_qt * 8u;
     return static_cast<uint64_t>((2u * L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8u * 4u;
+}
+
+uint64_t i8_sync_words(const ScanLaunch& L) {
+    const ResidentPlan r = i8_resident_plan(L);
+    return r.use ? static_cast<uint64_t>(r.n_streams) * 12u * 32u : 0u; // [n_streams][4 pairs][32] strip counters (+ [n_streams][8][32] for the measurement build's timestamps)
 }
 
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
@@ -1393,6 +1840,8 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         else if (version == 42) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 2>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else if (version == 43) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 3>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else if (version == 44) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 4>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 45) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 5>), dim3(hg), dim3(H_THREADS), 0, st, a);
+        else if (version == 46) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 6>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else if (version == 48) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 8>), dim3(hg), dim3(H_THREADS), 0, st, a);
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hg), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
@@ -1415,7 +1864,27 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
 #endif
-    if (mode == MODE_SAMPLE) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+    if (mode == MODE_SAMPLE) {
+        hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+    const ResidentPlan rp = i8_resident_plan(L);
+#ifdef YAMS_ACCEL_MEASURE
+    if (rp.use && version >= 61 && version <= 68) { // ablations of the resident-query kernel
+        if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        else if (version == 64) hipLaunchKernelGGL((scan_tiles_i8r_kernel<4>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        else if (version == 68) hipLaunchKernelGGL((scan_tiles_i8r_kernel<8>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        else if (version == 66) hipLaunchKernelGGL((scan_tiles_i8r_kernel<9>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        else hipLaunchKernelGGL((scan_tiles_i8r_kernel<7>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        return hipGetLastError();
+    }
+    if (version == 40) { // the half-tile kernel where the library would pick the resident-query one (A/B runs)
+        hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+#endif
+    if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
 }

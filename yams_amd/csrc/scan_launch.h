@@ -16,6 +16,8 @@ struct ScanLaunch {
     const float* q_thr = nullptr;
     uint64_t* log_key = nullptr; uint32_t* log_q = nullptr; uint32_t* log_cnt = nullptr; uint32_t log_cap = 0;
     uint32_t* q_over = nullptr;
+    uint32_t* i8_sync = nullptr;         // resident-query form of the int8 filter: pacing counters (i8_sync_words())
+    int i8_form = 0;                     // int8 filter pass: 0 = the library's choice, 1 = half tiles, 2 = resident queries when possible
     int sample_layout = 0;               // rows of a sample group: 0 = 32x32 accumulator layout, 1 = 16x16 (int8 tier)
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
@@ -79,6 +81,8 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
 // After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
 // int8 tier: workgroups of the filter launch (the survivor log has 8 regions of log_cap entries per group)
 uint64_t i8_log_regions(const ScanLaunch& L);
+// pacing counters of the resident-query form (0 when the launch takes the half-tile form); zero them before the launch
+uint64_t i8_sync_words(const ScanLaunch& L);
 // after the filter pass: log entries -> per-query candidate lists (the returning atomics live here, where
 // thousands of independent threads hide their latency)
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L);
