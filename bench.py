@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2, help="search lanes: batches in flight, each on its own context / stream / host thread")
     ap.add_argument("--no-i8", action="store_true", help="no int8 shadow: the bf16 tier filters the large batches too")
     ap.add_argument("--split-filter", action="store_true", help="start with the split-bf16 (3-pass) filter instead of the single-pass bf16 one")
+    ap.add_argument("--half-tile", action="store_true", help="int8 tier: keep the per-tile (half-tile) filter kernel instead of the resident-query form (A/B runs)")
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
     ap.add_argument("--dist-backend", default=None, help="override the collective backend (gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry runs only)")
@@ -316,6 +317,8 @@ def main():
         pipe.merge_fn = merge_fn
 
     scan_flags = 4 if a.f32_filter else (8 if a.split_filter else 0)   # YAMS_SCAN_FLAG_F32_FILTER / _SPLIT_FILTER
+    if a.half_tile:
+        scan_flags |= 32                                                # YAMS_SCAN_FLAG_WIDE_TILE: per-tile kernel forms
     # Search lanes: every lane is its own context (stream + workspace) driven by its own host thread, as the
     # plugin serves concurrent search calls from its pool of contexts (plugin.cpp, "search_slots").  While
     # one lane's batch is in its serial tail (candidate selection, fp64 re-score, the host's look at the

@@ -923,15 +923,19 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
 
-    // One slab (parity P = slab & 1 = its ring stage) of the current unit:
-    //   half 1: fa[P] x query blocks 0-3; requests query blocks 4-7 of this slab and issues the four row
-    //           pieces of the slab two ahead into stage P (its fragments went to fa[P] during the previous
-    //           slab, and those reads have completed: the MFMAs of this half consume them);
-    //   wait:   the slab one ahead has landed (only the four pieces just issued are younger);
-    //   half 2: fa[P] x query blocks 4-7; requests the next slab's row fragments (fa[P ^ 1]) and its query
-    //           blocks 0-3.
-    // `sbase` / `slimp` / `ss` name the strip and slab the DMA pieces belong to, `sn` the next slab of the query tile.
-    auto body = [&](int s, int sn, const unsigned char* sbase, uint32_t slimp, int ss, auto par_tag) __attribute__((always_inline)) {
+    // One slab (parity P = slab & 1 = its ring stage) of the current strip:
+    //   half 1: fa[P] x query blocks 0-3; requests query blocks 4-7 of this slab;
+    //   wait:   the slab one ahead has landed (only the four pieces of the slab two ahead are younger);
+    //   half 2: fa[P] x query blocks 4-7; requests the next slab's row fragments (fa[P ^ 1], from stage P ^ 1)
+    //           and its query blocks 0-3, and — as soon as those fragment reads have returned — refills that
+    //           stage with the slab THREE ahead: a stage is empty for a third of a slab instead of a whole
+    //           one, so a piece has 1.6 slabs to land instead of 1.2 (the ring is what bounds the loop: 8 KiB
+    //           in flight per wave against ~1 us of loaded L2 -> LDS latency).
+    // `sbase` / `slimp` / `ss` name the strip and slab the DMA pieces belong to, `sn` the next slab of the query
+    // tile, `early` the first two slabs of a strip: slabs 1 and 2 landed before the strip began (the drain in
+    // front of the thresholds), so they wait for no DMA, and the survivor stores of the previous strip's
+    // epilogue — in the same in-order counter — get two slabs to complete before a counted wait looks at them.
+    auto body = [&](int sn, bool early, const unsigned char* sbase, uint32_t slimp, int ss, int s, auto par_tag) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
         const unsigned char* bq = lds + s * R_B_SLAB;
         const unsigned char* bqn = lds + sn * R_B_SLAB;
@@ -939,26 +943,16 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[0], 0, [&](int i) __attribute__((always_inline)) {
             if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
-            if (ABL != 1 && (i == 5 || i == 8 || i == 11 || i == 14)) piece(sbase, slimp, ss, P, ((i - 5) / 3) & 3);
         });
-        // (slab 0 of a unit waits for no DMA: slabs 0 and 1 landed before the unit began — the drain in front
-        // of the thresholds — and the survivor stores of the previous unit's epilogue, which sit in the same
-        // in-order counter, get a whole slab to complete before a counted wait looks at them)
-        if (ABL != 1) {
-            if (P == 1) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                int so = s;
-                asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for this)
-                if (so != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            }
-        }
+        if (ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pin4(fb[1]);
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[1], 4, [&](int i) __attribute__((always_inline)) {
             if (i < 4) fa[P ^ 1][i < 4 ? i : 0] = ld(ring, (P ^ 1) * 4096 + offF + (i < 4 ? i : 0) * 1024);
             if (i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(bqn, offF + ((i - 4) & 3) * 1024);
+            if (ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
+            if (ABL != 1 && i >= 11 && i < 15) piece(sbase, slimp, ss, P ^ 1, (i - 11) & 3);
         });
     };
 
@@ -966,6 +960,10 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) piece(cur.base, cur.limp, 2, 0, rb); // slab 2 into the stage slab 0 just left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (a strip begins with its slabs 1 and 2 landed)
 
     // ---- pacing ------------------------------------------------------------------------------------------
     // Pair p of the n_qt workgroups of a row stream reads the same strips in the same order; they come from
@@ -1007,18 +1005,16 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt[cb];
-        // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the
-        // last trip already belong to the next unit: a uniform select, not a second copy of the loop body
-        // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the
-        // last trip already belong to the next unit: a uniform select, not a second copy of the loop body
+        // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
+        // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
         int s = 0;
         do { // (nslab >= 4: a loop the compiler knows to run at least once keeps one register assignment)
-            const bool last = s + 2 >= nslab;
-            const unsigned char* dbase = last ? nxt.base : cur.base;
-            const uint32_t dlimp = last ? nxt.limp : cur.limp;
-            const int ss = last ? 0 : s + 2;
-            body(s, s + 1, dbase, dlimp, ss, C0{});
-            body(s + 1, ss, dbase, dlimp, ss + 1, C1{});
+            int so = s;
+            asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for `early`)
+            const bool early = so == 0;
+            const bool n0 = s + 3 >= nslab, n1 = s + 4 >= nslab;
+            body(s + 1, early, n0 ? nxt.base : cur.base, n0 ? nxt.limp : cur.limp, n0 ? s + 3 - nslab : s + 3, s, C0{});
+            body(s + 2 >= nslab ? 0 : s + 2, early, n1 ? nxt.base : cur.base, n1 ? nxt.limp : cur.limp, n1 ? s + 4 - nslab : s + 4, s + 1, C1{});
             s += 2;
         } while (s < nslab);
         asm volatile("" : "+s"(meta_n)); // (every slab waits lgkmcnt(0): the scalar load has long returned)
