@@ -417,6 +417,23 @@ YAMS_ACCEL_API yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8
                                                 uint64_t n_blobs, const yams_cdc_config_t* cfg,
                                                 uint32_t flags, yams_ingest_result_t* out);
 
+/* The same path for blobs in HOST memory (what ContentStore::store has after reading a file,
+ * content_store_impl.cpp:199-231): blobs cross PCIe in batches of ~batch_bytes (0 = 1 GiB; a blob is
+ * never split) through two device buffers, batch i + 1 uploading while batch i is chunked and hashed.
+ * Pinned (page-locked) blob memory uploads at link speed, pageable memory through the runtime's
+ * staging.  Results go to caller arrays: out_blob_first[n_blobs + 1] (prefix of chunk counts),
+ * out_chunk_offset / out_chunk_size [chunk_cap], out_chunk_digest [chunk_cap][32] (nullable),
+ * out_blob_digest [n_blobs][32] (required with YAMS_INGEST_BLOB_DIGESTS).  If the chunks do not fit
+ * chunk_cap the status is YAMS_ERR_INVALID_ARG and *out_n_chunks holds the required size (blob digests
+ * and out_blob_first are complete even then). */
+YAMS_ACCEL_API yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_host,
+                                              const uint64_t* blob_lengths, uint64_t n_blobs,
+                                              const yams_cdc_config_t* cfg, uint32_t flags,
+                                              uint64_t batch_bytes, uint64_t* out_blob_first,
+                                              uint64_t* out_chunk_offset, uint64_t* out_chunk_size,
+                                              uint8_t* out_chunk_digest, uint64_t chunk_cap,
+                                              uint8_t* out_blob_digest, uint64_t* out_n_chunks);
+
 /* IChunker::chunkDataLazy over host memory (chunker.h:84-86): fills caller arrays; hex may be
  * NULL.  Returns the chunk count in *out_count (cap = capacity of the arrays; if the count
  * exceeds cap the status is YAMS_ERR_INVALID_ARG and *out_count holds the required size). */

@@ -277,6 +277,96 @@ def test_ingest_config5_8GiB_every_blob_verified(acc, oracle):
     assert int(first[-1]) == out["n_chunks"] and 300_000 < out["n_chunks"] < 400_000
 
 
+def _skewed_lengths(rng, total_bytes):
+    """The blob-size mix SURVEY.md 8d asks for: 1 KiB ... 64 MiB log-uniform, plus the sizes around the
+    chunker's own constants (empty, below the 48-byte window, = min, = max +- 1)."""
+    special = [0, 1, 47, 48, 49, 16383, 16384, 16385, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 64 << 20]
+    lens, tot = list(special), sum(special)
+    while tot < total_bytes:
+        n = int(2.0 ** rng.uniform(10, 24.5))
+        lens.append(n); tot += n
+    order = rng.permutation(len(lens))
+    return [lens[i] for i in order]
+
+
+def _verify_blobs(oracle, blobs, first, co, cs, cd, bd, mode, cfg, every=1):
+    import _oracle
+    from concurrent.futures import ThreadPoolExecutor
+
+    def verify(bi):
+        b = blobs[bi]
+        ooff, osz = oracle.chunks(b, mode, **cfg)
+        lo, hi = int(first[bi]), int(first[bi + 1])
+        if hi - lo != len(ooff) or not (np.array_equal(co[lo:hi], ooff) and np.array_equal(cs[lo:hi], osz)):
+            return f"blob {bi} ({len(b)} B): boundaries differ"
+        mv = memoryview(b)
+        if bd[bi].tobytes() != hashlib.sha256(mv).digest():
+            return f"blob {bi} ({len(b)} B): blob digest differs"
+        for j in range(lo, hi, every):
+            o, n = int(co[j]), int(cs[j])
+            if cd[j].tobytes() != hashlib.sha256(mv[o:o + n]).digest():
+                return f"blob {bi}: chunk {j - lo} digest differs"
+        return None
+
+    with ThreadPoolExecutor(max_workers=_oracle.host_threads(64)) as ex:
+        return [m for m in ex.map(verify, range(len(blobs))) if m]
+
+
+@pytest.mark.parametrize("mode", ["streaming", "rabin"])
+def test_ingest_skewed_blob_set_device_and_host_streamed(acc, oracle, mode):
+    """A skewed blob set (1 KiB ... 64 MiB log-uniform + the sizes around window / min / max, ~0.6 GiB,
+    random bytes at unaligned offsets) through BOTH entry points — device-resident (yams_ingest_device)
+    and host-streamed in batches (yams_ingest_host: small batches here, so blobs of every size open and
+    close a batch and the 64 MiB blob is a batch of its own) — every blob against the CPU."""
+    import torch
+    rng = np.random.default_rng(146)
+    lens = _skewed_lengths(rng, 600 << 20)
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    cfg = {}
+    # device-resident: blobs packed back to back (arbitrary byte alignment)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) + 3
+    buf = np.concatenate([np.zeros(3, np.uint8)] + blobs + [np.zeros(64, np.uint8)])
+    tb = torch.from_numpy(buf).cuda()
+    res = acc.ingest_device(tb.data_ptr(), offs, lens, cdc_config(mode), flags=3)
+    out = acc.fetch_ingest(res, len(lens))
+    bad = _verify_blobs(oracle, blobs, out["blob_first"], out["chunk_offset"], out["chunk_size"], out["chunk_digest"],
+                        out["blob_digest"], mode, cfg)
+    assert not bad, bad[:5]
+    # host-streamed: the same blobs where they lie in (pageable) host memory
+    h = acc.ingest_host([b.ctypes.data for b in blobs], lens, cdc_config(mode), flags=3, batch_bytes=24 << 20)
+    assert h["n_chunks"] == out["n_chunks"]
+    assert np.array_equal(h["blob_first"], out["blob_first"])
+    assert np.array_equal(h["chunk_offset"], out["chunk_offset"]) and np.array_equal(h["chunk_size"], out["chunk_size"])
+    assert np.array_equal(h["chunk_digest"], out["chunk_digest"]) and np.array_equal(h["blob_digest"], out["blob_digest"])
+    # capacity protocol: too few chunk slots -> INVALID_ARG and the required size
+    from yams_amd.accel import AccelError
+    with pytest.raises(AccelError):
+        acc.ingest_host([b.ctypes.data for b in blobs], lens, cdc_config(mode), flags=3, batch_bytes=24 << 20, chunk_cap=10)
+    assert acc.last_required_chunks == out["n_chunks"]
+    # no blobs at all
+    e = acc.ingest_host([], [], cdc_config(mode), flags=3)
+    assert e["n_chunks"] == 0 and list(e["blob_first"]) == [0]
+
+
+def test_ingest_reference_benchmark_config_4k_16k_64k(acc, oracle):
+    """The reference's own chunking benchmark configuration (tests/benchmarks/core_benchmarks.cpp:
+    225-229: RabinChunker, min 4096 / target 16384 / max 65536, 1 MiB inputs): 512 such blobs, every one
+    against the CPU."""
+    import torch
+    n_blobs, blen = 512, 1 << 20
+    tb = torch.empty(n_blobs * blen, dtype=torch.uint8, device="cuda")
+    acc.synth_bytes(7, 0, n_blobs, blen, tb.data_ptr())
+    cfg = dict(min_size=4096, max_size=65536)
+    res = acc.ingest_device(tb.data_ptr(), [i * blen for i in range(n_blobs)], [blen] * n_blobs, cdc_config("rabin", **cfg), flags=3)
+    out = acc.fetch_ingest(res, n_blobs)
+    blobs = [oracle.synth_bytes(7, bi, 0, blen) for bi in range(n_blobs)]
+    bad = _verify_blobs(oracle, blobs, out["blob_first"], out["chunk_offset"], out["chunk_size"], out["chunk_digest"],
+                        out["blob_digest"], "rabin", cfg)
+    assert not bad, bad[:5]
+    sizes = out["chunk_size"]
+    assert sizes.max() <= 65536 and 8000 < sizes.mean() < 20000
+
+
 def test_chunker_vtable(accel_lib, oracle):
     L = accel_lib
     assert L.yams_plugin_init(b"{}", None) == 0

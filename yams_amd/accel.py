@@ -399,6 +399,31 @@ class Accel:
                                               flags, C.byref(res)))
         return res
 
+    def ingest_host(self, blob_ptrs, blob_lengths, cfg: CdcConfig | None = None, flags: int = 3,
+                    batch_bytes: int = 0, chunk_cap: int | None = None) -> dict:
+        """yams_ingest_host: blobs in host memory (addresses in blob_ptrs), streamed through the device
+        in batches.  Returns blob_first, chunk_offset, chunk_size, chunk_digest, blob_digest (numpy)."""
+        cfg = cfg or cdc_config()
+        bl = np.ascontiguousarray(blob_lengths, np.uint64)
+        n = int(bl.size)
+        ptrs = (C.c_void_p * max(n, 1))(*[int(p) if p else None for p in blob_ptrs])
+        if chunk_cap is None:
+            chunk_cap = int(sum(int(x) // max(int(cfg.min_size), 1) + 2 for x in bl))
+        first = np.zeros(n + 1, np.uint64)
+        off = np.empty(chunk_cap, np.uint64); sz = np.empty(chunk_cap, np.uint64)
+        dg = np.empty((chunk_cap, 32), np.uint8) if flags & 1 else None
+        bd = np.empty((n, 32), np.uint8) if flags & 2 else None
+        cnt = C.c_uint64(0)
+        rc = self.L.yams_ingest_host(self.ctx, ptrs, bl.ctypes.data_as(_lib.u64p), n, C.byref(cfg), flags, batch_bytes,
+                                     first.ctypes.data_as(_lib.u64p), off.ctypes.data_as(_lib.u64p),
+                                     sz.ctypes.data_as(_lib.u64p), dg.ctypes.data if dg is not None else None,
+                                     chunk_cap, bd.ctypes.data if bd is not None else None, C.byref(cnt))
+        self.last_required_chunks = int(cnt.value)
+        self._check(rc)
+        m = int(cnt.value)
+        return {"n_chunks": m, "blob_first": first, "chunk_offset": off[:m], "chunk_size": sz[:m],
+                "chunk_digest": dg[:m] if dg is not None else None, "blob_digest": bd}
+
     def download(self, ptr: int, dtype, count: int) -> np.ndarray:
         out = np.empty(count, dtype=dtype)
         if out.nbytes:

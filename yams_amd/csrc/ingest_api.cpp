@@ -222,6 +222,131 @@ yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8_t* data,
     return ingest_impl(ctx, data, blob_offsets_host, blob_lengths_host, n_blobs, cfg, flags, true, out);
 }
 
+// Host-sourced ingest: the blobs live in host memory (files just read, network buffers).  They cross
+// PCIe in batches through two device buffers: while the kernels work on batch i, batch i + 1 is
+// already on its way on a copy stream of its own; the results of a batch (a few bytes per chunk) go
+// back before the next one starts.  Small blobs: bound by the link.  Large blobs: a batch cannot end
+// before the SHA-256 chain of its longest blob has (one lane, ~35 MB/s), so batches are GiB-sized.
+yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_host,
+                               const uint64_t* blob_lengths, uint64_t n_blobs,
+                               const yams_cdc_config_t* cfg, uint32_t flags, uint64_t batch_bytes,
+                               uint64_t* out_blob_first, uint64_t* out_chunk_offset,
+                               uint64_t* out_chunk_size, uint8_t* out_chunk_digest, uint64_t chunk_cap,
+                               uint8_t* out_blob_digest, uint64_t* out_n_chunks) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (out_n_chunks) *out_n_chunks = 0;
+    if (n_blobs && (!blobs_host || !blob_lengths)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob list");
+    if (!out_blob_first) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob_first");
+    if ((flags & YAMS_INGEST_BLOB_DIGESTS) && n_blobs && !out_blob_digest) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob digests");
+    CdcParams cp{};
+    YA_TRY(make_params(ctx, cfg, &cp)); // (before any allocation: bad configurations fail like the device entry point)
+    (void)hipSetDevice(ctx->device);
+    out_blob_first[0] = 0;
+    if (n_blobs == 0) return YAMS_OK;
+    if (batch_bytes == 0) batch_bytes = 1ull << 30;
+    // batches of consecutive blobs (a blob never straddles two: its digest is one chain); every blob
+    // starts on a 16-byte boundary of the device buffer
+    struct Batch { uint64_t first, count, bytes; };
+    std::vector<Batch> batches;
+    uint64_t largest = 0;
+    for (uint64_t b = 0; b < n_blobs;) {
+        Batch bt{b, 0, 0};
+        while (b < n_blobs) {
+            if (blob_lengths[b] && !blobs_host[b]) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob");
+            const uint64_t padded = (blob_lengths[b] + 15) & ~15ull;
+            if (bt.count && bt.bytes + padded > batch_bytes) break;
+            bt.bytes += padded; ++bt.count; ++b;
+        }
+        largest = std::max(largest, bt.bytes);
+        batches.push_back(bt);
+    }
+    uint8_t* d_buf[2];
+    YA_TRY(ws_get(ctx, "ing_host_buf0", largest + 64, (void**)&d_buf[0]));
+    YA_TRY(ws_get(ctx, "ing_host_buf1", batches.size() > 1 ? largest + 64 : 64, (void**)&d_buf[1]));
+    hipStream_t copy_st = nullptr;
+    hipEvent_t landed[2] = {nullptr, nullptr};
+    yams_status_t rc = YAMS_OK;
+    auto cleanup = [&]() {
+        if (copy_st) { (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); }
+        for (hipEvent_t e : landed) if (e) (void)hipEventDestroy(e);
+    };
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        rc = fail(ctx, YAMS_ERR_INTERNAL, what);
+        return false;
+    };
+    if (!hip_ok(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking), "copy stream") ||
+        !hip_ok(hipEventCreateWithFlags(&landed[0], hipEventDisableTiming), "event") ||
+        !hip_ok(hipEventCreateWithFlags(&landed[1], hipEventDisableTiming), "event")) { cleanup(); return rc; }
+    std::vector<uint64_t> offs, lens;
+    auto upload = [&](size_t bi) -> bool { // batch bi -> device buffer bi & 1, on the copy stream
+        const Batch& bt = batches[bi];
+        // blobs that are neighbours in host memory (one mapped file, one receive buffer) and in the device
+        // buffer travel as ONE copy: a copy call costs the host ~10 us whatever its size
+        uint64_t at = 0, run_dst = 0, run_len = 0;
+        const uint8_t* run_src = nullptr;
+        auto flush = [&]() -> bool {
+            const bool ok = run_len == 0 || hip_ok(hipMemcpyAsync(d_buf[bi & 1] + run_dst, run_src, run_len, hipMemcpyHostToDevice, copy_st), "upload");
+            run_len = 0;
+            return ok;
+        };
+        for (uint64_t j = 0; j < bt.count; ++j) {
+            const uint64_t n = blob_lengths[bt.first + j];
+            const uint8_t* src = blobs_host[bt.first + j];
+            if (n) {
+                if (run_len && src == run_src + run_len && at == run_dst + run_len) {
+                    run_len += n;
+                } else {
+                    if (!flush()) return false;
+                    run_src = src; run_dst = at; run_len = n;
+                }
+            }
+            at += (n + 15) & ~15ull;
+        }
+        if (!flush()) return false;
+        return hip_ok(hipEventRecord(landed[bi & 1], copy_st), "event record");
+    };
+    uint64_t chunk_base = 0;
+    bool too_small = false;
+    if (!upload(0)) { cleanup(); return rc; }
+    for (size_t bi = 0; bi < batches.size() && rc == YAMS_OK; ++bi) {
+        const Batch& bt = batches[bi];
+        // the buffer batch bi + 1 goes into was batch bi - 1's: its kernels and result copies have completed
+        // (every batch ends with a synchronisation of the context's stream)
+        if (bi + 1 < batches.size() && !upload(bi + 1)) break;
+        if (!hip_ok(hipStreamWaitEvent(ctx->stream, landed[bi & 1], 0), "wait")) break;
+        offs.resize(bt.count); lens.resize(bt.count);
+        uint64_t at = 0;
+        for (uint64_t j = 0; j < bt.count; ++j) {
+            offs[j] = at; lens[j] = blob_lengths[bt.first + j];
+            at += (lens[j] + 15) & ~15ull;
+        }
+        yams_ingest_result_t r;
+        rc = ingest_impl(ctx, d_buf[bi & 1], offs.data(), lens.data(), bt.count, cfg, flags, true, &r);
+        if (rc != YAMS_OK) break;
+        hipStream_t st = ctx->stream;
+        std::vector<uint64_t> first(bt.count + 1);
+        if (!hip_ok(hipMemcpyAsync(first.data(), r.blob_first, (bt.count + 1) * 8, hipMemcpyDeviceToHost, st), "results")) break;
+        if (chunk_base + r.n_chunks > chunk_cap || (r.n_chunks && (!out_chunk_offset || !out_chunk_size))) too_small = true;
+        if (!too_small && r.n_chunks) {
+            if (!hip_ok(hipMemcpyAsync(out_chunk_offset + chunk_base, r.chunk_offset, r.n_chunks * 8, hipMemcpyDeviceToHost, st), "results") ||
+                !hip_ok(hipMemcpyAsync(out_chunk_size + chunk_base, r.chunk_size, r.n_chunks * 8, hipMemcpyDeviceToHost, st), "results")) break;
+            if (out_chunk_digest && r.chunk_digest &&
+                !hip_ok(hipMemcpyAsync(out_chunk_digest + chunk_base * 32, r.chunk_digest, r.n_chunks * 32, hipMemcpyDeviceToHost, st), "results")) break;
+        }
+        if (out_blob_digest && r.blob_digest &&
+            !hip_ok(hipMemcpyAsync(out_blob_digest + bt.first * 32, r.blob_digest, bt.count * 32, hipMemcpyDeviceToHost, st), "results")) break;
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) break;
+        for (uint64_t j = 0; j <= bt.count; ++j) out_blob_first[bt.first + j] = chunk_base + first[j];
+        chunk_base += r.n_chunks;
+    }
+    cleanup();
+    if (rc != YAMS_OK) return rc;
+    if (out_n_chunks) *out_n_chunks = chunk_base;
+    if (too_small) return fail(ctx, YAMS_ERR_INVALID_ARG, "chunk arrays too small (out_n_chunks holds the required size)");
+    return YAMS_OK;
+}
+
 yams_status_t yams_sha256_batch_device(yams_accel_ctx* ctx, const uint8_t* data,
                                        const uint64_t* offsets, const uint64_t* lengths,
                                        uint64_t n_msgs, uint8_t* digests) {
