@@ -359,6 +359,7 @@ private:
                 return Error{ErrorCode::InvalidArgument, "Query embedding dimension mismatch (expected=" +
                                                              std::to_string(dim_) + ", got=" + std::to_string(q.size()) + ")"};
         if (auto s = syncMirror(); !s) return s.error();
+        if (k > YAMS_SCAN_MAX_K) return searchPeeled(queries, k, thr, diagnostics, rowMask, flags, visited, evaluated);
         std::vector<float> flat(queries.size() * dim_);
         for (size_t i = 0; i < queries.size(); ++i) std::copy(queries[i].begin(), queries[i].end(), flat.begin() + i * dim_);
         yams_scan_hit_t* hits = nullptr; uint32_t* counts = nullptr; yams_scan_diag_t diag{};
@@ -395,6 +396,47 @@ private:
             diagnostics->exactDistanceEvaluations += own ? evaluated * queries.size() : diag.exact_distance_evaluations;
             diagnostics->returnedRows = diag.returned_rows;
         }
+        return out;
+    }
+
+    // k above what one device call returns (YAMS_SCAN_MAX_K): the reference takes any k
+    // (sqlite_vec_backend.cpp:4299-4303 keeps a heap of k), callers that over-fetch for fusion or re-ranking
+    // use thousands.  Per query, rounds of at most YAMS_SCAN_MAX_K: every round excludes the rows already
+    // returned through the allow-mask, so it yields exactly the next best rows in the reference's order
+    // (similarity desc, chunk_id asc) — the concatenation IS the top k.  The vec0 engine ranks by distance and
+    // applies the similarity threshold after the cut (:4506-4510): its rounds defer the threshold.
+    Result<std::vector<std::vector<VectorRecord>>>
+    searchPeeled(const std::vector<std::vector<float>>& queries, size_t k, float thr, VectorSearchDiagnostics* diagnostics,
+                 const uint32_t* rowMask, uint32_t flags, size_t visited, size_t evaluated) {
+        const bool l2 = engine_ == VectorSearchEngine::Vec0L2;
+        const size_t words = std::max<size_t>((records_.size() + 31) / 32, 1);
+        std::vector<std::vector<VectorRecord>> out(queries.size());
+        for (size_t qi = 0; qi < queries.size(); ++qi) {
+            std::vector<uint32_t> mask(words, 0u);
+            if (rowMask) std::copy(rowMask, rowMask + words, mask.begin());
+            else for (size_t r = 0; r < records_.size(); ++r) if (alive_[r]) mask[r >> 5] |= 1u << (r & 31);
+            size_t remaining = k;
+            bool first = true;
+            while (remaining > 0) {
+                const size_t kk = std::min<size_t>(remaining, YAMS_SCAN_MAX_K);
+                auto r = searchSimilarBatchImpl({queries[qi]}, kk, thr, first ? diagnostics : nullptr, mask.data(),
+                                                flags | (l2 ? YAMS_SCAN_FLAG_DEFER_THRESHOLD : 0u), visited, evaluated);
+                if (!r) return r.error();
+                auto& got = r.value().front();
+                const size_t n = got.size();
+                for (auto& rec : got) {
+                    const size_t row = byId_.at(rec.chunk_id);
+                    mask[row >> 5] &= ~(1u << (row & 31));
+                    out[qi].push_back(std::move(rec));
+                }
+                first = false;
+                if (n < kk) break; // nothing left (above the threshold)
+                remaining -= n;
+            }
+            if (l2) out[qi].erase(std::remove_if(out[qi].begin(), out[qi].end(), [&](const VectorRecord& x) { return x.relevance_score < thr; }),
+                                  out[qi].end());
+        }
+        if (diagnostics) diagnostics->returnedRows = out.empty() ? 0 : out.back().size();
         return out;
     }
 

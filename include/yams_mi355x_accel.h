@@ -189,7 +189,9 @@ typedef struct yams_scan_corpus_s {
                                              too small for it to balance (default: the library chooses);
                                              with YAMS_SCAN_FLAG_WIDE_TILE: never take it.  Results are
                                              identical, only the kernel form differs              */
-#define YAMS_SCAN_MAX_K 1024u
+#define YAMS_SCAN_MAX_K 1024u  /* results per query and call; larger k: rounds behind the allow-mask, as
+                                  AccelVectorIndex::searchPeeled does (include/yams_accel/vector_index.hpp) */
+#define YAMS_SCAN_MAX_DIM 8192u /* the fp64 re-score stages a query and its candidate rows in LDS */
 
 typedef struct yams_scan_params_s {
     uint32_t k;                 /* results per query; 0 => empty result (:4123-4126)             */
@@ -248,7 +250,9 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ct
  *   out_rows     device [n_queries][k] int64: row_base + row ordinal; unused slots hold -1
  *   out_counts   device [n_queries] uint32
  *   out_dist     device [n_queries][k] fp32, nullable: L2 distance (YAMS_SCAN_L2 only)
- *   out_ranks    device [n_queries][k] uint32, nullable: tie rank of each hit (for shard merges)
+ *   out_ranks    device [n_queries][k] uint32, nullable: tie rank of each hit = corpus.tie_rank[row]
+ *                (the row ordinal without a rank table).  SHARD-LOCAL unless the shard's tie_rank table
+ *                holds corpus-wide ranks: see yams_scan_merge_topk_device before merging by it
  * Returns YAMS_ERR_INVALID_ARG if any query is non-finite or has norm^2 < 1e-10 (:4127-4130;
  * a batch fails as a whole, :1635-1647), or on a dimension / alignment violation.
  * The call synchronises the context's stream before returning. */
@@ -272,6 +276,11 @@ YAMS_ACCEL_API yams_status_t yams_scan_topk_host(yams_accel_ctx* ctx,
 /* k-way merge of per-shard top-k lists (the step after an RCCL all-gather): inputs are
  * device [n_shards][n_queries][k] arrays laid out exactly as yams_scan_topk_device writes them
  * (ranks nullable => row ids break ties).  Order: similarity desc / distance asc, then rank asc.
+ * in_ranks MUST be comparable ACROSS shards, i.e. positions in one corpus-wide chunk_id ordering
+ * (:4218-4223) — ranks that each shard numbered on its own (a per-shard tie_rank table, or the row
+ * ordinals a shard reports without one) order exact cross-shard ties wrongly.  Callers without a
+ * corpus-wide ranking pass in_ranks = NULL (global row ids break ties: right whenever rows were
+ * appended in chunk_id order) or use yams_scan_merge_records_device with rank_of_row.
  * For YAMS_SCAN_L2 the similarity_threshold is applied after the merge (:4508-4510). */
 YAMS_ACCEL_API yams_status_t yams_scan_merge_topk_device(
     yams_accel_ctx* ctx, uint32_t n_shards, uint32_t n_queries, const yams_scan_params_t* params,

@@ -356,6 +356,39 @@ int main(int argc, char** argv) {
             auto excl = all.searchSimilar(qv, 10, -1.0f, std::optional<std::string>("doc_5"), want); // doc_5 not a candidate
             CHECK(excl.has_value() && excl.value().empty());
         }
+        {   // k above YAMS_SCAN_MAX_K (the reference takes any k, :4299-4303): rounds behind the allow-mask must
+            // give exactly the first k of the full ordering — checked against an AllMatching search (every row,
+            // sorted by the reference's comparator) and across the round boundaries, ties included
+            std::vector<float> qv = recs[500].embedding;
+            auto full = all.searchSimilar(qv, 1, -1.0f, std::nullopt, {}, {}, nullptr, vector::ExactRowSelection::AllMatching);
+            CHECK(full.has_value() && full.value().size() == static_cast<size_t>(N));
+            for (size_t kk : {size_t(1025), size_t(2500), size_t(N + 10)}) {
+                auto big = all.searchSimilar(qv, kk, -1.0f);
+                CHECK(big.has_value() && big.value().size() == std::min<size_t>(kk, N));
+                if (big && full) {
+                    auto head = full.value(); head.resize(std::min<size_t>(kk, N));
+                    CHECK(same(big.value(), head));
+                }
+            }
+            auto thr = all.searchSimilar(qv, 3000, 0.2f);             // fewer rows above the threshold than k
+            size_t above = 0;
+            if (full) for (const auto& r : full.value()) above += r.relevance_score >= 0.2f;
+            CHECK(thr.has_value() && thr.value().size() == std::min<size_t>(above, 3000));
+            auto batch = all.searchSimilarBatch({qv, recs[3].embedding}, 1500, -1.0f);
+            CHECK(batch.has_value() && batch.value().size() == 2 && batch.value()[0].size() == 1500 && batch.value()[1].size() == 1500);
+            if (batch && full) { auto head = full.value(); head.resize(1500); CHECK(same(batch.value()[0], head)); }
+            // vec0 engine: ranked by distance, the similarity threshold applied after the cut at k (:4506-4510)
+            auto l2r = vector::createAccelVectorIndex(plugin, 32, vector::VectorSearchEngine::Vec0L2);
+            auto& l2 = *l2r.value();
+            CHECK(l2.initialize().has_value() && l2.insertVectorsBatch(recs).has_value());
+            auto near1 = l2.searchSimilar(qv, 1024, -1.0f), near2 = l2.searchSimilar(qv, 2000, -1.0f);
+            CHECK(near1.has_value() && near2.has_value() && near2.value().size() == 2000);
+            if (near1 && near2) { auto head = near2.value(); head.resize(1024); CHECK(same(near1.value(), head)); }
+            auto cut = l2.searchSimilar(qv, 2000, 0.1f);
+            size_t keep = 0;
+            if (near2) for (const auto& r : near2.value()) keep += r.relevance_score >= 0.1f;
+            CHECK(cut.has_value() && cut.value().size() == keep && keep > 0 && keep < 2000);
+        }
         auto ties = all.searchSimilar(recs[500].embedding, 2, -1.0f);
         CHECK(ties.has_value() && ties.value().size() == 2 && ties.value()[0].chunk_id == "chunk_000500" && ties.value()[1].chunk_id == "chunk_000507");
         // an id below the current maximum ends the append-order shortcut: ranks are uploaded and the

@@ -107,6 +107,22 @@ def test_reference_rejects_invalid_queries(acc):
     assert r.counts[0] == 0
 
 
+def test_large_dimensions_up_to_the_limit_and_a_clean_refusal_above(acc, oracle):
+    """The fp64 re-score stages the query and its candidate rows in LDS: every dimension up to
+    YAMS_SCAN_MAX_DIM (8192) must launch on every path (filter + re-score, widened, exhaustive), a larger
+    one is refused up front with YAMS_ERR_UNSUPPORTED instead of failing a launch somewhere inside."""
+    rng = np.random.default_rng(5)
+    for d in (4096, 8192):
+        corpus = oracle.synth_rows(50, 0, 5000, d)
+        q = oracle.synth_rows(50, 1 << 40, 2, d)
+        corpus[10:4000] = (corpus[7] * rng.uniform(0.5, 2.0, (3990, 1))).astype(np.float32)   # thousands of exact ties: widen + fallback
+        check(acc, oracle, corpus, np.stack([q[0], corpus[7]]), 50, max_queries=2)
+        check(acc, oracle, corpus[:600], q, 700, flags=FLAG_FORCE_EXACT, expect_path=1)
+    with pytest.raises(_lib.AccelError) as e:
+        run(acc, np.ones((8, 8196), np.float32), np.ones(8196, np.float32), 1, shadow=False)
+    assert e.value.status == _lib.YAMS_ERR_UNSUPPORTED
+
+
 def test_reference_large_finite_scores(acc, oracle):
     # vector_smoke_catch2_test.cpp:263-302 (reference): +-FLT_MAX/4 self match stays finite, > 0.999
     L = np.float32(np.finfo(np.float32).max / 4)

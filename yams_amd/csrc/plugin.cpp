@@ -503,7 +503,7 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
         }
     }
     // only semantic flags cross the vtable; filter selection stays with the library
-    yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT)};
+    yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_DEFER_THRESHOLD)};
     const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
     std::vector<float> scores(slots), dist(slots);
     std::vector<int64_t> rows(slots);

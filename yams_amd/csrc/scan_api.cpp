@@ -145,6 +145,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     }
     if (!out_scores || !out_rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null outputs");
     if (params->k > YAMS_SCAN_MAX_K) return fail(ctx, YAMS_ERR_UNSUPPORTED, "k exceeds YAMS_SCAN_MAX_K");
+    if (corpus->dim > YAMS_SCAN_MAX_DIM) return fail(ctx, YAMS_ERR_UNSUPPORTED, "dim exceeds YAMS_SCAN_MAX_DIM (8192)");
     if (corpus->n_rows >= (1ull << 32)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "shard must hold < 2^32 rows");
     if (corpus->n_rows > 0 && !corpus->rows) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus rows");
     if ((corpus->tie_rank == nullptr) != (corpus->rank_row == nullptr))

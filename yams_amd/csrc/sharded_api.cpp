@@ -66,7 +66,8 @@ extern "C" yams_status_t yams_scan_merge_records_device(
     const unsigned char* base = static_cast<const unsigned char*>(records);
     MergeLaunch M{};
     M.n_shards = n_shards; M.n_queries = n_queries; M.k = params->k; M.metric = params->metric;
-    M.threshold = params->similarity_threshold;
+    // (a caller that cuts its own result further — rounds of a k above YAMS_SCAN_MAX_K — defers the vec0 threshold)
+    M.threshold = (params->flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) ? -__builtin_inff() : params->similarity_threshold;
     M.in_scores = reinterpret_cast<const float*>(base + lay->scores_off);
     M.in_rows = reinterpret_cast<const int64_t*>(base + lay->rows_off);
     M.in_counts = reinterpret_cast<const uint32_t*>(base + lay->counts_off);
