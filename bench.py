@@ -657,7 +657,17 @@ def main():
     passes = 3 if (a.split_filter or 3 * k + 64 > 2047) else 1
     i8 = t8 is not None and nq > 128 and passes == 1 and diag.get("filter_tier") == 1
     if i8:
-        kname = "scan_tiles_i8h_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, 128 x 256 half tiles, two workgroups per CU, exact integer accumulate)"
+        # the library's own choice of kernel form (scan_i8_kernel.hip, i8_resident_plan), restated for the label
+        n_qt = (nq + 127) // 128
+        n_streams = (32 // n_qt) * 8 if n_qt <= 32 else 0
+        n_filter_tiles = n_tiles - n_sample
+        resident = (not a.half_tile and d % 128 == 0 and 256 <= d <= 768 and 0 < n_qt <= 32 and (32 // n_qt) * n_qt * 10 >= 32 * 9
+                    and (n_filter_tiles + 1) // 2 >= 12 * n_streams)
+        if resident:
+            kname = ("scan_tiles_i8r_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "
+                     "workgroup of eight waves per CU, wave-private row rings, strips drawn per SIMD pair, exact integer accumulate)")
+        else:
+            kname = "scan_tiles_i8h_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, 128 x 256 half tiles, two workgroups per CU, exact integer accumulate)"
         peak = PEAK_I8_MFMA_TOPS
     elif bf16 and passes == 3:
         kname = "scan_tiles_bf16v2_kernel<FILTER,COSINE,3> (v_mfma_f32_32x32x16_bf16, split hi/lo x3)"

@@ -23,6 +23,7 @@
 // first k-slabs are still on their way from HBM), so after the k loop "survives" is a sign bit: the
 // epilogue is one v_max3 tree per query block, and only lanes that hold a survivor (~1 %) look at
 // single elements.
+#include <cstdlib>
 #include <type_traits>
 
 #include "lds_dma.h"
@@ -763,7 +764,7 @@ constexpr int R_RING = 2 * 64 * I8_SLAB;           // per wave: two slabs of its
 constexpr int R_LDS = R_MAX_SLABS * R_B_SLAB + 8 * R_RING; // 160 KiB: everything a CU has
 
 template <int ABL = 0>
-__global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams) {
+__global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
 
     const uint32_t bid = blockIdx.x;
@@ -974,7 +975,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // load rides on the drain that is there anyway) and lets the slowest one come within R_WINDOW strips of
     // the one it just drew before it goes on.  Best effort: a bounded number of polls, no correctness
     // depends on it, no workgroup waits for one that is not resident.
-    constexpr uint32_t R_WINDOW = 4, R_POLLS = 4096;
+    constexpr uint32_t R_POLLS = 4096;
+    const uint32_t R_WINDOW = window;
     const uint32_t* sync_sib = pair_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
 #ifdef YAMS_ACCEL_MEASURE
     uint32_t units_read = 0;
@@ -1865,14 +1867,16 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
+    uint32_t window = 2; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; 1..8 measured: 14..19 GB from HBM per bench launch, times within noise)
 #ifdef YAMS_ACCEL_MEASURE
+    if (const char* wv = std::getenv("YAMS_ACCEL_I8R_WINDOW")) window = static_cast<uint32_t>(std::atoi(wv));
     if (rp.use && version >= 61 && version <= 68) { // ablations of the resident-query kernel
-        if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
-        else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
-        else if (version == 64) hipLaunchKernelGGL((scan_tiles_i8r_kernel<4>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
-        else if (version == 68) hipLaunchKernelGGL((scan_tiles_i8r_kernel<8>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
-        else if (version == 66) hipLaunchKernelGGL((scan_tiles_i8r_kernel<9>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
-        else hipLaunchKernelGGL((scan_tiles_i8r_kernel<7>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+        if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 64) hipLaunchKernelGGL((scan_tiles_i8r_kernel<4>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 68) hipLaunchKernelGGL((scan_tiles_i8r_kernel<8>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 66) hipLaunchKernelGGL((scan_tiles_i8r_kernel<9>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else hipLaunchKernelGGL((scan_tiles_i8r_kernel<7>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
     if (version == 40) { // the half-tile kernel where the library would pick the resident-query one (A/B runs)
@@ -1880,7 +1884,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
 #endif
-    if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams);
+    if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
 }
