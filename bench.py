@@ -661,7 +661,7 @@ def main():
         n_qt = (nq + 127) // 128
         n_streams = (32 // n_qt) * 8 if n_qt <= 32 else 0
         n_filter_tiles = n_tiles - n_sample
-        resident = (not a.half_tile and d % 128 == 0 and 256 <= d <= 768 and 0 < n_qt <= 32 and (32 // n_qt) * n_qt * 10 >= 32 * 9
+        resident = (not a.half_tile and d % 128 == 0 and 640 <= d <= 768 and 3 <= n_qt <= 8 and (32 // n_qt) * n_qt * 10 >= 32 * 9
                     and (n_filter_tiles + 1) // 2 >= 12 * n_streams)
         if resident:
             kname = ("scan_tiles_i8r_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "

@@ -22,7 +22,13 @@ for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2"
     c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
     acc.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr()); acc.synchronize()
-    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr())
+    t8 = tm8 = None     # both shadows, as the plugin's mirrors carry them ("shadows": "both")
+    if d % 64 == 0 and d >= 256:
+        t8 = torch.empty((n, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
+        acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr()); acc.synchronize()
+    view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                           rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
+                           rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
     for _ in range(2):
         diag = acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr())
     reps = 10 if n <= 1_000_000 else 4
@@ -33,8 +39,8 @@ for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2"
     rows.append({"config": name, "rows": n, "dim": d, "Q": nq, "k": k, "metric": "l2" if metric else "cosine",
                  "ms": dt * 1e3, "QPS": nq / dt, "algorithmic_TFLOPs": 2.0 * n * d * nq / dt / 1e12,
                  "corpus_GBps": n * d * 4 / dt / 1e9, "path": diag["path"], "fallbacks": diag["exact_fallback_queries"], "escalated": diag["escalated_queries"],
-                 "widened": diag["widened_queries"]})
-    del tc, tq, tb, tn
+                 "widened": diag["widened_queries"], "filter_tier": diag["filter_tier"]})
+    del tc, tq, tb, tn, t8, tm8, view
     torch.cuda.empty_cache()
 for r_ in rows:
     print(json.dumps(r_))

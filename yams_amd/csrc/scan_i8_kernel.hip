@@ -1782,9 +1782,14 @@ static ResidentPlan i8_resident_plan(const ScanLaunch& L) {
     r.n_streams = streams_x * 8u;
     r.n_units = (L.plan.n_filter_tiles + 1u) / 2u;
     if (r.n_units == 0) return r;
-    if (L.i8_form != 2) { // the library's choice (the caller's RESIDENT_QUERIES flag skips these two)
+    if (L.i8_form != 2) { // the library's choice (the caller's RESIDENT_QUERIES flag skips these)
         if (streams_x * r.n_qt * 10u < per_xcd * 9u) return r;   // more than a tenth of the CUs would idle
         if (r.n_units < 12u * r.n_streams) return r;              // short streams: the half-tile kernel balances better
+        // measured on 12.5M-row shards (scripts/dbg/c2_forms.py): the per-strip fixed cost (epilogue, drain,
+        // counters) wants >= 10 slabs per strip (dim 384: 8.6 vs 6.5 ms for half tiles; 512: equal; 640: 4 %
+        // ahead), two query tiles leave it level with half tiles, and sixteen sibling workgroups per stream
+        // (2048 queries) run at half speed
+        if (dim < 640 || r.n_qt < 3 || r.n_qt > 8) return r;
     }
     r.grid = per_xcd * 8u;
     r.use = true;
