@@ -439,7 +439,7 @@ def main():
     t8 = tm8 = None
     shadow_i8_ms = i8_mean_err = None
     if tb is not None and not a.no_i8 and d % 64 == 0 and d >= 256 and not a.f32_filter and not a.split_filter:
-        t8 = torch.empty((n, d), dtype=torch.int8, device=dev)
+        t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device=dev)
         tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
         acc.synchronize(); t_sh = time.perf_counter()
         i8_mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)

@@ -145,8 +145,10 @@ typedef struct yams_scan_corpus_s {
                                   bit-identical with and without it.                              */
     const float* rows_nsq;     /* device, nullable iff rows_bf16 is: [n_rows] fp32 squared norms  */
     const int8_t* rows_i8;     /* device, nullable: the INT8 SHADOW built by
-                                  yams_scan_build_shadow_i8_device — [n_rows][dim] int8 =
-                                  round(unit-normalised row / s_b), 16-byte aligned, dim % 64 == 0, dim >= 256.
+                                  yams_scan_build_shadow_i8_device — YAMS_SCAN_I8_SHADOW_BYTES(n_rows,
+                                  dim) bytes of int8 = round(unit-normalised row / s_b), in the
+                                  blocked layout that call writes (opaque to callers), 16-byte
+                                  aligned, dim % 64 == 0, dim >= 256.
                                   Read by the first filter tier of cosine searches (half the bytes
                                   of the bf16 shadow, twice its matrix rate); like every filter
                                   tier it only proposes candidates, the fp64 re-score over `rows`
@@ -232,11 +234,16 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_device(yams_accel_ctx* ctx, 
  * [first_row, first_row + n_rows) — call it when those rows were uploaded or appended (the rows of a
  * block share one quantisation scale, so an append that starts inside a block re-quantises that
  * block's earlier rows too; all pointers are the BASES of the mirror's arrays, not offset ones).
- * dim must be a multiple of 64 and at least 256, rows 16-byte aligned.  out_rows_i8: [n][dim] int8; out_meta:
- * [ceil(n / 64)][2] fp32 for a mirror of n rows.  out_mean_err (host, nullable): mean residue bound
+ * dim must be a multiple of 64 and at least 256, rows 16-byte aligned.  For a mirror of n rows:
+ * out_rows_i8 holds YAMS_SCAN_I8_SHADOW_BYTES(n, dim) bytes — the shadow is padded to whole blocks of 64 rows
+ * and stored in the order the filter's DMA reads it ([row / 16][dim / 64][16 rows][64 bytes], the 16-byte
+ * chunks of a row permuted for conflict-free LDS reads): opaque, build it with this call only; out_meta:
+ * [ceil(n / 64)][2] fp32.  out_mean_err (host, nullable): mean residue bound
  * over the rebuilt blocks — a host that sees a large value (say > 0.02: heavy-tailed rows quantise
  * badly) may leave the int8 shadow out of the view and keep the bf16 one; asking for it
  * synchronises the stream. */
+#define YAMS_SCAN_I8_SHADOW_ROWS(n_rows) ((((uint64_t)(n_rows)) + 63u) / 64u * 64u)
+#define YAMS_SCAN_I8_SHADOW_BYTES(n_rows, dim) (YAMS_SCAN_I8_SHADOW_ROWS(n_rows) * (uint64_t)(dim))
 YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, const float* rows,
                                                               uint64_t first_row, uint64_t n_rows,
                                                               uint32_t dim, int8_t* out_rows_i8,

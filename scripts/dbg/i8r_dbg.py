@@ -9,7 +9,7 @@ acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 def one(n, d, nq, k, flags):
     tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(35, 0, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(35, 1 << 40, nq, d, tq.data_ptr())
-    t8 = torch.empty((n, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
+    t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
     acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr()); acc.synchronize()
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
     s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")

@@ -52,7 +52,7 @@ for case in range(a.cases):
     forms = ["default", "wide", "exact"]
     view8 = None
     if metric == SCAN_COSINE and d % 64 == 0 and d >= 256:   # the int8 tier: a view that carries only the int8 shadow
-        t8 = torch.empty((n, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
+        t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
         acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr())
         view8 = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
                                 rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())

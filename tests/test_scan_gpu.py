@@ -19,6 +19,20 @@ pytestmark = pytest.mark.gpu
 TOL = 0.0  # similarities must be bit-identical; the north_star tolerance would be 1e-5
 
 
+def unblock_i8_shadow(t8, d):
+    """The int8 shadow as row-major [padded rows][d]: it is stored blocked — [row / 16][slab][16 rows][4 positions]
+    [16 B], position p of row r holding chunk p ^ swz(r), swz = (0, 2, 3, 1)[(r >> 2) & 3] (scan_i8_kernel.hip,
+    i8_blocked_offset)."""
+    import torch
+    npad = t8.numel() // d
+    blocked = t8.view(npad // 16, d // 64, 16, 4, 16)
+    rowmajor = torch.empty((npad // 16, 16, d // 64, 4, 16), dtype=torch.int8, device=t8.device)
+    for g, sw in enumerate((0, 2, 3, 1)):
+        for p in range(4):
+            rowmajor[:, 4 * g:4 * g + 4, :, p ^ sw, :] = blocked[:, :, 4 * g:4 * g + 4, p, :].permute(0, 2, 1, 3)
+    return rowmajor.reshape(npad, d)
+
+
 def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0,
         shadow=True, mask=None):
     """shadow=True: the corpus view carries the bf16 filter shadow, as the plugin's device mirror
@@ -33,7 +47,7 @@ def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank
         db, dn = acc.alloc(corpus.size * 2), acc.alloc(corpus.shape[0] * 4)
         acc.build_shadow_device(dc.ptr, corpus.shape[0], corpus.shape[1], db.ptr, dn.ptr)
     if shadow in ("i8", "both") and corpus.size and corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256:
-        d8, dm8 = acc.alloc(corpus.size), acc.alloc((corpus.shape[0] + 15) // 16 * 8)
+        d8, dm8 = acc.alloc(_lib.i8_shadow_rows(corpus.shape[0]) * corpus.shape[1]), acc.alloc((corpus.shape[0] + 15) // 16 * 8)
         acc.build_shadow_i8_device(dc.ptr, corpus.shape[0], corpus.shape[1], d8.ptr, dm8.ptr)
     dmask, n_allowed = None, 0
     if mask is not None:
@@ -573,7 +587,7 @@ def test_sharded_search_behind_one_c_call(oracle, n_shards, layout, metric):
         dr, di = a.to_device(local_rank), a.to_device(inv)
         d8 = dm8 = None
         if metric == SCAN_COSINE:
-            d8, dm8 = a.alloc(part.size), a.alloc((len(glob) + 15) // 16 * 8)
+            d8, dm8 = a.alloc(_lib.i8_shadow_rows(len(glob)) * d), a.alloc((len(glob) + 15) // 16 * 8)
             a.build_shadow_i8_device(dc.ptr, len(glob), d, d8.ptr, dm8.ptr)
         keep += [dc, dr, di, d8, dm8]
         views.append(a.corpus_view(dc.ptr, len(glob), d, dr.ptr, di.ptr, rows_i8_ptr=d8.ptr if d8 else None,
@@ -623,13 +637,13 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     assert (tb[:4096].float() - unit).abs().max().item() <= 2.0 ** -8 * unit.abs().max().item() * 1.01
     t8 = tm8 = None
     if metric == SCAN_COSINE and d % 64 == 0 and d >= 256:   # the int8 shadow: first filter tier of cosine batches > 128 queries
-        t8 = torch.empty((n, d), dtype=torch.int8, device="cuda")
+        t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device="cuda")
         tm8 = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
         mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
         assert 0.0 < mean_err < 0.006                      # uniform components: ~ sqrt(3) / (127 sqrt(12)) = 0.0039
         unit8 = (tc[:4096].double() / n64.sqrt()[:, None])
         sc8 = tm8[:64, 0].double().repeat_interleave(64)[:, None]        # one scale per block of 64 rows
-        recon = t8[:4096].double() * sc8
+        recon = unblock_i8_shadow(t8[:4096], d).double() * sc8
         assert ((unit8 - recon).norm(dim=-1) <= tm8[:64, 1].double().repeat_interleave(64)).all()    # e_b bounds the measured residues
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
                            rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
@@ -822,8 +836,9 @@ def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
     corpus[1001] *= np.float32(7.0)                     # a row with a different largest component
     tc = torch.from_numpy(corpus).cuda()
     nb = (n + 63) // 64
-    a8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); am = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
-    b8 = torch.zeros((n, d), dtype=torch.int8, device="cuda"); bm = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    npad = nb * 64                                       # the shadow is padded to whole 64-row blocks (YAMS_SCAN_I8_SHADOW_ROWS)
+    a8 = torch.full((npad, d), 99, dtype=torch.int8, device="cuda"); am = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    b8 = torch.full((npad, d), 99, dtype=torch.int8, device="cuda"); bm = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
     acc.build_shadow_i8_device(tc.data_ptr(), n, d, a8.data_ptr(), am.data_ptr())
     first = 0
     for step in (1000, 1, 7, 2995, 1000):               # 1000 and 1001 fall inside a block
@@ -832,6 +847,11 @@ def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
     assert first == n
     acc.synchronize()
     assert torch.equal(a8, b8) and torch.equal(am, bm)
+    # the shadow is stored blocked — [row / 16][slab][16 rows][4 positions][16 B], position p of row r holding
+    # chunk p ^ swz(r), swz = (0, 2, 3, 1)[(r >> 2) & 3] (scan_i8_kernel.hip, i8_blocked_offset): undo it
+    a8 = unblock_i8_shadow(a8, d)
+    assert (a8[n:] == 0).all()                           # padding rows are defined (zero)
+    a8 = a8[:n]
     unit = tc.double() / tc.double().norm(dim=-1, keepdim=True)
     sc = am[:, 0].double().repeat_interleave(64)[:n, None]
     assert ((unit - a8.double() * sc).norm(dim=-1) <= am[:, 1].double().repeat_interleave(64)[:n]).all()

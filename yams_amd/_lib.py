@@ -22,6 +22,11 @@ FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG
 FLAG_WIDE_TILE = 32
 FLAG_NO_I8_FILTER = 64
 FLAG_RESIDENT_QUERIES = 128
+
+
+def i8_shadow_rows(n_rows: int) -> int:
+    """YAMS_SCAN_I8_SHADOW_ROWS: the int8 shadow is padded to whole blocks of 64 rows."""
+    return (int(n_rows) + 63) // 64 * 64
 TIER_NONE, TIER_I8, TIER_BF16, TIER_SPLIT, TIER_F32 = range(5)
 CDC_FLAG_GENERIC_KERNEL = 1
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2

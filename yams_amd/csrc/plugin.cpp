@@ -339,7 +339,7 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         (void)hipMemGetInfo(&dev_free, &dev_total);
         if (!s.rows.ensure(now * rb, ShardStore::share(dev_total, 0))) return internal_error("append:1");
         if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) return internal_error("append:2");
-        if (i8 && (!s.i8.ensure(now * rb / 4, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
+        if (i8 && (!s.i8.ensure((now + 63) / 64 * 64 * rb / 4 /* whole 64-row blocks: the shadow is stored blocked */, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
     }
     // copy: runs of consecutive global rows inside one stripe are consecutive local rows
     for (uint64_t r = n0; r < n1;) {

@@ -10,7 +10,7 @@ struct ScanArgs {
     const float* rows;      // [n_rows][dim]
     const uint16_t* rows_bf16; // nullable shadow: [n_rows][dim] RNE bf16 of rows
     const float* rows_nsq;     // with it: [n_rows] fp32 squared norms
-    const int8_t* rows_i8;     // nullable INT8 shadow: [n_rows][dim] round(unit row / s_r)
+    const int8_t* rows_i8;     // nullable INT8 shadow: round(unit row / s_b), blocked (i8_blocked_offset), padded to 64 rows
     const float* rows_i8_meta; // with it: [ceil(n_rows / 64)][2] = {s_b, e_b} per block of 64 rows
     const int8_t* q_i8;        // [dim/64][q_pad][64] int8 queries of the batch (int8 tier, k-slab-major)
     const float* q_meta;       // [q_pad][4] = {t_q, c_q, f_q, 0}

@@ -50,6 +50,19 @@ __device__ __forceinline__ int i8_swz(int row) {
     return (((j ^ (j >> 1)) & 1) << 1) | (j >> 1);
 }
 
+// The int8 shadow in memory = the LDS image of its DMA pieces: [row / 16][slab][16 rows][4 positions][16 B],
+// position p of row r holding the row's logical chunk p ^ i8_swz(r).  A piece (16 rows x one 64-byte slab) is
+// one contiguous KiB — eight full 128-byte lines — and lane i of the wave that stages it fetches bytes
+// [16 i, +16): with the rows stored row-major a piece was sixteen 64-byte segments, i.e. half of every line it
+// touched belonged to the neighbouring slab, and the row stream cost twice the L2 -> L1 line traffic (measured
+// on the bench shard, same kernel: 8.4-8.6 ms row-major, 7.7 ms blocked, identical results).  The shadow is
+// padded to whole blocks of 64 rows (one quantisation scale = four pieces).
+__host__ __device__ __forceinline__ uint64_t i8_blocked_offset(uint64_t row, uint32_t col, uint32_t dim) {
+    const uint32_t j = static_cast<uint32_t>(row & 15u), slab = col >> 6, chunk = (col >> 4) & 3u;
+    const uint32_t g = (j >> 2) & 3u, swz = (((g ^ (g >> 1)) & 1u) << 1) | (g >> 1);
+    return ((row >> 4) * (dim >> 6) + slab) * 1024u + j * 64u + ((chunk ^ swz) << 4) + (col & 15u);
+}
+
 // -T(row block, query) for T = A_lo IS_b - B_hi G_b - 2: what an accumulator starts at.  A_lo / B_hi
 // carry the relative slack for this fp32 evaluation, the 2 covers the truncation towards zero of the
 // conversion; clamped to +-2^30 (-2^30 = nothing survives, +2^30 = everything does — |xi . qi| <=
@@ -59,339 +72,6 @@ __device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, floa
     return static_cast<int>(__builtin_amdgcn_fmed3f(t, -1.0737418e9f, 1.0737418e9f));
 }
 
-#ifdef YAMS_ACCEL_MEASURE
-// The first form of this kernel (whole 256 x 256 tiles, eight waves, one workgroup per CU): kept in the
-// measurement build for A/B runs (scripts/filter_ablation.py i8:30); the product launches the half-tile
-// form below.
-// per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
-// MODE_SAMPLE writes dense upper bounds + group maxima (groups of 16 rows: the rows one lane holds
-// for a query block — 4 row blocks x 4 consecutive rows — see collect_sample_kernel, layout 1).
-template <int MODE, int ABL = 0>
-__global__ __launch_bounds__(I8_THREADS, 2) void scan_tiles_i8_kernel(ScanArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[I8_NST * I8_STAGE];
-    __shared__ uint32_t wave_log[8]; // survivors each wave has logged (wave-private slots)
-
-    const uint32_t bid = blockIdx.x;
-    const uint32_t xcd = bid & 7u;
-    const uint32_t w = bid >> 3;
-    const uint32_t qt = w % a.n_qtiles;
-    const uint32_t sel = (w / a.n_qtiles) * 8u + xcd;
-    if (sel >= a.n_sel_tiles) return;
-    uint32_t tile;
-    if (MODE == MODE_SAMPLE) tile = sel * a.stride;
-    else tile = sel + sel / (a.stride - 1u) + 1u;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) x queries [128 wc, +128)
-    const int l15 = lane & 15, lq = lane >> 4;
-    const uint64_t row0 = static_cast<uint64_t>(tile) * I8_ROWS;
-    const uint32_t q0 = qt * I8_QUERIES;
-    const uint32_t dim = a.dim;
-    const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
-    if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
-
-    // ---- DMA sources: every wave stages 32 rows and 32 queries per slab (4 pieces of 1 KiB) -------
-    uint32_t voffA[2], voffB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ i8_swz(rowA);
-        uint64_t r = row0 + rowA;
-        if (r >= a.n_rows) r = a.n_rows - 1; // row0 < n_rows
-        voffA[i] = static_cast<uint32_t>(r - row0) * dim + c * 16u;
-        voffB[i] = static_cast<uint32_t>(rowA) * 64u + c * 16u;
-    }
-    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + row0 * dim);
-    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
-    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
-    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
-        (__attribute__((address_space(3))) unsigned char*)lds));
-    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
-    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + I8_A_BYTES + wid * 2048);
-    auto piece = [&](int s, int p) __attribute__((always_inline)) {
-        if ((ABL == 1) && s >= I8_NST) return; // measurement build: no refills after the prologue
-        const uint32_t st = (s & (I8_NST - 1)) * I8_STAGE;
-        if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + st + p * 1024);
-        else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + st + (p - 2) * 1024);
-    };
-
-    i32x4v acc[4][8];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
-
-    // fragment offsets inside a stage: row block rb adds rb * 1 KiB, query block cb adds cb * 1 KiB
-    // (block starts are multiples of 16 rows, so the swizzle term depends on the lane only)
-    const int offA = (wr * 64 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
-    const int offB = I8_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
-
-    // epilogue inputs, requested now (older than every DMA piece, so the counted waits stay valid;
-    // the compiler waits for them at their first use, after the loop): a load issued at the end would
-    // sit on the critical path of every tile — the block scales stream from HBM
-    const uint64_t strip = row0 + static_cast<uint32_t>(wr * 64);
-    float sb, eb;                       // wave-uniform: scale and residue bound of this wave's 64 rows
-    {
-        const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
-        const uint64_t blk = strip / I8_BLOCK_ROWS;
-        const float2 m = blk < n_blocks ? reinterpret_cast<const float2*>(a.rows_i8_meta)[blk] : make_float2(1.f, 0.f);
-        sb = m.x; eb = m.y;
-    }
-    // The per-query threshold halves {A_lo, B_hi}: loaded from inline asm so that the compiler does
-    // not wait for them with a conservative vmcnt(0) (it cannot see the DMA pieces that follow); they
-    // are older than every piece, so "at most 14 younger operations outstanding" means they landed.
-    typedef float qthr_t __attribute__((ext_vector_type(2)));
-    qthr_t qthr[8];
-    constexpr bool THR = MODE == MODE_FILTER && (ABL == 0 || ABL == 8);
-    if (THR) {
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const float* p = a.q_thr + 2ull * (q0 + wc * 128 + cb * 16 + l15); // < q_pad: the table is padded
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[cb]) : "v"(p) : "memory");
-        }
-    }
-
-    auto wait_vm = [&](int pieces) __attribute__((always_inline)) {
-        if (pieces >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (pieces >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (pieces >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    {   // prologue: slabs 0..2 and the first half of slab 3 in flight, slab 0 landed
-        int issued = 0;
-        for (int s = 0; s < 3 && s < nslab; ++s) { for (int p = 0; p < 4; ++p) piece(s, p); issued += 4; }
-        if (nslab > 3) { piece(3, 0); piece(3, 1); issued += 2; }
-        if (THR) {
-            // accumulators start at -T(row block, query block) while the slabs are in flight
-            asm volatile("s_waitcnt vmcnt(14)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
-                                                 "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
-            const float is = 1.0f / sb, g = eb * is;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const int nt = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
-            }
-        }
-        wait_vm(issued - 4);
-        __builtin_amdgcn_s_barrier();
-    }
-    // Fragments: A (4 row blocks) double-buffered across slabs, B in two halves of 4 query blocks.
-    i32x4v fa[2][4], fb[2][4];
-    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(lds, offA + rb * 1024);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offB + cb * 1024);
-    int stage = 0;
-
-    // One slab = two halves of 16 MFMAs (all four row blocks x four query blocks each).
-    //   half 1: multiplies fa[cur] x fb[0]; requests the other four query blocks of THIS slab (fb[1])
-    //           and issues the second half of slab s+3's DMA pieces (its stage was released by the
-    //           barrier of the previous iteration);
-    //   barrier: slab s+1 has landed, every wave is done reading slab s;
-    //   half 2: multiplies fa[cur] x fb[1]; requests slab s+1's row blocks (fa[nxt]) and first four
-    //           query blocks (fb[0]) and issues the first half of slab s+4's pieces.
-    // Loads and DMA pieces sit one per MFMA gap; the steady-state body is one basic block.
-    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rb = i >> 2, c = i & 3;
-            if (ABL != 2)
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
-            else if (i == 0)
-                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
-            __builtin_amdgcn_sched_barrier(0);
-            filler(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    // REM = slabs left including this one (5 = five or more): decides which DMA halves are still to be
-    // issued, how many newer slabs may be in flight at the barrier, and whether a next slab exists.
-    // CUR = which of the two row-fragment buffers this slab uses (compile time: a runtime index would
-    // push the fragment arrays into scratch memory).
-    auto body = [&](int s, auto cur_tag, auto rem_tag) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_tag)::value;
-        constexpr int REM = decltype(rem_tag)::value;
-        constexpr bool H1 = REM >= 4;                  // slab s+3 exists: issue its second half
-        constexpr bool H2 = REM >= 5;                  // slab s+4 exists: issue its first half
-        constexpr int VM = REM >= 4 ? 2 : (REM == 3 ? 1 : 0);
-        constexpr bool MORE = REM >= 2;
-        const unsigned char* base = lds + stage * I8_STAGE;
-        stage = (stage + 1) & (I8_NST - 1);
-        const unsigned char* nbase = lds + stage * I8_STAGE;
-        pin4(fa[CUR]); pin4(fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[CUR], fb[0], 0, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fb[1][i < 4 ? i : 0] = ld(base, offB + (4 + (i < 4 ? i : 0)) * 1024);
-            if (H1 && (i == 6 || i == 12)) piece(s + 3, i == 6 ? 2 : 3);
-        });
-        if (VM == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (VM == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        pin4(fb[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[CUR], fb[1], 4, [&](int i) __attribute__((always_inline)) {
-            if (MORE && i < 4) fa[CUR ^ 1][i < 4 ? i : 0] = ld(nbase, offA + (i < 4 ? i : 0) * 1024);
-            if (MORE && i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(nbase, offB + ((i - 4) & 3) * 1024);
-            if (H2 && (i == 9 || i == 13)) piece(s + 4, i == 9 ? 0 : 1);
-        });
-    };
-    using R5 = std::integral_constant<int, 5>;
-    using R4 = std::integral_constant<int, 4>;
-    using R3 = std::integral_constant<int, 3>;
-    using R2 = std::integral_constant<int, 2>;
-    using R1 = std::integral_constant<int, 1>;
-    // nslab >= 4 (dim >= 256, checked by the host).  The last four slabs have their own bodies; the
-    // nslab - 4 steady-state slabs run two per trip with the buffer parity fixed at compile time.  An
-    // odd count runs one steady body first and then renames the prefetched row fragments into buffer
-    // 0, so that a single code path leads into the pair loop and the tail (several alternative paths
-    // of unrolled bodies made the register allocator spill the accumulators).
-    const int n_steady = nslab - 4;
-    int s = 0;
-    if (n_steady & 1) {
-        body(0, C0{}, R5{});
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) fa[0][rb] = fa[1][rb];
-        s = 1;
-    }
-    for (; s < n_steady; s += 2) { body(s, C0{}, R5{}); body(s + 1, C1{}, R5{}); }
-    body(s, C0{}, R4{}); body(s + 1, C1{}, R3{}); body(s + 2, C0{}, R2{}); body(s + 3, C1{}, R1{});
-
-    if (ABL != 0 && ABL != 8) { // measurement builds: keep the accumulators alive, emit nothing
-        int t = 0;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
-        if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
-        return;
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------------------
-    // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
-    const uint32_t qb = q0 + wc * 128;
-    if (MODE == MODE_SAMPLE) {
-        const float ninf = -__builtin_inff();
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const uint32_t qi = qb + cb * 16 + l15;
-            const bool qok = qi < a.n_queries;
-            const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
-            float m = ninf;
-            const float S = sb * qm.x, K = fmaf(eb, qm.y, qm.z);
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const uint64_t rbase = strip + 16 * rb + 4 * lq;
-                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
-                    v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
-                    m = fmaxf(m, v[r]);
-                }
-                if (qok) {
-                    const uint64_t srow = static_cast<uint64_t>(sel) * I8_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
-                    *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-            if (qok) {
-                const uint32_t gid = (sel * I8_ROWS + static_cast<uint32_t>(wr * 64)) / 16u + lq;
-                a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
-            }
-        }
-        return;
-    }
-    // FILTER: the accumulators hold I - T, a survivor is a non-negative one
-    uint32_t hot = 0;
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        int m = acc[0][cb][0];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-        if (m >= 0 && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
-    }
-    if (hot == 0) return; // ~99 % of the lanes
-    // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
-    // per query block (all of them issued before the first store), then the stores
-    uint32_t pass[8];
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        pass[cb] = 0u;
-        if ((hot >> cb) & 1u) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const uint64_t rbase = strip + 16 * rb + 4 * lq;
-                const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (acc[rb][cb][r] >= 0 && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
-            }
-        }
-    }
-    if (ABL == 8) { // measurement build: the whole epilogue up to here, but nothing is emitted
-        uint32_t t = 0;
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
-        if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
-        return;
-    }
-    // Survivors go to this wave's region of the log: slots come from an LDS counter (a ~100-cycle round
-    // trip; a returning GLOBAL atomic per query block took microseconds at the end of every tile), the
-    // stores are fire-and-forget.  i8_log_gather_kernel moves the log into the per-query lists.
-    uint32_t mine = 0;
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) mine += static_cast<uint32_t>(__builtin_popcount(pass[cb]));
-    uint32_t pos = mine ? atomicAdd(&wave_log[wid], mine) : 0u;
-    const uint64_t region = (static_cast<uint64_t>(bid) * 8u + static_cast<uint32_t>(wid)) * a.log_cap;
-    // An entry is (accumulator, row) + the query: no global load sits between the k loop and the end of
-    // the tile; the gather kernel turns the accumulator back into the score bound u.
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        if (!pass[cb]) continue;
-        const uint32_t qi = qb + cb * 16 + l15;
-        bool lost = false;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
-                const uint64_t row = strip + 16 * rb + 4 * lq + r;
-                if (pos < a.log_cap) {
-                    a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(acc[rb][cb][r])) << 32) | static_cast<uint32_t>(row);
-                    a.log_q[region + pos] = qi;
-                } else {
-                    lost = true;
-                }
-                ++pos;
-            }
-        }
-        if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path (no return value used)
-    }
-    // the wave's total (all hot lanes ran the LDS add in the same instruction): one lane publishes it
-    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
-    if (lane == static_cast<int>(__builtin_ctzll(act))) {
-        const uint32_t total = wave_log[wid];
-        a.log_cnt[static_cast<uint64_t>(bid) * 8u + static_cast<uint32_t>(wid)] = total < a.log_cap ? total : a.log_cap;
-    }
-}
-
-#endif // YAMS_ACCEL_MEASURE
 
 // -------------------------------------------------------------------------------------------------
 // The filter on HALF tiles: 128 rows x 256 queries per workgroup of FOUR waves (wave tile still
@@ -435,22 +115,22 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
     if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
 
     // ---- DMA sources: every wave stages 32 rows (2 pieces of 1 KiB) and 64 queries (4 pieces) per slab ----
-    const uint64_t rowb = row0 < a.n_rows ? row0 : a.n_rows - 1; // loads of rows past the end read the last row
+    // Row pieces are contiguous KiBs of the blocked shadow (i8_blocked_offset); a 64-row strip of a ragged
+    // last tile that lies past the (64-row padded) end re-reads the shadow's last strip.
+    const uint64_t padded_rows = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS * I8_BLOCK_ROWS;
+    const uint32_t piece_row_stride = static_cast<uint32_t>(nslab) * 1024u;
+    uint64_t stripA = row0 + static_cast<uint32_t>(wid >> 1) * 64u;   // the 64-row strip this wave's two pieces belong to
+    if (stripA >= padded_rows) stripA = padded_rows - 64;
     uint32_t voffA[2], voffB[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ i8_swz(rowA);
-        uint64_t r = row0 + rowA;
-        if (r >= a.n_rows) r = a.n_rows - 1;
-        voffA[i] = static_cast<uint32_t>(r - rowb) * dim + c * 16u;
-    }
+    for (int i = 0; i < 2; ++i)
+        voffA[i] = static_cast<uint32_t>(((wid & 1) * 2 + i)) * piece_row_stride + static_cast<uint32_t>(lane) * 16u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rowB = (wid * 4 + i) * 16 + (lane >> 2);
         voffB[i] = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(rowB)) * 16u;
     }
-    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + rowb * dim);
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.rows_i8) + (stripA / 16) * piece_row_stride; // (wave-uniform)
     const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
     const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
@@ -463,7 +143,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
         if (ABL == 5 && s >= H_NST && p >= 2) return;     // measurement build: row pieces only (queries "resident")
         if (ABL == 6 && s >= H_NST && p < 2) return;      // measurement build: query pieces only
         const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
-        if (p < 2) lds_dma16_s(baseA + s * I8_SLAB, voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
+        if (p < 2) lds_dma16_s(baseA + s * 1024, voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
         else lds_dma16_s(baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
     };
 
@@ -792,19 +472,15 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     const uint64_t past_end = n_blocks * I8_BLOCK_ROWS;
 
     // ---- where this wave's strip of a unit lives ----------------------------------------------------
-    // A DMA piece = 16 rows x 64 bytes; lane i fetches 16 bytes of row i >> 2.  Byte offset of that
-    // row from the strip's base: (16 rb + prow) dim, clamped so that rows past the end of the shard read
-    // its last row (only the last unit can be ragged): ONE per-lane register for all pieces and units
-    // plus one clamp value per unit.
+    // The shadow is stored as the LDS image of its DMA pieces (i8_blocked_offset): a piece — 16 rows x one
+    // 64-byte slab — is ONE contiguous KiB, lane i fetches bytes [16 i, +16).  A strip is 64 rows = four
+    // consecutive 16-row blocks; strips never straddle the end of the (64-row padded) shadow.
     struct Geo {
         uint64_t row0;               // first row of the strip; >= n_rows when the strip does not exist
-        const unsigned char* base;   // DMA source base (uniform): the strip's first row (or the shard's last)
-        uint32_t limp;               // per lane: largest admissible offset + the lane's chunk offset
+        const unsigned char* base;   // first piece of the strip (uniform); an absent strip reads the last one
     };
-    const int prow = lane >> 2;
-    const uint32_t pchunk = ((lane & 3) ^ i8_swz(prow)) * 16u;
-    const uint32_t vlin0p = static_cast<uint32_t>(prow) * dim + pchunk;
-    const uint32_t dim16 = dim * 16u;
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    const uint32_t piece_row_stride = static_cast<uint32_t>(nslab) * 1024u; // bytes between the pieces of consecutive 16-row blocks
     // Strip k of this wave's PAIR (waves w and w + 4 share a SIMD and a strip sequence, see "work sharing"
     // below): unit (k >> 1) of the stream, tile (k & 1) of that unit, rows [64 (w & 3), +64) of the tile.
     auto unit_of = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t { return stream + (k >> 1) * n_streams; };
@@ -817,16 +493,13 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             row0 = static_cast<uint64_t>(tile) * I8_ROWS + static_cast<uint32_t>((wid & 3) * 64);
         }
         g.row0 = row0;
-        const uint64_t rowb = row0 < a.n_rows ? row0 : a.n_rows - 1;
-        const uint64_t room = a.n_rows - 1 - rowb;                         // rows after the base row
-        g.limp = static_cast<uint32_t>(room < 63 ? room : 63) * dim + pchunk;
-        g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + rowb * dim;
+        const uint64_t rowb = row0 < past_end ? row0 : past_end - 64; // (n_rows >= 4096 on this path)
+        g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + (rowb / 16) * piece_row_stride;
     };
-    // row piece rb of slab ss of the strip at `src` into ring stage P
-    auto piece = [&](const unsigned char* sbase, uint32_t limp, int ss, int P, int rb) __attribute__((always_inline)) {
-        uint32_t off = vlin0p + static_cast<uint32_t>(rb) * dim16;
-        off = off < limp ? off : limp;
-        lds_dma16_s(sbase + ss * I8_SLAB, off, ringW + P * 4096 + rb * 1024);
+    // row piece rb of slab ss of the strip at `sbase` into ring stage P
+    auto piece = [&](const unsigned char* sbase, int ss, int P, int rb) __attribute__((always_inline)) {
+        lds_dma16_s(sbase + static_cast<uint32_t>(rb) * piece_row_stride + static_cast<uint32_t>(ss) * 1024u, lane16,
+                    ringW + P * 4096 + rb * 1024);
     };
     typedef float f2_t __attribute__((ext_vector_type(2)));
     auto meta_ptr = [&](uint64_t row0) __attribute__((always_inline)) -> const float* {
@@ -852,8 +525,9 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // ---- prologue: the resident query tile (wave w stages 16 queries of every slab), the first two
     //      slabs of the first unit, its thresholds ---------------------------------------------------
     {
+        const int prow = lane >> 2;                        // the query of a piece this lane fetches 16 bytes of
         const int rowB = wid * 16 + prow;
-        const uint32_t voffB = static_cast<uint32_t>(rowB) * 64u + pchunk; // i8_swz(rowB) == i8_swz(prow)
+        const uint32_t voffB = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(prow)) * 16u; // i8_swz(rowB) == i8_swz(prow)
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
         const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
         for (int s = 0; s < nslab; ++s)
@@ -887,7 +561,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) piece(cur.base, cur.limp, s, s, rb);
+        for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     qthr_request();
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
@@ -932,11 +606,11 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     //           stage with the slab THREE ahead: a stage is empty for a third of a slab instead of a whole
     //           one, so a piece has 1.6 slabs to land instead of 1.2 (the ring is what bounds the loop: 8 KiB
     //           in flight per wave against ~1 us of loaded L2 -> LDS latency).
-    // `sbase` / `slimp` / `ss` name the strip and slab the DMA pieces belong to, `sn` the next slab of the query
+    // `sbase` / `ss` name the strip and slab the DMA pieces belong to, `sn` the next slab of the query
     // tile, `early` the first two slabs of a strip: slabs 1 and 2 landed before the strip began (the drain in
     // front of the thresholds), so they wait for no DMA, and the survivor stores of the previous strip's
     // epilogue — in the same in-order counter — get two slabs to complete before a counted wait looks at them.
-    auto body = [&](int sn, bool early, const unsigned char* sbase, uint32_t slimp, int ss, int s, auto par_tag) __attribute__((always_inline)) {
+    auto body = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
         const unsigned char* bq = lds + s * R_B_SLAB;
         const unsigned char* bqn = lds + sn * R_B_SLAB;
@@ -953,7 +627,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             if (i < 4) fa[P ^ 1][i < 4 ? i : 0] = ld(ring, (P ^ 1) * 4096 + offF + (i < 4 ? i : 0) * 1024);
             if (i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(bqn, offF + ((i - 4) & 3) * 1024);
             if (ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
-            if (ABL != 1 && i >= 11 && i < 15) piece(sbase, slimp, ss, P ^ 1, (i - 11) & 3);
+            if (ABL != 1 && i >= 11 && i < 15) piece(sbase, ss, P ^ 1, (i - 11) & 3);
         });
     };
 
@@ -963,7 +637,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) piece(cur.base, cur.limp, 2, 0, rb); // slab 2 into the stage slab 0 just left
+    for (int rb = 0; rb < 4; ++rb) piece(cur.base, 2, 0, rb); // slab 2 into the stage slab 0 just left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (a strip begins with its slabs 1 and 2 landed)
 
     // ---- pacing ------------------------------------------------------------------------------------------
@@ -1015,8 +689,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for `early`)
             const bool early = so == 0;
             const bool n0 = s + 3 >= nslab, n1 = s + 4 >= nslab;
-            body(s + 1, early, n0 ? nxt.base : cur.base, n0 ? nxt.limp : cur.limp, n0 ? s + 3 - nslab : s + 3, s, C0{});
-            body(s + 2 >= nslab ? 0 : s + 2, early, n1 ? nxt.base : cur.base, n1 ? nxt.limp : cur.limp, n1 ? s + 4 - nslab : s + 4, s + 1, C1{});
+            body(s + 1, early, n0 ? nxt.base : cur.base, n0 ? s + 3 - nslab : s + 3, s, C0{});
+            body(s + 2 >= nslab ? 0 : s + 2, early, n1 ? nxt.base : cur.base, n1 ? s + 4 - nslab : s + 4, s + 1, C1{});
             s += 2;
         } while (s < nslab);
         asm volatile("" : "+s"(meta_n)); // (every slab waits lgkmcnt(0): the scalar load has long returned)
@@ -1143,372 +817,6 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #endif
 }
 
-#ifdef YAMS_ACCEL_MEASURE
-// -------------------------------------------------------------------------------------------------
-// The PERSISTENT form of the half-tile filter: 2 workgroups per CU stay resident and walk the virtual
-// block ids bid, bid + grid, ...  The 3-stage ring runs straight through the tile boundaries: while
-// the last three slabs of a tile are multiplied, their DMA slots already carry the first slabs of the
-// NEXT tile (and its thresholds and block scale), so a tile no longer starts with an empty ring and
-// a trip to HBM — the only thing between two k loops is the epilogue.
-//   issue order around a boundary (n = next tile):  ... | n0a | n0b | n1a | n1b | thr x8, meta | n2a |
-//   tile start: s_waitcnt vmcnt(3) = everything but n2a has landed, barrier, first fragments.
-// MEASUREMENT BUILD ONLY (scripts/filter_ablation.py i8:50): on MI355X it runs the 12.5M x 768 x 1024 launch in
-// 8.87 ms against 8.90 ms for the plain half-tile kernel — with two workgroups per CU the other workgroup
-// already covers a tile's start, so the product keeps the simpler kernel.
-// Stores of the epilogue also count in vmcnt; they only make the counted waits conservative (a count
-// of N leaves at most N LOADS outstanding, and loads complete in order).
-// -------------------------------------------------------------------------------------------------
-template <int MODE, int ABL = 0>
-__global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8p_kernel(ScanArgs a, uint32_t n_virtual) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
-    __shared__ uint32_t wave_log[4]; // survivors each wave has logged in the current tile (wave-private slots)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1; // wave tile: rows [64 wr, +64) of the half tile x queries [128 wc, +128)
-    const int l15 = lane & 15, lq = lane >> 4;
-    const uint32_t dim = a.dim;
-    const int nslab = dim / I8_SLAB; // dim % 64 == 0 and dim >= 256 are preconditions of this tier
-    if (MODE == MODE_FILTER && lane == 0) wave_log[wid] = 0u;
-
-    // ---- where a virtual block lives ----------------------------------------------------------------
-    struct Geo {
-        uint32_t vb, sel, hf, q0;
-        uint64_t row0;
-        const unsigned char* baseA;
-        const unsigned char* baseB;
-        uint32_t voffA[2];
-        bool valid;
-    };
-    auto locate = [&](uint32_t vb, Geo& g, const Geo& fallback) __attribute__((always_inline)) {
-        const uint32_t xcd = vb & 7u, w = vb >> 3;
-        const uint32_t qt = w % a.n_qtiles;
-        const uint32_t sel2 = (w / a.n_qtiles) * 8u + xcd; // (selected 256-row tile, which half of it)
-        const uint32_t sel = sel2 >> 1;
-        if (vb >= n_virtual || sel >= a.n_sel_tiles) { g = fallback; g.valid = false; return; } // (its DMA slots re-read the fallback tile)
-        g.vb = vb; g.sel = sel; g.hf = sel2 & 1u; g.q0 = qt * I8_QUERIES; g.valid = true;
-        const uint32_t tile = MODE == MODE_SAMPLE ? sel * a.stride : sel + sel / (a.stride - 1u) + 1u;
-        g.row0 = static_cast<uint64_t>(tile) * I8_ROWS + g.hf * H_ROWS; // may lie past the end (ragged last tile)
-        const uint64_t rowb = g.row0 < a.n_rows ? g.row0 : a.n_rows - 1; // loads of rows past the end read the last row
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rowA = (wid * 2 + i) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ i8_swz(rowA);
-            uint64_t r = g.row0 + rowA;
-            if (r >= a.n_rows) r = a.n_rows - 1;
-            g.voffA[i] = static_cast<uint32_t>(r - rowb) * dim + c * 16u;
-        }
-        g.baseA = reinterpret_cast<const unsigned char*>(a.rows_i8 + rowb * dim);
-        g.baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(g.q0) * 64;
-    };
-
-    // ---- DMA: every wave stages 32 rows (2 pieces of 1 KiB) and 64 queries (4 pieces) per slab --------
-    uint32_t voffB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rowB = (wid * 4 + i) * 16 + (lane >> 2);
-        voffB[i] = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(rowB)) * 16u;
-    }
-    const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
-    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
-        (__attribute__((address_space(3))) unsigned char*)lds));
-    const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds0 + wid * 2048);
-    const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds0 + H_A_BYTES + wid * 4096);
-    // piece p of slab s of tile g into ring stage `st` (0..2): p = 0, 1 rows, p = 2..5 queries
-    auto piece = [&](const Geo& g, int s, int st, int p) __attribute__((always_inline)) {
-        const uint32_t so = static_cast<uint32_t>(st) * H_STAGE;
-        if (p < 2) lds_dma16_s(g.baseA + s * I8_SLAB, g.voffA[p < 2 ? p : 0], ldsA + so + p * 1024);
-        else lds_dma16_s(g.baseB + s * qslab_bytes, voffB[p >= 2 ? p - 2 : 0], ldsB + so + (p - 2) * 1024);
-    };
-    // the thresholds {A_lo, B_hi} of this lane's eight queries and the block scale {s_b, e_b} of the wave's
-    // 64 rows: loaded from inline asm (the compiler would wait for them with a vmcnt(0) that drains the ring)
-    typedef float f2_t __attribute__((ext_vector_type(2)));
-    f2_t qthr[8], meta;
-    constexpr bool THR = MODE == MODE_FILTER && (ABL == 0 || ABL == 8);
-    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
-    auto thr_load = [&](const Geo& g, int i) __attribute__((always_inline)) {
-        if (i < 8) {
-            if (!THR) return;
-            const float* p = a.q_thr + 2ull * (g.q0 + wc * 128 + i * 16 + l15); // < q_pad: the table is padded
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[i < 8 ? i : 0]) : "v"(p) : "memory");
-        } else {
-            uint64_t blk = (g.row0 + static_cast<uint32_t>(wr * 64)) / I8_BLOCK_ROWS;
-            if (blk >= n_blocks) blk = n_blocks - 1; // a strip past the end: nothing of it is ever emitted
-            const float* p = a.rows_i8_meta + 2ull * blk;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(meta) : "v"(p) : "memory");
-        }
-    };
-
-    // fragment offsets inside a stage: row block rb adds rb * 1 KiB, query block cb adds cb * 1 KiB
-    // (block starts are multiples of 16 rows, so the swizzle term depends on the lane only)
-    const int offA = (wr * 64 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
-    const int offB = H_A_BYTES + (wc * 128 + l15) * 64 + ((lq ^ i8_swz(l15)) << 4);
-
-    i32x4v acc[4][8];
-    i32x4v fa[2][4], fb[2][4];
-    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v { return *reinterpret_cast<const i32x4v*>(base + off); };
-    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rb = i >> 2, c = i & 3;
-            if (ABL != 2)
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
-            else if (i == 0)
-                asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
-            __builtin_amdgcn_sched_barrier(0);
-            filler(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using R4 = std::integral_constant<int, 4>;
-    using R3 = std::integral_constant<int, 3>;
-    using R2 = std::integral_constant<int, 2>;
-    using R1 = std::integral_constant<int, 1>;
-
-    Geo cur, nxt;
-    locate(blockIdx.x, cur, cur);
-    if (!cur.valid) return; // (grid <= n_virtual; a padded id can only be a workgroup's first)
-    int stage = 0;
-    {   // first tile: thresholds, block scale, slabs 0 and 1 and the first half of slab 2
-        for (int i = 0; i < 9; ++i) thr_load(cur, i);
-        for (int s = 0; s < 2; ++s) for (int p = 0; p < 6; ++p) piece(cur, s, s, p);
-        piece(cur, 2, 2, 0); piece(cur, 2, 2, 1); piece(cur, 2, 2, 2);
-    }
-
-    // One slab = two halves of 16 MFMAs (all four row blocks x four query blocks each).
-    //   half 1: multiplies fa[cur] x fb[0]; requests the other four query blocks of THIS slab (fb[1])
-    //           and issues the second half of the DMA pieces of the slab two ahead (its stage was
-    //           released by the barrier of the previous slab);
-    //   barrier: the next slab has landed (it is older than the six pieces of the one after it),
-    //           every wave is done reading this one;
-    //   half 2: multiplies fa[cur] x fb[1]; requests the next slab's row blocks (fa[nxt]) and first four
-    //           query blocks (fb[0]) and issues the first half of the pieces of the slab three ahead
-    //           into the stage this slab just left.
-    // REM = slabs of this tile left including this one (4 = four or more).  "Two / three ahead" run on
-    // into the next tile: REM 3 issues n0a in half 2, REM 2 n0b | n1a, REM 1 n1b | thresholds, scale, n2a.
-    // CUR = which of the two row-fragment buffers this slab uses (compile time: a runtime index would
-    // push the fragment arrays into scratch memory).
-    auto body = [&](int s, auto cur_tag, auto rem_tag) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_tag)::value;
-        constexpr int REM = decltype(rem_tag)::value;
-        constexpr bool MORE = REM >= 2;
-        const int st0 = stage;                                   // this slab (and, after the barrier, the slab three ahead)
-        const int st1 = stage == 2 ? 0 : stage + 1;              // the next slab
-        const int st2 = st1 == 2 ? 0 : st1 + 1;                  // two ahead
-        const unsigned char* base = lds + st0 * H_STAGE;
-        const unsigned char* nbase = lds + st1 * H_STAGE;
-        stage = st1;
-        pin4(fa[CUR]); pin4(fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[CUR], fb[0], 0, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fb[1][i < 4 ? i : 0] = ld(base, offB + (4 + (i < 4 ? i : 0)) * 1024);
-            if (i == 5 || i == 9 || i == 13) {
-                const int p = i == 5 ? 3 : (i == 9 ? 4 : 5);
-                if (REM >= 3) piece(cur, s + 2, st2, p); else piece(nxt, 2 - REM, st2, p);
-            }
-        });
-        if (MORE) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        pin4(fb[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[CUR], fb[1], 4, [&](int i) __attribute__((always_inline)) {
-            if (MORE && i < 4) fa[CUR ^ 1][i < 4 ? i : 0] = ld(nbase, offA + (i < 4 ? i : 0) * 1024);
-            if (MORE && i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(nbase, offB + ((i - 4) & 3) * 1024);
-            if (!MORE && i < 9) thr_load(nxt, i);
-            if (i == 9 || i == 11 || i == 13) {
-                const int p = i == 9 ? 0 : (i == 11 ? 1 : 2);
-                if (REM >= 4) piece(cur, s + 3, st0, p); else piece(nxt, 3 - REM, st0, p);
-            }
-        });
-    };
-
-    for (;;) {
-        // ---- tile start: everything but the three youngest pieces has landed ---------------------------
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
-                                            "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]), "+v"(meta) :: "memory");
-        const uint64_t strip = cur.row0 + static_cast<uint32_t>(wr * 64);
-        const bool strip_ok = strip / I8_BLOCK_ROWS < n_blocks;
-        const float sb = strip_ok ? meta[0] : 1.0f, eb = strip_ok ? meta[1] : 0.0f; // wave-uniform
-        if (THR) {
-            // accumulators start at -T(row block, query block)
-            const float is = 1.0f / sb, g = eb * is;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const int nt = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
-            }
-        } else {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
-        }
-        __builtin_amdgcn_s_barrier();
-        {
-            const unsigned char* base = lds + stage * H_STAGE;
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(base, offA + rb * 1024);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(base, offB + cb * 1024);
-        }
-        locate(cur.vb + gridDim.x, nxt, cur);
-
-        // nslab >= 4 (dim >= 256, checked by the host).  The last three slabs have their own bodies; the
-        // nslab - 3 before them run two per trip with the buffer parity fixed at compile time.  An odd
-        // count runs one body first and then renames the prefetched row fragments into buffer 0, so that
-        // a single code path leads into the pair loop and the tail.
-        const int n_steady = nslab - 3;
-        int s = 0;
-        if (n_steady & 1) {
-            body(0, C0{}, R4{});
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) fa[0][rb] = fa[1][rb];
-            s = 1;
-        }
-        for (; s < n_steady; s += 2) { body(s, C0{}, R4{}); body(s + 1, C1{}, R4{}); }
-        body(s, C0{}, R3{}); body(s + 1, C1{}, R2{}); body(s + 2, C0{}, R1{});
-
-        // ---- epilogue ------------------------------------------------------------------------------
-        // accumulator element acc[rb][cb][r]: row = strip + 16 rb + 4 lq + r, query = qb + 16 cb + l15
-        [&]() __attribute__((always_inline)) {
-            if (ABL != 0 && ABL != 8) { // measurement builds: keep the accumulators alive, emit nothing
-                int t = 0;
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
-                if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
-                return;
-            }
-            const uint32_t qb = cur.q0 + wc * 128;
-            if (MODE == MODE_SAMPLE) {
-                const float ninf = -__builtin_inff();
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb) {
-                    const uint32_t qi = qb + cb * 16 + l15;
-                    const bool qok = qi < a.n_queries;
-                    const float4 qm = reinterpret_cast<const float4*>(a.q_meta)[qi]; // {t_q, c_q, f_q, 0}
-                    float m = ninf;
-                    const float S = sb * qm.x, K = fmaf(eb, qm.y, qm.z);
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) {
-                        const uint64_t rbase = strip + 16 * rb + 4 * lq;
-                        const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
-                            v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
-                            m = fmaxf(m, v[r]);
-                        }
-                        if (qok) {
-                            const uint64_t srow = static_cast<uint64_t>(cur.sel) * I8_ROWS + cur.hf * H_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
-                            *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-                    }
-                    if (qok) {
-                        const uint32_t gid = (cur.sel * I8_ROWS + cur.hf * H_ROWS + static_cast<uint32_t>(wr * 64)) / 16u + lq;
-                        a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
-                    }
-                }
-                return;
-            }
-            // FILTER: the accumulators hold I - T, a survivor is a non-negative one
-            uint32_t hot = 0;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                int m = acc[0][cb][0];
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-                if (m >= 0 && qb + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
-            }
-            if (hot == 0) return; // ~99 % of the lanes
-            // the lane holds survivors: which elements (row bound and allow-mask checked here), one reservation
-            // for all of them, then the stores
-            uint32_t pass[8];
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                pass[cb] = 0u;
-                if ((hot >> cb) & 1u) {
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) {
-                        const uint64_t rbase = strip + 16 * rb + 4 * lq;
-                        const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (acc[rb][cb][r] >= 0 && rbase + r < a.n_rows && ((mw >> r) & 1u)) pass[cb] |= 1u << (4 * rb + r);
-                    }
-                }
-            }
-            if (ABL == 8) { // measurement build: the whole epilogue up to here, but nothing is emitted
-                uint32_t t = 0;
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb) t |= pass[cb];
-                if (t == 0x1234u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
-                return;
-            }
-            // Survivors go to this wave's region of the log: slots come from an LDS counter (a ~100-cycle round
-            // trip), the stores are fire-and-forget.  i8_log_gather_kernel moves the log into the per-query lists.
-            uint32_t mine = 0;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) mine += static_cast<uint32_t>(__builtin_popcount(pass[cb]));
-            uint32_t pos = mine ? atomicAdd(&wave_log[wid], mine) : 0u;
-            const uint64_t rix = static_cast<uint64_t>(cur.vb) * 4u + static_cast<uint32_t>(wid);
-            const uint64_t region = rix * a.log_cap;
-            // An entry is (accumulator, row) + the query; the gather kernel turns the accumulator back into the
-            // score bound u.
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                if (!pass[cb]) continue;
-                const uint32_t qi = qb + cb * 16 + l15;
-                bool lost = false;
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (!((pass[cb] >> (4 * rb + r)) & 1u)) continue;
-                        const uint64_t row = strip + 16 * rb + 4 * lq + r;
-                        if (pos < a.log_cap) {
-                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(acc[rb][cb][r])) << 32) | static_cast<uint32_t>(row);
-                            a.log_q[region + pos] = qi;
-                        } else {
-                            lost = true;
-                        }
-                        ++pos;
-                    }
-                }
-                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
-            }
-            // the wave's total (all hot lanes ran the LDS add in the same instruction): one lane publishes it
-            // and clears the counter for the next tile
-            const uint64_t act = __builtin_amdgcn_ballot_w64(true);
-            if (lane == static_cast<int>(__builtin_ctzll(act))) {
-                const uint32_t total = wave_log[wid];
-                a.log_cnt[rix] = total < a.log_cap ? total : a.log_cap;
-                wave_log[wid] = 0u;
-            }
-        }();
-        if (!nxt.valid) break;
-        cur = nxt;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
-}
-
-#endif // YAMS_ACCEL_MEASURE
 
 // Log -> per-query candidate lists.  One thread per log region.  An entry carries the accumulator
 // I - T of a survivor; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
@@ -1590,7 +898,6 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
     float emax = 0.f;
     for (int rr = 0; rr < nr; ++rr) {
         const float* src = rows + (r0 + rr) * dim;
-        int8_t* dst = out_i8 + (r0 + rr) * dim;
         const float inv = rinv[rr];
         float esq = 0.f;
         for (uint32_t c = lane * 4; c < dim; c += 256) {
@@ -1605,12 +912,15 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
                 esq = fmaf(d, d, esq);
                 packed |= (static_cast<uint32_t>(static_cast<int>(qf)) & 0xffu) << (8 * e);
             }
-            *reinterpret_cast<uint32_t*>(dst + c) = inv != 0.f ? packed : 0u;
+            *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = inv != 0.f ? packed : 0u;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) esq += __shfl_xor(esq, d);
         if (inv != 0.f) emax = fmaxf(emax, esq);
     }
+    for (int rr = nr; rr < I8_BLOCK_ROWS; ++rr) // the padding rows of the last block: defined (zero), never emitted
+        for (uint32_t c = lane * 4; c < dim; c += 256)
+            *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = 0u;
     if (lane == 0) {
         const float fd = static_cast<float>(dim);
         const float e = any ? sqrtf(emax) * (1.0f + (fd + 16.f) * 5.9604645e-8f) + (fd + 64.f) * 5.9604645e-8f : 0.f;
@@ -1819,54 +1129,17 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
 }
 
 // Half tiles (128 rows x 256 queries), XCD-aware block -> tile map as for the bf16 tier.  version:
-// measurement build only (30 = the 8-wave whole-tile kernel, 31/32/37/38 its ablations; 41 = no DMA
-// refills after the prologue, 42 = no MFMAs, 47 = the whole loop but no epilogue, 48 = no emission).
+// measurement build only — 40 = half tiles where the library would pick the resident-query form;
+// 41..48 ablations of the half-tile kernel (41 no DMA refills after the prologue, 42 no MFMAs, 43 neither,
+// 44 no fragment reads, 45 / 46 row / query pieces only, 47 no epilogue, 48 no emission); 61..68 of the
+// resident-query kernel (61 no refills, 62 no MFMAs, 64 no fragment reads, 66 no survivor stores, 67 no
+// epilogue, 68 no emission).
 hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version) {
     (void)version;
     ScanArgs a = make_scan_args(L);
     a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
-#ifdef YAMS_ACCEL_MEASURE
-    const uint32_t groups = (a.n_sel_tiles + 7) / 8;
-    const uint32_t grid = groups * a.n_qtiles * 8;
-    if (mode == MODE_FILTER && version == 38) { // the epilogue without its reservations and stores
-        hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 8>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-        return hipGetLastError();
-    }
-    if (mode == MODE_FILTER && version == 30) { // the 8-wave, whole-tile form (same log layout: 8 regions per tile)
-        hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 0>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-        return hipGetLastError();
-    }
-    if (mode == MODE_FILTER && version >= 41 && version <= 48) { // ablations of the half-tile kernel
-        const uint32_t hg = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
-        if (version == 41) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 1>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 42) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 2>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 43) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 3>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 44) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 4>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 45) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 5>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 46) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 6>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else if (version == 48) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 8>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hg), dim3(H_THREADS), 0, st, a);
-        return hipGetLastError();
-    }
-    if (mode == MODE_FILTER && (version == 31 || version == 32 || version == 37)) {
-        if (version == 31) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 1>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-        else if (version == 32) hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 2>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((scan_tiles_i8_kernel<MODE_FILTER, 7>), dim3(grid), dim3(I8_THREADS), 0, st, a);
-        return hipGetLastError();
-    }
-#endif
     const uint32_t hgrid = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
-#ifdef YAMS_ACCEL_MEASURE
-    if (mode == MODE_FILTER && version >= 50 && version <= 58) { // the persistent form and its ablations
-        const uint32_t pg = hgrid < 512u ? hgrid : 512u;
-        if (version == 50) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 0>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
-        else if (version == 52) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 2>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
-        else if (version == 58) hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 8>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
-        else hipLaunchKernelGGL((scan_tiles_i8p_kernel<MODE_FILTER, 7>), dim3(pg), dim3(H_THREADS), 0, st, a, hgrid);
-        return hipGetLastError();
-    }
-#endif
     if (mode == MODE_SAMPLE) {
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
@@ -1874,8 +1147,19 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     const ResidentPlan rp = i8_resident_plan(L);
     uint32_t window = 2; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; 1..8 measured: 14..19 GB from HBM per bench launch, times within noise)
 #ifdef YAMS_ACCEL_MEASURE
+    if (version >= 41 && version <= 48) {
+        if (version == 41) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 1>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 42) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 43) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 3>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 44) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 4>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 45) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 5>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 46) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 6>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else if (version == 48) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 8>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
     if (const char* wv = std::getenv("YAMS_ACCEL_I8R_WINDOW")) window = static_cast<uint32_t>(std::atoi(wv));
-    if (rp.use && version >= 61 && version <= 68) { // ablations of the resident-query kernel
+    if (rp.use && version >= 61 && version <= 68) {
         if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 64) hipLaunchKernelGGL((scan_tiles_i8r_kernel<4>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
@@ -1884,7 +1168,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         else hipLaunchKernelGGL((scan_tiles_i8r_kernel<7>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
-    if (version == 40) { // the half-tile kernel where the library would pick the resident-query one (A/B runs)
+    if (version == 40) {
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
