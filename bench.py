@@ -622,7 +622,7 @@ def main():
     stride = max(1, n_tiles // ((s_target + tr - 1) // tr))
     n_sample = (n_tiles + stride - 1) // stride
     filt_rows = min(n, (n_tiles - n_sample) * tr)
-    if world == 1 and not a.no_hbm_leg and tb is not None and bf16 and nq >= 64:
+    if world == 1 and not a.no_hbm_leg and (tb is not None or t8 is not None) and bf16 and nq >= 64:
         q64 = 64
         s64 = torch.empty((q64, k), dtype=torch.float32, device=dev)
         r64 = torch.empty((q64, k), dtype=torch.int64, device=dev)
@@ -640,9 +640,17 @@ def main():
         torch.cuda.synchronize(); dt64 = (time.perf_counter() - t1) / a.steps
         f64_ms, f64_n = acc.kernel_ms("scan_filter")
         acc.enable_timing(False)
-        byts = filt_rows * d * 2 + filt_rows * 4 + q64 * d * 2
+        d64 = acc.scan_topk_device(view, tq.data_ptr(), q64, k, -1.0, SCAN_COSINE, s64.data_ptr(), r64.data_ptr(),
+                                   c64.data_ptr(), flags=scan_flags, want_diag=True)
+        i8_64 = d64.get("filter_tier") == 1
+        if i8_64:      # the int8 shadow, streamed once by the resident-query kernel (one query tile: every workgroup has its own row stream)
+            byts = filt_rows * d + (filt_rows // 64) * 8 + q64 * d
+            k64 = "scan_tiles_i8r_kernel (int8 shadow, one 128-query tile resident per CU, 256 row streams)"
+        else:
+            byts = filt_rows * d * 2 + filt_rows * 4 + q64 * d * 2
+            k64 = "scan_tiles_bf16n_kernel<FILTER,COSINE,2> (narrow form over the bf16 shadow, Q <= 64)"
         same = bool(torch.equal(r64, res["rows"][:q64]) and torch.equal(s64, res["scores"][:q64]))
-        hbm_leg = {"bound": "hbm", "kernel": "scan_tiles_bf16n_kernel<FILTER,COSINE,2> (narrow form, Q <= 64)",
+        hbm_leg = {"bound": "hbm", "kernel": k64,
                    "queries": q64, "achieved": byts / (f64_ms * 1e-3) / 1e9 if f64_ms else None, "peak": PEAK_HBM_GBPS,
                    "unit": "GB/s", "frac": byts / (f64_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if f64_ms else None,
                    "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n, "traffic": None,
@@ -661,7 +669,7 @@ def main():
         n_qt = (nq + 127) // 128
         n_streams = (32 // n_qt) * 8 if n_qt <= 32 else 0
         n_filter_tiles = n_tiles - n_sample
-        resident = (not a.half_tile and d % 128 == 0 and 640 <= d <= 768 and 3 <= n_qt <= 8 and (32 // n_qt) * n_qt * 10 >= 32 * 9
+        resident = (not a.half_tile and d % 128 == 0 and 384 <= d <= 768 and 2 <= n_qt <= 8 and (32 // n_qt) * n_qt * 10 >= 32 * 9
                     and (n_filter_tiles + 1) // 2 >= 12 * n_streams)
         if resident:
             kname = ("scan_tiles_i8r_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "

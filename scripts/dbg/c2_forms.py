@@ -6,7 +6,7 @@ from yams_amd.accel import Accel
 from yams_amd import _lib
 from yams_amd._lib import SCAN_COSINE
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
-for (n, d, nq) in [(12_500_000, 512, 1024), (12_500_000, 640, 1024), (12_500_000, 768, 384), (12_500_000, 768, 768), (12_500_000, 768, 2048)]:
+for (n, d, nq) in [(12_500_000, 384, 1024), (12_500_000, 512, 1024), (12_500_000, 640, 1024), (12_500_000, 768, 256), (12_500_000, 768, 384), (12_500_000, 768, 512), (12_500_000, 768, 1024), (12_500_000, 768, 2048), (1_000_000, 384, 256), (2_000_000, 768, 1024)]:
     k = 100
     tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 0, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(42, 1 << 40, nq, d, tq.data_ptr())

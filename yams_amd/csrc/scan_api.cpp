@@ -241,10 +241,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // v_mfma_i32_16x16x64_i8 (scan_i8_kernel.hip) — more than twice the sustained matrix rate,
         // half the shadow bytes, exact integer accumulation; its filter score is an upper bound of the
         // similarity built from the MEASURED quantisation residues, so the proof needs no extra error term.
-        // Batches of <= 128 queries stay on the narrow bf16 form when a bf16 shadow is there too.
+        // Batches of <= 128 queries take it when the shard is large enough for the resident-query kernel form
+        // (decided below, once the plan is known); on smaller shards they stay on the narrow bf16 form when a
+        // bf16 shadow is there too.
         bool i8 = bf16 && passes == 1 && metric == YAMS_SCAN_COSINE && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
-                  !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER) && (nq > 128 || !corpus->rows_bf16);
+                  !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER);
 #ifdef YAMS_ACCEL_MEASURE
         // Measurement build only (libyams_mi355x_accel_measure.so, scripts/): kernel-form and
         // ablation selection from the environment.  The product library never reads it.
@@ -259,8 +261,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
             L.rows_bf16 = corpus->rows_bf16; L.rows_nsq = corpus->rows_nsq; // used by the single-pass kernel
         }
-        if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         L.i8_form = (params->flags & YAMS_SCAN_FLAG_WIDE_TILE) ? 1 : ((params->flags & YAMS_SCAN_FLAG_RESIDENT_QUERIES) ? 2 : 0);
+        if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
+        if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms

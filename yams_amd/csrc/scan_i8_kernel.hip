@@ -647,9 +647,10 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // and measured without pacing they drift apart until most strips are fetched again: 34 GB from HBM per
     // launch instead of 9.4.  So a wave looks at its siblings' strip counters at the end of a strip (the
     // load rides on the drain that is there anyway) and lets the slowest one come within R_WINDOW strips of
-    // the one it just drew before it goes on.  Best effort: a bounded number of polls, no correctness
-    // depends on it, no workgroup waits for one that is not resident.
-    constexpr uint32_t R_POLLS = 4096;
+    // the one it just drew before it goes on.  Best effort: a bounded number of polls (then the wave stops
+    // pacing altogether), no correctness depends on it, no workgroup waits for one that is not resident.
+    constexpr uint32_t R_POLLS = 1024;
+    bool pacing = true;
     const uint32_t R_WINDOW = window;
     const uint32_t* sync_sib = pair_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
 #ifdef YAMS_ACCEL_MEASURE
@@ -724,13 +725,17 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             qthr_wait();
             thresholds();
             k_new = take_result(); // (landed with the drain above, like the siblings' counters)
-            if (n_qt > 1 && more) {
+            if (n_qt > 1 && more && pacing) {
                 asm volatile("" : "+v"(sib));
-                for (uint32_t polls = 0; polls < R_POLLS; ++polls) {
+                uint32_t polls = 0;
+                for (; polls < R_POLLS; ++polls) {
                     if (__builtin_amdgcn_ballot_w64(sib + R_WINDOW < k_new) == 0) break;
                     __builtin_amdgcn_s_sleep(8);
                     asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sib) : "v"(sync_sib) : "memory");
                 }
+                // a sibling that did not move for ~1 ms is not resident (another kernel holds its CU): this wave
+                // stops pacing for the rest of the launch rather than pay the timeout at every strip
+                if (polls == R_POLLS) pacing = false;
             }
         } else { // measurement builds: keep the accumulators alive, emit nothing
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1095,16 +1100,22 @@ static ResidentPlan i8_resident_plan(const ScanLaunch& L) {
     if (L.i8_form != 2) { // the library's choice (the caller's RESIDENT_QUERIES flag skips these)
         if (streams_x * r.n_qt * 10u < per_xcd * 9u) return r;   // more than a tenth of the CUs would idle
         if (r.n_units < 12u * r.n_streams) return r;              // short streams: the half-tile kernel balances better
-        // measured on 12.5M-row shards (scripts/dbg/c2_forms.py): the per-strip fixed cost (epilogue, drain,
-        // counters) wants >= 10 slabs per strip (dim 384: 8.6 vs 6.5 ms for half tiles; 512: equal; 640: 4 %
-        // ahead), two query tiles leave it level with half tiles, and sixteen sibling workgroups per stream
-        // (2048 queries) run at half speed
-        if (dim < 640 || r.n_qt < 3 || r.n_qt > 8) return r;
+        // measured on 12.5M-row shards (scripts/dbg/c2_forms.py, step times resident / half tiles): dim 384
+        // 5.96 / 6.09 ms, 512 6.39 / 7.23, 640 7.5 / 8.6, 768 8.75 / 9.7 at 1024 queries; 768 with 256 queries
+        // 2.70 / 3.0, 384: 3.8 / 5.1, 512: 4.8 / 5.3; sixteen sibling workgroups per stream (2048 queries) lose:
+        // 20.9 / 18.1
+        if (dim < 384 || r.n_qt > 8) return r;
     }
     r.grid = per_xcd * 8u;
     r.use = true;
     return r;
 }
+
+// Would the filter pass of this launch take the resident-query form?  (scan_api.cpp: batches of <= 128 queries
+// take the int8 tier only then — the persistent kernel streams the int8 shadow at 6.1 TB/s, 1.55 ms for the
+// 12.5M x 768 shard against 3.1 ms for the narrow bf16 form over the twice as large bf16 shadow; on shards too
+// small for it the narrow bf16 form stays ahead of int8 half tiles.)
+bool i8_takes_resident_form(const ScanLaunch& L) { return i8_resident_plan(L).use; }
 
 // survivor-log regions of the filter launch: one per (workgroup, wave) of the half-tile kernel, one per
 // (unit, query tile, wave) of the resident-query kernel — a 64 x 128 wave tile either way
