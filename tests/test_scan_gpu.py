@@ -713,6 +713,13 @@ def test_full_size_config4_shard_12p5Mx768_cosine_top100_q1024(acc, oracle):
     _full_size(acc, oracle, 12_500_000, 768, 1024, 100, SCAN_COSINE, n_oracle_queries=3)
 
 
+def test_full_size_config4_shard_small_batch_takes_the_int8_stream(acc, oracle):
+    """The same shard with 8 queries: on a shard this large small batches take the int8 resident-query form with
+    one query tile (every CU streams its own rows of the int8 shadow — half the bytes of the narrow bf16 form);
+    two queries against the oracle over the full shard, all eight against the bf16 tier and the exhaustive path."""
+    _full_size(acc, oracle, 12_500_000, 768, 8, 100, SCAN_COSINE, n_oracle_queries=2)
+
+
 def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle):
     """BASELINE config 1: the reference's own CPU-runnable case — 10 000 x 384, k = 10, one query
     per call, data from ITS recipe (std::mt19937(42), U(-1,1), fp32 normalise; corpus first, then
