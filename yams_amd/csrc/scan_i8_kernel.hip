@@ -1156,7 +1156,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
-    uint32_t window = 2; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; 1..8 measured: 14..19 GB from HBM per bench launch, times within noise)
+    uint32_t window = 1; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; measured on the bench launch: window 1 17 GB from HBM and 7.6-7.8 ms, 2 / 3 20 GB and 7.9 ms, unpaced 19+ GB)
 #ifdef YAMS_ACCEL_MEASURE
     if (version >= 41 && version <= 48) {
         if (version == 41) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 1>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
