@@ -262,6 +262,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             L.rows_bf16 = corpus->rows_bf16; L.rows_nsq = corpus->rows_nsq; // used by the single-pass kernel
         }
         L.i8_form = (params->flags & YAMS_SCAN_FLAG_WIDE_TILE) ? 1 : ((params->flags & YAMS_SCAN_FLAG_RESIDENT_QUERIES) ? 2 : 0);
+#ifdef YAMS_ACCEL_MEASURE
+        if (bf16_version == 40) L.i8_form = 1; // A/B runs: half tiles where the library would pick the resident-query form
+#endif
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
@@ -312,11 +315,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         uint32_t* d_qover = nullptr;
         if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip), one region per (workgroup, wave)
             const uint64_t regions = i8_log_regions(L);
-            // a wave tile is 64 rows x 128 queries; the threshold admits ~tau_rank * stride rows per query.
-            // 4x the expectation + 16 (at 12.5M rows: 0.6 expected, 16 slots; a 300k-row shard: 16 expected, 80).
-            // A region that still overflows marks its queries (q_over) and they take the exhaustive path.
-            const double per_wave = 8192.0 * plan.tau_rank * plan.sample_stride / static_cast<double>(std::max<uint64_t>(1, plan.n_rows));
-            L.log_cap = std::min<uint32_t>(8192, round_up(static_cast<uint32_t>(std::min(8192.0, 4.0 * per_wave)) + 16, 16));
+            L.log_cap = i8_log_capacity(L);
             YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * 8, (void**)&L.log_key));
             YA_TRY(ws_get(ctx, "i8_log_q", static_cast<size_t>(regions) * L.log_cap * 4, (void**)&L.log_q));
             YA_TRY(ws_get(ctx, "i8_log_cnt", static_cast<size_t>(regions) * 4, (void**)&L.log_cnt));

@@ -665,6 +665,12 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int cb = 0; cb < 8; ++cb) nt[cb] = THR ? i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g) : 0;
     };
     thresholds();
+    // Survivors go to ONE log region per wave and launch ((stream, query tile, wave): ~500 entries at the bench
+    // shape), filled front to back: no per-strip region, count or memset, and the gather kernel gets 2048 dense
+    // regions of one query tile each instead of 1.5 million mostly empty ones.
+    const uint32_t log_region = (stream * n_qt + qt) * 8u + static_cast<uint32_t>(wid);
+    const uint64_t region = static_cast<uint64_t>(log_region) * a.log_cap;
+    uint32_t log_pos = 0;
 
     if (unit_of(k_cur) < n_units) for (;;) {
         const uint32_t u = unit_of(k_cur);
@@ -756,9 +762,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
             // bound u and moves the entry into its query's candidate list.
             const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
-            const uint64_t rid = (static_cast<uint64_t>(u) * n_qt + qt) * 8u + static_cast<uint32_t>((wid & 3) + 4 * (k_cur & 1u));
-            const uint64_t region = rid * a.log_cap;
-            uint32_t base = 0; // entries of this strip so far (wave-uniform)
+            uint32_t base = log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const bool hot_cb = (hot >> cb) & 1u;
@@ -804,13 +808,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 }
                 if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
             }
-            if (lane == 0 && ABL != 8 && ABL != 9) a.log_cnt[rid] = base < a.log_cap ? base : a.log_cap;
+            log_pos = base;
             if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
         }
         if (!more) break;
         cur = nxt;
         k_cur = k_nxt; k_nxt = k_fut; k_fut = k_new;
     }
+    if (lane == 0 && ABL == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
 #ifdef YAMS_ACCEL_MEASURE
     if (lane == 0 && n_qt <= 8) { // measurement build: when each wave started and ended (100 MHz ticks) and how many strips it took
@@ -845,6 +850,48 @@ __global__ __launch_bounds__(256) void i8_log_gather_kernel(const uint64_t* log_
         const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
         const float u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
         const uint32_t pos = atomicAdd(&list_count[q], 1u);
+        if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
+    }
+}
+
+// The same for the resident-query kernel's logs: one region per (row stream, query tile, wave), i.e. all entries
+// of a region belong to ONE 128-query tile.  A workgroup per region: the entries are counted per query in LDS,
+// every query present reserves its list slots with ONE global atomic (the per-entry atomics of the form above
+// piled 1000 increments on each of 1024 addresses), then the entries are placed.
+__global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t* log_key, const uint32_t* log_q, const uint32_t* log_cnt,
+                                                                 uint32_t log_cap, uint32_t n_qt, const float* rows_meta,
+                                                                 const float* q_meta, const float* q_thr, uint32_t* list_count,
+                                                                 uint64_t* list, uint32_t list_cap) {
+    __shared__ uint32_t hist[R_QUERIES], slot0[R_QUERIES];
+    const uint32_t r = blockIdx.x;
+    const uint32_t n = log_cnt[r];
+    if (n == 0) return;
+    const uint32_t q0 = ((r >> 3) % n_qt) * R_QUERIES;
+    const int tid = threadIdx.x;
+    if (tid < R_QUERIES) hist[tid] = 0u;
+    __syncthreads();
+    const uint64_t* keys = log_key + static_cast<uint64_t>(r) * log_cap;
+    const uint32_t* qs = log_q + static_cast<uint64_t>(r) * log_cap;
+    for (uint32_t i = tid; i < n; i += 256) atomicAdd(&hist[qs[i] - q0], 1u);
+    __syncthreads();
+    if (tid < R_QUERIES) {
+        const uint32_t c = hist[tid];
+        slot0[tid] = c ? atomicAdd(&list_count[q0 + tid], c) : 0u;
+        hist[tid] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint64_t e = keys[i];
+        const uint32_t q = qs[i];
+        const uint32_t row = static_cast<uint32_t>(e);
+        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
+        const float2 m = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
+        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
+        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
+        const float is = 1.0f / m.x;
+        const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
+        const float u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        const uint32_t pos = slot0[q - q0] + atomicAdd(&hist[q - q0], 1u);
         if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
 }
@@ -1121,7 +1168,7 @@ bool i8_takes_resident_form(const ScanLaunch& L) { return i8_resident_plan(L).us
 // (unit, query tile, wave) of the resident-query kernel — a 64 x 128 wave tile either way
 uint64_t i8_log_regions(const ScanLaunch& L) {
     const ResidentPlan r = i8_resident_plan(L);
-    if (r.use) return static_cast<uint64_t>(r.n_units) * r.n_qt * 8u;
+    if (r.use) return static_cast<uint64_t>(r.n_streams) * r.n_qt * 8u;
     return static_cast<uint64_t>((2u * L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8u * 4u;
 }
 
@@ -1130,9 +1177,36 @@ uint64_t i8_sync_words(const ScanLaunch& L) {
     return r.use ? static_cast<uint64_t>(r.n_streams) * 12u * 32u : 0u; // [n_streams][4 pairs][32] strip counters (+ [n_streams][8][32] for the measurement build's timestamps)
 }
 
+// entries per log region.  Half tiles: a wave tile is 64 rows x 128 queries and the threshold admits about
+// tau_rank * stride rows per query: 4x the expectation + 16 (12.5M rows: 0.6 expected, 16 slots; a 300k-row
+// shard: 16 expected, 80).  Resident queries: everything a wave finds in a launch, 4x its share of the
+// expected nq * tau_rank * stride survivors + 256 (waves draw 60-140 % of the mean number of strips).  A region
+// that still overflows marks its queries (q_over) and they take the exhaustive path.
+uint32_t i8_log_capacity(const ScanLaunch& L) {
+    const ScanPlan& p = L.plan;
+    const ResidentPlan r = i8_resident_plan(L);
+    if (r.use) {
+        const double total = static_cast<double>(p.n_queries) * p.tau_rank * p.sample_stride;
+        const double share = total / (static_cast<double>(r.n_streams) * r.n_qt * 8.0);
+        const double cap = 4.0 * share + 256.0;
+        const uint64_t c = static_cast<uint64_t>(cap < 4.0e6 ? cap : 4.0e6);
+        return static_cast<uint32_t>((c + 15) / 16 * 16);
+    }
+    const double per_wave = 8192.0 * p.tau_rank * p.sample_stride / static_cast<double>(p.n_rows ? p.n_rows : 1);
+    const uint32_t c = static_cast<uint32_t>(per_wave * 4.0 < 8192.0 ? per_wave * 4.0 : 8192.0) + 16;
+    return (c + 15) / 16 * 16 < 8192u ? (c + 15) / 16 * 16 : 8192u;
+}
+
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     const uint64_t regions = i8_log_regions(L);
     if (regions == 0) return hipSuccess;
+    const ResidentPlan rp = i8_resident_plan(L);
+    if (rp.use) {
+        hipLaunchKernelGGL(i8_log_gather_wave_kernel, dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
+                           L.log_key, L.log_q, L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count,
+                           L.list, L.plan.list_cap);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(i8_log_gather_kernel, dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
                        L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
                        L.plan.list_cap);

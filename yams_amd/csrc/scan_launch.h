@@ -81,6 +81,8 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
 // After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
 // int8 tier: workgroups of the filter launch (the survivor log has 8 regions of log_cap entries per group)
 uint64_t i8_log_regions(const ScanLaunch& L);
+// entries per survivor-log region of this launch (depends on the kernel form the launch takes)
+uint32_t i8_log_capacity(const ScanLaunch& L);
 // whether the int8 filter pass of this launch would take the resident-query kernel form
 bool i8_takes_resident_form(const ScanLaunch& L);
 // pacing counters of the resident-query form (0 when the launch takes the half-tile form); zero them before the launch
