@@ -300,7 +300,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
         float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
-        YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
+        if (i8) L.dense = nullptr; // (the int8 sample pass keeps group maxima only, launch_i8_collect_sample)
+        else YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
         YA_TRY(ws_get(ctx, "gmax", static_cast<size_t>(nq) * plan.n_groups * 4, (void**)&L.gmax));
         YA_TRY(ws_get(ctx, "tau", static_cast<size_t>(nq) * 4, (void**)&d_tau));
         YA_TRY(ws_get(ctx, "lcount", static_cast<size_t>(nq) * 4, (void**)&d_lcount));
@@ -335,7 +336,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
-        YA_HIP(ctx, launch_collect_sample(st, L));
+        if (i8) YA_HIP(ctx, launch_i8_collect_sample(st, L)); else YA_HIP(ctx, launch_collect_sample(st, L));
         { GatedSweep gs(ctx, st); // sweeps of contexts that share a gate run one after the other
           TimedRegion tr(ctx, "scan_filter");
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
                     v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
                     m = fmaxf(m, v[r]);
                 }
-                if (qok) {
+                if (qok && a.dense) { // (no dense buffer: i8_collect_sample_kernel re-derives the scores of the few groups that matter)
                     const uint64_t srow = static_cast<uint64_t>(sel) * I8_ROWS + hf * H_ROWS + static_cast<uint32_t>(wr * 64 + 16 * rb + 4 * lq);
                     *reinterpret_cast<float4*>(a.dense + dense_index(qi, srow, a.n_queries)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -896,6 +896,61 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
     }
 }
 
+// Sample rows that reach the threshold join the candidate lists (the int8 tier's form of collect_sample_kernel).
+// The sample pass keeps only the maximum of every group of 16 rows (the rows one lane holds for a query block:
+// 64 (gid >> 2) + 4 (gid & 3) + {0..3} + 16 {0..3} of the sample) — writing all scores densely was 800 MB and
+// 0.13 ms per 1024-query batch of the bench shard.  tau is the tau_rank-th largest group maximum, so only about
+// tau_rank groups per query reach it: their 16 scores are re-derived here, exactly (the same integer dot product,
+// the same two fmaf as the sample pass), from the int8 shadow and the int8 query.
+__global__ __launch_bounds__(256) void i8_collect_sample_kernel(const uint32_t* gmax, uint32_t n_groups, uint32_t n_queries,
+                                                                const int8_t* rows_i8, const float* rows_meta, const int8_t* q_i8,
+                                                                const float* q_meta, uint32_t q_pad, uint32_t dim,
+                                                                uint32_t stride, uint64_t n_rows, const uint32_t* row_mask,
+                                                                const float* tau, uint32_t* list_count, uint64_t* list,
+                                                                uint32_t list_cap) {
+    const uint32_t q = blockIdx.y;
+    const float t = tau[q];
+    const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
+    const uint32_t nchunk = dim / 16;                    // 16-byte chunks per row
+    const int lane = threadIdx.x & 63;
+    const float4 qm = reinterpret_cast<const float4*>(q_meta)[q]; // {t_q, c_q, f_q, 0}
+    // a wave looks at 64 groups at a time (one per lane); every group that reaches tau is then scored by the WHOLE
+    // wave: lane l takes row l & 15 of the group and every fourth 16-byte chunk from chunk l >> 4 on
+    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u, wstep = gridDim.x * blockDim.x;
+    for (uint32_t g0 = wave0; g0 < n_groups; g0 += wstep) {
+        const uint32_t gl = g0 + static_cast<uint32_t>(lane);
+        const bool hot = gl < n_groups && !(ord2f(gm[gl]) < t);
+        for (uint64_t hm = __builtin_amdgcn_ballot_w64(hot); hm; hm &= hm - 1) {
+            const uint32_t g = g0 + static_cast<uint32_t>(__builtin_ctzll(hm));
+            const int i = lane & 15;
+            const uint64_t sidx = static_cast<uint64_t>(g >> 2) * 64 + 4 * (g & 3) + 16 * (i >> 2) + (i & 3);
+            const uint64_t row = (sidx / I8_ROWS) * stride * I8_ROWS + (sidx % I8_ROWS);
+            const bool ok = row < n_rows && (!row_mask || ((row_mask[row >> 5] >> (row & 31u)) & 1u));
+            const uint64_t rr = row < n_rows ? row : n_rows - 1;
+            int dot = 0;
+            for (uint32_t ch = static_cast<uint32_t>(lane >> 4); ch < nchunk; ch += 4) {
+                const int4 xv = *reinterpret_cast<const int4*>(rows_i8 + i8_blocked_offset(rr, ch * 16, dim));
+                const int4 qv = *reinterpret_cast<const int4*>(q_i8 + (static_cast<uint64_t>(ch >> 2) * q_pad + q) * 64 + (ch & 3u) * 16);
+                dot = __builtin_amdgcn_sdot4(xv.x, qv.x, dot, false);
+                dot = __builtin_amdgcn_sdot4(xv.y, qv.y, dot, false);
+                dot = __builtin_amdgcn_sdot4(xv.z, qv.z, dot, false);
+                dot = __builtin_amdgcn_sdot4(xv.w, qv.w, dot, false);
+            }
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            if (lane < 16 && ok) {
+                const float2 bm = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
+                const float S = bm.x * qm.x, K = fmaf(bm.y, qm.y, qm.z);   // (as in the sample pass's epilogue)
+                const float u = fmaf(static_cast<float>(dot), S, K);
+                if (!(u < t)) {
+                    const uint32_t pos = atomicAdd(&list_count[q], 1u);
+                    if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, static_cast<uint32_t>(row));
+                }
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // The INT8 shadow.  One wave per block of 64 rows.  A row is first scaled by its own largest
 // component (so tiny and huge rows normalise without under- or overflow), normalised in fp32, and
@@ -1170,6 +1225,16 @@ uint64_t i8_log_regions(const ScanLaunch& L) {
     const ResidentPlan r = i8_resident_plan(L);
     if (r.use) return static_cast<uint64_t>(r.n_streams) * r.n_qt * 8u;
     return static_cast<uint64_t>((2u * L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8u * 4u;
+}
+
+hipError_t launch_i8_collect_sample(hipStream_t st, const ScanLaunch& L) {
+    if (L.plan.sample_rows == 0 || L.plan.n_groups == 0) return hipSuccess;
+    uint32_t gx = (L.plan.n_groups + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(i8_collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.gmax, L.plan.n_groups,
+                       L.plan.n_queries, L.rows_i8, L.rows_i8_meta, L.q_i8, L.q_meta, L.q_pad, L.plan.dim, L.plan.sample_stride,
+                       L.plan.n_rows, L.row_mask, L.tau, L.list_count, L.list, L.plan.list_cap);
+    return hipGetLastError();
 }
 
 uint64_t i8_sync_words(const ScanLaunch& L) {

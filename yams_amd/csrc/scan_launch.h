@@ -90,6 +90,8 @@ uint64_t i8_sync_words(const ScanLaunch& L);
 // after the filter pass: log entries -> per-query candidate lists (the returning atomics live here, where
 // thousands of independent threads hide their latency)
 hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L);
+// int8 tier: sample rows that reach tau join the lists, their scores re-derived from the group maxima's groups
+hipError_t launch_i8_collect_sample(hipStream_t st, const ScanLaunch& L);
 hipError_t launch_i8_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
                                 float* q_thr);
 hipError_t launch_scan_sample(hipStream_t st, const ScanLaunch& L, int metric);
