@@ -85,8 +85,9 @@ constexpr int H_A_BYTES = H_ROWS * I8_SLAB;        // 8 KiB
 constexpr int H_STAGE = H_A_BYTES + I8_B_BYTES;    // 24 KiB
 
 // per-query thresholds of the filter pass: qthr[q] = {A_lo, B_hi} (see i8_query_thresholds_kernel)
-// MODE_SAMPLE writes dense upper bounds + group maxima (groups of 16 rows: the rows one lane holds
-// for a query block — 4 row blocks x 4 consecutive rows — see collect_sample_kernel, layout 1).
+// MODE_SAMPLE writes group maxima (groups of 16 rows: the rows one lane holds for a query block — 4 row
+// blocks x 4 consecutive rows) and, only when a dense buffer is given, all upper bounds (the int8 tier runs
+// without one: i8_collect_sample_kernel re-derives the scores of the groups that reach tau).
 template <int MODE, int ABL = 0>
 __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
