@@ -710,6 +710,9 @@ def main():
                 "executed_mfma_tflops": (ach_tf * passes if bf16 else ach_tf) if ach_tf else None,
                 "mfma_peak_for_executed": PEAK_I8_MFMA_TOPS if i8 else (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
                 "frac_of_bf16_peak": (ach_tf / PEAK_BF16_MFMA_TFLOPS) if ach_tf else None,
+                # MI355X_MICROARCH.md lists no spec peak for I8, only a micro-benchmark ceiling (>= 3944 TOPS, 16x16x64);
+                # `peak` above is the nominal 2x-bf16 figure (5000), the stricter of the two
+                "frac_of_guide_i8_ubench_ceiling": (ach_tf / 3944.0) if (ach_tf and i8) else None,
                 "sample_pass_ms": samp_ms,
                 "shadow_build_ms": shadow_ms, "shadow_i8_build_ms": shadow_i8_ms, "shadow_i8_mean_residue": i8_mean_err,
                 # the other floor of this kernel: one read of the filter rows from HBM per launch
