@@ -436,8 +436,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
 //     drain at a tile boundary and no tile prologue: the row stream runs straight through the units;
 //   * the eight workgroups that hold the eight query tiles of a batch sit on the same XCD and walk the
 //     same row units in the same order, so a row comes from HBM once and seven times from that L2.
-// A unit = 512 rows (two consecutive filter tiles; wave w owns strip w & 3 of tile w >> 2), the
-// accumulator layout, thresholds, survivor log and epilogue are those of the half-tile kernel.
+// A unit = 512 rows (two consecutive filter tiles = eight 64-row strips; the waves w and w + 4 of a SIMD
+// draw the strips w & 3 of both tiles from one counter, see "work sharing"), the accumulator layout and the
+// thresholds are those of the half-tile kernel; survivors go to one log region per wave.
 // -------------------------------------------------------------------------------------------------
 constexpr int R_QUERIES = 128, R_THREADS = 512, R_MAX_SLABS = 12;
 constexpr int R_B_SLAB = R_QUERIES * I8_SLAB;      // 8 KiB of queries per k-slab
