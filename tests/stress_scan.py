@@ -3,7 +3,8 @@ covers far more shapes per second than the parity tests): for random (rows, dim,
 threshold, allow-mask) the default path — narrow filter for small batches, 256-query tile above —
 must return bit-identical rows / scores / counts to the exhaustive fp64 path
 (YAMS_SCAN_FLAG_FORCE_EXACT), which shares no filter code with it, and to the wide form
-(YAMS_SCAN_FLAG_WIDE_TILE).  Prints one summary line; exit code 1 on any mismatch.
+(YAMS_SCAN_FLAG_WIDE_TILE); where the shape allows it also the int8 tier, in its half-tile form and forced into its
+resident-query form (YAMS_SCAN_FLAG_RESIDENT_QUERIES).  Prints one summary line; exit code 1 on any mismatch.
 
     python tests/stress_scan.py [--cases 60] [--seed 1]
 """
@@ -13,7 +14,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from yams_amd.accel import Accel
-from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_WIDE_TILE
+from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_WIDE_TILE, FLAG_RESIDENT_QUERIES
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
@@ -25,7 +26,7 @@ bad, done, paths = [], 0, {}
 for case in range(a.cases):
     d = int(rng.choice([64, 96, 128, 160, 256, 384, 768, 1024]))
     n = int(rng.integers(4096, 120_000 if d <= 256 else 40_000))
-    nq = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200]))
+    nq = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 257, 300, 520]))
     k = int(rng.choice([1, 5, 10, 50, 100, 200]))
     metric = SCAN_L2 if rng.random() < 0.3 else SCAN_COSINE
     thr = float(rng.choice([-1.0, 0.0, 0.1])) if metric == SCAN_COSINE else -1.0
@@ -57,12 +58,15 @@ for case in range(a.cases):
         view8 = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
                                 rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
         forms.insert(0, "i8")
+        if d % 128 == 0 and d <= 768:     # the resident-query kernel form of the int8 filter, forced on these small shards
+            forms.insert(0, "i8r")
     out = {}
     for form in forms:
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        diag = acc.scan_topk_device(view8 if form == "i8" else view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
-                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else (FLAG_WIDE_TILE if form == "wide" else 0))
+        diag = acc.scan_topk_device(view8 if form in ("i8", "i8r") else view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
+                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else
+                                    (FLAG_WIDE_TILE if form == "wide" else (FLAG_RESIDENT_QUERIES if form == "i8r" else 0)))
         torch.cuda.synchronize()
         cn = c.cpu().numpy()
         sel = np.arange(k)[None, :] < cn[:, None]        # only the returned prefix is defined
