@@ -395,6 +395,21 @@ def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check):
     return {"blobs": len(pick), "ok": bool(ok)}
 
 
+def hbm_leg_traffic(n, d, nq, i8):
+    """HBM bytes per launch of the small-batch filter from the builder's PMC pass (profiles/*_small_batch_pmc.json),
+    when it was taken on this very shape and kernel; labelled as such."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_small_batch_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq and ("i8r" in j.get("kernel", "")) == bool(i8):
+                return j.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(f)} (builder run: rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                                                       "correction; NOT measured in this run)")
+        except Exception:
+            pass
+    return None, None
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -653,7 +668,8 @@ def main():
         hbm_leg = {"bound": "hbm", "kernel": k64,
                    "queries": q64, "achieved": byts / (f64_ms * 1e-3) / 1e9 if f64_ms else None, "peak": PEAK_HBM_GBPS,
                    "unit": "GB/s", "frac": byts / (f64_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if f64_ms else None,
-                   "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n, "traffic": None,
+                   "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n,
+                   "traffic": hbm_leg_traffic(n, d, q64, i8_64)[0], "traffic_source": hbm_leg_traffic(n, d, q64, i8_64)[1],
                    "ms_per_step": dt64 * 1e3, "qps_on_resident_corpus": q64 / dt64,
                    "results_identical_to_the_q1024_run": same}
 
