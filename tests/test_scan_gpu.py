@@ -636,7 +636,7 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     unit = (tc[:4096].double() / n64.sqrt()[:, None]).float()
     assert (tb[:4096].float() - unit).abs().max().item() <= 2.0 ** -8 * unit.abs().max().item() * 1.01
     t8 = tm8 = None
-    if metric == SCAN_COSINE and d % 64 == 0 and d >= 256:   # the int8 shadow: first filter tier of cosine batches > 128 queries
+    if (metric == SCAN_COSINE and d % 64 == 0 and d >= 256) or (d % 128 == 0 and 256 <= d <= 768):   # the int8 shadow: first filter tier of cosine batches > 128 queries, and of L2 batches on shards that take the resident-query form
         t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device="cuda")
         tm8 = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
         mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
@@ -788,6 +788,68 @@ def test_int8_resident_query_form_matches_the_oracle_and_the_half_tile_form(acc,
     assert np.array_equal(a.rows, b.rows) and np.array_equal(a.counts, b.counts)
     assert np.array_equal(a.scores.view(np.uint32), b.scores.view(np.uint32))
     assert a.diag["filter_candidates"] == b.diag["filter_candidates"]
+
+
+def _l2_corpus(oracle, seed, n, d, nq, kind):
+    """Row / query sets for the L2 int8 tier: the synthetic uniform rows as they are, unit rows, norms spread
+    within a factor of two (the tier's limit), or tight clusters with the queries next to rows (tau' > 0)."""
+    rng = np.random.default_rng(seed)
+    corpus = oracle.synth_rows(seed, 0, n, d)
+    q = oracle.synth_rows(seed, 1 << 40, nq, d)
+    if kind == "unit":
+        corpus = (corpus / np.linalg.norm(corpus.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    elif kind == "spread":
+        corpus = (corpus * rng.uniform(0.85, 1.35, (n, 1))).astype(np.float32)
+    elif kind == "clustered":
+        centres = rng.normal(0, 1, (8, d)).astype(np.float32)
+        corpus = (centres[rng.integers(0, 8, n)] + 0.05 * rng.normal(0, 1, (n, d))).astype(np.float32)
+        q = (corpus[rng.integers(0, n, nq)] + 0.02 * rng.normal(0, 1, (nq, d))).astype(np.float32)
+    if nq > 2 and kind != "clustered":
+        q[0] *= np.float32(3.0); q[1] *= np.float32(0.2)     # queries of other lengths than the rows
+    return np.ascontiguousarray(corpus), np.ascontiguousarray(q)
+
+
+@pytest.mark.parametrize("n,d,nq,k,thr,kind", [
+    (50000, 256, 130, 100, -1.0, "uniform"), (70001, 384, 300, 50, 0.05, "uniform"), (40449, 512, 700, 30, -1.0, "unit"),
+    (90000, 768, 1024, 100, -1.0, "spread"), (33333, 768, 40, 100, -1.0, "clustered"), (20500, 640, 129, 20, -1.0, "uniform"),
+    (20000, 256, 1, 10, -1.0, "unit"),
+])
+def test_int8_tier_under_l2_matches_the_oracle_and_the_bf16_tier(acc, oracle, n, d, nq, k, thr, kind):
+    """L2 batches on the int8 tier (scan_i8_kernel.hip, "L2 on the int8 tier"): the cosine tier's shadow, the score
+    bound G(u, |x|^2), an integer threshold with a per-row part — forced onto small shards through the
+    resident-query flag.  Bit-identical to the oracle (rows, cosines, distances) and to the bf16 tier, with and
+    without an allow-mask; nothing escalates on well-behaved norms."""
+    corpus, q = _l2_corpus(oracle, 71, n, d, nq, kind)
+    r = check(acc, oracle, corpus, q, k, thr=thr, metric=SCAN_L2, max_queries=6, expect_path=0, shadow="both",
+              expect_tier=_lib.TIER_I8, flags=_lib.FLAG_RESIDENT_QUERIES)
+    if kind != "clustered":
+        assert r.diag["exact_fallback_queries"] == 0, r.diag
+    b = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_NO_I8_FILTER, shadow="both")
+    assert b.diag["filter_tier"] == _lib.TIER_BF16
+    assert np.array_equal(r.rows, b.rows) and np.array_equal(r.counts, b.counts)
+    assert np.array_equal(r.scores.view(np.uint32), b.scores.view(np.uint32))
+    assert np.array_equal(r.dist.view(np.uint32), b.dist.view(np.uint32))
+    mask = np.random.default_rng(n).random(n) < 0.5
+    a = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_RESIDENT_QUERIES, shadow="both", mask=mask)
+    c = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_NO_I8_FILTER, shadow="both", mask=mask)
+    if a.diag["path"] == 0:      # (half of a small shard is a sparse mask: gathered and scored in fp64, no filter tier)
+        assert a.diag["filter_tier"] == _lib.TIER_I8 and c.diag["filter_tier"] == _lib.TIER_BF16
+    assert np.array_equal(a.rows, c.rows) and np.array_equal(a.counts, c.counts)
+    assert np.array_equal(a.dist.view(np.uint32), c.dist.view(np.uint32))
+
+
+def test_int8_tier_under_l2_steps_aside_for_norms_it_cannot_bound(acc, oracle):
+    """A zero row (valid under L2, but there is no unit vector to quantise) or norms spread over more than a
+    factor of two: the batch stays on the bf16 tier — same results."""
+    n, d, nq, k = 30000, 256, 140, 20
+    base, q = _l2_corpus(oracle, 73, n, d, nq, "uniform")
+    for how in ("zero", "wide"):
+        corpus = base.copy()
+        if how == "zero": corpus[12345] = 0
+        else: corpus[::7] *= np.float32(2.5)
+        r = check(acc, oracle, corpus, q, k, metric=SCAN_L2, max_queries=3, expect_path=0, shadow="both",
+                  expect_tier=_lib.TIER_BF16, flags=_lib.FLAG_RESIDENT_QUERIES)
+        assert r.diag["exact_fallback_queries"] == 0
 
 
 def test_int8_tier_proves_small_dense_shards_without_escalating(acc, oracle):

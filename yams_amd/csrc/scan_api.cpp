@@ -192,13 +192,38 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     const bool sparse_mask = corpus->row_mask && n_eff < 4 * kMfmaMinRows;
     bool use_mfma = !(params->flags & YAMS_SCAN_FLAG_FORCE_EXACT) && aligned &&
                     corpus->n_rows >= kMfmaMinRows && !sparse_mask;
+    // L2 on the int8 tier (scan_i8_kernel.hip, "L2 on the int8 tier") needs the shard's norm statistics: every
+    // squared norm inside the filter's range and a norm spread the per-query line can follow.  They ride on the
+    // sync the L2 path has anyway.
+    bool l2_i8_ok = false;
+    float* d_l2_nmin = nullptr; uint32_t* d_l2_stats = nullptr;
+    const bool l2_i8_wanted = use_mfma && metric == YAMS_SCAN_L2 && corpus->rows_i8 && corpus->rows_i8_meta && corpus->rows_nsq &&
+                              (dim & 127u) == 0 && dim >= 256 && dim <= 768 && corpus->n_rows >= 4096 &&
+                              (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
+                              !(params->flags & (YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER | YAMS_SCAN_FLAG_WIDE_TILE)) &&
+                              !split_only;
+    uint32_t* h_l2_stats = h_pin + 4 * static_cast<size_t>(nq) + 8;
     if (use_mfma && metric == YAMS_SCAN_L2) {
         // The L2 filter works on raw magnitudes; queries far outside the fp32 comfort zone take
         // the fp64 path (needs the norms on the host: one small sync).
         YA_HIP(ctx, hipMemcpyAsync(h_qnup, d_qnorm_up, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        if (l2_i8_wanted) {
+            const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
+            YA_TRY(ws_get(ctx, "i8_l2_nmin", static_cast<size_t>(n_blocks) * 4, (void**)&d_l2_nmin));
+            YA_TRY(ws_get(ctx, "i8_l2_stats", 32, (void**)&d_l2_stats));
+            YA_HIP(ctx, hipMemsetAsync(d_l2_stats, 0, 32, st));
+            YA_HIP(ctx, launch_i8_l2_norm_stats(st, corpus->rows_nsq, corpus->rows_i8_meta, corpus->n_rows, d_l2_nmin, d_l2_stats));
+            YA_HIP(ctx, hipMemcpyAsync(h_l2_stats, d_l2_stats, 32, hipMemcpyDeviceToHost, st));
+        }
         YA_HIP(ctx, hipStreamSynchronize(st));
         for (uint32_t i = 0; i < nq; ++i)
             if (!(h_qnup[i] < 1e15f) || (h_qnup[i] != 0.f && h_qnup[i] < 1e-15f)) use_mfma = false;
+        if (l2_i8_wanted) {
+            float lo, hi;
+            const uint32_t lo_bits = ~h_l2_stats[0], hi_bits = h_l2_stats[1];
+            std::memcpy(&lo, &lo_bits, 4); std::memcpy(&hi, &hi_bits, 4);
+            l2_i8_ok = h_l2_stats[3] == 0 && h_l2_stats[1] != 0 && hi <= 4.0f * lo; // no row outside the range, norms within a factor of two
+        }
     }
 
     uint64_t filter_candidates = 0, rescored_nested = 0;
@@ -244,7 +269,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // Batches of <= 128 queries take it when the shard is large enough for the resident-query kernel form
         // (decided below, once the plan is known); on smaller shards they stay on the narrow bf16 form when a
         // bf16 shadow is there too.
-        bool i8 = bf16 && passes == 1 && metric == YAMS_SCAN_COSINE && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
+        // L2 batches take it too when the shard's norms allow it (l2_i8_ok above) and the launch takes the
+        // resident-query kernel form — the only one that carries the per-row part of the L2 threshold.
+        bool i8 = bf16 && passes == 1 && (metric == YAMS_SCAN_COSINE || l2_i8_ok) && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                   !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER);
 #ifdef YAMS_ACCEL_MEASURE
@@ -266,7 +293,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (bf16_version == 40) L.i8_form = 1; // A/B runs: half tiles where the library would pick the resident-query form
 #endif
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
+        if (i8 && metric == YAMS_SCAN_L2 && !i8_takes_resident_form(L)) i8 = false;
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
+        if (i8 && metric == YAMS_SCAN_L2) { L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim); }
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms
@@ -289,8 +318,16 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "q_meta", static_cast<size_t>(q_pad) * 16, (void**)&d_qmeta));
             float* d_qthr;
             YA_TRY(ws_get(ctx, "q_thr", static_cast<size_t>(q_pad) * 8, (void**)&d_qthr));
-            YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, q_pad, dim, d_qi8, d_qmeta));
+            YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, q_pad, dim, d_qi8, d_qmeta, L.i8_l2));
             L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_thr = d_qthr; L.q_pad = q_pad; L.sample_layout = 1;
+            if (L.i8_l2) { // the per-batch tables of the L2 threshold: built after the sample pass (below)
+                const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
+                float* d_l2meta; uint8_t* d_rbias; uint32_t* d_qbias;
+                YA_TRY(ws_get(ctx, "i8_l2_meta", static_cast<size_t>(n_blocks) * 8, (void**)&d_l2meta));
+                YA_TRY(ws_get(ctx, "i8_l2_rbias", static_cast<size_t>(n_blocks) * 64, (void**)&d_rbias));
+                YA_TRY(ws_get(ctx, "i8_l2_qbias", static_cast<size_t>(q_pad) * 4, (void**)&d_qbias));
+                L.i8_l2_meta = d_l2meta; L.i8_row_bias = d_rbias; L.i8_q_bias = d_qbias;
+            }
         } else if (bf16) {
             uint16_t* d_qhi; uint16_t* d_qlo;
             const uint32_t q_pad = plan.n_qtiles * plan.tile_queries;
@@ -335,7 +372,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
         YA_HIP(ctx, launch_select_tau(st, L, d_work32));
-        if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
+        if (i8 && L.i8_l2) {
+            YA_HIP(ctx, launch_i8_l2_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, dim, d_l2_stats, const_cast<float*>(L.q_thr),
+                                                const_cast<uint32_t*>(L.i8_q_bias)));
+            YA_HIP(ctx, launch_i8_l2_rows(st, corpus->rows_nsq, corpus->rows_i8_meta, d_l2_nmin, corpus->n_rows, d_l2_stats,
+                                          const_cast<float*>(L.i8_l2_meta), const_cast<uint8_t*>(L.i8_row_bias)));
+        } else if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
         if (i8) YA_HIP(ctx, launch_i8_collect_sample(st, L)); else YA_HIP(ctx, launch_collect_sample(st, L));
         { GatedSweep gs(ctx, st); // sweeps of contexts that share a gate run one after the other
           TimedRegion tr(ctx, "scan_filter");

@@ -23,6 +23,10 @@ struct ScanArgs {
     uint32_t log_cap;
     uint32_t* q_over;          // [n_queries] set when a log region was too small for a query's survivors
     uint32_t* i8_sync;         // resident-query form: [n_streams][4 wave pairs][32 query tiles] strips drawn so far (zeroed before the launch)
+    // int8 tier, L2 batches (scan_i8_kernel.hip, "L2 on the int8 tier"): the per-row part of the integer threshold
+    const uint8_t* i8_row_bias; // [ceil(n_rows / 64)][4 lq][4 rb][4 r] a_r of row 16 rb + 4 lq + r of the block; null for cosine
+    const uint32_t* i8_q_bias;  // [q_pad] m_q: a survivor needs I >= T(block, q) + a_r m_q
+    float l2_eps;               // relative slack of the L2 score bound (i8_l2_eps)
     const float* qprep;     // [n_queries][dim] prepared queries (unit-norm for cosine, raw for L2)
     const uint16_t* q_hi;   // [dim/16][q_pad][16] bf16 head of qprep (split-bf16 kernel, k-slab-major)
     const uint16_t* q_lo;   // same layout: bf16 of (qprep - head)

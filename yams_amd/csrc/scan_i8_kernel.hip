@@ -72,6 +72,47 @@ __device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, floa
     return static_cast<int>(__builtin_amdgcn_fmed3f(t, -1.0737418e9f, 1.0737418e9f));
 }
 
+// -------------------------------------------------------------------------------------------------
+// L2 on the int8 tier (vec0 order: ascending |x - q|, i.e. descending g = q.x - |x|^2 / 2).
+// The shadow is the cosine tier's (unit rows), the queries stay raw, so u = s_b t_q I + e_b c_q + f_q
+// bounds x~ . q from above and, with n = |x| (sqrt of the fp32 squared norm of the bf16 shadow's
+// rows_nsq, relative error far below eps),
+//     g = n (x~ . q) - n^2 / 2  <=  n u - n^2 / 2 + eps (|n u| + n^2 / 2) =: G(u, n^2)      (i8_l2_bound)
+// is the filter score: sample maxima, tau, the candidate keys and the re-score's proof all live in
+// units of g, exactly as on the bf16 tier.  What is new is the integer threshold.  G >= tau needs
+//     u >= h(n) = tau' / n + n / 2,      tau' = tau - (the most the eps term can add for this query),
+// and h is concave (tau' < 0) or convex in n, never linear: a block threshold from the smallest norm
+// of the block alone would let through everything within beta (n_r - nmin_b) of the bound — for rows
+// whose norms spread by 1.6 % (uniform components, dim 768) that is a thousand times the survivors.
+// So per query a LINE below h over the shard's norm range [Nmin, Nmax],
+//     h(n) >= alpha_q + beta_q n,   beta_q = max(1/2 - tau' / (Nmin Nmax), 0),
+//     alpha_q = min over [Nmin, Nmax] of h(n) - beta_q n   (the end points, or the stationary point of
+//     a convex h) — the chord of a concave h, the tangent at the geometric mean of a convex one,
+// which splits the condition into a block part and a row part, n_r = nmin_b + d_r:
+//     I >= [(alpha_q - f_q - c_q e_max) / t_q] / s_b + (beta_q / t_q) nmin_b / s_b + (beta_q / t_q) d_r / s_b
+//          `----------------- T(block, query): A_q IS_b - B_q G_b -----------------'   `--- >= a_r m_q ---'
+// with e_max = the largest e_b of the shard (e_b is the largest of 64 measured residues: it hardly varies
+// from block to block, and c_q (e_max - e_b) is all this costs).  T has the cosine tier's form with the
+// block's second meta word replaced by -nmin_b: the filter kernel gets a second meta array and is otherwise unchanged.  The
+// row part is an 8-bit a_r = floor(d_r / (s_b W)) (W = the largest d_r / s_b of the shard / 255) times
+// a per-query integer m_q = floor(beta_q W / t_q): accumulators start at -T - a_r m_q, one v_mad_i24
+// per element where the cosine kernel has a v_mov.  The gather kernel undoes both, forms G and keeps
+// the rows with G >= tau.  Preconditions (scan_api.cpp): every squared norm inside norm_in_range()
+// (else the bf16 tier, whose NaN scores carry such rows), Nmax / Nmin <= 2, the resident-query form.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float i8_l2_bound(float u, float nsq, float eps) {
+    const float t1 = sqrtf(nsq) * u;
+    return fmaf(eps, fmaf(0.5f, nsq, fabsf(t1)), fmaf(-0.5f, nsq, t1));
+}
+// d_r: how far row norm n lies above its block's smallest, made safe against the rounding of both square roots
+__device__ __forceinline__ float i8_l2_spread(float n, float nmin) {
+    return fmaxf(0.f, (n - nmin) - n * 2.3841858e-7f);
+}
+// W from the largest d_r / s_b of the shard (the same expression wherever a_r or m_q is formed)
+__device__ __forceinline__ float i8_l2_unit(uint32_t spread_max_bits) {
+    return __uint_as_float(spread_max_bits) * (1.0f / 255.0f) * (1.0f + 9.5367432e-7f);
+}
+
 
 // -------------------------------------------------------------------------------------------------
 // The filter on HALF tiles: 128 rows x 256 queries per workgroup of FOUR waves (wave tile still
@@ -88,8 +129,11 @@ constexpr int H_STAGE = H_A_BYTES + I8_B_BYTES;    // 24 KiB
 // MODE_SAMPLE writes group maxima (groups of 16 rows: the rows one lane holds for a query block — 4 row
 // blocks x 4 consecutive rows) and, only when a dense buffer is given, all upper bounds (the int8 tier runs
 // without one: i8_collect_sample_kernel re-derives the scores of the groups that reach tau).
-template <int MODE, int ABL = 0>
+// METRIC (sample pass only): under L2 the score of a row is G(u, |x|^2) (i8_l2_bound); the filter pass of
+// L2 batches always takes the resident-query form.
+template <int MODE, int ABL = 0, int METRIC = YAMS_SCAN_COSINE>
 __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a) {
+    static_assert(METRIC == YAMS_SCAN_COSINE || MODE == MODE_SAMPLE, "L2: sample pass only");
     __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
     __shared__ uint32_t wave_log[4]; // survivors each wave has logged (wave-private slots)
 
@@ -316,6 +360,16 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
     const uint32_t qb = q0 + wc * 128;
     if (MODE == MODE_SAMPLE) {
         const float ninf = -__builtin_inff();
+        float nsqv[4][4]; // L2: the squared norms of this lane's sixteen rows
+        if (METRIC == YAMS_SCAN_L2) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t row = strip + 16 * rb + 4 * lq + r;
+                    nsqv[rb][r] = row < a.n_rows ? a.rows_nsq[row] : 1.f;
+                }
+        }
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             const uint32_t qi = qb + cb * 16 + l15;
@@ -330,7 +384,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                    float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                    if (METRIC == YAMS_SCAN_L2) u = i8_l2_bound(u, nsqv[rb][r], a.l2_eps);
                     v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
                     m = fmaxf(m, v[r]);
                 }
@@ -445,7 +500,9 @@ constexpr int R_B_SLAB = R_QUERIES * I8_SLAB;      // 8 KiB of queries per k-sla
 constexpr int R_RING = 2 * 64 * I8_SLAB;           // per wave: two slabs of its 64 rows
 constexpr int R_LDS = R_MAX_SLABS * R_B_SLAB + 8 * R_RING; // 160 KiB: everything a CU has
 
-template <int ABL = 0>
+// L2: the accumulators start at -T(block, query) - a_r m_q ("L2 on the int8 tier" above); a.rows_i8_meta is the
+// batch's thresholds meta, a.i8_row_bias / a.i8_q_bias hold a_r and m_q.  Nothing else differs.
+template <int ABL = 0, bool L2 = false>
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
 
@@ -519,9 +576,35 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int cb = 0; cb < 8; ++cb)
             asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(qthr[cb]) : "v"(qthr_p), "n"(cb * 128) : "memory");
     };
+    // L2: m_q of this lane's eight queries and a_r of its sixteen rows of a strip (one 16-byte load: byte r of word
+    // rb = row 16 rb + 4 lq + r), requested and completed together with the thresholds — like them they live only
+    // from the end of one strip to the accumulator set-up of the next, in registers the k loop has no use for then
+    int qbias[8];
+    i32x4v rbias;
+    // (uniform base + 32-bit lane offset: no 64-bit per-lane address has to stay alive across the k loop)
+    auto qbias_request = [&]() __attribute__((always_inline)) {
+        const uint32_t* sb_ = a.i8_q_bias + q0; // < q_pad with the lane offsets
+        const uint32_t voff = static_cast<uint32_t>(lane & 15) * 4u;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+            asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(qbias[cb]) : "v"(voff), "s"(sb_), "n"(cb * 64) : "memory");
+    };
+    auto rbias_request = [&](uint64_t row0) __attribute__((always_inline)) {
+        uint64_t blk = row0 / I8_BLOCK_ROWS;
+        if (blk >= n_blocks) blk = n_blocks - 1; // a strip past the end: nothing of it is ever emitted
+        const uint8_t* sb_ = a.i8_row_bias + blk * 64u;
+        const uint32_t voff = static_cast<uint32_t>(lane >> 4) * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbias) : "v"(voff), "s"(sb_) : "memory");
+    };
     auto qthr_wait = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
-                                            "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+        if (L2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]), "+v"(rbias),
+                                                "+v"(qbias[0]), "+v"(qbias[1]), "+v"(qbias[2]), "+v"(qbias[3]),
+                                                "+v"(qbias[4]), "+v"(qbias[5]), "+v"(qbias[6]), "+v"(qbias[7]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
     };
 
     // ---- prologue: the resident query tile (wave w stages 16 queries of every slab), the first two
@@ -565,6 +648,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     qthr_request();
+    if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
         const float* mp = meta_ptr(cur.row0);
@@ -689,7 +773,9 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt[cb];
+                for (int r = 0; r < 4; ++r)
+                    acc[rb][cb][r] = L2 ? nt[cb] - __mul24(static_cast<int>((static_cast<uint32_t>(rbias[rb]) >> (8 * r)) & 255u), qbias[cb])
+                                        : nt[cb];
         // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
         // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
         int s = 0;
@@ -709,6 +795,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         uint32_t sib = 0; // pacing: the siblings' strip counters
         if (THR && n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
         if (THR) qthr_request();         // for the NEXT unit's thresholds; in flight under the sign test below
+        if (THR && L2) { qbias_request(); rbias_request(nxt.row0); }
 
         // ---- epilogue of the unit: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
         //      the accumulators hold I - T, a survivor is a non-negative one ---------------------------------
@@ -860,10 +947,17 @@ __global__ __launch_bounds__(256) void i8_log_gather_kernel(const uint64_t* log_
 // of a region belong to ONE 128-query tile.  A workgroup per region: the entries are counted per query in LDS,
 // every query present reserves its list slots with ONE global atomic (the per-entry atomics of the form above
 // piled 1000 increments on each of 1024 addresses), then the entries are placed.
+// L2: the log entry is I - T - a_r m_q; T comes from the batch's thresholds meta, u from the shadow's own meta, the
+// score is G(u, |x|^2) and only rows with G >= tau are kept (the integer test is a necessary condition only).
+struct I8GatherL2 {
+    const float* l2_meta;       // [blocks][2] thresholds meta of the batch (what the filter kernel saw)
+    const uint8_t* row_bias; const uint32_t* q_bias; const float* rows_nsq; const float* tau; float eps;
+};
+template <bool L2>
 __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t* log_key, const uint32_t* log_q, const uint32_t* log_cnt,
                                                                  uint32_t log_cap, uint32_t n_qt, const float* rows_meta,
                                                                  const float* q_meta, const float* q_thr, uint32_t* list_count,
-                                                                 uint64_t* list, uint32_t list_cap) {
+                                                                 uint64_t* list, uint32_t list_cap, I8GatherL2 l2) {
     __shared__ uint32_t hist[R_QUERIES], slot0[R_QUERIES];
     const uint32_t r = blockIdx.x;
     const uint32_t n = log_cnt[r];
@@ -874,7 +968,37 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
     __syncthreads();
     const uint64_t* keys = log_key + static_cast<uint64_t>(r) * log_cap;
     const uint32_t* qs = log_q + static_cast<uint64_t>(r) * log_cap;
-    for (uint32_t i = tid; i < n; i += 256) atomicAdd(&hist[qs[i] - q0], 1u);
+    // the score of entry i (same inputs, same instructions as the filter kernel for T); false = not a candidate
+    auto score = [&](uint32_t i, uint32_t& q, uint32_t& row, float& u) __attribute__((always_inline)) -> bool {
+        const uint64_t e = keys[i];
+        q = qs[i];
+        row = static_cast<uint32_t>(e);
+        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
+        const uint32_t blk = row / I8_BLOCK_ROWS;
+        const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
+        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
+        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
+        if (!L2) {
+            const float is = 1.0f / m.x;
+            const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
+            u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+            return true;
+        }
+        const float2 mt = reinterpret_cast<const float2*>(l2.l2_meta)[blk];
+        const float is = 1.0f / mt.x;
+        const int nt = i8_neg_threshold(qt.x, is, qt.y, mt.y * is);
+        const uint32_t j = row & 63u;
+        const int ar = l2.row_bias[static_cast<uint64_t>(blk) * 64u + ((j >> 2) & 3u) * 16u + (j >> 4) * 4u + (j & 3u)];
+        const int dot = accv - nt + ar * static_cast<int>(l2.q_bias[q]);
+        const float ub = fmaf(static_cast<float>(dot), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        u = i8_l2_bound(ub, l2.rows_nsq[row], l2.eps);
+        return !(u < l2.tau[q]);
+    };
+    for (uint32_t i = tid; i < n; i += 256) {
+        uint32_t q, row; float u;
+        if (!L2) atomicAdd(&hist[qs[i] - q0], 1u);
+        else if (score(i, q, row, u)) atomicAdd(&hist[q - q0], 1u);
+    }
     __syncthreads();
     if (tid < R_QUERIES) {
         const uint32_t c = hist[tid];
@@ -883,16 +1007,8 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) {
-        const uint64_t e = keys[i];
-        const uint32_t q = qs[i];
-        const uint32_t row = static_cast<uint32_t>(e);
-        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
-        const float2 m = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
-        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
-        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
-        const float is = 1.0f / m.x;
-        const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
-        const float u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        uint32_t q, row; float u;
+        if (!score(i, q, row, u)) continue;
         const uint32_t pos = slot0[q - q0] + atomicAdd(&hist[q - q0], 1u);
         if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
@@ -909,7 +1025,7 @@ __global__ __launch_bounds__(256) void i8_collect_sample_kernel(const uint32_t* 
                                                                 const float* q_meta, uint32_t q_pad, uint32_t dim,
                                                                 uint32_t stride, uint64_t n_rows, const uint32_t* row_mask,
                                                                 const float* tau, uint32_t* list_count, uint64_t* list,
-                                                                uint32_t list_cap) {
+                                                                uint32_t list_cap, const float* l2_rows_nsq, float l2_eps) {
     const uint32_t q = blockIdx.y;
     const float t = tau[q];
     const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
@@ -943,7 +1059,8 @@ __global__ __launch_bounds__(256) void i8_collect_sample_kernel(const uint32_t* 
             if (lane < 16 && ok) {
                 const float2 bm = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
                 const float S = bm.x * qm.x, K = fmaf(bm.y, qm.y, qm.z);   // (as in the sample pass's epilogue)
-                const float u = fmaf(static_cast<float>(dot), S, K);
+                float u = fmaf(static_cast<float>(dot), S, K);
+                if (l2_rows_nsq) u = i8_l2_bound(u, l2_rows_nsq[row], l2_eps); // (L2 batches: as in the sample pass's epilogue)
                 if (!(u < t)) {
                     const uint32_t pos = atomicAdd(&list_count[q], 1u);
                     if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, static_cast<uint32_t>(row));
@@ -1066,8 +1183,9 @@ __global__ __launch_bounds__(256) void i8_meta_stats_kernel(const float* meta, u
 // layout the filter's DMA pieces expect); meta[q] = {t_q, c_q, f_q, 0} with c_q >= |t_q qi| and
 // f_q >= |q~ - t_q qi| + 1e-6 (the absolute slop covers the fp32 evaluation of the score bound and the
 // fp64 -> fp32 rounding of the exact similarity).  Padding queries are zero with t_q = 1.
+// raw (L2 batches): the queries are not unit vectors, the absolute slop scales with their norm.
 __global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                                                      int8_t* q_i8, float* q_meta) {
+                                                      int8_t* q_i8, float* q_meta, int raw) {
     const uint32_t q = blockIdx.x;
     __shared__ float red[256];
     const bool live = q < nq;
@@ -1116,7 +1234,8 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32
         const float up = 1.0f + (fd + 16.f) * 5.9604645e-8f;
         q_meta[4 * q + 0] = t;
         q_meta[4 * q + 1] = ok ? sqrtf(csum) * up : 0.f;
-        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + (fd + 32.f) * 5.9604645e-8f + 1e-6f : 0.f;
+        const float unit = raw ? sqrtf(csum) * up : 1.0f;
+        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + ((fd + 32.f) * 5.9604645e-8f + 1e-6f) * unit : 0.f;
         q_meta[4 * q + 3] = 0.f;
     }
 }
@@ -1140,6 +1259,121 @@ __global__ void i8_query_thresholds_kernel(const float* tau, const float* q_meta
     }
     q_thr[2 * q] = A;
     q_thr[2 * q + 1] = B;
+}
+
+// ---- L2 on the int8 tier: the per-batch tables ("L2 on the int8 tier" at the top of this file) --------------
+// stats words: [0] ~bits(smallest squared norm), [1] bits(largest), [2] bits(largest d_r / s_b), [3] rows whose
+// squared norm is outside norm_in_range(), [4] bits(largest e_b).  All values are positive floats (their bit patterns
+// order like the values), the buffer starts zeroed.
+// (1) One wave per 64-row block, grid-stride; a workgroup folds its blocks before it touches the shared words.
+__global__ __launch_bounds__(256) void i8_l2_norm_stats_kernel(const float* rows_nsq, const float* rows_meta, uint64_t n_rows,
+                                                               uint64_t n_blocks, float* nmin_out, uint32_t* stats) {
+    __shared__ uint32_t red[4][5];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t lo = 0xffffffffu, hi = 0u, sp = 0u, bad = 0u, em = 0u; // wave-uniform after each block
+    for (uint64_t blk = static_cast<uint64_t>(blockIdx.x) * 4u + wid; blk < n_blocks; blk += static_cast<uint64_t>(gridDim.x) * 4u) {
+        const uint64_t r = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
+        const bool live = r < n_rows;
+        const float nsq = live ? rows_nsq[r] : 1.f;
+        const bool ok = live && norm_in_range(nsq);
+        bad += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !ok)));
+        const float n = sqrtf(nsq);
+        float mn = ok ? n : __builtin_inff(), mx = ok ? n : 0.f;
+        float qlo = ok ? nsq : __builtin_inff(), qhi = ok ? nsq : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, d)); mx = fmaxf(mx, __shfl_xor(mx, d));
+            qlo = fminf(qlo, __shfl_xor(qlo, d)); qhi = fmaxf(qhi, __shfl_xor(qhi, d));
+        }
+        const float sb = rows_meta[2 * blk];
+        em = max(em, __float_as_uint(rows_meta[2 * blk + 1])); // (e_b >= 0)
+        float d_over_s = ok ? i8_l2_spread(n, mn) / sb : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) d_over_s = fmaxf(d_over_s, __shfl_xor(d_over_s, d));
+        if (lane == 0) nmin_out[blk] = mn; // (+inf for a block without a usable row: the batch leaves this tier anyway)
+        if (qlo < __builtin_inff()) {
+            lo = min(lo, __float_as_uint(qlo)); hi = max(hi, __float_as_uint(qhi));
+            sp = max(sp, __float_as_uint(d_over_s));
+        }
+    }
+    if (lane == 0) { red[wid][0] = lo; red[wid][1] = hi; red[wid][2] = sp; red[wid][3] = bad; red[wid][4] = em; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); sp = max(sp, red[w][2]); bad += red[w][3]; em = max(em, red[w][4]);
+        }
+        if (lo != 0xffffffffu) { atomicMax(&stats[0], ~lo); atomicMax(&stats[1], hi); atomicMax(&stats[2], sp); }
+        atomicMax(&stats[4], em);
+        if (bad) atomicAdd(&stats[3], bad);
+    }
+}
+
+// (2) After the sample pass, one thread per (padded) query: q_thr = {A_lo, B}, q_bias = m_q.  fp64 for the line
+// under h; the fp32 values the filter kernel multiplies carry the cosine tier's slack (A: 2^-19 downwards; B is
+// rounded to nearest, its slack sits in the thresholds meta, i8_l2_rows_kernel).
+__global__ void i8_l2_thresholds_kernel(const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad, float eps,
+                                        const uint32_t* stats, float* q_thr, uint32_t* q_bias) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q_pad) return;
+    float A = __builtin_inff(), B = 0.f;
+    uint32_t mq = 0u;
+    if (q < nq) {
+        const float t = q_meta[4 * q], c = q_meta[4 * q + 1], f = q_meta[4 * q + 2], ta = tau[q];
+        if (!(ta > -__builtin_inff())) A = -__builtin_inff(); // no threshold (or NaN): keep everything
+        else {
+            const double n_lo = sqrt(static_cast<double>(__uint_as_float(~stats[0])));
+            const double n_hi = sqrt(static_cast<double>(__uint_as_float(stats[1])));
+            const double W = static_cast<double>(i8_l2_unit(stats[2]));
+            // |u| <= (1 + 2 e_b) c + f < 3 c + f; the eps term of G is at most eps (n |u| + n^2 / 2)
+            const double u_max = 3.0 * c + f;
+            const double tp = static_cast<double>(ta) - 1.5 * eps * (n_hi * u_max + 0.5 * n_hi * n_hi);
+            double beta = 0.5 - tp / (n_lo * n_hi);
+            if (!(beta >= 0.0)) beta = 0.0; // (the block and row parts use the smallest norms: the slope may not be negative)
+            const double slope = 0.5 - beta; // phi(n) = h(n) - beta n = tp / n + slope n
+            double alpha = fmin(tp / n_lo + slope * n_lo, tp / n_hi + slope * n_hi);
+            if (tp > 0.0 && slope > 0.0) { // convex h: the stationary point of phi, when it lies inside the range
+                const double ns = sqrt(tp / slope);
+                if (ns > n_lo && ns < n_hi) alpha = fmin(alpha, 2.0 * sqrt(tp * slope));
+            }
+            alpha -= fabs(alpha) * 1e-12 + 1e-300;
+            const double e_max = static_cast<double>(__uint_as_float(stats[4])) * (1.0 + 1e-6);
+            A = static_cast<float>((alpha - static_cast<double>(f) - static_cast<double>(c) * e_max) / static_cast<double>(t));
+            A -= fabsf(A) * 1.9073486e-6f;
+            B = static_cast<float>(beta / static_cast<double>(t));
+            const double m = floor(beta / static_cast<double>(t) * W * (1.0 - 1e-6));
+            mq = m > 0.0 ? (m < 2097152.0 ? static_cast<uint32_t>(m) : 2097152u) : 0u;
+            if (!(fabsf(A) <= 1e15f) || !(B <= 1e15f)) { A = -__builtin_inff(); B = 0.f; mq = 0u; } // far outside any sane range: keep everything rather than overflow a product
+        }
+    }
+    q_thr[2 * q] = A;
+    q_thr[2 * q + 1] = B;
+    q_bias[q] = mq;
+}
+
+// (3) One wave per block: the thresholds meta {s_b, -nmin_b (rounded up)} and the row biases
+// a_r = floor(d_r / (s_b W)), stored where the filter kernel's lanes fetch them: [block][lq][rb][r].
+__global__ __launch_bounds__(256) void i8_l2_rows_kernel(const float* rows_nsq, const float* rows_meta, const float* nmin_in,
+                                                         uint64_t n_rows, uint64_t n_blocks, const uint32_t* stats,
+                                                         float* l2_meta, uint8_t* row_bias) {
+    const uint64_t blk = static_cast<uint64_t>(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x & 63;
+    const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
+    const float nmin = nmin_in[blk];
+    const float W = i8_l2_unit(stats[2]);
+    const uint64_t r = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
+    uint32_t ar = 0u;
+    if (r < n_rows && W > 0.f) {
+        const float d_over_s = i8_l2_spread(sqrtf(rows_nsq[r]), nmin) / m.x;     // (as in i8_l2_norm_stats_kernel)
+        const float v = floorf(d_over_s / W * (1.0f - 9.5367432e-7f));
+        ar = static_cast<uint32_t>(fminf(fmaxf(v, 0.f), 255.f));
+    }
+    const uint32_t j = static_cast<uint32_t>(lane);
+    row_bias[blk * 64u + ((j >> 2) & 3u) * 16u + (j >> 4) * 4u + (j & 3u)] = static_cast<uint8_t>(ar);
+    if (lane == 0) {
+        l2_meta[2 * blk] = m.x;
+        l2_meta[2 * blk + 1] = -nmin * (1.0f - 4.0531158e-6f); // (2^-22 for the square root, 2^-18 for the products the filter kernel forms with it)
+    }
 }
 
 } // namespace yams_accel
@@ -1167,9 +1401,38 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
 }
 
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta) {
+                          int8_t* q_i8, float* q_meta, bool raw_queries) {
     if (q_pad == 0) return hipSuccess;
-    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta);
+    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta, raw_queries ? 1 : 0);
+    return hipGetLastError();
+}
+
+float i8_l2_eps(uint32_t dim) { return (static_cast<float>(dim) + 64.f) * 5.9604645e-8f; }
+
+hipError_t launch_i8_l2_norm_stats(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, uint64_t n_rows,
+                                   float* nmin, uint32_t* stats) {
+    const uint64_t n_blocks = (n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t want = (n_blocks + 3) / 4;
+    hipLaunchKernelGGL(i8_l2_norm_stats_kernel, dim3(static_cast<uint32_t>(want < 2048 ? want : 2048)), dim3(256), 0, st,
+                       rows_nsq, rows_i8_meta, n_rows, n_blocks, nmin, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_l2_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
+                                   uint32_t dim, const uint32_t* stats, float* q_thr, uint32_t* q_bias) {
+    if (q_pad == 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_l2_thresholds_kernel, dim3((q_pad + 255) / 256), dim3(256), 0, st, tau, q_meta, nq, q_pad,
+                       i8_l2_eps(dim), stats, q_thr, q_bias);
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_l2_rows(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, const float* nmin,
+                             uint64_t n_rows, const uint32_t* stats, float* l2_meta, uint8_t* row_bias) {
+    const uint64_t n_blocks = (n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_l2_rows_kernel, dim3(static_cast<uint32_t>((n_blocks + 3) / 4)), dim3(256), 0, st, rows_nsq,
+                       rows_i8_meta, nmin, n_rows, n_blocks, stats, l2_meta, row_bias);
     return hipGetLastError();
 }
 
@@ -1235,7 +1498,8 @@ hipError_t launch_i8_collect_sample(hipStream_t st, const ScanLaunch& L) {
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(i8_collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.gmax, L.plan.n_groups,
                        L.plan.n_queries, L.rows_i8, L.rows_i8_meta, L.q_i8, L.q_meta, L.q_pad, L.plan.dim, L.plan.sample_stride,
-                       L.plan.n_rows, L.row_mask, L.tau, L.list_count, L.list, L.plan.list_cap);
+                       L.plan.n_rows, L.row_mask, L.tau, L.list_count, L.list, L.plan.list_cap,
+                       L.i8_l2 ? L.rows_nsq : nullptr, L.l2_eps);
     return hipGetLastError();
 }
 
@@ -1255,7 +1519,7 @@ uint32_t i8_log_capacity(const ScanLaunch& L) {
     if (r.use) {
         const double total = static_cast<double>(p.n_queries) * p.tau_rank * p.sample_stride;
         const double share = total / (static_cast<double>(r.n_streams) * r.n_qt * 8.0);
-        const double cap = 4.0 * share + 256.0;
+        const double cap = (L.i8_l2 ? 8.0 : 4.0) * share + 256.0; // (L2: the integer test lets through somewhat more than reach tau)
         const uint64_t c = static_cast<uint64_t>(cap < 4.0e6 ? cap : 4.0e6);
         return static_cast<uint32_t>((c + 15) / 16 * 16);
     }
@@ -1269,9 +1533,15 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     if (regions == 0) return hipSuccess;
     const ResidentPlan rp = i8_resident_plan(L);
     if (rp.use) {
-        hipLaunchKernelGGL(i8_log_gather_wave_kernel, dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
-                           L.log_key, L.log_q, L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count,
-                           L.list, L.plan.list_cap);
+        const I8GatherL2 l2{L.i8_l2_meta, L.i8_row_bias, L.i8_q_bias, L.rows_nsq, L.tau, L.l2_eps};
+        if (L.i8_l2)
+            hipLaunchKernelGGL((i8_log_gather_wave_kernel<true>), dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
+                               L.log_key, L.log_q, L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count,
+                               L.list, L.plan.list_cap, l2);
+        else
+            hipLaunchKernelGGL((i8_log_gather_wave_kernel<false>), dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
+                               L.log_key, L.log_q, L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count,
+                               L.list, L.plan.list_cap, l2);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(i8_log_gather_kernel, dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
@@ -1293,10 +1563,17 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t hgrid = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
     if (mode == MODE_SAMPLE) {
-        hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        if (L.i8_l2) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
+    if (L.i8_l2) { // L2 batches: the resident-query form only (scan_api.cpp checks that the plan takes it)
+        if (!rp.use) return hipErrorInvalidValue;
+        a.rows_i8_meta = L.i8_l2_meta; // the thresholds meta of this batch; the shadow's own meta is the gather kernel's
+        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+        return hipGetLastError();
+    }
     uint32_t window = 1; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; measured on the bench launch: window 1 17 GB from HBM and 7.6-7.8 ms, 2 / 3 20 GB and 7.9 ms, unpaced 19+ GB)
 #ifdef YAMS_ACCEL_MEASURE
     if (version >= 41 && version <= 48) {

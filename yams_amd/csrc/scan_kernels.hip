@@ -1098,7 +1098,7 @@ ScanArgs make_scan_args(const ScanLaunch& L) {
     ScanArgs a{};
     a.rows = L.rows; a.rows_bf16 = L.rows_bf16; a.rows_nsq = L.rows_nsq;
     a.rows_i8 = L.rows_i8; a.rows_i8_meta = L.rows_i8_meta; a.q_i8 = L.q_i8; a.q_meta = L.q_meta; a.q_thr = L.q_thr;
-    a.log_key = L.log_key; a.log_q = L.log_q; a.log_cnt = L.log_cnt; a.log_cap = L.log_cap; a.q_over = L.q_over; a.i8_sync = L.i8_sync; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
+    a.log_key = L.log_key; a.log_q = L.log_q; a.log_cnt = L.log_cnt; a.log_cap = L.log_cap; a.q_over = L.q_over; a.i8_sync = L.i8_sync; a.i8_row_bias = L.i8_row_bias; a.i8_q_bias = L.i8_q_bias; a.l2_eps = L.l2_eps; a.row_mask = L.row_mask; a.qprep = L.qprep; a.q_hi = L.q_hi; a.q_lo = L.q_lo; a.q_pad = L.q_pad; a.n_rows = L.plan.n_rows; a.dim = L.plan.dim;
     a.n_queries = L.plan.n_queries; a.stride = L.plan.sample_stride; a.n_qtiles = L.plan.n_qtiles;
     a.dense = L.dense; a.gmax = L.gmax; a.sample_rows = L.plan.sample_rows;
     a.n_groups = L.plan.n_groups; a.tau = L.tau; a.list_count = L.list_count; a.list = L.list;

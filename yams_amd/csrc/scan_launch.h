@@ -17,6 +17,12 @@ struct ScanLaunch {
     uint64_t* log_key = nullptr; uint32_t* log_q = nullptr; uint32_t* log_cnt = nullptr; uint32_t log_cap = 0;
     uint32_t* q_over = nullptr;
     uint32_t* i8_sync = nullptr;         // resident-query form of the int8 filter: pacing counters (i8_sync_words())
+    // int8 tier under L2 (launch_i8_l2_*): thresholds meta {s_b, -nmin_b}, row / query biases
+    bool i8_l2 = false;
+    const float* i8_l2_meta = nullptr;
+    const uint8_t* i8_row_bias = nullptr;
+    const uint32_t* i8_q_bias = nullptr;
+    float l2_eps = 0.f;
     int i8_form = 0;                     // int8 filter pass: 0 = the library's choice, 1 = half tiles, 2 = resident queries when possible
     int sample_layout = 0;               // rows of a sample group: 0 = 32x32 accumulator layout, 1 = 16x16 (int8 tier)
     const uint32_t* row_mask = nullptr;
@@ -73,7 +79,20 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
 hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version);
 // Quantises the prepared (unit) queries of a batch: k-slab-major int8 plane + {t_q, c_q, f_q} per query.
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta);
+                          int8_t* q_i8, float* q_meta, bool raw_queries = false);
+// L2 on the int8 tier.  Per batch and shard: (1) norm statistics of the shard — per 64-row block the smallest row norm,
+// shard-wide the norm range, the largest in-block spread in units of the block scale, and how many rows have a
+// squared norm outside norm_in_range() (any such row keeps the batch off this tier); stats = 8 words, zeroed first.
+// (2) after the sample pass: the per-query threshold halves and biases; (3) the per-block thresholds meta and the
+// per-row biases.  nmin = [ceil(n_rows / 64)] floats of workspace.  stats words: ~bits(min |x|^2), bits(max |x|^2),
+// bits(max in-block norm spread / s_b), rows out of range, bits(max e_b).
+hipError_t launch_i8_l2_norm_stats(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, uint64_t n_rows,
+                                   float* nmin, uint32_t* stats);
+hipError_t launch_i8_l2_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
+                                   uint32_t dim, const uint32_t* stats, float* q_thr, uint32_t* q_bias);
+hipError_t launch_i8_l2_rows(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, const float* nmin,
+                             uint64_t n_rows, const uint32_t* stats, float* l2_meta, uint8_t* row_bias);
+float i8_l2_eps(uint32_t dim);
 // (Re)builds the INT8 shadow of every 16-row block that intersects rows [first_row, first_row + n_rows)
 // of the mirror at `rows`; stats (nullable) = {sum of e_b (double), blocks counted (u64 bits)}.
 hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
