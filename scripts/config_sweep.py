@@ -36,10 +36,16 @@ for name, n, d, nq, k, metric in [("C1", 10_000, 384, 1, 10, SCAN_COSINE), ("C2"
     for _ in range(reps):
         acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr(), want_diag=False)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    acc.enable_timing(True)     # (HIP events around the two sweeps: serialises the call, so outside the timed loop)
+    acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(), dist.data_ptr(), want_diag=False)
+    torch.cuda.synchronize()
+    filt_ms, _ = acc.kernel_ms("scan_filter"); samp_ms, _ = acc.kernel_ms("scan_sample")
+    acc.enable_timing(False)
     rows.append({"config": name, "rows": n, "dim": d, "Q": nq, "k": k, "metric": "l2" if metric else "cosine",
                  "ms": dt * 1e3, "QPS": nq / dt, "algorithmic_TFLOPs": 2.0 * n * d * nq / dt / 1e12,
                  "corpus_GBps": n * d * 4 / dt / 1e9, "path": diag["path"], "fallbacks": diag["exact_fallback_queries"], "escalated": diag["escalated_queries"],
-                 "widened": diag["widened_queries"], "filter_tier": diag["filter_tier"]})
+                 "widened": diag["widened_queries"], "filter_tier": diag["filter_tier"], "filter_candidates": diag["filter_candidates"],
+                 "filter_kernel_ms": filt_ms, "sample_kernel_ms": samp_ms})
     del tc, tq, tb, tn, t8, tm8, view
     torch.cuda.empty_cache()
 for r_ in rows:
