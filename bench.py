@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true")
+    ap.add_argument("--no-l2-leg", action="store_true", help="skip the BASELINE config 3 (10M x 768 L2) leg")
     ap.add_argument("--oracle-queries", type=int, default=None, help="queries checked against the oracle over the whole resident corpus (default 4 at N=1, 2 at N>1; 0 = skip)")
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
     ap.add_argument("--seed", type=int, default=42)
@@ -419,7 +420,7 @@ def main():
     import torch
     from yams_amd import dist as ydist
     from yams_amd.accel import Accel
-    from yams_amd._lib import SCAN_COSINE
+    from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_NO_I8_FILTER
 
     if a.single_device:
         os.environ["LOCAL_RANK"] = "0"
@@ -673,6 +674,57 @@ def main():
                    "ms_per_step": dt64 * 1e3, "qps_on_resident_corpus": q64 / dt64,
                    "results_identical_to_the_q1024_run": same}
 
+    # ---- BASELINE config 3 on the same resident rows: 10M x 768, L2 top-k, 1024 queries, N = 1 ------
+    # (a prefix of the shard and of its shadows — the blocked int8 shadow of the first 10M rows is a prefix too)
+    l2_leg = None
+    n3 = 10_000_000
+    if (world == 1 and not a.no_l2_leg and tb is not None and t8 is not None and n >= n3 and d == 768 and nq >= 1024
+            and scan_flags == 0):
+        view3 = acc.corpus_view(tc.data_ptr(), n3, d, row_base=row_base, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                                rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
+        q3 = 1024
+        s3 = torch.empty((q3, k), dtype=torch.float32, device=dev); r3 = torch.empty((q3, k), dtype=torch.int64, device=dev)
+        c3 = torch.empty(q3, dtype=torch.int32, device=dev); d3 = torch.empty((q3, k), dtype=torch.float32, device=dev)
+
+        def step3(flags=0, want_diag=False, out=(s3, r3, c3, d3)):
+            return acc.scan_topk_device(view3, tq.data_ptr(), q3, k, -1.0, SCAN_L2, out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr(), out[3].data_ptr(), flags=flags, want_diag=want_diag)
+        for _ in range(max(2, a.warmup)):
+            step3()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step3()
+        torch.cuda.synchronize(); dt3 = (time.perf_counter() - t1) / a.steps
+        acc.enable_timing(True)
+        dg3 = step3(want_diag=True)
+        torch.cuda.synchronize()
+        f3_ms, _ = acc.kernel_ms("scan_filter")
+        acc.enable_timing(False)
+        # the same batch through the bf16 tier: every query, bit for bit (the full-size oracle check of this shape is
+        # tests/test_scan_gpu.py::test_full_size_config3_10Mx768_l2_top100_q1024)
+        sb3 = torch.empty_like(s3); rb3 = torch.empty_like(r3); cb3 = torch.empty_like(c3); db3 = torch.empty_like(d3)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        dgb = step3(flags=FLAG_NO_I8_FILTER, want_diag=True, out=(sb3, rb3, cb3, db3))
+        torch.cuda.synchronize(); dtb = time.perf_counter() - t1
+        tr3 = (n3 + 255) // 256
+        st3 = max(1, tr3 // ((min(n3, max(n3 // 64, 8192)) + 255) // 256))
+        filt3 = (tr3 - (tr3 + st3 - 1) // st3) * 256
+        ops3 = 2.0 * q3 * d * filt3
+        i8_3 = dg3.get("filter_tier") == 1
+        l2_leg = {"workload": "BASELINE config 3: 10M x 768 fp32, exact L2 top-%d, %d queries per batch (the first 10M resident rows)" % (k, q3),
+                  "ms_per_step": dt3 * 1e3, "qps": q3 / dt3, "filter_tier": dg3.get("filter_tier"),
+                  "kernel": ("scan_tiles_i8r_kernel<L2> (int8 shadow, per-row integer thresholds)" if i8_3
+                             else "scan_tiles_bf16s_kernel<FILTER,L2>"),
+                  "bound": "mfma", "launch_ms": f3_ms, "achieved": ops3 / (f3_ms * 1e-3) / 1e12 if f3_ms else None,
+                  "peak": PEAK_I8_MFMA_TOPS if i8_3 else PEAK_BF16_MFMA_TFLOPS, "unit": "TOP/s" if i8_3 else "TFLOP/s",
+                  "frac": ops3 / (f3_ms * 1e-3) / 1e12 / (PEAK_I8_MFMA_TOPS if i8_3 else PEAK_BF16_MFMA_TFLOPS) if f3_ms else None,
+                  "filter_candidates": dg3.get("filter_candidates"), "widened_queries": dg3.get("widened_queries"),
+                  "escalated_queries": dg3.get("escalated_queries"), "exact_fallback_queries": dg3.get("exact_fallback_queries"),
+                  "bf16_tier_ms_per_step_one_cold_call": dtb * 1e3, "bf16_tier_filter_tier": dgb.get("filter_tier"),
+                  "results_identical_to_the_bf16_tier": bool(torch.equal(r3, rb3) and torch.equal(s3, sb3) and torch.equal(c3, cb3)
+                                                             and torch.equal(d3, db3))}
+        del s3, r3, c3, d3, sb3, rb3, cb3, db3
+
     if rank != 0:
         return
     # ---- roofline of the dominant kernel (the FILTER pass of the scan) -----------------------------
@@ -760,6 +812,8 @@ def main():
            "roofline": roofline}
     if hbm_leg is not None:
         out["roofline_hbm_leg"] = hbm_leg
+    if l2_leg is not None:
+        out["config3_l2"] = l2_leg
     if check is not None:
         out.update(check)
     if world > 1:

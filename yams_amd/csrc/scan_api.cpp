@@ -26,16 +26,17 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // passes: MFMA passes of the filter (0 = exact f32 kernel, 1 = RNE bf16, 3 = split bf16).  A looser
 // filter needs more candidates re-scored before the proof can succeed, not a different threshold.
-ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes, int metric) {
+// l2_band: the single-pass L2 filter of the bf16 tier (its score carries +E itself, the band around the k-th best
+// is 2E wide); the int8 tier's L2 bound is as tight as its cosine bound and plans like it.
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes, bool l2_band) {
     ScanPlan p;
     p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
     p.tile_rows = bf16 ? 256 : kTileRows;
     p.tile_queries = bf16 ? 256 : kTileQueries;
     p.n_tiles = static_cast<uint32_t>((n_rows + p.tile_rows - 1) / p.tile_rows);
     p.n_qtiles = (nq + p.tile_queries - 1) / p.tile_queries;
-    // (the L2 filter score is an upper bound carrying +E itself, so its band is 2E wide)
     p.kprime = (passes == 1)
-                   ? std::min<uint32_t>(round_up(metric == YAMS_SCAN_L2 ? 6 * k + 128 : 3 * k + 64, 32), kRescoreMax)
+                   ? std::min<uint32_t>(round_up(l2_band ? 6 * k + 128 : 3 * k + 64, 32), kRescoreMax)
                    : std::min<uint32_t>(round_up(k + std::max<uint32_t>(16, k / 4), 32), kRescoreMax);
     const uint64_t s_target = std::min<uint64_t>(n_rows, std::max<uint64_t>(n_rows / 64, 8192));
     uint32_t want_tiles = static_cast<uint32_t>((s_target + p.tile_rows - 1) / p.tile_rows);
@@ -282,7 +283,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
         if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 68))) i8 = false;
 #endif
-        const ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric);
+        ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2);
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
         if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
@@ -295,7 +296,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
         if (i8 && metric == YAMS_SCAN_L2 && !i8_takes_resident_form(L)) i8 = false;
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
-        if (i8 && metric == YAMS_SCAN_L2) { L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim); }
+        if (i8 && metric == YAMS_SCAN_L2) {
+            L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);
+            plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, false); // (tile geometry unchanged: the form decision above stands)
+            L.plan = plan;
+        }
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
         // relative error of the filter's dot product, in units of |x||q|:
         //   exact f32 : fp32 FMA chain over dim terms

@@ -1265,46 +1265,60 @@ __global__ void i8_query_thresholds_kernel(const float* tau, const float* q_meta
 // stats words: [0] ~bits(smallest squared norm), [1] bits(largest), [2] bits(largest d_r / s_b), [3] rows whose
 // squared norm is outside norm_in_range(), [4] bits(largest e_b).  All values are positive floats (their bit patterns
 // order like the values), the buffer starts zeroed.
-// (1) One wave per 64-row block, grid-stride; a workgroup folds its blocks before it touches the shared words.
+// (1) One wave per 64-row block, grid-stride.  Only the block's smallest norm needs a wave reduction per block
+// (it is stored, and the spread of every row is measured against it); everything shard-wide is folded per lane
+// over the wave's blocks, across the wave and the workgroup at the end, and then touches the shared words once.
 __global__ __launch_bounds__(256) void i8_l2_norm_stats_kernel(const float* rows_nsq, const float* rows_meta, uint64_t n_rows,
                                                                uint64_t n_blocks, float* nmin_out, uint32_t* stats) {
     __shared__ uint32_t red[4][5];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t lo = 0xffffffffu, hi = 0u, sp = 0u, bad = 0u, em = 0u; // wave-uniform after each block
-    for (uint64_t blk = static_cast<uint64_t>(blockIdx.x) * 4u + wid; blk < n_blocks; blk += static_cast<uint64_t>(gridDim.x) * 4u) {
-        const uint64_t r = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
-        const bool live = r < n_rows;
-        const float nsq = live ? rows_nsq[r] : 1.f;
+    float qlo = __builtin_inff(), qhi = 0.f, sp = 0.f, em = 0.f; // per lane: squared-norm range, largest d_r / s_b, largest e_b
+    uint32_t bad = 0u;
+    const uint64_t step = static_cast<uint64_t>(gridDim.x) * 4u;
+    uint64_t blk = static_cast<uint64_t>(blockIdx.x) * 4u + wid;
+    auto fetch = [&](uint64_t b) -> float { // 1 for the rows past the end (they are never "ok")
+        const uint64_t r = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
+        return (b < n_blocks && r < n_rows) ? rows_nsq[r] : 1.f;
+    };
+    float nsq = fetch(blk);
+    while (blk < n_blocks) {
+        const float nsq_next = fetch(blk + step); // (the next block's load is in flight under this block's reduction)
+        const bool live = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane) < n_rows;
         const bool ok = live && norm_in_range(nsq);
-        bad += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !ok)));
+        bad += (live && !ok) ? 1u : 0u;
         const float n = sqrtf(nsq);
-        float mn = ok ? n : __builtin_inff(), mx = ok ? n : 0.f;
-        float qlo = ok ? nsq : __builtin_inff(), qhi = ok ? nsq : 0.f;
+        float mn = ok ? n : __builtin_inff();
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, d)); mx = fmaxf(mx, __shfl_xor(mx, d));
-            qlo = fminf(qlo, __shfl_xor(qlo, d)); qhi = fmaxf(qhi, __shfl_xor(qhi, d));
+        for (int d = 32; d >= 1; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
+        const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
+        if (ok) {
+            qlo = fminf(qlo, nsq); qhi = fmaxf(qhi, nsq);
+            sp = fmaxf(sp, i8_l2_spread(n, mn) / m.x);
         }
-        const float sb = rows_meta[2 * blk];
-        em = max(em, __float_as_uint(rows_meta[2 * blk + 1])); // (e_b >= 0)
-        float d_over_s = ok ? i8_l2_spread(n, mn) / sb : 0.f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) d_over_s = fmaxf(d_over_s, __shfl_xor(d_over_s, d));
+        em = fmaxf(em, m.y); // (e_b >= 0)
         if (lane == 0) nmin_out[blk] = mn; // (+inf for a block without a usable row: the batch leaves this tier anyway)
-        if (qlo < __builtin_inff()) {
-            lo = min(lo, __float_as_uint(qlo)); hi = max(hi, __float_as_uint(qhi));
-            sp = max(sp, __float_as_uint(d_over_s));
-        }
+        nsq = nsq_next;
+        blk += step;
     }
-    if (lane == 0) { red[wid][0] = lo; red[wid][1] = hi; red[wid][2] = sp; red[wid][3] = bad; red[wid][4] = em; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        qlo = fminf(qlo, __shfl_xor(qlo, d)); qhi = fmaxf(qhi, __shfl_xor(qhi, d));
+        sp = fmaxf(sp, __shfl_xor(sp, d)); em = fmaxf(em, __shfl_xor(em, d));
+        bad += __shfl_xor(bad, d);
+    }
+    if (lane == 0) {
+        red[wid][0] = __float_as_uint(qlo); red[wid][1] = __float_as_uint(qhi); red[wid][2] = __float_as_uint(sp);
+        red[wid][3] = bad; red[wid][4] = __float_as_uint(em);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t lo = red[0][0], hi = red[0][1], s2 = red[0][2], b2 = red[0][3], e2 = red[0][4]; // (positive floats: bit patterns order like the values)
         for (int w = 1; w < 4; ++w) {
-            lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); sp = max(sp, red[w][2]); bad += red[w][3]; em = max(em, red[w][4]);
+            lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); s2 = max(s2, red[w][2]); b2 += red[w][3]; e2 = max(e2, red[w][4]);
         }
-        if (lo != 0xffffffffu) { atomicMax(&stats[0], ~lo); atomicMax(&stats[1], hi); atomicMax(&stats[2], sp); }
-        atomicMax(&stats[4], em);
-        if (bad) atomicAdd(&stats[3], bad);
+        if (lo != 0x7f800000u) { atomicMax(&stats[0], ~lo); atomicMax(&stats[1], hi); atomicMax(&stats[2], s2); }
+        if (b2) atomicAdd(&stats[3], b2);
+        atomicMax(&stats[4], e2);
     }
 }
 
