@@ -61,12 +61,14 @@ for case in range(a.cases):
         forms.insert(0, "i8")
         if d % 128 == 0 and d <= 768:     # the resident-query kernel form of the int8 filter, forced on these small shards
             forms.insert(0, "i8r")
-    if metric == SCAN_L2 and d % 128 == 0 and 256 <= d <= 768:   # L2 on the int8 tier: both shadows, resident-query form forced; steps aside for zero / huge rows and wide norm ranges
+    if metric == SCAN_L2 and d % 64 == 0 and d >= 256:   # L2 on the int8 tier: both shadows, half tiles and the resident-query form forced; steps aside for zero / huge rows and wide norm ranges
         t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device="cuda"); tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device="cuda")
         acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr())
         view8 = acc.corpus_view(tc.data_ptr(), n, d, None, None, 0, mask_t.data_ptr() if mask_t is not None else None, mask_n,
                                 rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(), rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
-        forms.insert(0, "i8r")
+        forms.insert(0, "i8")
+        if d % 128 == 0 and d <= 768:
+            forms.insert(0, "i8r")
     out = {}
     for form in forms:
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -91,9 +93,10 @@ for case in range(a.cases):
     dg = out["default"][4]
     key = f"path{dg['path']}/widened{int(dg['widened_queries'] > 0)}/escalated{int(dg['escalated_queries'] > 0)}/fallback{int(dg['exact_fallback_queries'] > 0)}"
     paths[key] = paths.get(key, 0) + 1
-    if metric == SCAN_L2 and "i8r" in out:
-        key = f"l2_i8r_tier{int(out['i8r'][4]['filter_tier'])}"
-        paths[key] = paths.get(key, 0) + 1
+    for form in ("i8", "i8r"):
+        if metric == SCAN_L2 and form in out:
+            key = f"l2_{form}_tier{int(out[form][4]['filter_tier'])}"
+            paths[key] = paths.get(key, 0) + 1
     done += 1
     del tc, tq, tb, tn
 print(json.dumps({"cases": done, "mismatches": len(bad), "paths": paths, "first_bad": bad[:3]}))

@@ -812,13 +812,15 @@ def _l2_corpus(oracle, seed, n, d, nq, kind):
 @pytest.mark.parametrize("n,d,nq,k,thr,kind", [
     (50000, 256, 130, 100, -1.0, "uniform"), (70001, 384, 300, 50, 0.05, "uniform"), (40449, 512, 700, 30, -1.0, "unit"),
     (90000, 768, 1024, 100, -1.0, "spread"), (33333, 768, 40, 100, -1.0, "clustered"), (20500, 640, 129, 20, -1.0, "uniform"),
-    (20000, 256, 1, 10, -1.0, "unit"),
+    (20000, 256, 1, 10, -1.0, "unit"), (60000, 320, 200, 50, -1.0, "uniform"), (30011, 1536, 133, 10, -1.0, "spread"),
+    (150001, 448, 260, 100, 0.02, "unit"),
 ])
 def test_int8_tier_under_l2_matches_the_oracle_and_the_bf16_tier(acc, oracle, n, d, nq, k, thr, kind):
     """L2 batches on the int8 tier (scan_i8_kernel.hip, "L2 on the int8 tier"): the cosine tier's shadow, the score
-    bound G(u, |x|^2), an integer threshold with a per-row part — forced onto small shards through the
-    resident-query flag.  Bit-identical to the oracle (rows, cosines, distances) and to the bf16 tier, with and
-    without an allow-mask; nothing escalates on well-behaved norms."""
+    bound G(u, |x|^2), an integer threshold with a per-row part — in the resident-query form (forced onto these small
+    shards through the flag; dims it cannot hold fall to half tiles) and in the half-tile form.  Bit-identical to
+    the oracle (rows, cosines, distances) and to the bf16 tier, with and without an allow-mask; nothing escalates on
+    well-behaved norms."""
     corpus, q = _l2_corpus(oracle, 71, n, d, nq, kind)
     r = check(acc, oracle, corpus, q, k, thr=thr, metric=SCAN_L2, max_queries=6, expect_path=0, shadow="both",
               expect_tier=_lib.TIER_I8, flags=_lib.FLAG_RESIDENT_QUERIES)
@@ -826,9 +828,14 @@ def test_int8_tier_under_l2_matches_the_oracle_and_the_bf16_tier(acc, oracle, n,
         assert r.diag["exact_fallback_queries"] == 0, r.diag
     b = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_NO_I8_FILTER, shadow="both")
     assert b.diag["filter_tier"] == _lib.TIER_BF16
-    assert np.array_equal(r.rows, b.rows) and np.array_equal(r.counts, b.counts)
-    assert np.array_equal(r.scores.view(np.uint32), b.scores.view(np.uint32))
-    assert np.array_equal(r.dist.view(np.uint32), b.dist.view(np.uint32))
+    h = run(acc, corpus, q, k, thr, SCAN_L2, flags=FLAG_WIDE_TILE, shadow="both")       # the per-tile kernel forms
+    if nq > 128:
+        assert h.diag["filter_tier"] == _lib.TIER_I8
+        assert h.diag["filter_candidates"] == r.diag["filter_candidates"]            # the same survivors, not just the same top k
+    for other in (b, h, run(acc, corpus, q, k, thr, SCAN_L2, shadow="both")):
+        assert np.array_equal(r.rows, other.rows) and np.array_equal(r.counts, other.counts)
+        assert np.array_equal(r.scores.view(np.uint32), other.scores.view(np.uint32))
+        assert np.array_equal(r.dist.view(np.uint32), other.dist.view(np.uint32))
     mask = np.random.default_rng(n).random(n) < 0.5
     a = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_RESIDENT_QUERIES, shadow="both", mask=mask)
     c = run(acc, corpus, q, k, thr, SCAN_L2, flags=_lib.FLAG_NO_I8_FILTER, shadow="both", mask=mask)

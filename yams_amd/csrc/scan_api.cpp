@@ -199,9 +199,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     bool l2_i8_ok = false;
     float* d_l2_nmin = nullptr; uint32_t* d_l2_stats = nullptr;
     const bool l2_i8_wanted = use_mfma && metric == YAMS_SCAN_L2 && corpus->rows_i8 && corpus->rows_i8_meta && corpus->rows_nsq &&
-                              (dim & 127u) == 0 && dim >= 256 && dim <= 768 && corpus->n_rows >= 4096 &&
+                              (dim & 63u) == 0 && dim >= 256 && corpus->n_rows >= 4096 &&
                               (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
-                              !(params->flags & (YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER | YAMS_SCAN_FLAG_WIDE_TILE)) &&
+                              !(params->flags & (YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER)) &&
                               !split_only;
     uint32_t* h_l2_stats = h_pin + 4 * static_cast<size_t>(nq) + 8;
     if (use_mfma && metric == YAMS_SCAN_L2) {
@@ -270,8 +270,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // Batches of <= 128 queries take it when the shard is large enough for the resident-query kernel form
         // (decided below, once the plan is known); on smaller shards they stay on the narrow bf16 form when a
         // bf16 shadow is there too.
-        // L2 batches take it too when the shard's norms allow it (l2_i8_ok above) and the launch takes the
-        // resident-query kernel form — the only one that carries the per-row part of the L2 threshold.
+        // L2 batches take it too when the shard's norms allow it (l2_i8_ok above).
         bool i8 = bf16 && passes == 1 && (metric == YAMS_SCAN_COSINE || l2_i8_ok) && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                   !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER);
@@ -294,7 +293,6 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (bf16_version == 40) L.i8_form = 1; // A/B runs: half tiles where the library would pick the resident-query form
 #endif
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
-        if (i8 && metric == YAMS_SCAN_L2 && !i8_takes_resident_form(L)) i8 = false;
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         if (i8 && metric == YAMS_SCAN_L2) {
             L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);

@@ -129,11 +129,11 @@ constexpr int H_STAGE = H_A_BYTES + I8_B_BYTES;    // 24 KiB
 // MODE_SAMPLE writes group maxima (groups of 16 rows: the rows one lane holds for a query block — 4 row
 // blocks x 4 consecutive rows) and, only when a dense buffer is given, all upper bounds (the int8 tier runs
 // without one: i8_collect_sample_kernel re-derives the scores of the groups that reach tau).
-// METRIC (sample pass only): under L2 the score of a row is G(u, |x|^2) (i8_l2_bound); the filter pass of
-// L2 batches always takes the resident-query form.
+// METRIC = L2 ("L2 on the int8 tier" above): the sample pass scores a row with G(u, |x|^2) (i8_l2_bound); the
+// filter pass starts its accumulators at -T - a_r m_q (a.rows_i8_meta is then the thresholds meta of the shard).
 template <int MODE, int ABL = 0, int METRIC = YAMS_SCAN_COSINE>
 __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a) {
-    static_assert(METRIC == YAMS_SCAN_COSINE || MODE == MODE_SAMPLE, "L2: sample pass only");
+    static_assert(METRIC == YAMS_SCAN_COSINE || ABL == 0, "the measurement forms exist for the cosine kernels only");
     __shared__ __attribute__((aligned(16))) unsigned char lds[H_NST * H_STAGE];
     __shared__ uint32_t wave_log[4]; // survivors each wave has logged (wave-private slots)
 
@@ -229,14 +229,37 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qthr[cb]) : "v"(p) : "memory");
         }
     }
+    // L2: m_q of this lane's eight queries, a_r of its sixteen rows (byte r of word rb = row 16 rb + 4 lq + r) — like the
+    // threshold halves requested before the first DMA piece, so the same counted wait covers them
+    constexpr bool L2F = THR && METRIC == YAMS_SCAN_L2;
+    int qbias[8];
+    i32x4v rbias;
+    if (L2F) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const uint32_t* p = a.i8_q_bias + (q0 + wc * 128 + cb * 16 + l15);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(qbias[cb]) : "v"(p) : "memory");
+        }
+        const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+        uint64_t blk = strip / I8_BLOCK_ROWS;
+        if (blk >= n_blocks) blk = n_blocks - 1; // a strip past the end: nothing of it is ever emitted
+        const uint8_t* p = a.i8_row_bias + blk * 64u + static_cast<uint32_t>(lq) * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rbias) : "v"(p) : "memory");
+    }
 
     {   // prologue: slabs 0 and 1 and the first half of slab 2 in flight (nslab >= 4), slab 0 landed
         for (int s = 0; s < 2; ++s) for (int p = 0; p < 6; ++p) piece(s, s, p);
         piece(2, 2, 0); piece(2, 2, 1); piece(2, 2, 2);
         if (THR) {
             // accumulators start at -T(row block, query block) while the slabs are in flight
-            asm volatile("s_waitcnt vmcnt(15)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
-                                                 "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
+            if (L2F)
+                asm volatile("s_waitcnt vmcnt(15)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                     "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]), "+v"(rbias),
+                                                     "+v"(qbias[0]), "+v"(qbias[1]), "+v"(qbias[2]), "+v"(qbias[3]),
+                                                     "+v"(qbias[4]), "+v"(qbias[5]), "+v"(qbias[6]), "+v"(qbias[7]) :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(15)" : "+v"(qthr[0]), "+v"(qthr[1]), "+v"(qthr[2]), "+v"(qthr[3]),
+                                                     "+v"(qthr[4]), "+v"(qthr[5]), "+v"(qthr[6]), "+v"(qthr[7]) :: "memory");
             const float is = 1.0f / sb, g = eb * is;
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
@@ -244,7 +267,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rb][cb][r] = nt;
+                    for (int r = 0; r < 4; ++r)
+                        acc[rb][cb][r] = L2F ? nt - __mul24(static_cast<int>((static_cast<uint32_t>(rbias[rb]) >> (8 * r)) & 255u), qbias[cb])
+                                             : nt;
             }
         }
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); // 15 pieces issued, slab 0's six have landed
@@ -917,42 +942,63 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 }
 
 
-// Log -> per-query candidate lists.  One thread per log region.  An entry carries the accumulator
-// I - T of a survivor; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
-// filter kernel derived it (same inputs, same instructions).
+// The survivor log -> per-query candidate lists.  An entry carries the accumulator of a survivor (I - T; under L2
+// I - T - a_r m_q) and its row; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
+// filter kernel derived it (same inputs, same instructions).  L2: T comes from the shard's thresholds meta, u from
+// the shadow's own meta, the score is G(u, |x|^2) and only rows with G >= tau are kept (the integer test is a
+// necessary condition only).
+struct I8GatherL2 {
+    const float* l2_meta;       // [blocks][2] thresholds meta (what the filter kernel saw)
+    const uint8_t* row_bias; const uint32_t* q_bias; const float* rows_nsq; const float* tau; float eps;
+};
+template <bool L2>
+__device__ __forceinline__ bool i8_entry_score(uint64_t e, uint32_t q, const float* rows_meta, const float* q_meta,
+                                               const float* q_thr, const I8GatherL2& l2, uint32_t& row, float& u) {
+    row = static_cast<uint32_t>(e);
+    const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
+    const uint32_t blk = row / I8_BLOCK_ROWS;
+    const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
+    const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
+    const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
+    if (!L2) {
+        const float is = 1.0f / m.x;
+        const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
+        u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        return true;
+    }
+    const float2 mt = reinterpret_cast<const float2*>(l2.l2_meta)[blk];
+    const float is = 1.0f / mt.x;
+    const int nt = i8_neg_threshold(qt.x, is, qt.y, mt.y * is);
+    const uint32_t j = row & 63u;
+    const int ar = l2.row_bias[static_cast<uint64_t>(blk) * 64u + ((j >> 2) & 3u) * 16u + (j >> 4) * 4u + (j & 3u)];
+    const int dot = accv - nt + ar * static_cast<int>(l2.q_bias[q]);
+    const float ub = fmaf(static_cast<float>(dot), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+    u = i8_l2_bound(ub, l2.rows_nsq[row], l2.eps);
+    return !(u < l2.tau[q]);
+}
+
+// Half-tile kernel's logs: one thread per log region.
+template <bool L2>
 __global__ __launch_bounds__(256) void i8_log_gather_kernel(const uint64_t* log_key, const uint32_t* log_q, const uint32_t* log_cnt,
                                                             uint32_t log_cap, uint64_t n_regions, const float* rows_meta,
                                                             const float* q_meta, const float* q_thr, uint32_t* list_count,
-                                                            uint64_t* list, uint32_t list_cap) {
+                                                            uint64_t* list, uint32_t list_cap, I8GatherL2 l2) {
     const uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     const uint32_t n = log_cnt[r];
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t e = log_key[r * log_cap + i];
         const uint32_t q = log_q[r * log_cap + i];
-        const uint32_t row = static_cast<uint32_t>(e);
-        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
-        const float2 m = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
-        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
-        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
-        const float is = 1.0f / m.x;
-        const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
-        const float u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        uint32_t row; float u;
+        if (!i8_entry_score<L2>(log_key[r * log_cap + i], q, rows_meta, q_meta, q_thr, l2, row, u)) continue;
         const uint32_t pos = atomicAdd(&list_count[q], 1u);
         if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
 }
 
-// The same for the resident-query kernel's logs: one region per (row stream, query tile, wave), i.e. all entries
-// of a region belong to ONE 128-query tile.  A workgroup per region: the entries are counted per query in LDS,
-// every query present reserves its list slots with ONE global atomic (the per-entry atomics of the form above
-// piled 1000 increments on each of 1024 addresses), then the entries are placed.
-// L2: the log entry is I - T - a_r m_q; T comes from the batch's thresholds meta, u from the shadow's own meta, the
-// score is G(u, |x|^2) and only rows with G >= tau are kept (the integer test is a necessary condition only).
-struct I8GatherL2 {
-    const float* l2_meta;       // [blocks][2] thresholds meta of the batch (what the filter kernel saw)
-    const uint8_t* row_bias; const uint32_t* q_bias; const float* rows_nsq; const float* tau; float eps;
-};
+// The resident-query kernel's logs: one region per (row stream, query tile, wave), i.e. all entries of a region
+// belong to ONE 128-query tile.  A workgroup per region: the entries are counted per query in LDS, every query
+// present reserves its list slots with ONE global atomic (the per-entry atomics of the form above piled 1000
+// increments on each of 1024 addresses), then the entries are placed.
 template <bool L2>
 __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t* log_key, const uint32_t* log_q, const uint32_t* log_cnt,
                                                                  uint32_t log_cap, uint32_t n_qt, const float* rows_meta,
@@ -968,36 +1014,10 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
     __syncthreads();
     const uint64_t* keys = log_key + static_cast<uint64_t>(r) * log_cap;
     const uint32_t* qs = log_q + static_cast<uint64_t>(r) * log_cap;
-    // the score of entry i (same inputs, same instructions as the filter kernel for T); false = not a candidate
-    auto score = [&](uint32_t i, uint32_t& q, uint32_t& row, float& u) __attribute__((always_inline)) -> bool {
-        const uint64_t e = keys[i];
-        q = qs[i];
-        row = static_cast<uint32_t>(e);
-        const int accv = static_cast<int>(static_cast<uint32_t>(e >> 32));
-        const uint32_t blk = row / I8_BLOCK_ROWS;
-        const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
-        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
-        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
-        if (!L2) {
-            const float is = 1.0f / m.x;
-            const int nt = i8_neg_threshold(qt.x, is, qt.y, m.y * is);
-            u = fmaf(static_cast<float>(accv - nt), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
-            return true;
-        }
-        const float2 mt = reinterpret_cast<const float2*>(l2.l2_meta)[blk];
-        const float is = 1.0f / mt.x;
-        const int nt = i8_neg_threshold(qt.x, is, qt.y, mt.y * is);
-        const uint32_t j = row & 63u;
-        const int ar = l2.row_bias[static_cast<uint64_t>(blk) * 64u + ((j >> 2) & 3u) * 16u + (j >> 4) * 4u + (j & 3u)];
-        const int dot = accv - nt + ar * static_cast<int>(l2.q_bias[q]);
-        const float ub = fmaf(static_cast<float>(dot), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
-        u = i8_l2_bound(ub, l2.rows_nsq[row], l2.eps);
-        return !(u < l2.tau[q]);
-    };
     for (uint32_t i = tid; i < n; i += 256) {
-        uint32_t q, row; float u;
-        if (!L2) atomicAdd(&hist[qs[i] - q0], 1u);
-        else if (score(i, q, row, u)) atomicAdd(&hist[q - q0], 1u);
+        const uint32_t q = qs[i];
+        uint32_t row; float u;
+        if (!L2 || i8_entry_score<L2>(keys[i], q, rows_meta, q_meta, q_thr, l2, row, u)) atomicAdd(&hist[q - q0], 1u);
     }
     __syncthreads();
     if (tid < R_QUERIES) {
@@ -1007,8 +1027,9 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) {
-        uint32_t q, row; float u;
-        if (!score(i, q, row, u)) continue;
+        const uint32_t q = qs[i];
+        uint32_t row; float u;
+        if (!i8_entry_score<L2>(keys[i], q, rows_meta, q_meta, q_thr, l2, row, u)) continue;
         const uint32_t pos = slot0[q - q0] + atomicAdd(&hist[q - q0], 1u);
         if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
@@ -1537,7 +1558,7 @@ uint32_t i8_log_capacity(const ScanLaunch& L) {
         const uint64_t c = static_cast<uint64_t>(cap < 4.0e6 ? cap : 4.0e6);
         return static_cast<uint32_t>((c + 15) / 16 * 16);
     }
-    const double per_wave = 8192.0 * p.tau_rank * p.sample_stride / static_cast<double>(p.n_rows ? p.n_rows : 1);
+    const double per_wave = 8192.0 * p.tau_rank * p.sample_stride / static_cast<double>(p.n_rows ? p.n_rows : 1) * (L.i8_l2 ? 2.0 : 1.0);
     const uint32_t c = static_cast<uint32_t>(per_wave * 4.0 < 8192.0 ? per_wave * 4.0 : 8192.0) + 16;
     return (c + 15) / 16 * 16 < 8192u ? (c + 15) / 16 * 16 : 8192u;
 }
@@ -1546,8 +1567,8 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     const uint64_t regions = i8_log_regions(L);
     if (regions == 0) return hipSuccess;
     const ResidentPlan rp = i8_resident_plan(L);
+    const I8GatherL2 l2{L.i8_l2_meta, L.i8_row_bias, L.i8_q_bias, L.rows_nsq, L.tau, L.l2_eps};
     if (rp.use) {
-        const I8GatherL2 l2{L.i8_l2_meta, L.i8_row_bias, L.i8_q_bias, L.rows_nsq, L.tau, L.l2_eps};
         if (L.i8_l2)
             hipLaunchKernelGGL((i8_log_gather_wave_kernel<true>), dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
                                L.log_key, L.log_q, L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count,
@@ -1558,9 +1579,14 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
                                L.list, L.plan.list_cap, l2);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(i8_log_gather_kernel, dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
-                       L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
-                       L.plan.list_cap);
+    if (L.i8_l2)
+        hipLaunchKernelGGL((i8_log_gather_kernel<true>), dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
+                           L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
+                           L.plan.list_cap, l2);
+    else
+        hipLaunchKernelGGL((i8_log_gather_kernel<false>), dim3(static_cast<uint32_t>((regions + 255) / 256)), dim3(256), 0, st,
+                           L.log_key, L.log_q, L.log_cnt, L.log_cap, regions, L.rows_i8_meta, L.q_meta, L.q_thr, L.list_count, L.list,
+                           L.plan.list_cap, l2);
     return hipGetLastError();
 }
 
@@ -1582,10 +1608,10 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
-    if (L.i8_l2) { // L2 batches: the resident-query form only (scan_api.cpp checks that the plan takes it)
-        if (!rp.use) return hipErrorInvalidValue;
-        a.rows_i8_meta = L.i8_l2_meta; // the thresholds meta of this batch; the shadow's own meta is the gather kernel's
-        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+    if (L.i8_l2) { // L2 batches: the same two kernel forms with the row / query biases (no measurement forms)
+        a.rows_i8_meta = L.i8_l2_meta; // the thresholds meta of the shard; the shadow's own meta is the gather kernel's
+        if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+        else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
     uint32_t window = 1; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; measured on the bench launch: window 1 17 GB from HBM and 7.6-7.8 ms, 2 / 3 20 GB and 7.9 ms, unpaced 19+ GB)
