@@ -1289,37 +1289,46 @@ __global__ void i8_query_thresholds_kernel(const float* tau, const float* q_meta
 // (1) One wave per 64-row block, grid-stride.  Only the block's smallest norm needs a wave reduction per block
 // (it is stored, and the spread of every row is measured against it); everything shard-wide is folded per lane
 // over the wave's blocks, across the wave and the workgroup at the end, and then touches the shared words once.
-__global__ __launch_bounds__(256) void i8_l2_norm_stats_kernel(const float* rows_nsq, const float* rows_meta, uint64_t n_rows,
-                                                               uint64_t n_blocks, float* nmin_out, uint32_t* stats) {
-    __shared__ uint32_t red[4][5];
+// (a workgroup per CU, sixteen waves each: with 2048 small workgroups the kernel spent 0.1 ms queueing their
+// atomics on the five shared words)
+constexpr int L2S_WAVES = 16;
+__global__ __launch_bounds__(L2S_WAVES * 64) void i8_l2_norm_stats_kernel(const float* rows_nsq, const float* rows_meta, uint64_t n_rows,
+                                                                         uint64_t n_blocks, float* nmin_out, uint32_t* stats) {
+    __shared__ uint32_t red[L2S_WAVES][5];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float qlo = __builtin_inff(), qhi = 0.f, sp = 0.f, em = 0.f; // per lane: squared-norm range, largest d_r / s_b, largest e_b
     uint32_t bad = 0u;
-    const uint64_t step = static_cast<uint64_t>(gridDim.x) * 4u;
-    uint64_t blk = static_cast<uint64_t>(blockIdx.x) * 4u + wid;
-    auto fetch = [&](uint64_t b) -> float { // 1 for the rows past the end (they are never "ok")
-        const uint64_t r = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
-        return (b < n_blocks && r < n_rows) ? rows_nsq[r] : 1.f;
-    };
-    float nsq = fetch(blk);
-    while (blk < n_blocks) {
-        const float nsq_next = fetch(blk + step); // (the next block's load is in flight under this block's reduction)
-        const bool live = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane) < n_rows;
-        const bool ok = live && norm_in_range(nsq);
-        bad += (live && !ok) ? 1u : 0u;
-        const float n = sqrtf(nsq);
-        float mn = ok ? n : __builtin_inff();
+    // four blocks per trip: their loads are in flight together (a trip costs one memory latency, and a wave has
+    // ~20 blocks of a 10M-row shard)
+    constexpr int NB = 4;
+    const uint64_t step = static_cast<uint64_t>(gridDim.x) * L2S_WAVES;
+    for (uint64_t blk0 = static_cast<uint64_t>(blockIdx.x) * L2S_WAVES + wid; blk0 < n_blocks; blk0 += step * NB) {
+        float nsq[NB]; float2 m[NB];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
-        const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
-        if (ok) {
-            qlo = fminf(qlo, nsq); qhi = fmaxf(qhi, nsq);
-            sp = fmaxf(sp, i8_l2_spread(n, mn) / m.x);
+        for (int j = 0; j < NB; ++j) {
+            const uint64_t b = blk0 + j * step;
+            const uint64_t r = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
+            nsq[j] = (b < n_blocks && r < n_rows) ? rows_nsq[r] : 1.f; // (rows past the end are never "ok")
+            m[j] = b < n_blocks ? reinterpret_cast<const float2*>(rows_meta)[b] : make_float2(1.f, 0.f);
         }
-        em = fmaxf(em, m.y); // (e_b >= 0)
-        if (lane == 0) nmin_out[blk] = mn; // (+inf for a block without a usable row: the batch leaves this tier anyway)
-        nsq = nsq_next;
-        blk += step;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const uint64_t b = blk0 + j * step;
+            if (b >= n_blocks) break;
+            const bool live = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane) < n_rows;
+            const bool ok = live && norm_in_range(nsq[j]);
+            bad += (live && !ok) ? 1u : 0u;
+            const float n = sqrtf(nsq[j]);
+            float mn = ok ? n : __builtin_inff();
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
+            if (ok) {
+                qlo = fminf(qlo, nsq[j]); qhi = fmaxf(qhi, nsq[j]);
+                sp = fmaxf(sp, i8_l2_spread(n, mn) / m[j].x);
+            }
+            em = fmaxf(em, m[j].y); // (e_b >= 0)
+            if (lane == 0) nmin_out[b] = mn; // (+inf for a block without a usable row: the batch leaves this tier anyway)
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1334,7 +1343,7 @@ __global__ __launch_bounds__(256) void i8_l2_norm_stats_kernel(const float* rows
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t lo = red[0][0], hi = red[0][1], s2 = red[0][2], b2 = red[0][3], e2 = red[0][4]; // (positive floats: bit patterns order like the values)
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < L2S_WAVES; ++w) {
             lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); s2 = max(s2, red[w][2]); b2 += red[w][3]; e2 = max(e2, red[w][4]);
         }
         if (lo != 0x7f800000u) { atomicMax(&stats[0], ~lo); atomicMax(&stats[1], hi); atomicMax(&stats[2], s2); }
@@ -1448,8 +1457,8 @@ hipError_t launch_i8_l2_norm_stats(hipStream_t st, const float* rows_nsq, const 
                                    float* nmin, uint32_t* stats) {
     const uint64_t n_blocks = (n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
     if (n_blocks == 0) return hipSuccess;
-    const uint64_t want = (n_blocks + 3) / 4;
-    hipLaunchKernelGGL(i8_l2_norm_stats_kernel, dim3(static_cast<uint32_t>(want < 2048 ? want : 2048)), dim3(256), 0, st,
+    const uint64_t want = (n_blocks + L2S_WAVES - 1) / L2S_WAVES;
+    hipLaunchKernelGGL(i8_l2_norm_stats_kernel, dim3(static_cast<uint32_t>(want < 256 ? want : 256)), dim3(L2S_WAVES * 64), 0, st,
                        rows_nsq, rows_i8_meta, n_rows, n_blocks, nmin, stats);
     return hipGetLastError();
 }
