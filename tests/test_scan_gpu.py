@@ -1065,6 +1065,12 @@ def test_plugin_mirror_grows_in_place_and_is_dealt_to_shards(accel_lib, oracle, 
     for qi in range(3):
         orow, _, _ = oracle.scan_l2(corpus, q[qi], k, -1.0, rank.astype(np.uint64))
         assert rows[qi] == list(orow)
+    # ... and a batch on the int8 side of the threshold: the mirror's shadows carry L2 on that tier too
+    rows, _, diag = _vt_search(vt, cid, np.ascontiguousarray(q), k, thr=-1.0, metric=1)
+    assert diag["filter_tier"] == _lib.TIER_I8, diag
+    for qi in (0, 1, 70, 139):
+        orow, _, _ = oracle.scan_l2(corpus, q[qi], k, -1.0, rank.astype(np.uint64))
+        assert rows[qi] == list(orow), qi
     assert vt.corpus_clear(None, cid) == 0 and vt.corpus_size(None, cid, C.byref(nn), None) == 0 and nn.value == 0
     assert vt.corpus_append(None, cid, corpus[:5000].ctypes.data_as(_lib.f32p), 5000) == 0    # reusable after clear
     rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q[1:2]), 5)
