@@ -22,7 +22,7 @@ use_gpu = torch.cuda.is_available() and os.environ.get("YAMS_DIST_TEST_CPU") is 
 backend = os.environ.get("YAMS_DIST_TEST_BACKEND", "gloo")
 if use_gpu and backend == "gloo":
     os.environ["LOCAL_RANK"] = "0"             # every rank on cuda:0 (one-GPU box)
-rank, world, local = ydist.init_from_env(backend=backend)
+rank, world, local = ydist.init_from_env(backend=backend, force=True)   # (a world of one forms its group too: the one-rank RCCL test)
 o = _oracle.oracle()
 n, d, nq, k = (40000, 64, 6, 20) if use_gpu else (3000, 16, 4, 10)
 n_batches = 3
@@ -31,14 +31,14 @@ corpus[7] = corpus[n - 100]                    # cross-shard exact tie
 b = ydist.shard_bounds(n, world)
 lo, hi = b[rank], b[rank + 1]
 dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-pipe = ydist.GatherPipeline(nq, k, dev, depth=2)
+pipe = ydist.GatherPipeline(nq, k, dev, depth=2, force_collective=True)
 
 if use_gpu:
     from yams_amd.accel import Accel
     from yams_amd._lib import SCAN_COSINE
     torch.cuda.set_device(local)
     acc = Accel(local, torch.cuda.current_stream().cuda_stream)
-    acc_merge = Accel(local, pipe.side_stream_ptr()) if world > 1 else acc
+    acc_merge = Accel(local, pipe.side_stream_ptr()) if pipe.active else acc
     tc = torch.from_numpy(corpus[lo:hi]).to(dev)
     torch.cuda.synchronize()                   # the contexts run on their own (non-blocking) streams
     view = acc.corpus_view(tc.data_ptr(), hi - lo, d, row_base=lo)
@@ -107,7 +107,7 @@ for bi in range(n_batches - pipe.depth, n_batches):   # the batches still reside
     if bi % 2 == 0 or bi < 0:
         continue
     compare(bi, pipe.result(bi % pipe.depth), batches[bi])
-t = torch.tensor([1.0 if ok else 0.0])
+t = torch.tensor([1.0 if ok else 0.0], device=dev if backend == "nccl" else "cpu")
 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
 if bad:
     print("MISMATCH " + json.dumps(bad[:4]), file=sys.stderr, flush=True)

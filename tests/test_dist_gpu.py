@@ -23,6 +23,19 @@ def test_sharded_search_with_the_merge_kernel_behind_the_collective(world):
     assert out["ok"] and out["world"] == world and out["gpu"] and out["merge"] == "merge_topk_kernel", r.stderr[-3000:]
 
 
+def test_rccl_with_one_rank_runs_the_collective_and_the_merge(monkeypatch):
+    """What a one-GPU box can run of RCCL: a process group of ONE rank on backend "nccl" (= RCCL), through the
+    product pipeline — communicator init under HSA_ENABLE_IPC_MODE_LEGACY=0, all_gather_into_tensor of the packed
+    record on the pipeline's side stream, the merge kernel behind it, an all_reduce and a barrier — with the merged
+    top-k checked against the oracle.  Two ranks on one device are refused by RCCL, so the multi-rank collective
+    itself remains unexecuted here."""
+    monkeypatch.setenv("YAMS_DIST_TEST_BACKEND", "nccl")
+    r = ydist.launch_ranks(os.path.join(ROOT, "tests", "_dist_worker.py"), 1, [], capture=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["world"] == 1 and out["gpu"] and out["backend"] == "nccl" and out["merge"] == "merge_topk_kernel"
+
+
 def test_bench_self_launches_n_ranks_and_checks_the_merge_against_the_oracle():
     """`python bench.py --gpus 2` with no torchrun environment starts two ranks itself and prints ONE
     line with n_gpus = 2; the merged top-k of the last timed step equals the oracle over the union

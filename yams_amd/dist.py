@@ -16,14 +16,15 @@ def shard_bounds(n_rows: int, world: int) -> list[int]:
     return [n_rows * g // world for g in range(world + 1)]
 
 
-def init_from_env(backend: str | None = None):
-    """Rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
+def init_from_env(backend: str | None = None, force: bool = False):
+    """Rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  force: form the process
+    group for a single rank too (the one-GPU RCCL test: communicator, collective and merge of a world of one)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -73,14 +74,16 @@ class GatherPipeline:
     host copy) and then `merge_fn(gathered views, merged views)` — the k-way merge kernel on a
     context bound to that side stream.  The caller's next sweep runs meanwhile on its own stream;
     `wait(s)` blocks the host until slot s is merged (before its record is reused, or to read it).
-    With world == 1 there is no collective and no merge: the merged views ARE the local views."""
+    With world == 1 there is no collective and no merge: the merged views ARE the local views — unless
+    `force_collective` asks for them anyway (a process group of one rank: what a one-GPU box can run of RCCL)."""
 
-    def __init__(self, nq: int, k: int, device, with_dist: bool = False, depth: int = 2):
+    def __init__(self, nq: int, k: int, device, with_dist: bool = False, depth: int = 2, force_collective: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.backend = dist.get_backend() if dist.is_initialized() else None
+        self.active = dist.is_initialized() and (self.world > 1 or force_collective)   # collective + merge after every scan
         self.nq, self.k, self.depth, self.device = nq, k, depth, device
         spec = [("scores", nq * k * 4), ("rows", nq * k * 8), ("counts", nq * 4)]
         if with_dist:
@@ -90,8 +93,8 @@ class GatherPipeline:
         self.shapes = {"scores": (nq, k), "rows": (nq, k), "counts": (nq,), "dist": (nq, k)}
         self.rec = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
         on_gpu = device.type == "cuda"
-        self.side = torch.cuda.Stream(device=device) if on_gpu and self.world > 1 else None
-        if self.world > 1:
+        self.side = torch.cuda.Stream(device=device) if on_gpu and self.active else None
+        if self.active:
             self.gathered = [torch.zeros((self.world, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(depth)]
             self.merged = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.done = [torch.cuda.Event() if on_gpu else None for _ in range(depth)]
@@ -115,7 +118,7 @@ class GatherPipeline:
 
     def result(self, slot):
         """Merged top-k of the slot's batch (valid after wait(slot))."""
-        return self.local(slot) if self.world == 1 else self._views(self.merged[slot])
+        return self.local(slot) if not self.active else self._views(self.merged[slot])
 
     def side_stream_ptr(self):
         return self.side.cuda_stream if self.side is not None else None
@@ -124,7 +127,7 @@ class GatherPipeline:
     def launch(self, slot):
         """Collective + merge of the slot's batch.  The scan that filled the record has completed on
         the host's view (yams_scan_topk_device synchronises its stream before returning)."""
-        if self.world == 1:
+        if not self.active:
             return
         torch, dist = self.torch, self.dist
         rec, out = self.rec[slot], self.gathered[slot]
@@ -150,7 +153,7 @@ class GatherPipeline:
         self.busy[slot] = True
 
     def wait(self, slot):
-        if self.world == 1 or not self.busy[slot]:
+        if not self.active or not self.busy[slot]:
             return
         if self.done[slot] is not None:
             self.done[slot].synchronize()
