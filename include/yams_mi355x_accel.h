@@ -154,9 +154,11 @@ typedef struct yams_scan_corpus_s {
                                   tier it only proposes candidates, the fp64 re-score over `rows`
                                   decides: results are bit-identical with and without it.
                                   L2 searches take the same tier when the view also carries rows_nsq
-                                  (i.e. both shadows), every row's squared norm lies in (1e-30, 1e30)
-                                  and the row norms of the shard are within a factor of two of each
-                                  other (checked per call); otherwise L2 stays on the bf16 tier.      */
+                                  (i.e. both shadows), the row norms of the shard are within a factor
+                                  of two of each other and at most 64 rows have a squared norm outside
+                                  (1e-30, 1e30) (zero / overflowing / non-finite rows: carried along as
+                                  unconditional candidates); checked per call, otherwise L2 stays on
+                                  the bf16 tier.                                                      */
     const float* rows_i8_meta; /* device, nullable iff rows_i8 is: [ceil(n_rows / 64)][2] =
                                   {s_b, e_b} per block of 64 rows: the block's quantisation scale
                                   and the largest measured residue |x/|x| - s_b * int8 row| of

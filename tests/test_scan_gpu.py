@@ -845,18 +845,36 @@ def test_int8_tier_under_l2_matches_the_oracle_and_the_bf16_tier(acc, oracle, n,
     assert np.array_equal(a.dist.view(np.uint32), c.dist.view(np.uint32))
 
 
-def test_int8_tier_under_l2_steps_aside_for_norms_it_cannot_bound(acc, oracle):
-    """A zero row (valid under L2, but there is no unit vector to quantise) or norms spread over more than a
-    factor of two: the batch stays on the bf16 tier — same results."""
+def test_int8_tier_under_l2_rows_without_a_usable_norm(acc, oracle):
+    """Zero rows (valid L2 neighbours, but there is no unit vector to quantise), rows whose squared norm overflows
+    the filter's range and rows with a non-finite component have no score bound: up to 64 of them ride along as
+    unconditional candidates of every query and the batch stays on the int8 tier; more than that, or norms spread
+    over more than a factor of two, and the batch steps aside to the bf16 tier.  Same results either way."""
     n, d, nq, k = 30000, 256, 140, 20
     base, q = _l2_corpus(oracle, 73, n, d, nq, "uniform")
-    for how in ("zero", "wide"):
+    q[5] = np.float32(0.01) * base[20000]                         # a short query: the zero rows are among its nearest
+    for how, tier in (("few", _lib.TIER_I8), ("many", _lib.TIER_BF16), ("wide", _lib.TIER_BF16)):
         corpus = base.copy()
-        if how == "zero": corpus[12345] = 0
-        else: corpus[::7] *= np.float32(2.5)
-        r = check(acc, oracle, corpus, q, k, metric=SCAN_L2, max_queries=3, expect_path=0, shadow="both",
-                  expect_tier=_lib.TIER_BF16, flags=_lib.FLAG_RESIDENT_QUERIES)
-        assert r.diag["exact_fallback_queries"] == 0
+        if how == "few":
+            corpus[[12345, 64, 29999]] = 0                         # zero rows, one of them the shard's last
+            corpus[777] *= np.float32(1e16)                        # |x|^2 far outside the range, still finite
+            corpus[4096, 3] = np.nan; corpus[9000, 0] = np.inf     # never returned (vector_database.cpp:1771-1784)
+            corpus[128:192] *= np.float32(1.0)                     # (a whole block of ordinary rows next to them)
+        elif how == "many":
+            corpus[1000:1100] = 0
+        else:
+            corpus[::7] *= np.float32(2.5)
+        for flags in (_lib.FLAG_RESIDENT_QUERIES, FLAG_WIDE_TILE):
+            r = check(acc, oracle, corpus, q, k, metric=SCAN_L2, max_queries=8, expect_path=0, shadow="both",
+                      expect_tier=tier, flags=flags)
+            assert r.diag["exact_fallback_queries"] == 0
+        if how == "few":
+            assert 12345 in r.rows[5] and 64 in r.rows[5] and 29999 in r.rows[5]      # the zero rows are returned
+            mask = np.ones(n, bool); mask[[12345, 777]] = False                       # ... unless the allow-mask hides them
+            m = run(acc, corpus, q, k, -1.0, SCAN_L2, flags=_lib.FLAG_RESIDENT_QUERIES, shadow="both", mask=mask)
+            e = run(acc, corpus, q, k, -1.0, SCAN_L2, flags=FLAG_FORCE_EXACT, shadow="both", mask=mask)
+            assert m.diag["filter_tier"] == _lib.TIER_I8 and 12345 not in m.rows[5] and 64 in m.rows[5]
+            assert np.array_equal(m.rows, e.rows) and np.array_equal(m.dist.view(np.uint32), e.dist.view(np.uint32))
 
 
 def test_int8_tier_proves_small_dense_shards_without_escalating(acc, oracle):

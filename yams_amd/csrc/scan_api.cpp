@@ -197,7 +197,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     // squared norm inside the filter's range and a norm spread the per-query line can follow.  They ride on the
     // sync the L2 path has anyway.
     bool l2_i8_ok = false;
-    float* d_l2_nmin = nullptr; uint32_t* d_l2_stats = nullptr;
+    float* d_l2_nmin = nullptr; uint32_t* d_l2_stats = nullptr; uint32_t* d_l2_special = nullptr;
+    uint32_t l2_n_special = 0;
     const bool l2_i8_wanted = use_mfma && metric == YAMS_SCAN_L2 && corpus->rows_i8 && corpus->rows_i8_meta && corpus->rows_nsq &&
                               (dim & 63u) == 0 && dim >= 256 && corpus->n_rows >= 4096 &&
                               (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
@@ -212,8 +213,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
             YA_TRY(ws_get(ctx, "i8_l2_nmin", static_cast<size_t>(n_blocks) * 4, (void**)&d_l2_nmin));
             YA_TRY(ws_get(ctx, "i8_l2_stats", 32, (void**)&d_l2_stats));
+            YA_TRY(ws_get(ctx, "i8_l2_special", static_cast<size_t>(i8_l2_max_special()) * 4, (void**)&d_l2_special));
             YA_HIP(ctx, hipMemsetAsync(d_l2_stats, 0, 32, st));
-            YA_HIP(ctx, launch_i8_l2_norm_stats(st, corpus->rows_nsq, corpus->rows_i8_meta, corpus->n_rows, d_l2_nmin, d_l2_stats));
+            YA_HIP(ctx, launch_i8_l2_norm_stats(st, corpus->rows_nsq, corpus->rows_i8_meta, corpus->n_rows, d_l2_nmin, d_l2_stats,
+                                                d_l2_special));
             YA_HIP(ctx, hipMemcpyAsync(h_l2_stats, d_l2_stats, 32, hipMemcpyDeviceToHost, st));
         }
         YA_HIP(ctx, hipStreamSynchronize(st));
@@ -223,7 +226,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             float lo, hi;
             const uint32_t lo_bits = ~h_l2_stats[0], hi_bits = h_l2_stats[1];
             std::memcpy(&lo, &lo_bits, 4); std::memcpy(&hi, &hi_bits, 4);
-            l2_i8_ok = h_l2_stats[3] == 0 && h_l2_stats[1] != 0 && hi <= 4.0f * lo; // no row outside the range, norms within a factor of two
+            // a few rows without a usable norm ride along as unconditional candidates; the others within a factor of two
+            l2_n_special = h_l2_stats[3];
+            l2_i8_ok = l2_n_special <= i8_l2_max_special() && h_l2_stats[1] != 0 && hi <= 4.0f * lo;
         }
     }
 
@@ -382,6 +387,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
                                           const_cast<float*>(L.i8_l2_meta), const_cast<uint8_t*>(L.i8_row_bias)));
         } else if (i8) YA_HIP(ctx, launch_i8_thresholds(st, d_tau, L.q_meta, nq, L.q_pad, const_cast<float*>(L.q_thr)));
         if (i8) YA_HIP(ctx, launch_i8_collect_sample(st, L)); else YA_HIP(ctx, launch_collect_sample(st, L));
+        if (i8 && L.i8_l2) YA_HIP(ctx, launch_i8_l2_add_special(st, L, d_l2_special, l2_n_special));
         { GatedSweep gs(ctx, st); // sweeps of contexts that share a gate run one after the other
           TimedRegion tr(ctx, "scan_filter");
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 1, bf16_version));

@@ -97,8 +97,10 @@ __device__ __forceinline__ int i8_neg_threshold(float A, float is, float B, floa
 // row part is an 8-bit a_r = floor(d_r / (s_b W)) (W = the largest d_r / s_b of the shard / 255) times
 // a per-query integer m_q = floor(beta_q W / t_q): accumulators start at -T - a_r m_q, one v_mad_i24
 // per element where the cosine kernel has a v_mov.  The gather kernel undoes both, forms G and keeps
-// the rows with G >= tau.  Preconditions (scan_api.cpp): every squared norm inside norm_in_range()
-// (else the bf16 tier, whose NaN scores carry such rows), Nmax / Nmin <= 2, the resident-query form.
+// the rows with G >= tau.  Rows whose squared norm lies outside norm_in_range() (zero rows — valid under L2 —,
+// overflowing or non-finite ones) have no usable bound: they are left out of every table and statistic, score
+// -inf in the sample pass, and join EVERY query's candidate list unconditionally (i8_l2_add_special_kernel; at
+// most I8_L2_MAX_SPECIAL of them, else the batch stays on the bf16 tier, as it does when Nmax / Nmin > 2).
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float i8_l2_bound(float u, float nsq, float eps) {
     const float t1 = sqrtf(nsq) * u;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void scan_tiles_i8h_kernel(ScanArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float u = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
-                    if (METRIC == YAMS_SCAN_L2) u = i8_l2_bound(u, nsqv[rb][r], a.l2_eps);
+                    if (METRIC == YAMS_SCAN_L2) u = norm_in_range(nsqv[rb][r]) ? i8_l2_bound(u, nsqv[rb][r], a.l2_eps) : ninf; // (unbounded rows are candidates of every query anyway)
                     v[r] = (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? u : ninf;
                     m = fmaxf(m, v[r]);
                 }
@@ -973,7 +975,9 @@ __device__ __forceinline__ bool i8_entry_score(uint64_t e, uint32_t q, const flo
     const int ar = l2.row_bias[static_cast<uint64_t>(blk) * 64u + ((j >> 2) & 3u) * 16u + (j >> 4) * 4u + (j & 3u)];
     const int dot = accv - nt + ar * static_cast<int>(l2.q_bias[q]);
     const float ub = fmaf(static_cast<float>(dot), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
-    u = i8_l2_bound(ub, l2.rows_nsq[row], l2.eps);
+    const float nsq = l2.rows_nsq[row];
+    if (!norm_in_range(nsq)) return false; // already in every list (i8_l2_add_special_kernel)
+    u = i8_l2_bound(ub, nsq, l2.eps);
     return !(u < l2.tau[q]);
 }
 
@@ -1081,8 +1085,13 @@ __global__ __launch_bounds__(256) void i8_collect_sample_kernel(const uint32_t* 
                 const float2 bm = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
                 const float S = bm.x * qm.x, K = fmaf(bm.y, qm.y, qm.z);   // (as in the sample pass's epilogue)
                 float u = fmaf(static_cast<float>(dot), S, K);
-                if (l2_rows_nsq) u = i8_l2_bound(u, l2_rows_nsq[row], l2_eps); // (L2 batches: as in the sample pass's epilogue)
-                if (!(u < t)) {
+                bool unbounded = false;
+                if (l2_rows_nsq) { // (L2 batches: as in the sample pass's epilogue)
+                    const float nsq = l2_rows_nsq[row];
+                    unbounded = !norm_in_range(nsq);
+                    u = i8_l2_bound(u, nsq, l2_eps);
+                }
+                if (!unbounded && !(u < t)) {
                     const uint32_t pos = atomicAdd(&list_count[q], 1u);
                     if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, static_cast<uint32_t>(row));
                 }
@@ -1284,20 +1293,22 @@ __global__ void i8_query_thresholds_kernel(const float* tau, const float* q_meta
 
 // ---- L2 on the int8 tier: the per-batch tables ("L2 on the int8 tier" at the top of this file) --------------
 // stats words: [0] ~bits(smallest squared norm), [1] bits(largest), [2] bits(largest d_r / s_b), [3] rows whose
-// squared norm is outside norm_in_range(), [4] bits(largest e_b).  All values are positive floats (their bit patterns
-// order like the values), the buffer starts zeroed.
+// squared norm is outside norm_in_range() (the first I8_L2_MAX_SPECIAL of them are listed in `special`), [4]
+// bits(largest e_b).  All values are positive floats (their bit patterns order like the values), the buffer starts
+// zeroed.  The statistics cover the rows inside the range only.
 // (1) One wave per 64-row block, grid-stride.  Only the block's smallest norm needs a wave reduction per block
 // (it is stored, and the spread of every row is measured against it); everything shard-wide is folded per lane
 // over the wave's blocks, across the wave and the workgroup at the end, and then touches the shared words once.
 // (a workgroup per CU, sixteen waves each: with 2048 small workgroups the kernel spent 0.1 ms queueing their
 // atomics on the five shared words)
 constexpr int L2S_WAVES = 16;
+constexpr uint32_t I8_L2_MAX_SPECIAL = 64; // rows without a usable norm that a batch carries as unconditional candidates
 __global__ __launch_bounds__(L2S_WAVES * 64) void i8_l2_norm_stats_kernel(const float* rows_nsq, const float* rows_meta, uint64_t n_rows,
-                                                                         uint64_t n_blocks, float* nmin_out, uint32_t* stats) {
+                                                                         uint64_t n_blocks, float* nmin_out, uint32_t* stats,
+                                                                         uint32_t* special) {
     __shared__ uint32_t red[L2S_WAVES][5];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float qlo = __builtin_inff(), qhi = 0.f, sp = 0.f, em = 0.f; // per lane: squared-norm range, largest d_r / s_b, largest e_b
-    uint32_t bad = 0u;
     // four blocks per trip: their loads are in flight together (a trip costs one memory latency, and a wave has
     // ~20 blocks of a 10M-row shard)
     constexpr int NB = 4;
@@ -1317,7 +1328,10 @@ __global__ __launch_bounds__(L2S_WAVES * 64) void i8_l2_norm_stats_kernel(const 
             if (b >= n_blocks) break;
             const bool live = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane) < n_rows;
             const bool ok = live && norm_in_range(nsq[j]);
-            bad += (live && !ok) ? 1u : 0u;
+            if (live && !ok) { // rare: a slot in the list of unbounded rows
+                const uint32_t slot = atomicAdd(&stats[3], 1u);
+                if (slot < I8_L2_MAX_SPECIAL) special[slot] = static_cast<uint32_t>(b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane));
+            }
             const float n = sqrtf(nsq[j]);
             float mn = ok ? n : __builtin_inff();
 #pragma unroll
@@ -1334,20 +1348,18 @@ __global__ __launch_bounds__(L2S_WAVES * 64) void i8_l2_norm_stats_kernel(const 
     for (int d = 32; d >= 1; d >>= 1) {
         qlo = fminf(qlo, __shfl_xor(qlo, d)); qhi = fmaxf(qhi, __shfl_xor(qhi, d));
         sp = fmaxf(sp, __shfl_xor(sp, d)); em = fmaxf(em, __shfl_xor(em, d));
-        bad += __shfl_xor(bad, d);
     }
     if (lane == 0) {
         red[wid][0] = __float_as_uint(qlo); red[wid][1] = __float_as_uint(qhi); red[wid][2] = __float_as_uint(sp);
-        red[wid][3] = bad; red[wid][4] = __float_as_uint(em);
+        red[wid][3] = 0u; red[wid][4] = __float_as_uint(em);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t lo = red[0][0], hi = red[0][1], s2 = red[0][2], b2 = red[0][3], e2 = red[0][4]; // (positive floats: bit patterns order like the values)
+        uint32_t lo = red[0][0], hi = red[0][1], s2 = red[0][2], e2 = red[0][4]; // (positive floats: bit patterns order like the values)
         for (int w = 1; w < L2S_WAVES; ++w) {
-            lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); s2 = max(s2, red[w][2]); b2 += red[w][3]; e2 = max(e2, red[w][4]);
+            lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); s2 = max(s2, red[w][2]); e2 = max(e2, red[w][4]);
         }
         if (lo != 0x7f800000u) { atomicMax(&stats[0], ~lo); atomicMax(&stats[1], hi); atomicMax(&stats[2], s2); }
-        if (b2) atomicAdd(&stats[3], b2);
         atomicMax(&stats[4], e2);
     }
 }
@@ -1403,12 +1415,14 @@ __global__ __launch_bounds__(256) void i8_l2_rows_kernel(const float* rows_nsq, 
     if (blk >= n_blocks) return;
     const int lane = threadIdx.x & 63;
     const float2 m = reinterpret_cast<const float2*>(rows_meta)[blk];
-    const float nmin = nmin_in[blk];
+    float nmin = nmin_in[blk];
+    if (!(nmin < __builtin_inff())) nmin = 0.f; // a block without a bounded row: nothing of it needs to pass (its rows are unconditional candidates)
     const float W = i8_l2_unit(stats[2]);
     const uint64_t r = blk * I8_BLOCK_ROWS + static_cast<uint32_t>(lane);
     uint32_t ar = 0u;
     if (r < n_rows && W > 0.f) {
-        const float d_over_s = i8_l2_spread(sqrtf(rows_nsq[r]), nmin) / m.x;     // (as in i8_l2_norm_stats_kernel)
+        const float nsq = rows_nsq[r];
+        const float d_over_s = norm_in_range(nsq) ? i8_l2_spread(sqrtf(nsq), nmin) / m.x : 0.f; // (as in i8_l2_norm_stats_kernel)
         const float v = floorf(d_over_s / W * (1.0f - 9.5367432e-7f));
         ar = static_cast<uint32_t>(fminf(fmaxf(v, 0.f), 255.f));
     }
@@ -1417,6 +1431,20 @@ __global__ __launch_bounds__(256) void i8_l2_rows_kernel(const float* rows_nsq, 
     if (lane == 0) {
         l2_meta[2 * blk] = m.x;
         l2_meta[2 * blk + 1] = -nmin * (1.0f - 4.0531158e-6f); // (2^-22 for the square root, 2^-18 for the products the filter kernel forms with it)
+    }
+}
+
+// (4) The rows without a usable norm join every query's candidate list with the largest key (they are re-scored
+// first; the reference's own rules then keep or drop them: a zero row is a valid L2 neighbour, a non-finite one is not).
+__global__ void i8_l2_add_special_kernel(const uint32_t* special, uint32_t n_special, const uint32_t* row_mask,
+                                         uint32_t n_queries, uint32_t* list_count, uint64_t* list, uint32_t list_cap) {
+    const uint32_t q = blockIdx.x;
+    if (q >= n_queries) return;
+    for (uint32_t i = threadIdx.x; i < n_special; i += blockDim.x) {
+        const uint32_t row = special[i];
+        if (row_mask && !((row_mask[row >> 5] >> (row & 31u)) & 1u)) continue;
+        const uint32_t pos = atomicAdd(&list_count[q], 1u);
+        if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(__builtin_inff(), row);
     }
 }
 
@@ -1453,13 +1481,22 @@ hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint3
 
 float i8_l2_eps(uint32_t dim) { return (static_cast<float>(dim) + 64.f) * 5.9604645e-8f; }
 
+uint32_t i8_l2_max_special() { return I8_L2_MAX_SPECIAL; }
+
+hipError_t launch_i8_l2_add_special(hipStream_t st, const ScanLaunch& L, const uint32_t* special, uint32_t n_special) {
+    if (n_special == 0 || L.plan.n_queries == 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_l2_add_special_kernel, dim3(L.plan.n_queries), dim3(64), 0, st, special, n_special, L.row_mask,
+                       L.plan.n_queries, L.list_count, L.list, L.plan.list_cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_i8_l2_norm_stats(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, uint64_t n_rows,
-                                   float* nmin, uint32_t* stats) {
+                                   float* nmin, uint32_t* stats, uint32_t* special) {
     const uint64_t n_blocks = (n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
     if (n_blocks == 0) return hipSuccess;
     const uint64_t want = (n_blocks + L2S_WAVES - 1) / L2S_WAVES;
     hipLaunchKernelGGL(i8_l2_norm_stats_kernel, dim3(static_cast<uint32_t>(want < 256 ? want : 256)), dim3(L2S_WAVES * 64), 0, st,
-                       rows_nsq, rows_i8_meta, n_rows, n_blocks, nmin, stats);
+                       rows_nsq, rows_i8_meta, n_rows, n_blocks, nmin, stats, special);
     return hipGetLastError();
 }
 

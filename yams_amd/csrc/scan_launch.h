@@ -81,13 +81,17 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
                           int8_t* q_i8, float* q_meta, bool raw_queries = false);
 // L2 on the int8 tier.  Per batch and shard: (1) norm statistics of the shard — per 64-row block the smallest row norm,
-// shard-wide the norm range, the largest in-block spread in units of the block scale, and how many rows have a
-// squared norm outside norm_in_range() (any such row keeps the batch off this tier); stats = 8 words, zeroed first.
+// shard-wide the norm range, the largest in-block spread in units of the block scale, and the rows whose squared
+// norm lies outside norm_in_range() (counted and listed: unconditional candidates); stats = 8 words, zeroed first.
 // (2) after the sample pass: the per-query threshold halves and biases; (3) the per-block thresholds meta and the
 // per-row biases.  nmin = [ceil(n_rows / 64)] floats of workspace.  stats words: ~bits(min |x|^2), bits(max |x|^2),
 // bits(max in-block norm spread / s_b), rows out of range, bits(max e_b).
 hipError_t launch_i8_l2_norm_stats(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, uint64_t n_rows,
-                                   float* nmin, uint32_t* stats);
+                                   float* nmin, uint32_t* stats, uint32_t* special);
+// rows without a usable norm (stats word 3 counts them, `special` lists the first i8_l2_max_special()): every query's
+// candidate list gets them unconditionally; more than that many keep the batch on the bf16 tier
+uint32_t i8_l2_max_special();
+hipError_t launch_i8_l2_add_special(hipStream_t st, const ScanLaunch& L, const uint32_t* special, uint32_t n_special);
 hipError_t launch_i8_l2_thresholds(hipStream_t st, const float* tau, const float* q_meta, uint32_t nq, uint32_t q_pad,
                                    uint32_t dim, const uint32_t* stats, float* q_thr, uint32_t* q_bias);
 hipError_t launch_i8_l2_rows(hipStream_t st, const float* rows_nsq, const float* rows_i8_meta, const float* nmin,
