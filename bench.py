@@ -723,6 +723,28 @@ def main():
                   "bf16_tier_ms_per_step_one_cold_call": dtb * 1e3, "bf16_tier_filter_tier": dgb.get("filter_tier"),
                   "results_identical_to_the_bf16_tier": bool(torch.equal(r3, rb3) and torch.equal(s3, sb3) and torch.equal(c3, cb3)
                                                              and torch.equal(d3, db3))}
+        # ... and its HBM-bound point: the same shard at 64 queries (one resident query tile, every CU streams its own rows)
+        q3s = 64
+        def step3s(want_diag=False):
+            return acc.scan_topk_device(view3, tq.data_ptr(), q3s, k, -1.0, SCAN_L2, s3.data_ptr(), r3.data_ptr(), c3.data_ptr(),
+                                        d3.data_ptr(), want_diag=want_diag)
+        for _ in range(max(2, a.warmup)):
+            step3s()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step3s()
+        torch.cuda.synchronize(); dt3s = (time.perf_counter() - t1) / a.steps
+        acc.enable_timing(True)
+        dg3s = step3s(want_diag=True)
+        torch.cuda.synchronize()
+        f3s_ms, _ = acc.kernel_ms("scan_filter")
+        acc.enable_timing(False)
+        byts3 = filt3 * d + (filt3 // 64) * (8 + 64) + q3s * d          # int8 shadow + thresholds meta + row biases + queries
+        l2_leg["q64"] = {"ms_per_step": dt3s * 1e3, "qps": q3s / dt3s, "filter_tier": dg3s.get("filter_tier"), "bound": "hbm",
+                         "launch_ms": f3s_ms, "algorithmic_bytes_per_launch": byts3,
+                         "achieved": byts3 / (f3s_ms * 1e-3) / 1e9 if f3s_ms else None, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": byts3 / (f3s_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if f3s_ms else None,
+                         "results_identical_to_the_q1024_run": bool(torch.equal(r3[:q3s], rb3[:q3s]) and torch.equal(d3[:q3s], db3[:q3s]))}
         del s3, r3, c3, d3, sb3, rb3, cb3, db3
 
     if rank != 0:
