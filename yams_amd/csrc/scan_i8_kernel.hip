@@ -1328,9 +1328,16 @@ __global__ __launch_bounds__(L2S_WAVES * 64) void i8_l2_norm_stats_kernel(const 
             if (b >= n_blocks) break;
             const bool live = b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane) < n_rows;
             const bool ok = live && norm_in_range(nsq[j]);
-            if (live && !ok) { // rare: a slot in the list of unbounded rows
-                const uint32_t slot = atomicAdd(&stats[3], 1u);
-                if (slot < I8_L2_MAX_SPECIAL) special[slot] = static_cast<uint32_t>(b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane));
+            // rare: slots in the list of unbounded rows — one atomic per block that has any, and none at all once the
+            // count is past the cap (a shard full of zero rows must not queue millions of atomics on one word)
+            if (const uint64_t um = __builtin_amdgcn_ballot_w64(live && !ok)) {
+                uint32_t base = 0u;
+                if (lane == 0 && __atomic_load_n(&stats[3], __ATOMIC_RELAXED) <= I8_L2_MAX_SPECIAL)
+                    base = atomicAdd(&stats[3], static_cast<uint32_t>(__builtin_popcountll(um)));
+                else if (lane == 0) base = I8_L2_MAX_SPECIAL + 1u; // (already over: the batch leaves this tier, the list is moot)
+                base = static_cast<uint32_t>(__shfl(static_cast<int>(base), 0));
+                const uint32_t slot = base + static_cast<uint32_t>(__builtin_popcountll(um & ((1ull << lane) - 1ull)));
+                if (live && !ok && slot < I8_L2_MAX_SPECIAL) special[slot] = static_cast<uint32_t>(b * I8_BLOCK_ROWS + static_cast<uint32_t>(lane));
             }
             const float n = sqrtf(nsq[j]);
             float mn = ok ? n : __builtin_inff();
