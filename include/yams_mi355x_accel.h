@@ -322,17 +322,65 @@ YAMS_ACCEL_API yams_status_t yams_scan_merge_records_device(
     const uint32_t* rank_of_row, int64_t rank_row_base, float* out_scores, int64_t* out_rows,
     uint32_t* out_counts, float* out_dist);
 
-/* One search over a corpus row-sharded across several devices of this node, behind one call: a
- * context + host thread per shard, per-shard exact top-k, records copied device-to-device to the
- * first shard's device, merged there.  `devices[i]` is the HIP device of shard i (shards may share
- * a device).  shards[i] is shard i's view (device pointers valid on devices[i]; row_base / stripe
- * fields give global ids); upload and build shadows through yams_scan_sharded_ctx(s, i).
+/* One search over a corpus row-sharded across the devices of this node — what a host's
+ * searchSimilarBatch (sqlite_vec_backend.cpp:1612-1647) calls when the corpus does not fit one GPU.
+ * ONE process, one RCCL communicator over the shard devices (ncclCommInitAll; librccl.so.1 is bound
+ * with dlopen when the first communicator is needed), per batch: every shard's exact top-k into a packed
+ * record, ONE ncclAllGather of the records on a side stream, merge_topk_kernel on the first shard's
+ * device, the merged result downloaded into pinned memory.  A persistent worker thread per (shard, lane)
+ * drives its device; `lanes` batches are in flight, so collective + merge of batch i run under the filter
+ * sweep of batch i + 1 (submit / wait below; yams_scan_sharded_topk_host is submit + wait).
+ * `devices[i]` is the HIP device of shard i.  Shards that SHARE a device cannot form a communicator (RCCL
+ * refuses two ranks on one device): such handles — the parity tests of a one-GPU box — move their records
+ * with device-to-device copies instead.  shards[i] is shard i's view (device pointers valid on devices[i];
+ * row_base / stripe fields give global ids); upload and build shadows through yams_scan_sharded_ctx(s, i).
  * rank_of_row (nullable): device array on devices[0], the global tie ranking — needed only when
  * the shards carry tie_rank arrays (then each shard's tie_rank must be a local permutation that
- * preserves the global order).  A handle serves one call at a time. */
+ * preserves the global order). */
 typedef struct yams_scan_sharded yams_scan_sharded;
+#define YAMS_SHARDED_COLLECTIVE_AUTO 0u /* RCCL when there are >= 2 shards, each on its own device, and the
+                                           communicator can be formed; else device-to-device copies of the
+                                           records (one shard: nothing to exchange)                         */
+#define YAMS_SHARDED_COLLECTIVE_RCCL 1u /* require the communicator — also for ONE shard (a communicator of one
+                                           rank: all-gather + merge still run); creation fails with
+                                           YAMS_ERR_UNSUPPORTED when RCCL cannot be loaded or initialised,
+                                           YAMS_ERR_INVALID_ARG when shards share a device                  */
+#define YAMS_SHARDED_COLLECTIVE_PEER 2u /* never RCCL: device-to-device copies                               */
+typedef struct yams_scan_sharded_options_s {
+    uint32_t struct_size; /* sizeof(yams_scan_sharded_options_t)                                  */
+    uint32_t lanes;       /* batches in flight, 1..16; 0 = 2                                      */
+    uint32_t collective;  /* YAMS_SHARDED_COLLECTIVE_*                                            */
+    uint32_t reserved;
+} yams_scan_sharded_options_t;
 YAMS_ACCEL_API yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards,
                                                       yams_scan_sharded** out);
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_create_ex(const int* devices, uint32_t n_shards,
+                                                         const yams_scan_sharded_options_t* options,
+                                                         yams_scan_sharded** out);
+YAMS_ACCEL_API uint32_t yams_scan_sharded_lanes(const yams_scan_sharded* s);
+/* {"shards":n,"lanes":l,"devices":[..],"collective":"rccl"|"peer_copy"|"none","rccl_version":..,
+ *  "rccl_library":"<path the symbols came from>","batches":..,"collectives":..}; malloc'd, release with
+ * yams_accel_free_string. */
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char** out_json);
+/* The context lane `lane` uses on shard `shard` (kernel timings of a pipelined run; the plugin's per-call
+ * row masks live in its workspace).  yams_scan_sharded_ctx(s, i) is lane 0's. */
+YAMS_ACCEL_API yams_accel_ctx* yams_scan_sharded_lane_ctx(yams_scan_sharded* s, uint32_t shard, uint32_t lane);
+/* Pipelined use: acquire a lane (wait != 0: block until one is free; else YAMS_ERR_NOT_FOUND when every lane
+ * has a batch in flight), submit a batch on it — the queries are copied into the lane's pinned staging, the
+ * call returns at once —, submit the next batch on another lane, wait() for the first: it returns the merged
+ * result and frees the lane.  The shard views, and rank_of_row, must stay valid until wait() returns.
+ * A batch fails as a whole (:1635-1647); a failed batch still takes part in its collective, so the handle
+ * stays usable.  Lanes are independent: different host threads may drive different lanes concurrently. */
+#define YAMS_SHARDED_SUBMIT_DIAG 1u /* fill the diagnostics wait() returns (costs one more look at the result counts) */
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_lane_acquire(yams_scan_sharded* s, int wait, uint32_t* out_lane);
+YAMS_ACCEL_API void yams_scan_sharded_lane_release(yams_scan_sharded* s, uint32_t lane); /* a lane acquired but not submitted */
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_submit(
+    yams_scan_sharded* s, uint32_t lane, const yams_scan_corpus_t* shards, const float* queries_host,
+    uint32_t n_queries, const yams_scan_params_t* params, const uint32_t* rank_of_row,
+    int64_t rank_row_base, uint32_t flags);
+YAMS_ACCEL_API yams_status_t yams_scan_sharded_wait(
+    yams_scan_sharded* s, uint32_t lane, float* out_scores_host, int64_t* out_rows_host,
+    uint32_t* out_counts_host, float* out_dist_host, yams_scan_diag_t* diag);
 YAMS_ACCEL_API void yams_scan_sharded_destroy(yams_scan_sharded* s);
 YAMS_ACCEL_API uint32_t yams_scan_sharded_count(const yams_scan_sharded* s);
 YAMS_ACCEL_API yams_accel_ctx* yams_scan_sharded_ctx(yams_scan_sharded* s, uint32_t shard);

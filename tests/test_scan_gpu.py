@@ -615,6 +615,111 @@ def test_sharded_search_behind_one_c_call(oracle, n_shards, layout, metric):
     sh.close()
 
 
+def _one_shard_views(sh, oracle, corpus, d, parts):
+    """Uploads `corpus` as len(parts) contiguous shards through the handle's contexts (int8 + bf16 shadows)."""
+    keep, views = [], []
+    for i, (lo, hi) in enumerate(parts):
+        a = sh.ctx(i)
+        part = np.ascontiguousarray(corpus[lo:hi])
+        dc = a.to_device(part)
+        db, dn = a.alloc((hi - lo) * d * 2), a.alloc((hi - lo) * 4)
+        a.build_shadow_device(dc.ptr, hi - lo, d, db.ptr, dn.ptr)
+        d8, dm8 = a.alloc(_lib.i8_shadow_rows(hi - lo) * d), a.alloc((hi - lo + 15) // 16 * 8)
+        a.build_shadow_i8_device(dc.ptr, hi - lo, d, d8.ptr, dm8.ptr)
+        a.synchronize()                                 # (the lanes search on their own streams)
+        keep += [dc, db, dn, d8, dm8]
+        views.append(a.corpus_view(dc.ptr, hi - lo, d, row_base=lo, rows_bf16_ptr=db.ptr, rows_nsq_ptr=dn.ptr,
+                                   rows_i8_ptr=d8.ptr, rows_i8_meta_ptr=dm8.ptr))
+    return keep, views
+
+
+def _check_vs_oracle(oracle, corpus, q, r, k, thr, metric):
+    for qi in range(q.shape[0]):
+        if metric == SCAN_COSINE:
+            rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, thr)
+            dist = None
+        else:
+            rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, thr)
+        c = int(r.counts[qi])
+        assert c == len(rows) and np.array_equal(r.rows[qi, :c], rows), (qi, r.rows[qi, :8], rows[:8])
+        assert np.array_equal(r.scores[qi, :c].view(np.uint32), sims.view(np.uint32))
+        if dist is not None:
+            assert np.array_equal(r.dist[qi, :c].view(np.uint32), dist.view(np.uint32))
+
+
+def test_sharded_search_through_an_rccl_communicator_of_one_rank(oracle):
+    """The C-ABI sharded path with its collective REQUIRED: ncclCommInitAll over the handle's devices (here one:
+    what a one-GPU box can run of RCCL), per batch one ncclAllGather of the packed record on the lane's side
+    stream, merge_topk_kernel behind it, the download into pinned memory — two batches in flight on two lanes,
+    both metrics, oracle-checked bit for bit.  A batch that fails (NaN query) still takes part in its
+    collective, so the handle stays usable."""
+    from yams_amd.accel import ShardedScan
+    n, d, k = 30011, 256, 25
+    corpus = oracle.synth_rows(43, 0, n, d)
+    qa = oracle.synth_rows(43, 1 << 40, 9, d)
+    qb = oracle.synth_rows(43, (1 << 40) + 100, 5, d)
+    sh = ShardedScan([0], lanes=2, collective="rccl")
+    info = sh.info()
+    assert info["collective"] == "rccl" and info["communicator_ranks"] == 1 and info["rccl_version"] > 20000, info
+    assert "rccl" in info["rccl_library"]
+    keep, views = _one_shard_views(sh, oracle, corpus, d, [(0, n)])
+    la = sh.submit(views, qa, k, -1.0, SCAN_COSINE)
+    lb = sh.submit(views, qb, k, 0.05, SCAN_L2)
+    assert la != lb
+    with pytest.raises(_lib.AccelError) as e:       # both lanes have a batch in flight
+        sh.submit(views, qa, k, -1.0, SCAN_COSINE, block=False)
+    assert e.value.status == _lib.YAMS_ERR_NOT_FOUND
+    ra, rb = sh.wait(la), sh.wait(lb)
+    _check_vs_oracle(oracle, corpus, qa, ra, k, -1.0, SCAN_COSINE)
+    _check_vs_oracle(oracle, corpus, qb, rb, k, 0.05, SCAN_L2)
+    assert ra.diag["rows_visited"] == 9 * n and ra.diag["filter_tier"] in (_lib.TIER_I8, _lib.TIER_BF16)
+    # a failing batch between two good ones
+    bad = qa.copy(); bad[2, 7] = np.nan
+    l1 = sh.submit(views, bad, k, -1.0, SCAN_COSINE)
+    l2 = sh.submit(views, qb, k, -1.0, SCAN_COSINE)
+    with pytest.raises(_lib.AccelError) as e:
+        sh.wait(l1)
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    _check_vs_oracle(oracle, corpus, qb, sh.wait(l2), k, -1.0, SCAN_COSINE)
+    r3 = sh.topk(views, qa, k, -1.0, SCAN_COSINE)   # submit + wait behind one call
+    _check_vs_oracle(oracle, corpus, qa, r3, k, -1.0, SCAN_COSINE)
+    info = sh.info()
+    assert info["batches"] == 5 and info["collectives"] == 5, info
+    # empty results before the query is looked at: k == 0
+    r0 = sh.topk(views, bad, 0, -1.0, SCAN_COSINE)
+    assert (r0.counts == 0).all()
+    sh.close()
+
+
+def test_sharded_pipeline_on_one_device_equals_the_single_call(oracle):
+    """Three shards that share device 0 (no communicator possible: RCCL refuses two ranks on one device — asking
+    for it is an error), three lanes: three different batches in flight, every result equal to the oracle over
+    the whole corpus and to the one-call form; lanes are reused."""
+    from yams_amd.accel import ShardedScan
+    with pytest.raises(_lib.AccelError) as e:
+        ShardedScan([0, 0], collective="rccl")
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    n, d, k = 40000, 256, 20
+    corpus = oracle.synth_rows(44, 0, n, d)
+    corpus[17] = corpus[n - 3] = corpus[n // 3 + 1]      # exact ties across shards
+    batches = [oracle.synth_rows(44, (1 << 40) + 50 * j, 3 + 2 * j, d) for j in range(5)]
+    batches[0][0] = corpus[17]
+    sh = ShardedScan([0, 0, 0], lanes=3)
+    assert sh.info()["collective"] == "peer_copy" and sh.lanes == 3
+    parts = [(n * i // 3, n * (i + 1) // 3) for i in range(3)]
+    keep, views = _one_shard_views(sh, oracle, corpus, d, parts)
+    lanes = [sh.submit(views, b, k, -1.0, SCAN_COSINE) for b in batches[:3]]
+    assert sorted(lanes) == [0, 1, 2]
+    res = [sh.wait(l) for l in lanes]
+    lanes = [sh.submit(views, b, k, -1.0, SCAN_COSINE) for b in batches[3:]]
+    res += [sh.wait(l) for l in lanes]
+    for b, r in zip(batches, res):
+        _check_vs_oracle(oracle, corpus, b, r, k, -1.0, SCAN_COSINE)
+        one = sh.topk(views, b, k, -1.0, SCAN_COSINE)
+        assert np.array_equal(one.rows, r.rows) and np.array_equal(one.scores.view(np.uint32), r.scores.view(np.uint32))
+    sh.close()
+
+
 # ---- BASELINE.json full sizes: size-independent properties ----------------------------------------
 def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     import torch

@@ -48,6 +48,14 @@ class ScanCorpus(C.Structure):
                 ("reserved2", C.c_uint32)]
 
 
+class ShardedOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("collective", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+SHARDED_COLLECTIVE_AUTO, SHARDED_COLLECTIVE_RCCL, SHARDED_COLLECTIVE_PEER = 0, 1, 2
+SHARDED_SUBMIT_DIAG = 1
+
+
 class RecordLayout(C.Structure):
     _fields_ = [("scores_off", C.c_uint64), ("rows_off", C.c_uint64), ("counts_off", C.c_uint64),
                 ("dist_off", C.c_uint64), ("ranks_off", C.c_uint64), ("bytes", C.c_uint64)]
@@ -161,7 +169,10 @@ EXPORTS = [
     "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device",
     "yams_scan_record_layout", "yams_scan_merge_records_device", "yams_scan_sharded_create",
     "yams_scan_sharded_destroy", "yams_scan_sharded_count", "yams_scan_sharded_ctx",
-    "yams_scan_sharded_last_error", "yams_scan_sharded_topk_host",
+    "yams_scan_sharded_last_error", "yams_scan_sharded_topk_host", "yams_scan_sharded_create_ex",
+    "yams_scan_sharded_lanes", "yams_scan_sharded_info_json", "yams_scan_sharded_lane_ctx",
+    "yams_scan_sharded_lane_acquire", "yams_scan_sharded_lane_release", "yams_scan_sharded_submit",
+    "yams_scan_sharded_wait",
     "yams_synth_rows_device", "yams_synth_bytes_device", "yams_sha256_batch_device",
     "yams_sha256_host", "yams_sha256_many_host", "yams_verify_chunks_device", "yams_cdc_default_config",
     "yams_dedup_set_create", "yams_dedup_set_destroy", "yams_dedup_set_size", "yams_dedup_insert_device",
@@ -248,6 +259,18 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_scan_sharded_last_error.restype = C.c_char_p
     L.yams_scan_sharded_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32, C.POINTER(ScanParams), vp,
                                               C.c_int64, vp, vp, vp, vp, C.POINTER(ScanDiag)]
+    L.yams_scan_sharded_create_ex.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(ShardedOptions), C.POINTER(vp)]
+    L.yams_scan_sharded_lanes.argtypes = [vp]
+    L.yams_scan_sharded_lanes.restype = C.c_uint32
+    L.yams_scan_sharded_info_json.argtypes = [vp, C.POINTER(vp)]
+    L.yams_scan_sharded_lane_ctx.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.yams_scan_sharded_lane_ctx.restype = vp
+    L.yams_scan_sharded_lane_acquire.argtypes = [vp, C.c_int, u32p]
+    L.yams_scan_sharded_lane_release.argtypes = [vp, C.c_uint32]
+    L.yams_scan_sharded_lane_release.restype = None
+    L.yams_scan_sharded_submit.argtypes = [vp, C.c_uint32, C.POINTER(ScanCorpus), vp, C.c_uint32, C.POINTER(ScanParams), vp,
+                                           C.c_int64, C.c_uint32]
+    L.yams_scan_sharded_wait.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_synth_rows_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     L.yams_synth_bytes_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     L.yams_sha256_batch_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]

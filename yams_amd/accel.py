@@ -119,28 +119,51 @@ class DedupSet:
 
 
 class ShardedScan:
-    """yams_scan_sharded_*: one search over a corpus row-sharded across several devices (shards may
-    share a device), behind one C call.  `ctx(i)` is an Accel bound to shard i's context — upload the
-    shard's rows and build its shadows through it."""
+    """yams_scan_sharded_*: one search over a corpus row-sharded across several devices behind the C ABI — one
+    process, one RCCL communicator over the shard devices, all-gather + merge per batch, `lanes` batches in
+    flight (shards that share a device, the one-GPU tests, exchange their records with device copies).
+    `ctx(i)` is an Accel bound to shard i's lane-0 context — upload the shard's rows and build its shadows
+    through it.  collective: "auto" | "rccl" (require the communicator, also for one shard) | "peer"."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, lanes: int = 0, collective: str = "auto"):
         self.L = _lib.load()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        st = self.L.yams_scan_sharded_create(arr, len(devices), C.byref(h))
+        opt = _lib.ShardedOptions(C.sizeof(_lib.ShardedOptions), lanes,
+                                  {"auto": _lib.SHARDED_COLLECTIVE_AUTO, "rccl": _lib.SHARDED_COLLECTIVE_RCCL,
+                                   "peer": _lib.SHARDED_COLLECTIVE_PEER}[collective], 0)
+        st = self.L.yams_scan_sharded_create_ex(arr, len(devices), C.byref(opt), C.byref(h))
         if st != 0:
-            raise AccelError(st, "yams_scan_sharded_create failed")
+            raise AccelError(st, "yams_scan_sharded_create_ex failed")
         self.h = h
         self.n = len(devices)
-        self._views = []
-        for i in range(self.n):
-            a = Accel.__new__(Accel)
-            a.L = self.L; a.ctx = C.c_void_p(self.L.yams_scan_sharded_ctx(self.h, i)); a.device = devices[i]
-            a._borrowed = True
-            self._views.append(a)
+        self.devices = list(devices)
+        self.lanes = self.L.yams_scan_sharded_lanes(h)
+        self._views = [self._borrow(i, 0) for i in range(self.n)]
+        self._inflight = {}
+
+    def _borrow(self, shard: int, lane: int) -> "Accel":
+        a = Accel.__new__(Accel)
+        a.L = self.L; a.ctx = C.c_void_p(self.L.yams_scan_sharded_lane_ctx(self.h, shard, lane)); a.device = self.devices[shard]
+        a._borrowed = True
+        return a
 
     def ctx(self, i: int) -> "Accel":
         return self._views[i]
+
+    def lane_ctx(self, shard: int, lane: int) -> "Accel":
+        """The context lane `lane` uses on shard `shard` (kernel timings of a pipelined run)."""
+        return self._borrow(shard, lane)
+
+    def info(self) -> dict:
+        p = C.c_void_p()
+        st = self.L.yams_scan_sharded_info_json(self.h, C.byref(p))
+        if st != 0:
+            raise AccelError(st, "yams_scan_sharded_info_json failed")
+        try:
+            return json.loads(C.string_at(p).decode())
+        finally:
+            self.L.yams_accel_free_string(p)
 
     def close(self):
         if getattr(self, "h", None):
@@ -155,6 +178,46 @@ class ShardedScan:
         except Exception:
             pass
 
+    def _error(self, st):
+        return AccelError(st, self.L.yams_scan_sharded_last_error(self.h).decode())
+
+    # -- pipelined form ------------------------------------------------------------------------------
+    def submit(self, shards, queries: np.ndarray, k: int, threshold: float = 0.0, metric: int = SCAN_COSINE,
+               flags: int = 0, rank_of_row_ptr: int | None = None, rank_row_base: int = 0, want_diag: bool = True,
+               block: bool = True) -> int:
+        """Starts one batch on a free lane and returns the lane; wait(lane) returns its merged result."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        lane = C.c_uint32()
+        st = self.L.yams_scan_sharded_lane_acquire(self.h, 1 if block else 0, C.byref(lane))
+        if st != 0:
+            raise self._error(st)
+        prm = ScanParams(k, threshold, metric, flags)
+        arr = (ScanCorpus * self.n)(*shards)
+        st = self.L.yams_scan_sharded_submit(self.h, lane.value, arr, q.ctypes.data, q.shape[0], C.byref(prm), rank_of_row_ptr,
+                                             rank_row_base, _lib.SHARDED_SUBMIT_DIAG if want_diag else 0)
+        if st != 0:
+            self.L.yams_scan_sharded_lane_release(self.h, lane.value)
+            raise self._error(st)
+        self._inflight[lane.value] = (q.shape[0], k, arr)       # (the views must outlive the batch)
+        return lane.value
+
+    def wait(self, lane: int) -> ScanResult:
+        nq, k, _ = self._inflight.pop(lane)
+        kk = max(k, 1)
+        scores = np.full((nq, kk), -np.inf, np.float32)
+        rows = np.full((nq, kk), -1, np.int64)
+        counts = np.zeros(nq, np.uint32)
+        dist = np.full((nq, kk), np.inf, np.float32)
+        diag = ScanDiag()
+        st = self.L.yams_scan_sharded_wait(self.h, lane, scores.ctypes.data, rows.ctypes.data, counts.ctypes.data,
+                                           dist.ctypes.data, C.byref(diag))
+        if st != 0:
+            raise self._error(st)
+        return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
+
+    # -- one call ------------------------------------------------------------------------------------
     def topk(self, shards, queries: np.ndarray, k: int, threshold: float = 0.0, metric: int = SCAN_COSINE,
              flags: int = 0, rank_of_row_ptr: int | None = None, rank_row_base: int = 0) -> ScanResult:
         q = np.ascontiguousarray(queries, dtype=np.float32)
@@ -172,7 +235,7 @@ class ShardedScan:
                                                 rank_row_base, scores.ctypes.data, rows.ctypes.data,
                                                 counts.ctypes.data, dist.ctypes.data, C.byref(diag))
         if st != 0:
-            raise AccelError(st, self.L.yams_scan_sharded_last_error(self.h).decode())
+            raise self._error(st)
         return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
 
 

@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, measure: bool = False) -> 
         if verbose and out:
             print(out.decode())
     link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
-            "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+            "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-ldl", "-lpthread"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())

@@ -19,6 +19,7 @@
 #include <shared_mutex>
 #include <sstream>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "accel_ctx.h"
@@ -27,6 +28,19 @@
 // the reference's include/yams/plugins/abi.h:18-34 declares them (no local restatement here).
 
 namespace {
+
+// No exception may cross the C ABI (model_provider_v1.h:44-49; the reference's own plugins wrap every entry point,
+// plugins/onnx/model_provider.cpp:51,94,105): every function pointer of the three vtables is the guarded form of
+// its implementation — std::bad_alloc from an absurd batch size, or anything else thrown below, becomes
+// YAMS_ERR_INTERNAL (void functions just return).
+template <auto Fn> struct Guard;
+template <typename R, typename... A, R (*Fn)(A...)> struct Guard<Fn> {
+    static R call(A... a) noexcept {
+        try { return Fn(a...); }
+        catch (...) { if constexpr (!std::is_void_v<R>) return static_cast<R>(YAMS_ERR_INTERNAL); }
+    }
+};
+#define GUARDED(fn) (&Guard<&fn>::call)
 
 // ------------------------------------------------------------------------------------------------
 // A device buffer that grows IN PLACE: one virtual range reserved up front, physical chunks mapped
@@ -40,6 +54,12 @@ namespace {
 // that stays mapped is always seen.  So a buffer whose corpus is destroyed is PARKED, mapping intact,
 // and handed to the next corpus on that device (park / unpark below); physical memory goes back to the
 // driver only when the process exits.
+// Parked mappings are adopted BEST-FIT at the next buffer's first ensure() (the smallest one that holds the
+// request; a mapping more than 4x larger than the request is left for a corpus that needs it, a fresh range is
+// reserved instead).  Physical memory goes back to the driver (a) when a device allocation fails while
+// mappings are parked (evict_parked: unmap + RETIRE the range — it stays reserved and is never mapped
+// again, so no stale translation can be hit), and (b) at yams_plugin_shutdown, when no kernel can still be
+// reading through the translations.  Only address space is spent on retired ranges.
 // Falls back to allocate-copy-free growth if the driver refuses the virtual-memory calls.
 // ------------------------------------------------------------------------------------------------
 #ifdef YAMS_ACCEL_MEASURE
@@ -63,6 +83,8 @@ struct GrowBuf {
     bool ensure(size_t bytes, size_t reserve_bytes) {
         if (bytes <= mapped) return true;
         (void)hipSetDevice(device);
+        if (!plain && !base) adopt(bytes); // a parked mapping of this (device, role) that fits, if there is one
+        if (bytes <= mapped) return true;
         if (!plain && !base) {
             size_t want = std::max(reserve_bytes, bytes);
             want = (want + kGran - 1) / kGran * kGran;
@@ -82,6 +104,11 @@ struct GrowBuf {
             prop.location.id = device;
             hipMemGenericAllocationHandle_t h;
             hipError_t e = hipMemCreate(&h, add, &prop, 0);
+            if (e != hipSuccess && evict_parked(device)) { // parked mirrors of destroyed corpora give their memory back first
+                (void)hipGetLastError();
+                if (mapped + (bytes - mapped + kGran - 1) / kGran * kGran <= reserved) add = (bytes - mapped + kGran - 1) / kGran * kGran;
+                e = hipMemCreate(&h, add, &prop, 0);
+            }
             if (e != hipSuccess) { GROW_TRACE("hipMemCreate", e); (void)hipGetLastError(); return false; }
             hipMemAccessDesc acc{};
             acc.location = prop.location;
@@ -125,11 +152,14 @@ struct GrowBuf {
         }
         return true;
     }
-    void release(); // parks the mapping for the next corpus (or frees a fallback allocation)
-    void adopt();   // takes a parked mapping of the same (device, role), if there is one
+    void release();            // parks the mapping for the next corpus (or frees a fallback allocation)
+    void adopt(size_t bytes);  // takes the best-fitting parked mapping of the same (device, role), if there is one
+    void unmap_and_retire();   // gives the physical memory back; the virtual range stays reserved, never mapped again
+    static bool evict_parked(int device);   // all parked mappings of a device; true if anything was freed
+    static void evict_all_parked();
 };
 
-// parked mappings, per (device, role); they outlive yams_plugin_shutdown (a re-initialised plugin reuses them)
+// parked mappings, per (device, role), until a corpus adopts them, memory runs short or the plugin shuts down
 std::mutex g_park_mu;
 std::map<std::pair<int, int>, std::vector<GrowBuf>> g_parked;
 
@@ -141,16 +171,52 @@ void GrowBuf::release() {
     }
     base = nullptr; reserved = mapped = 0; plain = false; chunk_end.clear();
 }
-void GrowBuf::adopt() {
+void GrowBuf::adopt(size_t bytes) {
     if (base) return;
     std::lock_guard<std::mutex> lk(g_park_mu);
     auto& v = g_parked[{device, role}];
     if (v.empty()) return;
-    // the largest mapping first: it needs the fewest new chunks
-    size_t best = 0;
-    for (size_t i = 1; i < v.size(); ++i) if (v[i].mapped > v[best].mapped) best = i;
+    // best fit: the smallest parked mapping that holds the request — but not one more than 4x larger (a small
+    // corpus must not pin the mirror of a destroyed 100 GB one; that one waits for a corpus of its size).
+    // Nothing large enough: the largest one that is not larger than needed, it grows in place.
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].mapped >= bytes && v[i].mapped / 4 <= std::max<size_t>(bytes, 64ull << 20) && (best == v.size() || v[i].mapped < v[best].mapped)) best = i;
+    if (best == v.size())
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].mapped < bytes && v[i].reserved >= bytes && (best == v.size() || v[i].mapped > v[best].mapped)) best = i;
+    if (best == v.size()) return;
     base = v[best].base; reserved = v[best].reserved; mapped = v[best].mapped; chunk_end = std::move(v[best].chunk_end);
     v.erase(v.begin() + static_cast<std::ptrdiff_t>(best));
+}
+void GrowBuf::unmap_and_retire() {
+    if (plain || !base) return;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize(); // nothing may still read through these translations
+    size_t off = 0;
+    for (size_t end : chunk_end) { if (hipMemUnmap(base + off, end - off) != hipSuccess) (void)hipGetLastError(); off = end; }
+    // the range itself is NOT freed: a later reservation could land on it, and a mapping at an address that
+    // was mapped before is read through stale translations on this driver (scripts/ubench/vmm_stale.hip)
+    base = nullptr; reserved = mapped = 0; chunk_end.clear();
+}
+bool GrowBuf::evict_parked(int device) {
+    std::vector<GrowBuf> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (auto& kv : g_parked)
+            if (kv.first.first == device) { for (auto& b : kv.second) victims.push_back(std::move(b)); kv.second.clear(); }
+    }
+    size_t freed = 0;
+    for (auto& b : victims) { freed += b.mapped; b.unmap_and_retire(); }
+    return freed != 0;
+}
+void GrowBuf::evict_all_parked() {
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (auto& kv : g_parked) if (!kv.second.empty()) devs.push_back(kv.first.first);
+    }
+    for (int d : devs) (void)evict_parked(d);
 }
 
 // One shard of a corpus: the rows dealt to one device, plus their filter shadows.
@@ -216,8 +282,11 @@ struct PluginState {
     std::vector<int> devices;        // config "devices": [..] (or "device": n); rows are striped over them
     bool want_bf16 = true, want_i8 = true;
     std::string init_error;
-    Pool<yams_scan_sharded*> search_slots;   // concurrent searches: one sharded handle (a context per device) each
-    std::map<int, yams_accel_gate*> gates;   // one per device: the search contexts' filter sweeps run one after the other
+    // searches: ONE sharded handle over the plugin's devices (one RCCL communicator when there are several),
+    // "search_slots" lanes = concurrent searches in flight, each on its own contexts / streams / worker threads;
+    // the lanes of one device share a sweep gate inside the handle (sharded_api.cpp)
+    yams_scan_sharded* sharded = nullptr;
+    uint32_t search_slots = 0;
     Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
     std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
     std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
@@ -295,9 +364,9 @@ yams_status_t vs_corpus_create(void*, uint32_t dim, uint64_t* out_id) {
         auto& s = c->sh[i];
         s.device = g.devices[i];
         int role = 0;
-        for (GrowBuf* b : {&s.rows, &s.bf16, &s.i8, &s.nsq, &s.i8meta, &s.tie, &s.inv}) { b->device = s.device; b->role = role++; b->adopt(); }
+        for (GrowBuf* b : {&s.rows, &s.bf16, &s.i8, &s.nsq, &s.i8meta, &s.tie, &s.inv}) { b->device = s.device; b->role = role++; }
     }
-    c->rank_of_row.device = g.devices[0]; c->rank_of_row.role = 7; c->rank_of_row.adopt();
+    c->rank_of_row.device = g.devices[0]; c->rank_of_row.role = 7; // (parked mappings are adopted at the first ensure(), best fit)
     std::lock_guard<std::mutex> lk(g.corpora_mu);
     *out_id = g.next_id++;
     g.corpora[*out_id] = c;
@@ -336,7 +405,10 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
         if (now == old) continue;
         (void)hipSetDevice(s.device);
-        (void)hipMemGetInfo(&dev_free, &dev_total);
+        if (hipMemGetInfo(&dev_free, &dev_total) != hipSuccess || dev_total == 0) {
+            (void)hipGetLastError();
+            dev_total = 288ull << 30; // the reservation is address space only: size it for the part this library is written for
+        }
         if (!s.rows.ensure(now * rb, ShardStore::share(dev_total, 0))) return internal_error("append:1");
         if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) return internal_error("append:2");
         if (i8 && (!s.i8.ensure((now + 63) / 64 * 64 * rb / 4 /* whole 64-row blocks: the shadow is stored blocked */, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
@@ -470,7 +542,12 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
     if (dim != c->dim) return YAMS_ERR_INVALID_ARG;
     if (nq && !queries) return YAMS_ERR_INVALID_ARG;
     std::shared_lock<std::shared_mutex> lk(c->mu);      // concurrent searches share the corpus
-    Lease<yams_scan_sharded*> slot(g.search_slots);     // ... and each runs on its own contexts / streams
+    struct LaneLease {                                  // ... and each runs on its own lane of the sharded handle
+        uint32_t lane = 0; bool held = false;
+        ~LaneLease() { if (held) yams_scan_sharded_lane_release(g.sharded, lane); }
+    } slot;
+    if (yams_scan_sharded_lane_acquire(g.sharded, 1, &slot.lane) != YAMS_OK) return YAMS_ERR_INTERNAL;
+    slot.held = true;
     const uint32_t n_sh = static_cast<uint32_t>(c->sh.size());
     std::vector<yams_scan_corpus_t> views(n_sh);
     for (uint32_t i = 0; i < n_sh; ++i) {
@@ -495,7 +572,8 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
                 local[w] = m;
                 bits += static_cast<uint64_t>(__builtin_popcount(m));
             }
-            yams_accel_ctx* sc = yams_scan_sharded_ctx(slot.v, i);
+            yams_accel_ctx* sc = yams_scan_sharded_lane_ctx(g.sharded, i, slot.lane);
+            (void)hipSetDevice(s.device);
             uint32_t* d_mask = nullptr;
             if (yams_accel::ws_get(sc, "plugin_row_mask", words * 4, (void**)&d_mask) != YAMS_OK) return YAMS_ERR_INTERNAL;
             if (yams_accel_upload(sc, d_mask, local.data(), words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
@@ -510,9 +588,13 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
     auto* counts = static_cast<uint32_t*>(std::calloc(std::max<uint32_t>(nq, 1), sizeof(uint32_t)));
     auto* hits = static_cast<yams_scan_hit_t*>(std::calloc(std::max<size_t>(slots, 1), sizeof(yams_scan_hit_t)));
     if (!counts || !hits) { std::free(counts); std::free(hits); return YAMS_ERR_INTERNAL; }
-    const yams_status_t s = yams_scan_sharded_topk_host(slot.v, views.data(), queries, nq, &prm,
-                                                        c->has_ranks && n_sh > 1 ? c->rank_of_row.as<uint32_t>() : nullptr, 0,
-                                                        scores.data(), rows.data(), counts, dist.data(), out_diag);
+    yams_status_t s = yams_scan_sharded_submit(g.sharded, slot.lane, views.data(), queries, nq, &prm,
+                                               c->has_ranks && n_sh > 1 ? c->rank_of_row.as<uint32_t>() : nullptr, 0,
+                                               out_diag ? YAMS_SHARDED_SUBMIT_DIAG : 0u);
+    if (s == YAMS_OK) {
+        slot.held = false; // wait() frees the lane
+        s = yams_scan_sharded_wait(g.sharded, slot.lane, scores.data(), rows.data(), counts, dist.data(), out_diag);
+    }
     if (s != YAMS_OK) { std::free(counts); std::free(hits); return s; }
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t i = 0; i < k; ++i) {
@@ -551,9 +633,10 @@ yams_status_t vs_runtime_info(void*, char** out_json) {
 void vs_free_string(void*, char* s) { std::free(s); }
 
 yams_vector_scan_v1 g_vector_scan = {
-    YAMS_IFACE_VECTOR_SCAN_V1_VERSION, nullptr, vs_corpus_create, vs_corpus_append,
-    vs_corpus_set_tie_ranks, vs_corpus_clear, vs_corpus_destroy, vs_corpus_size, vs_search_batch,
-    vs_free_hits, vs_runtime_info, vs_free_string, vs_search_batch_masked, vs_search_batch_ex};
+    YAMS_IFACE_VECTOR_SCAN_V1_VERSION, nullptr, GUARDED(vs_corpus_create), GUARDED(vs_corpus_append),
+    GUARDED(vs_corpus_set_tie_ranks), GUARDED(vs_corpus_clear), GUARDED(vs_corpus_destroy), GUARDED(vs_corpus_size),
+    GUARDED(vs_search_batch), GUARDED(vs_free_hits), GUARDED(vs_runtime_info), GUARDED(vs_free_string),
+    GUARDED(vs_search_batch_masked), GUARDED(vs_search_batch_ex)};
 
 // ---- content_hash_v1 --------------------------------------------------------------------------
 // Every call leases one of the plugin's work contexts (own stream, own workspace), so hashing, chunking
@@ -791,11 +874,11 @@ yams_status_t ch_dedup_destroy(void*, uint64_t id) {
     return YAMS_OK;
 }
 
-yams_content_hash_v1 g_content_hash = {YAMS_IFACE_CONTENT_HASH_V1_VERSION, nullptr, ch_hash,
-                                       ch_hash_many, ch_stream_create, ch_stream_init,
-                                       ch_stream_update, ch_stream_finalize, ch_stream_destroy,
-                                       ch_verify_many, ch_dedup_create, ch_dedup_insert,
-                                       ch_dedup_contains, ch_dedup_size, ch_dedup_destroy};
+yams_content_hash_v1 g_content_hash = {YAMS_IFACE_CONTENT_HASH_V1_VERSION, nullptr, GUARDED(ch_hash),
+                                       GUARDED(ch_hash_many), GUARDED(ch_stream_create), GUARDED(ch_stream_init),
+                                       GUARDED(ch_stream_update), GUARDED(ch_stream_finalize), GUARDED(ch_stream_destroy),
+                                       GUARDED(ch_verify_many), GUARDED(ch_dedup_create), GUARDED(ch_dedup_insert),
+                                       GUARDED(ch_dedup_contains), GUARDED(ch_dedup_size), GUARDED(ch_dedup_destroy)};
 
 // ---- chunker_v1 -------------------------------------------------------------------------------
 yams_status_t ck_default_config(void*, uint32_t mode, yams_cdc_config_t* out_cfg) {
@@ -832,8 +915,8 @@ yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc
 }
 void ck_free_chunks(void*, yams_chunk_ref_t* chunks, size_t) { std::free(chunks); }
 
-yams_chunker_v1 g_chunker = {YAMS_IFACE_CHUNKER_V1_VERSION, nullptr, ck_default_config,
-                             ck_chunk_data, ck_free_chunks};
+yams_chunker_v1 g_chunker = {YAMS_IFACE_CHUNKER_V1_VERSION, nullptr, GUARDED(ck_default_config),
+                             GUARDED(ck_chunk_data), GUARDED(ck_free_chunks)};
 
 void teardown_locked() { // g.mu held exclusively
     {
@@ -846,13 +929,14 @@ void teardown_locked() { // g.mu held exclusively
         for (auto& kv : g_dedup) { std::lock_guard<std::mutex> el(kv.second->mu); destroy_dedup(*kv.second); }
         g_dedup.clear();
     }
-    for (auto* s : g.search_slots.drain()) yams_scan_sharded_destroy(s);
-    for (auto& kv : g.gates) yams_accel_gate_destroy(kv.second);
-    g.gates.clear();
+    if (g.sharded) yams_scan_sharded_destroy(g.sharded);
+    g.sharded = nullptr;
     for (auto* c : g.work_ctx.drain()) yams_accel_ctx_destroy(c);
     for (auto* c : g.upload_ctx) yams_accel_ctx_destroy(c);
     g.upload_ctx.clear();
     g.initialised = false;
+    // nothing reads the parked mirrors of destroyed corpora any more: their physical memory goes back to the driver
+    GrowBuf::evict_all_parked();
 }
 
 } // namespace
@@ -869,7 +953,7 @@ const char* yams_plugin_get_manifest_json(void) { return kManifest; }
 // never dereferenced.  config_json: {"device": n} or {"devices": [..]} (a corpus is dealt to all of
 // them in stripes and searched behind one call), "search_slots": concurrent searches (default 2),
 // "shadows": "both" (default) | "bf16" | "i8" | "none".
-int yams_plugin_init(const char* config_json, const void* host_context) {
+static int plugin_init_impl(const char* config_json, const void* host_context) {
     (void)host_context;
     std::unique_lock<std::shared_mutex> lk(g.mu);
     if (g.initialised) return YAMS_PLUGIN_OK;
@@ -896,16 +980,17 @@ int yams_plugin_init(const char* config_json, const void* host_context) {
         if (s != YAMS_OK) return failed(s == YAMS_ERR_UNSUPPORTED ? "no gfx950 device visible" : "context creation failed");
         g.upload_ctx.push_back(c);
     }
-    for (long i = 0; i < slots; ++i) {
-        yams_scan_sharded* sh = nullptr;
-        if (yams_scan_sharded_create(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &sh) != YAMS_OK)
-            return failed("search slot creation failed");
-        g.search_slots.add(sh);
-        for (uint32_t d = 0; d < g.devices.size(); ++d) {
-            yams_accel_gate*& gate = g.gates[g.devices[d]];
-            if (!gate && yams_accel_gate_create(g.devices[d], &gate) != YAMS_OK) return failed("sweep gate creation failed");
-            (void)yams_accel_ctx_set_gate(yams_scan_sharded_ctx(sh, d), gate);
+    {
+        yams_scan_sharded_options_t so{};
+        so.struct_size = sizeof so; so.lanes = static_cast<uint32_t>(slots); so.collective = YAMS_SHARDED_COLLECTIVE_AUTO;
+        if (config_json && std::strstr(config_json, "\"collective\"")) { // "collective": "rccl" (require it) | "peer" | "auto"
+            const char* p = std::strstr(config_json, "\"collective\"");
+            if (std::strstr(p, "\"rccl\"")) so.collective = YAMS_SHARDED_COLLECTIVE_RCCL;
+            else if (std::strstr(p, "\"peer\"")) so.collective = YAMS_SHARDED_COLLECTIVE_PEER;
         }
+        if (yams_scan_sharded_create_ex(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &so, &g.sharded) != YAMS_OK)
+            return failed("sharded search handle creation failed");
+        g.search_slots = static_cast<uint32_t>(slots);
     }
     for (long i = 0; i < std::max<long>(2, slots); ++i) {
         yams_accel_ctx* c = nullptr;
@@ -917,9 +1002,16 @@ int yams_plugin_init(const char* config_json, const void* host_context) {
     return YAMS_PLUGIN_OK;
 }
 
+int yams_plugin_init(const char* config_json, const void* host_context) {
+    try { return plugin_init_impl(config_json, host_context); }
+    catch (...) { return YAMS_PLUGIN_ERR_INIT_FAILED; } // the host keeps its built-in CPU backends
+}
+
 void yams_plugin_shutdown(void) {
-    std::unique_lock<std::shared_mutex> lk(g.mu);
-    if (g.initialised) teardown_locked();
+    try {
+        std::unique_lock<std::shared_mutex> lk(g.mu);
+        if (g.initialised) teardown_locked();
+    } catch (...) {}
 }
 
 // Returns a pointer to a static vtable; unknown id or version -> NOT_FOUND, null args -> INVALID
@@ -943,7 +1035,7 @@ int yams_plugin_get_interface(const char* iface_id, uint32_t version, void** out
 }
 
 // malloc'd; the host free()s it (abi_plugin_loader.cpp:481-500).
-int yams_plugin_get_health_json(char** out_json) {
+static int plugin_health_impl(char** out_json) {
     if (!out_json) return YAMS_PLUGIN_ERR_INVALID;
     std::shared_lock<std::shared_mutex> lk(g.mu);
     std::ostringstream os;
@@ -951,9 +1043,13 @@ int yams_plugin_get_health_json(char** out_json) {
     { std::lock_guard<std::mutex> cl(g.corpora_mu); n_corpora = g.corpora.size(); }
     os << "{\"status\":\"" << (g.initialised ? "ok" : "not_initialised") << "\",\"devices\":[";
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
-    os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots.size()
+    os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
        << ",\"chunk_calls\":" << g.chunk_calls.load();
+    if (g.sharded) { // how the shards exchange their records: "collective":"rccl" | "peer_copy" | "none" (one device)
+        char* info = nullptr;
+        if (yams_scan_sharded_info_json(g.sharded, &info) == YAMS_OK && info) { os << ",\"sharded\":" << info; std::free(info); }
+    }
     if (!g.init_error.empty()) os << ",\"error\":\"" << g.init_error << "\"";
     os << "}";
     const std::string s = os.str();
@@ -962,6 +1058,11 @@ int yams_plugin_get_health_json(char** out_json) {
     std::memcpy(buf, s.c_str(), s.size() + 1);
     *out_json = buf;
     return YAMS_PLUGIN_OK;
+}
+
+int yams_plugin_get_health_json(char** out_json) {
+    try { return plugin_health_impl(out_json); }
+    catch (...) { return YAMS_PLUGIN_ERR_INIT_FAILED; }
 }
 
 } // extern "C"

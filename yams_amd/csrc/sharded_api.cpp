@@ -1,14 +1,42 @@
-// sharded_api.cpp — one search over a corpus that is row-sharded across several devices of this node,
-// behind ONE C call (the in-process form of the multi-GPU split; bench.py's one-process-per-GPU form
-// uses the same record layout and the same merge kernel behind an RCCL all-gather).
+// sharded_api.cpp — one search over a corpus that is row-sharded across the devices of this node, behind the
+// C ABI: ONE process, one RCCL communicator over the shard devices, one ncclAllGather of the packed per-shard
+// record per batch, the k-way merge kernel behind it.  This is what a C++ host calling
+// SqliteVecBackend::searchSimilarBatch (src/vector/sqlite_vec_backend.cpp:1612-1647; caller
+// src/daemon/components/EmbeddingService.cpp:572) reaches; bench.py's one-process-per-GPU form
+// (yams_amd/dist.py) uses the same record layout and the same merge kernel behind torch.distributed.
 //
-// Reference: SqliteVecBackend::searchSimilarBatch (src/vector/sqlite_vec_backend.cpp:1612-1647) sees
-// one corpus; here every shard runs the exact scan on its own device with its own context and host
-// thread, writes its per-query top-k as one packed record, the records are copied device-to-device
-// (peer-to-peer over xGMI where enabled) next to each other on the first shard's device, and the
-// k-way merge kernel produces the answer there.  The corpus itself never moves.
+// Shape of a handle:
+//   * `lanes` batches in flight (submit / wait).  A lane owns, on every shard, a context (stream + workspace),
+//     a record buffer and a side stream, plus pinned staging for its queries and its merged result.
+//   * one persistent worker thread per (shard, lane), bound to the shard's device for its whole life: no
+//     thread is created per call.  submit() copies the queries into the lane's pinned staging ONCE and
+//     wakes the lane's workers; each uploads the batch to its device, runs the exact per-shard top-k
+//     (yams_scan_topk_device, fp64-exact: the gathered scores are final, the merge is a pure comparison)
+//     into the lane's record, then joins the collective on the lane's SIDE stream: ncclAllGather of the
+//     record, and on the root shard merge_topk_kernel + the download into pinned memory behind it.  The
+//     worker is then free for the lane's next batch; the other lane's sweep has the GPUs meanwhile, so
+//     collective + merge of batch i run under the sweep of batch i + 1.
+//   * collectives of one communicator must be issued in the same order on every rank: a turnstile per shard
+//     admits them in submit order, whichever lane finishes first.
+//   * the contexts of one device share a sweep gate (yams_accel_gate): big filter sweeps run one after the
+//     other, everything around them overlaps.
+// RCCL is bound at run time (dlopen of librccl.so.1 when the first communicator is needed): a host that
+// hashes files or searches one GPU never maps the 570 MB collective library.  Shards that SHARE a device
+// (the parity tests on a one-GPU box) cannot form a communicator — RCCL refuses duplicate devices — and use
+// device-to-device copies of the records instead; that path is not a second production backend.
+// The corpus itself never moves.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <sstream>
 #include <thread>
 #include <vector>
 
@@ -16,12 +44,6 @@
 #include "scan_launch.h"
 
 using namespace yams_accel;
-
-struct yams_scan_sharded {
-    std::vector<yams_accel_ctx*> ctx; // one per shard (several shards may share a device)
-    std::vector<int> device;
-    std::string last_error;
-};
 
 namespace {
 uint64_t align16(uint64_t v) { return (v + 15) & ~static_cast<uint64_t>(15); }
@@ -83,58 +105,615 @@ extern "C" yams_status_t yams_scan_merge_records_device(
     return YAMS_OK;
 }
 
-extern "C" yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards, yams_scan_sharded** out) {
+
+namespace {
+
+// ---- RCCL, bound at run time -----------------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int version = 0;
+    std::string path, error;
+    bool ok() const { return handle != nullptr; }
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the SONAME first: a process that already maps RCCL (e.g. through torch) gets that very copy
+        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char* n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+            if (const char* e = dlerror()) r.error = e;
+        }
+        if (!r.handle) return;
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(r.handle, name);
+            if (!p) { r.error = std::string("librccl lacks ") + name; }
+            return p;
+        };
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.GetVersion || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+            dlclose(r.handle); r.handle = nullptr; return;
+        }
+        r.error.clear();
+        (void)r.GetVersion(&r.version);
+        Dl_info info{};
+        if (dladdr(reinterpret_cast<void*>(r.AllGather), &info) && info.dli_fname) r.path = info.dli_fname;
+    });
+    return r;
+}
+
+enum Mode : int { kNone = 0, kRccl = 1, kPeer = 2 };
+
+struct ShardLane {                  // what one lane owns on one shard
+    yams_accel_ctx* ctx = nullptr;  // the scan's context: its own stream and workspace
+    hipStream_t side = nullptr;     // collective (and, on the root shard, merge + download) of this lane
+    unsigned char* gathered = nullptr; size_t gathered_cap = 0; // [n shards][record stride]
+    std::thread worker;
+};
+
+struct Lane {
+    // --- state, under yams_scan_sharded::mu
+    bool acquired = false, submitted = false, trivial = false, want_diag = false;
+    uint64_t seq = 0;               // position in the collective order (turnstile)
+    uint64_t job = 0;               // generation: the lane's workers run when it moves
+    uint32_t pending = 0;           // workers that have not reported yet
+    std::atomic<uint32_t> peer_left{0};
+    // --- the batch
+    uint32_t nq = 0, dim = 0; yams_scan_params_t prm{}; bool l2 = false;
+    const uint32_t* rank_of_row = nullptr; int64_t rank_row_base = 0;
+    std::vector<yams_scan_corpus_t> views;
+    yams_scan_record_layout_t lay{}; uint64_t stride = 0;
+    std::vector<yams_status_t> st; std::vector<yams_scan_diag_t> dg; std::vector<std::string> err;
+    yams_status_t merge_st = YAMS_OK; std::string merge_err; bool merge_issued = false;
+    // --- resources
+    float* h_queries = nullptr; size_t h_queries_cap = 0;   // pinned: the batch, uploaded from here by every shard
+    unsigned char* h_out = nullptr; size_t h_out_cap = 0;   // pinned: counts | scores | rows | dist of the merged result
+    yams_accel_ctx* merge_ctx = nullptr;                    // root device, bound to the root's side stream
+    hipEvent_t done = nullptr;                              // merged result has landed in h_out
+    std::vector<ShardLane> sh;
+};
+
+size_t align16s(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+struct OutLayout { size_t counts, scores, rows, dist, bytes; };
+OutLayout out_layout(size_t nq, size_t k) {
+    OutLayout o;
+    size_t off = 0;
+    o.counts = off; off = align16s(off + nq * 4);
+    o.scores = off; off = align16s(off + nq * k * 4);
+    o.rows = off;   off = align16s(off + nq * k * 8);
+    o.dist = off;   off = align16s(off + nq * k * 4);
+    o.bytes = off;
+    return o;
+}
+
+} // namespace
+
+struct yams_scan_sharded {
+    std::vector<int> device;
+    uint32_t n = 0, n_lanes = 0;
+    int mode = kNone;
+    std::vector<ncclComm_t> comm;                // kRccl: one per shard, one communicator
+    std::map<int, yams_accel_gate*> gates;       // one per distinct device
+    std::vector<std::unique_ptr<Lane>> lanes;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done, cv_lane, cv_turn;
+    std::vector<uint64_t> coll_next;             // per shard: the seq whose collective is due next
+    uint64_t next_seq = 0;
+    bool stop = false;
+    std::string last_error, fallback_reason;
+    std::atomic<uint64_t> batches{0}, collectives{0};
+};
+
+namespace {
+
+yams_status_t set_error(yams_scan_sharded* s, yams_status_t st, const std::string& m) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->last_error = m;
+    return st;
+}
+
+// merge + download of lane L's batch, enqueued on the root shard's side stream of that lane (the current
+// device must be the root's)
+void issue_merge(yams_scan_sharded* s, Lane& L) {
+    yams_accel_ctx* m = L.merge_ctx;
+    hipStream_t st = L.sh[0].side;
+    const size_t nq = L.nq, k = L.prm.k;
+    const OutLayout o = out_layout(nq, k);
+    float* d_s; int64_t* d_r; uint32_t* d_c; float* d_d;
+    L.merge_issued = true;
+    yams_status_t r = ws_get(m, "merged_scores", nq * k * 4, (void**)&d_s);
+    if (r == YAMS_OK) r = ws_get(m, "merged_rows", nq * k * 8, (void**)&d_r);
+    if (r == YAMS_OK) r = ws_get(m, "merged_counts", nq * 4, (void**)&d_c);
+    if (r == YAMS_OK) r = ws_get(m, "merged_dist", nq * k * 4, (void**)&d_d);
+    if (r == YAMS_OK)
+        r = yams_scan_merge_records_device(m, s->n, L.nq, &L.prm, L.sh[0].gathered, L.stride, &L.lay, L.rank_of_row,
+                                           L.rank_row_base, d_s, d_r, d_c, d_d);
+    if (r == YAMS_OK) {
+        hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_c, nq * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_s, nq * k * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_r, nq * k * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && L.l2) e = hipMemcpyAsync(L.h_out + o.dist, d_d, nq * k * 4, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { (void)hipGetLastError(); r = fail(m, YAMS_ERR_INTERNAL, "download of the merged result failed"); }
+    }
+    (void)hipEventRecord(L.done, st);
+    L.merge_st = r;
+    if (r != YAMS_OK) L.merge_err = yams_accel_last_error(m);
+}
+
+// One shard's part of lane L's batch (worker thread of (shard i, lane L); current device = the shard's).
+yams_status_t run_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& err) {
+    ShardLane& SL = L.sh[i];
+    yams_accel_ctx* c = SL.ctx;
+    const size_t nq = L.nq, k = L.prm.k, dim = L.dim;
+    // this lane's previous exchange finished long ago (its wait() returned); a stream query, not a stall
+    (void)hipStreamSynchronize(SL.side);
+    float* d_q = nullptr; unsigned char* d_rec = nullptr;
+    yams_status_t st = ws_get(c, "shard_queries", nq * dim * 4, (void**)&d_q);
+    if (st == YAMS_OK) st = ws_get(c, "shard_record", static_cast<size_t>(L.stride), (void**)&d_rec);
+    if (st == YAMS_OK && hipMemcpyAsync(d_q, L.h_queries, nq * dim * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        st = fail(c, YAMS_ERR_INTERNAL, "query upload failed");
+    }
+    if (st == YAMS_OK) {
+        yams_scan_params_t prm = L.prm;
+        if (L.l2 && s->mode != kNone) prm.flags |= YAMS_SCAN_FLAG_DEFER_THRESHOLD; // vec0: the k nearest first, the threshold after the merge
+        st = yams_scan_topk_device(c, &L.views[i], d_q, L.nq, &prm, reinterpret_cast<float*>(d_rec + L.lay.scores_off),
+                                   reinterpret_cast<int64_t*>(d_rec + L.lay.rows_off),
+                                   reinterpret_cast<uint32_t*>(d_rec + L.lay.counts_off),
+                                   L.l2 ? reinterpret_cast<float*>(d_rec + L.lay.dist_off) : nullptr, nullptr,
+                                   L.want_diag ? &L.dg[i] : nullptr);
+    }
+    if (st != YAMS_OK) {
+        err = yams_accel_last_error(c);
+        // the exchange below still happens (a rank that skips a collective hangs the others): an empty record
+        if (d_rec) { (void)hipMemsetAsync(d_rec, 0, static_cast<size_t>(L.stride), c->stream); (void)hipStreamSynchronize(c->stream); }
+    }
+    if (s->mode == kNone) { // one shard: its own ordering (tie ranks included) is final, nothing to merge
+        if (st != YAMS_OK) return st;
+        const OutLayout o = out_layout(nq, k);
+        hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_rec + L.lay.counts_off, nq * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_rec + L.lay.scores_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_rec + L.lay.rows_off, nq * k * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && L.l2) e = hipMemcpyAsync(L.h_out + o.dist, d_rec + L.lay.dist_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); err = "result download failed"; return YAMS_ERR_INTERNAL; }
+        return YAMS_OK;
+    }
+    if (!d_rec) return st; // (cannot happen: submit() sized the buffers)
+    if (s->mode == kRccl) {
+        {   // collectives of one communicator go out in submit order on every rank
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; });
+        }
+        const ncclResult_t r = rccl().AllGather(d_rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
+        if (i == 0) { issue_merge(s, L); ++s->collectives; }
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            ++s->coll_next[i];
+        }
+        s->cv_turn.notify_all();
+        if (r != ncclSuccess && st == YAMS_OK) {
+            err = std::string("ncclAllGather failed: ") + rccl().GetErrorString(r);
+            st = YAMS_ERR_INTERNAL;
+        }
+        return st;
+    }
+    // shards that share a device (or a host without RCCL): the record is copied next to the others on the root's device
+    hipError_t e;
+    unsigned char* dst = L.sh[0].gathered + L.stride * i;
+    if (s->device[i] == s->device[0]) e = hipMemcpyAsync(dst, d_rec, static_cast<size_t>(L.stride), hipMemcpyDeviceToDevice, c->stream);
+    else e = hipMemcpyPeerAsync(dst, s->device[0], d_rec, s->device[i], static_cast<size_t>(L.stride), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); if (st == YAMS_OK) { err = "record copy to the merge device failed"; st = YAMS_ERR_INTERNAL; } }
+    if (L.peer_left.fetch_sub(1) == 1) { // the last record has landed: this thread enqueues the merge
+        (void)hipSetDevice(s->device[0]);
+        issue_merge(s, L);
+        (void)hipSetDevice(s->device[i]);
+    }
+    return st;
+}
+
+void worker_main(yams_scan_sharded* s, uint32_t i, uint32_t li) {
+    (void)hipSetDevice(s->device[i]);
+    Lane& L = *s->lanes[li];
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_job.wait(lk, [&] { return s->stop || L.job != seen; });
+            if (L.job == seen) return; // stop
+            seen = L.job;
+        }
+        yams_status_t st; std::string err;
+        try { st = run_shard(s, L, i, err); }
+        catch (const std::exception& e) { st = YAMS_ERR_INTERNAL; err = e.what(); }
+        catch (...) { st = YAMS_ERR_INTERNAL; err = "unknown exception in a shard worker"; }
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            L.st[i] = st; L.err[i] = std::move(err);
+            if (--L.pending == 0) s->cv_done.notify_all();
+        }
+    }
+}
+
+void destroy_handle(yams_scan_sharded* s) {
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        // batches in flight run to their end first (their collectives need every rank)
+        s->cv_done.wait(lk, [&] { for (auto& L : s->lanes) if (L->submitted && L->pending) return false; return true; });
+        s->stop = true;
+    }
+    s->cv_job.notify_all();
+    for (auto& L : s->lanes)
+        for (auto& SL : L->sh) if (SL.worker.joinable()) SL.worker.join();
+    for (auto& L : s->lanes) {
+        for (uint32_t i = 0; i < L->sh.size(); ++i) {
+            ShardLane& SL = L->sh[i];
+            (void)hipSetDevice(s->device[i]);
+            if (SL.side) (void)hipStreamSynchronize(SL.side);
+        }
+    }
+    if (s->mode == kRccl)
+        for (uint32_t i = 0; i < s->comm.size(); ++i)
+            if (s->comm[i]) { (void)hipSetDevice(s->device[i]); (void)rccl().CommDestroy(s->comm[i]); }
+    for (auto& L : s->lanes) {
+        (void)hipSetDevice(s->device[0]);
+        if (L->merge_ctx) yams_accel_ctx_destroy(L->merge_ctx); // bound to the root's side stream, which it does not own
+        if (L->done) (void)hipEventDestroy(L->done);
+        if (L->h_queries) (void)hipHostFree(L->h_queries);
+        if (L->h_out) (void)hipHostFree(L->h_out);
+        for (uint32_t i = 0; i < L->sh.size(); ++i) {
+            ShardLane& SL = L->sh[i];
+            (void)hipSetDevice(s->device[i]);
+            if (SL.ctx) yams_accel_ctx_destroy(SL.ctx);
+            if (SL.gathered) (void)hipFree(SL.gathered);
+            if (SL.side) (void)hipStreamDestroy(SL.side);
+        }
+    }
+    for (auto& kv : s->gates) yams_accel_gate_destroy(kv.second);
+    delete s;
+}
+
+yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan_sharded_options_t* opt, yams_scan_sharded** out) {
     if (!out) return YAMS_ERR_INVALID_ARG;
     *out = nullptr;
     if (!devices || n_shards == 0 || n_shards > 64) return YAMS_ERR_INVALID_ARG;
-    auto* s = new yams_scan_sharded();
+    uint32_t n_lanes = 2, collective = YAMS_SHARDED_COLLECTIVE_AUTO;
+    if (opt) {
+        if (opt->struct_size < sizeof(yams_scan_sharded_options_t)) return YAMS_ERR_INVALID_ARG;
+        if (opt->lanes) n_lanes = opt->lanes;
+        collective = opt->collective;
+    }
+    if (n_lanes > 16 || collective > YAMS_SHARDED_COLLECTIVE_PEER) return YAMS_ERR_INVALID_ARG;
+    const int n_dev = yams_accel_device_count();
+    if (n_dev <= 0) return YAMS_ERR_UNSUPPORTED; // no GPU: there is deliberately no CPU fallback
+    bool distinct = true;
     for (uint32_t i = 0; i < n_shards; ++i) {
-        yams_accel_ctx* c = nullptr;
-        const yams_status_t st = yams_accel_ctx_create(devices[i], nullptr, &c);
-        if (st != YAMS_OK) {
-            for (auto* p : s->ctx) yams_accel_ctx_destroy(p);
-            delete s;
-            return st;
-        }
-        s->ctx.push_back(c);
-        s->device.push_back(devices[i]);
+        if (devices[i] < 0 || devices[i] >= n_dev) return YAMS_ERR_INVALID_ARG;
+        for (uint32_t j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
     }
-    // records travel device-to-device: enable peer access towards the merge device where the
-    // hardware offers it (xGMI); without it hipMemcpyPeerAsync stages through the host
-    const int d0 = s->device[0];
-    for (uint32_t i = 1; i < n_shards; ++i) {
-        const int di = s->device[i];
-        if (di == d0) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, di, d0) == hipSuccess && can) {
-            (void)hipSetDevice(di);
-            const hipError_t e = hipDeviceEnablePeerAccess(d0, 0);
-            if (e != hipSuccess) (void)hipGetLastError(); // already enabled, or not permitted: staged copies still work
-        } else {
-            (void)hipGetLastError();
+    if (collective == YAMS_SHARDED_COLLECTIVE_RCCL && !distinct) return YAMS_ERR_INVALID_ARG; // RCCL refuses two ranks on one device
+
+    auto* s = new yams_scan_sharded();
+    s->n = n_shards; s->n_lanes = n_lanes;
+    s->device.assign(devices, devices + n_shards);
+    s->coll_next.assign(n_shards, 0);
+    auto bail = [&](yams_status_t st) { destroy_handle(s); return st; };
+
+    // the communicator: one process, one ncclCommInitAll over the shard devices
+    const bool want_rccl = collective == YAMS_SHARDED_COLLECTIVE_RCCL ||
+                           (collective == YAMS_SHARDED_COLLECTIVE_AUTO && distinct && n_shards >= 2);
+    s->mode = n_shards >= 2 ? kPeer : kNone;
+    if (want_rccl) {
+        Rccl& R = rccl();
+        std::string why;
+        if (!R.ok()) why = "librccl.so.1 could not be loaded: " + R.error;
+        else {
+            s->comm.assign(n_shards, nullptr);
+            const ncclResult_t r = R.CommInitAll(s->comm.data(), static_cast<int>(n_shards), s->device.data());
+            if (r != ncclSuccess) { why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(r); s->comm.clear(); (void)hipGetLastError(); }
+        }
+        if (why.empty()) s->mode = kRccl;
+        else if (collective == YAMS_SHARDED_COLLECTIVE_RCCL) {
+            std::fprintf(stderr, "[yams_mi355x_accel] %s\n", why.c_str());
+            return bail(YAMS_ERR_UNSUPPORTED);
+        } else s->fallback_reason = why; // AUTO: device-to-device copies of the records; reported by ..._info_json
+    }
+
+    for (uint32_t i = 0; i < n_shards; ++i) {
+        yams_accel_gate*& g = s->gates[devices[i]];
+        if (!g && yams_accel_gate_create(devices[i], &g) != YAMS_OK) return bail(YAMS_ERR_INTERNAL);
+    }
+    for (uint32_t li = 0; li < n_lanes; ++li) {
+        s->lanes.emplace_back(new Lane());
+        Lane& L = *s->lanes.back();
+        L.sh.resize(n_shards);
+        for (uint32_t i = 0; i < n_shards; ++i) {
+            ShardLane& SL = L.sh[i];
+            const yams_status_t st = yams_accel_ctx_create(devices[i], nullptr, &SL.ctx);
+            if (st != YAMS_OK) return bail(st);
+            (void)yams_accel_ctx_set_gate(SL.ctx, s->gates[devices[i]]);
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&SL.side, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); return bail(YAMS_ERR_INTERNAL); }
+        }
+        (void)hipSetDevice(devices[0]);
+        if (yams_accel_ctx_create(devices[0], L.sh[0].side, &L.merge_ctx) != YAMS_OK) return bail(YAMS_ERR_INTERNAL);
+        if (hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return bail(YAMS_ERR_INTERNAL); }
+    }
+    if (s->mode == kPeer) {
+        // records travel device-to-device: enable peer access towards the merge device where the
+        // hardware offers it (xGMI); without it hipMemcpyPeerAsync stages through the host
+        const int d0 = s->device[0];
+        for (uint32_t i = 1; i < n_shards; ++i) {
+            const int di = s->device[i];
+            if (di == d0) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, d0) == hipSuccess && can) {
+                (void)hipSetDevice(di);
+                if (hipDeviceEnablePeerAccess(d0, 0) != hipSuccess) (void)hipGetLastError(); // already enabled, or not permitted: staged copies still work
+            } else (void)hipGetLastError();
         }
     }
-    (void)hipSetDevice(d0);
+    for (uint32_t li = 0; li < n_lanes; ++li)
+        for (uint32_t i = 0; i < n_shards; ++i) s->lanes[li]->sh[i].worker = std::thread(worker_main, s, i, li);
+    (void)hipSetDevice(s->device[0]);
     *out = s;
     return YAMS_OK;
 }
 
+// pinned staging of a lane grows on the caller's thread while the lane is idle
+bool grow_pinned(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return true;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = (bytes + bytes / 4 + 4095) & ~static_cast<size_t>(4095);
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    *cap = want;
+    return true;
+}
+
+yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_corpus_t* shards, const float* queries_host,
+                          uint32_t n_queries, const yams_scan_params_t* params, const uint32_t* rank_of_row, int64_t rank_row_base,
+                          uint32_t flags) {
+    if (!s) return YAMS_ERR_INVALID_ARG;
+    if (lane >= s->n_lanes) return set_error(s, YAMS_ERR_INVALID_ARG, "no such lane");
+    Lane& L = *s->lanes[lane];
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!L.acquired || L.submitted) { s->last_error = "lane is not acquired, or its batch has not been waited for"; return YAMS_ERR_INVALID_ARG; }
+    }
+    if (!shards || !params) return set_error(s, YAMS_ERR_INVALID_ARG, "null shards/params");
+    if (n_queries && !queries_host) return set_error(s, YAMS_ERR_INVALID_ARG, "null queries");
+    const uint32_t n = s->n;
+    const uint32_t dim = shards[0].dim;
+    for (uint32_t i = 1; i < n; ++i)
+        if (shards[i].dim != dim) return set_error(s, YAMS_ERR_INVALID_ARG, "shards disagree on the dimension");
+    L.nq = n_queries; L.dim = dim; L.prm = *params; L.l2 = params->metric == YAMS_SCAN_L2;
+    L.rank_of_row = rank_of_row; L.rank_row_base = rank_row_base;
+    L.want_diag = (flags & YAMS_SHARDED_SUBMIT_DIAG) != 0;
+    L.merge_issued = false; L.merge_st = YAMS_OK; L.merge_err.clear();
+    // empty results before the query is validated (:4123-4126): nothing runs on the devices
+    L.trivial = n_queries == 0 || params->k == 0 || dim == 0;
+    if (!L.trivial) {
+        if (params->k > YAMS_SCAN_MAX_K) return set_error(s, YAMS_ERR_UNSUPPORTED, "k exceeds YAMS_SCAN_MAX_K");
+        if (s->mode != kNone && static_cast<uint64_t>(n) * params->k > 8192) return set_error(s, YAMS_ERR_UNSUPPORTED, "n_shards * k exceeds 8192");
+        const size_t nq = n_queries, k = params->k;
+        yams_scan_record_layout(n_queries, params->k, L.l2 ? 1 : 0, 0, &L.lay);
+        L.stride = L.lay.bytes;
+        int dev0 = s->device[0];
+        (void)hipGetDevice(&dev0); // the caller's current device is restored below
+        if (!grow_pinned(reinterpret_cast<void**>(&L.h_queries), &L.h_queries_cap, nq * dim * 4) ||
+            !grow_pinned(reinterpret_cast<void**>(&L.h_out), &L.h_out_cap, out_layout(nq, k).bytes))
+            return set_error(s, YAMS_ERR_INTERNAL, "pinned staging could not be allocated");
+        // device buffers of the batch are sized HERE, on the caller's thread while the lane is idle, so that no rank
+        // can drop out of a collective later for want of memory
+        for (uint32_t i = 0; i < n; ++i) {
+            void* p;
+            (void)hipSetDevice(s->device[i]);
+            if (ws_get(L.sh[i].ctx, "shard_queries", nq * dim * 4, &p) != YAMS_OK ||
+                ws_get(L.sh[i].ctx, "shard_record", static_cast<size_t>(L.stride), &p) != YAMS_OK) {
+                (void)hipSetDevice(dev0);
+                return set_error(s, YAMS_ERR_INTERNAL, yams_accel_last_error(L.sh[i].ctx));
+            }
+        }
+        if (s->mode != kNone) { // receive buffers of the exchange
+            const size_t need = static_cast<size_t>(L.stride) * n;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (s->mode == kPeer && i != 0) break;
+                ShardLane& SL = L.sh[i];
+                if (SL.gathered_cap >= need) continue;
+                (void)hipSetDevice(s->device[i]);
+                if (SL.gathered) { (void)hipStreamSynchronize(SL.side); (void)hipFree(SL.gathered); SL.gathered = nullptr; SL.gathered_cap = 0; }
+                const size_t want = need + need / 4;
+                if (hipMalloc(reinterpret_cast<void**>(&SL.gathered), want) != hipSuccess) {
+                    (void)hipGetLastError(); SL.gathered = nullptr; (void)hipSetDevice(dev0);
+                    return set_error(s, YAMS_ERR_INTERNAL, "receive buffer of the all-gather could not be allocated");
+                }
+                SL.gathered_cap = want;
+            }
+        }
+        (void)hipSetDevice(dev0);
+        std::memcpy(L.h_queries, queries_host, nq * dim * 4);
+        L.views.assign(shards, shards + n);
+        L.st.assign(n, YAMS_OK); L.err.assign(n, std::string());
+        L.dg.assign(n, yams_scan_diag_t{});
+    }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        L.submitted = true;
+        if (!L.trivial) {
+            L.pending = n;
+            L.peer_left.store(n);
+            if (s->mode == kRccl) L.seq = s->next_seq++;
+            ++L.job;
+        }
+    }
+    if (!L.trivial) { ++s->batches; s->cv_job.notify_all(); }
+    return YAMS_OK;
+}
+
+yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_host, int64_t* out_rows_host, uint32_t* out_counts_host,
+                        float* out_dist_host, yams_scan_diag_t* diag) {
+    if (!s) return YAMS_ERR_INVALID_ARG;
+    if (lane >= s->n_lanes) return set_error(s, YAMS_ERR_INVALID_ARG, "no such lane");
+    Lane& L = *s->lanes[lane];
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (!L.acquired || !L.submitted) { s->last_error = "nothing was submitted on this lane"; return YAMS_ERR_INVALID_ARG; }
+        s->cv_done.wait(lk, [&] { return L.trivial || L.pending == 0; });
+    }
+    auto release = [&](yams_status_t st, const std::string& m) {
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (st != YAMS_OK) s->last_error = m;
+            L.acquired = L.submitted = false;
+        }
+        s->cv_lane.notify_one();
+        return st;
+    };
+    if (diag) std::memset(diag, 0, sizeof(*diag));
+    const size_t nq = L.nq, k = L.prm.k;
+    if (L.trivial) {
+        if (nq && !out_counts_host) return release(YAMS_ERR_INVALID_ARG, "null out_counts");
+        if (nq) std::memset(out_counts_host, 0, nq * 4);
+        return release(YAMS_OK, "");
+    }
+    if (L.merge_issued) (void)hipEventSynchronize(L.done); // also when a shard failed: the lane's buffers must be quiet before reuse
+    for (uint32_t i = 0; i < s->n; ++i)
+        if (L.st[i] != YAMS_OK) return release(L.st[i], L.err[i]); // a batch fails as a whole (:1635-1647)
+    if (s->mode != kNone && L.merge_st != YAMS_OK) return release(L.merge_st, L.merge_err);
+    if (!out_counts_host || !out_scores_host || !out_rows_host) return release(YAMS_ERR_INVALID_ARG, "null outputs");
+    const OutLayout o = out_layout(nq, k);
+    std::memcpy(out_counts_host, L.h_out + o.counts, nq * 4);
+    std::memcpy(out_scores_host, L.h_out + o.scores, nq * k * 4);
+    std::memcpy(out_rows_host, L.h_out + o.rows, nq * k * 8);
+    if (out_dist_host && L.l2) std::memcpy(out_dist_host, L.h_out + o.dist, nq * k * 4);
+    if (diag && L.want_diag) {
+        if (s->n == 1) *diag = L.dg[0];
+        diag->used_exact_scan = 1; diag->rows_visited_observed = 1;
+        if (s->n > 1)
+            for (uint32_t i = 0; i < s->n; ++i) {
+                const yams_scan_diag_t& d = L.dg[i];
+                diag->rows_visited += d.rows_visited;
+                diag->exact_distance_evaluations += d.exact_distance_evaluations;
+                diag->filter_candidates += d.filter_candidates;
+                diag->rescored_rows += d.rescored_rows;
+                diag->widened_queries += d.widened_queries;
+                diag->exact_fallback_queries += d.exact_fallback_queries;
+                diag->escalated_queries += d.escalated_queries;
+                diag->path = std::max(diag->path, d.path);
+                diag->filter_tier = std::max(diag->filter_tier, d.filter_tier);
+            }
+        uint64_t ret = 0;
+        for (size_t q = 0; q < nq; ++q) ret += out_counts_host[q];
+        diag->returned_rows = ret;
+    }
+    return release(YAMS_OK, "");
+}
+
+} // namespace
+
+// No exception crosses the C ABI (model_provider_v1.h:44-49; the reference's plugins wrap every entry,
+// plugins/onnx/model_provider.cpp:51-105).
+#define YAMS_GUARD(expr) try { return (expr); } catch (const std::bad_alloc&) { return YAMS_ERR_INTERNAL; } catch (...) { return YAMS_ERR_INTERNAL; }
+
+extern "C" yams_status_t yams_scan_sharded_create_ex(const int* devices, uint32_t n_shards, const yams_scan_sharded_options_t* options,
+                                                     yams_scan_sharded** out) {
+    YAMS_GUARD(create_impl(devices, n_shards, options, out));
+}
+
+extern "C" yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards, yams_scan_sharded** out) {
+    YAMS_GUARD(create_impl(devices, n_shards, nullptr, out));
+}
+
 extern "C" void yams_scan_sharded_destroy(yams_scan_sharded* s) {
     if (!s) return;
-    for (auto* c : s->ctx) yams_accel_ctx_destroy(c);
-    delete s;
+    try { destroy_handle(s); } catch (...) {}
 }
 
-extern "C" uint32_t yams_scan_sharded_count(const yams_scan_sharded* s) {
-    return s ? static_cast<uint32_t>(s->ctx.size()) : 0u;
-}
+extern "C" uint32_t yams_scan_sharded_count(const yams_scan_sharded* s) { return s ? s->n : 0u; }
+extern "C" uint32_t yams_scan_sharded_lanes(const yams_scan_sharded* s) { return s ? s->n_lanes : 0u; }
 
-extern "C" yams_accel_ctx* yams_scan_sharded_ctx(yams_scan_sharded* s, uint32_t shard) {
-    return (s && shard < s->ctx.size()) ? s->ctx[shard] : nullptr;
+extern "C" yams_accel_ctx* yams_scan_sharded_lane_ctx(yams_scan_sharded* s, uint32_t shard, uint32_t lane) {
+    return (s && shard < s->n && lane < s->n_lanes) ? s->lanes[lane]->sh[shard].ctx : nullptr;
 }
+extern "C" yams_accel_ctx* yams_scan_sharded_ctx(yams_scan_sharded* s, uint32_t shard) { return yams_scan_sharded_lane_ctx(s, shard, 0); }
 
 extern "C" const char* yams_scan_sharded_last_error(const yams_scan_sharded* s) {
     return s ? s->last_error.c_str() : "null sharded handle";
+}
+
+extern "C" yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char** out_json) {
+    if (!s || !out_json) return YAMS_ERR_INVALID_ARG;
+    try {
+        std::ostringstream os;
+        os << "{\"shards\":" << s->n << ",\"lanes\":" << s->n_lanes << ",\"devices\":[";
+        for (uint32_t i = 0; i < s->n; ++i) os << (i ? "," : "") << s->device[i];
+        os << "],\"collective\":\"" << (s->mode == kRccl ? "rccl" : (s->mode == kPeer ? "peer_copy" : "none")) << "\"";
+        if (s->mode == kRccl) {
+            const Rccl& R = rccl();
+            os << ",\"rccl_version\":" << R.version << ",\"rccl_library\":\"" << R.path << "\",\"communicator_ranks\":" << s->comm.size();
+        }
+        if (!s->fallback_reason.empty()) {
+            std::string r = s->fallback_reason;
+            for (char& ch : r) if (ch == '"' || ch == '\\' || ch == '\n') ch = ' ';
+            os << ",\"rccl_unavailable\":\"" << r << "\"";
+        }
+        os << ",\"batches\":" << s->batches.load() << ",\"collectives\":" << s->collectives.load() << "}";
+        const std::string str = os.str();
+        char* buf = static_cast<char*>(std::malloc(str.size() + 1));
+        if (!buf) return YAMS_ERR_INTERNAL;
+        std::memcpy(buf, str.c_str(), str.size() + 1);
+        *out_json = buf;
+        return YAMS_OK;
+    } catch (...) { return YAMS_ERR_INTERNAL; }
+}
+
+extern "C" yams_status_t yams_scan_sharded_lane_acquire(yams_scan_sharded* s, int wait, uint32_t* out_lane) {
+    if (!s || !out_lane) return YAMS_ERR_INVALID_ARG;
+    try {
+        std::unique_lock<std::mutex> lk(s->mu);
+        for (;;) {
+            for (uint32_t li = 0; li < s->n_lanes; ++li)
+                if (!s->lanes[li]->acquired) { s->lanes[li]->acquired = true; s->lanes[li]->submitted = false; *out_lane = li; return YAMS_OK; }
+            if (!wait) return YAMS_ERR_NOT_FOUND; // every lane has a batch in flight: wait() for one
+            s->cv_lane.wait(lk);
+        }
+    } catch (...) { return YAMS_ERR_INTERNAL; }
+}
+
+extern "C" void yams_scan_sharded_lane_release(yams_scan_sharded* s, uint32_t lane) {
+    if (!s || lane >= s->n_lanes) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        Lane& L = *s->lanes[lane];
+        if (L.submitted) return; // a submitted batch is released by wait()
+        L.acquired = false;
+    }
+    s->cv_lane.notify_one();
+}
+
+extern "C" yams_status_t yams_scan_sharded_submit(yams_scan_sharded* s, uint32_t lane, const yams_scan_corpus_t* shards,
+                                                  const float* queries_host, uint32_t n_queries, const yams_scan_params_t* params,
+                                                  const uint32_t* rank_of_row, int64_t rank_row_base, uint32_t flags) {
+    YAMS_GUARD(submit_impl(s, lane, shards, queries_host, n_queries, params, rank_of_row, rank_row_base, flags));
+}
+
+extern "C" yams_status_t yams_scan_sharded_wait(yams_scan_sharded* s, uint32_t lane, float* out_scores_host, int64_t* out_rows_host,
+                                                uint32_t* out_counts_host, float* out_dist_host, yams_scan_diag_t* diag) {
+    YAMS_GUARD(wait_impl(s, lane, out_scores_host, out_rows_host, out_counts_host, out_dist_host, diag));
 }
 
 extern "C" yams_status_t yams_scan_sharded_topk_host(
@@ -143,108 +722,13 @@ extern "C" yams_status_t yams_scan_sharded_topk_host(
     float* out_scores_host, int64_t* out_rows_host, uint32_t* out_counts_host, float* out_dist_host,
     yams_scan_diag_t* diag) {
     if (!s) return YAMS_ERR_INVALID_ARG;
-    auto failed = [&](yams_status_t st, const std::string& m) { s->last_error = m; return st; };
-    if (!shards || !params) return failed(YAMS_ERR_INVALID_ARG, "null shards/params");
     if (diag) std::memset(diag, 0, sizeof(*diag));
-    if (n_queries == 0) return YAMS_OK;
-    if (!queries_host || !out_counts_host) return failed(YAMS_ERR_INVALID_ARG, "null queries/out_counts");
-    const uint32_t n = static_cast<uint32_t>(s->ctx.size());
-    if (n == 1) { // one shard: its own ordering (tie ranks included) is final, nothing to merge
-        const yams_status_t st1 = yams_scan_topk_host(s->ctx[0], &shards[0], queries_host, n_queries, params, out_scores_host,
-                                                      out_rows_host, out_counts_host, out_dist_host, diag);
-        if (st1 != YAMS_OK) s->last_error = yams_accel_last_error(s->ctx[0]);
-        return st1;
-    }
-    const uint32_t dim = shards[0].dim;
-    for (uint32_t i = 1; i < n; ++i)
-        if (shards[i].dim != dim) return failed(YAMS_ERR_INVALID_ARG, "shards disagree on the dimension");
-    const size_t nq = n_queries, k = params->k;
-    if (k == 0 || dim == 0) { // empty result before the query is validated (:4123-4126)
-        std::memset(out_counts_host, 0, nq * 4);
-        return YAMS_OK;
-    }
-    if (!out_scores_host || !out_rows_host) return failed(YAMS_ERR_INVALID_ARG, "null outputs");
-    const bool l2 = params->metric == YAMS_SCAN_L2;
-    yams_scan_record_layout_t lay;
-    yams_scan_record_layout(n_queries, params->k, l2 ? 1 : 0, 0, &lay);
-    const uint64_t stride = lay.bytes;
-
-    yams_accel_ctx* c0 = s->ctx[0];
-    (void)hipSetDevice(c0->device);
-    unsigned char* d_gather = nullptr;
-    if (ws_get(c0, "shard_gather", static_cast<size_t>(stride) * n, (void**)&d_gather) != YAMS_OK)
-        return failed(YAMS_ERR_INTERNAL, yams_accel_last_error(c0));
-
-    std::vector<yams_status_t> st(n, YAMS_OK);
-    std::vector<yams_scan_diag_t> dg(n);
-    auto work = [&](uint32_t i) {
-        yams_accel_ctx* c = s->ctx[i];
-        (void)hipSetDevice(c->device);
-        float* d_q = nullptr; unsigned char* d_rec = nullptr;
-        if ((st[i] = ws_get(c, "shard_queries", nq * dim * 4, (void**)&d_q)) != YAMS_OK) return;
-        if ((st[i] = ws_get(c, "shard_record", static_cast<size_t>(stride), (void**)&d_rec)) != YAMS_OK) return;
-        if (hipMemcpyAsync(d_q, queries_host, nq * dim * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-            (void)hipGetLastError(); st[i] = fail(c, YAMS_ERR_INTERNAL, "query upload failed"); return;
-        }
-        yams_scan_params_t prm = *params;
-        if (l2) prm.flags |= YAMS_SCAN_FLAG_DEFER_THRESHOLD; // vec0: the k nearest first, the threshold after the merge
-        st[i] = yams_scan_topk_device(c, &shards[i], d_q, n_queries, &prm,
-                                      reinterpret_cast<float*>(d_rec + lay.scores_off),
-                                      reinterpret_cast<int64_t*>(d_rec + lay.rows_off),
-                                      reinterpret_cast<uint32_t*>(d_rec + lay.counts_off),
-                                      l2 ? reinterpret_cast<float*>(d_rec + lay.dist_off) : nullptr, nullptr, &dg[i]);
-        if (st[i] != YAMS_OK) return;
-        hipError_t e;
-        if (c->device == c0->device)
-            e = hipMemcpyAsync(d_gather + stride * i, d_rec, stride, hipMemcpyDeviceToDevice, c->stream);
-        else
-            e = hipMemcpyPeerAsync(d_gather + stride * i, c0->device, d_rec, c->device, stride, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { (void)hipGetLastError(); st[i] = fail(c, YAMS_ERR_INTERNAL, "record copy to the merge device failed"); }
-    };
-    if (n == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve(n);
-        for (uint32_t i = 0; i < n; ++i) th.emplace_back(work, i);
-        for (auto& t : th) t.join();
-    }
-    for (uint32_t i = 0; i < n; ++i)
-        if (st[i] != YAMS_OK) return failed(st[i], yams_accel_last_error(s->ctx[i])); // a batch fails as a whole (:1635-1647)
-
-    (void)hipSetDevice(c0->device);
-    float* d_s; int64_t* d_r; uint32_t* d_c; float* d_d;
-    if (ws_get(c0, "shard_out_scores", nq * k * 4, (void**)&d_s) != YAMS_OK ||
-        ws_get(c0, "shard_out_rows", nq * k * 8, (void**)&d_r) != YAMS_OK ||
-        ws_get(c0, "shard_out_counts", nq * 4, (void**)&d_c) != YAMS_OK ||
-        ws_get(c0, "shard_out_dist", nq * k * 4, (void**)&d_d) != YAMS_OK)
-        return failed(YAMS_ERR_INTERNAL, yams_accel_last_error(c0));
-    yams_status_t ms = yams_scan_merge_records_device(c0, n, n_queries, params, d_gather, stride, &lay, rank_of_row,
-                                                      rank_row_base, d_s, d_r, d_c, d_d);
-    if (ms != YAMS_OK) return failed(ms, yams_accel_last_error(c0));
-    hipError_t e = hipMemcpyAsync(out_counts_host, d_c, nq * 4, hipMemcpyDeviceToHost, c0->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_scores_host, d_s, nq * k * 4, hipMemcpyDeviceToHost, c0->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_rows_host, d_r, nq * k * 8, hipMemcpyDeviceToHost, c0->stream);
-    if (e == hipSuccess && out_dist_host) e = hipMemcpyAsync(out_dist_host, d_d, nq * k * 4, hipMemcpyDeviceToHost, c0->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); return failed(YAMS_ERR_INTERNAL, "result download failed"); }
-    if (diag) {
-        diag->used_exact_scan = 1; diag->rows_visited_observed = 1;
-        for (uint32_t i = 0; i < n; ++i) {
-            diag->rows_visited += dg[i].rows_visited;
-            diag->exact_distance_evaluations += dg[i].exact_distance_evaluations;
-            diag->filter_candidates += dg[i].filter_candidates;
-            diag->rescored_rows += dg[i].rescored_rows;
-            diag->widened_queries += dg[i].widened_queries;
-            diag->exact_fallback_queries += dg[i].exact_fallback_queries;
-            diag->escalated_queries += dg[i].escalated_queries;
-            diag->path = std::max(diag->path, dg[i].path);
-            diag->filter_tier = std::max(diag->filter_tier, dg[i].filter_tier);
-        }
-        uint64_t ret = 0;
-        for (size_t q = 0; q < nq; ++q) ret += out_counts_host[q];
-        diag->returned_rows = ret;
-    }
-    return YAMS_OK;
+    if (n_queries == 0 && shards && params) return YAMS_OK; // searchSimilarBatch on an empty batch (:1615-1617)
+    uint32_t lane = 0;
+    yams_status_t st = yams_scan_sharded_lane_acquire(s, 1, &lane);
+    if (st != YAMS_OK) return st;
+    st = yams_scan_sharded_submit(s, lane, shards, queries_host, n_queries, params, rank_of_row, rank_row_base,
+                                  diag ? YAMS_SHARDED_SUBMIT_DIAG : 0u);
+    if (st != YAMS_OK) { yams_scan_sharded_lane_release(s, lane); return st; }
+    return yams_scan_sharded_wait(s, lane, out_scores_host, out_rows_host, out_counts_host, out_dist_host, diag);
 }
