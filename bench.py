@@ -61,6 +61,14 @@ def parse():
     ap.add_argument("--no-i8", action="store_true", help="no int8 shadow: the bf16 tier filters the large batches too")
     ap.add_argument("--split-filter", action="store_true", help="start with the split-bf16 (3-pass) filter instead of the single-pass bf16 one")
     ap.add_argument("--half-tile", action="store_true", help="int8 tier: keep the per-tile (half-tile) filter kernel instead of the resident-query form (A/B runs)")
+    ap.add_argument("--via-c-abi", action="store_true",
+                    help="ONE process drives all --gpus devices through yams_scan_sharded_* (the C ABI a C++ host calls: one RCCL "
+                         "communicator, all-gather + merge per batch, submit/wait lanes) and prints the same JSON line")
+    ap.add_argument("--no-telemetry", action="store_true", help="skip the clock / power / throttle-reason window")
+    ap.add_argument("--no-c-abi-leg", action="store_true", help="skip the C-ABI sharded leg of the default run")
+    ap.add_argument("--no-boundary-leg", action="store_true", help="skip the plugin-door (vector_scan_v1.search_batch from host memory) leg")
+    ap.add_argument("--child-json", action="store_true", help=argparse.SUPPRESS)   # --via-c-abi as the child of a torchrun rank 0
+    ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
     ap.add_argument("--dist-backend", default=None, help="override the collective backend (gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry runs only)")
@@ -396,6 +404,264 @@ def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check):
     return {"blobs": len(pick), "ok": bool(ok)}
 
 
+def result_digest(rows, scores, counts):
+    """sha256 over the merged result of one batch (rows, score bits, counts): two paths agree iff their digests do."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(rows, dtype=np.int64).tobytes())
+    h.update(np.ascontiguousarray(scores, dtype=np.float32).tobytes())
+    h.update(np.ascontiguousarray(counts).astype(np.uint32).tobytes())
+    return h.hexdigest()
+
+
+def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, oracle_queries=0, collective="rccl"):
+    """The multi-GPU form a C++ host gets (sharded_api.cpp): ONE process, `devices` driven through yams_scan_sharded_*
+    — persistent shard workers, one RCCL communicator (of one rank on a one-GPU box), per batch one ncclAllGather of
+    the packed per-shard records on a side stream + merge_topk_kernel, `lanes` batches in flight so that
+    collective + merge of batch i run under the sweep of batch i + 1.  Queries and results live in HOST memory here
+    (pinned staging + PCIe both ways are inside the timed region).  `views`: per-device corpus views to reuse
+    (the default N = 1 run hands over its resident shard); otherwise every shard is generated and its shadows built
+    through the C ABI alone — no torch tensor is involved."""
+    import numpy as np
+    from yams_amd.accel import ShardedScan
+    from yams_amd._lib import SCAN_COSINE
+    n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
+    world = len(devices)
+    # three batches in flight: with queries and results crossing the host, two lanes leave the GPU waiting for the
+    # host's turn-around between a wait() and the next submit() (8.66 ms per step against 8.49 / 8.44 with 3 / 4 lanes)
+    lanes = max(3, a.lanes)
+    t_setup = time.perf_counter()
+    # RCCL prints a version banner on STDOUT when its first communicator is formed: keep this process's stdout
+    # for the one JSON line (file descriptor 1 points at stderr while the handle is created)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        sh = ShardedScan(devices, lanes=lanes, collective=collective)
+    finally:
+        os.dup2(saved, 1); os.close(saved)
+    info = sh.info()
+    own = []
+    if views is None:
+        views = []
+        for i in range(world):
+            c = sh.ctx(i)
+            rows = c.alloc(n * d * 4); own.append(rows)
+            c.synth_rows(a.seed, n * i, n, d, rows.ptr)
+            bf = c.alloc(n * d * 2); nsq = c.alloc(n * 4); own += [bf, nsq]
+            c.build_shadow_device(rows.ptr, n, d, bf.ptr, nsq.ptr)
+            i8 = c.alloc((n + 63) // 64 * 64 * d); m8 = c.alloc((n + 63) // 64 * 8 + 64); own += [i8, m8]
+            c.build_shadow_i8_device(rows.ptr, n, d, i8.ptr, m8.ptr)
+            views.append(c.corpus_view(rows.ptr, n, d, row_base=n * i, rows_bf16_ptr=bf.ptr, rows_nsq_ptr=nsq.ptr,
+                                       rows_i8_ptr=i8.ptr, rows_i8_meta_ptr=m8.ptr))
+        for i in range(world):
+            sh.ctx(i).synchronize()
+    setup_s = time.perf_counter() - t_setup
+    # the same query batches as the main run: Philox rows (1 << 40) + b * nq ...
+    c0 = sh.ctx(0)
+    stage = c0.alloc(nq * d * 4)
+    qb = []
+    for b in range(n_query_batches):
+        c0.synth_rows(a.seed, (1 << 40) + b * nq, nq, d, stage.ptr); c0.synchronize()
+        qb.append(stage.download(np.float32, nq * d).reshape(nq, d))
+    stage.free()
+
+    def run(count, first, collect=None):
+        inflight = []
+        for i in range(first, first + count):
+            if len(inflight) == lanes:
+                j, l = inflight.pop(0)
+                r = sh.wait(l)
+                if collect is not None:
+                    collect[j] = r
+            inflight.append((i, sh.submit(views, qb[i % n_query_batches], k, -1.0, SCAN_COSINE, want_diag=False)))
+        for j, l in inflight:
+            r = sh.wait(l)
+            if collect is not None:
+                collect[j] = r
+    run(max(a.warmup, 2), 0)
+    timed_ctx = [sh.lane_ctx(0, l) for l in range(lanes)]
+    for c in timed_ctx:
+        c.enable_timing(True)
+    got = {}
+    t0 = time.perf_counter()
+    run(a.steps, a.warmup, collect=got)
+    dt = time.perf_counter() - t0
+    tot, cnt = 0.0, 0
+    for c in timed_ctx:
+        ms, n_ = c.kernel_ms("scan_filter")
+        if ms is not None and n_:
+            tot += ms * n_; cnt += n_
+        c.enable_timing(False)
+    filt_ms = tot / cnt if cnt else None
+    last = a.warmup + a.steps - 1
+    res = got[last]
+    digests = {}
+    for j in sorted(got)[-n_query_batches:]:
+        digests[str(j % n_query_batches)] = result_digest(got[j].rows, got[j].scores, got[j].counts)
+    # the exchange itself, checked at any N: per-shard top-k through the single-shard C-ABI call, merged on the host
+    # with the reference comparator (similarity desc, row id asc), against the handle's merged result
+    nchk = min(8, nq)
+    qs = qb[last % n_query_batches][:nchk]
+    parts = [sh.ctx(i).scan_topk(views[i], qs, k, -1.0, SCAN_COSINE) for i in range(world)]
+    exch_ok = True
+    for qi in range(nchk):
+        rows = np.concatenate([p.rows[qi, :int(p.counts[qi])] for p in parts])
+        sims = np.concatenate([p.scores[qi, :int(p.counts[qi])] for p in parts])
+        order = np.lexsort((rows, -sims.astype(np.float64)))[:k]
+        exch_ok &= bool(int(res.counts[qi]) == len(order) and np.array_equal(res.rows[qi, :len(order)], rows[order])
+                        and np.array_equal(res.scores[qi, :len(order)].view(np.uint32), sims[order].view(np.uint32)))
+    out = {"what": "one process, yams_scan_sharded_* (C ABI): persistent shard workers, one RCCL communicator, one ncclAllGather "
+                   "of the packed records + merge_topk_kernel per batch on a side stream, submit/wait lanes; queries and "
+                   "results in host memory (pinned staging + PCIe both ways inside the timed region)",
+           "n_devices": world, "devices": list(devices), "lanes": lanes, "collective": info.get("collective"),
+           "rccl_version": info.get("rccl_version"), "rccl_library": info.get("rccl_library"),
+           "communicator_ranks": info.get("communicator_ranks"), "rccl_unavailable": info.get("rccl_unavailable"),
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "qps_on_resident_corpus": nq * a.steps / dt, "value": nq * a.steps / dt * (n * world / HEADLINE_ROWS), "unit": "QPS",
+           "filter_launch_ms_shard0": filt_ms, "collectives": sh.info().get("collectives"),
+           "merged_equals_host_merge_of_per_shard_results": {"queries": nchk, "ok": exch_ok},
+           "result_digests": digests, "setup_s": setup_s, "distinct_query_batches": n_query_batches}
+    if oracle_queries > 0:
+        _oracle = oracle_mod()
+        qsel = [int(x) for x in np.linspace(0, nq - 1, min(oracle_queries, nq)).round()]
+        qh = qb[last % n_query_batches][qsel]
+        inter, exact = 0, True
+        per_shard = []
+        t_or = time.perf_counter()
+        for i in range(world):
+            base = views[i].rows
+            c = sh.ctx(i)
+
+            def fetch(lo, hi, base=base, c=c):
+                out_ = np.empty((hi - lo, d), np.float32)
+                c._check(c.L.yams_accel_download(c.ctx, out_.ctypes.data, base + lo * d * 4, out_.nbytes))
+                return out_
+            part = _oracle.scan_threaded(fetch, n, qh, k, slice_rows=32768, threads=min(_oracle.host_threads(), 96))
+            per_shard.append([(rows + n * i, sims) for rows, sims in part])
+        for j, qi in enumerate(qsel):
+            rows = np.concatenate([p[j][0] for p in per_shard]); sims = np.concatenate([p[j][1] for p in per_shard])
+            order = np.lexsort((rows, -sims.astype(np.float64)))[:k]
+            rows, sims = rows[order], sims[order]
+            inter += len(set(res.rows[qi, :k].tolist()) & set(rows.tolist()))
+            exact &= bool(int(res.counts[qi]) == len(rows) and np.array_equal(res.rows[qi, :len(rows)], rows)
+                          and np.array_equal(res.scores[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+        out.update({"recall_at_k": inter / float(len(qsel) * k), "bit_exact_vs_oracle": exact, "oracle_queries": len(qsel),
+                    "oracle_seconds": time.perf_counter() - t_or})
+    sh.close()
+    for o in own:
+        o.free()
+    return out
+
+
+def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
+    """The PLUGIN DOOR measured end to end: vector_scan_v1.search_batch as a host calls it — queries in
+    pageable host memory, per call: copy into pinned staging, H2D, the scan, D2H, packing of the hit records, free_hits —
+    at Q = 1 / 16 / 1024 on BASELINE config 1 (10k x 384, k = 10), config 2 (1M x 384, k = 100) and the config-4 shard
+    (k = 100).  The mirrors are the plugin's own (corpus_append from host memory, shadows built at upload)."""
+    import ctypes as C
+    import numpy as np
+    from yams_amd import _lib
+    L = acc.L
+    L.yams_plugin_shutdown()
+    if L.yams_plugin_init(b'{"device": %d, "search_slots": 2}' % dev.index, None) != 0:
+        return {"error": "yams_plugin_init failed"}
+    p = C.c_void_p()
+    L.yams_plugin_get_interface(b"vector_scan_v1", 1, C.byref(p))
+    vt = C.cast(p, C.POINTER(_lib.VectorScanV1)).contents
+    out = {"what": "vector_scan_v1.search_batch from pageable host memory: staging + H2D + scan + D2H + hit packing + free_hits, "
+                   "one call at a time (latency) — ms per call, median of the timed calls"}
+    legs = [("config1_10k_x384_k10", 10_000, 384, 10), ("config2_1M_x384_k100", 1_000_000, 384, 100)]
+    if rows_c4:
+        legs.append((f"config4_shard_{rows_c4}_x{a.dim}_k{a.k}", rows_c4, a.dim, a.k))
+    for name, n, d, k in legs:
+        cid = C.c_uint64()
+        if vt.corpus_create(None, d, C.byref(cid)) != 0:
+            out[name] = {"error": "corpus_create failed"}; continue
+        t0 = time.perf_counter()
+        chunk = 1 << 20
+        stage = torch.empty((min(n, chunk), d), dtype=torch.float32, device=dev)
+        ok = True
+        for r0 in range(0, n, chunk):
+            m = min(chunk, n - r0)
+            if tc_full is not None and d == a.dim and n == rows_c4:
+                host = tc_full[r0:r0 + m].cpu().numpy()          # the bench's own resident shard, through host memory
+            else:
+                acc.synth_rows(a.seed + 7, r0, m, d, stage.data_ptr()); acc.synchronize()
+                host = stage[:m].cpu().numpy()
+            ok &= vt.corpus_append(None, cid, host.ctypes.data_as(_lib.f32p), m) == 0
+        del stage
+        upload_s = time.perf_counter() - t0
+        if not ok:
+            out[name] = {"error": "corpus_append failed"}; vt.corpus_destroy(None, cid); continue
+        qdev = torch.empty((1024, d), dtype=torch.float32, device=dev)
+        acc.synth_rows(a.seed + 7, 1 << 40, 1024, d, qdev.data_ptr()); acc.synchronize()
+        qh = qdev.cpu().numpy()
+        leg = {"rows": n, "dim": d, "k": k, "upload_s_incl_shadows": upload_s}
+        for q in (1, 16, 1024):
+            hits = C.POINTER(_lib.ScanHit)(); counts = _lib.u32p()
+            reps = 30 if (n <= 1_000_000 or q < 1024) else 8
+            ts = []
+            for it in range(reps + 3):
+                qq = qh[(it * q) % (1024 - q + 1):][:q]
+                t1 = time.perf_counter()
+                st = vt.search_batch(None, cid, qq.ctypes.data_as(_lib.f32p), q, d, k, -1.0, 0, C.byref(hits), C.byref(counts), None)
+                if st == 0:
+                    vt.free_hits(None, hits, counts)
+                t2 = time.perf_counter()
+                if st != 0:
+                    leg[f"q{q}"] = {"error": st}; break
+                if it >= 3:
+                    ts.append(t2 - t1)
+            if ts:
+                ts.sort()
+                leg[f"q{q}"] = {"ms_per_call": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "qps": q / ts[len(ts) // 2], "calls": len(ts)}
+        # the device-entry number of the same shape beside it (queries and results stay in HBM)
+        out[name] = leg
+        vt.corpus_destroy(None, cid)
+        del qdev
+    L.yams_plugin_shutdown()
+    torch.cuda.empty_cache()
+    return out
+
+
+def c_abi_main(a):
+    """`bench.py --gpus N --via-c-abi`: the whole job from ONE process through the C ABI; prints the contract's line."""
+    devices = [0] * a.gpus if a.single_device else list(range(a.gpus))
+    oq = a.oracle_queries if a.oracle_queries is not None else (4 if a.gpus == 1 else 0)
+    r = c_abi_sharded_run(a, devices, n_query_batches=max(1, a.query_batches), oracle_queries=oq,
+                          collective="peer" if a.single_device and a.gpus > 1 else "rccl")
+    if a.child_json:
+        print(json.dumps(r))
+        return
+    n, d, k = a.rows_per_gpu, a.dim, a.k
+    tr = 256
+    n_tiles = (n + tr - 1) // tr
+    stride = max(1, n_tiles // ((min(n, max(n // 64, 8192)) + tr - 1) // tr))
+    filt_rows = min(n, (n_tiles - (n_tiles + stride - 1) // stride) * tr)
+    flops = 2.0 * a.queries * d * filt_rows
+    ach = flops / (r["filter_launch_ms_shard0"] * 1e-3) / 1e12 if r["filter_launch_ms_shard0"] else None
+    out = {"metric": "k-NN QPS + recall@k, 100M x 768 fp32 cosine top-100; ingest GB/s SHA-256+CDC",
+           "value": r["value"], "unit": "QPS", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "i8 (MFMA filter, exact i32 accumulate) + f64 (exact re-score)", "data": "synthetic",
+           "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: 100Mx768 over 8 GPUs), "
+                                  f"query batch {a.queries}", "rows_per_gpu": n, "corpus_rows": n * a.gpus, "dim": d, "k": k,
+                      "query_batch": a.queries,
+                      "parallelism": f"row-shard x{a.gpus}, ONE process through the C ABI (yams_scan_sharded_*): RCCL all-gather + merge "
+                                     "per batch, overlapped with the next sweep", "search_lanes": a.lanes},
+           "launcher": "single process (--via-c-abi)",
+           "roofline": {"bound": "mfma", "kernel": "scan_tiles_i8r_kernel (shard 0's lanes)", "achieved": ach, "peak": PEAK_I8_MFMA_TOPS,
+                        "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS if ach else None, "launch_ms": r["filter_launch_ms_shard0"],
+                        "traffic": None},
+           "c_abi_sharded": r}
+    for kk in ("recall_at_k", "bit_exact_vs_oracle", "oracle_queries"):
+        if kk in r:
+            out[kk] = r[kk]
+    print(json.dumps(out))
+
+
 def hbm_leg_traffic(n, d, nq, i8):
     """HBM bytes per launch of the small-batch filter from the builder's PMC pass (profiles/*_small_batch_pmc.json),
     when it was taken on this very shape and kernel; labelled as such."""
@@ -413,6 +679,8 @@ def hbm_leg_traffic(n, d, nq, i8):
 
 def main():
     a = parse()
+    if a.via_c_abi:
+        return c_abi_main(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
 
@@ -439,8 +707,15 @@ def main():
     # synthetic data, generated in HBM (Philox recipe of SURVEY.md 8d; regenerable on the CPU)
     tc = torch.empty((n, d), dtype=torch.float32, device=dev)
     acc.synth_rows(a.seed, row_base, n, d, tc.data_ptr())
-    tq = torch.empty((nq, d), dtype=torch.float32, device=dev)
-    acc.synth_rows(a.seed, 1 << 40, nq, d, tq.data_ptr())        # same queries on every rank
+    # `query_batches` distinct query batches rotate through the steps (same on every rank): batch b = Philox rows
+    # (1 << 40) + b * nq ...  `tq` is re-pointed at the batch of the LAST TIMED step below (checks, later legs).
+    n_qb = max(1, a.query_batches)
+    tqs = []
+    for b in range(n_qb):
+        t_ = torch.empty((nq, d), dtype=torch.float32, device=dev)
+        acc.synth_rows(a.seed, (1 << 40) + b * nq, nq, d, t_.data_ptr())
+        tqs.append(t_)
+    tq = tqs[0]
     # the filter shadow of the mirror (bf16 copy + squared norms), built once when rows are uploaded
     # (plugin.cpp corpus_append does the same); part of the resident index, not of the timed step
     tb = tn = None
@@ -505,7 +780,7 @@ def main():
         pipe.wait(slot)                 # the merge of batch i - lanes has long finished: its record is free
         loc = pipe.local(slot)
         # (the call returns after its own host sync on the query status words: results are complete)
-        diag = accs[lane].scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
+        diag = accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
                                            loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
                                            want_diag=want_diag)
         with turn_cv:
@@ -576,7 +851,9 @@ def main():
     samp_ms, samp_n = lane_kernel_ms("scan_sample")
     for c in accs:
         c.enable_timing(False)
-    res = pipe.result(last_slot)          # the merged top-k of the LAST TIMED step
+    res = {kk: v.clone() for kk, v in pipe.result(last_slot).items()}   # the merged top-k of the LAST TIMED step
+    last_batch = (batch_no[0] - 1) % n_qb
+    tq = tqs[last_batch]                  # its queries: every check and every later leg works on this batch
     r_timed = res["rows"].cpu().numpy().copy()
     s_timed = res["scores"].cpu().numpy().copy()
     c_timed = res["counts"].cpu().numpy().copy()
@@ -617,10 +894,37 @@ def main():
                      "oracle_queries": n_oq, "oracle_query_ids": qsel, "oracle_seconds": t_or,
                      "oracle_threads_per_rank": stats.get("threads"), "oracle_scan_thread_seconds": stats.get("scan_thread_s")}
 
-    # diagnostics of the same batch, outside the timed region (every step scans the same inputs)
+    # diagnostics of one more batch, outside the timed region
     diag, _ = step(batch_no[0], want_diag=True)
     batch_no[0] += 1
     fence()
+
+    # ---- clock / power / THROTTLE REASON while the same steps run for ~1.5 s (outside the timed region) ----
+    telemetry = None
+    if world == 1 and not a.no_telemetry:
+        try:
+            from yams_amd import telemetry as ytel
+            bus = ytel.hip_pci_bus(local)
+            hw = ytel.hwmon_dir(bus)
+            thr = ytel.Throttle(bus)
+            smp = ytel.HwmonSampler(hw) if hw else None
+            if smp:
+                smp.start()
+            t_a = time.perf_counter(); snap_a = thr.snapshot()
+            n_sus = 0
+            while time.perf_counter() - t_a < 1.5:
+                run_steps(2 * lanes); n_sus += 2 * lanes
+            fence()
+            t_b = time.perf_counter(); snap_b = thr.snapshot()
+            if smp:
+                smp.stop = True; smp.join()
+            telemetry = {"window": f"{n_sus} further steps of the timed workload, {t_b - t_a:.2f} s, outside the timed region",
+                         "ms_per_step_in_window": (t_b - t_a) / max(1, n_sus) * 1e3, "pci_bus": bus,
+                         "hwmon": smp.window(t_a + 0.3, t_b) if smp else None,
+                         "power_cap_W": (int(open(os.path.join(hw, "power1_cap")).read()) / 1e6) if hw and os.path.exists(os.path.join(hw, "power1_cap")) else None,
+                         "throttle": thr.between(snap_a, snap_b) if snap_a and snap_b else {"error": thr.error}}
+        except Exception as e:      # noqa: BLE001 - telemetry never fails the bench
+            telemetry = {"error": repr(e)}
     fallbacks = diag["exact_fallback_queries"] * a.steps
     ms_per_step = dt / a.steps * 1e3
     qps_resident = nq * a.steps / dt                       # queries/s against the rows resident on the N GPUs
@@ -747,6 +1051,48 @@ def main():
                          "results_identical_to_the_q1024_run": bool(torch.equal(r3[:q3s], rb3[:q3s]) and torch.equal(d3[:q3s], db3[:q3s]))}
         del s3, r3, c3, d3, sb3, rb3, cb3, db3
 
+    # ---- the same workload through the C ABI's sharded entry points (what a C++ host calls) ----------
+    c_abi = None
+    if not a.no_c_abi_leg and scan_flags == 0 and t8 is not None:
+        if world == 1:
+            try:
+                c_abi = c_abi_sharded_run(a, [local], views=[view], n_query_batches=n_qb, oracle_queries=0)
+                c_abi["identical_to_the_timed_step"] = c_abi["result_digests"].get(str(last_batch)) == \
+                    result_digest(r_timed, s_timed, c_timed)
+                c_abi["note"] = ("the resident shard of this run, handed over as a view; a communicator of ONE rank "
+                                 "(all-gather + merge still run per batch)")
+            except Exception as e:      # noqa: BLE001 - the headline number above stands on its own
+                c_abi = {"error": repr(e)}
+        else:
+            # N > 1 under torchrun: rank 0 starts ONE more process that drives all N devices through the C ABI while the
+            # ranks wait on the HOST (a gloo barrier: an RCCL barrier would spin a kernel on every device meanwhile)
+            import subprocess
+            hostpg = torch.distributed.new_group(backend="gloo")
+            fence()
+            torch.distributed.barrier(group=hostpg)
+            if rank == 0:
+                cmd = [sys.executable, os.path.abspath(__file__), "--via-c-abi", "--child-json", "--gpus", str(world),
+                       "--steps", str(a.steps), "--warmup", str(a.warmup), "--rows-per-gpu", str(n), "--dim", str(d),
+                       "--queries", str(nq), "--k", str(k), "--lanes", str(lanes), "--seed", str(a.seed),
+                       "--query-batches", str(n_qb)] + (["--single-device"] if a.single_device else [])
+                env = dict(os.environ)
+                for kk in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                           "TORCHELASTIC_RUN_ID"):
+                    env.pop(kk, None)
+                try:
+                    cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+                    line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                    if cp.returncode == 0 and line:
+                        c_abi = json.loads(line[-1])
+                        c_abi["identical_to_the_timed_step"] = c_abi["result_digests"].get(str(last_batch)) == \
+                            result_digest(r_timed, s_timed, c_timed)
+                        c_abi["note"] = "a second process on the same node, started by rank 0 after the timed region; the ranks idle on the host meanwhile"
+                    else:
+                        c_abi = {"error": f"child exited {cp.returncode}", "stderr_tail": cp.stderr[-1500:]}
+                except Exception as e:  # noqa: BLE001
+                    c_abi = {"error": repr(e)}
+            torch.distributed.barrier(group=hostpg)
+
     if rank != 0:
         return
     # ---- roofline of the dominant kernel (the FILTER pass of the scan) -----------------------------
@@ -823,7 +1169,7 @@ def main():
                                   f"100Mx768 over 8 GPUs), query batch {nq}",
                       "rows_per_gpu": n, "corpus_rows": total_rows, "dim": d, "k": k, "query_batch": nq,
                       "parallelism": f"row-shard x{world} + RCCL all-gather top-k merge (overlapped with the next sweep)" if world > 1 else "single shard",
-                      "search_lanes": lanes},
+                      "search_lanes": lanes, "distinct_query_batches": n_qb},
            "value_definition": "queries/s against the 100M x 768 headline corpus = (rows scored x queries)/s / 1e8; "
                                "equals qps_on_resident_corpus x corpus_rows / 1e8 (identical at N = 8)",
            "qps_on_resident_corpus": qps_resident,
@@ -832,6 +1178,14 @@ def main():
            "scan_diag_per_batch": {kk: diag[kk] for kk in ("filter_tier", "filter_candidates", "rescored_rows", "widened_queries",
                                                              "escalated_queries", "exact_fallback_queries")},
            "roofline": roofline}
+    if telemetry is not None:
+        roofline["telemetry"] = telemetry
+        hw_ = (telemetry.get("hwmon") or {})
+        roofline["sclk_MHz"] = (hw_.get("sclk_MHz") or {}).get("mean")
+        roofline["power_W"] = (hw_.get("power_W") or {}).get("mean")
+        roofline["limiter"] = (telemetry.get("throttle") or {}).get("limiter")
+    if c_abi is not None:
+        out["c_abi_sharded"] = c_abi
     if hbm_leg is not None:
         out["roofline_hbm_leg"] = hbm_leg
     if l2_leg is not None:
@@ -843,6 +1197,13 @@ def main():
                              "overlapped": pipe.side is not None and torch.distributed.get_backend() != "gloo"}
     # CPU baseline and the ingest leg: rank 0 at N = 1 only (at N > 1 the other ranks would sit in the
     # final barrier meanwhile)
+    if not a.no_boundary_leg and world == 1:
+        try:
+            free_b, _ = torch.cuda.mem_get_info()
+            need = n * d * 7 * 1.15                      # the plugin's own mirror of the shard: fp32 + bf16 + int8
+            out["boundary"] = boundary_leg(a, acc, torch, dev, tc, n if free_b > need + (8 << 30) else 0)
+        except Exception as e:          # noqa: BLE001
+            out["boundary"] = {"error": repr(e)}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_scan(tc, tq, n, k)
     if not a.no_ingest and world == 1:

@@ -52,3 +52,27 @@ def test_bench_self_launches_n_ranks_and_checks_the_merge_against_the_oracle():
     assert out["n_gpus"] == 2 and out["config"]["corpus_rows"] == 600000
     assert out["recall_at_k"] == 1.0 and out["bit_exact_vs_oracle"] is True and out["oracle_queries"] == 3
     assert out["exact_fallback_queries"] == 0 and out["roofline"]["launches"] == 3
+    # ... and rank 0's extra process drove both shards from ONE process through the C ABI (here: two shards on one
+    # device, so device copies instead of the communicator) and got the very same merged result
+    ca = out["c_abi_sharded"]
+    assert "error" not in ca, ca
+    assert ca["n_devices"] == 2 and ca["collective"] == "peer_copy" and ca["identical_to_the_timed_step"] is True
+    assert ca["merged_equals_host_merge_of_per_shard_results"]["ok"] is True
+
+
+def test_bench_through_the_c_abi_from_one_process_with_an_rccl_communicator():
+    """`python bench.py --gpus 1 --via-c-abi`: ONE process, yams_scan_sharded_* with the communicator required (one
+    rank here), submit/wait lanes, the contract's JSON line, oracle-checked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--via-c-abi", "--rows-per-gpu", "300000", "--dim", "256",
+           "--queries", "300", "--k", "50", "--steps", "4", "--warmup", "1", "--oracle-queries", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    ca = out["c_abi_sharded"]
+    assert out["n_gpus"] == 1 and out["launcher"].startswith("single process") and out["unit"] == "QPS" and out["value"] > 0
+    assert ca["collective"] == "rccl" and ca["communicator_ranks"] == 1 and ca["collectives"] >= 5 and ca["rccl_version"] > 20000
+    assert out["recall_at_k"] == 1.0 and out["bit_exact_vs_oracle"] is True
+    assert ca["merged_equals_host_merge_of_per_shard_results"]["ok"] is True

@@ -177,6 +177,7 @@ yams_status_t yams_accel_ctx_set_gate(yams_accel_ctx* ctx, yams_accel_gate* gate
 
 yams_status_t yams_accel_ctx_synchronize(yams_accel_ctx* ctx) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return YAMS_OK;
 }
@@ -217,6 +218,7 @@ yams_status_t yams_accel_malloc(yams_accel_ctx* ctx, size_t bytes, void** out_de
 }
 void yams_accel_free(yams_accel_ctx* ctx, void* dev) {
     if (!ctx || !dev) return;
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dev);
 }
@@ -224,6 +226,7 @@ yams_status_t yams_accel_upload(yams_accel_ctx* ctx, void* dst_dev, const void* 
                                 size_t bytes) {
     if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return YAMS_ERR_INVALID_ARG;
     if (!bytes) return YAMS_OK;
+    (void)hipSetDevice(ctx->device);
     YA_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return YAMS_OK;
@@ -232,6 +235,7 @@ yams_status_t yams_accel_download(yams_accel_ctx* ctx, void* dst_host, const voi
                                   size_t bytes) {
     if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return YAMS_ERR_INVALID_ARG;
     if (!bytes) return YAMS_OK;
+    (void)hipSetDevice(ctx->device);
     YA_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return YAMS_OK;

@@ -244,7 +244,7 @@ void issue_merge(yams_scan_sharded* s, Lane& L) {
         hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_c, nq * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_s, nq * k * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_r, nq * k * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && L.l2) e = hipMemcpyAsync(L.h_out + o.dist, d_d, nq * k * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.dist, d_d, nq * k * 4, hipMemcpyDeviceToHost, st); // (cosine: 1 - similarity)
         if (e != hipSuccess) { (void)hipGetLastError(); r = fail(m, YAMS_ERR_INTERNAL, "download of the merged result failed"); }
     }
     (void)hipEventRecord(L.done, st);
@@ -272,7 +272,7 @@ yams_status_t run_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& 
         st = yams_scan_topk_device(c, &L.views[i], d_q, L.nq, &prm, reinterpret_cast<float*>(d_rec + L.lay.scores_off),
                                    reinterpret_cast<int64_t*>(d_rec + L.lay.rows_off),
                                    reinterpret_cast<uint32_t*>(d_rec + L.lay.counts_off),
-                                   L.l2 ? reinterpret_cast<float*>(d_rec + L.lay.dist_off) : nullptr, nullptr,
+                                   L.lay.dist_off != UINT64_MAX ? reinterpret_cast<float*>(d_rec + L.lay.dist_off) : nullptr, nullptr,
                                    L.want_diag ? &L.dg[i] : nullptr);
     }
     if (st != YAMS_OK) {
@@ -286,7 +286,7 @@ yams_status_t run_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& 
         hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_rec + L.lay.counts_off, nq * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_rec + L.lay.scores_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_rec + L.lay.rows_off, nq * k * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && L.l2) e = hipMemcpyAsync(L.h_out + o.dist, d_rec + L.lay.dist_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.dist, d_rec + L.lay.dist_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { (void)hipGetLastError(); err = "result download failed"; return YAMS_ERR_INTERNAL; }
         return YAMS_OK;
@@ -510,7 +510,9 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         if (params->k > YAMS_SCAN_MAX_K) return set_error(s, YAMS_ERR_UNSUPPORTED, "k exceeds YAMS_SCAN_MAX_K");
         if (s->mode != kNone && static_cast<uint64_t>(n) * params->k > 8192) return set_error(s, YAMS_ERR_UNSUPPORTED, "n_shards * k exceeds 8192");
         const size_t nq = n_queries, k = params->k;
-        yams_scan_record_layout(n_queries, params->k, L.l2 ? 1 : 0, 0, &L.lay);
+        // records that travel carry distances only under L2 (the merge derives 1 - similarity for cosine); a lone
+        // shard's record is the result itself and always has them
+        yams_scan_record_layout(n_queries, params->k, (L.l2 || s->mode == kNone) ? 1 : 0, 0, &L.lay);
         L.stride = L.lay.bytes;
         int dev0 = s->device[0];
         (void)hipGetDevice(&dev0); // the caller's current device is restored below
@@ -599,7 +601,7 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
     std::memcpy(out_counts_host, L.h_out + o.counts, nq * 4);
     std::memcpy(out_scores_host, L.h_out + o.scores, nq * k * 4);
     std::memcpy(out_rows_host, L.h_out + o.rows, nq * k * 8);
-    if (out_dist_host && L.l2) std::memcpy(out_dist_host, L.h_out + o.dist, nq * k * 4);
+    if (out_dist_host) std::memcpy(out_dist_host, L.h_out + o.dist, nq * k * 4); // L2 distance, or 1 - similarity
     if (diag && L.want_diag) {
         if (s->n == 1) *diag = L.dg[0];
         diag->used_exact_scan = 1; diag->rows_visited_observed = 1;
