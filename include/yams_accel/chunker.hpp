@@ -92,13 +92,87 @@ public:
     // sequence RabinChunker produces (rabin_chunker.cpp:144-147); the boundaries all come back from
     // one device call, so the calls happen after it.
     void setProgressCallback(ProgressCallback callback) override { progress_ = std::move(callback); }
+
+    // MANY buffers per call (chunker_v1.chunk_many): what ContentStore::store needs for a batch of files
+    // (content_store_impl.cpp:199-231) — chunk lists with per-chunk hashes and, if asked for, the whole-buffer
+    // (file) hashes — from ONE device call that runs at the batched ingest rate instead of one launch sequence
+    // per file.  A plugin build without chunk_many (NULL entry: "not implemented",
+    // abi_model_provider_adapter.cpp:121-122) is served buffer by buffer through chunk_data.
+    struct BatchResult {
+        std::vector<std::vector<Chunk>> chunks;   // per buffer, in order
+        std::vector<Hash> bufferHashes;           // per buffer; empty unless asked for
+    };
+    BatchResult chunkMany(const std::vector<std::span<const std::byte>>& buffers, bool withBufferHashes = false, bool lazy = true) {
+        BatchResult out;
+        out.chunks.resize(buffers.size());
+        const bool batched = vt_->abi_version >= 2 && vt_->chunk_many && vt_->free_chunk_batch;
+        if (!batched) {
+            if (withBufferHashes) throw std::runtime_error("this chunker_v1 build has no chunk_many: buffer hashes need a hasher");
+            for (size_t b = 0; b < buffers.size(); ++b) out.chunks[b] = run(buffers[b], lazy);
+            return out;
+        }
+        const yams_cdc_config_t cfg = config();
+        std::vector<const uint8_t*> ptrs(buffers.size());
+        std::vector<size_t> lens(buffers.size());
+        for (size_t b = 0; b < buffers.size(); ++b) { ptrs[b] = reinterpret_cast<const uint8_t*>(buffers[b].data()); lens[b] = buffers[b].size(); }
+        yams_chunk_batch_t* batch = nullptr;
+        const yams_status_t st = vt_->chunk_many(vt_->self, ptrs.data(), lens.data(), buffers.size(), &cfg,
+                                                 withBufferHashes ? YAMS_CHUNK_MANY_BUFFER_HASHES : 0u, &batch);
+        if (st != YAMS_OK || !batch) throw std::runtime_error("Failed to chunk the batch on the accelerator");
+        try {
+            for (size_t b = 0; b < buffers.size(); ++b) {
+                auto& dst = out.chunks[b];
+                dst.resize(batch->first_chunk[b + 1] - batch->first_chunk[b]);
+                for (size_t i = 0; i < dst.size(); ++i) {
+                    const yams_chunk_ref_t& r = batch->chunks[batch->first_chunk[b] + i];
+                    dst[i].offset = r.offset; dst[i].size = r.size; dst[i].hash.assign(r.hash_hex, 64);
+                    if (!lazy) { auto s = buffers[b].subspan(dst[i].offset, dst[i].size); dst[i].data.assign(s.begin(), s.end()); }
+                }
+                if (withBufferHashes) out.bufferHashes.emplace_back(batch->buffer_hash_hex + 65 * b, 64);
+            }
+        } catch (...) { vt_->free_chunk_batch(vt_->self, batch); throw; } // the paired free, also on the exception path (:131-149)
+        vt_->free_chunk_batch(vt_->self, batch);
+        return out;
+    }
+    // Files: read, then one chunkMany over all of them (bounded: files are grouped so that at most ~maxBytes are in
+    // host memory at once).
+    BatchResult chunkFiles(const std::vector<std::filesystem::path>& paths, bool withFileHashes = true,
+                           size_t maxBytes = size_t(1) << 30) {
+        BatchResult out;
+        size_t i = 0;
+        while (i < paths.size()) {
+            std::vector<std::vector<std::byte>> bufs;
+            size_t bytes = 0;
+            while (i < paths.size() && (bufs.empty() || bytes < maxBytes)) {
+                std::ifstream file(paths[i], std::ios::binary);
+                if (!file) throw std::runtime_error("Failed to open file: " + paths[i].string());
+                std::vector<std::byte> data;
+                char block[64 << 10];
+                while (file.read(block, sizeof block) || file.gcount() > 0) // until EOF, like the reference's readers
+                    data.insert(data.end(), reinterpret_cast<std::byte*>(block), reinterpret_cast<std::byte*>(block) + file.gcount());
+                bytes += data.size();
+                bufs.push_back(std::move(data));
+                ++i;
+            }
+            std::vector<std::span<const std::byte>> spans;
+            for (auto& b : bufs) spans.emplace_back(b.data(), b.size());
+            BatchResult part = chunkMany(spans, withFileHashes, /*lazy=*/false);
+            for (auto& c : part.chunks) out.chunks.push_back(std::move(c));
+            for (auto& h : part.bufferHashes) out.bufferHashes.push_back(std::move(h));
+        }
+        return out;
+    }
 private:
-    std::vector<Chunk> run(std::span<const std::byte> data, bool lazy) {
+    yams_cdc_config_t config() const {
         yams_cdc_config_t cfg{};
         cfg.window_size = config_.windowSize; cfg.min_size = config_.minChunkSize;
         cfg.max_size = config_.maxChunkSize; cfg.polynomial = config_.polynomial;
         cfg.mask = config_.chunkMask;
         cfg.mode = kind_ == AccelChunkerKind::Streaming ? YAMS_CDC_STREAMING : YAMS_CDC_RABIN;
+        return cfg;
+    }
+    std::vector<Chunk> run(std::span<const std::byte> data, bool lazy) {
+        const yams_cdc_config_t cfg = config();
         yams_chunk_ref_t* refs = nullptr; size_t n = 0;
         const yams_status_t st = vt_->chunk_data(vt_->self, reinterpret_cast<const uint8_t*>(data.data()),
                                                  data.size(), &cfg, &refs, &n);
@@ -126,6 +200,13 @@ inline Result<std::unique_ptr<IChunker>> createAccelChunker(std::shared_ptr<acce
     auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, YAMS_IFACE_CHUNKER_V1_VERSION);
     if (!vt) return vt.error();
     return std::unique_ptr<IChunker>(new AccelChunker(std::move(plugin), vt.value(), kind, std::move(config)));
+}
+// the concrete type, for hosts that batch (chunkMany / chunkFiles)
+inline Result<std::unique_ptr<AccelChunker>> createAccelBatchChunker(std::shared_ptr<accel::Plugin> plugin,
+                                                                     AccelChunkerKind kind, ChunkingConfig config = {}) {
+    auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, YAMS_IFACE_CHUNKER_V1_VERSION);
+    if (!vt) return vt.error();
+    return std::make_unique<AccelChunker>(std::move(plugin), vt.value(), kind, std::move(config));
 }
 
 } // namespace yams::chunking

@@ -38,62 +38,83 @@ public:
 };
 #endif
 
+// One SHA-256 chain is sequential: a device lane advances it at ~35 MB/s, a host core with SHA-NI at > 1 GB/s.
+// The device is for MANY chains at once (hashMany / hashFiles / chunker_v1 / yams_ingest_*).  The vtable therefore
+// REFUSES lone long chains (YAMS_ERR_UNSUPPORTED, see content_hash_v1 in yams_mi355x_accel.h) and this adapter hands
+// them to the hasher the HOST supplies — its own SHA256Hasher (src/crypto/sha256_hasher.cpp) — which also serves the
+// streaming calls and hashFile.  Without a host hasher everything still works through the plugin's streaming door:
+// correct, slow, and documented as such.
 class AccelSHA256Hasher final : public IContentHasher {
 public:
-    AccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin, yams_content_hash_v1* vt)
-        : plugin_(std::move(plugin)), vt_(vt) {
-        if (vt_->stream_create(vt_->self, &stream_) != YAMS_OK)
+    AccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin, yams_content_hash_v1* vt,
+                      std::unique_ptr<IContentHasher> hostHasher = nullptr)
+        : plugin_(std::move(plugin)), vt_(vt), host_(std::move(hostHasher)) {
+        if (!host_ && vt_->stream_create(vt_->self, &stream_) != YAMS_OK)
             throw std::runtime_error("Failed to create SHA256 stream on the accelerator");
     }
     ~AccelSHA256Hasher() override { if (stream_) vt_->stream_destroy(vt_->self, stream_); }
     AccelSHA256Hasher(const AccelSHA256Hasher&) = delete;
     AccelSHA256Hasher& operator=(const AccelSHA256Hasher&) = delete;
 
-    void init() override { check(vt_->stream_init(vt_->self, stream_), "Failed to initialize SHA256"); }
+    // ---- the streaming interface: one chain — the host's hasher when there is one --------------------------
+    void init() override {
+        if (host_) return host_->init();
+        check(vt_->stream_init(vt_->self, stream_), "Failed to initialize SHA256");
+    }
     void update(std::span<const std::byte> data) override {
+        if (host_) return host_->update(data);
         check(vt_->stream_update(vt_->self, stream_, reinterpret_cast<const uint8_t*>(data.data()), data.size()),
               "Failed to update SHA256");
     }
     std::string finalize() override { // re-initialises for reuse, sha256_hasher.cpp:103-106
+        if (host_) return host_->finalize();
         char hex[65];
         check(vt_->stream_finalize(vt_->self, stream_, hex), "Failed to finalize SHA256");
         return std::string(hex, 64);
     }
-    // sha256_hasher.cpp:111-150.  The reference streams 64 KiB reads through update(); a device has
-    // nothing to gain from a launch per read, so the file is read whole and hashed with ONE upload
-    // and ONE kernel (content_hash_v1.hash).  A single SHA-256 chain is sequential by definition: one
-    // file at a time is a job for the host's hasher — the device pays off on batches (hashMany,
-    // hashFiles, chunker_v1, yams_ingest_device); see INTEGRATION.md.
+    // sha256_hasher.cpp:111-150: reads until EOF (not until file_size(): growing and special files hash as the
+    // reference hashes them) in bounded pieces through update(); progress after every read (:136-138).
     std::string hashFile(const std::filesystem::path& path) override {
+        if (host_) { host_->setProgressCallback(progress_); return host_->hashFile(path); }
         std::ifstream file(path, std::ios::binary);
         if (!file) throw std::runtime_error("Failed to open file: " + path.string());
-        const uint64_t fileSize = std::filesystem::file_size(path);
-        std::vector<std::byte> data(static_cast<size_t>(fileSize));
+        std::error_code ec;
+        const uint64_t fileSize = std::filesystem::file_size(path, ec); // for the progress callback only
+        init();
+        std::vector<std::byte> buf(size_t(1) << 20);
         uint64_t processed = 0;
-        while (file && processed < fileSize) {
-            const size_t want = static_cast<size_t>(std::min<uint64_t>(fileSize - processed, 64u << 10)); // the reference's read size (:120)
-            file.read(reinterpret_cast<char*>(data.data() + processed), static_cast<std::streamsize>(want));
-            const auto n = file.gcount();
-            if (n <= 0) break;
-            processed += static_cast<uint64_t>(n);
-            if (progress_) progress_(processed, fileSize); // sha256_hasher.cpp:136-138
+        while (file.read(reinterpret_cast<char*>(buf.data()), static_cast<std::streamsize>(buf.size())) || file.gcount() > 0) {
+            const auto n = static_cast<size_t>(file.gcount());
+            update(std::span<const std::byte>(buf.data(), n));
+            processed += n;
+            if (progress_) progress_(processed, ec ? processed : fileSize);
         }
-        data.resize(static_cast<size_t>(processed));
-        return hash(std::span<const std::byte>(data.data(), data.size()));
+        return finalize();
     }
-    // Many files per call: read them all, one device call for all digests.
-    std::vector<std::string> hashFiles(const std::vector<std::filesystem::path>& paths) {
-        std::vector<std::vector<std::byte>> bufs(paths.size());
-        std::vector<std::span<const std::byte>> spans;
-        for (size_t i = 0; i < paths.size(); ++i) {
-            std::ifstream file(paths[i], std::ios::binary);
-            if (!file) throw std::runtime_error("Failed to open file: " + paths[i].string());
-            bufs[i].resize(static_cast<size_t>(std::filesystem::file_size(paths[i])));
-            file.read(reinterpret_cast<char*>(bufs[i].data()), static_cast<std::streamsize>(bufs[i].size()));
-            bufs[i].resize(static_cast<size_t>(file.gcount()));
-            spans.emplace_back(bufs[i].data(), bufs[i].size());
+    // Many files per call: groups of at most ~maxBytes are read and hashed with ONE device call each; a group the
+    // device refuses (a lone long chain in it) goes through hash() file by file.
+    std::vector<std::string> hashFiles(const std::vector<std::filesystem::path>& paths, size_t maxBytes = size_t(1) << 30) {
+        std::vector<std::string> out;
+        size_t i = 0;
+        while (i < paths.size()) {
+            std::vector<std::vector<std::byte>> bufs;
+            size_t bytes = 0;
+            while (i < paths.size() && (bufs.empty() || bytes < maxBytes)) {
+                std::ifstream file(paths[i], std::ios::binary);
+                if (!file) throw std::runtime_error("Failed to open file: " + paths[i].string());
+                std::vector<std::byte> data;
+                char block[64 << 10];
+                while (file.read(block, sizeof block) || file.gcount() > 0)
+                    data.insert(data.end(), reinterpret_cast<std::byte*>(block), reinterpret_cast<std::byte*>(block) + file.gcount());
+                bytes += data.size();
+                bufs.push_back(std::move(data));
+                ++i;
+            }
+            std::vector<std::span<const std::byte>> spans;
+            for (auto& b : bufs) spans.emplace_back(b.data(), b.size());
+            for (auto& h : hashMany(spans)) out.push_back(std::move(h));
         }
-        return hashMany(spans);
+        return out;
     }
     // sha256_hasher.cpp:152-161: any failure becomes ErrorCode::FileNotFound
     std::future<Result<std::string>> hashFileAsync(const std::filesystem::path& path) override {
@@ -103,11 +124,13 @@ public:
         });
     }
     void setProgressCallback(ProgressCallback callback) override { progress_ = std::move(callback); }
-    // SHA256Hasher::hash(span) one-shot, sha256_hasher.cpp:167-195
+    // SHA256Hasher::hash(span) one-shot, sha256_hasher.cpp:167-195.  Short messages: one device call.  A long lone
+    // chain is refused by the device (YAMS_ERR_UNSUPPORTED): the host's hasher takes it, else the streaming door.
     std::string hash(std::span<const std::byte> data) {
         char hex[65];
-        check(vt_->hash(vt_->self, reinterpret_cast<const uint8_t*>(data.data()), data.size(), hex),
-              "Failed to hash");
+        const yams_status_t st = vt_->hash(vt_->self, reinterpret_cast<const uint8_t*>(data.data()), data.size(), hex);
+        if (st == YAMS_ERR_UNSUPPORTED) return oneChain(data);
+        check(st, "Failed to hash");
         return std::string(hex, 64);
     }
     // Many buffers per call — the shape that suits a GPU (one message per lane).
@@ -115,23 +138,44 @@ public:
         std::vector<const uint8_t*> ptrs; std::vector<size_t> lens;
         for (auto& m : msgs) { ptrs.push_back(reinterpret_cast<const uint8_t*>(m.data())); lens.push_back(m.size()); }
         std::vector<char> hex(msgs.size() * 65);
-        check(vt_->hash_many(vt_->self, ptrs.data(), lens.data(), msgs.size(), hex.data()), "Failed to hash batch");
+        const yams_status_t st = vt_->hash_many(vt_->self, ptrs.data(), lens.data(), msgs.size(), hex.data());
         std::vector<std::string> out;
+        if (st == YAMS_ERR_UNSUPPORTED) { // a batch dominated by one long chain: every message on its own
+            for (auto& m : msgs) out.push_back(hash(m));
+            return out;
+        }
+        check(st, "Failed to hash batch");
         for (size_t i = 0; i < msgs.size(); ++i) out.emplace_back(hex.data() + 65 * i, 64);
         return out;
     }
+    bool hasHostHasher() const { return host_ != nullptr; }
 private:
+    std::string oneChain(std::span<const std::byte> data) {
+        if (host_) { host_->init(); host_->update(data); return host_->finalize(); }
+        // no host hasher: a private stream on the device (the handle of init/update/finalize stays untouched)
+        void* st = nullptr;
+        check(vt_->stream_create(vt_->self, &st), "Failed to create SHA256 stream on the accelerator");
+        char hex[65];
+        yams_status_t rc = vt_->stream_update(vt_->self, st, reinterpret_cast<const uint8_t*>(data.data()), data.size());
+        if (rc == YAMS_OK) rc = vt_->stream_finalize(vt_->self, st, hex);
+        vt_->stream_destroy(vt_->self, st);
+        check(rc, "Failed to hash");
+        return std::string(hex, 64);
+    }
     static void check(yams_status_t st, const char* what) { if (st != YAMS_OK) throw std::runtime_error(what); }
     std::shared_ptr<accel::Plugin> plugin_;
     yams_content_hash_v1* vt_;
+    std::unique_ptr<IContentHasher> host_;
     void* stream_ = nullptr;
     ProgressCallback progress_;
 };
 
-inline Result<std::unique_ptr<AccelSHA256Hasher>> createAccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin) {
+// hostHasher: the host's own IContentHasher (e.g. crypto::createSHA256Hasher()) for single chains; may be null.
+inline Result<std::unique_ptr<AccelSHA256Hasher>> createAccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin,
+                                                                          std::unique_ptr<IContentHasher> hostHasher = nullptr) {
     auto vt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, YAMS_IFACE_CONTENT_HASH_V1_VERSION);
     if (!vt) return vt.error();
-    return std::make_unique<AccelSHA256Hasher>(std::move(plugin), vt.value());
+    return std::make_unique<AccelSHA256Hasher>(std::move(plugin), vt.value(), std::move(hostHasher));
 }
 
 } // namespace yams::crypto

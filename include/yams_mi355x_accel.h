@@ -552,7 +552,8 @@ YAMS_ACCEL_API yams_status_t yams_dedup_probe_host(yams_dedup_set* set, const ui
 #define YAMS_IFACE_CONTENT_HASH_V1 "content_hash_v1"
 #define YAMS_IFACE_CONTENT_HASH_V1_VERSION 1u
 #define YAMS_IFACE_CHUNKER_V1 "chunker_v1"
-#define YAMS_IFACE_CHUNKER_V1_VERSION 1u
+#define YAMS_IFACE_CHUNKER_V1_VERSION 2u /* 2: chunk_many / free_chunk_batch appended (hosts that asked for 1 see the
+                                           same leading fields) */
 
 /* The YAMS plugin entry points (include/yams/plugins/abi.h:18-34 in the reference; the declarations
  * are identical, so this header and the reference's can be included together). */
@@ -622,10 +623,23 @@ typedef struct yams_vector_scan_v1 {
                                      uint32_t** out_counts, yams_scan_diag_t* out_diag);
 } yams_vector_scan_v1;
 
+/* WHAT THE DEVICE IS WORSE AT IS REFUSED, NOT SERVED SLOWLY.  SHA-256 of one message is one sequential chain: a
+ * GPU lane advances it at ~35 MB/s, a host core with SHA-NI at > 1 GB/s.  The device wins only with many
+ * chains in flight.  So:
+ *   - hash() of more than YAMS_HASH_LONE_CHAIN_MAX bytes returns YAMS_ERR_UNSUPPORTED;
+ *   - hash_many() / verify_many() return YAMS_ERR_UNSUPPORTED when the call cannot finish before ONE host core
+ *     would: longest message > max(YAMS_HASH_LONE_CHAIN_MAX, total bytes / YAMS_HASH_CHAIN_RATIO);
+ * and the host hashes those with its own SHA256Hasher — the reference's convention for optional features
+ * (abi_model_provider_adapter.cpp:121-122,159-170; UNSUPPORTED -> ErrorCode::NotImplemented, :528-552).
+ * AccelSHA256Hasher (include/yams_accel/hasher.hpp) takes the host's hasher for exactly that.  The stream_*
+ * functions are a compatibility door for hosts without one: correct, never fast. */
+#define YAMS_HASH_LONE_CHAIN_MAX (1u << 20)
+#define YAMS_HASH_CHAIN_RATIO 37u /* ~ 1.3 GB/s per host core / 35 MB/s per device chain */
 typedef struct yams_content_hash_v1 {
     uint32_t abi_version; /* YAMS_IFACE_CONTENT_HASH_V1_VERSION */
     void* self;
-    /* IContentHasher::hash one-shot: 64 hex chars + NUL into out_hex. */
+    /* IContentHasher::hash one-shot: 64 hex chars + NUL into out_hex.  More than YAMS_HASH_LONE_CHAIN_MAX bytes:
+     * YAMS_ERR_UNSUPPORTED (see above). */
     yams_status_t (*hash)(void* self, const uint8_t* data, size_t n, char out_hex[65]);
     /* Many messages per call (what makes a GPU worthwhile). */
     yams_status_t (*hash_many)(void* self, const uint8_t* const* msgs, const size_t* lens,
@@ -663,6 +677,17 @@ typedef struct yams_chunk_ref_s { /* ChunkRef, chunker.h:32-41 (hash as hex) */
     char pad[7];
 } yams_chunk_ref_t;
 
+/* Result of chunk_many: the chunk tables of all buffers back to back. */
+typedef struct yams_chunk_batch_s {
+    size_t n_buffers;
+    size_t n_chunks;
+    size_t* first_chunk;       /* [n_buffers + 1]: buffer b owns chunks[first_chunk[b] .. first_chunk[b + 1])     */
+    yams_chunk_ref_t* chunks;  /* [n_chunks]: offset within its buffer, size, SHA-256 of the chunk (hex)          */
+    char* buffer_hash_hex;     /* [n_buffers][65]: SHA-256 of each whole buffer (the file hash of
+                                  ContentStore::store, content_store_impl.cpp:199-231), or NULL if not asked for  */
+} yams_chunk_batch_t;
+#define YAMS_CHUNK_MANY_BUFFER_HASHES 1u
+
 typedef struct yams_chunker_v1 {
     uint32_t abi_version; /* YAMS_IFACE_CHUNKER_V1_VERSION */
     void* self;
@@ -672,6 +697,15 @@ typedef struct yams_chunker_v1 {
                                 const yams_cdc_config_t* cfg, yams_chunk_ref_t** out_chunks,
                                 size_t* out_count);
     void (*free_chunks)(void* self, yams_chunk_ref_t* chunks, size_t count);
+    /* ---- version 2 (NULL in older builds: "not implemented", abi_model_provider_adapter.cpp:121-122) --------
+     * MANY buffers per call — the shape that lets the device run at its ingest rate (yams_ingest_host: uploads
+     * of batch i + 1 under the kernels of batch i; ~500 GB/s device-resident, PCIe-bound from host memory)
+     * instead of one launch sequence per file: boundaries + per-chunk SHA-256 of every buffer and, with
+     * YAMS_CHUNK_MANY_BUFFER_HASHES, the whole-buffer digests — everything ContentStore::store needs for a
+     * batch of files (content_store_impl.cpp:199-231) in one call.  Release with free_chunk_batch. */
+    yams_status_t (*chunk_many)(void* self, const uint8_t* const* buffers, const size_t* lens, size_t n_buffers,
+                                const yams_cdc_config_t* cfg, uint32_t flags, yams_chunk_batch_t** out_batch);
+    void (*free_chunk_batch)(void* self, yams_chunk_batch_t* batch);
 } yams_chunker_v1;
 
 #ifdef __cplusplus

@@ -89,6 +89,62 @@ int main(int argc, char** argv) {
         CHECK(!bad.has_value() && bad.error().code == ErrorCode::FileNotFound);   // sha256_hasher.cpp:152-161
         std::filesystem::remove(path);
     }
+    // ---- lone long chains are the HOST's: the vtable refuses them, the adapter hands them to the host's hasher ----
+    {
+        auto vt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, YAMS_IFACE_CONTENT_HASH_V1_VERSION);
+        CHECK(vt.has_value());
+        std::mt19937 rng(5);
+        std::vector<std::byte> big(3 << 20), small(4096);
+        for (auto& b : big) b = static_cast<std::byte>(rng());
+        for (auto& b : small) b = static_cast<std::byte>(rng());
+        char hex[65];
+        CHECK(vt.value()->hash(vt.value()->self, reinterpret_cast<const uint8_t*>(big.data()), big.size(), hex) == YAMS_ERR_UNSUPPORTED);
+        CHECK(vt.value()->hash(vt.value()->self, reinterpret_cast<const uint8_t*>(small.data()), small.size(), hex) == YAMS_OK);
+        // one 3 MiB message among a few small ones: the call could not finish before one host core would -> refused;
+        // among 4096 small ones (16 MiB in total... still dominated) -> refused; 200 x 1 MiB: served
+        {
+            std::vector<const uint8_t*> ptrs{reinterpret_cast<const uint8_t*>(big.data())};
+            std::vector<size_t> lens{big.size()};
+            for (int i = 0; i < 8; ++i) { ptrs.push_back(reinterpret_cast<const uint8_t*>(small.data())); lens.push_back(small.size()); }
+            std::vector<char> out(ptrs.size() * 65);
+            CHECK(vt.value()->hash_many(vt.value()->self, ptrs.data(), lens.data(), ptrs.size(), out.data()) == YAMS_ERR_UNSUPPORTED);
+            ptrs.clear(); lens.clear();
+            for (int i = 0; i < 200; ++i) { ptrs.push_back(reinterpret_cast<const uint8_t*>(big.data()) + (i % 3) * 1000); lens.push_back(1 << 20); }
+            out.resize(ptrs.size() * 65);
+            CHECK(vt.value()->hash_many(vt.value()->self, ptrs.data(), lens.data(), ptrs.size(), out.data()) == YAMS_OK);
+            CHECK(std::string(out.data(), 64) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big.data(), size_t(1) << 20)));
+        }
+        auto made = crypto::createAccelSHA256Hasher(plugin, std::make_unique<crypto::SHA256Hasher>());
+        CHECK(made.has_value() && made.value()->hasHostHasher());
+        auto& acc = *made.value();
+        CHECK(acc.hash(big) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));       // host chain
+        CHECK(acc.hash(small) == crypto::SHA256Hasher::hash(std::span<const std::byte>(small)));   // device
+        acc.init(); acc.update({big.data(), 1000}); acc.update({big.data() + 1000, big.size() - 1000});
+        CHECK(acc.finalize() == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+        // hashMany: a skewed batch (refused as a whole) falls apart into single chains; a regular batch is one device call
+        std::vector<std::span<const std::byte>> skew{{big.data(), big.size()}, {small.data(), small.size()}, {small.data(), 0}};
+        auto hs = acc.hashMany(skew);
+        CHECK(hs.size() == 3 && hs[0] == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)) &&
+              hs[1] == crypto::SHA256Hasher::hash(std::span<const std::byte>(small)) &&
+              hs[2] == crypto::SHA256Hasher::hash(std::span<const std::byte>(small.data(), 0)));
+        // hashFiles: bounded groups, read until EOF
+        std::vector<std::filesystem::path> paths;
+        std::vector<std::string> want;
+        for (int i = 0; i < 12; ++i) {
+            const auto pth = std::filesystem::temp_directory_path() / ("yams_accel_files_" + std::to_string(i) + ".bin");
+            const size_t n = i == 0 ? 0 : (size_t(1) << (8 + i)) + i * 37;
+            { std::ofstream f(pth, std::ios::binary); f.write(reinterpret_cast<const char*>(big.data()) + i * 101, n); }
+            paths.push_back(pth);
+            want.push_back(crypto::SHA256Hasher::hash(std::span<const std::byte>(big.data() + i * 101, n)));
+        }
+        CHECK(acc.hashFiles(paths, /*maxBytes=*/300000) == want);
+        // ... and without a host hasher the same calls go through the plugin's streaming door
+        auto bare = crypto::createAccelSHA256Hasher(plugin);
+        CHECK(bare.has_value() && !bare.value()->hasHostHasher());
+        CHECK(bare.value()->hash(big) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+        CHECK(bare.value()->hashFiles(paths) == want);
+        for (auto& pth : paths) std::filesystem::remove(pth);
+    }
 
     // ---- IChunker: both chunkers next to the reference's ---------------------------------------------------
     for (int kind = 0; kind < 2; ++kind) {
@@ -113,6 +169,27 @@ int main(int argc, char** argv) {
                 CHECK(lazy[i].data.empty() && lazy[i].hash == r[i].hash && lazy[i].offset == r[i].offset && lazy[i].size == r[i].size);
         }
         CHECK(acc->getConfig().minChunkSize == 2048 && acc->getConfig().chunkMask == 0x1FFF);
+        // chunk_many: a batch of buffers in ONE device call — chunk tables, chunk hashes and whole-buffer hashes
+        auto batcher = chunking::createAccelBatchChunker(plugin, kind ? chunking::AccelChunkerKind::Streaming : chunking::AccelChunkerKind::Rabin, cfg);
+        CHECK(batcher.has_value());
+        std::vector<std::span<const std::byte>> bufs;
+        for (size_t n : {size_t(100000), size_t(0), size_t(47), size_t(2048), size_t(2049), data.size(), size_t(65537), size_t(1)})
+            bufs.emplace_back(data.data() + (n % 977), n);
+        for (bool lazy : {true, false}) {
+            auto res = batcher.value()->chunkMany(bufs, /*withBufferHashes=*/true, lazy);
+            CHECK(res.chunks.size() == bufs.size() && res.bufferHashes.size() == bufs.size());
+            for (size_t b = 0; b < bufs.size(); ++b) {
+                auto r = ref->chunkData(bufs[b]);
+                CHECK(res.chunks[b].size() == r.size());
+                for (size_t i = 0; i < r.size() && i < res.chunks[b].size(); ++i) {
+                    const auto& c = res.chunks[b][i];
+                    CHECK(c.hash == r[i].hash && c.offset == r[i].offset && c.size == r[i].size);
+                    CHECK(lazy ? c.data.empty() : c.data == r[i].data);
+                }
+                CHECK(res.bufferHashes[b] == crypto::SHA256Hasher::hash(bufs[b]));
+            }
+        }
+        CHECK(batcher.value()->chunkMany({}, true).chunks.empty());
     }
 
     // ---- IVectorStore + capability seams ---------------------------------------------------------------------

@@ -385,6 +385,71 @@ def test_chunker_vtable(accel_lib, oracle):
         assert (chunks[i].offset, chunks[i].size) == (int(ooff[i]), int(osz[i]))
         assert chunks[i].hash_hex.decode() == hashlib.sha256(data[int(ooff[i]):int(ooff[i] + osz[i])].tobytes()).hexdigest()
     vt.free_chunks(None, chunks, n)
+    # chunk_many (version 2): a batch of buffers in ONE device call — the batched ingest path behind the plugin door
+    rng = np.random.default_rng(48)
+    bufs = [rng.integers(0, 256, n_, dtype=np.uint8) for n_ in (300000, 0, 47, 2048, 2049, 1 << 20, 1, 70001)]
+    bufs[3][:] = 0                                        # a constant buffer: no candidates, forced cuts only
+    ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * len(bufs))(*[b.size for b in bufs])
+    for flags in (0, _lib.CHUNK_MANY_BUFFER_HASHES):
+        batch = C.POINTER(_lib.ChunkBatch)()
+        assert vt.chunk_many(None, ptrs, lens, len(bufs), C.byref(cfg), flags, C.byref(batch)) == 0
+        bt = batch.contents
+        assert bt.n_buffers == len(bufs) and bt.first_chunk[0] == 0 and bt.first_chunk[len(bufs)] == bt.n_chunks
+        assert bool(bt.buffer_hash_hex) == bool(flags)
+        for b, data_b in enumerate(bufs):
+            ooff, osz = oracle.chunks(data_b, "streaming", min_size=2048, max_size=16384)
+            lo, hi = bt.first_chunk[b], bt.first_chunk[b + 1]
+            assert hi - lo == len(ooff), (b, hi - lo, len(ooff))
+            for i in range(len(ooff)):
+                ch = bt.chunks[lo + i]
+                assert (ch.offset, ch.size) == (int(ooff[i]), int(osz[i]))
+                if i % 7 == 0 or i == len(ooff) - 1:
+                    assert ch.hash_hex.decode() == hashlib.sha256(data_b[int(ooff[i]):int(ooff[i] + osz[i])].tobytes()).hexdigest()
+            if flags:
+                assert C.string_at(C.addressof(bt.buffer_hash_hex.contents) + 65 * b).decode() == hashlib.sha256(data_b.tobytes()).hexdigest()
+        vt.free_chunk_batch(None, batch)
+    batch = C.POINTER(_lib.ChunkBatch)()
+    assert vt.chunk_many(None, None, None, 0, C.byref(cfg), 1, C.byref(batch)) == 0 and batch.contents.n_chunks == 0
+    vt.free_chunk_batch(None, batch)
+    assert vt.chunk_many(None, ptrs, lens, len(bufs), None, 0, C.byref(batch)) == _lib.YAMS_ERR_INVALID_ARG
+    L.yams_plugin_shutdown()
+
+
+def test_content_hash_vtable_refuses_lone_long_chains(accel_lib):
+    """One SHA-256 chain runs at ~35 MB/s on a device lane and > 1 GB/s on a host core: hash() above
+    YAMS_HASH_LONE_CHAIN_MAX and batches dominated by one long message return YAMS_ERR_UNSUPPORTED (the host hashes
+    those itself, abi_model_provider_adapter.cpp:121-122); what the device is good at is served."""
+    L = accel_lib
+    assert L.yams_plugin_init(b"{}", None) == 0
+    p = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"content_hash_v1", 1, C.byref(p)) == 0
+    vt = C.cast(p, C.POINTER(_lib.ContentHashV1)).contents
+    rng = np.random.default_rng(49)
+    big = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    out = C.create_string_buffer(65)
+    assert vt.hash(None, big.ctypes.data_as(_lib.u8p), big.size, out) == _lib.YAMS_ERR_UNSUPPORTED
+    assert vt.hash(None, big.ctypes.data_as(_lib.u8p), _lib.HASH_LONE_CHAIN_MAX, out) == 0
+    assert out.value.decode() == hashlib.sha256(big[:_lib.HASH_LONE_CHAIN_MAX].tobytes()).hexdigest()
+    # 1 x 3 MiB + 8 x 4 KiB: refused; 150 x 1 MiB: served; 150 x 1 MiB + 1 x 3 MiB: served (3 MiB < 153 MiB / 37)
+    def many(sizes):
+        ptrs = (_lib.u8p * len(sizes))(*[C.cast(big.ctypes.data + (i * 4099) % 1000, _lib.u8p) for i in range(len(sizes))])
+        lens = (C.c_size_t * len(sizes))(*sizes)
+        hexes = C.create_string_buffer(65 * len(sizes))
+        st = vt.hash_many(None, ptrs, lens, len(sizes), hexes)
+        return st, [hexes.raw[65 * i:65 * i + 64].decode() for i in range(len(sizes))]
+    assert many([3 << 20] + [4096] * 8)[0] == _lib.YAMS_ERR_UNSUPPORTED
+    st, hx = many([1 << 20] * 150 + [3 << 20])
+    assert st == 0
+    for i in (0, 77, 150):
+        o = (i * 4099) % 1000
+        n_ = (1 << 20) if i < 150 else (3 << 20)
+        assert hx[i] == hashlib.sha256(big[o:o + n_].tobytes()).hexdigest()
+    hp = C.c_void_p()
+    assert L.yams_plugin_get_health_json(C.byref(hp)) == 0
+    import json
+    assert json.loads(C.string_at(hp))["refused_lone_chains"] >= 2
+    C.CDLL(None).free(hp)
     L.yams_plugin_shutdown()
 
 

@@ -190,7 +190,8 @@ def test_empty_and_degenerate(acc):
     (100, 3, 2, 7, SCAN_COSINE, -1.0),            # dim not a multiple of 4 -> fp64 path
     (3000, 64, 5, 10, SCAN_COSINE, 0.0),
     (3000, 384, 3, 100, SCAN_L2, -1.0),
-    (4096, 128, 9, 10, SCAN_COSINE, -1.0),        # smallest MFMA-path corpus
+    (4096, 128, 9, 10, SCAN_COSINE, -1.0),        # few queries on a small corpus: the fused one-launch path
+    (4096, 128, 19, 10, SCAN_COSINE, -1.0),       # smallest MFMA-path corpus (more than 16 queries)
     (5001, 100, 4, 20, SCAN_COSINE, -1.0),        # ragged tile + dim % 32 != 0
     (20000, 384, 37, 100, SCAN_COSINE, -1.0),
     (20000, 768, 130, 10, SCAN_L2, -1.0),
@@ -205,7 +206,8 @@ def test_empty_and_degenerate(acc):
 def test_parity_sweep(acc, oracle, n, d, nq, k, metric, thr):
     corpus = oracle.synth_rows(7, 0, n, d)
     queries = oracle.synth_rows(7, 1 << 40, nq, d)
-    path = 0 if (n >= 4096 and d % 4 == 0) else 1
+    fused = n <= 16384 and nq <= 16 and d % 32 == 0          # scan_small_kernel: one launch, every row in fp64
+    path = 0 if (n >= 4096 and d % 4 == 0 and not fused) else 1
     check(acc, oracle, corpus, queries, k, thr, metric, max_queries=24, expect_path=path)
 
 
@@ -615,6 +617,104 @@ def test_sharded_search_behind_one_c_call(oracle, n_shards, layout, metric):
     sh.close()
 
 
+@pytest.mark.parametrize("metric", [SCAN_COSINE, SCAN_L2])
+def test_small_corpus_runs_as_one_fused_launch(acc, oracle, metric):
+    """Corpora of at most 16384 rows with at most 16 queries (BASELINE config 1 and the reference's one-query calls,
+    search_vector_pipeline.cpp:221): scan_small_kernel scores every row in fp64 in the reference's order and reduces to
+    the final top-k in ONE launch.  Against the oracle bit for bit: 1 / 4 / 16 queries, ragged row counts around the
+    256-row workgroups, tie ranks, allow-masks, thresholds, a shard with a row base and with stripes, hostile rows,
+    the record path's zero-norm rule; and against the exhaustive multi-launch pipeline (FORCE_EXACT)."""
+    rng = np.random.default_rng(91)
+    for n, d, nq, k in [(10_000, 384, 1, 10), (10_000, 384, 16, 10), (257, 64, 3, 5), (1, 32, 1, 3), (255, 96, 2, 256),
+                        (16_384, 128, 4, 32), (5000, 768, 7, 100), (3000, 1024, 2, 17)]:
+        corpus = oracle.synth_rows(61, 0, n, d)
+        q = oracle.synth_rows(61, 1 << 40, nq, d)
+        if n > 600:
+            corpus[5] = corpus[n - 2] = corpus[n // 2]         # exact ties
+            q[0] = corpus[5]
+            corpus[7] = 0.0                                     # zero row: skipped by cosine, a valid L2 neighbour
+            corpus[9] = np.float32(3e38) / 4                    # +-FLT_MAX/4 (vector_smoke_catch2_test.cpp:263-302)
+            corpus[11, 3] = np.nan
+        thr = 0.02 if metric == SCAN_L2 else -1.0
+        rank = rng.permutation(n).astype(np.uint32)
+        inv = np.empty_like(rank); inv[rank] = np.arange(n, dtype=np.uint32)
+        dc, dr, di = acc.to_device(corpus), acc.to_device(rank), acc.to_device(inv)
+        for use_rank in (False, True):
+            view = acc.corpus_view(dc.ptr, n, d, dr.ptr if use_rank else None, di.ptr if use_rank else None, row_base=1000)
+            r = acc.scan_topk(view, q, k, thr, metric)
+            assert r.diag["path"] == 1 and r.diag["filter_tier"] == 0 and r.diag["rows_visited"] == nq * n
+            rk = rank.astype(np.uint64) if use_rank else None
+            for qi in range(nq):
+                if metric == SCAN_COSINE:
+                    rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, thr, rk)
+                    dist = None
+                else:
+                    rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, thr, rk)
+                c = int(r.counts[qi])
+                assert c == len(rows) and np.array_equal(r.rows[qi, :c], rows + 1000), (n, d, nq, k, qi, r.rows[qi, :6], rows[:6])
+                assert np.array_equal(r.scores[qi, :c].view(np.uint32), sims.view(np.uint32))
+                if dist is not None:
+                    assert np.array_equal(r.dist[qi, :c].view(np.uint32), dist.view(np.uint32))
+                else:
+                    assert np.array_equal(r.dist[qi, :c], np.float32(1.0) - r.scores[qi, :c])
+                assert (r.rows[qi, c:] == -1).all()
+            ex = acc.scan_topk(view, q, k, thr, metric, flags=FLAG_FORCE_EXACT)     # the multi-launch exhaustive pipeline
+            assert np.array_equal(ex.rows, r.rows) and np.array_equal(ex.counts, r.counts)
+            assert np.array_equal(ex.scores.view(np.uint32), r.scores.view(np.uint32))
+    # allow-masks (document_hash / candidate_hashes), dense and sparse, with tie ranks
+    n, d = 9000, 128
+    corpus = oracle.synth_rows(62, 0, n, d)
+    q = oracle.synth_rows(62, 1 << 40, 5, d)
+    rank = rng.permutation(n).astype(np.uint32)
+    for allowed in (np.sort(rng.choice(n, 6000, replace=False)), np.sort(rng.choice(n, 40, replace=False)), []):
+        r = _masked(acc, oracle, corpus, q, 12, allowed, metric, tie_rank=rank)
+        assert r.diag["path"] == 1
+    # a striped shard: local rows -> global ids
+    n, d = 8192 + 300, 64
+    corpus = oracle.synth_rows(63, 0, n, d)
+    q = oracle.synth_rows(63, 1 << 40, 2, d)
+    dc = acc.to_device(corpus)
+    view = acc.corpus_view(dc.ptr, n, d, row_base=7, stripe_rows=4096, n_stripes=3, stripe_index=1)
+    r = acc.scan_topk(view, q, 9, -1.0, metric)
+    for qi in range(2):
+        rows = (oracle.scan_cosine(corpus, q[qi], 9)[0] if metric == SCAN_COSINE else oracle.scan_l2(corpus, q[qi], 9, -1.0)[0])
+        glob = 7 + ((rows // 4096) * 3 + 1) * 4096 + rows % 4096
+        assert np.array_equal(r.rows[qi], glob)
+    # invalid queries: the batch fails as a whole (:4127-4130); a zero query is invalid for cosine only
+    bad = q.copy(); bad[1, 5] = np.inf
+    with pytest.raises(_lib.AccelError) as e:
+        acc.scan_topk(view, bad, 9, -1.0, metric)
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    zq = q.copy(); zq[0] = 0.0
+    if metric == SCAN_COSINE:
+        with pytest.raises(_lib.AccelError):
+            acc.scan_topk(view, zq, 9, -1.0, metric)
+    else:
+        assert acc.scan_topk(view, zq, 9, -1.0, metric).counts[0] == 9
+    # and the handle is fine afterwards (the ticket counters were left at zero)
+    assert acc.scan_topk(view, q, 9, -1.0, metric).counts.tolist() == [9, 9]
+
+
+def test_small_corpus_record_path_zero_norm_rule(acc, oracle):
+    """YAMS_SCAN_FLAG_RECORD_PATH on the fused path: rows with norm^2 in [1e-12, 1e-10) are dropped (:204-211)."""
+    n, d = 4000, 64
+    corpus = oracle.synth_rows(64, 0, n, d)
+    q = oracle.synth_rows(64, 1 << 40, 3, d)
+    qu = q / np.linalg.norm(q, axis=1, keepdims=True)
+    for i in range(3):
+        corpus[100 + i] = (qu[i] * 5e-6).astype(np.float32)      # norm^2 = 2.5e-11, cosine 1.0 with query i
+    dc = acc.to_device(corpus)
+    view = acc.corpus_view(dc.ptr, n, d)
+    fast = acc.scan_topk(view, q, 5, -1.0, SCAN_COSINE)
+    rec = acc.scan_topk(view, q, 5, -1.0, SCAN_COSINE, flags=_lib.FLAG_RECORD_PATH)
+    assert fast.diag["path"] == 1 and rec.diag["path"] == 1
+    allow = np.ones(n, np.uint8)
+    for qi in range(3):
+        assert fast.rows[qi, 0] == 100 + qi and rec.rows[qi, 0] != 100 + qi
+        rows, sims = oracle.scan_cosine_records(corpus, q[qi], 5, -1.0, None, allow)[:2]
+        assert np.array_equal(rec.rows[qi], rows) and np.array_equal(rec.scores[qi].view(np.uint32), sims.view(np.uint32))
+
+
 def _one_shard_views(sh, oracle, corpus, d, parts):
     """Uploads `corpus` as len(parts) contiguous shards through the handle's contexts (int8 + bf16 shadows)."""
     keep, views = [], []
@@ -834,9 +934,10 @@ def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle)
     corpus = oracle.mt19937_rows(42, 0, n, d)
     queries = oracle.mt19937_rows(42, n, nq, d)
     for qi in range(nq):
-        r = check(acc, oracle, corpus, queries[qi], k, thr=0.0, expect_path=0)   # the reference bench passes 0.0
+        r = check(acc, oracle, corpus, queries[qi], k, thr=0.0, expect_path=1)   # the reference bench passes 0.0; one fused launch
         assert r.counts[0] == k and r.diag["exact_fallback_queries"] == 0
-    check(acc, oracle, corpus, queries, k, thr=-1.0, expect_path=0)
+    check(acc, oracle, corpus, queries, k, thr=-1.0, expect_path=1)
+    check(acc, oracle, corpus, queries, k, thr=-1.0, flags=_lib.FLAG_NO_I8_FILTER, expect_path=0)   # the MFMA filter pipeline on the same shape
     check(acc, oracle, corpus, queries[:1], k, thr=-1.0, flags=FLAG_FORCE_EXACT, expect_path=1)
 
 
@@ -845,7 +946,7 @@ def test_config1_10kx384_cosine_top10_single_query_reference_recipe(acc, oracle)
 @pytest.mark.parametrize("n,d,nq,k,thr", [
     (20000, 256, 1, 10, -1.0), (20007, 320, 5, 50, 0.1), (50000, 256, 130, 100, -1.0),
     (70001, 256, 300, 50, -1.0), (33333, 768, 40, 100, 0.05), (150000, 384, 260, 100, -1.0),
-    (9000, 1024, 7, 20, -1.0), (4096, 448, 3, 200, -1.0), (30011, 1536, 33, 10, -1.0),
+    (9000, 1024, 17, 20, -1.0), (4096, 448, 3, 300, -1.0), (30011, 1536, 33, 10, -1.0),
 ])
 def test_int8_tier_matches_the_oracle(acc, oracle, n, d, nq, k, thr):
     """The int8 tier (v_mfma_i32_32x32x32_i8 over the int8 shadow; filter score = a rigorous upper

@@ -148,6 +148,15 @@ class ContentHashV1(C.Structure):
     ]
 
 
+class ChunkBatch(C.Structure):
+    _fields_ = [("n_buffers", C.c_size_t), ("n_chunks", C.c_size_t), ("first_chunk", C.POINTER(C.c_size_t)),
+                ("chunks", C.POINTER(ChunkRef)), ("buffer_hash_hex", C.POINTER(C.c_char))]
+
+
+CHUNK_MANY_BUFFER_HASHES = 1
+HASH_LONE_CHAIN_MAX = 1 << 20
+
+
 class ChunkerV1(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("self", vp),
@@ -155,6 +164,9 @@ class ChunkerV1(C.Structure):
         ("chunk_data", C.CFUNCTYPE(ST, vp, u8p, C.c_size_t, C.POINTER(CdcConfig),
                                    C.POINTER(C.POINTER(ChunkRef)), C.POINTER(C.c_size_t))),
         ("free_chunks", C.CFUNCTYPE(None, vp, C.POINTER(ChunkRef), C.c_size_t)),
+        ("chunk_many", C.CFUNCTYPE(ST, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(CdcConfig), C.c_uint32,
+                                   C.POINTER(C.POINTER(ChunkBatch)))),
+        ("free_chunk_batch", C.CFUNCTYPE(None, vp, C.POINTER(ChunkBatch))),
     ]
 
 

@@ -293,7 +293,7 @@ struct PluginState {
     std::mutex corpora_mu;
     std::map<uint64_t, std::shared_ptr<Corpus>> corpora;
     uint64_t next_id = 1;
-    std::atomic<uint64_t> searches{0}, hashes{0}, chunk_calls{0};
+    std::atomic<uint64_t> searches{0}, hashes{0}, chunk_calls{0}, refused_chains{0};
 };
 PluginState g;
 
@@ -301,7 +301,7 @@ const char kManifest[] =
     "{\"name\":\"yams_mi355x_accel\",\"version\":\"" YAMS_ACCEL_VERSION_STRING "\",\"abi\":1,"
     "\"description\":\"MI355X (gfx950) exact vector scan, SHA-256 and content-defined chunking\","
     "\"interfaces\":[{\"id\":\"vector_scan_v1\",\"version\":1},"
-    "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":1}]}";
+    "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":2}]}";
 
 // Minimal readers for the init config: {"device": 0} | {"devices": [0,1,...], "search_slots": 2,
 // "shadows": "both" | "bf16" | "i8" | "none"}
@@ -641,14 +641,23 @@ yams_vector_scan_v1 g_vector_scan = {
 // ---- content_hash_v1 --------------------------------------------------------------------------
 // Every call leases one of the plugin's work contexts (own stream, own workspace), so hashing, chunking
 // and searches of different host threads overlap on the device instead of queueing on one mutex.
+// One SHA-256 chain is sequential: ~35 MB/s on a device lane, > 1 GB/s on a host core.  Work the device is worse
+// at is refused (YAMS_ERR_UNSUPPORTED: the host hashes it itself), not served slowly — see the header.
+bool chains_suit_the_device(const size_t* lens, size_t n) {
+    size_t longest = 0, total = 0;
+    for (size_t i = 0; i < n; ++i) { longest = std::max(longest, lens[i]); total += lens[i]; }
+    return longest <= std::max<size_t>(YAMS_HASH_LONE_CHAIN_MAX, total / YAMS_HASH_CHAIN_RATIO);
+}
 yams_status_t ch_hash(void*, const uint8_t* data, size_t n, char out_hex[65]) {
     NEED_INIT();
+    if (n > YAMS_HASH_LONE_CHAIN_MAX) { ++g.refused_chains; return YAMS_ERR_UNSUPPORTED; }
     Lease<yams_accel_ctx*> w(g.work_ctx);
     ++g.hashes;
     return yams_sha256_host(w.v, data, n, out_hex);
 }
 yams_status_t ch_hash_many(void*, const uint8_t* const* msgs, const size_t* lens, size_t n, char* out_hex) {
     NEED_INIT();
+    if (n && lens && !chains_suit_the_device(lens, n)) { ++g.refused_chains; return YAMS_ERR_UNSUPPORTED; }
     Lease<yams_accel_ctx*> w(g.work_ctx);
     g.hashes += n;
     return yams_sha256_many_host(w.v, msgs, lens, n, out_hex);
@@ -789,6 +798,7 @@ yams_status_t ch_verify_many(void*, const uint8_t* const* msgs, const size_t* le
                              size_t n, uint8_t* out_valid) {
     if (n == 0) return YAMS_OK;
     if (!msgs || !lens || !expected_hex || !out_valid) return YAMS_ERR_INVALID_ARG;
+    if (!chains_suit_the_device(lens, n)) { ++g.refused_chains; return YAMS_ERR_UNSUPPORTED; }
     std::vector<char> hex(n * 65);
     {
         NEED_INIT();
@@ -915,8 +925,59 @@ yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc
 }
 void ck_free_chunks(void*, yams_chunk_ref_t* chunks, size_t) { std::free(chunks); }
 
+void to_hex(const uint8_t* d, char out[65]) {
+    static const char kHexDigits[] = "0123456789abcdef";
+    for (int i = 0; i < 32; ++i) { out[2 * i] = kHexDigits[d[i] >> 4]; out[2 * i + 1] = kHexDigits[d[i] & 15]; }
+    out[64] = 0;
+}
+void ck_free_chunk_batch(void*, yams_chunk_batch_t* b) {
+    if (!b) return;
+    std::free(b->first_chunk); std::free(b->chunks); std::free(b->buffer_hash_hex); std::free(b);
+}
+// Many buffers per call: the batched ingest path (yams_ingest_host) behind the plugin door.
+yams_status_t ck_chunk_many(void*, const uint8_t* const* buffers, const size_t* lens, size_t n, const yams_cdc_config_t* cfg,
+                            uint32_t flags, yams_chunk_batch_t** out_batch) {
+    NEED_INIT();
+    if (!out_batch) return YAMS_ERR_INVALID_ARG;
+    *out_batch = nullptr;
+    if (!cfg || (n && (!buffers || !lens))) return YAMS_ERR_INVALID_ARG;
+    const bool want_blob = (flags & YAMS_CHUNK_MANY_BUFFER_HASHES) != 0;
+    const uint64_t floor = std::max<uint64_t>(1, cfg->min_size);
+    std::vector<uint64_t> len64(n);
+    uint64_t cap = 0;
+    for (size_t i = 0; i < n; ++i) { len64[i] = lens[i]; cap += lens[i] / floor + 2; }
+    std::vector<uint64_t> first(n + 1, 0), off(cap), sz(cap);
+    std::vector<uint8_t> dig(cap * 32), bdig(want_blob ? n * 32 : 0);
+    uint64_t cnt = 0;
+    if (n) {
+        Lease<yams_accel_ctx*> w(g.work_ctx);
+        const yams_status_t s = yams_ingest_host(w.v, buffers, len64.data(), n, cfg,
+                                                 YAMS_INGEST_CHUNK_DIGESTS | (want_blob ? YAMS_INGEST_BLOB_DIGESTS : 0u), 0,
+                                                 first.data(), off.data(), sz.data(), dig.data(), cap,
+                                                 want_blob ? bdig.data() : nullptr, &cnt);
+        if (s != YAMS_OK) return s;
+    }
+    auto* b = static_cast<yams_chunk_batch_t*>(std::calloc(1, sizeof(yams_chunk_batch_t)));
+    if (!b) return YAMS_ERR_INTERNAL;
+    b->n_buffers = n; b->n_chunks = static_cast<size_t>(cnt);
+    b->first_chunk = static_cast<size_t*>(std::calloc(n + 1, sizeof(size_t)));
+    b->chunks = static_cast<yams_chunk_ref_t*>(std::calloc(std::max<size_t>(b->n_chunks, 1), sizeof(yams_chunk_ref_t)));
+    b->buffer_hash_hex = want_blob ? static_cast<char*>(std::calloc(std::max<size_t>(n, 1), 65)) : nullptr;
+    if (!b->first_chunk || !b->chunks || (want_blob && !b->buffer_hash_hex)) { ck_free_chunk_batch(nullptr, b); return YAMS_ERR_INTERNAL; }
+    for (size_t i = 0; i <= n; ++i) b->first_chunk[i] = static_cast<size_t>(first[i]);
+    for (size_t i = 0; i < b->n_chunks; ++i) {
+        b->chunks[i].offset = off[i]; b->chunks[i].size = sz[i];
+        to_hex(dig.data() + 32 * i, b->chunks[i].hash_hex);
+    }
+    if (want_blob) for (size_t i = 0; i < n; ++i) to_hex(bdig.data() + 32 * i, b->buffer_hash_hex + 65 * i);
+    g.chunk_calls += n;
+    *out_batch = b;
+    return YAMS_OK;
+}
+
 yams_chunker_v1 g_chunker = {YAMS_IFACE_CHUNKER_V1_VERSION, nullptr, GUARDED(ck_default_config),
-                             GUARDED(ck_chunk_data), GUARDED(ck_free_chunks)};
+                             GUARDED(ck_chunk_data), GUARDED(ck_free_chunks), GUARDED(ck_chunk_many),
+                             GUARDED(ck_free_chunk_batch)};
 
 void teardown_locked() { // g.mu held exclusively
     {
@@ -1045,7 +1106,8 @@ static int plugin_health_impl(char** out_json) {
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
-       << ",\"chunk_calls\":" << g.chunk_calls.load();
+       << ",\"chunk_calls\":" << g.chunk_calls.load()
+       << ",\"refused_lone_chains\":" << g.refused_chains.load();
     if (g.sharded) { // how the shards exchange their records: "collective":"rccl" | "peer_copy" | "none" (one device)
         char* info = nullptr;
         if (yams_scan_sharded_info_json(g.sharded, &info) == YAMS_OK && info) { os << ",\"sharded\":" << info; std::free(info); }

@@ -122,6 +122,69 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
     return YAMS_OK;
 }
 
+// Small corpora and few queries (BASELINE config 1; the reference's most common call is ONE query,
+// search_vector_pipeline.cpp:221 -> sqlite_vec_backend.cpp:1436-1454): every row scored in fp64 in the reference's
+// order and reduced to the final top-k by ONE launch (scan_small_kernel.hip), one look at the query flags.
+constexpr uint64_t kSmallRows = 16384;
+constexpr uint32_t kSmallQueries = 16;
+bool small_scan_applies(const yams_scan_corpus_t& c, uint32_t nq, const yams_scan_params_t& p) {
+    if (c.n_rows == 0 || c.n_rows > kSmallRows || nq > kSmallQueries) return false;
+    // callers that name a filter tier or the exhaustive pipeline get what they name
+    if (p.flags & (YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER | YAMS_SCAN_FLAG_WIDE_TILE |
+                   YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_RESIDENT_QUERIES)) return false;
+    if ((c.dim & 31u) || c.dim > 1024 || (reinterpret_cast<uintptr_t>(c.rows) & 15u)) return false;
+    const uint32_t n_wg = static_cast<uint32_t>((c.n_rows + 255) / 256), kk = std::min<uint32_t>(p.k, 256);
+    return p.k <= 256 && static_cast<uint64_t>(n_wg) * kk <= 2048;
+}
+
+yams_status_t small_scan(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, const float* queries, uint32_t nq,
+                         const yams_scan_params_t* params, float* out_scores, int64_t* out_rows, uint32_t* out_counts,
+                         float* out_dist, uint32_t* out_ranks, yams_scan_diag_t* diag) {
+    hipStream_t st = ctx->stream;
+    const uint32_t n_wg = static_cast<uint32_t>((corpus->n_rows + 255) / 256), kk = std::min<uint32_t>(params->k, 256);
+    const uint32_t qb = nq == 1 ? 1 : 4;
+    SmallScanArgs a{};
+    a.rows = corpus->rows; a.n_rows = static_cast<uint32_t>(corpus->n_rows); a.dim = corpus->dim; a.queries = queries; a.nq = nq;
+    a.tie_rank = corpus->tie_rank; a.rank_row = corpus->rank_row; a.row_mask = corpus->row_mask; a.row_base = corpus->row_base;
+    a.stripe_rows = corpus->stripe_rows; a.n_stripes = corpus->n_stripes; a.stripe_index = corpus->stripe_index;
+    a.k = params->k; a.kk = kk; a.sort_cap = small_scan_sort_cap(n_wg, kk);
+    a.threshold = params->similarity_threshold; a.flags = params->flags;
+    a.out_scores = out_scores; a.out_rows = out_rows; a.out_counts = out_counts; a.out_dist = out_dist; a.out_ranks = out_ranks;
+    YA_TRY(ws_get(ctx, "small_keys", static_cast<size_t>(nq) * n_wg * kk * 8, (void**)&a.part_key));
+    YA_TRY(ws_get(ctx, "small_aux", static_cast<size_t>(nq) * n_wg * kk * 4, (void**)&a.part_aux));
+    YA_TRY(ws_get(ctx, "small_flags", static_cast<size_t>(nq) * 4, (void**)&a.qflags));
+    {   // the ticket counters are zero between launches (the kernel leaves them so): cleared when first allocated
+        const std::string name = ctx->ws_ns + "small_counter";
+        const bool fresh = ctx->bufs.find(name) == ctx->bufs.end();
+        YA_TRY(ws_get(ctx, "small_counter", 64, (void**)&a.counter));
+        if (fresh) YA_HIP(ctx, hipMemsetAsync(a.counter, 0, 64, st));
+    }
+    uint32_t* h_pin;
+    YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 8 + 64, (void**)&h_pin));
+    { TimedRegion tr(ctx, "small_scan");
+      YA_HIP(ctx, launch_small_scan(st, static_cast<int>(params->metric), a, qb));
+      tr.end(); }
+    YA_HIP(ctx, hipMemcpyAsync(h_pin, a.qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+    if (diag) YA_HIP(ctx, hipMemcpyAsync(h_pin + nq, out_counts, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+    YA_HIP(ctx, hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < nq; ++i) {
+        const bool bad = (params->metric == YAMS_SCAN_COSINE) ? (h_pin[i] != 0) : ((h_pin[i] & 1u) != 0);
+        if (bad) return fail(ctx, YAMS_ERR_INVALID_ARG, "Exact vector search requires a finite, non-zero query embedding");
+    }
+    if (diag) {
+        const uint64_t n_eff = corpus->row_mask ? corpus->row_mask_count : corpus->n_rows;
+        diag->used_exact_scan = 1; diag->rows_visited_observed = 1;
+        diag->rows_visited = static_cast<uint64_t>(nq) * n_eff;
+        diag->exact_distance_evaluations = static_cast<uint64_t>(nq) * n_eff;
+        uint64_t ret = 0;
+        for (uint32_t i = 0; i < nq; ++i) ret += h_pin[nq + i];
+        diag->returned_rows = ret;
+        diag->rescored_rows = static_cast<uint64_t>(nq) * n_eff; // every row was scored in fp64
+        diag->path = 1; diag->filter_tier = 0;
+    }
+    return YAMS_OK;
+}
+
 // split_only: this is the escalation run of a batch whose single-pass filter left queries unproven.
 yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, const float* queries,
                         uint32_t n_queries, const yams_scan_params_t* params, float* out_scores,
@@ -160,6 +223,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     if (corpus->stripe_rows && (corpus->n_stripes == 0 || corpus->stripe_index >= corpus->n_stripes))
         return fail(ctx, YAMS_ERR_INVALID_ARG, "striped shard needs stripe_index < n_stripes");
     (void)hipSetDevice(ctx->device);
+    if (!split_only && small_scan_applies(*corpus, n_queries, *params))
+        return small_scan(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts, out_dist, out_ranks, diag);
 
     const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
     const int metric = static_cast<int>(params->metric);
