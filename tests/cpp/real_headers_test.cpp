@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
             std::vector<char> out(ptrs.size() * 65);
             CHECK(vt.value()->hash_many(vt.value()->self, ptrs.data(), lens.data(), ptrs.size(), out.data()) == YAMS_ERR_UNSUPPORTED);
             ptrs.clear(); lens.clear();
-            for (int i = 0; i < 200; ++i) { ptrs.push_back(reinterpret_cast<const uint8_t*>(big.data()) + (i % 3) * 1000); lens.push_back(1 << 20); }
+            for (int i = 0; i < 200; ++i) { ptrs.push_back(reinterpret_cast<const uint8_t*>(big.data()) + (i % 3) * 1000); lens.push_back(1 << 20); } // (inside the 3 MiB)
             out.resize(ptrs.size() * 65);
             CHECK(vt.value()->hash_many(vt.value()->self, ptrs.data(), lens.data(), ptrs.size(), out.data()) == YAMS_OK);
             CHECK(std::string(out.data(), 64) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big.data(), size_t(1) << 20)));
@@ -173,8 +173,8 @@ int main(int argc, char** argv) {
         auto batcher = chunking::createAccelBatchChunker(plugin, kind ? chunking::AccelChunkerKind::Streaming : chunking::AccelChunkerKind::Rabin, cfg);
         CHECK(batcher.has_value());
         std::vector<std::span<const std::byte>> bufs;
-        for (size_t n : {size_t(100000), size_t(0), size_t(47), size_t(2048), size_t(2049), data.size(), size_t(65537), size_t(1)})
-            bufs.emplace_back(data.data() + (n % 977), n);
+        for (size_t n : {size_t(100000), size_t(0), size_t(47), size_t(2048), size_t(2049), data.size() - 1000, size_t(65537), size_t(1)})
+            bufs.emplace_back(data.data() + (n % 977), n);   // (unaligned starts, overlapping ranges of one array)
         for (bool lazy : {true, false}) {
             auto res = batcher.value()->chunkMany(bufs, /*withBufferHashes=*/true, lazy);
             CHECK(res.chunks.size() == bufs.size() && res.bufferHashes.size() == bufs.size());

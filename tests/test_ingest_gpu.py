@@ -431,19 +431,19 @@ def test_content_hash_vtable_refuses_lone_long_chains(accel_lib):
     assert vt.hash(None, big.ctypes.data_as(_lib.u8p), big.size, out) == _lib.YAMS_ERR_UNSUPPORTED
     assert vt.hash(None, big.ctypes.data_as(_lib.u8p), _lib.HASH_LONE_CHAIN_MAX, out) == 0
     assert out.value.decode() == hashlib.sha256(big[:_lib.HASH_LONE_CHAIN_MAX].tobytes()).hexdigest()
-    # 1 x 3 MiB + 8 x 4 KiB: refused; 150 x 1 MiB: served; 150 x 1 MiB + 1 x 3 MiB: served (3 MiB < 153 MiB / 37)
+    # 1 x 3 MiB + 8 x 4 KiB: refused; 150 x 1 MiB + 1 x 2.5 MiB: served (2.5 MiB < 152.5 MiB / 37)
     def many(sizes):
         ptrs = (_lib.u8p * len(sizes))(*[C.cast(big.ctypes.data + (i * 4099) % 1000, _lib.u8p) for i in range(len(sizes))])
         lens = (C.c_size_t * len(sizes))(*sizes)
         hexes = C.create_string_buffer(65 * len(sizes))
         st = vt.hash_many(None, ptrs, lens, len(sizes), hexes)
         return st, [hexes.raw[65 * i:65 * i + 64].decode() for i in range(len(sizes))]
-    assert many([3 << 20] + [4096] * 8)[0] == _lib.YAMS_ERR_UNSUPPORTED
-    st, hx = many([1 << 20] * 150 + [3 << 20])
+    assert many([(3 << 20) - 1000] + [4096] * 8)[0] == _lib.YAMS_ERR_UNSUPPORTED
+    st, hx = many([1 << 20] * 150 + [5 << 19])
     assert st == 0
     for i in (0, 77, 150):
         o = (i * 4099) % 1000
-        n_ = (1 << 20) if i < 150 else (3 << 20)
+        n_ = (1 << 20) if i < 150 else (5 << 19)
         assert hx[i] == hashlib.sha256(big[o:o + n_].tobytes()).hexdigest()
     hp = C.c_void_p()
     assert L.yams_plugin_get_health_json(C.byref(hp)) == 0

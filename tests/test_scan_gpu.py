@@ -626,7 +626,7 @@ def test_small_corpus_runs_as_one_fused_launch(acc, oracle, metric):
     the record path's zero-norm rule; and against the exhaustive multi-launch pipeline (FORCE_EXACT)."""
     rng = np.random.default_rng(91)
     for n, d, nq, k in [(10_000, 384, 1, 10), (10_000, 384, 16, 10), (257, 64, 3, 5), (1, 32, 1, 3), (255, 96, 2, 256),
-                        (16_384, 128, 4, 32), (5000, 768, 7, 100), (3000, 1024, 2, 17)]:
+                        (16_384, 128, 4, 16), (5000, 768, 7, 50), (3000, 1024, 2, 17)]:
         corpus = oracle.synth_rows(61, 0, n, d)
         q = oracle.synth_rows(61, 1 << 40, nq, d)
         if n > 600:

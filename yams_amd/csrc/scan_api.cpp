@@ -134,7 +134,7 @@ bool small_scan_applies(const yams_scan_corpus_t& c, uint32_t nq, const yams_sca
                    YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_RESIDENT_QUERIES)) return false;
     if ((c.dim & 31u) || c.dim > 1024 || (reinterpret_cast<uintptr_t>(c.rows) & 15u)) return false;
     const uint32_t n_wg = static_cast<uint32_t>((c.n_rows + 255) / 256), kk = std::min<uint32_t>(p.k, 256);
-    return p.k <= 256 && static_cast<uint64_t>(n_wg) * kk <= 2048;
+    return p.k <= 256 && static_cast<uint64_t>(n_wg) * kk <= small_scan_max_survivors();
 }
 
 yams_status_t small_scan(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, const float* queries, uint32_t nq,
@@ -147,7 +147,7 @@ yams_status_t small_scan(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, 
     a.rows = corpus->rows; a.n_rows = static_cast<uint32_t>(corpus->n_rows); a.dim = corpus->dim; a.queries = queries; a.nq = nq;
     a.tie_rank = corpus->tie_rank; a.rank_row = corpus->rank_row; a.row_mask = corpus->row_mask; a.row_base = corpus->row_base;
     a.stripe_rows = corpus->stripe_rows; a.n_stripes = corpus->n_stripes; a.stripe_index = corpus->stripe_index;
-    a.k = params->k; a.kk = kk; a.sort_cap = small_scan_sort_cap(n_wg, kk);
+    a.k = params->k; a.kk = kk; a.sort_cap = 0;
     a.threshold = params->similarity_threshold; a.flags = params->flags;
     a.out_scores = out_scores; a.out_rows = out_rows; a.out_counts = out_counts; a.out_dist = out_dist; a.out_ranks = out_ranks;
     YA_TRY(ws_get(ctx, "small_keys", static_cast<size_t>(nq) * n_wg * kk * 8, (void**)&a.part_key));
@@ -161,12 +161,22 @@ yams_status_t small_scan(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, 
     }
     uint32_t* h_pin;
     YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 8 + 64, (void**)&h_pin));
+#ifdef YAMS_ACCEL_MEASURE
+    if (std::getenv("YAMS_ACCEL_SMALL_STAMPS")) YA_TRY(ws_get(ctx, "small_dbg", static_cast<size_t>(n_wg) * 64, (void**)&a.dbg));
+#endif
     { TimedRegion tr(ctx, "small_scan");
       YA_HIP(ctx, launch_small_scan(st, static_cast<int>(params->metric), a, qb));
       tr.end(); }
     YA_HIP(ctx, hipMemcpyAsync(h_pin, a.qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
     if (diag) YA_HIP(ctx, hipMemcpyAsync(h_pin + nq, out_counts, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
     YA_HIP(ctx, hipStreamSynchronize(st));
+#ifdef YAMS_ACCEL_MEASURE
+    if (a.dbg) if (const char* dump = std::getenv("YAMS_ACCEL_SMALL_STAMPS")) {
+        std::vector<unsigned long long> h(static_cast<size_t>(n_wg) * 8);
+        YA_HIP(ctx, hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+#endif
     for (uint32_t i = 0; i < nq; ++i) {
         const bool bad = (params->metric == YAMS_SCAN_COSINE) ? (h_pin[i] != 0) : ((h_pin[i] & 1u) != 0);
         if (bad) return fail(ctx, YAMS_ERR_INVALID_ARG, "Exact vector search requires a finite, non-zero query embedding");

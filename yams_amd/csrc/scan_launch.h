@@ -70,14 +70,15 @@ struct SmallScanArgs {
     const float* queries; uint32_t nq;
     const uint32_t* tie_rank; const uint32_t* rank_row; const uint32_t* row_mask;
     int64_t row_base; uint32_t stripe_rows, n_stripes, stripe_index;
-    uint32_t k, kk, sort_cap;   // kk = keys a workgroup keeps per query = min(k, 256); sort_cap = pow2 >= max(256, n_wg * kk)
+    uint32_t k, kk, sort_cap;   // kk = keys a workgroup keeps per query = min(k, 256); n_wg * kk <= small_scan_max_survivors()
     float threshold; uint32_t flags;
     uint64_t* part_key; float* part_aux;   // [nq][n_wg][kk]
     uint32_t* counter;                     // [query chunks], zero between launches (the kernel resets it)
     uint32_t* qflags;                      // [nq]: bit0 non-finite element, bit1 norm^2 < 1e-10
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist; uint32_t* out_ranks;
+    unsigned long long* dbg = nullptr;     // measurement build only: [n_wg][8] phase stamps (100 MHz wall clock)
 };
-uint32_t small_scan_sort_cap(uint32_t n_wg, uint32_t kk);
+uint32_t small_scan_max_survivors();
 hipError_t launch_small_scan(hipStream_t st, int metric, const SmallScanArgs& a, uint32_t qb);
 
 constexpr uint32_t kRescoreMax = 2047; // + 1 boundary key == kSelectCap / 2 (select convergence)

@@ -13,11 +13,12 @@
 //     so the reads back are conflict-free), pays the latency once per pass and then sums out of LDS;
 //   * query validity + ||q|| (fp64, sequential, :4206-4211) are computed by every workgroup for its own queries
 //     (a 384-element chain beside the row walk of the other waves) — no separate prep launch;
-//   * per query the workgroup sorts its 256 keys (similarity desc | distance asc, then the tie rank) and writes
-//     its best kk = min(k, 256);
+//   * per query the workgroup keeps its best kk = min(k, 256) of its 256 keys (similarity desc | distance asc, then
+//     the tie rank) by RANK COUNTING: a key's place is the number of keys greater than it, counted by its thread
+//     against the list in LDS — no sorting network, no barrier per step;
 //   * the workgroup that finishes LAST for a query chunk (one ticket counter per chunk, reset by that workgroup)
-//     sorts the n_wg * kk survivors and writes the result: scores, rows, counts, distances, ranks — the vec0
-//     rule under L2 (the k nearest first, THEN the cosine threshold, :4506-4510).
+//     selects from the n_wg * kk <= 1024 survivors the same way and writes the result: scores, rows, counts, distances, ranks — the vec0 rule under L2 (the k nearest first, THEN
+//     the cosine threshold, :4506-4510).
 // Host side: one launch, one look at the query flags (scan_api.cpp, small_scan).
 #include "common.h"
 #include "lds_dma.h"
@@ -36,39 +37,44 @@ __device__ __forceinline__ int64_t small_global_row(const SmallScanArgs& a, uint
     return a.row_base + static_cast<int64_t>((t * a.n_stripes + a.stripe_index) * a.stripe_rows + w);
 }
 
-// descending bitonic sort of (key, idx) pairs s[0, m), m a power of two, by all threads of the workgroup
-__device__ __forceinline__ void sort_pairs_desc(uint64_t* skey, uint32_t* sidx, int m) {
-    for (int kk = 2; kk <= m; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (m >> 1); t += SM_THREADS) {
-                const int i = 2 * t - (t & (j - 1));
-                const int ixj = i + j;
-                const uint64_t x = skey[i], y = skey[ixj];
-                const bool up = (i & kk) == 0;
-                if (up ? (x < y) : (x > y)) {
-                    skey[i] = y; skey[ixj] = x;
-                    const uint32_t tt = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = tt;
-                }
-            }
-            __syncthreads();
-        }
+// Selection by RANK COUNTING instead of sorting.  Keys are unique (they carry the row's tie rank) or zero (empty
+// slot), so the place of a key in the descending order is the number of keys greater than it: every thread counts
+// that for its own key(s) against the list in LDS — broadcast reads, 16 bytes = two keys at a time, no bank
+// conflicts, no barrier inside — and the keys whose rank is below the cut write themselves straight to their place.
+// n^2 / 256 comparisons per thread: 256 for a workgroup's own 256 keys, <= 4096 for the <= 1024 survivors of the
+// final selection.  (A bitonic network over the same keys — in LDS with a barrier per step, or in registers with a
+// shuffle per step — took 10-25 us per list at the clocks such a small launch runs at: more than the scoring pass.)
+__device__ __forceinline__ uint32_t rank_of(const uint64_t* list, uint32_t n_pow2 /* multiple of 16 */, uint64_t mine) {
+    uint32_t r = 0;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* l2 = reinterpret_cast<const u64x2*>(list);
+#pragma unroll 8
+    for (uint32_t i = 0; i < n_pow2 / 2; ++i) { // (n a multiple of 16 keys, zero-padded: zeros are never greater)
+        const u64x2 v = l2[i];
+        r += (v.x > mine ? 1u : 0u) + (v.y > mine ? 1u : 0u);
     }
+    return r;
 }
+
+#ifdef YAMS_ACCEL_MEASURE
+#define SM_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SM_STAMP(i) ((void)0)
+#endif
 
 template <int METRIC, int QB>
 __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim = a.dim;
     const uint32_t dim4 = (dim + 3u) & ~3u;
-    unsigned char* sring = smem;                                         // [4 waves][SM_RING_BYTES]; the sort arrays reuse it after the walk
-    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);                  // [sort_cap]
-    uint32_t* sidx = reinterpret_cast<uint32_t*>(skey + a.sort_cap);     // [sort_cap]
-    float* saux = reinterpret_cast<float*>(sidx + a.sort_cap);           // [256]: cosine of this workgroup's rows (L2)
+    unsigned char* sring = smem;                                         // [4 waves][SM_RING_BYTES]; the key staging reuses it after the walk
+    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);                  // [QB][256]: this workgroup's keys per query
+    float* saux = reinterpret_cast<float*>(skey + QB * SM_THREADS);      // [QB][256]: cosine of its rows (L2)
     float* sq = reinterpret_cast<float*>(smem + 4 * SM_RING_BYTES);      // [QB][dim4]
     __shared__ double s_qn[QB];
     __shared__ uint32_t s_last;
-    __shared__ uint32_t s_outn;
 
+    SM_STAMP(0);
     const uint32_t q0 = blockIdx.y * QB;
     const uint32_t nqc = min(static_cast<uint32_t>(QB), a.nq - q0);      // queries of this chunk
     for (uint32_t i = threadIdx.x; i < QB * dim4; i += SM_THREADS) {
@@ -87,23 +93,49 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
     for (int j = 0; j < QB; ++j) { dot[j] = 0.0; dsq[j] = 0.0; }
     const uint32_t wrow0 = blockIdx.x * SM_THREADS + wave * 64;          // the wave's 64 consecutive rows
     const bool wave_live = wrow0 < a.n_rows;
-    const float* xrow = a.rows + static_cast<uint64_t>(row) * dim;
     const uint32_t ring = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
                               (__attribute__((address_space(3))) unsigned char*)sring)) + wave * SM_RING_BYTES; // LDS byte address
     const uint32_t n_chunks = dim / 32;
+    // One DMA instruction fetches a 128-byte line of EIGHT rows (lane = row-in-8 * 8 + slot): eight memory requests,
+    // not the sixty-four of a lane-per-row fetch (the walk was bound by that: ~1 request per cycle per CU).  The LDS
+    // image of an instruction is lane-linear, so the eight 16-byte pieces of a row land next to each other, 128 bytes
+    // from the next row — the 64 lanes reading "piece p of my row" would hit four bank groups.  The rotation is
+    // therefore applied at the SOURCE: slot s of row R receives piece (s - rho(R)) mod 8, rho(R) = ((R >> 1) & 3) +
+    // 4 * ((R >> 3) & 1), so that lane R finds piece p in slot (p + rho(R)) mod 8 and sixteen consecutive lanes
+    // touch sixteen different bank groups; the registers a lane sums from keep their natural order.
+    auto rho = [](uint32_t r64) { return ((r64 >> 1) & 3u) + 4u * ((r64 >> 3) & 1u); };
+    const uint32_t dma_row8 = static_cast<uint32_t>(lane) >> 3, dma_slot = static_cast<uint32_t>(lane) & 7u;
     auto issue_pass = [&](uint32_t c0, uint32_t nc) {
         for (uint32_t c = 0; c < nc; ++c) {
 #pragma unroll
-            for (int pc = 0; pc < 8; ++pc)
-                lds_dma16(xrow + (c0 + c) * 32 + pc * 4, __builtin_amdgcn_readfirstlane(ring + (c * 8 + pc) * 1024));
+            for (int g = 0; g < 8; ++g) {
+                const uint32_t r64 = 8u * g + dma_row8;                    // row of the wave this lane fetches for
+                uint32_t rr = wrow0 + r64;
+                if (rr >= a.n_rows) rr = a.n_rows - 1;                    // (a valid address; the lane's key is dropped later)
+                const uint32_t piece = (dma_slot - rho(r64)) & 7u;
+                lds_dma16(a.rows + static_cast<uint64_t>(rr) * dim + (c0 + c) * 32 + piece * 4,
+                          __builtin_amdgcn_readfirstlane(ring + (c * 8 + g) * 1024));
+            }
         }
     };
+    SM_STAMP(1);
     if (wave_live) issue_pass(0, min(static_cast<uint32_t>(SM_PASS_CHUNKS), n_chunks));
+    SM_STAMP(2);
     // ---- query validity + norm: lanes 0..QB-1 of the last wave, while its first pass is in flight ------------
     if (wave == 3 && lane < QB) {
         double acc = 0.0;
-        const float* s = sq + lane * dim4;
-        for (uint32_t i = 0; i < dim; ++i) { const double d = static_cast<double>(s[i]); acc = fma(d, d, acc); }
+        const float4* s4 = reinterpret_cast<const float4*>(sq + lane * dim4);
+        for (uint32_t i = 0; i < dim / 32; ++i) { // 32 elements per step: the eight reads go out together
+            float4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = s4[i * 8 + t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = static_cast<double>(vv[e]); acc = fma(d, d, acc); }
+            }
+        }
         uint32_t f = 0;
         if (!isfinite(acc)) f |= 1u;             // a non-finite element (fp64 cannot overflow on fp32 squares)
         if (!(acc >= 1e-10)) f |= 2u;            // isZeroNormEmbedding, :204-211
@@ -111,24 +143,35 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
         if (blockIdx.x == 0 && static_cast<uint32_t>(lane) < nqc) a.qflags[q0 + lane] = f;
     }
     if (wave_live) {
-        const unsigned char* mine = sring + wave * SM_RING_BYTES + lane * 16;
+        // lane L = row L of the wave: block (L >> 3) of a chunk, row-in-8 (L & 7), piece p in slot (p + rho(L)) & 7
+        const unsigned char* mine = sring + wave * SM_RING_BYTES + (lane >> 3) * 1024 + (lane & 7) * 128;
+        const uint32_t my_rho = rho(static_cast<uint32_t>(lane));
         for (uint32_t c0 = 0; c0 < n_chunks; c0 += SM_PASS_CHUNKS) {
             const uint32_t nc = min(static_cast<uint32_t>(SM_PASS_CHUNKS), n_chunks - c0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this pass has landed
             for (uint32_t c = 0; c < nc; ++c) {
+                // all LDS reads of a chunk go out before the first sum (one latency per chunk, not one per 16 bytes)
+                float4 rv[8], qv[QB][8];
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) rv[pc] = *reinterpret_cast<const float4*>(mine + c * 8192 + ((pc + my_rho) & 7u) * 16);
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+#pragma unroll
+                    for (int pc = 0; pc < 8; ++pc)
+                        qv[j][pc] = *reinterpret_cast<const float4*>(sq + j * dim4 + (c0 + c) * 32 + pc * 4);
 #pragma unroll
                 for (int pc = 0; pc < 8; ++pc) {
-                    const float4 v = *reinterpret_cast<const float4*>(mine + (c * 8 + pc) * 1024);
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    const float vv[4] = {rv[pc].x, rv[pc].y, rv[pc].z, rv[pc].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const double sv = static_cast<double>(vv[e]);
                         nsq = fma(sv, sv, nsq);                           // :4253-4266, sequential i, fp64
 #pragma unroll
                         for (int j = 0; j < QB; ++j) {
-                            const double qv = static_cast<double>(sq[j * dim4 + (c0 + c) * 32 + pc * 4 + e]);
-                            dot[j] = fma(sv, qv, dot[j]);
-                            if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq[j] = fma(d, d, dsq[j]); }
+                            const float qq[4] = {qv[j][pc].x, qv[j][pc].y, qv[j][pc].z, qv[j][pc].w};
+                            const double qd = static_cast<double>(qq[e]);
+                            dot[j] = fma(sv, qd, dot[j]);
+                            if (METRIC == YAMS_SCAN_L2) { const double d = sv - qd; dsq[j] = fma(d, d, dsq[j]); }
                         }
                     }
                 }
@@ -139,11 +182,12 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
             }
         }
     }
+    SM_STAMP(3);
     __syncthreads(); // the norms are there, and nobody reads the rings any more (the sort arrays live there)
     const uint32_t rank = live ? (a.tie_rank ? a.tie_rank[row] : row) : 0u;
     const uint32_t kk = a.kk;
 
-    // ---- per query: this workgroup's best kk ----------------------------------------------------------------
+    // ---- per query: this workgroup's best kk.  Every thread parks its keys; a key's rank is counted by its thread ----
     for (uint32_t j = 0; j < nqc; ++j) {
         double dj = 0.0, qj = 0.0;
 #pragma unroll
@@ -172,18 +216,50 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
                 }
             }
         }
-        skey[threadIdx.x] = key; sidx[threadIdx.x] = threadIdx.x; saux[threadIdx.x] = aux;
-        __syncthreads();
-        sort_pairs_desc(skey, sidx, SM_THREADS);
-        const uint64_t base = (static_cast<uint64_t>(q0 + j) * gridDim.x + blockIdx.x) * kk;
-        for (uint32_t i = threadIdx.x; i < kk; i += SM_THREADS) {
-            a.part_key[base + i] = skey[i];
-            if (METRIC == YAMS_SCAN_L2) a.part_aux[base + i] = saux[sidx[i]];
+        skey[j * SM_THREADS + threadIdx.x] = key;
+        if (METRIC == YAMS_SCAN_L2) saux[j * SM_THREADS + threadIdx.x] = aux;
+    }
+    __syncthreads();
+    // Two levels: a key that is not among the best kk of its own WAVE's 64 cannot be among the workgroup's best kk,
+    // so each thread first counts within its wave (64 comparisons); the survivors (<= 4 kk) are compacted and
+    // ranked among themselves.  (kk >= 64 keeps everything: one level, 256 comparisons.)
+    uint64_t* scomp = skey + QB * SM_THREADS + (QB * SM_THREADS) / 2;    // [QB][256] compacted survivors (behind saux)
+    __shared__ uint32_t s_ncomp[QB];
+    if (threadIdx.x < QB) s_ncomp[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < QB * SM_THREADS; i += SM_THREADS) scomp[i] = 0;
+    __syncthreads();
+    uint64_t mine_k[QB];
+    bool surv[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        mine_k[j] = 0; surv[j] = false;
+        if (static_cast<uint32_t>(j) < nqc) {
+            const uint64_t mine = skey[j * SM_THREADS + threadIdx.x];
+            mine_k[j] = mine;
+            if (mine) {
+                const uint32_t rl = kk >= 64 ? 0u : rank_of(skey + j * SM_THREADS + wave * 64, 64, mine);
+                if (rl < kk) { surv[j] = true; scomp[j * SM_THREADS + atomicAdd(&s_ncomp[j], 1u)] = mine; }
+            }
         }
-        __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        if (static_cast<uint32_t>(j) >= nqc) break;
+        const uint32_t nc = s_ncomp[j];                                   // valid keys kept (all of them when kk >= 64)
+        const uint64_t base = (static_cast<uint64_t>(q0 + j) * gridDim.x + blockIdx.x) * kk;
+        if (surv[j]) {
+            const uint32_t r = rank_of(scomp + j * SM_THREADS, (nc + 15u) & ~15u, mine_k[j]);
+            if (r < kk) {
+                a.part_key[base + r] = mine_k[j];
+                if (METRIC == YAMS_SCAN_L2) a.part_aux[base + r] = saux[j * SM_THREADS + threadIdx.x];
+            }
+        }
+        if (threadIdx.x >= nc && threadIdx.x < kk) a.part_key[base + threadIdx.x] = 0;   // fewer valid keys than kk: empty slots
     }
 
-    // ---- the last workgroup of this query chunk finishes the job ---------------------------------------------
+    SM_STAMP(4);
+    // ---- the last workgroup of this query chunk finishes the job ----------------------------------------------
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -192,88 +268,121 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
         if (s_last) a.counter[blockIdx.y] = 0; // ready for the next call
     }
     __syncthreads();
+    SM_STAMP(5);
     if (!s_last) return;
     __threadfence();
-    const uint32_t total = gridDim.x * kk;
-    int m = 64;
-    while (m < static_cast<int>(total)) m <<= 1;
+    SM_STAMP(6);
+    const uint32_t total = gridDim.x * kk;                                // <= small_scan_max_survivors()
+    uint32_t total2 = 64;
+    while (total2 < total) total2 <<= 1;
+    uint64_t* fkey = skey;                                               // [total2]
+    uint32_t* frank_row = reinterpret_cast<uint32_t*>(fkey + 1024);      // [256]: (L2) survivor index of rank r
+    float* fcs = reinterpret_cast<float*>(frank_row + 256);              // [256]: (L2) its cosine
     for (uint32_t j = 0; j < nqc; ++j) {
         const uint32_t q = q0 + j;
         const uint64_t base = static_cast<uint64_t>(q) * total;
-        for (int i = threadIdx.x; i < m; i += SM_THREADS) {
-            skey[i] = static_cast<uint32_t>(i) < total ? __builtin_nontemporal_load(a.part_key + base + i) : 0ull;
-            sidx[i] = i;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total2; i += SM_THREADS)
+            fkey[i] = i < total ? __builtin_nontemporal_load(a.part_key + base + i) : 0ull;
+        __syncthreads();
+        // Every workgroup's list is sorted, so list b alone holds kk keys >= its last one: the k best overall (k == kk
+        // unless k > 256) are all >= tau = the LARGEST of the lists' last keys.  Only those candidates are compacted
+        // and ranked — a few dozen for ordinary data instead of all n_wg * kk (any number stays correct).
+        __shared__ unsigned long long s_tau;
+        __shared__ uint32_t s_nc;
+        if (threadIdx.x == 0) { s_tau = 0; s_nc = 0; }
+        __syncthreads();
+        if (a.k <= kk)
+            for (uint32_t b2 = threadIdx.x; b2 < gridDim.x; b2 += SM_THREADS) atomicMax(&s_tau, static_cast<unsigned long long>(fkey[b2 * kk + kk - 1]));
+        __syncthreads();
+        const uint64_t tau = s_tau;                                        // (0 when some list is not full: nothing is pruned)
+        uint64_t* fcand = fkey + 1024 + 512;                               // [1024] candidates (behind frank_row / fcs)
+        uint32_t* fsrc = reinterpret_cast<uint32_t*>(fcand + 1024);        // [1024] their index among the survivors
+        for (uint32_t i = threadIdx.x; i < 1024; i += SM_THREADS) fcand[i] = 0;
+        __syncthreads();
+        uint32_t nv_mine = 0;
+        for (uint32_t i = threadIdx.x; i < total; i += SM_THREADS) {
+            const uint64_t mine = fkey[i];
+            if (!mine) continue;
+            ++nv_mine;
+            if (mine < tau) continue;
+            const uint32_t slot = atomicAdd(&s_nc, 1u);
+            fcand[slot] = mine; fsrc[slot] = i;
         }
         __syncthreads();
-        sort_pairs_desc(skey, sidx, m);
-        uint32_t nv;
-        { uint32_t lo = 0, hi = static_cast<uint32_t>(m);   // valid (non-zero) keys: binary search on the sorted array
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skey[mid] != 0) lo = mid + 1; else hi = mid; }
-          nv = lo; }
-        const uint32_t take = nv < a.k ? nv : a.k;
+        const uint32_t n_cand = s_nc;
+        for (uint32_t c = threadIdx.x; c < n_cand; c += SM_THREADS) {
+            const uint64_t mine = fcand[c];
+            const uint32_t i = fsrc[c];
+            const uint32_t r = rank_of(fcand, (n_cand + 15u) & ~15u, mine);
+            if (r >= a.k) continue;
+            if (METRIC == YAMS_SCAN_COSINE) {
+                const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
+                const uint32_t rk = key_idx(mine);
+                const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
+                const float sim = key_score(mine);
+                a.out_scores[o] = sim;
+                a.out_rows[o] = small_global_row(a, rowi);
+                if (a.out_ranks) a.out_ranks[o] = rk;
+                if (a.out_dist) a.out_dist[o] = 1.0f - sim;
+            } else {
+                frank_row[r] = i;                                         // (k <= 256)
+                fcs[r] = __builtin_nontemporal_load(a.part_aux + base + i);
+            }
+        }
+        // number of valid survivors (block-wide sum of the per-thread counts)
+        __shared__ uint32_t s_nv;
+        if (threadIdx.x == 0) s_nv = 0;
+        __syncthreads();
+        if (nv_mine) atomicAdd(&s_nv, nv_mine);
+        __syncthreads();
+        const uint32_t take = s_nv < a.k ? s_nv : a.k;
         if (METRIC == YAMS_SCAN_COSINE) {
-            for (uint32_t i = threadIdx.x; i < a.k; i += SM_THREADS) {
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + i;
-                if (i < take) {
-                    const uint32_t rk = key_idx(skey[i]);
-                    const uint32_t r = a.tie_rank ? a.rank_row[rk] : rk;
-                    const float sim = key_score(skey[i]);
-                    a.out_scores[o] = sim;
-                    a.out_rows[o] = small_global_row(a, r);
-                    if (a.out_ranks) a.out_ranks[o] = rk;
-                    if (a.out_dist) a.out_dist[o] = 1.0f - sim;
-                } else {
-                    a.out_scores[o] = -__builtin_inff();
-                    a.out_rows[o] = -1;
-                    if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
-                    if (a.out_dist) a.out_dist[o] = __builtin_inff();
-                }
+            for (uint32_t r = take + threadIdx.x; r < a.k; r += SM_THREADS) {
+                const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
+                a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
+                if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
+                if (a.out_dist) a.out_dist[o] = __builtin_inff();
             }
             if (threadIdx.x == 0) a.out_counts[q] = take;
         } else {
-            // vec0 semantics: the k nearest, THEN the cosine threshold (:4506-4510), order preserved
-            if (threadIdx.x == 0) {
-                uint32_t outn = 0;
-                const bool defer = (a.flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) != 0;
-                for (uint32_t i = 0; i < take; ++i) {
-                    const float cs = __builtin_nontemporal_load(a.part_aux + base + sidx[i]);
-                    if (!defer && cs < a.threshold) continue;
-                    const uint64_t o = static_cast<uint64_t>(q) * a.k + outn;
-                    const uint32_t rk = key_idx(skey[i]);
-                    const uint32_t r = a.tie_rank ? a.rank_row[rk] : rk;
-                    a.out_scores[o] = cs;
-                    a.out_rows[o] = small_global_row(a, r);
-                    if (a.out_dist) a.out_dist[o] = -key_score(skey[i]);
-                    if (a.out_ranks) a.out_ranks[o] = rk;
-                    ++outn;
-                }
-                s_outn = outn;
-                a.out_counts[q] = outn;
+            // vec0 semantics: the k nearest, THEN the cosine threshold (:4506-4510), order preserved: the place of
+            // rank r is the number of passing ranks before it
+            const bool defer = (a.flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) != 0;
+            const uint32_t r = threadIdx.x;
+            const bool pass = r < take && (defer || !(fcs[r] < a.threshold));
+            uint32_t pos = 0;
+            for (uint32_t i = 0; i < r && i < take; ++i) pos += (defer || !(fcs[i] < a.threshold)) ? 1u : 0u;
+            if (pass) {
+                const uint64_t mine = fkey[frank_row[r]];
+                const uint64_t o = static_cast<uint64_t>(q) * a.k + pos;
+                const uint32_t rk = key_idx(mine);
+                const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
+                a.out_scores[o] = fcs[r];
+                a.out_rows[o] = small_global_row(a, rowi);
+                if (a.out_dist) a.out_dist[o] = -key_score(mine);
+                if (a.out_ranks) a.out_ranks[o] = rk;
             }
-            __syncthreads();
-            for (uint32_t i = s_outn + threadIdx.x; i < a.k; i += SM_THREADS) {
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + i;
-                a.out_scores[o] = -__builtin_inff();
-                a.out_rows[o] = -1;
+            const uint32_t outn = static_cast<uint32_t>(__syncthreads_count(pass));
+            for (uint32_t rr = outn + threadIdx.x; rr < a.k; rr += SM_THREADS) {
+                const uint64_t o = static_cast<uint64_t>(q) * a.k + rr;
+                a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
                 if (a.out_dist) a.out_dist[o] = __builtin_inff();
                 if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
             }
+            if (threadIdx.x == 0) a.out_counts[q] = outn;
         }
-        __syncthreads();
     }
+    SM_STAMP(7);
 }
 
 } // namespace
 
-uint32_t small_scan_sort_cap(uint32_t n_wg, uint32_t kk) {
-    uint32_t m = SM_THREADS;
-    while (m < n_wg * kk) m <<= 1;
-    return m;
-}
+uint32_t small_scan_max_survivors() { return 1024; } // n_wg * kk the last workgroup ranks in LDS
 
 size_t small_scan_lds_bytes(uint32_t dim, uint32_t qb, uint32_t sort_cap) {
     const size_t dim4 = (dim + 3u) & ~3u;
-    // rings (the sort arrays alias them: sort_cap * 12 + 1 KiB <= 128 KiB) + the queries
+    // rings (the key staging of the selection aliases them) + the queries
     (void)sort_cap;
     return static_cast<size_t>(4) * SM_RING_BYTES + qb * dim4 * 4;
 }
