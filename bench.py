@@ -1027,6 +1027,24 @@ def main():
                   "bf16_tier_ms_per_step_one_cold_call": dtb * 1e3, "bf16_tier_filter_tier": dgb.get("filter_tier"),
                   "results_identical_to_the_bf16_tier": bool(torch.equal(r3, rb3) and torch.equal(s3, sb3) and torch.equal(c3, cb3)
                                                              and torch.equal(d3, db3))}
+        # L2 parity is UNPINNED (the vec0 arithmetic lives in the absent sqlite-vec-cpp): this repository accumulates in fp64,
+        # the dependency most likely in fp32.  How many of the 1024 top-k sets would differ?  The device's top 2k under our
+        # definition, re-measured with fp32 accumulation on the host (sequential / 8 / 16 SIMD lanes): a REPORT of the size
+        # of the gap, not a parity claim.
+        try:
+            K2 = 2 * k
+            s2 = torch.empty((q3, K2), dtype=torch.float32, device=dev); r2 = torch.empty((q3, K2), dtype=torch.int64, device=dev)
+            c2 = torch.empty(q3, dtype=torch.int32, device=dev); d2 = torch.empty((q3, K2), dtype=torch.float32, device=dev)
+            acc.scan_topk_device(view3, tq.data_ptr(), q3, K2, -1.0, SCAN_L2, s2.data_ptr(), r2.data_ptr(), c2.data_ptr(), d2.data_ptr())
+            _o = oracle_mod()
+            rep = _o.l2_definition_report(_o.oracle(), lambda rows: tc[torch.from_numpy(rows - row_base).to(dev)].cpu().numpy(),
+                                          tq[:q3].cpu().numpy(), r2.cpu().numpy(), d2.cpu().numpy(), k)
+            rep["note"] = ("L2 parity is unpinned: third_party/sqlite-vec-cpp is absent from the reference checkout; `bit-identical` "
+                           "above means identical to THIS repository's fp64-accumulate definition (oracle/yams_oracle.c)")
+            l2_leg["definition_gap_report"] = rep
+            del s2, r2, c2, d2
+        except Exception as e:      # noqa: BLE001
+            l2_leg["definition_gap_report"] = {"error": repr(e)}
         # ... and its HBM-bound point: the same shard at 64 queries (one resident query tile, every CU streams its own rows)
         q3s = 64
         def step3s(want_diag=False):

@@ -16,6 +16,14 @@
 // (the host's SqliteVecBackend with search disabled, or any IVectorStore), every mutation and every
 // SQL-only method is forwarded to it and the mirror is warmed from it at initialize(); without one
 // the backend is an in-memory store (tests, caches).
+//
+// Transactions (vector_store.h:71-76; SqliteVecBackend: BEGIN IMMEDIATE ... COMMIT / ROLLBACK): the device mirror
+// holds COMMITTED state.  While a transaction is open, mutations go to the durable store at once (it is what can
+// roll back) and are JOURNALED for the mirror; commit applies the journal in order, rollback drops it — a search
+// never returns a chunk_id that getVector() cannot resolve afterwards.  Without a durable store the mirror is the
+// store: mutations apply at once and an undo log restores the previous rows on rollback.  If the mirror fails after
+// the durable store succeeded (device out of memory), the mirror is marked stale and re-warmed from the durable
+// store before the next search.
 #pragma once
 #ifndef YAMS_ACCEL_USE_HOST_TYPES
 #error "exact_scan_backend.hpp binds to the host's headers: define YAMS_ACCEL_USE_HOST_TYPES"
@@ -25,6 +33,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <unordered_map>
+#include <variant>
 
 #include "vector_index.hpp"
 
@@ -45,17 +54,7 @@ public:
         std::unique_lock lk(mu_);
         if (durable_) {
             if (auto s = durable_->initialize(db_path); !s) return s;
-            // warm the device mirror from the durable rows (document-level rows included)
-            std::vector<VectorRecord> all;
-            auto hashes = durable_->getEmbeddedDocumentHashes();
-            if (!hashes) return hashes.error();
-            for (const auto& h : hashes.value()) {
-                auto rows = durable_->getVectorsByDocument(h);
-                if (!rows) return rows.error();
-                for (auto& r : rows.value()) all.push_back(std::move(r));
-            }
-            if (!all.empty())
-                if (auto s = table_.insertVectorsBatch(all); !s) return s;
+            if (auto s = warmLocked(); !s) return s;
         }
         initialized_ = true;
         return {};
@@ -73,33 +72,37 @@ public:
     }
     bool tablesExist() const override { return durable_ ? durable_->tablesExist() : tables_; }
 
-    // ---- CRUD: durable store first (it validates and persists), then the device mirror ------------------
+    // ---- CRUD: durable store first (it validates and persists), then the device mirror — at once outside a
+    // transaction, at commit inside one -------------------------------------------------------------------------
     Result<void> insertVector(const VectorRecord& record) override { return insertVectorsBatch({record}); }
     Result<void> insertVectorsBatch(const std::vector<VectorRecord>& records) override {
         std::unique_lock lk(mu_);
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
         if (durable_) if (auto s = durable_->insertVectorsBatch(records); !s) return s;
-        return table_.insertVectorsBatch(records);
+        return mirror(Op{InsertOp{records}});
     }
     Result<void> updateVector(const std::string& chunk_id, const VectorRecord& record) override {
         std::unique_lock lk(mu_);
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
-        auto have = table_.getVector(chunk_id);
-        if (!have || !have.value()) return Error{ErrorCode::NotFound, "chunk not found"};
-        if (durable_) if (auto s = durable_->updateVector(chunk_id, record); !s) return s;
+        if (durable_) {
+            if (auto s = durable_->updateVector(chunk_id, record); !s) return s; // (it knows whether the chunk exists)
+        } else {
+            auto have = table_.getVector(chunk_id);
+            if (!have || !have.value()) return Error{ErrorCode::NotFound, "chunk not found"};
+        }
         VectorRecord r = record;
         r.chunk_id = chunk_id;
-        return table_.insertVectorsBatch({r});
+        return mirror(Op{InsertOp{{std::move(r)}}});
     }
     Result<void> deleteVector(const std::string& chunk_id) override {
         std::unique_lock lk(mu_);
         if (durable_) if (auto s = durable_->deleteVector(chunk_id); !s) return s;
-        return table_.deleteVector(chunk_id);
+        return mirror(Op{DeleteOp{chunk_id}});
     }
     Result<void> deleteVectorsByDocument(const std::string& document_hash) override {
         std::unique_lock lk(mu_);
         if (durable_) if (auto s = durable_->deleteVectorsByDocument(document_hash); !s) return s;
-        return table_.deleteVectorsByDocument(document_hash);
+        return mirror(Op{DeleteDocOp{document_hash}});
     }
 
     // ---- search: always the device -------------------------------------------------------------------
@@ -114,8 +117,10 @@ public:
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatch(const std::vector<std::vector<float>>& query_embeddings, size_t k,
                        float similarity_threshold = 0.0f, size_t num_threads = 0) override {
-        std::unique_lock lk(mu_); // (the mirror is synchronised lazily inside the search)
+        if (auto s = syncForSearch(); !s) return s.error();
+        std::shared_lock lk(mu_); // searches share (vector_database.cpp:539,618): the plugin's search lanes serve them side by side
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (mirrorStale_ || table_.needsSync()) { lk.unlock(); return searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads); } // a writer slipped in
         return table_.searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads);
     }
     // sqlite_vec_backend.cpp:4650-4661: the diagnostics are reset, the caller's collect flag survives
@@ -240,12 +245,120 @@ public:
         st.avg_embedding_magnitude = st.total_vectors ? mag / static_cast<double>(st.total_vectors) : 0.0;
         return st;
     }
-    // ---- transactions: the durable store's; the mirror follows committed batches -------------------------
-    Result<void> beginTransaction() override { return durable_ ? durable_->beginTransaction() : Result<void>{}; }
-    Result<void> commitTransaction() override { return durable_ ? durable_->commitTransaction() : Result<void>{}; }
-    Result<void> rollbackTransaction() override { return durable_ ? durable_->rollbackTransaction() : Result<void>{}; }
+    // ---- transactions: the durable store's; the mirror holds committed state (see the header comment) ---------
+    Result<void> beginTransaction() override {
+        std::unique_lock lk(mu_);
+        if (inTxn_) return Error{ErrorCode::InvalidState, "transaction already open"};
+        if (durable_) if (auto s = durable_->beginTransaction(); !s) return s;
+        inTxn_ = true; journal_.clear(); undo_.clear();
+        return {};
+    }
+    Result<void> commitTransaction() override {
+        std::unique_lock lk(mu_);
+        if (!inTxn_) return durable_ ? durable_->commitTransaction() : Result<void>{};
+        if (durable_) if (auto s = durable_->commitTransaction(); !s) return s; // (still open: the caller rolls back)
+        inTxn_ = false;
+        undo_.clear();
+        std::vector<Op> ops;
+        ops.swap(journal_);
+        for (auto& op : ops)
+            if (auto s = applyToMirror(op); !s) { mirrorStale_ = durable_ != nullptr; if (!durable_) return s; break; }
+        return {};
+    }
+    Result<void> rollbackTransaction() override {
+        std::unique_lock lk(mu_);
+        if (!inTxn_) return durable_ ? durable_->rollbackTransaction() : Result<void>{};
+        inTxn_ = false;
+        journal_.clear(); // (durable mode: the mirror never saw these)
+        Result<void> rc{};
+        if (durable_) rc = durable_->rollbackTransaction();
+        else {
+            // in-memory mode: put the previous rows back, newest change first
+            for (auto it = undo_.rbegin(); it != undo_.rend(); ++it) {
+                for (const auto& id : it->inserted) (void)table_.deleteVector(id);
+                if (!it->previous.empty()) if (auto s = table_.insertVectorsBatch(it->previous); !s) rc = s;
+            }
+        }
+        undo_.clear();
+        return rc;
+    }
 
 private:
+    struct InsertOp { std::vector<VectorRecord> records; };
+    struct DeleteOp { std::string chunk_id; };
+    struct DeleteDocOp { std::string document_hash; };
+    using Op = std::variant<InsertOp, DeleteOp, DeleteDocOp>;
+    struct Undo { std::vector<std::string> inserted; std::vector<VectorRecord> previous; };
+
+    Result<void> applyToMirror(const Op& op) {
+        if (const auto* i = std::get_if<InsertOp>(&op)) return table_.insertVectorsBatch(i->records);
+        if (const auto* d = std::get_if<DeleteOp>(&op)) {
+            auto s = table_.deleteVector(d->chunk_id);
+            // (the durable store accepted the delete of a chunk the mirror does not hold: nothing to do)
+            if (!s && durable_ && s.error().code == ErrorCode::NotFound) return {};
+            return s;
+        }
+        return table_.deleteVectorsByDocument(std::get<DeleteDocOp>(op).document_hash);
+    }
+    // One mutation on its way to the mirror (mu_ held exclusively; the durable store has already accepted it).
+    Result<void> mirror(Op op) {
+        if (inTxn_ && durable_) { journal_.push_back(std::move(op)); return {}; } // applied at commit
+        if (inTxn_) { // in-memory mode: apply now, remember how to undo it
+            Undo u;
+            if (const auto* i = std::get_if<InsertOp>(&op)) {
+                for (const auto& r : i->records) {
+                    auto have = table_.getVector(r.chunk_id);
+                    if (have && have.value()) u.previous.push_back(*have.value());
+                    u.inserted.push_back(r.chunk_id);
+                }
+            } else if (const auto* d = std::get_if<DeleteOp>(&op)) {
+                auto have = table_.getVector(d->chunk_id);
+                if (have && have.value()) u.previous.push_back(*have.value());
+            } else {
+                const auto& h = std::get<DeleteDocOp>(op).document_hash;
+                table_.forEachRecord([&](const VectorRecord& r) { if (r.document_hash == h) u.previous.push_back(r); });
+            }
+            auto s = applyToMirror(op);
+            if (s) undo_.push_back(std::move(u));
+            return s;
+        }
+        auto s = applyToMirror(op);
+        if (!s && durable_) { mirrorStale_ = true; return {}; } // the durable store HAS the change: re-warm before the next search
+        return s;
+    }
+    // (re)builds the mirror from the durable rows (document-level rows included)
+    Result<void> warmLocked() {
+        std::vector<VectorRecord> all;
+        auto hashes = durable_->getEmbeddedDocumentHashes();
+        if (!hashes) return hashes.error();
+        for (const auto& h : hashes.value()) {
+            auto rows = durable_->getVectorsByDocument(h);
+            if (!rows) return rows.error();
+            for (auto& r : rows.value()) all.push_back(std::move(r));
+        }
+        if (!all.empty())
+            if (auto s = table_.insertVectorsBatch(all); !s) return s;
+        return {};
+    }
+    // Everything a search may have to WRITE happens here, under the exclusive lock: re-warming a stale mirror and
+    // uploading rows appended since the last search.  The search itself then only reads (shared lock).
+    Result<void> syncForSearch() {
+        {
+            std::shared_lock rd(mu_);
+            if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+            if (!mirrorStale_ && !table_.needsSync()) return {};
+        }
+        std::unique_lock lk(mu_);
+        if (auto s = rewarmIfStaleLocked(); !s) return s;
+        return table_.sync();
+    }
+    Result<void> rewarmIfStaleLocked() {
+        if (!mirrorStale_ || !durable_) return {};
+        table_.clear();
+        if (auto s = warmLocked(); !s) return s; // (still stale: the next search tries again)
+        mirrorStale_ = false;
+        return {};
+    }
     static void resetKeepingCollectFlag(VectorSearchDiagnostics& d) {
         const bool collect = d.collectVisitedDocumentHashes;
         d = {};
@@ -255,8 +368,13 @@ private:
     search(const std::vector<float>& q, size_t k, float thr, const std::optional<std::string>& document_hash,
            const std::unordered_set<std::string>& candidate_hashes, const std::map<std::string, std::string>& metadata_filters,
            VectorSearchDiagnostics* diagnostics, ExactRowSelection selection) {
-        std::unique_lock lk(mu_); // (the lazy mirror upload mutates; the scan itself is the long part and runs on the device)
+        if (auto s = syncForSearch(); !s) return s.error();
+        std::shared_lock lk(mu_); // the scan is the long part: searches share the lock, only the mirror upload excludes
         if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (mirrorStale_ || table_.needsSync()) { // a writer slipped in between the two locks: synchronise again
+            lk.unlock();
+            return search(q, k, thr, document_hash, candidate_hashes, metadata_filters, diagnostics, selection);
+        }
         if (q.empty() || (selection == ExactRowSelection::TopK && k == 0)) return std::vector<VectorRecord>{}; // :4123-4126
         if (selection == ExactRowSelection::AllMatching)
             return table_.searchSimilarRows(q, k, thr, candidate_hashes, diagnostics, selection);
@@ -290,6 +408,9 @@ private:
     mutable std::shared_mutex mu_;
     bool initialized_ = false, tables_ = false;
     size_t dim_ = 0;
+    bool inTxn_ = false, mirrorStale_ = false;
+    std::vector<Op> journal_;   // durable mode: mutations of the open transaction, applied to the mirror at commit
+    std::vector<Undo> undo_;    // in-memory mode: how to put the previous rows back on rollback
 };
 
 // The C-linkage object factory a C++ host may prefer over the vtable door (precedent:

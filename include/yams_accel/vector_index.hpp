@@ -308,7 +308,19 @@ private:
         deviceRows_ = records_.size();
         return {};
     }
+public:
+    // Pending work for the device mirror (rows appended since the last upload, tombstones worth compacting, a stale
+    // chunk_id ranking)?  Searches synchronise lazily; a host that serves concurrent searches under a shared lock
+    // (vector_database.cpp:539,618) calls sync() under its exclusive lock first — with nothing pending a search only
+    // reads this object.
+    bool needsSync() const {
+        return (dead_ > 1024 && dead_ * 4 > records_.size()) || records_.size() > deviceRows_ ||
+               (ranksDirty_ && !records_.empty() && !idOrdered_);
+    }
+    Result<void> sync() { return syncMirror(); }
+private:
     Result<void> syncMirror() {
+        if (!needsSync()) return {};
         if (dead_ > 1024 && dead_ * 4 > records_.size()) { // compact: drop the tombstones, re-upload
             std::vector<VectorRecord> keep;
             std::vector<uint8_t> zn;
@@ -553,6 +565,17 @@ public:
     template <typename Fn> void forEachRecord(Fn&& fn) const {
         for (const auto& [dim, idx] : byDim_) idx->forEachRecord(fn);
     }
+    bool needsSync() const {
+        for (const auto& [dim, idx] : byDim_) if (idx->needsSync()) return true;
+        return false;
+    }
+    Result<void> sync() {
+        for (auto& [dim, idx] : byDim_) if (auto s = idx->sync(); !s) return s;
+        return {};
+    }
+    // Drops every mirror (the device memory is parked by the plugin for the next corpus): what a re-warm from the
+    // durable store starts from.
+    void clear() { byDim_.clear(); dimOf_.clear(); }
     Result<std::optional<VectorRecord>> getVector(const std::string& chunkId) const {
         auto it = dimOf_.find(chunkId);
         if (it == dimOf_.end()) return std::optional<VectorRecord>{};

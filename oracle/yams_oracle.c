@@ -406,6 +406,61 @@ ORACLE_API long oracle_exact_scan_l2(const float* corpus, size_t n_rows, size_t 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * The OTHER plausible definition of the vec0 distance: fp32 accumulation.  The public sqlite-vec (and, most
+ * likely, the absent trvon/sqlite-vec-cpp) accumulates (a_i - b_i)^2 in float — sequentially in its scalar form,
+ * in 4 / 8 / 16 independent lanes that are summed at the end in its NEON / AVX forms (src/vector/meson.build:76-106
+ * sets the SIMD flags for that dependency).  The fp64 definition above is THIS repository's choice; these variants
+ * exist so that tests and bench.py can REPORT how far the choice matters (distances agree to ~1e-6 relative, the
+ * top-k index SET differs only when two rows sit within that of each other at the cut): `lanes` = 1 sequential,
+ * else that many round-robin partial sums (element i goes to lane i % lanes) added left to right.
+ * ---------------------------------------------------------------------------------------------- */
+ORACLE_API float oracle_l2_distance_f32acc(const float* a, const float* b, size_t dim, int lanes) {
+    if (lanes <= 1) {
+        float acc = 0.0f;
+        for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; acc += d * d; }
+        return sqrtf(acc);
+    }
+    float part[64];
+    if (lanes > 64) lanes = 64;
+    for (int l = 0; l < lanes; ++l) part[l] = 0.0f;
+    for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; part[i % (size_t)lanes] += d * d; }
+    float acc = 0.0f;
+    for (int l = 0; l < lanes; ++l) acc += part[l];
+    return sqrtf(acc);
+}
+/* rows[m][dim] against one query */
+ORACLE_API void oracle_l2_distance_f32acc_many(const float* rows, const float* query, size_t m, size_t dim, int lanes,
+                                               float* out) {
+    for (size_t r = 0; r < m; ++r) out[r] = oracle_l2_distance_f32acc(rows + r * dim, query, dim, lanes);
+}
+/* the whole scan under that definition (same contract as oracle_exact_scan_l2) */
+ORACLE_API long oracle_exact_scan_l2_f32acc(const float* corpus, size_t n_rows, size_t dim, const float* query, size_t k,
+                                            float similarity_threshold, const uint64_t* tie_rank, int lanes,
+                                            int64_t* out_rows, float* out_dist, float* out_sims) {
+    if (dim == 0 || k == 0) return 0;
+    oracle_l2hit* all = (oracle_l2hit*)malloc(sizeof(oracle_l2hit) * (n_rows ? n_rows : 1));
+    size_t m = 0;
+    for (size_t r = 0; r < n_rows; ++r) {
+        const float* e = corpus + r * dim;
+        int finite = 1;
+        for (size_t i = 0; i < dim; ++i) if (!isfinite(e[i])) { finite = 0; break; }
+        if (!finite) continue;
+        const float dd = oracle_l2_distance_f32acc(e, query, dim, lanes);
+        if (!isfinite(dd)) continue;
+        all[m].dist = dd; all[m].rank = tie_rank ? tie_rank[r] : (uint64_t)r; all[m].row = (int64_t)r; ++m;
+    }
+    qsort(all, m, sizeof(oracle_l2hit), l2_cmp);
+    size_t take = m < k ? m : k, outn = 0;
+    for (size_t i = 0; i < take; ++i) {
+        float sim = (float)oracle_cosine_similarity(query, corpus + (size_t)all[i].row * dim, dim);
+        if (sim < similarity_threshold) continue;
+        out_rows[outn] = all[i].row; out_dist[outn] = all[i].dist; out_sims[outn] = sim; ++outn;
+    }
+    free(all);
+    return (long)outn;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic-data recipes shared by tests and bench (so the CPU side can regenerate any slice).
  * Philox4x32-10 counter-based generator (Salmon et al., SC'11): key = (seed_lo, seed_hi),
  * counter = (i0, i1, i2, i3).  Used for corpora too large to hold on the host.

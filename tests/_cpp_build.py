@@ -27,7 +27,7 @@ def build_real_headers_test(reference: str = "/root/reference"):
                 os.path.join(reference, "src", "chunking", "rabin_chunker.cpp"),
                 os.path.join(reference, "src", "chunking", "streaming_chunker.cpp")]
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++20", "-O1", "-Wall", "-Wno-unused-variable", "-DYAMS_ACCEL_USE_HOST_TYPES",
+    cmd = [cxx, "-std=c++20", "-O1", "-g", "-rdynamic", "-Wall", "-Wno-unused-variable", "-DYAMS_ACCEL_USE_HOST_TYPES",
            "-I" + os.path.join(root, "oracle", "shim"), "-I" + os.path.join(reference, "include"),
            "-I" + os.path.join(reference, "src", "chunking"), "-I" + os.path.join(root, "include"),
            "-o", exe, src, *ref_srcs, "-lcrypto", "-lpthread", "-ldl"]

@@ -67,6 +67,11 @@ class Oracle:
         L.oracle_exact_scan_l2.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                            C.c_float, u64p, i64p, f32p, f32p]
         L.oracle_exact_scan_l2.restype = C.c_long
+        L.oracle_exact_scan_l2_f32acc.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_float, u64p, C.c_int,
+                                                  i64p, f32p, f32p]
+        L.oracle_exact_scan_l2_f32acc.restype = C.c_long
+        L.oracle_l2_distance_f32acc_many.argtypes = [f32p, f32p, C.c_size_t, C.c_size_t, C.c_int, f32p]
+        L.oracle_l2_distance_f32acc_many.restype = None
         L.oracle_cosine_similarity.argtypes = [f32p, f32p, C.c_size_t]
         L.oracle_cosine_similarity.restype = C.c_double
         L.oracle_philox4x32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
@@ -148,6 +153,26 @@ class Oracle:
         cnt = self.L.oracle_exact_scan_l2(_ptr(corpus, f32p), n, d, _ptr(query, f32p), k, thr, tr,
                                           _ptr(rows, i64p), _ptr(dist, f32p), _ptr(sims, f32p))
         return rows[:cnt].copy(), dist[:cnt].copy(), sims[:cnt].copy()
+
+    def scan_l2_f32acc(self, corpus, query, k, thr=-1.0, tie_rank=None, lanes=1):
+        """The vec0 scan under the OTHER plausible definition: fp32 accumulation (sequential, or `lanes` SIMD-style
+        partial sums) — what the absent sqlite-vec-cpp most likely does.  For reports, not for parity."""
+        corpus = np.ascontiguousarray(corpus, np.float32); query = np.ascontiguousarray(query, np.float32)
+        n, d = corpus.shape
+        rows = np.full(max(k, 1), -1, np.int64); dist = np.zeros(max(k, 1), np.float32)
+        sims = np.zeros(max(k, 1), np.float32)
+        tr = None
+        if tie_rank is not None:
+            tie_rank = np.ascontiguousarray(tie_rank, np.uint64); tr = _ptr(tie_rank, u64p)
+        cnt = self.L.oracle_exact_scan_l2_f32acc(_ptr(corpus, f32p), n, d, _ptr(query, f32p), k, thr, tr, lanes,
+                                                 _ptr(rows, i64p), _ptr(dist, f32p), _ptr(sims, f32p))
+        return rows[:cnt].copy(), dist[:cnt].copy(), sims[:cnt].copy()
+
+    def l2_f32acc_many(self, rows, query, lanes=1):
+        rows = np.ascontiguousarray(rows, np.float32); query = np.ascontiguousarray(query, np.float32)
+        out = np.empty(rows.shape[0], np.float32)
+        self.L.oracle_l2_distance_f32acc_many(_ptr(rows, f32p), _ptr(query, f32p), rows.shape[0], rows.shape[1], lanes, _ptr(out, f32p))
+        return out
 
     def cosine(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
@@ -328,3 +353,37 @@ def scan_threaded(get_slice, n_rows, queries, k, metric="cosine", thr=-1.0, slic
             keep = ~(sims < np.float32(thr))      # vec0: k nearest, THEN the cosine threshold (:4506-4510)
             res.append((rows[keep], sims[keep], dist[keep]))
     return res
+
+
+def l2_definition_report(o, fetch_rows, queries, rows64, dist64, k):
+    """How much the choice of the L2 accumulation precision matters.  `rows64` / `dist64` [nq][K]: the top
+    K > k rows of every query under THIS repository's definition (fp64 accumulate), e.g. from the device; for those
+    candidates the distance is recomputed with fp32 accumulation (sequential, 8 and 16 SIMD-style lanes) and the top-k
+    SET and ORDER under each variant are compared with the fp64 ones.  Conclusive for a query when no candidate beyond
+    rank K could overtake the cut: the fp64 gap between rank k and rank K exceeds twice the largest measured
+    |d32 - d64| of the query."""
+    nq, K = rows64.shape
+    out = {"queries": int(nq), "k": int(k), "candidates_per_query": int(K), "variants": {}}
+    for name, lanes in (("f32_sequential", 1), ("f32_simd8", 8), ("f32_simd16", 16)):
+        set_diff = order_diff = inconclusive = 0
+        max_abs = max_rel = 0.0
+        for qi in range(nq):
+            rr = rows64[qi]
+            cand = fetch_rows(rr)
+            d32 = o.l2_f32acc_many(cand, queries[qi], lanes)
+            d64 = dist64[qi]
+            err = float(np.abs(d32.astype(np.float64) - d64.astype(np.float64)).max())
+            max_abs = max(max_abs, err)
+            max_rel = max(max_rel, float((np.abs(d32.astype(np.float64) - d64) / np.maximum(d64, 1e-30)).max()))
+            if not (float(d64[K - 1]) - float(d64[k - 1]) > 2.0 * err):
+                inconclusive += 1
+            order32 = np.lexsort((rr, d32))[:k]          # (distance asc, row id asc)
+            top32 = rr[order32]
+            if set(top32.tolist()) != set(rr[:k].tolist()):
+                set_diff += 1
+            if not np.array_equal(top32, rr[:k]):
+                order_diff += 1
+        out["variants"][name] = {"top_k_sets_that_differ": set_diff, "top_k_orders_that_differ": order_diff,
+                                 "queries_not_conclusive": inconclusive, "max_abs_distance_difference": max_abs,
+                                 "max_rel_distance_difference": max_rel}
+    return out

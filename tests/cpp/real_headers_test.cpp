@@ -9,6 +9,11 @@
 // Usage: real_headers_test <path/to/libyams_mi355x_accel.so> [--expect-no-gpu]
 #include <yams/chunking/chunker.h>
 #include <yams/chunking/streaming_chunker.h>
+#include <atomic>
+#include <csignal>
+#include <execinfo.h>
+#include <thread>
+#include <unistd.h>
 #include <yams/crypto/hasher.h>
 #include <yams/vector/vector_store.h>
 
@@ -44,7 +49,71 @@ static float refCosine(const std::vector<float>& q, const std::vector<float>& x)
     return static_cast<float>(dot / (std::sqrt(nsq) * std::sqrt(qsq)));
 }
 
+// A durable IVectorStore for the transaction tests: rows in a map, a snapshot taken at BEGIN and put back at ROLLBACK
+// (what SqliteVecBackend's BEGIN IMMEDIATE ... COMMIT / ROLLBACK amounts to for these calls).  It never searches.
+struct FakeDurableStore final : vector::IVectorStore {
+    std::map<std::string, vector::VectorRecord> rows, snapshot;
+    bool inTxn = false, init = false;
+    int failNextCommit = 0;
+    Result<void> initialize(const std::string&) override { init = true; return {}; }
+    void close() override { init = false; }
+    bool isInitialized() const override { return init; }
+    Result<void> createTables(size_t) override { return {}; }
+    bool tablesExist() const override { return true; }
+    Result<void> insertVector(const vector::VectorRecord& r) override { rows[r.chunk_id] = r; return {}; }
+    Result<void> insertVectorsBatch(const std::vector<vector::VectorRecord>& rs) override { for (auto& r : rs) rows[r.chunk_id] = r; return {}; }
+    Result<void> updateVector(const std::string& id, const vector::VectorRecord& r) override {
+        if (!rows.count(id)) return Error{ErrorCode::NotFound, "chunk not found"};
+        rows[id] = r; rows[id].chunk_id = id; return {};
+    }
+    Result<void> deleteVector(const std::string& id) override { rows.erase(id); return {}; }
+    Result<void> deleteVectorsByDocument(const std::string& h) override {
+        for (auto it = rows.begin(); it != rows.end();) it = it->second.document_hash == h ? rows.erase(it) : std::next(it);
+        return {};
+    }
+    Result<std::vector<vector::VectorRecord>> searchSimilar(const std::vector<float>&, size_t, float, const std::optional<std::string>&,
+                                                            const std::unordered_set<std::string>&,
+                                                            const std::map<std::string, std::string>&) override {
+        return Error{ErrorCode::NotImplemented, "the durable store does not search"};
+    }
+    Result<std::vector<std::vector<vector::VectorRecord>>> searchSimilarBatch(const std::vector<std::vector<float>>&, size_t, float, size_t) override {
+        return Error{ErrorCode::NotImplemented, "the durable store does not search"};
+    }
+    Result<std::optional<vector::VectorRecord>> getVector(const std::string& id) override {
+        auto it = rows.find(id);
+        return it == rows.end() ? std::optional<vector::VectorRecord>{} : std::optional<vector::VectorRecord>{it->second};
+    }
+    Result<std::map<std::string, vector::VectorRecord>> getVectorsBatch(const std::vector<std::string>& ids) override {
+        std::map<std::string, vector::VectorRecord> out;
+        for (auto& id : ids) if (rows.count(id)) out[id] = rows[id];
+        return out;
+    }
+    Result<std::vector<vector::VectorRecord>> getVectorsByDocument(const std::string& h) override {
+        std::vector<vector::VectorRecord> out;
+        for (auto& [id, r] : rows) if (r.document_hash == h) out.push_back(r);
+        return out;
+    }
+    Result<std::unordered_map<std::string, vector::VectorRecord>> getDocumentLevelVectorsAll() override { return std::unordered_map<std::string, vector::VectorRecord>{}; }
+    Result<size_t> forEachDocumentLevelVector(const std::function<bool(vector::VectorRecord&&)>&) override { return size_t(0); }
+    Result<bool> hasEmbedding(const std::string& h) override { for (auto& [id, r] : rows) if (r.document_hash == h) return true; return false; }
+    Result<std::unordered_set<std::string>> getEmbeddedDocumentHashes() override {
+        std::unordered_set<std::string> out;
+        for (auto& [id, r] : rows) out.insert(r.document_hash);
+        return out;
+    }
+    Result<size_t> getVectorCount() override { return rows.size(); }
+    Result<vector::VectorDatabaseStats> getStats() override { vector::VectorDatabaseStats st; st.total_vectors = rows.size(); return st; }
+    Result<void> beginTransaction() override { if (inTxn) return Error{ErrorCode::InvalidState, "nested"}; inTxn = true; snapshot = rows; return {}; }
+    Result<void> commitTransaction() override {
+        if (failNextCommit) { --failNextCommit; return Error{ErrorCode::DatabaseError, "commit failed"}; }
+        inTxn = false; return {};
+    }
+    Result<void> rollbackTransaction() override { if (inTxn) rows = snapshot; inTxn = false; return {}; }
+};
+
 int main(int argc, char** argv) {
+    std::setvbuf(stdout, nullptr, _IONBF, 0); // (a crash must not swallow the failures printed before it)
+    std::signal(SIGSEGV, [](int) { void* bt[48]; const int n = backtrace(bt, 48); backtrace_symbols_fd(bt, n, 1); _exit(139); });
     if (argc < 2) { std::printf("usage: %s <plugin.so> [--expect-no-gpu]\n", argv[0]); return 2; }
     const bool expectNoGpu = argc > 2 && std::strcmp(argv[2], "--expect-no-gpu") == 0;
     auto loaded = accel::Plugin::load(argv[1], "{\"device\":0}");
@@ -57,6 +126,7 @@ int main(int argc, char** argv) {
     auto plugin = loaded.value();
     static_assert(static_cast<int>(ErrorCode::Unknown) == 36, "the host's ErrorCode (core/types.h:25-63)");
 
+    std::printf("[section] hasher\n");
     // ---- IContentHasher: the accelerator next to the reference's SHA256Hasher -----------------------------
     {
         auto made = crypto::createAccelSHA256Hasher(plugin);
@@ -89,6 +159,7 @@ int main(int argc, char** argv) {
         CHECK(!bad.has_value() && bad.error().code == ErrorCode::FileNotFound);   // sha256_hasher.cpp:152-161
         std::filesystem::remove(path);
     }
+    std::printf("[section] lone chains\n");
     // ---- lone long chains are the HOST's: the vtable refuses them, the adapter hands them to the host's hasher ----
     {
         auto vt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, YAMS_IFACE_CONTENT_HASH_V1_VERSION);
@@ -146,6 +217,7 @@ int main(int argc, char** argv) {
         for (auto& pth : paths) std::filesystem::remove(pth);
     }
 
+    std::printf("[section] chunker\n");
     // ---- IChunker: both chunkers next to the reference's ---------------------------------------------------
     for (int kind = 0; kind < 2; ++kind) {
         chunking::ChunkingConfig cfg;
@@ -192,6 +264,7 @@ int main(int argc, char** argv) {
         CHECK(batcher.value()->chunkMany({}, true).chunks.empty());
     }
 
+    std::printf("[section] vector store\n");
     // ---- IVectorStore + capability seams ---------------------------------------------------------------------
     {
         std::unique_ptr<vector::IVectorStore> backend = vector::createAccelExactScanBackend(plugin);
@@ -292,6 +365,72 @@ int main(int argc, char** argv) {
         backend->close();
         CHECK(!backend->isInitialized());
         CHECK(backend->searchSimilar(q, 1, -1.0f).error().code == ErrorCode::NotInitialized);
+    }
+
+    std::printf("[section] transactions\n");
+    // ---- transactions: the device mirror holds COMMITTED state (phantom chunk_ids after a rollback) -----
+    for (int durableMode = 0; durableMode < 2; ++durableMode) {
+        auto durable = std::make_shared<FakeDurableStore>();
+        std::unique_ptr<vector::IVectorStore> backend =
+            vector::createAccelExactScanBackend(plugin, durableMode ? std::static_pointer_cast<vector::IVectorStore>(durable) : nullptr);
+        const size_t dim = 64;
+        std::mt19937 rng(7);
+        auto rec = [&](const std::string& id, const std::string& doc) { return vector::VectorRecord(id, doc, unit(rng, dim), "c"); };
+        if (durableMode) { // rows that exist before initialize(): the mirror is warmed from the durable store
+            (void)durable->insertVector(rec("chunk_old_1", "doc_old"));
+            (void)durable->insertVector(rec("chunk_old_2", "doc_old"));
+        }
+        CHECK(backend->initialize(":memory:").has_value() && backend->createTables(dim).has_value());
+        if (!durableMode) { CHECK(backend->insertVector(rec("chunk_old_1", "doc_old")).has_value()); CHECK(backend->insertVector(rec("chunk_old_2", "doc_old")).has_value()); }
+        const auto target = rec("chunk_new", "doc_new");
+        const auto old1 = backend->getVector("chunk_old_1").value().value();
+        auto top = [&](const std::vector<float>& qq) { auto r = backend->searchSimilar(qq, 1, -1.0f); return r && !r.value().empty() ? r.value().front().chunk_id : std::string("<none>"); };
+        CHECK(top(old1.embedding) == "chunk_old_1");
+        // rollback: an inserted row never becomes searchable, a deleted row is back, a replaced row has its old vector
+        CHECK(backend->beginTransaction().has_value());
+        CHECK(!backend->beginTransaction().has_value());                          // one transaction at a time
+        CHECK(backend->insertVector(target).has_value());
+        CHECK(backend->deleteVector("chunk_old_2").has_value());
+        vector::VectorRecord repl = old1; repl.embedding = target.embedding;
+        CHECK(backend->updateVector("chunk_old_1", repl).has_value());
+        CHECK(backend->rollbackTransaction().has_value());
+        CHECK(top(target.embedding) != "chunk_new");
+        {
+            const auto found = backend->searchSimilar(target.embedding, 10, -1.0f);
+            CHECK(found.has_value());
+            for (const auto& r : found.value()) CHECK(backend->getVector(r.chunk_id).value().has_value());   // no phantom ids
+        }
+        CHECK(backend->getVector("chunk_old_2").value().has_value() && !backend->getVector("chunk_new").value().has_value());
+        CHECK(top(old1.embedding) == "chunk_old_1" && backend->getVectorCount().value() == 2);
+        // commit: everything of the transaction becomes searchable, in order (insert, then replace, then a document delete)
+        CHECK(backend->beginTransaction().has_value());
+        CHECK(backend->insertVector(target).has_value());
+        CHECK(backend->insertVector(rec("chunk_gone", "doc_gone")).has_value());
+        CHECK(backend->deleteVectorsByDocument("doc_gone").has_value());
+        if (durableMode) CHECK(top(target.embedding) != "chunk_new");             // durable mode: not before the commit
+        CHECK(backend->commitTransaction().has_value());
+        CHECK(top(target.embedding) == "chunk_new" && backend->getVectorCount().value() == 3);
+        CHECK(!backend->hasEmbedding("doc_gone").value());
+        if (durableMode) {
+            // a commit the durable store refuses leaves the transaction open; the rollback that follows drops the journal
+            CHECK(backend->beginTransaction().has_value());
+            CHECK(backend->insertVector(rec("chunk_never", "doc_never")).has_value());
+            durable->failNextCommit = 1;
+            CHECK(!backend->commitTransaction().has_value());
+            CHECK(backend->rollbackTransaction().has_value());
+            CHECK(!backend->getVector("chunk_never").value().has_value());
+            const auto found = backend->searchSimilar(target.embedding, 10, -1.0f);
+            CHECK(found.has_value());
+            for (const auto& r : found.value()) CHECK(r.chunk_id != "chunk_never");
+        }
+        // searches share the lock: four threads at once, same answers
+        {
+            std::vector<std::thread> th; std::atomic<int> ok{0};
+            for (int t = 0; t < 4; ++t) th.emplace_back([&] { for (int i = 0; i < 5; ++i) if (top(target.embedding) == "chunk_new") ++ok; });
+            for (auto& t : th) t.join();
+            CHECK(ok == 20);
+        }
+        backend->close();
     }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
     return failures ? 1 : 0;

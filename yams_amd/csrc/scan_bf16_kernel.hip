@@ -200,146 +200,6 @@ __device__ __forceinline__ void bf16_epilogue(const ScanArgs& a, f32x16 (&acc)[N
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Epilogue of the INT8 filter tier (cosine).  acc[u][r] = the EXACT integer dot product of the
-// quantised row and query, xi . qi.  With x~ = s_r xi + d_r (unit row, quantisation residue d_r) and
-// q~ = t_q qi + p_q:      cos = x~ . q~ = s_r t_q (xi . qi) + d_r . (t_q qi) + x~ . p_q
-//                             <= s_r t_q I + e_r c_q + f_q =: u(r, q)
-// (e_r >= |d_r| per row from the shadow build, c_q = |t_q qi| and f_q >= |p_q| + rounding slop per
-// query from prep_i8_kernel; Cauchy-Schwarz, |x~| = 1).  The filter score of this tier IS that
-// upper bound, so the completeness proof of the re-score needs no further error term.
-// A row survives iff u >= tau_q  <=>  I >= (tau_q - f_q - e_r c_q) / (s_r t_q).  The cheap reject
-// compares the lane's maximum I of a query block against the SMALLEST such threshold of the 32-row
-// block (from the block's min/max 1/s_r and max e_r/s_r: three 32-lane reductions per block), in
-// integers' clothing: one v_max tree per block exactly like the bf16 tier; only hot blocks (~0.1 %)
-// evaluate u per element.  Rows whose norm is out of range carry e_r = +inf (always a candidate).
-// -------------------------------------------------------------------------------------------------
-template <int MODE, int NCB, int PHASE = 0>
-__device__ __forceinline__ void i8_epilogue(const ScanArgs& a, i32x16 (&acc)[NCB], float s_row, float e_row,
-                                            uint64_t row0, uint32_t row_in_tile, uint32_t q0, uint32_t sel,
-                                            int h, int l31, const float2* lds_meta /* [tile rows] {s_r, e_r} */,
-                                            const float* q_t, const float* q_c,
-                                            const float* q_f, const float* tau_pre,
-                                            uint32_t* pend_pass = nullptr, uint32_t* pend_base = nullptr) {
-    static_assert(PHASE == 0 || MODE == MODE_FILTER, "phases exist for the filter epilogue only");
-    uint32_t qidx[NCB];
-    bool qok[NCB];
-#pragma unroll
-    for (int u = 0; u < NCB; ++u) {
-        qidx[u] = q0 + u * 32 + l31;
-        qok[u] = qidx[u] < a.n_queries;
-    }
-    const uint64_t wave_row0 = row0 + row_in_tile;
-    constexpr int I_MASKED = static_cast<int>(0x80000000u);
-    if (PHASE != 2 && a.row_mask) { // rows outside the allow-mask never score
-        const uint32_t mw = mask_word(a.row_mask, wave_row0, a.n_rows);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (!((mw >> i) & 1u)) {
-#pragma unroll
-                for (int u = 0; u < NCB; ++u) acc[u][r] = I_MASKED;
-            }
-        }
-    }
-    // u(r, q) of accumulator element r of query block uu_.  The row factors come from the tile's
-    // LDS copy (a per-lane read: safe under divergence, unlike a cross-lane shuffle).
-    auto upper = [&](int uu_, int r) -> float {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float2 me = lds_meta[row_in_tile + i];
-        const int I = acc[uu_][r];
-        const float v = fmaf(static_cast<float>(I), me.x * q_t[uu_], fmaf(me.y, q_c[uu_], q_f[uu_]));
-        return I == I_MASKED ? -__builtin_inff() : v;
-    };
-    if (MODE == MODE_SAMPLE) {
-        const float ninf = -__builtin_inff();
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) {
-            float m = ninf;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const uint64_t rbase = wave_row0 + 8 * g4 + 4 * h;
-                float4 v;
-                v.x = (rbase + 0 < a.n_rows) ? upper(u, 4 * g4 + 0) : ninf;
-                v.y = (rbase + 1 < a.n_rows) ? upper(u, 4 * g4 + 1) : ninf;
-                v.z = (rbase + 2 < a.n_rows) ? upper(u, 4 * g4 + 2) : ninf;
-                v.w = (rbase + 3 < a.n_rows) ? upper(u, 4 * g4 + 3) : ninf;
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-                if (qok[u]) {
-                    const uint64_t srow = static_cast<uint64_t>(sel) * BT_ROWS + row_in_tile + 8 * g4 + 4 * h;
-                    *reinterpret_cast<float4*>(a.dense + dense_index(qidx[u], srow, a.n_queries)) = v;
-                }
-            }
-            if (qok[u]) {
-                const uint32_t gid = (sel * BT_ROWS + row_in_tile) / 16u + h;
-                a.gmax[static_cast<uint64_t>(qidx[u]) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
-            }
-        }
-        return;
-    }
-    uint32_t pass[NCB], base[NCB];
-    if (PHASE == 2) {
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) { pass[u] = pend_pass[u]; base[u] = pend_base[u]; }
-    } else {
-        // the block's extreme row factors (lanes l and l + 32 hold the same row: reduce over 32 lanes)
-        const float is = 1.0f / s_row;             // s_row > 0 always (1.0 for rows without a usable norm)
-        float min_is = is, max_is = is, max_g = e_row * is;
-#pragma unroll
-        for (int dlt = 16; dlt >= 1; dlt >>= 1) {
-            min_is = fminf(min_is, __shfl_xor(min_is, dlt));
-            max_is = fmaxf(max_is, __shfl_xor(max_is, dlt));
-            max_g = fmaxf(max_g, __shfl_xor(max_g, dlt));
-        }
-        uint32_t hot = 0;
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) {
-            int m = acc[u][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = acc[u][r] > m ? acc[u][r] : m;
-            const float A = (tau_pre[u] - q_f[u]) / q_t[u];
-            const float B = q_c[u] / q_t[u];
-            float Tm = (A >= 0.f ? A * min_is : A * max_is) - B * max_g;
-            Tm -= fabsf(Tm) * 3.8146973e-6f + 2.0f;     // 2^-18 relative + 2: rcp / product / conversion rounding
-            if (!(static_cast<float>(m) < Tm) && qok[u]) hot |= 1u << u; // (a NaN threshold keeps the block)
-        }
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) {
-            pass[u] = 0u;
-            if ((hot >> u) & 1u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = upper(u, r);
-                    if (!(v < tau_pre[u]) && row < a.n_rows && acc[u][r] != I_MASKED) pass[u] |= 1u << r;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NCB; ++u) {
-            base[u] = 0u;
-            if (pass[u]) base[u] = atomicAdd(&a.list_count[qidx[u]], static_cast<uint32_t>(__builtin_popcount(pass[u])));
-        }
-        if (PHASE == 1) {
-#pragma unroll
-            for (int u = 0; u < NCB; ++u) { pend_pass[u] = pass[u]; pend_base[u] = base[u]; }
-            return;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NCB; ++u) {
-        if (!pass[u]) continue;
-        uint32_t pos = base[u];
-        uint64_t* lst = a.list + static_cast<uint64_t>(qidx[u]) * a.list_cap;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (!((pass[u] >> r) & 1u)) continue;
-            const uint64_t row = wave_row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (pos < a.list_cap) lst[pos] = pack_key(upper(u, r), static_cast<uint32_t>(row));
-            ++pos;
-        }
-    }
-}
 
 // =================================================================================================
 // v2: LDS-DMA staged, 4-deep ring, one A tile per wave.

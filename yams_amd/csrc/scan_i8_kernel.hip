@@ -1134,7 +1134,10 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
         bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-        const bool ok = !bad && amax > 0.f;
+        // (a subnormal largest component — squared norm < 1e-74 — would overflow 1 / amax: such a row is unusable like
+        // an all-zero one; the reference never returns it under cosine (:4267-4269), under L2 it travels with the
+        // rows whose norm is outside norm_in_range())
+        const bool ok = !bad && amax >= 1.17549435e-38f;
         const float ia = ok ? 1.0f / amax : 0.f;
         float nsq = 0.f;
         for (uint32_t c = lane * 4; c < dim; c += 256) {
