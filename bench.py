@@ -175,10 +175,33 @@ def ingest_leg(acc, torch, gib, seed):
     acc.synchronize()
     acc.enable_timing(True)
     reps = 3
+    # clock / power / throttle reason of the device while the timed calls run (the roofline below is priced at the
+    # nominal 2.4 GHz: what the part actually clocks at under this integer load says how much of the gap is the clock)
+    tel = None
+    try:
+        from yams_amd import telemetry as ytel
+        bus = ytel.hip_pci_bus(torch.cuda.current_device())
+        hw = ytel.hwmon_dir(bus)
+        thr = ytel.Throttle(bus)
+        smp = ytel.HwmonSampler(hw) if hw else None
+        if smp:
+            smp.start()
+        snap_a = thr.snapshot()
+    except Exception:      # noqa: BLE001
+        smp = thr = snap_a = None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
         res = acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=3)
-    acc.synchronize(); dt = (time.perf_counter() - t0) / reps
+    acc.synchronize(); t1 = time.perf_counter(); dt = (t1 - t0) / reps
+    try:
+        if thr is not None:
+            snap_b = thr.snapshot()
+            if smp:
+                smp.stop = True; smp.join()
+            tel = {"hwmon": smp.window(t0 + 0.05, t1) if smp else None,
+                   "throttle": thr.between(snap_a, snap_b) if snap_a and snap_b else {"error": thr.error}}
+    except Exception as e:  # noqa: BLE001
+        tel = {"error": repr(e)}
     sha_ms, _ = acc.kernel_ms("sha256")
     cdc_ms, _ = acc.kernel_ms("cdc_candidates")
     acc.enable_timing(False)
@@ -202,6 +225,11 @@ def ingest_leg(acc, torch, gib, seed):
            "bit_exact_vs_cpu_sample": verified,
            "roofline": {"bound": "valu-issue (int32)", "achieved": total / dt / 1e9, "peak": total / floor_s / 1e9,
                         "unit": "GB/s", "frac": floor_s / dt,
+                        "sclk_MHz": ((tel or {}).get("hwmon") or {}).get("sclk_MHz", {}).get("mean") if tel else None,
+                        "frac_at_measured_clock": (floor_s / dt * 2400.0 / (((tel or {}).get("hwmon") or {}).get("sclk_MHz", {}).get("mean") or 2400.0))
+                        if tel and ((tel or {}).get("hwmon") or {}).get("sclk_MHz") else None,
+                        "limiter": ((tel or {}).get("throttle") or {}).get("limiter") if tel else None,
+                        "telemetry": tel,
                         "model": "wave-instructions = SHA blocks/64 x 1400 + bytes x 9/64; floor = that x 4 cycles / "
                                  "(1024 SIMDs x 2.4 GHz)", "model_wave_instructions": wave_instr,
                         "pmc_cross_check": "profiles/r01_ingest_pmc.json (SQ_INSTS_VALU 1.016e11 for the same call: "

@@ -632,7 +632,22 @@ extern "C" yams_status_t yams_scan_topk_device(yams_accel_ctx* ctx,
                                                yams_scan_diag_t* diag) {
     // Very large batches run as slices: the per-batch workspace (sample scores, candidate lists)
     // grows with the query count, and one corpus pass already amortises over 4096 queries.
-    constexpr uint32_t kBatchMax = 4096;
+    uint32_t kBatchMax = 4096;
+    // Calls of more than 1024 queries on a shard whose 1024-query batches take the int8 tier's resident-query form run
+    // as slices of 1024: that form holds at most eight 128-query tiles per row stream, and the half-tile form it would
+    // otherwise fall back to is slower than two resident sweeps (2048 queries on the 12.5M x 768 shard: 18.1 ms in
+    // one half-tile batch against 2 x 8.1 ms).
+    if (n_queries > 1024 && ctx && corpus && params && queries && corpus->rows_i8 && corpus->rows_i8_meta &&
+        (corpus->dim & 63u) == 0 && corpus->dim >= 256 && params->k <= YAMS_SCAN_MAX_K &&
+        !(params->flags & (YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER |
+                           YAMS_SCAN_FLAG_WIDE_TILE | YAMS_SCAN_FLAG_FORCE_EXACT)) &&
+        3 * params->k + 64 <= kRescoreMax && corpus->n_rows >= kMfmaMinRows && corpus->n_rows < (1ull << 32)) {
+        (void)hipSetDevice(ctx->device);
+        ScanLaunch probe;
+        probe.plan = make_plan(corpus->n_rows, corpus->dim, 1024, params->k, true, 1, false);
+        probe.i8_form = (params->flags & YAMS_SCAN_FLAG_RESIDENT_QUERIES) ? 2 : 0;
+        if (i8_takes_resident_form(probe)) kBatchMax = 1024;
+    }
     if (n_queries <= kBatchMax || !ctx || !corpus || !params || !queries)
         return scan_impl(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts,
                          out_dist, out_ranks, diag, false);
