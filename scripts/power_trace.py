@@ -1,7 +1,9 @@
-"""Socket power and shader clock while the filter kernels run (VERDICT r1 #7c): samples the amdgpu hwmon
-files of THIS process's GPU (power1_input, freq1_input) every ~2 ms around sustained loops of the scan
-step at the bench shape, for the int8 resident-query form, the int8 half-tile form and the bf16 tier.
-Prints one JSON object (profiles/r02_power_trace.json is a copy of it)."""
+"""Socket power, shader clock and THROTTLE REASON while the filter kernels run (VERDICT r1 #7c, r2 #2c): samples the amdgpu
+hwmon files of THIS process's GPU (power1_input, freq1_input) every ~2 ms around sustained loops of the scan step at the
+bench shape — the int8 resident-query form, the int8 half-tile form and the bf16 tier — and reads the SMU's throttler
+residency accumulators (amdsmi gpu_metrics: PPT, socket / VR / HBM thermal, prochot) before and after each leg: the share
+of the leg in which each limiter held the clock (yams_amd/telemetry.py).  Prints one JSON object
+(profiles/r03_power_trace.json is a copy of it)."""
 import ctypes, glob, json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -64,16 +66,21 @@ def main():
         pass
     smp = Sampler(hw); smp.start()
     time.sleep(0.5)
+    from yams_amd import telemetry as ytel
+    thr = ytel.Throttle(bus)
+    throttle = {}
     marks = {}
     for name, flags in (("int8_resident_query", 0), ("int8_half_tile", _lib.FLAG_WIDE_TILE), ("bf16_single_pass", _lib.FLAG_NO_I8_FILTER)):
         for _ in range(3):
             acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), flags=flags, want_diag=False)
         acc.enable_timing(True)
+        snap_a = thr.snapshot()
         t0 = time.perf_counter(); steps = 0
         while time.perf_counter() - t0 < 2.5:
             acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), flags=flags, want_diag=False)
             steps += 1
         t1 = time.perf_counter()
+        throttle[name] = thr.between(snap_a, thr.snapshot()) if snap_a else {"error": thr.error}
         fms, fn_ = acc.kernel_ms("scan_filter")
         acc.enable_timing(False)
         marks[name] = (t0, t1, steps, fms)
@@ -88,7 +95,8 @@ def main():
         q = lambda a, x: a[min(len(a) - 1, int(x * len(a)))] if a else None
         out["legs"][name] = {"steps": steps, "ms_per_step": (t1 - t0) / steps * 1e3, "filter_launch_ms": fms, "samples": len(rows),
                              "power_W": {"mean": sum(ps) / max(1, len(ps)), "p10": q(ps, 0.1), "p50": q(ps, 0.5), "p90": q(ps, 0.9), "max": ps[-1] if ps else None},
-                             "sclk_MHz": {"mean": sum(fs) / max(1, len(fs)), "p10": q(fs, 0.1), "p50": q(fs, 0.5), "p90": q(fs, 0.9), "min": fs[0] if fs else None}}
+                             "sclk_MHz": {"mean": sum(fs) / max(1, len(fs)), "p10": q(fs, 0.1), "p50": q(fs, 0.5), "p90": q(fs, 0.9), "min": fs[0] if fs else None},
+                             "throttle": throttle.get(name)}
     print(json.dumps(out))
 
 
