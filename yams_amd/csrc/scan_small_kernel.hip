@@ -56,6 +56,108 @@ __device__ __forceinline__ uint32_t rank_of(const uint64_t* list, uint32_t n_pow
     return r;
 }
 
+// The final selection of ONE query by a group of NT threads (the whole workgroup, or one wave when the chunk holds
+// several queries: then the selections of a chunk run side by side): every workgroup's list is sorted, so list b
+// alone holds kk keys >= its last one and the k best overall are all >= tau = the LARGEST of the lists' last keys;
+// only those candidates are compacted and ranked — a few dozen for ordinary data instead of all n_wg * kk (any
+// number stays correct).  `region`: SM_FINAL_REGION bytes of LDS of the group's own.
+constexpr int SM_FINAL_REGION = 23040;
+template <int NT> __device__ __forceinline__ void group_sync() {
+    if (NT == SM_THREADS) __syncthreads();
+    else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } // (a wave's LDS operations complete in order)
+}
+template <int METRIC, int NT>
+__device__ __forceinline__ void final_select(const SmallScanArgs& a, uint32_t q, uint32_t total, uint32_t kk,
+                                             unsigned char* region, int t) {
+    uint64_t* fkey = reinterpret_cast<uint64_t*>(region);                    // [1024] the survivors
+    uint64_t* fcand = fkey + 1024;                                          // [1024] the candidates (>= tau)
+    uint32_t* fsrc = reinterpret_cast<uint32_t*>(fcand + 1024);             // [1024] their index among the survivors
+    uint32_t* frank_row = fsrc + 1024;                                      // [256]: (L2) survivor index of rank r
+    float* fcs = reinterpret_cast<float*>(frank_row + 256);                 // [256]: (L2) its cosine
+    unsigned long long* s_tau = reinterpret_cast<unsigned long long*>(fcs + 256);
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_tau + 1);               // [0] candidates, [1] valid survivors, [2] passing (L2)
+    const uint64_t base = static_cast<uint64_t>(q) * total;
+    uint32_t total2 = 64;
+    while (total2 < total) total2 <<= 1;
+    for (uint32_t i = t; i < total2; i += NT) fkey[i] = i < total ? __builtin_nontemporal_load(a.part_key + base + i) : 0ull;
+    for (uint32_t i = t; i < 1024; i += NT) fcand[i] = 0;
+    if (t == 0) { *s_tau = 0; s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
+    group_sync<NT>();
+    const uint32_t n_lists = total / kk;
+    if (a.k <= kk)
+        for (uint32_t b2 = t; b2 < n_lists; b2 += NT) atomicMax(s_tau, static_cast<unsigned long long>(fkey[b2 * kk + kk - 1]));
+    group_sync<NT>();
+    const uint64_t tau = *s_tau;                                            // (0 when no list is full: nothing is pruned)
+    uint32_t nv_mine = 0;
+    for (uint32_t i = t; i < total; i += NT) {
+        const uint64_t mine = fkey[i];
+        if (!mine) continue;
+        ++nv_mine;
+        if (mine < tau) continue;
+        const uint32_t slot = atomicAdd(&s_cnt[0], 1u);
+        fcand[slot] = mine; fsrc[slot] = i;
+    }
+    if (nv_mine) atomicAdd(&s_cnt[1], nv_mine);
+    group_sync<NT>();
+    const uint32_t n_cand = s_cnt[0];
+    const uint32_t take = s_cnt[1] < a.k ? s_cnt[1] : a.k;
+    for (uint32_t c = t; c < n_cand; c += NT) {
+        const uint64_t mine = fcand[c];
+        const uint32_t r = rank_of(fcand, (n_cand + 15u) & ~15u, mine);
+        if (r >= a.k) continue;
+        if (METRIC == YAMS_SCAN_COSINE) {
+            const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
+            const uint32_t rk = key_idx(mine);
+            const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
+            const float sim = key_score(mine);
+            a.out_scores[o] = sim;
+            a.out_rows[o] = small_global_row(a, rowi);
+            if (a.out_ranks) a.out_ranks[o] = rk;
+            if (a.out_dist) a.out_dist[o] = 1.0f - sim;
+        } else {
+            frank_row[r] = c;                                               // (k <= 256)
+            fcs[r] = __builtin_nontemporal_load(a.part_aux + base + fsrc[c]);
+        }
+    }
+    if (METRIC == YAMS_SCAN_COSINE) {
+        for (uint32_t r = take + t; r < a.k; r += NT) {
+            const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
+            a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
+            if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
+            if (a.out_dist) a.out_dist[o] = __builtin_inff();
+        }
+        if (t == 0) a.out_counts[q] = take;
+        return;
+    }
+    // vec0 semantics: the k nearest, THEN the cosine threshold (:4506-4510), order preserved: the place of rank r is
+    // the number of passing ranks before it
+    group_sync<NT>();
+    const bool defer = (a.flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) != 0;
+    for (uint32_t r = t; r < take; r += NT) {
+        if (!(defer || !(fcs[r] < a.threshold))) continue;
+        uint32_t pos = 0;
+        for (uint32_t i = 0; i < r; ++i) pos += (defer || !(fcs[i] < a.threshold)) ? 1u : 0u;
+        const uint64_t mine = fcand[frank_row[r]];
+        const uint64_t o = static_cast<uint64_t>(q) * a.k + pos;
+        const uint32_t rk = key_idx(mine);
+        const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
+        a.out_scores[o] = fcs[r];
+        a.out_rows[o] = small_global_row(a, rowi);
+        if (a.out_dist) a.out_dist[o] = -key_score(mine);
+        if (a.out_ranks) a.out_ranks[o] = rk;
+        atomicAdd(&s_cnt[2], 1u);
+    }
+    group_sync<NT>();
+    const uint32_t outn = s_cnt[2];
+    for (uint32_t rr = outn + t; rr < a.k; rr += NT) {
+        const uint64_t o = static_cast<uint64_t>(q) * a.k + rr;
+        a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
+        if (a.out_dist) a.out_dist[o] = __builtin_inff();
+        if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
+    }
+    if (t == 0) a.out_counts[q] = outn;
+}
+
 #ifdef YAMS_ACCEL_MEASURE
 #define SM_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -273,106 +375,9 @@ __global__ __launch_bounds__(SM_THREADS) void small_scan_kernel(SmallScanArgs a)
     __threadfence();
     SM_STAMP(6);
     const uint32_t total = gridDim.x * kk;                                // <= small_scan_max_survivors()
-    uint32_t total2 = 64;
-    while (total2 < total) total2 <<= 1;
-    uint64_t* fkey = skey;                                               // [total2]
-    uint32_t* frank_row = reinterpret_cast<uint32_t*>(fkey + 1024);      // [256]: (L2) survivor index of rank r
-    float* fcs = reinterpret_cast<float*>(frank_row + 256);              // [256]: (L2) its cosine
-    for (uint32_t j = 0; j < nqc; ++j) {
-        const uint32_t q = q0 + j;
-        const uint64_t base = static_cast<uint64_t>(q) * total;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total2; i += SM_THREADS)
-            fkey[i] = i < total ? __builtin_nontemporal_load(a.part_key + base + i) : 0ull;
-        __syncthreads();
-        // Every workgroup's list is sorted, so list b alone holds kk keys >= its last one: the k best overall (k == kk
-        // unless k > 256) are all >= tau = the LARGEST of the lists' last keys.  Only those candidates are compacted
-        // and ranked — a few dozen for ordinary data instead of all n_wg * kk (any number stays correct).
-        __shared__ unsigned long long s_tau;
-        __shared__ uint32_t s_nc;
-        if (threadIdx.x == 0) { s_tau = 0; s_nc = 0; }
-        __syncthreads();
-        if (a.k <= kk)
-            for (uint32_t b2 = threadIdx.x; b2 < gridDim.x; b2 += SM_THREADS) atomicMax(&s_tau, static_cast<unsigned long long>(fkey[b2 * kk + kk - 1]));
-        __syncthreads();
-        const uint64_t tau = s_tau;                                        // (0 when some list is not full: nothing is pruned)
-        uint64_t* fcand = fkey + 1024 + 512;                               // [1024] candidates (behind frank_row / fcs)
-        uint32_t* fsrc = reinterpret_cast<uint32_t*>(fcand + 1024);        // [1024] their index among the survivors
-        for (uint32_t i = threadIdx.x; i < 1024; i += SM_THREADS) fcand[i] = 0;
-        __syncthreads();
-        uint32_t nv_mine = 0;
-        for (uint32_t i = threadIdx.x; i < total; i += SM_THREADS) {
-            const uint64_t mine = fkey[i];
-            if (!mine) continue;
-            ++nv_mine;
-            if (mine < tau) continue;
-            const uint32_t slot = atomicAdd(&s_nc, 1u);
-            fcand[slot] = mine; fsrc[slot] = i;
-        }
-        __syncthreads();
-        const uint32_t n_cand = s_nc;
-        for (uint32_t c = threadIdx.x; c < n_cand; c += SM_THREADS) {
-            const uint64_t mine = fcand[c];
-            const uint32_t i = fsrc[c];
-            const uint32_t r = rank_of(fcand, (n_cand + 15u) & ~15u, mine);
-            if (r >= a.k) continue;
-            if (METRIC == YAMS_SCAN_COSINE) {
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
-                const uint32_t rk = key_idx(mine);
-                const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
-                const float sim = key_score(mine);
-                a.out_scores[o] = sim;
-                a.out_rows[o] = small_global_row(a, rowi);
-                if (a.out_ranks) a.out_ranks[o] = rk;
-                if (a.out_dist) a.out_dist[o] = 1.0f - sim;
-            } else {
-                frank_row[r] = i;                                         // (k <= 256)
-                fcs[r] = __builtin_nontemporal_load(a.part_aux + base + i);
-            }
-        }
-        // number of valid survivors (block-wide sum of the per-thread counts)
-        __shared__ uint32_t s_nv;
-        if (threadIdx.x == 0) s_nv = 0;
-        __syncthreads();
-        if (nv_mine) atomicAdd(&s_nv, nv_mine);
-        __syncthreads();
-        const uint32_t take = s_nv < a.k ? s_nv : a.k;
-        if (METRIC == YAMS_SCAN_COSINE) {
-            for (uint32_t r = take + threadIdx.x; r < a.k; r += SM_THREADS) {
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + r;
-                a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
-                if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
-                if (a.out_dist) a.out_dist[o] = __builtin_inff();
-            }
-            if (threadIdx.x == 0) a.out_counts[q] = take;
-        } else {
-            // vec0 semantics: the k nearest, THEN the cosine threshold (:4506-4510), order preserved: the place of
-            // rank r is the number of passing ranks before it
-            const bool defer = (a.flags & YAMS_SCAN_FLAG_DEFER_THRESHOLD) != 0;
-            const uint32_t r = threadIdx.x;
-            const bool pass = r < take && (defer || !(fcs[r] < a.threshold));
-            uint32_t pos = 0;
-            for (uint32_t i = 0; i < r && i < take; ++i) pos += (defer || !(fcs[i] < a.threshold)) ? 1u : 0u;
-            if (pass) {
-                const uint64_t mine = fkey[frank_row[r]];
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + pos;
-                const uint32_t rk = key_idx(mine);
-                const uint32_t rowi = a.tie_rank ? a.rank_row[rk] : rk;
-                a.out_scores[o] = fcs[r];
-                a.out_rows[o] = small_global_row(a, rowi);
-                if (a.out_dist) a.out_dist[o] = -key_score(mine);
-                if (a.out_ranks) a.out_ranks[o] = rk;
-            }
-            const uint32_t outn = static_cast<uint32_t>(__syncthreads_count(pass));
-            for (uint32_t rr = outn + threadIdx.x; rr < a.k; rr += SM_THREADS) {
-                const uint64_t o = static_cast<uint64_t>(q) * a.k + rr;
-                a.out_scores[o] = -__builtin_inff(); a.out_rows[o] = -1;
-                if (a.out_dist) a.out_dist[o] = __builtin_inff();
-                if (a.out_ranks) a.out_ranks[o] = 0xffffffffu;
-            }
-            if (threadIdx.x == 0) a.out_counts[q] = outn;
-        }
-    }
+    // one query: the whole workgroup selects; several: wave j selects query j, the selections run side by side
+    if (nqc == 1) final_select<METRIC, SM_THREADS>(a, q0, total, kk, smem, threadIdx.x);
+    else if (static_cast<uint32_t>(wave) < nqc) final_select<METRIC, 64>(a, q0 + wave, total, kk, smem + wave * SM_FINAL_REGION, lane);
     SM_STAMP(7);
 }
 

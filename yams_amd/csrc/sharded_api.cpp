@@ -552,6 +552,25 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         L.st.assign(n, YAMS_OK); L.err.assign(n, std::string());
         L.dg.assign(n, yams_scan_diag_t{});
     }
+    // One shard and a handful of queries (the reference's everyday call is ONE query): latency is the product, and two
+    // thread hand-offs (wake the worker, wake the waiter) cost more than the search.  The lane is this caller's, its
+    // worker is idle: the batch runs right here, on the caller's thread; wait() finds it finished.
+    if (!L.trivial && s->mode == kNone && n_queries <= 16) {
+        int dev_before = s->device[0];
+        (void)hipGetDevice(&dev_before);
+        (void)hipSetDevice(s->device[0]);
+        std::string err;
+        yams_status_t st;
+        try { st = run_shard(s, L, 0, err); }
+        catch (...) { st = YAMS_ERR_INTERNAL; err = "exception in the shard scan"; }
+        (void)hipSetDevice(dev_before);
+        std::lock_guard<std::mutex> lk(s->mu);
+        L.st[0] = st; L.err[0] = std::move(err);
+        L.pending = 0;
+        L.submitted = true;
+        ++s->batches;
+        return YAMS_OK;
+    }
     {
         std::lock_guard<std::mutex> lk(s->mu);
         L.submitted = true;
