@@ -369,6 +369,25 @@ def ingest_breadth(acc, torch, seed):
     del tb
     torch.cuda.empty_cache()
 
+    # (ii b) ONE long message: a SHA-256 chain is sequential — what the device does with it, what one host core does,
+    # and what the plugin door therefore refuses (content_hash_v1: YAMS_ERR_UNSUPPORTED above 1 MiB per lone chain)
+    try:
+        n_one = 16 << 20
+        one = o.synth_bytes(seed + 3, 0, 0, n_one)
+        t0 = time.perf_counter(); hex_dev = acc.sha256_hex(one); dt_dev = time.perf_counter() - t0
+        t0 = time.perf_counter(); hex_host = hashlib.sha256(memoryview(one)).hexdigest(); dt_host = time.perf_counter() - t0
+        res["lone_chain"] = {"bytes": n_one, "device_MBps": n_one / dt_dev / 1e6, "device_ms": dt_dev * 1e3,
+                             "host_one_core_MBps": n_one / dt_host / 1e6, "host_ms": dt_host * 1e3, "host_hasher": "hashlib (OpenSSL)",
+                             "digests_equal": hex_dev == hex_host,
+                             "crossover": "none: one chain is slower on the device at every size (fixed call cost ~0.1 ms + ~35 MB/s "
+                                          "against > 1 GB/s on a host core); the device wins with many chains per call",
+                             "plugin_policy": {"hash_refused_above_bytes": 1 << 20,
+                                               "hash_many_refused_when_longest_exceeds": "max(1 MiB, total bytes / 37)",
+                                               "status": "YAMS_ERR_UNSUPPORTED -> the host's own SHA256Hasher (AccelSHA256Hasher takes it as a "
+                                                         "constructor argument)"}}
+    except Exception as e:      # noqa: BLE001
+        res["lone_chain"] = {"error": repr(e)}
+
     # (iii) the reference benchmark's configuration: RabinChunker 4K / 16K / 64K on 1 MiB inputs
     blen, n_blobs = 1 << 20, 8192
     tb = torch.empty(n_blobs * blen, dtype=torch.uint8, device="cuda")
@@ -1004,7 +1023,13 @@ def main():
                    "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n,
                    "traffic": hbm_leg_traffic(n, d, q64, i8_64)[0], "traffic_source": hbm_leg_traffic(n, d, q64, i8_64)[1],
                    "ms_per_step": dt64 * 1e3, "qps_on_resident_corpus": q64 / dt64,
-                   "results_identical_to_the_q1024_run": same}
+                   "results_identical_to_the_q1024_run": same,
+                   "bytes_definition": ("the bytes this sweep has to read: the 1-byte-per-element int8 shadow built at upload "
+                                        "(+ 2 B bf16 shadow: 1.75x the fp32 rows resident per shard), NOT SURVEY 8(d)'s fp32 rows "
+                                        "(38.4 GB per shard) — against those the sweep reads 4x fewer bytes; the fp32 rows are read "
+                                        "only by the fp64 re-score of the candidates") if i8_64 else
+                                       "the 2-byte-per-element bf16 shadow built at upload, not SURVEY 8(d)'s fp32 rows",
+                   "fp32_rows_bytes": n * d * 4}
 
     # ---- BASELINE config 3 on the same resident rows: 10M x 768, L2 top-k, 1024 queries, N = 1 ------
     # (a prefix of the shard and of its shadows — the blocked int8 shadow of the first 10M rows is a prefix too)
