@@ -944,6 +944,392 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 }
 
 
+
+// -------------------------------------------------------------------------------------------------
+// The resident-query filter with 128 x 128 WAVE TILES (round 3; cosine only): one wave per SIMD, four waves per
+// workgroup, the accumulators — 256 registers — in the AGPR half of the wave's 512.  Why: with 64 x 128 wave tiles
+// every 32 MFMAs cost 12 KiB of LDS fragment reads + 4 KiB of DMA writes; at the matrix pipe's full rate that is
+// exactly the 128 B/clk an LDS delivers, and the kernel sits at 70 % MFMA busy with the LDS 70 % busy beside it
+// (profiles/r02_pmc.json; no fragment reads at all: the bare-MFMA 4.3 ms).  A 128 x 128 wave tile reads 16 KiB of
+// fragments per 64 MFMAs: a third fewer LDS bytes per multiply-add (the DMA bytes per multiply-add stay).  The
+// price: no second wave on the SIMD to hide a wave's epilogue, so the accumulators are initialised by the first
+// slab's MFMAs themselves (C operand = the threshold vector) and the sign test is the only per-strip serial part.
+// Same strip geometry as scan_tiles_i8r_kernel (a unit = 512 rows = two filter tiles; wave w owns rows
+// [128 w, +128) of every unit of its stream — a static assignment: the four waves sit on four SIMDs of their own),
+// the same blocked shadow, query tile, thresholds, survivor log and pacing counters.
+// -------------------------------------------------------------------------------------------------
+constexpr int Q_THREADS = 256;
+constexpr int Q_RING = 2 * 128 * I8_SLAB;          // per wave: two slabs of its 128 rows (16 KiB)
+constexpr int Q_LDS = R_MAX_SLABS * R_B_SLAB + 4 * Q_RING; // 160 KiB
+
+template <int ABL = 0>
+__global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[Q_LDS];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, slot = bid >> 3;       // workgroup b runs on XCD b % 8
+    const uint32_t qt = slot % n_qt, st = slot / n_qt;    // the query tile it holds, its row stream on this XCD
+    if (st >= (n_streams >> 3)) return;
+    const uint32_t stream = st * 8u + xcd;
+    if (stream >= n_units) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint32_t dim = a.dim;
+    const int nslab = dim / I8_SLAB; // even, 4..12 (checked by the host)
+    const uint32_t q0 = qt * R_QUERIES;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) unsigned char*)lds));
+    const uint32_t ringW = __builtin_amdgcn_readfirstlane(lds0 + R_MAX_SLABS * R_B_SLAB + wid * Q_RING);
+    const unsigned char* ring = lds + R_MAX_SLABS * R_B_SLAB + wid * Q_RING;
+    const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
+    const uint64_t past_end = n_blocks * I8_BLOCK_ROWS;
+
+    struct Geo {
+        uint64_t row0;               // first row of the strip; >= n_rows when the strip does not exist
+        const unsigned char* base;   // first piece of the strip (uniform); an absent strip reads the shard's last rows
+    };
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    const uint32_t piece_row_stride = static_cast<uint32_t>(nslab) * 1024u; // bytes between the pieces of consecutive 16-row blocks
+    // strip i of this wave: unit stream + i * n_streams, tile (w >> 1) of the unit, rows [128 (w & 1), +128) of the tile
+    auto unit_of = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return stream + i * n_streams; };
+    auto locate = [&](uint32_t i, Geo& g) __attribute__((always_inline)) {
+        const uint32_t un_ = unit_of(i);
+        const uint32_t sel = un_ < n_units ? 2u * un_ + static_cast<uint32_t>(wid >> 1) : 0xffffffffu;
+        uint64_t row0 = past_end;
+        if (sel < a.n_sel_tiles) {
+            const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+            row0 = static_cast<uint64_t>(tile) * I8_ROWS + static_cast<uint32_t>((wid & 1) * 128);
+        }
+        g.row0 = row0;
+        uint64_t rowb = row0;
+        if (rowb + 128 > past_end) rowb = past_end >= 128 ? past_end - 128 : 0; // (n_rows >= 4096 on this path; a strip's tail past the padded shadow reads earlier rows, never emitted)
+        g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + (rowb / 16) * piece_row_stride;
+    };
+    // row piece rb (16 rows) of slab ss of the strip at `sbase` into ring stage P
+    auto piece = [&](const unsigned char* sbase, int ss, int P, int rb) __attribute__((always_inline)) {
+        lds_dma16_s(sbase + static_cast<uint32_t>(rb) * piece_row_stride + static_cast<uint32_t>(ss) * 1024u, lane16,
+                    ringW + P * 8192 + rb * 1024);
+    };
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    // {A_lo, B_hi} of this lane's eight queries: loaded ONCE — unlike scan_tiles_i8r_kernel this kernel has the
+    // registers to keep them (nothing is re-requested under the epilogue, so nothing in flight can be moved by the
+    // register allocator)
+    f2_t qthr[8];
+    {
+        const f2_t* qthr_p = reinterpret_cast<const f2_t*>(a.q_thr) + (q0 + l15); // < q_pad: the table is padded
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) qthr[cb] = qthr_p[cb * 16];
+    }
+    // block scales / residue bounds of the strip's two 64-row blocks: {s0, e0, s1, e1}, one scalar load
+    auto meta_ptr = [&](uint64_t row0) __attribute__((always_inline)) -> const float* {
+        uint64_t blk = row0 / I8_BLOCK_ROWS;
+        if (blk + 2 > n_blocks) blk = n_blocks >= 2 ? n_blocks - 2 : 0; // a strip past the end: nothing of it is ever emitted
+        return a.rows_i8_meta + 2ull * blk;
+    };
+
+    // ---- prologue: the resident query tile (wave w stages 32 queries of every slab), the first two slabs ----
+    {
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
+        const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            const int prow = lane >> 2;                        // the query of a piece this lane fetches 16 bytes of
+            const int rowB = (wid * 2 + hq) * 16 + prow;
+            const uint32_t voffB = static_cast<uint32_t>(rowB) * 64u + ((lane & 3) ^ i8_swz(prow)) * 16u;
+            for (int s = 0; s < nslab; ++s)
+                lds_dma16_s(baseB + s * qslab_bytes, voffB, __builtin_amdgcn_readfirstlane(lds0 + s * R_B_SLAB + (wid * 2 + hq) * 1024));
+        }
+    }
+    uint32_t* const my_cnt = a.i8_sync + (static_cast<uint64_t>(stream) * 4u + static_cast<uint32_t>(wid)) * 32u;
+    const uint32_t* sync_sib = my_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
+    Geo cur, nxt;
+    locate(0u, cur);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) piece(cur.base, s, s, rb);
+    float sb[2], eb[2];
+    {
+        const float* mp = meta_ptr(cur.row0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            sb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[2 * b])));
+            eb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[2 * b + 1])));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
+
+    const int offF = l15 * 64 + ((lq ^ i8_swz(l15)) << 4);
+    i32x4v acc[8][8];
+    i32x4v fa[2][8], fb[2][4];
+    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v {
+        return *reinterpret_cast<const i32x4v*>(base + off);
+    };
+    int nt[2][8]; // -T(block b of this strip, query block cb)
+    auto thresholds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float is = 1.0f / sb[b], g = eb[b] * is; // (the same expressions as in i8_log_gather_kernel)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) nt[b][cb] = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
+        }
+    };
+    // 32 MFMAs: the strip's eight row blocks x four query blocks.  FIRST: the strip's first slab — the accumulators
+    // are BORN here, C operand = the threshold of (block, query block)
+    auto half = [&](const i32x4v (&A)[8], const i32x4v (&B)[4], int cb0, auto first_tag, auto&& filler) __attribute__((always_inline)) {
+        constexpr bool first = decltype(first_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int rb = i >> 2, c = i & 3;
+            if (first) {
+                const int t0 = nt[rb >> 2][cb0 + c];
+                const i32x4v init = {t0, t0, t0, t0};
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], init, 0, 0, 0);
+            } else {
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            filler(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto pin8 = [&](i32x4v (&F)[8]) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]));
+    };
+    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+
+    // One slab (parity P = its ring stage) — the schedule of scan_tiles_i8r_kernel's body with twice the rows:
+    //   half 1: fa[P] x query blocks 0-3; requests query blocks 4-7 of this slab;
+    //   wait:   the slab one ahead has landed (only the eight pieces of the slab two ahead are younger);
+    //   half 2: fa[P] x query blocks 4-7; requests the next slab's row fragments (fa[P ^ 1], from stage P ^ 1) and its
+    //           query blocks 0-3, and — once those row fragments have left the stage — refills it with the slab
+    //           THREE ahead.
+    uint32_t sib = 0;       // pacing: the siblings' strip counters, requested in a strip's last half
+    uint32_t k_cur = 0;
+    auto body = [&](int sn, auto early_tag, auto first_tag, const unsigned char* sbase, int ss, int s, auto par_tag, bool last) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_tag)::value;
+        constexpr bool early = decltype(early_tag)::value;
+        const unsigned char* bq = lds + s * R_B_SLAB;
+        const unsigned char* bqn = lds + sn * R_B_SLAB;
+        pin8(fa[P]); pin4(fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[P], fb[0], 0, first_tag, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
+        });
+        if (ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[P], fb[1], 4, first_tag, [&](int i) __attribute__((always_inline)) {
+            if (i < 8) fa[P ^ 1][i < 8 ? i : 0] = ld(ring, (P ^ 1) * 8192 + offF + (i < 8 ? i : 0) * 1024);
+            if (i >= 8 && i < 12) fb[0][(i - 8) & 3] = ld(bqn, offF + ((i - 8) & 3) * 1024);
+            if (ABL != 1 && i == 18) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
+            // the strip's last half: "this wave has finished strip k_cur" (a few MFMAs early; pacing is best effort) and
+            // the siblings' counters — OLDER than the eight pieces below, so the counted wait at the strip's end covers them
+            if (P == 1 && i == 19 && last) {
+                unsigned long long keep;
+                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %2, %3, off sc0 sc1\n\ts_mov_b64 exec, %1\n\t"
+                             "global_load_dword %0, %4, off sc0 sc1"
+                             : "=&v"(sib), "=&s"(keep) : "v"(my_cnt + qt), "v"(k_cur + 1u), "v"(sync_sib) : "memory");
+            }
+            if (ABL != 1 && i >= 20 && i < 28) piece(sbase, ss, P ^ 1, (i - 20) & 7);
+        });
+    };
+
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) piece(cur.base, 2, 0, rb); // slab 2 into the stage slab 0 just left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (a strip begins with its slabs 1 and 2 landed)
+
+    constexpr uint32_t Q_POLLS = 1024;
+    bool pacing = true;
+    thresholds();
+    const uint32_t log_region = (stream * n_qt + qt) * 8u + static_cast<uint32_t>(wid);
+    const uint64_t region = static_cast<uint64_t>(log_region) * a.log_cap;
+    uint32_t log_pos = 0;
+
+    uint64_t tm_loop = 0, tm_epi = 0, tm_wait = 0, tm_pace = 0; // (100 MHz ticks; measurement only)
+    if (unit_of(k_cur) < n_units) for (;;) {
+        const uint64_t tm0 = wall_clock64();
+        const bool more = unit_of(k_cur + 1) < n_units;
+        locate(k_cur + 1, nxt); // (past the end of the stream: the spare DMA slots read the shard's last rows; nobody consumes them)
+        float meta_n[4];        // the next strip's block scales, on their way through the scalar cache
+        {
+            const float* mp = meta_ptr(nxt.row0);
+            typedef float f4s __attribute__((ext_vector_type(4)));
+            f4s mv;
+            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(mv) : "s"(mp) : "memory");
+            asm volatile("" : "+s"(mv));
+            meta_n[0] = mv[0]; meta_n[1] = mv[1]; meta_n[2] = mv[2]; meta_n[3] = mv[3];
+        }
+        // the strip's first slab stands apart: it gives birth to the accumulators (compile-time C operand), and slab 1
+        // landed before the strip began (no counted wait); nslab >= 4, so the loop runs at least once
+        using T = std::true_type; using F = std::false_type;
+        body(1, T{}, T{}, nslab <= 3 ? nxt.base : cur.base, nslab <= 3 ? 3 - nslab : 3, 0, C0{}, false);
+        body(2, F{}, F{}, nslab <= 4 ? nxt.base : cur.base, nslab <= 4 ? 4 - nslab : 4, 1, C1{}, false);
+        int s = 2;
+        do {
+            const bool n0 = s + 3 >= nslab, n1 = s + 4 >= nslab;
+            body(s + 1, F{}, F{}, n0 ? nxt.base : cur.base, n0 ? s + 3 - nslab : s + 3, s, C0{}, false);
+            body(s + 2 >= nslab ? 0 : s + 2, F{}, F{}, n1 ? nxt.base : cur.base, n1 ? s + 4 - nslab : s + 4, s + 1, C1{}, s + 2 >= nslab);
+            s += 2;
+        } while (s < nslab);
+        const uint64_t tm1 = wall_clock64();
+
+        // ---- epilogue of the strip: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
+        //      the accumulators hold I - T, a survivor is a non-negative one.  Nothing else runs on this SIMD while
+        //      the wave is here, so every instruction counts: the sign test is 1.5 instructions per accumulator
+        //      register (two AGPR reads and a v_max3 per pair — written out: left to itself the compiler copies all
+        //      256 into VGPRs after the loop and keeps the copies for the emission, 80 spilled registers, and a
+        //      scratch reload waits for every survivor store in front of it) ---------------------------------
+        const uint64_t strip = cur.row0;
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); // (the last MFMAs' results: the reads below are inline asm, no hazard recogniser looks at them)
+        uint32_t hotw = 0; // bit cb: some lane holds a survivor in query block cb (wave-uniform)
+        uint32_t hot = 0;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            int m = static_cast<int>(0x80000000u);
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) {
+                int t0, t1;
+                asm volatile("v_accvgpr_read_b32 %1, %3\n\tv_accvgpr_read_b32 %2, %4\n\tv_max3_i32 %0, %1, %2, %0"
+                             : "+v"(m), "=&v"(t0), "=&v"(t1) : "a"(acc[i >> 2][cb][i & 3]), "a"(acc[(i + 1) >> 2][cb][(i + 1) & 3]));
+            }
+            const bool h = m >= 0 && q0 + cb * 16 + l15 < a.n_queries;
+            if (h) hot |= 1u << cb;
+            if (__builtin_amdgcn_ballot_w64(h) != 0) hotw |= 1u << cb;
+        }
+        if (strip >= a.n_rows) hotw = 0;
+        asm volatile("" : "+s"(hotw));
+        const uint64_t tm1b = wall_clock64();
+        if (hotw != 0) {
+            const uint32_t rows_left = static_cast<uint32_t>(a.n_rows - strip < 128 ? a.n_rows - strip : 128);
+            // bit 4 rb + r of a lane = its element (rb, r) = row strip + 16 rb + 4 lq + r: rows past the end and masked rows
+            uint32_t valid = 0xffffffffu;
+            if (rows_left < 128 || a.row_mask) {
+                valid = 0;
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    const uint32_t off0 = 16 * rb + 4 * lq;
+                    uint32_t mw = 0xfu;
+                    if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) valid |= (off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                }
+            }
+            uint32_t base = log_pos;
+            // one trip per query block that holds a survivor (one or two, typically): ONE copy of the code — eight
+            // unrolled copies ran from a cold instruction cache every time
+            do {
+                const int cb = __builtin_ctz(hotw);
+                hotw &= hotw - 1u;
+                int av[32];
+#define YAMS_Q_RD1(C, I) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av[I]) : "a"(acc[(I) >> 2][C][(I) & 3]));
+#define YAMS_Q_RD4(C, I) YAMS_Q_RD1(C, I) YAMS_Q_RD1(C, I + 1) YAMS_Q_RD1(C, I + 2) YAMS_Q_RD1(C, I + 3)
+#define YAMS_Q_READ_BLOCK(C)                                                                                           \
+    YAMS_Q_RD4(C, 0) YAMS_Q_RD4(C, 4) YAMS_Q_RD4(C, 8) YAMS_Q_RD4(C, 12) YAMS_Q_RD4(C, 16) YAMS_Q_RD4(C, 20) YAMS_Q_RD4(C, 24) YAMS_Q_RD4(C, 28)
+                switch (cb) {
+                    case 0: YAMS_Q_READ_BLOCK(0) break;
+                    case 1: YAMS_Q_READ_BLOCK(1) break;
+                    case 2: YAMS_Q_READ_BLOCK(2) break;
+                    case 3: YAMS_Q_READ_BLOCK(3) break;
+                    case 4: YAMS_Q_READ_BLOCK(4) break;
+                    case 5: YAMS_Q_READ_BLOCK(5) break;
+                    case 6: YAMS_Q_READ_BLOCK(6) break;
+                    default: YAMS_Q_READ_BLOCK(7) break;
+                }
+#undef YAMS_Q_READ_BLOCK
+#undef YAMS_Q_RD4
+#undef YAMS_Q_RD1
+                const uint32_t qi = q0 + static_cast<uint32_t>(cb) * 16u + l15;
+                // the sign bits, one instruction per element: shift the mask left, the element's sign comes in at the bottom
+                uint32_t sg = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) sg = __builtin_amdgcn_alignbit(sg, static_cast<uint32_t>(av[i]), 31);
+                uint32_t pm = __builtin_bitreverse32(~sg) & valid; // bit i: element i is a survivor
+                if (!((hot >> cb) & 1u)) pm = 0;
+                bool lost = false;
+                for (;;) { // one trip per survivor of the busiest lane (one, typically)
+                    const bool p = pm != 0;
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                    if (m == 0) break;
+                    const int e = p ? __builtin_ctz(pm) : 0;
+                    // element e of the 32: a select tree, 31 v_cndmask (the operands pass through an empty asm: the
+                    // compiler would otherwise turn "c ? av[2 j + 1] : av[2 j]" into an indexed load and the array into scratch)
+                    auto sel = [](bool c, int x, int y) __attribute__((always_inline)) -> int {
+                        asm("" : "+v"(x), "+v"(y));
+                        return c ? x : y;
+                    };
+                    int t16[16], t8[8], t4[4];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) t16[j] = sel(e & 1, av[2 * j + 1], av[2 * j]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t8[j] = sel(e & 2, t16[2 * j + 1], t16[2 * j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t4[j] = sel(e & 4, t8[2 * j + 1], t8[2 * j]);
+                    const int u0 = sel(e & 8, t4[1], t4[0]), u1 = sel(e & 8, t4[3], t4[2]);
+                    const int val = sel(e & 16, u1, u0);
+                    const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                    base += static_cast<uint32_t>(__builtin_popcountll(m));
+                    if (p) {
+                        const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
+                        // the gather kernel re-derives T from the entry's ROW (its 64-row block): the accumulator goes in as is
+                        if (pos < a.log_cap) {
+                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
+                            a.log_q[region + pos] = qi;
+                        } else {
+                            lost = true;
+                        }
+                    }
+                    pm &= pm - 1u;
+                }
+                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+            } while (hotw != 0);
+            log_pos = base;
+        }
+        const uint64_t tm2 = wall_clock64();
+        // the next strip's thresholds
+        sb[0] = meta_n[0]; eb[0] = meta_n[1]; sb[1] = meta_n[2]; eb[1] = meta_n[3];
+        // the next strip's slab 1 and the siblings' counters are older than the eight pieces of its slab 2 — and than any
+        // survivor store of this strip: a counted wait, the stores drain under the next strip's first slab
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(sib) :: "memory");
+        thresholds();
+        const uint64_t tm3 = wall_clock64();
+        if (n_qt > 1 && more && pacing) {
+            asm volatile("" : "+v"(sib));
+            uint32_t polls = 0;
+            for (; polls < Q_POLLS; ++polls) {
+                if (__builtin_amdgcn_ballot_w64(sib + window < k_cur + 1u) == 0) break;
+                __builtin_amdgcn_s_sleep(8);
+                asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sib) : "v"(sync_sib) : "memory");
+            }
+            if (polls == Q_POLLS) pacing = false;
+        }
+        tm_loop += tm1 - tm0; tm_epi += tm1b - tm1; tm_wait += tm2 - tm1b; tm_pace += wall_clock64() - tm2; (void)tm3;
+        if (!more) break;
+        cur = nxt;
+        ++k_cur;
+    }
+    if (lane == 0 && n_qt <= 8) { // where the time went, per wave
+        uint32_t* const dbg = a.i8_sync + (static_cast<uint64_t>(n_streams) * 4u + static_cast<uint64_t>(stream) * 8u + static_cast<uint32_t>(wid)) * 32u;
+        dbg[qt * 4 + 0] = static_cast<uint32_t>(tm_loop); dbg[qt * 4 + 1] = static_cast<uint32_t>(tm_epi);
+        dbg[qt * 4 + 2] = static_cast<uint32_t>(tm_wait); dbg[qt * 4 + 3] = static_cast<uint32_t>(tm_pace);
+    }
+    if (lane == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
+}
+
+
 // The survivor log -> per-query candidate lists.  An entry carries the accumulator of a survivor (I - T; under L2
 // I - T - a_r m_q) and its row; the score bound is u = s_b t_q I + e_b c_q + f_q with T re-derived exactly as the
 // filter kernel derived it (same inputs, same instructions).  L2: T comes from the shard's thresholds meta, u from
@@ -1695,6 +2081,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     }
     if (version == 40) {
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+    if (rp.use && version == 70) { // 128 x 128 wave tiles, one wave per SIMD
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<0>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        return hipGetLastError();
+    }
+    if (rp.use && version == 71) { // the same without DMA refills after the prologue (ablation)
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<1>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
 #endif
