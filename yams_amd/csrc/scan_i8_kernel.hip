@@ -950,17 +950,29 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 // workgroup, the accumulators — 256 registers — in the AGPR half of the wave's 512.  Why: with 64 x 128 wave tiles
 // every 32 MFMAs cost 12 KiB of LDS fragment reads + 4 KiB of DMA writes; at the matrix pipe's full rate that is
 // exactly the 128 B/clk an LDS delivers, and the kernel sits at 70 % MFMA busy with the LDS 70 % busy beside it
-// (profiles/r02_pmc.json; no fragment reads at all: the bare-MFMA 4.3 ms).  A 128 x 128 wave tile reads 16 KiB of
-// fragments per 64 MFMAs: a third fewer LDS bytes per multiply-add (the DMA bytes per multiply-add stay).  The
-// price: no second wave on the SIMD to hide a wave's epilogue, so the accumulators are initialised by the first
-// slab's MFMAs themselves (C operand = the threshold vector) and the sign test is the only per-strip serial part.
+// (profiles/r02_pmc.json; no fragment reads at all: the bare-MFMA 4.3 ms).  Here
+//   * the ROW fragments do not pass through the LDS at all: a row piece is read by exactly one wave, the blocked
+//     shadow already is the fragment image (a lane's 16 bytes of a 1 KiB piece), and a wave that owns 256 VGPRs
+//     besides its accumulators can hold THREE slabs of its 128 rows (96 registers, loaded straight from global
+//     memory: one being multiplied, two on their way — ~1 us of latency cover, what the DMA ring had; four
+//     slabs did not fit: the register allocator started moving accumulators through VGPRs);
+//   * the QUERY fragments (shared by the four waves and by every strip) stay in the LDS: 8 KiB of reads per
+//     64 MFMAs and wave — 32 B/clk per CU instead of 128.
+// The price: no second wave on the SIMD to hide a wave's epilogue.  So the accumulators are born in the first
+// slab's MFMAs (C operand = the constant 0: no initialisation pass, no AGPR besides the 256), the thresholds enter
+// in the epilogue (a survivor is I >= T: one maximum per 64-row block and query block against T), and the sign
+// test and the emission are written for instruction count (see there).
 // Same strip geometry as scan_tiles_i8r_kernel (a unit = 512 rows = two filter tiles; wave w owns rows
 // [128 w, +128) of every unit of its stream — a static assignment: the four waves sit on four SIMDs of their own),
-// the same blocked shadow, query tile, thresholds, survivor log and pacing counters.
+// the same blocked shadow, query tile, thresholds, survivor log and pacing counters.  dim % 192 == 0 (the register
+// ring is indexed statically: three slabs per trip of the k loop) — 384 and 768, the dimensions of BASELINE.json.
 // -------------------------------------------------------------------------------------------------
 constexpr int Q_THREADS = 256;
-constexpr int Q_RING = 2 * 128 * I8_SLAB;          // per wave: two slabs of its 128 rows (16 KiB)
-constexpr int Q_LDS = R_MAX_SLABS * R_B_SLAB + 4 * Q_RING; // 160 KiB
+#ifndef Q_DEPTH_SLABS
+#define Q_DEPTH_SLABS 3
+#endif
+constexpr int Q_DEPTH = Q_DEPTH_SLABS;                          // slabs of row fragments in registers (one being multiplied, two on their way)
+constexpr int Q_LDS = R_MAX_SLABS * R_B_SLAB;       // 96 KiB: the query tile
 
 template <int ABL = 0>
 __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
@@ -978,12 +990,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const uint32_t dim = a.dim;
-    const int nslab = dim / I8_SLAB; // even, 4..12 (checked by the host)
+    const int nslab = dim / I8_SLAB; // 6 or 12 (checked by the host)
     const uint32_t q0 = qt * R_QUERIES;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
-    const uint32_t ringW = __builtin_amdgcn_readfirstlane(lds0 + R_MAX_SLABS * R_B_SLAB + wid * Q_RING);
-    const unsigned char* ring = lds + R_MAX_SLABS * R_B_SLAB + wid * Q_RING;
     const uint64_t n_blocks = (a.n_rows + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS;
     const uint64_t past_end = n_blocks * I8_BLOCK_ROWS;
 
@@ -991,7 +1001,6 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         uint64_t row0;               // first row of the strip; >= n_rows when the strip does not exist
         const unsigned char* base;   // first piece of the strip (uniform); an absent strip reads the shard's last rows
     };
-    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
     const uint32_t piece_row_stride = static_cast<uint32_t>(nslab) * 1024u; // bytes between the pieces of consecutive 16-row blocks
     // strip i of this wave: unit stream + i * n_streams, tile (w >> 1) of the unit, rows [128 (w & 1), +128) of the tile
     auto unit_of = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return stream + i * n_streams; };
@@ -1007,11 +1016,6 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         uint64_t rowb = row0;
         if (rowb + 128 > past_end) rowb = past_end >= 128 ? past_end - 128 : 0; // (n_rows >= 4096 on this path; a strip's tail past the padded shadow reads earlier rows, never emitted)
         g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + (rowb / 16) * piece_row_stride;
-    };
-    // row piece rb (16 rows) of slab ss of the strip at `sbase` into ring stage P
-    auto piece = [&](const unsigned char* sbase, int ss, int P, int rb) __attribute__((always_inline)) {
-        lds_dma16_s(sbase + static_cast<uint32_t>(rb) * piece_row_stride + static_cast<uint32_t>(ss) * 1024u, lane16,
-                    ringW + P * 8192 + rb * 1024);
     };
     typedef float f2_t __attribute__((ext_vector_type(2)));
     // {A_lo, B_hi} of this lane's eight queries: loaded ONCE — unlike scan_tiles_i8r_kernel this kernel has the
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         return a.rows_i8_meta + 2ull * blk;
     };
 
-    // ---- prologue: the resident query tile (wave w stages 32 queries of every slab), the first two slabs ----
+    // ---- prologue: the resident query tile (wave w stages 32 queries of every slab) ----------------------
     {
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.q_i8) + static_cast<uint64_t>(q0) * 64;
         const uint64_t qslab_bytes = static_cast<uint64_t>(a.q_pad) * 64;
@@ -1047,10 +1051,6 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     const uint32_t* sync_sib = my_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
     Geo cur, nxt;
     locate(0u, cur);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int rb = 0; rb < 8; ++rb) piece(cur.base, s, s, rb);
     float sb[2], eb[2];
     {
         const float* mp = meta_ptr(cur.row0);
@@ -1063,9 +1063,18 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
 
+    // a lane's 16 bytes of a 1 KiB piece (16 rows x one slab): row l15, 16-byte chunk lq (stored swizzled) — in the
+    // query tile's LDS image and in the blocked shadow alike
     const int offF = l15 * 64 + ((lq ^ i8_swz(l15)) << 4);
     i32x4v acc[8][8];
-    i32x4v fa[2][8], fb[2][4];
+    i32x4v fa[Q_DEPTH][8], fb[2][4];
+    uint32_t voff[8]; // row block rb of a strip: its piece of slab 0 + this lane's bytes
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) voff[rb] = static_cast<uint32_t>(rb) * piece_row_stride + static_cast<uint32_t>(offF);
+    // row block rb of slab ss of the strip at `sbase` into register slot S (lands some time later: see `landed`)
+    auto fetch1 = [](i32x4v& dst, uint32_t vo, const unsigned char* sslab) __attribute__((always_inline)) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(sslab) : "memory");
+    };
     auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v {
         return *reinterpret_cast<const i32x4v*>(base + off);
     };
@@ -1079,81 +1088,81 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         }
     };
     // 32 MFMAs: the strip's eight row blocks x four query blocks.  FIRST: the strip's first slab — the accumulators
-    // are BORN here, C operand = the threshold of (block, query block)
+    // are BORN here (C operand = 0)
     auto half = [&](const i32x4v (&A)[8], const i32x4v (&B)[4], int cb0, auto first_tag, auto&& filler) __attribute__((always_inline)) {
         constexpr bool first = decltype(first_tag)::value;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int rb = i >> 2, c = i & 3;
-            if (first) {
-                const int t0 = nt[rb >> 2][cb0 + c];
-                const i32x4v init = {t0, t0, t0, t0};
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], init, 0, 0, 0);
-            } else {
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
-            }
+            // (written out with the accumulator constrained to the AGPR file: through the builtin the register allocator
+            // — 64 tuples for 256 AGPRs, no slack — kept 18 of them in VGPRs and shuttled them through a[0:3])
+            if (first) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
+            else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
             __builtin_amdgcn_sched_barrier(0);
             filler(i);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto pin8 = [&](i32x4v (&F)[8]) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]));
-    };
     auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
 
-    // One slab (parity P = its ring stage) — the schedule of scan_tiles_i8r_kernel's body with twice the rows:
-    //   half 1: fa[P] x query blocks 0-3; requests query blocks 4-7 of this slab;
-    //   wait:   the slab one ahead has landed (only the eight pieces of the slab two ahead are younger);
-    //   half 2: fa[P] x query blocks 4-7; requests the next slab's row fragments (fa[P ^ 1], from stage P ^ 1) and its
-    //           query blocks 0-3, and — once those row fragments have left the stage — refills it with the slab
-    //           THREE ahead.
-    uint32_t sib = 0;       // pacing: the siblings' strip counters, requested in a strip's last half
+    uint32_t sib = 0;       // pacing: the siblings' strip counters, requested in a strip's last slab
     uint32_t k_cur = 0;
-    auto body = [&](int sn, auto early_tag, auto first_tag, const unsigned char* sbase, int ss, int s, auto par_tag, bool last) __attribute__((always_inline)) {
-        constexpr int P = decltype(par_tag)::value;
-        constexpr bool early = decltype(early_tag)::value;
+    // One slab (register slot S = slab % 3):
+    //   wait:   this slab's row fragments have landed (the eight loads of the slab behind it are younger);
+    //   half 1: fa[S] x query blocks 0-3; requests query blocks 4-7 of this slab and the row fragments of the slab
+    //           TWO ahead (into the slot the previous slab has just left);
+    //   half 2: fa[S] x query blocks 4-7; requests the next slab's query blocks 0-3.
+    // `sslab` names the slab the row fragments are requested from (the last two slabs of a strip request the
+    // next strip's first two), `sn` the next slab of the query tile.
+    auto body = [&](int sn, auto first_tag, const unsigned char* sslab, int s, auto slot_tag, bool last) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        using SN = std::integral_constant<int, (S + Q_DEPTH - 1) % Q_DEPTH>;
         const unsigned char* bq = lds + s * R_B_SLAB;
         const unsigned char* bqn = lds + sn * R_B_SLAB;
-        pin8(fa[P]); pin4(fb[0]);
+        if (ABL != 1 && Q_DEPTH == 4)
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]),
+                                                  "+v"(fa[S][4]), "+v"(fa[S][5]), "+v"(fa[S][6]), "+v"(fa[S][7]) :: "memory");
+        else if (ABL != 1)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]),
+                                                 "+v"(fa[S][4]), "+v"(fa[S][5]), "+v"(fa[S][6]), "+v"(fa[S][7]) :: "memory");
+        pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
-        half(fa[P], fb[0], 0, first_tag, [&](int i) __attribute__((always_inline)) {
+        half(fa[S], fb[0], 0, first_tag, [&](int i) __attribute__((always_inline)) {
             if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
-        });
-        if (ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pin4(fb[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[P], fb[1], 4, first_tag, [&](int i) __attribute__((always_inline)) {
-            if (i < 8) fa[P ^ 1][i < 8 ? i : 0] = ld(ring, (P ^ 1) * 8192 + offF + (i < 8 ? i : 0) * 1024);
-            if (i >= 8 && i < 12) fb[0][(i - 8) & 3] = ld(bqn, offF + ((i - 8) & 3) * 1024);
-            if (ABL != 1 && i == 18) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
-            // the strip's last half: "this wave has finished strip k_cur" (a few MFMAs early; pacing is best effort) and
-            // the siblings' counters — OLDER than the eight pieces below, so the counted wait at the strip's end covers them
-            if (P == 1 && i == 19 && last) {
+            // the strip's last slab: "this wave has finished strip k_cur" (a slab early; pacing is best effort) and the
+            // siblings' counters — OLDER than the eight loads below, so the counted wait at the strip's end covers them
+            if (i == 5 && last) {
                 unsigned long long keep;
                 asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %2, %3, off sc0 sc1\n\ts_mov_b64 exec, %1\n\t"
                              "global_load_dword %0, %4, off sc0 sc1"
                              : "=&v"(sib), "=&s"(keep) : "v"(my_cnt + qt), "v"(k_cur + 1u), "v"(sync_sib) : "memory");
             }
-            if (ABL != 1 && i >= 20 && i < 28) piece(sbase, ss, P ^ 1, (i - 20) & 7);
+            if (ABL != 1 && i >= 6 && i < 14) fetch1(fa[SN::value][(i - 6) & 7], voff[(i - 6) & 7], sslab);
+        });
+        pin4(fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        half(fa[S], fb[1], 4, first_tag, [&](int i) __attribute__((always_inline)) {
+            if (i < 4) fb[0][i < 4 ? i : 0] = ld(bqn, offF + (i < 4 ? i : 0) * 1024);
         });
     };
 
+    // the first strip's slabs 0 and 1; the first query fragments
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
+    for (int rb = 0; rb < 8; ++rb) fetch1(fa[0][rb], voff[rb], cur.base);
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) fetch1(fa[1][rb], voff[rb], cur.base + 1024);
+    if (Q_DEPTH == 4) {
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) fetch1(fa[2][rb], voff[rb], cur.base + 2048);
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) piece(cur.base, 2, 0, rb); // slab 2 into the stage slab 0 just left
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (a strip begins with its slabs 1 and 2 landed)
 
     constexpr uint32_t Q_POLLS = 1024;
     bool pacing = true;
-    thresholds();
     const uint32_t log_region = (stream * n_qt + qt) * 8u + static_cast<uint32_t>(wid);
     const uint64_t region = static_cast<uint64_t>(log_region) * a.log_cap;
     uint32_t log_pos = 0;
@@ -1162,7 +1171,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     if (unit_of(k_cur) < n_units) for (;;) {
         const uint64_t tm0 = wall_clock64();
         const bool more = unit_of(k_cur + 1) < n_units;
-        locate(k_cur + 1, nxt); // (past the end of the stream: the spare DMA slots read the shard's last rows; nobody consumes them)
+        locate(k_cur + 1, nxt); // (past the end of the stream: the spare loads read the shard's last rows; nobody consumes them)
         float meta_n[4];        // the next strip's block scales, on their way through the scalar cache
         {
             const float* mp = meta_ptr(nxt.row0);
@@ -1172,40 +1181,74 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
             asm volatile("" : "+s"(mv));
             meta_n[0] = mv[0]; meta_n[1] = mv[1]; meta_n[2] = mv[2]; meta_n[3] = mv[3];
         }
-        // the strip's first slab stands apart: it gives birth to the accumulators (compile-time C operand), and slab 1
-        // landed before the strip began (no counted wait); nslab >= 4, so the loop runs at least once
+        // three slabs per trip (the register slot is a compile-time constant); the strip's first slab stands apart: it
+        // gives birth to the accumulators (compile-time C operand).  Slab s requests the row fragments of slab s + 2.
         using T = std::true_type; using F = std::false_type;
-        body(1, T{}, T{}, nslab <= 3 ? nxt.base : cur.base, nslab <= 3 ? 3 - nslab : 3, 0, C0{}, false);
-        body(2, F{}, F{}, nslab <= 4 ? nxt.base : cur.base, nslab <= 4 ? 4 - nslab : 4, 1, C1{}, false);
-        int s = 2;
-        do {
-            const bool n0 = s + 3 >= nslab, n1 = s + 4 >= nslab;
-            body(s + 1, F{}, F{}, n0 ? nxt.base : cur.base, n0 ? s + 3 - nslab : s + 3, s, C0{}, false);
-            body(s + 2 >= nslab ? 0 : s + 2, F{}, F{}, n1 ? nxt.base : cur.base, n1 ? s + 4 - nslab : s + 4, s + 1, C1{}, s + 2 >= nslab);
-            s += 2;
-        } while (s < nslab);
+        auto src = [&](int s3) __attribute__((always_inline)) -> const unsigned char* { // slab s3 of this strip, or slab s3 - nslab of the next
+            return s3 >= nslab ? nxt.base + static_cast<uint32_t>(s3 - nslab) * 1024u : cur.base + static_cast<uint32_t>(s3) * 1024u;
+        };
+        if constexpr (Q_DEPTH == 3) {
+            body(1, T{}, src(2), 0, C0{}, false);
+            body(2, F{}, src(3), 1, C1{}, false);
+            body(3, F{}, src(4), 2, C2{}, false);
+            int s = 3;
+            do { // (nslab >= 6)
+                body(s + 1, F{}, src(s + 2), s, C0{}, false);
+                body(s + 2, F{}, src(s + 3), s + 1, C1{}, false);
+                body(s + 3 >= nslab ? 0 : s + 3, F{}, src(s + 4), s + 2, C2{}, s + 3 >= nslab);
+                s += 3;
+            } while (s < nslab);
+        } else {
+            using C3 = std::integral_constant<int, 3>;
+            body(1, T{}, src(3), 0, C0{}, false);
+            body(2, F{}, src(4), 1, C1{}, false);
+            body(3, F{}, src(5), 2, C2{}, false);
+            body(4, F{}, src(6), 3, C3{}, false);
+            int s = 4;
+            do { // (nslab >= 8)
+                body(s + 1, F{}, src(s + 3), s, C0{}, false);
+                body(s + 2, F{}, src(s + 4), s + 1, C1{}, false);
+                body(s + 3, F{}, src(s + 5), s + 2, C2{}, false);
+                body(s + 4 >= nslab ? 0 : s + 4, F{}, src(s + 6), s + 3, C3{}, s + 4 >= nslab);
+                s += 4;
+            } while (s < nslab);
+        }
         const uint64_t tm1 = wall_clock64();
 
-        // ---- epilogue of the strip: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
-        //      the accumulators hold I - T, a survivor is a non-negative one.  Nothing else runs on this SIMD while
-        //      the wave is here, so every instruction counts: the sign test is 1.5 instructions per accumulator
-        //      register (two AGPR reads and a v_max3 per pair — written out: left to itself the compiler copies all
-        //      256 into VGPRs after the loop and keeps the copies for the emission, 80 spilled registers, and a
-        //      scratch reload waits for every survivor store in front of it) ---------------------------------
+        // ---- epilogue of the strip: acc[rb][cb][r] = I of row row0 + 16 rb + 4 lq + r and query q0 + 16 cb + l15; a
+        //      survivor is I >= T(64-row block, query), i.e. I + nt >= 0.  Nothing else runs on this SIMD while the
+        //      wave is here, so every instruction counts: the test is 1.5 instructions per accumulator register — two
+        //      AGPR reads and a v_max3 per pair, one maximum per (64-row block, query block) against its threshold —
+        //      written out: left to itself the compiler copies all 256 into VGPRs after the loop and keeps the copies
+        //      for the emission, 80 spilled registers, and a scratch reload waits for every survivor store in front
+        //      of it ---------------------------------------------------------------------------------------
         const uint64_t strip = cur.row0;
+        thresholds();
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); // (the last MFMAs' results: the reads below are inline asm, no hazard recogniser looks at them)
         uint32_t hotw = 0; // bit cb: some lane holds a survivor in query block cb (wave-uniform)
         uint32_t hot = 0;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
-            int m = static_cast<int>(0x80000000u);
+            int mb[2];
 #pragma unroll
-            for (int i = 0; i < 32; i += 2) {
-                int t0, t1;
-                asm volatile("v_accvgpr_read_b32 %1, %3\n\tv_accvgpr_read_b32 %2, %4\n\tv_max3_i32 %0, %1, %2, %0"
-                             : "+v"(m), "=&v"(t0), "=&v"(t1) : "a"(acc[i >> 2][cb][i & 3]), "a"(acc[(i + 1) >> 2][cb][(i + 1) & 3]));
+            for (int b = 0; b < 2; ++b) {
+                // four independent chains: with one wave on the SIMD a dependent VALU instruction waits out the whole
+                // pipeline (measured: ~8 clocks per instruction in a single chain)
+                int m0 = static_cast<int>(0x80000000u), m1 = m0, m2 = m0, m3 = m0;
+#pragma unroll
+                for (int i = 16 * b; i < 16 * b + 16; i += 8) {
+                    int t0, t1, t2, t3, t4, t5, t6, t7;
+                    asm volatile("v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
+                                 "v_accvgpr_read_b32 %8, %16\n\tv_accvgpr_read_b32 %9, %17\n\tv_accvgpr_read_b32 %10, %18\n\tv_accvgpr_read_b32 %11, %19\n\t"
+                                 "v_max3_i32 %0, %4, %5, %0\n\tv_max3_i32 %1, %6, %7, %1\n\tv_max3_i32 %2, %8, %9, %2\n\tv_max3_i32 %3, %10, %11, %3"
+                                 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                                 : "a"(acc[i >> 2][cb][0]), "a"(acc[i >> 2][cb][1]), "a"(acc[i >> 2][cb][2]), "a"(acc[i >> 2][cb][3]),
+                                   "a"(acc[(i >> 2) + 1][cb][0]), "a"(acc[(i >> 2) + 1][cb][1]), "a"(acc[(i >> 2) + 1][cb][2]), "a"(acc[(i >> 2) + 1][cb][3]));
+                }
+                const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+                mb[b] = (m01 > m23 ? m01 : m23) + nt[b][cb];
             }
-            const bool h = m >= 0 && q0 + cb * 16 + l15 < a.n_queries;
+            const bool h = (mb[0] >= 0 || mb[1] >= 0) && q0 + cb * 16 + l15 < a.n_queries;
             if (h) hot |= 1u << cb;
             if (__builtin_amdgcn_ballot_w64(h) != 0) hotw |= 1u << cb;
         }
@@ -1233,29 +1276,36 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
             do {
                 const int cb = __builtin_ctz(hotw);
                 hotw &= hotw - 1u;
-                int av[32];
-#define YAMS_Q_RD1(C, I) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av[I]) : "a"(acc[(I) >> 2][C][(I) & 3]));
-#define YAMS_Q_RD4(C, I) YAMS_Q_RD1(C, I) YAMS_Q_RD1(C, I + 1) YAMS_Q_RD1(C, I + 2) YAMS_Q_RD1(C, I + 3)
-#define YAMS_Q_READ_BLOCK(C)                                                                                           \
-    YAMS_Q_RD4(C, 0) YAMS_Q_RD4(C, 4) YAMS_Q_RD4(C, 8) YAMS_Q_RD4(C, 12) YAMS_Q_RD4(C, 16) YAMS_Q_RD4(C, 20) YAMS_Q_RD4(C, 24) YAMS_Q_RD4(C, 28)
-                switch (cb) {
-                    case 0: YAMS_Q_READ_BLOCK(0) break;
-                    case 1: YAMS_Q_READ_BLOCK(1) break;
-                    case 2: YAMS_Q_READ_BLOCK(2) break;
-                    case 3: YAMS_Q_READ_BLOCK(3) break;
-                    case 4: YAMS_Q_READ_BLOCK(4) break;
-                    case 5: YAMS_Q_READ_BLOCK(5) break;
-                    case 6: YAMS_Q_READ_BLOCK(6) break;
-                    default: YAMS_Q_READ_BLOCK(7) break;
-                }
-#undef YAMS_Q_READ_BLOCK
-#undef YAMS_Q_RD4
-#undef YAMS_Q_RD1
+                // Element i of the block is read out of its AGPR wherever it is needed — twice per survivor at worst —
+                // instead of holding the block's 32 values in VGPRs: the wave's 256 VGPRs belong to the row fragments
+                // in flight.  SIGNS: shift the mask left, the element's sign comes in at the bottom; ELEMENT e of a
+                // lane: a compare-and-select chain over the 32.  (I - T = I + nt is what the log carries: the gather
+                // kernel re-derives T from the entry's row.)
+                uint32_t sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0; // (four chains of eight elements each, as above)
+                int e = 0, val0 = 0, val1 = 0, val2 = 0, val3 = 0;
+#define YAMS_Q_CH(X, I) ((I) < 8 ? X##0 : (I) < 16 ? X##1 : (I) < 24 ? X##2 : X##3)
+#define YAMS_Q_SG1(C, I) { int t_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[(I) >> 2][C][(I) & 3])); \
+                           const uint32_t n_ = __builtin_amdgcn_alignbit(YAMS_Q_CH(sg, I), static_cast<uint32_t>(t_ + nt[(I) >> 4][C]), 31); \
+                           if ((I) < 8) sg0 = n_; else if ((I) < 16) sg1 = n_; else if ((I) < 24) sg2 = n_; else sg3 = n_; }
+#define YAMS_Q_EL1(C, I) { int t_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[(I) >> 2][C][(I) & 3])); \
+                           const int n_ = e == (I) ? t_ + nt[(I) >> 4][C] : YAMS_Q_CH(val, I); \
+                           if ((I) < 8) val0 = n_; else if ((I) < 16) val1 = n_; else if ((I) < 24) val2 = n_; else val3 = n_; }
+#define YAMS_Q_4(M, C, I) M(C, I) M(C, I + 8) M(C, I + 16) M(C, I + 24)
+#define YAMS_Q_32(M, C) YAMS_Q_4(M, C, 0) YAMS_Q_4(M, C, 1) YAMS_Q_4(M, C, 2) YAMS_Q_4(M, C, 3) YAMS_Q_4(M, C, 4) YAMS_Q_4(M, C, 5) YAMS_Q_4(M, C, 6) YAMS_Q_4(M, C, 7)
+#define YAMS_Q_SWITCH(M)                                                                                               \
+    switch (cb) {                                                                                                      \
+        case 0: YAMS_Q_32(M, 0) break;                                                                                 \
+        case 1: YAMS_Q_32(M, 1) break;                                                                                 \
+        case 2: YAMS_Q_32(M, 2) break;                                                                                 \
+        case 3: YAMS_Q_32(M, 3) break;                                                                                 \
+        case 4: YAMS_Q_32(M, 4) break;                                                                                 \
+        case 5: YAMS_Q_32(M, 5) break;                                                                                 \
+        case 6: YAMS_Q_32(M, 6) break;                                                                                 \
+        default: YAMS_Q_32(M, 7) break;                                                                                \
+    }
+                YAMS_Q_SWITCH(YAMS_Q_SG1)
                 const uint32_t qi = q0 + static_cast<uint32_t>(cb) * 16u + l15;
-                // the sign bits, one instruction per element: shift the mask left, the element's sign comes in at the bottom
-                uint32_t sg = 0;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) sg = __builtin_amdgcn_alignbit(sg, static_cast<uint32_t>(av[i]), 31);
+                const uint32_t sg = (sg0 << 24) | (sg1 << 16) | (sg2 << 8) | sg3; // bit 31 - i: element i is negative
                 uint32_t pm = __builtin_bitreverse32(~sg) & valid; // bit i: element i is a survivor
                 if (!((hot >> cb) & 1u)) pm = 0;
                 bool lost = false;
@@ -1263,22 +1313,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
                     const bool p = pm != 0;
                     const uint64_t m = __builtin_amdgcn_ballot_w64(p);
                     if (m == 0) break;
-                    const int e = p ? __builtin_ctz(pm) : 0;
-                    // element e of the 32: a select tree, 31 v_cndmask (the operands pass through an empty asm: the
-                    // compiler would otherwise turn "c ? av[2 j + 1] : av[2 j]" into an indexed load and the array into scratch)
-                    auto sel = [](bool c, int x, int y) __attribute__((always_inline)) -> int {
-                        asm("" : "+v"(x), "+v"(y));
-                        return c ? x : y;
-                    };
-                    int t16[16], t8[8], t4[4];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) t16[j] = sel(e & 1, av[2 * j + 1], av[2 * j]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t8[j] = sel(e & 2, t16[2 * j + 1], t16[2 * j]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t4[j] = sel(e & 4, t8[2 * j + 1], t8[2 * j]);
-                    const int u0 = sel(e & 8, t4[1], t4[0]), u1 = sel(e & 8, t4[3], t4[2]);
-                    const int val = sel(e & 16, u1, u0);
+                    e = p ? __builtin_ctz(pm) : 0;
+                    val0 = val1 = val2 = val3 = 0;
+                    YAMS_Q_SWITCH(YAMS_Q_EL1)
+                    const int val = val0 | val1 | val2 | val3; // (one chain holds the element, the others 0)
                     const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
                     base += static_cast<uint32_t>(__builtin_popcountll(m));
                     if (p) {
@@ -1295,15 +1333,20 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
                 }
                 if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
             } while (hotw != 0);
+#undef YAMS_Q_SWITCH
+#undef YAMS_Q_32
+#undef YAMS_Q_4
+#undef YAMS_Q_EL1
+#undef YAMS_Q_SG1
+#undef YAMS_Q_CH
             log_pos = base;
         }
         const uint64_t tm2 = wall_clock64();
-        // the next strip's thresholds
+        // the next strip's block scales
         sb[0] = meta_n[0]; eb[0] = meta_n[1]; sb[1] = meta_n[2]; eb[1] = meta_n[3];
         // the next strip's slab 1 and the siblings' counters are older than the eight pieces of its slab 2 — and than any
         // survivor store of this strip: a counted wait, the stores drain under the next strip's first slab
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(sib) :: "memory");
-        thresholds();
         const uint64_t tm3 = wall_clock64();
         if (n_qt > 1 && more && pacing) {
             asm volatile("" : "+v"(sib));
@@ -1326,7 +1369,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         dbg[qt * 4 + 2] = static_cast<uint32_t>(tm_wait); dbg[qt * 4 + 3] = static_cast<uint32_t>(tm_pace);
     }
     if (lane == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the spare loads of the strip that does not exist)
 }
 
 
@@ -2083,11 +2126,11 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
-    if (rp.use && version == 70) { // 128 x 128 wave tiles, one wave per SIMD
+    if (rp.use && version == 70 && L.plan.dim % (64u * Q_DEPTH) == 0 && L.plan.dim >= 128u * Q_DEPTH) { // 128 x 128 wave tiles, one wave per SIMD
         hipLaunchKernelGGL((scan_tiles_i8q_kernel<0>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
-    if (rp.use && version == 71) { // the same without DMA refills after the prologue (ablation)
+    if (rp.use && version == 71 && L.plan.dim % (64u * Q_DEPTH) == 0 && L.plan.dim >= 128u * Q_DEPTH) { // the same without row loads after the prologue (ablation)
         hipLaunchKernelGGL((scan_tiles_i8q_kernel<1>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
