@@ -30,7 +30,7 @@ for v in sys.argv[1:]:
     out[v] = {"filter_ms": acc.kernel_ms("scan_filter")[0], "candidates": dg.get("filter_candidates"), "fallback": dg.get("exact_fallback_queries"),
               "widened": dg.get("widened_queries")}
     acc.enable_timing(False)
-    if v in ("70", "71"):  # where the waves' time went (100 MHz ticks per wave and launch)
+    if v in ("70", "71", "72"):  # where the waves' time went (100 MHz ticks per wave and launch)
         import numpy as np
         os.environ["YAMS_ACCEL_DUMP_SYNC"] = "/tmp/i8q_sync.bin"
         acc.scan_topk_device(view, tq.data_ptr(), nq, k, -1.0, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(), flags=0, want_diag=False)
@@ -38,7 +38,7 @@ for v in sys.argv[1:]:
         w = np.fromfile("/tmp/i8q_sync.bin", dtype=np.uint32)
         ns = w.size // (12 * 32); n_qt = (nq + 127) // 128
         dbg = w[ns * 4 * 32:].reshape(ns, 8, 32)[:, :4, :n_qt * 4].reshape(ns, 4, n_qt, 4).astype(np.float64) / 100.0  # us
-        out[v]["phase_us_mean"] = dict(zip(("loop", "sign_test", "emission", "drain_and_pace"), [round(float(x), 1) for x in dbg.mean(axis=(0, 1, 2))]))
+        out[v]["phase_us_mean"] = dict(zip(("loop", "sign_test", "emission", "shader_MHz_x100"), [round(float(x), 1) for x in dbg.mean(axis=(0, 1, 2))]))
         out[v]["phase_us_max_wave_total"] = round(float(dbg.sum(axis=3).max()), 1)
         out[v]["strips_per_wave"] = int(w[:ns * 4 * 32].reshape(ns, 4, 32)[:, :, :n_qt].max())
     res[v] = (r.clone(), s.clone(), c.clone())

@@ -5,6 +5,7 @@ distances bit-identical to the fp64-then-cast reference arithmetic (north_star a
 hold 0 ulp and assert it)."""
 import ctypes as C
 import json
+import os
 
 import numpy as np
 import pytest
@@ -319,6 +320,24 @@ def test_product_library_ignores_measurement_environment(acc, oracle, monkeypatc
     q = oracle.synth_rows(18, 1 << 40, 4, 128)
     r = check(acc, oracle, corpus, q, 20, expect_path=0)
     assert r.diag["escalated_queries"] == 0 and (r.counts == 20).all()
+
+
+def test_measurement_build_filter_forms_agree_with_the_product_form():
+    """The two alternative forms of the resident-query int8 filter kept in the measurement build (128 x 128
+    wave tiles with one wave per SIMD; the product's tiles with direct row loads) are not dead code paths: on ragged
+    shards, with thresholds and an allow-mask, they give the product form's results bit for bit AND its candidate
+    sets (tests/_filter_forms.py, its own process: the measurement library is chosen at import)."""
+    import json, subprocess, sys
+    env = dict(os.environ, YAMS_ACCEL_MEASURE_LIB="1")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_filter_forms.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    recs = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(recs) == 5
+    for r in recs:
+        assert r["tier"] == _lib.TIER_I8, r
+        assert r["identical_70"] and r["identical_80"], r
+        assert r["candidates"]["70"] == r["candidates"]["2"] == r["candidates"]["80"], r
+        assert r["fallback"] == {"2": 0, "70": 0, "80": 0}, r
 
 
 def test_massive_ties_take_the_exhaustive_fp64_path(acc, oracle):

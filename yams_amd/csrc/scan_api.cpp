@@ -360,7 +360,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 71))) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 80))) i8 = false;
 #endif
         ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2);
         ScanLaunch L;
@@ -435,9 +435,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
         uint32_t* d_qover = nullptr;
         if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip), one region per (workgroup, wave)
+            L.i8_q_form = i8_takes_q_form(L, bf16_version);
+            if (corpus->row_mask && corpus->row_mask_count) L.i8_mask_inflation = static_cast<double>(corpus->n_rows) / static_cast<double>(corpus->row_mask_count);
             const uint64_t regions = i8_log_regions(L);
             L.log_cap = i8_log_capacity(L);
-            YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * 8, (void**)&L.log_key));
+            YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * i8_log_entry_bytes(L), (void**)&L.log_key));
             YA_TRY(ws_get(ctx, "i8_log_q", static_cast<size_t>(regions) * L.log_cap * 4, (void**)&L.log_q));
             YA_TRY(ws_get(ctx, "i8_log_cnt", static_cast<size_t>(regions) * 4, (void**)&L.log_cnt));
             YA_TRY(ws_get(ctx, "q_over", static_cast<size_t>(nq) * 4, (void**)&d_qover));
@@ -480,7 +482,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
 #endif
 
 #ifdef YAMS_ACCEL_MEASURE
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 40 && bf16_version != 50 && bf16_version != 70) { // ablated kernels produce no candidates: stop here
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 40 && bf16_version != 50 && bf16_version != 70 && bf16_version != 80) { // ablated kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;
@@ -515,6 +517,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         YA_HIP(ctx, hipMemcpyAsync(h_status, d_status, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
         YA_HIP(ctx, hipMemcpyAsync(h_lcount, d_lcount, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
         YA_HIP(ctx, hipStreamSynchronize(st));
+#ifdef YAMS_ACCEL_MEASURE
+        if (const char* dump = std::getenv("YAMS_ACCEL_DUMP_LCOUNT")) // per-query candidate counts of the filter pass
+            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h_lcount, 4, nq, f); std::fclose(f); }
+#endif
         std::vector<uint32_t> failed, overflowed;
         for (uint32_t i = 0; i < nq; ++i) {
             filter_candidates += std::min<uint32_t>(h_lcount[i], plan.list_cap);

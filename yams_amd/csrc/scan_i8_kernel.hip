@@ -529,7 +529,11 @@ constexpr int R_LDS = R_MAX_SLABS * R_B_SLAB + 8 * R_RING; // 160 KiB: everythin
 
 // L2: the accumulators start at -T(block, query) - a_r m_q ("L2 on the int8 tier" above); a.rows_i8_meta is the
 // batch's thresholds meta, a.i8_row_bias / a.i8_q_bias hold a_r and m_q.  Nothing else differs.
-template <int ABL = 0, bool L2 = false>
+// DIRECT (round 3): the row fragments are loaded straight from global memory into the register double buffer — the
+// blocked shadow already is the fragment image, and a strip's rows are read by one wave only, so the LDS ring bought
+// nothing but latency cover (1.6 slabs against the one slab a register pair gives) at the price of a DMA write and a
+// fragment read per row byte: half of the kernel's LDS traffic, which ran at the LDS's 128 B/clk.
+template <int ABL = 0, bool L2 = false, bool DIRECT = false>
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
 
@@ -670,10 +674,12 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     take_request(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k_fut = take_result();
     Geo cur, nxt;
     locate(k_cur, cur);
+    if (!DIRECT) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
+            for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
+    }
     qthr_request();
     if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
@@ -723,35 +729,53 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // tile, `early` the first two slabs of a strip: slabs 1 and 2 landed before the strip began (the drain in
     // front of the thresholds), so they wait for no DMA, and the survivor stores of the previous strip's
     // epilogue — in the same in-order counter — get two slabs to complete before a counted wait looks at them.
-    auto body = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag) __attribute__((always_inline)) {
+    auto dfetch = [](i32x4v& dst, uint32_t vo, const unsigned char* src) __attribute__((always_inline)) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(src) : "memory");
+    };
+    // DIRECT: `dnext` = the strip's piece of the NEXT slab (the next strip's slab 0 after the last one): its four row
+    // fragments are requested under half 1, into the registers the previous slab has just left, and waited for at
+    // the beginning of the next slab (`early`: the strip's first slab, whose fragments the drain at the end of the
+    // previous strip has covered)
+    auto body = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag, const unsigned char* dnext = nullptr) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
         const unsigned char* bq = lds + s * R_B_SLAB;
         const unsigned char* bqn = lds + sn * R_B_SLAB;
+        if (DIRECT && ABL != 1 && !early)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[P][0]), "+v"(fa[P][1]), "+v"(fa[P][2]), "+v"(fa[P][3]) :: "memory");
         pin4(fa[P]); pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[0], 0, [&](int i) __attribute__((always_inline)) {
             if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
+            if (DIRECT && ABL != 1 && i >= 4 && i < 8) dfetch(fa[P ^ 1][(i - 4) & 3], static_cast<uint32_t>(offF), dnext + static_cast<uint32_t>((i - 4) & 3) * piece_row_stride);
         });
-        if (ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!DIRECT && ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pin4(fb[1]);
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[1], 4, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fa[P ^ 1][i < 4 ? i : 0] = ld(ring, (P ^ 1) * 4096 + offF + (i < 4 ? i : 0) * 1024);
-            if (i >= 4 && i < 8) fb[0][(i - 4) & 3] = ld(bqn, offF + ((i - 4) & 3) * 1024);
-            if (ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
-            if (ABL != 1 && i >= 11 && i < 15) piece(sbase, ss, P ^ 1, (i - 11) & 3);
+            if (!DIRECT && i < 4) fa[P ^ 1][i < 4 ? i : 0] = ld(ring, (P ^ 1) * 4096 + offF + (i < 4 ? i : 0) * 1024);
+            if (DIRECT ? i < 4 : (i >= 4 && i < 8)) fb[0][i & 3] = ld(bqn, offF + (i & 3) * 1024);
+            if (!DIRECT && ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
+            if (!DIRECT && ABL != 1 && i >= 11 && i < 15) piece(sbase, ss, P ^ 1, (i - 11) & 3);
         });
     };
 
+    if (DIRECT) {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
+        for (int rb = 0; rb < 4; ++rb) dfetch(fa[0][rb], static_cast<uint32_t>(offF), cur.base + static_cast<uint32_t>(rb) * piece_row_stride);
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) fa[0][rb] = ld(ring, offF + rb * 1024);
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!DIRECT) {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) piece(cur.base, 2, 0, rb); // slab 2 into the stage slab 0 just left
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (a strip begins with its slabs 1 and 2 landed)
+        for (int rb = 0; rb < 4; ++rb) piece(cur.base, 2, 0, rb); // slab 2 into the stage slab 0 just left
+    }
+    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (a strip begins with its slabs 1 and 2 landed)
 
     // ---- pacing ------------------------------------------------------------------------------------------
     // Pair p of the n_qt workgroups of a row stream reads the same strips in the same order; they come from
@@ -811,8 +835,9 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for `early`)
             const bool early = so == 0;
             const bool n0 = s + 3 >= nslab, n1 = s + 4 >= nslab;
-            body(s + 1, early, n0 ? nxt.base : cur.base, n0 ? s + 3 - nslab : s + 3, s, C0{});
-            body(s + 2 >= nslab ? 0 : s + 2, early, n1 ? nxt.base : cur.base, n1 ? s + 4 - nslab : s + 4, s + 1, C1{});
+            body(s + 1, early, n0 ? nxt.base : cur.base, n0 ? s + 3 - nslab : s + 3, s, C0{}, cur.base + static_cast<uint32_t>(s + 1) * 1024u);
+            body(s + 2 >= nslab ? 0 : s + 2, DIRECT ? false : early, n1 ? nxt.base : cur.base, n1 ? s + 4 - nslab : s + 4, s + 1, C1{},
+                 s + 2 >= nslab ? nxt.base : cur.base + static_cast<uint32_t>(s + 2) * 1024u);
             s += 2;
         } while (s < nslab);
         asm volatile("" : "+s"(meta_n)); // (every slab waits lgkmcnt(0): the scalar load has long returned)
@@ -946,33 +971,42 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 
 
 // -------------------------------------------------------------------------------------------------
-// The resident-query filter with 128 x 128 WAVE TILES (round 3; cosine only): one wave per SIMD, four waves per
-// workgroup, the accumulators — 256 registers — in the AGPR half of the wave's 512.  Why: with 64 x 128 wave tiles
-// every 32 MFMAs cost 12 KiB of LDS fragment reads + 4 KiB of DMA writes; at the matrix pipe's full rate that is
-// exactly the 128 B/clk an LDS delivers, and the kernel sits at 70 % MFMA busy with the LDS 70 % busy beside it
-// (profiles/r02_pmc.json; no fragment reads at all: the bare-MFMA 4.3 ms).  Here
+// The resident-query filter with 128 x 128 WAVE TILES (round 3; cosine only): ONE wave per SIMD, four waves per
+// workgroup, 512 registers per wave.  Why: with 64 x 128 wave tiles (scan_tiles_i8r_kernel) every 32 MFMAs cost
+// 12 KiB of LDS fragment reads + 4 KiB of DMA writes; at the matrix pipe's full rate that is exactly the 128 B/clk
+// an LDS delivers, and the kernel sits at 70 % MFMA busy with the LDS 70 % busy beside it (profiles/r02_pmc.json;
+// no fragment reads at all: the bare-MFMA 4.3 ms).  Here
 //   * the ROW fragments do not pass through the LDS at all: a row piece is read by exactly one wave, the blocked
-//     shadow already is the fragment image (a lane's 16 bytes of a 1 KiB piece), and a wave that owns 256 VGPRs
-//     besides its accumulators can hold THREE slabs of its 128 rows (96 registers, loaded straight from global
-//     memory: one being multiplied, two on their way — ~1 us of latency cover, what the DMA ring had; four
-//     slabs did not fit: the register allocator started moving accumulators through VGPRs);
+//     shadow already is the fragment image (a lane's 16 bytes of a 1 KiB piece), and a wave with 512 registers can
+//     hold several slabs of its 128 rows in flight, loaded straight from global memory;
 //   * the QUERY fragments (shared by the four waves and by every strip) stay in the LDS: 8 KiB of reads per
 //     64 MFMAs and wave — 32 B/clk per CU instead of 128.
-// The price: no second wave on the SIMD to hide a wave's epilogue.  So the accumulators are born in the first
-// slab's MFMAs (C operand = the constant 0: no initialisation pass, no AGPR besides the 256), the thresholds enter
-// in the epilogue (a survivor is I >= T: one maximum per 64-row block and query block against T), and the sign
-// test and the emission are written for instruction count (see there).
+// The price: no second wave on the SIMD to hide a wave's epilogue — whatever the wave does between two strips is
+// added to the launch, at one instruction per 4+ clocks.  So
+//   * the accumulators are born in the first slab's MFMAs (C operand = the constant 0: no initialisation pass);
+//     the thresholds enter in the epilogue (a survivor is I >= T: one maximum per 64-row block and query block
+//     against T);
+//   * the register files are used the other way round: the FRAGMENTS (MFMA A / B operands, the targets of
+//     global_load / ds_read) live in the AGPRs, three quarters of the ACCUMULATORS (query blocks 0-5) in the
+//     architectural VGPRs, where v_max3 reads them directly — a v_accvgpr_read per accumulator register made the
+//     sign test 420 instructions per strip and 1.1 ms of the launch; it is 130 + 100 now (query blocks 6, 7 still
+//     sit in AGPRs: 256 VGPRs do not hold 256 accumulator registers and the addresses);
+//   * MFMAs, loads and waits are written out (inline asm) — the register allocator has no slack to play with:
+//     through the builtins it kept 18 accumulators in the wrong file and shuttled them through a[0:3].
 // Same strip geometry as scan_tiles_i8r_kernel (a unit = 512 rows = two filter tiles; wave w owns rows
 // [128 w, +128) of every unit of its stream — a static assignment: the four waves sit on four SIMDs of their own),
-// the same blocked shadow, query tile, thresholds, survivor log and pacing counters.  dim % 192 == 0 (the register
-// ring is indexed statically: three slabs per trip of the k loop) — 384 and 768, the dimensions of BASELINE.json.
+// the same blocked shadow, query tile, thresholds, survivor log and pacing counters.  dim % (64 Q_DEPTH) == 0 (the
+// register ring is indexed statically: Q_DEPTH slabs per trip of the k loop) — 384 and 768, the dimensions of
+// BASELINE.json, with Q_DEPTH = 3.
 // -------------------------------------------------------------------------------------------------
 constexpr int Q_THREADS = 256;
 #ifndef Q_DEPTH_SLABS
 #define Q_DEPTH_SLABS 3
 #endif
-constexpr int Q_DEPTH = Q_DEPTH_SLABS;                          // slabs of row fragments in registers (one being multiplied, two on their way)
+constexpr int Q_DEPTH = Q_DEPTH_SLABS;              // slabs of row fragments in registers (one being multiplied, the others on their way)
 constexpr int Q_LDS = R_MAX_SLABS * R_B_SLAB;       // 96 KiB: the query tile
+constexpr int Q_BLK_DWORDS = 36;                    // a block entry of the survivor log: 16-byte head + a lane's 32 accumulators of a query block
+#define Q_ACC_IN_AGPR(cb) ((cb) >= 6)               // query blocks whose accumulators live in AGPRs
 
 template <int ABL = 0>
 __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
@@ -990,7 +1024,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const uint32_t dim = a.dim;
-    const int nslab = dim / I8_SLAB; // 6 or 12 (checked by the host)
+    const int nslab = dim / I8_SLAB; // a multiple of Q_DEPTH, >= 2 Q_DEPTH (checked by the host)
     const uint32_t q0 = qt * R_QUERIES;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) unsigned char*)lds));
@@ -1000,6 +1034,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     struct Geo {
         uint64_t row0;               // first row of the strip; >= n_rows when the strip does not exist
         const unsigned char* base;   // first piece of the strip (uniform); an absent strip reads the shard's last rows
+        uint32_t rbmax;              // last 16-row block of the strip inside the (64-row padded) shadow: the blocks behind it re-read that one
     };
     const uint32_t piece_row_stride = static_cast<uint32_t>(nslab) * 1024u; // bytes between the pieces of consecutive 16-row blocks
     // strip i of this wave: unit stream + i * n_streams, tile (w >> 1) of the unit, rows [128 (w & 1), +128) of the tile
@@ -1013,24 +1048,21 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
             row0 = static_cast<uint64_t>(tile) * I8_ROWS + static_cast<uint32_t>((wid & 1) * 128);
         }
         g.row0 = row0;
-        uint64_t rowb = row0;
-        if (rowb + 128 > past_end) rowb = past_end >= 128 ? past_end - 128 : 0; // (n_rows >= 4096 on this path; a strip's tail past the padded shadow reads earlier rows, never emitted)
+        // (n_rows >= 4096 on this path.)  The shadow is padded to 64 rows, a strip is 128: the shard's last strip may
+        // have only its first 64 rows there — its row blocks 4-7 re-read block 3 (rows >= n_rows: never emitted);
+        // a strip that does not exist reads the shard's last 64 rows
+        const uint64_t rowb = row0 < past_end ? row0 : past_end - 64;
+        g.rbmax = rowb + 128 <= past_end ? 7u : 3u;
         g.base = reinterpret_cast<const unsigned char*>(a.rows_i8) + (rowb / 16) * piece_row_stride;
     };
     typedef float f2_t __attribute__((ext_vector_type(2)));
-    // {A_lo, B_hi} of this lane's eight queries: loaded ONCE — unlike scan_tiles_i8r_kernel this kernel has the
-    // registers to keep them (nothing is re-requested under the epilogue, so nothing in flight can be moved by the
-    // register allocator)
-    f2_t qthr[8];
-    {
-        const f2_t* qthr_p = reinterpret_cast<const f2_t*>(a.q_thr) + (q0 + l15); // < q_pad: the table is padded
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) qthr[cb] = qthr_p[cb * 16];
-    }
-    // block scales / residue bounds of the strip's two 64-row blocks: {s0, e0, s1, e1}, one scalar load
-    auto meta_ptr = [&](uint64_t row0) __attribute__((always_inline)) -> const float* {
+    // block scales / residue bounds of the strip's two 64-row blocks: {s0, e0, s1, e1}, one scalar load.  The shard's
+    // last strip may own the table's last block only: the load is taken one block earlier then (`shifted`) and the
+    // strip's first block is the loaded pair's second (its second block has no rows)
+    auto meta_ptr = [&](uint64_t row0, bool& shifted) __attribute__((always_inline)) -> const float* {
         uint64_t blk = row0 / I8_BLOCK_ROWS;
-        if (blk + 2 > n_blocks) blk = n_blocks >= 2 ? n_blocks - 2 : 0; // a strip past the end: nothing of it is ever emitted
+        shifted = blk + 1 == n_blocks;
+        if (blk + 2 > n_blocks) blk = n_blocks - 2; // (a strip past the end: nothing of it is ever emitted)
         return a.rows_i8_meta + 2ull * blk;
     };
 
@@ -1053,11 +1085,12 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
     locate(0u, cur);
     float sb[2], eb[2];
     {
-        const float* mp = meta_ptr(cur.row0);
+        bool shifted;
+        const float* mp = meta_ptr(cur.row0, shifted);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            sb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[2 * b])));
-            eb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[2 * b + 1])));
+            sb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[shifted ? 2 : 2 * b])));
+            eb[b] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[shifted ? 3 : 2 * b + 1])));
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1065,73 +1098,91 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
 
     // a lane's 16 bytes of a 1 KiB piece (16 rows x one slab): row l15, 16-byte chunk lq (stored swizzled) — in the
     // query tile's LDS image and in the blocked shadow alike
-    const int offF = l15 * 64 + ((lq ^ i8_swz(l15)) << 4);
-    i32x4v acc[8][8];
-    i32x4v fa[Q_DEPTH][8], fb[2][4];
-    uint32_t voff[8]; // row block rb of a strip: its piece of slab 0 + this lane's bytes
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) voff[rb] = static_cast<uint32_t>(rb) * piece_row_stride + static_cast<uint32_t>(offF);
-    // row block rb of slab ss of the strip at `sbase` into register slot S (lands some time later: see `landed`)
+    const uint32_t offF = static_cast<uint32_t>(l15 * 64 + ((lq ^ i8_swz(l15)) << 4));
+    const uint32_t ldsF = lds0 + offF;
+    i32x4v acc[8][8];               // [row block][query block]: VGPRs, query blocks 6 and 7 AGPRs
+    i32x4v fa[Q_DEPTH][8], fb[2][4]; // AGPRs
+    // row block rb of a slab (`sslab` = the strip's piece of that slab, uniform) into a register slot; lands later (see body)
     auto fetch1 = [](i32x4v& dst, uint32_t vo, const unsigned char* sslab) __attribute__((always_inline)) {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(sslab) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(vo), "s"(sslab) : "memory");
     };
-    auto ld = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> i32x4v {
-        return *reinterpret_cast<const i32x4v*>(base + off);
-    };
-    int nt[2][8]; // -T(block b of this strip, query block cb)
-    auto thresholds = [&]() __attribute__((always_inline)) {
+#define YAMS_Q_LDSQ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=a"(DST) : "v"(ADDR) : "memory")
+    // {A_lo, B_hi} of this lane's eight queries: loaded once, resident
+    f2_t qthr[8];
+    {
+        const f2_t* qthr_p = reinterpret_cast<const f2_t*>(a.q_thr) + (q0 + l15); // < q_pad: the table is padded
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float is = 1.0f / sb[b], g = eb[b] * is; // (the same expressions as in i8_log_gather_kernel)
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) nt[b][cb] = i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g);
-        }
+        for (int cb = 0; cb < 8; ++cb) qthr[cb] = qthr_p[cb * 16];
+    }
+    // -T(block b of this strip, query block cb): computed UNDER the strip's MFMAs (sixteen thresholds, four
+    // instructions each, one per MFMA slot of the first slab) — after the loop they would be 64 instructions of the
+    // serial epilogue
+    int nt[2][8];
+    float thr_is[2], thr_g[2];
+    auto threshold1 = [&](int b, int cb) __attribute__((always_inline)) {
+        nt[b][cb] = i8_neg_threshold(qthr[cb][0], thr_is[b], qthr[cb][1], thr_g[b]); // (the same expressions as in i8_log_gather_kernel)
+        asm volatile("" : "+v"(nt[b][cb]));
     };
     // 32 MFMAs: the strip's eight row blocks x four query blocks.  FIRST: the strip's first slab — the accumulators
     // are BORN here (C operand = 0)
-    auto half = [&](const i32x4v (&A)[8], const i32x4v (&B)[4], int cb0, auto first_tag, auto&& filler) __attribute__((always_inline)) {
+    auto half = [&](const i32x4v (&A)[8], const i32x4v (&B)[4], auto cb0_tag, auto first_tag, auto&& filler) __attribute__((always_inline)) {
         constexpr bool first = decltype(first_tag)::value;
+        constexpr int cb0 = decltype(cb0_tag)::value;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int rb = i >> 2, c = i & 3;
-            // (written out with the accumulator constrained to the AGPR file: through the builtin the register allocator
-            // — 64 tuples for 256 AGPRs, no slack — kept 18 of them in VGPRs and shuttled them through a[0:3])
-            if (first) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
-            else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
+            if (ABL == 2) { // measurement: no MFMAs (the memory pipeline alone)
+                if (first) { if (Q_ACC_IN_AGPR(cb0 + c)) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[rb][cb0 + c][0])); else acc[rb][cb0 + c] = i32x4v{-1, -1, -1, -1}; }
+                if (i == 0) asm volatile("" :: "a"(A[0]), "a"(A[1]), "a"(A[2]), "a"(A[3]), "a"(A[4]), "a"(A[5]), "a"(A[6]), "a"(A[7]), "a"(B[0]), "a"(B[1]), "a"(B[2]), "a"(B[3]));
+            } else if (Q_ACC_IN_AGPR(cb0 + c)) {
+                if (first) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc[rb][cb0 + c]) : "a"(A[rb]), "a"(B[c]));
+                else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[rb][cb0 + c]) : "a"(A[rb]), "a"(B[c]));
+            } else {
+                if (first) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=v"(acc[rb][cb0 + c]) : "a"(A[rb]), "a"(B[c]));
+                else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[rb][cb0 + c]) : "a"(A[rb]), "a"(B[c]));
+            }
             __builtin_amdgcn_sched_barrier(0);
             filler(i);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto pin4 = [&](i32x4v (&F)[4]) __attribute__((always_inline)) { asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3])); };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
+    using C4 = std::integral_constant<int, 4>;
 
     uint32_t sib = 0;       // pacing: the siblings' strip counters, requested in a strip's last slab
+    uint32_t st_prev = 0;   // survivor stores of the previous strip's epilogue (a multiple of 9; anything else: wait them out)
     uint32_t k_cur = 0;
-    // One slab (register slot S = slab % 3):
-    //   wait:   this slab's row fragments have landed (the eight loads of the slab behind it are younger);
+    // One slab (register slot S = slab % Q_DEPTH):
+    //   wait:   this slab's row fragments and its query blocks 0-3 have landed (the loads of the slabs behind it are younger);
     //   half 1: fa[S] x query blocks 0-3; requests query blocks 4-7 of this slab and the row fragments of the slab
-    //           TWO ahead (into the slot the previous slab has just left);
+    //           Q_DEPTH - 1 ahead (into the slot the previous slab has just left);
     //   half 2: fa[S] x query blocks 4-7; requests the next slab's query blocks 0-3.
-    // `sslab` names the slab the row fragments are requested from (the last two slabs of a strip request the
-    // next strip's first two), `sn` the next slab of the query tile.
-    auto body = [&](int sn, auto first_tag, const unsigned char* sslab, int s, auto slot_tag, bool last) __attribute__((always_inline)) {
+    // `sslab` names the slab the row fragments are requested from (the last slabs of a strip request the next
+    // strip's first ones), `sn` the next slab of the query tile.
+    // `stores`: survivor stores of the previous strip's epilogue that may still be in flight in front of this slab's
+    // row loads (the first two slabs of a strip; 0 elsewhere): the counter is in order, so the wait allows for them —
+    // waiting them out (a store's round trip) cost 0.6 ms of the launch
+    struct Slab { const unsigned char* p; uint32_t rbmax; }; // a strip's piece of a slab + the strip's last row block
+    auto body = [&](int sn, auto first_tag, Slab sslab, int s, auto slot_tag, bool last, uint32_t stores) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_tag)::value;
-        using SN = std::integral_constant<int, (S + Q_DEPTH - 1) % Q_DEPTH>;
-        const unsigned char* bq = lds + s * R_B_SLAB;
-        const unsigned char* bqn = lds + sn * R_B_SLAB;
-        if (ABL != 1 && Q_DEPTH == 4)
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]),
-                                                  "+v"(fa[S][4]), "+v"(fa[S][5]), "+v"(fa[S][6]), "+v"(fa[S][7]) :: "memory");
-        else if (ABL != 1)
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]),
-                                                 "+v"(fa[S][4]), "+v"(fa[S][5]), "+v"(fa[S][6]), "+v"(fa[S][7]) :: "memory");
-        pin4(fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[S], fb[0], 0, first_tag, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
+        constexpr int SN = (S + Q_DEPTH - 1) % Q_DEPTH;
+        const uint32_t aq = ldsF + static_cast<uint32_t>(s) * R_B_SLAB, aqn = ldsF + static_cast<uint32_t>(sn) * R_B_SLAB;
+#define YAMS_Q_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" : "+a"(fa[S][0]), "+a"(fa[S][1]), "+a"(fa[S][2]), "+a"(fa[S][3]), "+a"(fa[S][4]), \
+                                    "+a"(fa[S][5]), "+a"(fa[S][6]), "+a"(fa[S][7]), "+a"(fb[0][0]), "+a"(fb[0][1]), "+a"(fb[0][2]), "+a"(fb[0][3]) :: "memory")
+        if (ABL == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(fb[0][0]), "+a"(fb[0][1]), "+a"(fb[0][2]), "+a"(fb[0][3]) :: "memory");
+        else if (Q_DEPTH == 4) YAMS_Q_WAIT(16);
+        else if (stores == 9) YAMS_Q_WAIT(17);
+        else if (stores == 18) YAMS_Q_WAIT(26);
+        else if (stores == 27) YAMS_Q_WAIT(35);
+        else YAMS_Q_WAIT(8);
+#undef YAMS_Q_WAIT
+        half(fa[S], fb[0], C0{}, first_tag, [&](int i) __attribute__((always_inline)) {
+            if (i == 0) YAMS_Q_LDSQ(fb[1][0], aq, 4096);
+            if (i == 1) YAMS_Q_LDSQ(fb[1][1], aq, 5120);
+            if (i == 2) YAMS_Q_LDSQ(fb[1][2], aq, 6144);
+            if (i == 3) YAMS_Q_LDSQ(fb[1][3], aq, 7168);
             // the strip's last slab: "this wave has finished strip k_cur" (a slab early; pacing is best effort) and the
             // siblings' counters — OLDER than the eight loads below, so the counted wait at the strip's end covers them
             if (i == 5 && last) {
@@ -1140,91 +1191,92 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
                              "global_load_dword %0, %4, off sc0 sc1"
                              : "=&v"(sib), "=&s"(keep) : "v"(my_cnt + qt), "v"(k_cur + 1u), "v"(sync_sib) : "memory");
             }
-            if (ABL != 1 && i >= 6 && i < 14) fetch1(fa[SN::value][(i - 6) & 7], voff[(i - 6) & 7], sslab);
+            if (ABL != 1 && i >= 6 && i < 14)
+                fetch1(fa[SN][(i - 6) & 7], offF, sslab.p + (static_cast<uint32_t>((i - 6) & 7) < sslab.rbmax ? static_cast<uint32_t>((i - 6) & 7) : sslab.rbmax) * piece_row_stride);
+            if (decltype(first_tag)::value && i >= 16) threshold1(((i - 16) >> 3) & 1, (i - 16) & 7);
         });
-        pin4(fb[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        half(fa[S], fb[1], 4, first_tag, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fb[0][i < 4 ? i : 0] = ld(bqn, offF + (i < 4 ? i : 0) * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(fb[1][0]), "+a"(fb[1][1]), "+a"(fb[1][2]), "+a"(fb[1][3]) :: "memory");
+        half(fa[S], fb[1], C4{}, first_tag, [&](int i) __attribute__((always_inline)) {
+            if (i == 0) YAMS_Q_LDSQ(fb[0][0], aqn, 0);
+            if (i == 1) YAMS_Q_LDSQ(fb[0][1], aqn, 1024);
+            if (i == 2) YAMS_Q_LDSQ(fb[0][2], aqn, 2048);
+            if (i == 3) YAMS_Q_LDSQ(fb[0][3], aqn, 3072);
         });
     };
 
-    // the first strip's slabs 0 and 1; the first query fragments
+    // the first strip's first Q_DEPTH - 1 slabs; the first query fragments
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) fetch1(fa[0][rb], voff[rb], cur.base);
+    for (int d = 0; d < Q_DEPTH - 1; ++d)
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) fetch1(fa[1][rb], voff[rb], cur.base + 1024);
-    if (Q_DEPTH == 4) {
-#pragma unroll
-        for (int rb = 0; rb < 8; ++rb) fetch1(fa[2][rb], voff[rb], cur.base + 2048);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) fb[0][cb] = ld(lds, offF + cb * 1024);
+        for (int rb = 0; rb < 8; ++rb)
+            fetch1(fa[d][rb], offF, cur.base + static_cast<uint32_t>(d) * 1024u + (static_cast<uint32_t>(rb) < cur.rbmax ? static_cast<uint32_t>(rb) : cur.rbmax) * piece_row_stride);
+    YAMS_Q_LDSQ(fb[0][0], ldsF, 0); YAMS_Q_LDSQ(fb[0][1], ldsF, 1024); YAMS_Q_LDSQ(fb[0][2], ldsF, 2048); YAMS_Q_LDSQ(fb[0][3], ldsF, 3072);
 
     constexpr uint32_t Q_POLLS = 1024;
     bool pacing = true;
-    const uint32_t log_region = (stream * n_qt + qt) * 8u + static_cast<uint32_t>(wid);
+    const uint32_t log_region = (stream * n_qt + qt) * 4u + static_cast<uint32_t>(wid); // (four waves: four regions per workgroup)
     const uint64_t region = static_cast<uint64_t>(log_region) * a.log_cap;
     uint32_t log_pos = 0;
 
     uint64_t tm_loop = 0, tm_epi = 0, tm_wait = 0, tm_pace = 0; // (100 MHz ticks; measurement only)
+    const uint64_t ck_begin = clock64(), wk_begin = wall_clock64(); // shader clocks / 100 MHz ticks over the wave's life: the clock it ran at
     if (unit_of(k_cur) < n_units) for (;;) {
         const uint64_t tm0 = wall_clock64();
         const bool more = unit_of(k_cur + 1) < n_units;
         locate(k_cur + 1, nxt); // (past the end of the stream: the spare loads read the shard's last rows; nobody consumes them)
         float meta_n[4];        // the next strip's block scales, on their way through the scalar cache
         {
-            const float* mp = meta_ptr(nxt.row0);
+            bool shifted;
+            const float* mp = meta_ptr(nxt.row0, shifted);
             typedef float f4s __attribute__((ext_vector_type(4)));
             f4s mv;
             asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(mv) : "s"(mp) : "memory");
             asm volatile("" : "+s"(mv));
-            meta_n[0] = mv[0]; meta_n[1] = mv[1]; meta_n[2] = mv[2]; meta_n[3] = mv[3];
+            meta_n[0] = shifted ? mv[2] : mv[0]; meta_n[1] = shifted ? mv[3] : mv[1]; meta_n[2] = mv[2]; meta_n[3] = mv[3];
         }
-        // three slabs per trip (the register slot is a compile-time constant); the strip's first slab stands apart: it
-        // gives birth to the accumulators (compile-time C operand).  Slab s requests the row fragments of slab s + 2.
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { thr_is[b] = 1.0f / sb[b]; thr_g[b] = eb[b] * thr_is[b]; }
+        // Q_DEPTH slabs per trip (the register slot is a compile-time constant); the strip's first slab stands apart: it
+        // gives birth to the accumulators.  Slab s requests the row fragments of slab s + Q_DEPTH - 1.
         using T = std::true_type; using F = std::false_type;
-        auto src = [&](int s3) __attribute__((always_inline)) -> const unsigned char* { // slab s3 of this strip, or slab s3 - nslab of the next
-            return s3 >= nslab ? nxt.base + static_cast<uint32_t>(s3 - nslab) * 1024u : cur.base + static_cast<uint32_t>(s3) * 1024u;
+        auto src = [&](int s3) __attribute__((always_inline)) -> Slab { // slab s3 of this strip, or slab s3 - nslab of the next
+            return s3 >= nslab ? Slab{nxt.base + static_cast<uint32_t>(s3 - nslab) * 1024u, nxt.rbmax} : Slab{cur.base + static_cast<uint32_t>(s3) * 1024u, cur.rbmax};
         };
         if constexpr (Q_DEPTH == 3) {
-            body(1, T{}, src(2), 0, C0{}, false);
-            body(2, F{}, src(3), 1, C1{}, false);
-            body(3, F{}, src(4), 2, C2{}, false);
+            body(1, T{}, src(2), 0, C0{}, false, st_prev);
+            body(2, F{}, src(3), 1, C1{}, false, st_prev);
+            body(3, F{}, src(4), 2, C2{}, false, 0u);
             int s = 3;
             do { // (nslab >= 6)
-                body(s + 1, F{}, src(s + 2), s, C0{}, false);
-                body(s + 2, F{}, src(s + 3), s + 1, C1{}, false);
-                body(s + 3 >= nslab ? 0 : s + 3, F{}, src(s + 4), s + 2, C2{}, s + 3 >= nslab);
+                body(s + 1, F{}, src(s + 2), s, C0{}, false, 0u);
+                body(s + 2, F{}, src(s + 3), s + 1, C1{}, false, 0u);
+                body(s + 3 >= nslab ? 0 : s + 3, F{}, src(s + 4), s + 2, C2{}, s + 3 >= nslab, 0u);
                 s += 3;
             } while (s < nslab);
         } else {
             using C3 = std::integral_constant<int, 3>;
-            body(1, T{}, src(3), 0, C0{}, false);
-            body(2, F{}, src(4), 1, C1{}, false);
-            body(3, F{}, src(5), 2, C2{}, false);
-            body(4, F{}, src(6), 3, C3{}, false);
+            body(1, T{}, src(3), 0, C0{}, false, 0u);
+            body(2, F{}, src(4), 1, C1{}, false, st_prev);
+            body(3, F{}, src(5), 2, C2{}, false, 0u);
+            body(4, F{}, src(6), 3, C3{}, false, 0u);
             int s = 4;
             do { // (nslab >= 8)
-                body(s + 1, F{}, src(s + 3), s, C0{}, false);
-                body(s + 2, F{}, src(s + 4), s + 1, C1{}, false);
-                body(s + 3, F{}, src(s + 5), s + 2, C2{}, false);
-                body(s + 4 >= nslab ? 0 : s + 4, F{}, src(s + 6), s + 3, C3{}, s + 4 >= nslab);
+                body(s + 1, F{}, src(s + 3), s, C0{}, false, 0u);
+                body(s + 2, F{}, src(s + 4), s + 1, C1{}, false, 0u);
+                body(s + 3, F{}, src(s + 5), s + 2, C2{}, false, 0u);
+                body(s + 4 >= nslab ? 0 : s + 4, F{}, src(s + 6), s + 3, C3{}, s + 4 >= nslab, 0u);
                 s += 4;
             } while (s < nslab);
         }
         const uint64_t tm1 = wall_clock64();
 
         // ---- epilogue of the strip: acc[rb][cb][r] = I of row row0 + 16 rb + 4 lq + r and query q0 + 16 cb + l15; a
-        //      survivor is I >= T(64-row block, query), i.e. I + nt >= 0.  Nothing else runs on this SIMD while the
-        //      wave is here, so every instruction counts: the test is 1.5 instructions per accumulator register — two
-        //      AGPR reads and a v_max3 per pair, one maximum per (64-row block, query block) against its threshold —
-        //      written out: left to itself the compiler copies all 256 into VGPRs after the loop and keeps the copies
-        //      for the emission, 80 spilled registers, and a scratch reload waits for every survivor store in front
-        //      of it ---------------------------------------------------------------------------------------
+        //      survivor is I >= T(64-row block, query), i.e. I + nt >= 0: one maximum per (64-row block, query block)
+        //      against its threshold — 8 v_max3 per 16 accumulator registers in VGPRs; 8 v_accvgpr_read + 4 v_max3 per
+        //      8 in AGPRs (four independent chains either way) ------------------------------------------------
         const uint64_t strip = cur.row0;
-        thresholds();
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); // (the last MFMAs' results: the reads below are inline asm, no hazard recogniser looks at them)
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); // (the last MFMAs' results: they were written by inline asm, no hazard recogniser saw them)
+        auto mx3 = [](int x, int y, int z) __attribute__((always_inline)) -> int { const int t = x > y ? x : y; return t > z ? t : z; };
         uint32_t hotw = 0; // bit cb: some lane holds a survivor in query block cb (wave-uniform)
         uint32_t hot = 0;
 #pragma unroll
@@ -1232,21 +1284,27 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
             int mb[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                // four independent chains: with one wave on the SIMD a dependent VALU instruction waits out the whole
-                // pipeline (measured: ~8 clocks per instruction in a single chain)
-                int m0 = static_cast<int>(0x80000000u), m1 = m0, m2 = m0, m3 = m0;
+                int m;
+                if (Q_ACC_IN_AGPR(cb)) {
+                    int m0 = static_cast<int>(0x80000000u), m1 = m0, m2 = m0, m3 = m0;
 #pragma unroll
-                for (int i = 16 * b; i < 16 * b + 16; i += 8) {
-                    int t0, t1, t2, t3, t4, t5, t6, t7;
-                    asm volatile("v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
-                                 "v_accvgpr_read_b32 %8, %16\n\tv_accvgpr_read_b32 %9, %17\n\tv_accvgpr_read_b32 %10, %18\n\tv_accvgpr_read_b32 %11, %19\n\t"
-                                 "v_max3_i32 %0, %4, %5, %0\n\tv_max3_i32 %1, %6, %7, %1\n\tv_max3_i32 %2, %8, %9, %2\n\tv_max3_i32 %3, %10, %11, %3"
-                                 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-                                 : "a"(acc[i >> 2][cb][0]), "a"(acc[i >> 2][cb][1]), "a"(acc[i >> 2][cb][2]), "a"(acc[i >> 2][cb][3]),
-                                   "a"(acc[(i >> 2) + 1][cb][0]), "a"(acc[(i >> 2) + 1][cb][1]), "a"(acc[(i >> 2) + 1][cb][2]), "a"(acc[(i >> 2) + 1][cb][3]));
+                    for (int i = 16 * b; i < 16 * b + 16; i += 8) {
+                        int t0, t1, t2, t3, t4, t5, t6, t7;
+                        asm volatile("v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
+                                     "v_accvgpr_read_b32 %8, %16\n\tv_accvgpr_read_b32 %9, %17\n\tv_accvgpr_read_b32 %10, %18\n\tv_accvgpr_read_b32 %11, %19\n\t"
+                                     "v_max3_i32 %0, %4, %5, %0\n\tv_max3_i32 %1, %6, %7, %1\n\tv_max3_i32 %2, %8, %9, %2\n\tv_max3_i32 %3, %10, %11, %3"
+                                     : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                                     : "a"(acc[i >> 2][cb][0]), "a"(acc[i >> 2][cb][1]), "a"(acc[i >> 2][cb][2]), "a"(acc[i >> 2][cb][3]),
+                                       "a"(acc[(i >> 2) + 1][cb][0]), "a"(acc[(i >> 2) + 1][cb][1]), "a"(acc[(i >> 2) + 1][cb][2]), "a"(acc[(i >> 2) + 1][cb][3]));
+                    }
+                    m = mx3(m0, m1, m2 > m3 ? m2 : m3);
+                } else {
+                    const i32x4v &x0 = acc[4 * b][cb], &x1 = acc[4 * b + 1][cb], &x2 = acc[4 * b + 2][cb], &x3 = acc[4 * b + 3][cb];
+                    const int m0 = mx3(x0[0], x0[1], x0[2]), m1 = mx3(x0[3], x1[0], x1[1]), m2 = mx3(x1[2], x1[3], x2[0]);
+                    const int m3 = mx3(x2[1], x2[2], x2[3]), m4 = mx3(x3[0], x3[1], x3[2]);
+                    m = mx3(mx3(m0, m1, m2), mx3(m3, m4, x3[3]), static_cast<int>(0x80000000u));
                 }
-                const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
-                mb[b] = (m01 > m23 ? m01 : m23) + nt[b][cb];
+                mb[b] = m + nt[b][cb];
             }
             const bool h = (mb[0] >= 0 || mb[1] >= 0) && q0 + cb * 16 + l15 < a.n_queries;
             if (h) hot |= 1u << cb;
@@ -1255,98 +1313,58 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         if (strip >= a.n_rows) hotw = 0;
         asm volatile("" : "+s"(hotw));
         const uint64_t tm1b = wall_clock64();
+        st_prev = 0;
         if (hotw != 0) {
-            const uint32_t rows_left = static_cast<uint32_t>(a.n_rows - strip < 128 ? a.n_rows - strip : 128);
-            // bit 4 rb + r of a lane = its element (rb, r) = row strip + 16 rb + 4 lq + r: rows past the end and masked rows
-            uint32_t valid = 0xffffffffu;
-            if (rows_left < 128 || a.row_mask) {
-                valid = 0;
-#pragma unroll
-                for (int rb = 0; rb < 8; ++rb) {
-                    const uint32_t off0 = 16 * rb + 4 * lq;
-                    uint32_t mw = 0xfu;
-                    if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) valid |= (off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
-                }
-            }
+            // A lane that holds a survivor of query block cb writes ALL its 32 accumulators of that block: a BLOCK entry
+            // (Q_BLK_DWORDS dwords: {query, first row, -, -}, then I of element 4 rb + r = row first + 16 rb + r) —
+            // a ballot for the slots, nine stores, and the log gather kernel finds the survivors in it (thresholds, the
+            // shard's end and the row mask included).  Picking them out here, element by element, was 350 instructions
+            // per strip with nothing else running on the SIMD.
             uint32_t base = log_pos;
-            // one trip per query block that holds a survivor (one or two, typically): ONE copy of the code — eight
-            // unrolled copies ran from a cold instruction cache every time
-            do {
+            int32_t* const blk = reinterpret_cast<int32_t*>(a.log_key) + region * Q_BLK_DWORDS;
+            const uint32_t row_first = static_cast<uint32_t>(strip) + 4u * static_cast<uint32_t>(lq);
+            do { // one trip per query block that holds a survivor (one or two, typically): ONE copy of the code
                 const int cb = __builtin_ctz(hotw);
                 hotw &= hotw - 1u;
-                // Element i of the block is read out of its AGPR wherever it is needed — twice per survivor at worst —
-                // instead of holding the block's 32 values in VGPRs: the wave's 256 VGPRs belong to the row fragments
-                // in flight.  SIGNS: shift the mask left, the element's sign comes in at the bottom; ELEMENT e of a
-                // lane: a compare-and-select chain over the 32.  (I - T = I + nt is what the log carries: the gather
-                // kernel re-derives T from the entry's row.)
-                uint32_t sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0; // (four chains of eight elements each, as above)
-                int e = 0, val0 = 0, val1 = 0, val2 = 0, val3 = 0;
-#define YAMS_Q_CH(X, I) ((I) < 8 ? X##0 : (I) < 16 ? X##1 : (I) < 24 ? X##2 : X##3)
-#define YAMS_Q_SG1(C, I) { int t_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[(I) >> 2][C][(I) & 3])); \
-                           const uint32_t n_ = __builtin_amdgcn_alignbit(YAMS_Q_CH(sg, I), static_cast<uint32_t>(t_ + nt[(I) >> 4][C]), 31); \
-                           if ((I) < 8) sg0 = n_; else if ((I) < 16) sg1 = n_; else if ((I) < 24) sg2 = n_; else sg3 = n_; }
-#define YAMS_Q_EL1(C, I) { int t_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[(I) >> 2][C][(I) & 3])); \
-                           const int n_ = e == (I) ? t_ + nt[(I) >> 4][C] : YAMS_Q_CH(val, I); \
-                           if ((I) < 8) val0 = n_; else if ((I) < 16) val1 = n_; else if ((I) < 24) val2 = n_; else val3 = n_; }
-#define YAMS_Q_4(M, C, I) M(C, I) M(C, I + 8) M(C, I + 16) M(C, I + 24)
-#define YAMS_Q_32(M, C) YAMS_Q_4(M, C, 0) YAMS_Q_4(M, C, 1) YAMS_Q_4(M, C, 2) YAMS_Q_4(M, C, 3) YAMS_Q_4(M, C, 4) YAMS_Q_4(M, C, 5) YAMS_Q_4(M, C, 6) YAMS_Q_4(M, C, 7)
-#define YAMS_Q_SWITCH(M)                                                                                               \
-    switch (cb) {                                                                                                      \
-        case 0: YAMS_Q_32(M, 0) break;                                                                                 \
-        case 1: YAMS_Q_32(M, 1) break;                                                                                 \
-        case 2: YAMS_Q_32(M, 2) break;                                                                                 \
-        case 3: YAMS_Q_32(M, 3) break;                                                                                 \
-        case 4: YAMS_Q_32(M, 4) break;                                                                                 \
-        case 5: YAMS_Q_32(M, 5) break;                                                                                 \
-        case 6: YAMS_Q_32(M, 6) break;                                                                                 \
-        default: YAMS_Q_32(M, 7) break;                                                                                \
-    }
-                YAMS_Q_SWITCH(YAMS_Q_SG1)
+                const bool p = (hot >> cb) & 1u;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                base += static_cast<uint32_t>(__builtin_popcountll(m));
                 const uint32_t qi = q0 + static_cast<uint32_t>(cb) * 16u + l15;
-                const uint32_t sg = (sg0 << 24) | (sg1 << 16) | (sg2 << 8) | sg3; // bit 31 - i: element i is negative
-                uint32_t pm = __builtin_bitreverse32(~sg) & valid; // bit i: element i is a survivor
-                if (!((hot >> cb) & 1u)) pm = 0;
-                bool lost = false;
-                for (;;) { // one trip per survivor of the busiest lane (one, typically)
-                    const bool p = pm != 0;
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
-                    if (m == 0) break;
-                    e = p ? __builtin_ctz(pm) : 0;
-                    val0 = val1 = val2 = val3 = 0;
-                    YAMS_Q_SWITCH(YAMS_Q_EL1)
-                    const int val = val0 | val1 | val2 | val3; // (one chain holds the element, the others 0)
-                    const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                    base += static_cast<uint32_t>(__builtin_popcountll(m));
-                    if (p) {
-                        const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
-                        // the gather kernel re-derives T from the entry's ROW (its 64-row block): the accumulator goes in as is
-                        if (pos < a.log_cap) {
-                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
-                            a.log_q[region + pos] = qi;
-                        } else {
-                            lost = true;
-                        }
+                st_prev += 9;
+                if (__builtin_amdgcn_ballot_w64(p && pos >= a.log_cap) != 0) st_prev = 1000; // (an atomic besides the stores: no counting)
+                if (p && pos >= a.log_cap) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+                if (p && pos < a.log_cap) {
+                    i32x4v* const ent = reinterpret_cast<i32x4v*>(blk + static_cast<uint64_t>(pos) * Q_BLK_DWORDS);
+                    const i32x4v head = {static_cast<int>(qi), static_cast<int>(row_first), 0, 0};
+                    ent[0] = head;
+#define YAMS_Q_ST8(C) ent[1] = acc[0][C]; ent[2] = acc[1][C]; ent[3] = acc[2][C]; ent[4] = acc[3][C]; \
+                      ent[5] = acc[4][C]; ent[6] = acc[5][C]; ent[7] = acc[6][C]; ent[8] = acc[7][C];
+                    switch (cb) {
+                        case 0: YAMS_Q_ST8(0) break;
+                        case 1: YAMS_Q_ST8(1) break;
+                        case 2: YAMS_Q_ST8(2) break;
+                        case 3: YAMS_Q_ST8(3) break;
+                        case 4: YAMS_Q_ST8(4) break;
+                        case 5: YAMS_Q_ST8(5) break;
+                        case 6: YAMS_Q_ST8(6) break;
+                        default: YAMS_Q_ST8(7) break;
                     }
-                    pm &= pm - 1u;
+#undef YAMS_Q_ST8
                 }
-                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
             } while (hotw != 0);
-#undef YAMS_Q_SWITCH
-#undef YAMS_Q_32
-#undef YAMS_Q_4
-#undef YAMS_Q_EL1
-#undef YAMS_Q_SG1
-#undef YAMS_Q_CH
             log_pos = base;
         }
         const uint64_t tm2 = wall_clock64();
         // the next strip's block scales
         sb[0] = meta_n[0]; eb[0] = meta_n[1]; sb[1] = meta_n[2]; eb[1] = meta_n[3];
-        // the next strip's slab 1 and the siblings' counters are older than the eight pieces of its slab 2 — and than any
-        // survivor store of this strip: a counted wait, the stores drain under the next strip's first slab
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(sib) :: "memory");
+        // the next strip's first slab and the siblings' counters are older than the eight loads of its last prefetched
+        // slab — and than any survivor store of this strip: a counted wait, the stores drain under the next strip's
+        // first slab
+        if (st_prev == 9) asm volatile("s_waitcnt vmcnt(17)" : "+v"(sib) :: "memory");
+        else if (st_prev == 18) asm volatile("s_waitcnt vmcnt(26)" : "+v"(sib) :: "memory");
+        else if (st_prev == 27) asm volatile("s_waitcnt vmcnt(35)" : "+v"(sib) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(sib) :: "memory");
         const uint64_t tm3 = wall_clock64();
         if (n_qt > 1 && more && pacing) {
             asm volatile("" : "+v"(sib));
@@ -1363,10 +1381,13 @@ __global__ __launch_bounds__(Q_THREADS, 1) void scan_tiles_i8q_kernel(ScanArgs a
         cur = nxt;
         ++k_cur;
     }
+#undef YAMS_Q_LDSQ
     if (lane == 0 && n_qt <= 8) { // where the time went, per wave
         uint32_t* const dbg = a.i8_sync + (static_cast<uint64_t>(n_streams) * 4u + static_cast<uint64_t>(stream) * 8u + static_cast<uint32_t>(wid)) * 32u;
         dbg[qt * 4 + 0] = static_cast<uint32_t>(tm_loop); dbg[qt * 4 + 1] = static_cast<uint32_t>(tm_epi);
-        dbg[qt * 4 + 2] = static_cast<uint32_t>(tm_wait); dbg[qt * 4 + 3] = static_cast<uint32_t>(tm_pace);
+        dbg[qt * 4 + 2] = static_cast<uint32_t>(tm_wait);
+        dbg[qt * 4 + 3] = static_cast<uint32_t>((clock64() - ck_begin) * 100ull / (wall_clock64() - wk_begin + 1)); // MHz (the pace phase's slot)
+        (void)tm_pace;
     }
     if (lane == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the spare loads of the strip that does not exist)
@@ -1463,6 +1484,58 @@ __global__ __launch_bounds__(256) void i8_log_gather_wave_kernel(const uint64_t*
         const uint32_t q = qs[i];
         uint32_t row; float u;
         if (!i8_entry_score<L2>(keys[i], q, rows_meta, q_meta, q_thr, l2, row, u)) continue;
+        const uint32_t pos = slot0[q - q0] + atomicAdd(&hist[q - q0], 1u);
+        if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
+    }
+}
+
+// The same for the BLOCK entries of scan_tiles_i8q_kernel: an entry is a lane's 32 accumulators I of one query
+// block — element i = row first + 16 (i >> 2) + (i & 3) — and the survivors are picked out HERE: I >= T of the
+// row's 64-row block (the same instructions as everywhere: i8_neg_threshold), inside the shard, allowed by the row
+// mask.  One thread per element; the two passes (count, place) as above.
+__global__ __launch_bounds__(256) void i8_log_gather_blocks_kernel(const int32_t* log_blk, const uint32_t* log_cnt, uint32_t log_cap,
+                                                                   uint32_t n_qt, const float* rows_meta, const float* q_meta,
+                                                                   const float* q_thr, uint64_t n_rows, const uint32_t* row_mask,
+                                                                   uint32_t* list_count, uint64_t* list, uint32_t list_cap) {
+    __shared__ uint32_t hist[R_QUERIES], slot0[R_QUERIES];
+    const uint32_t r = blockIdx.x;
+    const uint32_t n = log_cnt[r];
+    if (n == 0) return;
+    const uint32_t q0 = ((r >> 2) % n_qt) * R_QUERIES;
+    const int tid = threadIdx.x;
+    if (tid < R_QUERIES) hist[tid] = 0u;
+    __syncthreads();
+    const int32_t* ents = log_blk + static_cast<uint64_t>(r) * log_cap * Q_BLK_DWORDS;
+    auto element = [&](uint32_t j, uint32_t& q, uint32_t& row, float& u) -> bool {
+        const int32_t* e = ents + static_cast<uint64_t>(j >> 5) * Q_BLK_DWORDS;
+        const uint32_t i = j & 31u;
+        q = static_cast<uint32_t>(e[0]);
+        row = static_cast<uint32_t>(e[1]) + 16u * (i >> 2) + (i & 3u);
+        if (row >= n_rows) return false;
+        if (row_mask && !((row_mask[row >> 5] >> (row & 31u)) & 1u)) return false;
+        const int I = e[4 + i];
+        const float2 m = reinterpret_cast<const float2*>(rows_meta)[row / I8_BLOCK_ROWS];
+        const float2 qt = reinterpret_cast<const float2*>(q_thr)[q];
+        const float is = 1.0f / m.x;
+        if (I + i8_neg_threshold(qt.x, is, qt.y, m.y * is) < 0) return false;
+        const float4 qm = reinterpret_cast<const float4*>(q_meta)[q];
+        u = fmaf(static_cast<float>(I), m.x * qm.x, fmaf(m.y, qm.y, qm.z));
+        return true;
+    };
+    for (uint32_t j = tid; j < n * 32u; j += 256) {
+        uint32_t q, row; float u;
+        if (element(j, q, row, u)) atomicAdd(&hist[q - q0], 1u);
+    }
+    __syncthreads();
+    if (tid < R_QUERIES) {
+        const uint32_t c = hist[tid];
+        slot0[tid] = c ? atomicAdd(&list_count[q0 + tid], c) : 0u;
+        hist[tid] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < n * 32u; j += 256) {
+        uint32_t q, row; float u;
+        if (!element(j, q, row, u)) continue;
         const uint32_t pos = slot0[q - q0] + atomicAdd(&hist[q - q0], 1u);
         if (pos < list_cap) list[static_cast<uint64_t>(q) * list_cap + pos] = pack_key(u, row);
     }
@@ -2004,10 +2077,23 @@ static ResidentPlan i8_resident_plan(const ScanLaunch& L) {
 // small for it the narrow bf16 form stays ahead of int8 half tiles.)
 bool i8_takes_resident_form(const ScanLaunch& L) { return i8_resident_plan(L).use; }
 
+bool i8_takes_q_form(const ScanLaunch& L, int version) {
+    if (L.i8_l2 || L.plan.dim % (64u * Q_DEPTH) != 0 || L.plan.dim < 128u * Q_DEPTH) return false;
+    if (!i8_resident_plan(L).use) return false;
+#ifdef YAMS_ACCEL_MEASURE
+    return version >= 70 && version <= 72;
+#else
+    (void)version;
+    return false;
+#endif
+}
+uint32_t i8_log_entry_bytes(const ScanLaunch& L) { return L.i8_q_form ? Q_BLK_DWORDS * 4u : 8u; }
+
 // survivor-log regions of the filter launch: one per (workgroup, wave) of the half-tile kernel, one per
 // (unit, query tile, wave) of the resident-query kernel — a 64 x 128 wave tile either way
 uint64_t i8_log_regions(const ScanLaunch& L) {
     const ResidentPlan r = i8_resident_plan(L);
+    if (r.use && L.i8_q_form) return static_cast<uint64_t>(r.n_streams) * r.n_qt * 4u;
     if (r.use) return static_cast<uint64_t>(r.n_streams) * r.n_qt * 8u;
     return static_cast<uint64_t>((2u * L.plan.n_filter_tiles + 7) / 8) * L.plan.n_qtiles * 8u * 4u;
 }
@@ -2036,6 +2122,15 @@ uint64_t i8_sync_words(const ScanLaunch& L) {
 uint32_t i8_log_capacity(const ScanLaunch& L) {
     const ScanPlan& p = L.plan;
     const ResidentPlan r = i8_resident_plan(L);
+    if (r.use && L.i8_q_form) {
+        // block entries: one per (lane, query block) that holds a survivor — about one per survivor, but found BEFORE
+        // the allow-mask is applied (the gather kernel applies it): as many more as the mask lets rows through
+        const double total = static_cast<double>(p.n_queries) * p.tau_rank * p.sample_stride * (L.i8_mask_inflation < 8.0 ? L.i8_mask_inflation : 8.0);
+        const double share = total / (static_cast<double>(r.n_streams) * r.n_qt * 4.0);
+        const double cap = 4.0 * share + 512.0;
+        const uint64_t c = static_cast<uint64_t>(cap < 1.0e6 ? cap : 1.0e6);
+        return static_cast<uint32_t>((c + 15) / 16 * 16);
+    }
     if (r.use) {
         const double total = static_cast<double>(p.n_queries) * p.tau_rank * p.sample_stride;
         const double share = total / (static_cast<double>(r.n_streams) * r.n_qt * 8.0);
@@ -2053,6 +2148,12 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     if (regions == 0) return hipSuccess;
     const ResidentPlan rp = i8_resident_plan(L);
     const I8GatherL2 l2{L.i8_l2_meta, L.i8_row_bias, L.i8_q_bias, L.rows_nsq, L.tau, L.l2_eps};
+    if (rp.use && L.i8_q_form) {
+        hipLaunchKernelGGL(i8_log_gather_blocks_kernel, dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
+                           reinterpret_cast<const int32_t*>(L.log_key), L.log_cnt, L.log_cap, rp.n_qt, L.rows_i8_meta, L.q_meta, L.q_thr,
+                           L.plan.n_rows, L.row_mask, L.list_count, L.list, L.plan.list_cap);
+        return hipGetLastError();
+    }
     if (rp.use) {
         if (L.i8_l2)
             hipLaunchKernelGGL((i8_log_gather_wave_kernel<true>), dim3(static_cast<uint32_t>(regions)), dim3(256), 0, st,
@@ -2126,11 +2227,19 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
-    if (rp.use && version == 70 && L.plan.dim % (64u * Q_DEPTH) == 0 && L.plan.dim >= 128u * Q_DEPTH) { // 128 x 128 wave tiles, one wave per SIMD
+    if (rp.use && version == 80) { // the resident-query form with direct row loads
+        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        return hipGetLastError();
+    }
+    if (rp.use && L.i8_q_form && version != 71 && version != 72) { // 128 x 128 wave tiles, one wave per SIMD
         hipLaunchKernelGGL((scan_tiles_i8q_kernel<0>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
-    if (rp.use && version == 71 && L.plan.dim % (64u * Q_DEPTH) == 0 && L.plan.dim >= 128u * Q_DEPTH) { // the same without row loads after the prologue (ablation)
+    if (rp.use && L.i8_q_form && version == 72) { // no MFMAs (ablation)
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<2>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        return hipGetLastError();
+    }
+    if (rp.use && L.i8_q_form && version == 71) { // the same without row loads after the prologue (ablation)
         hipLaunchKernelGGL((scan_tiles_i8q_kernel<1>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }

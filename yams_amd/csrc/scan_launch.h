@@ -24,6 +24,8 @@ struct ScanLaunch {
     const uint32_t* i8_q_bias = nullptr;
     float l2_eps = 0.f;
     int i8_form = 0;                     // int8 filter pass: 0 = the library's choice, 1 = half tiles, 2 = resident queries when possible
+    bool i8_q_form = false;              // resident queries with 128 x 128 wave tiles (i8_takes_q_form): the log holds BLOCK entries
+    double i8_mask_inflation = 1.0;      // n_rows / rows the allow-mask lets through (block entries are written before the mask is applied)
     int sample_layout = 0;               // rows of a sample group: 0 = 32x32 accumulator layout, 1 = 16x16 (int8 tier)
     const uint32_t* row_mask = nullptr;
     const float* qprep = nullptr;
@@ -125,6 +127,11 @@ uint64_t i8_log_regions(const ScanLaunch& L);
 uint32_t i8_log_capacity(const ScanLaunch& L);
 // whether the int8 filter pass of this launch would take the resident-query kernel form
 bool i8_takes_resident_form(const ScanLaunch& L);
+// ... and of those launches, which take its 128 x 128 wave-tile form (scan_tiles_i8q_kernel; `version`: the measurement
+// build's kernel selector, 0 otherwise).  Set ScanLaunch::i8_q_form from it before sizing the log.
+bool i8_takes_q_form(const ScanLaunch& L, int version);
+// bytes per entry of the survivor log (8 + 4 in two arrays: log_key gets the 8; block entries: 144, all in log_key)
+uint32_t i8_log_entry_bytes(const ScanLaunch& L);
 // pacing counters of the resident-query form (0 when the launch takes the half-tile form); zero them before the launch
 uint64_t i8_sync_words(const ScanLaunch& L);
 // after the filter pass: log entries -> per-query candidate lists (the returning atomics live here, where
