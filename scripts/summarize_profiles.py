@@ -32,7 +32,7 @@ copy(os.path.join(G, "prof_small", "small_kernel_stats.csv"), os.path.join(P, f"
 f = os.path.join(G, "prof_small_pmc", "small_counter_collection.csv")
 if os.path.exists(f):
     rows_ = list(csv.DictReader(open(f)))
-    v = [float(r["Counter_Value"]) for r in rows_ if ("scan_tiles_i8r_kernel<0>" in r["Kernel_Name"] or "scan_tiles_i8r_kernel<0, false>" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
+    v = [float(r["Counter_Value"]) for r in rows_ if ("scan_tiles_i8r_kernel<0>" in r["Kernel_Name"] or "scan_tiles_i8r_kernel<0, false" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
     small_i8 = bool(v)
     if not v:
         v = [float(r["Counter_Value"]) for r in rows_ if "bf16n_kernel<1," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
@@ -97,7 +97,7 @@ meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py
 json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(P, f"{tag}_pmc.json"))
 
-filt = ([k for k in summary if "scan_tiles_i8r_kernel<0>" in k or "scan_tiles_i8r_kernel<0, false>" in k] or [k for k in summary if "scan_tiles_i8h_kernel<1" in k] or [k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
+filt = ([k for k in summary if "scan_tiles_i8r_kernel<0>" in k or "scan_tiles_i8r_kernel<0, false" in k] or [k for k in summary if "scan_tiles_i8h_kernel<1" in k] or [k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
         or [k for k in summary if "bf16v2_kernel<1, 0" in k] or [k for k in summary if "scan_tiles_kernel<1, 0>" in k])
 if filt and "FETCH_SIZE" in summary[filt[0]]:
     fs = summary[filt[0]]["FETCH_SIZE"]["mean"]
