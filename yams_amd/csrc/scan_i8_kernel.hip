@@ -2176,6 +2176,9 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
     return hipGetLastError();
 }
 
+// Resident-query form: row fragments through the LDS ring (false) or straight into registers (true; DIRECT)?
+static bool i8r_direct_rows(uint32_t dim) { (void)dim; return false; }
+
 // Half tiles (128 rows x 256 queries), XCD-aware block -> tile map as for the bf16 tier.  version:
 // measurement build only — 40 = half tiles where the library would pick the resident-query form;
 // 41..48 ablations of the half-tile kernel (41 no DMA refills after the prologue, 42 no MFMAs, 43 neither,
@@ -2194,9 +2197,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
+    bool direct = i8r_direct_rows(L.plan.dim);
+#ifdef YAMS_ACCEL_MEASURE
+    if (const char* dv = std::getenv("YAMS_ACCEL_I8R_DIRECT")) direct = std::atoi(dv) != 0;
+#endif
     if (L.i8_l2) { // L2 batches: the same two kernel forms with the row / query biases (no measurement forms)
         a.rows_i8_meta = L.i8_l2_meta; // the thresholds meta of the shard; the shadow's own meta is the gather kernel's
-        if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+        if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+        else if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
@@ -2244,7 +2252,8 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
 #endif
-    if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    else if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
 }
