@@ -1,7 +1,7 @@
 """Run as a subprocess by test_scan_gpu.py with YAMS_ACCEL_MEASURE_LIB=1: the measurement build's alternative forms of
 the resident-query int8 filter — 70: 128 x 128 wave tiles, one wave per SIMD, row fragments loaded straight into
-registers, block entries in the survivor log; 80: the product's 64 x 128 wave tiles with direct row loads instead of
-the LDS ring — against the product form on the same shard: identical results AND identical candidate sets (count),
+registers, block entries in the survivor log; 80: 64 x 128 wave tiles with direct row loads (the product's form at
+dims 384 / 768 with >= 512 queries) — against the LDS-ring form (2; the product's form elsewhere) on the same shard: identical results AND identical candidate sets (count),
 on ragged shards (a last strip of 64 rows, a last unit of one tile), with thresholds and an allow-mask.  Prints one
 JSON line."""
 import json, os, sys
@@ -33,6 +33,7 @@ for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, Fal
     res = {}
     for v in ("2", "70", "80"):
         os.environ["YAMS_ACCEL_BF16_KERNEL"] = v
+        os.environ["YAMS_ACCEL_I8R_DIRECT"] = "0" if v == "2" else "1"   # "2": the LDS-ring form whatever the launcher's rule says
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         c = torch.zeros(nq, dtype=torch.int32, device="cuda")
         dg = acc.scan_topk_device(view, tq.data_ptr(), nq, k, thr, SCAN_COSINE, s.data_ptr(), r.data_ptr(), c.data_ptr(),

@@ -50,6 +50,7 @@ def test_no_scratch_traffic_inside_the_mfma_loops(src):
         if src == "scan_i8_kernel.hip":
             assert not any("scratch_" in l for l in body), name
     if src == "scan_i8_kernel.hip":     # both metrics of both kernel forms are there
-        for frag in ("scan_tiles_i8r_kernelILi0ELb0", "scan_tiles_i8r_kernelILi0ELb1", "scan_tiles_i8h_kernelILi1ELi0ELi0",
+        for frag in ("scan_tiles_i8r_kernelILi0ELb0ELb0", "scan_tiles_i8r_kernelILi0ELb1ELb0", "scan_tiles_i8r_kernelILi0ELb0ELb1",
+                     "scan_tiles_i8r_kernelILi0ELb1ELb1", "scan_tiles_i8h_kernelILi1ELi0ELi0",
                      "scan_tiles_i8h_kernelILi1ELi0ELi1", "scan_tiles_i8h_kernelILi0ELi0ELi1"):
             assert any(frag in k for k in tiles), frag
