@@ -745,8 +745,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         pin4(fa[P]); pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[0], 0, [&](int i) __attribute__((always_inline)) {
-            if (i < 4) fb[1][i < 4 ? i : 0] = ld(bq, offF + (4 + (i < 4 ? i : 0)) * 1024);
-            if (DIRECT && ABL != 1 && i >= 4 && i < 8) dfetch(fa[P ^ 1][(i - 4) & 3], static_cast<uint32_t>(offF), dnext + static_cast<uint32_t>((i - 4) & 3) * piece_row_stride);
+            if (DIRECT && ABL != 1 && i < 4) dfetch(fa[P ^ 1][i & 3], static_cast<uint32_t>(offF), dnext + static_cast<uint32_t>(i & 3) * piece_row_stride);
+            if (DIRECT ? (i >= 4 && i < 8) : i < 4) fb[1][i & 3] = ld(bq, offF + (4 + (i & 3)) * 1024);
         });
         if (!DIRECT && ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2178,15 +2178,17 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
 }
 
 // Resident-query form: row fragments through the LDS ring (false) or straight into registers (true; DIRECT)?
-// Measured on 12.5M-row shards (scripts/dbg/direct_sweep.sh, filter launch, ring / direct, three alternating runs each):
-//   1024 queries: dim 256 4.41 / 4.41 ms, 384 4.85 / 4.62, 512 5.51 / 5.71, 640 6.48 / 6.70, 768 7.69 / 7.76
-//                 (7.81 / 7.75 inside bench.py, L2 config 3: 6.51 / 6.48);
-//    512 queries: 512 2.88 / 2.93, 640 3.53 / 3.52;   256 queries: 384 1.33 / 1.40, 512 1.68 / 1.72, 768 2.40 / 2.49.
+// Measured on 12.5M-row shards (scripts/dbg/direct_sweep.sh: filter launch in ms, ring / direct, mean of three
+// alternating runs of six launches each):
+//   1024 queries (8 query tiles per stream): dim 256 4.43 / 4.42, 384 5.01 / 4.64, 512 5.43 / 5.45, 640 6.37 / 6.45,
+//                                            768 7.53 / 7.45;
+//    256 queries (2 query tiles per stream): dim 256 1.28 / 1.28, 384 1.34 / 1.36, 512 1.69 / 1.73, 640 2.04 / 2.04,
+//                                            768 2.37 / 2.38.
 // Bytes from HBM per launch at 768 x 1024: 17.4 GB / 10.2 GB (algorithmic 9.6: the ring runs three slabs ahead into
-// the next strip and the sibling workgroups of a stream drift further apart).  So: direct where it costs nothing —
-// the two dimensions of BASELINE.json — and the ring elsewhere; with few query tiles per stream (<= 256 queries) the
-// rows come from HBM rather than L2 and one slab of latency cover is too little.
-static bool i8r_direct_rows(uint32_t dim, uint32_t n_qt) { return (dim == 384 || dim == 768) && n_qt >= 4; }
+// the next strip and the sibling workgroups of a stream drift further apart).  So: direct when a stream has four or
+// more query tiles — the rows then come from L2 seven times out of eight and one slab of latency cover is enough —
+// and the ring for the small batches whose rows come from HBM.
+static bool i8r_direct_rows(uint32_t dim, uint32_t n_qt) { (void)dim; return n_qt >= 4; }
 
 // Half tiles (128 rows x 256 queries), XCD-aware block -> tile map as for the bf16 tier.  version:
 // measurement build only — 40 = half tiles where the library would pick the resident-query form;
