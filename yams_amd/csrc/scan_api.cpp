@@ -441,15 +441,17 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             L.log_cap = i8_log_capacity(L);
             YA_TRY(ws_get(ctx, "i8_log_key", static_cast<size_t>(regions) * L.log_cap * i8_log_entry_bytes(L), (void**)&L.log_key));
             YA_TRY(ws_get(ctx, "i8_log_q", static_cast<size_t>(regions) * L.log_cap * 4, (void**)&L.log_q));
-            YA_TRY(ws_get(ctx, "i8_log_cnt", static_cast<size_t>(regions) * 4, (void**)&L.log_cnt));
-            YA_TRY(ws_get(ctx, "q_over", static_cast<size_t>(nq) * 4, (void**)&d_qover));
-            YA_HIP(ctx, hipMemsetAsync(L.log_cnt, 0, static_cast<size_t>(regions) * 4, st));
-            YA_HIP(ctx, hipMemsetAsync(d_qover, 0, static_cast<size_t>(nq) * 4, st));
+            // the three small tables the filter launch needs zeroed — region counts, per-query overflow marks, pacing
+            // counters — share ONE buffer and one fill (each fill is a 5 us launch of its own in front of the sample pass)
+            const uint64_t sync_words = i8_sync_words(L);
+            const size_t z_cnt = (static_cast<size_t>(regions) * 4 + 255) & ~size_t(255), z_over = (static_cast<size_t>(nq) * 4 + 255) & ~size_t(255);
+            unsigned char* zeroed;
+            YA_TRY(ws_get(ctx, "i8_zeroed", z_cnt + z_over + static_cast<size_t>(sync_words) * 4, (void**)&zeroed));
+            YA_HIP(ctx, hipMemsetAsync(zeroed, 0, z_cnt + z_over + static_cast<size_t>(sync_words) * 4, st));
+            L.log_cnt = reinterpret_cast<uint32_t*>(zeroed);
+            d_qover = reinterpret_cast<uint32_t*>(zeroed + z_cnt);
             L.q_over = d_qover;
-            if (const uint64_t sync_words = i8_sync_words(L)) {
-                YA_TRY(ws_get(ctx, "i8_sync", static_cast<size_t>(sync_words) * 4, (void**)&L.i8_sync));
-                YA_HIP(ctx, hipMemsetAsync(L.i8_sync, 0, static_cast<size_t>(sync_words) * 4, st));
-            }
+            if (sync_words) L.i8_sync = reinterpret_cast<uint32_t*>(zeroed + z_cnt + z_over);
         }
 
         { TimedRegion tr(ctx, "scan_sample");
