@@ -90,6 +90,7 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     // and chunk hashing (which alone reach their VALU / HBM rooflines in a fraction of the time).
     const bool fork_blobs = (flags & YAMS_INGEST_BLOB_DIGESTS) && n_blobs > 0;
     uint8_t* d_blob_digests = nullptr;
+    uint64_t* d_sorted_blobs = nullptr;
     if (fork_blobs) {
         // Lanes of one workgroup advance in lock step, so messages are grouped by length
         // (longest first); out_slot maps the sorted position back to the blob index.
@@ -109,15 +110,25 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
         YA_HIP(ctx, hipMemcpyAsync(d_sorted, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, st));
         YA_HIP(ctx, hipStreamSynchronize(st)); // `sorted` is pageable and dies with this scope
         YA_TRY(ws_get(ctx, "ing_blob_digests", static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
+        d_sorted_blobs = d_sorted;
+    }
+    // the side stream's launch: at once, or (`long_after_cdc`) behind boundary detection
+    auto fork_long = [&]() -> yams_status_t {
         YA_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
         YA_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
         TimedRegion tr(ctx, "sha256_blobs", ctx->aux_stream);
-        YA_HIP(ctx, launch_sha256_long(ctx->aux_stream, data, d_sorted, d_sorted + n_blobs,
-                                       reinterpret_cast<const uint32_t*>(d_sorted + static_cast<size_t>(n_blobs) * 2),
+        YA_HIP(ctx, launch_sha256_long(ctx->aux_stream, data, d_sorted_blobs, d_sorted_blobs + n_blobs,
+                                       reinterpret_cast<const uint32_t*>(d_sorted_blobs + static_cast<size_t>(n_blobs) * 2),
                                        n_blobs, d_blob_digests));
         tr.end();
         YA_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
-    }
+        return YAMS_OK;
+    };
+    bool long_after_cdc = false;
+#ifdef YAMS_ACCEL_MEASURE
+    if (const char* e = std::getenv("YAMS_ACCEL_INGEST_LONG_AFTER_CDC")) long_after_cdc = std::atoi(e) != 0;
+#endif
+    if (fork_blobs && !(long_after_cdc && do_chunks)) YA_TRY(fork_long());
 
     uint64_t n_chunks = 0;
     uint64_t* d_msg_off = nullptr; uint64_t* d_msg_len = nullptr;
@@ -145,6 +156,7 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
             YA_HIP(ctx, launch_cdc_candidates(st, data, d_off, d_len, d_piece, n_blobs, pieces, cp, d_bitmap));
             tr.end();
         }
+        if (fork_blobs && long_after_cdc) YA_TRY(fork_long());
         {
             TimedRegion tr(ctx, "cdc_walk");
             YA_HIP(ctx, launch_cdc_walk(st, d_bitmap, d_len, d_piece, d_slot, n_blobs, cp, d_slot_off,

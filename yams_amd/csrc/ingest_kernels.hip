@@ -640,6 +640,7 @@ constexpr int LONG_LANE_STRIDE = 272;                  // bytes per lane per buf
                                                        // 68-word stride keeps ds_*_b128 conflict-free
 constexpr int LONG_BUF_BYTES = 64 * LONG_LANE_STRIDE;  // 17 408
 constexpr int LONG_PAIRS = 2;                          // producer/consumer pairs per workgroup
+template <int CONSUMER_PRIO = 3, int PRODUCER_PRIO = 2> // (wave priorities; other values: measurement build)
 __global__ __launch_bounds__(128 * LONG_PAIRS) void sha256_long_kernel(const uint8_t* data, const uint64_t* offs,
                                                           const uint64_t* lens,
                                                           const uint32_t* out_slot /*nullable*/,
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(128 * LONG_PAIRS) void sha256_long_kernel(const uin
 
     if (role == 1) {
         // ---------------- producer ----------------
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
         const uint8_t* p = have ? data + offs[m] : nullptr;
         const uint8_t* end = p + total;
         ShaWindow win;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(128 * LONG_PAIRS) void sha256_long_kernel(const uin
         __builtin_amdgcn_s_barrier(); // pairs with the consumer's final barrier
     } else {
         // ---------------- consumer ----------------
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(CONSUMER_PRIO);
         uint32_t st[8];
         sha256_init(st);
         __builtin_amdgcn_s_barrier(); // block 0 is published
@@ -883,8 +884,20 @@ hipError_t launch_sha256_long(hipStream_t st, const uint8_t* data, const uint64_
                               const uint64_t* lens, const uint32_t* out_slot, uint64_t n_msgs,
                               uint8_t* digests) {
     if (n_msgs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sha256_long_kernel, dim3(static_cast<uint32_t>((n_msgs + 64 * LONG_PAIRS - 1) / (64 * LONG_PAIRS))),
-                       dim3(128 * LONG_PAIRS), 0, st, data, offs, lens, out_slot, n_msgs, digests);
+    const dim3 grid(static_cast<uint32_t>((n_msgs + 64 * LONG_PAIRS - 1) / (64 * LONG_PAIRS))), block(128 * LONG_PAIRS);
+#ifdef YAMS_ACCEL_MEASURE
+    if (const char* e = std::getenv("YAMS_ACCEL_LONG_PRIO")) { // consumer / producer wave priorities, e.g. "10"
+        const int v = std::atoi(e);
+        if (v == 0) hipLaunchKernelGGL((sha256_long_kernel<0, 0>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
+        else if (v == 10) hipLaunchKernelGGL((sha256_long_kernel<1, 0>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
+        else if (v == 11) hipLaunchKernelGGL((sha256_long_kernel<1, 1>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
+        else if (v == 21) hipLaunchKernelGGL((sha256_long_kernel<2, 1>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
+        else hipLaunchKernelGGL((sha256_long_kernel<3, 2>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
+        LAUNCH_CHECK();
+        return hipSuccess;
+    }
+#endif
+    hipLaunchKernelGGL((sha256_long_kernel<3, 2>), grid, block, 0, st, data, offs, lens, out_slot, n_msgs, digests);
     LAUNCH_CHECK();
     return hipSuccess;
 }
