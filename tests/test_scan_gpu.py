@@ -322,6 +322,21 @@ def test_product_library_ignores_measurement_environment(acc, oracle, monkeypatc
     assert r.diag["escalated_queries"] == 0 and (r.counts == 20).all()
 
 
+def test_tau_select_with_more_tied_group_maxima_than_its_list_holds(acc, oracle):
+    """tau_select_kernel's two-pass form collects the keys at or above a lower bound into a 2048-entry list in LDS;
+    when more group maxima than that TIE at the top it must fall through to the radix select.  2.3M rows of which
+    every second one is the same vector (36k sampled rows = 2250 sample groups, every one of them holding a copy):
+    one query equal to that vector (its threshold is the tie value, its candidate list overflows, the exhaustive
+    fp64 path answers), two ordinary queries beside it; tie ranks decide among the 1.15M rows at similarity 1."""
+    n, d = 2_300_000, 32
+    corpus = oracle.synth_rows(51, 0, n, d)
+    q = oracle.synth_rows(51, 1 << 40, 3, d)
+    corpus[::2] = q[1]
+    rank = np.random.default_rng(51).permutation(n).astype(np.uint32)
+    r = check(acc, oracle, corpus, q, 10, tie_rank=rank, expect_path=0)
+    assert r.diag["exact_fallback_queries"] >= 1, r.diag
+
+
 def test_measurement_build_filter_forms_agree_with_the_product_form():
     """The two alternative forms of the resident-query int8 filter kept in the measurement build (128 x 128
     wave tiles with one wave per SIMD; the product's tiles with direct row loads) are not dead code paths: on ragged
