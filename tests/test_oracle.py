@@ -259,3 +259,21 @@ def test_l2_definitions_fp64_vs_fp32_accumulation_report(oracle, capsys):
     with capsys.disabled():
         print(f"\n[L2 definition report] {nq} queries x {n} rows x {d}: top-{k} sets that differ from the fp64 definition — "
               f"f32 sequential {sets[1]}, f32 8 lanes {sets[8]}, f32 16 lanes {sets[16]}; worst relative distance difference {worst:.2e}")
+
+
+def test_two_pass_rank_select_is_the_rank_th_largest_key():
+    """The arithmetic of tau_select_kernel's two-pass form (scan_kernels.hip), restated: the rank-th largest of the 256
+    per-thread maxima is a lower bound L of the rank-th largest key; the rank-th largest of the keys >= L is the
+    answer — including ties, keys of 0 and shares of unequal length."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    for n_groups, rank, hi in [(12207, 16, 1 << 32), (300, 256, 1 << 32), (20, 16, 1 << 32), (5000, 64, 7), (257, 1, 3), (4096, 33, 1 << 20)]:
+        for _ in range(20):
+            keys = rng.integers(0, hi, n_groups, dtype=np.uint64).astype(np.uint32)
+            want = np.sort(keys)[::-1][rank - 1]
+            maxima = np.array([keys[t::256].max() if t < n_groups else 0 for t in range(256)], dtype=np.uint32)
+            L = np.sort(maxima)[::-1][rank - 1]
+            coll = keys[keys >= L]
+            assert len(coll) >= rank
+            got = np.sort(coll)[::-1][rank - 1]
+            assert got == want and L <= want
