@@ -314,9 +314,10 @@ def ingest_breadth(acc, torch, seed):
     res["host_streamed"] = {"value": n_blobs * blen / dt / 1e9, "unit": "GB/s", "bytes": n_blobs * blen, "ms": dt * 1e3,
                             "blobs": n_blobs, "blob_bytes": blen, "batch_bytes": batch, "source": "pinned host memory",
                             "includes": "H2D of every byte + kernels + D2H of chunk tables and digests (never the headline `value`)",
-                            "bound": "a batch cannot finish before the SHA-256 chain of its longest blob (65 536 sequential blocks for "
-                                     "4 MiB: ~120 ms at ~35 MB/s per chain), so batches of 4 MiB blobs must be GiB-sized to cover it; "
-                                     "the PCIe-bound case is the small-blob leg below",
+                            "bound": "the SHA-256 chain of a blob (65 536 sequential blocks for 4 MiB: ~120 ms at ~35 MB/s per chain) outlasts "
+                                     "its batch's upload and other kernels: each batch's chains run on a lane of their own and are joined three "
+                                     "batches later, so a long stream of 2 GiB batches moves at the link's rate; these 8 GiB are four batches, "
+                                     "the last one's chains have nothing left to hide under (round 2, chains joined per batch: 13.7 GB/s)",
                             "chunks": h["n_chunks"], "bit_exact_vs_cpu_sample": {"blobs": len(pick), "ok": ok}}
     # the same bytes as 256 KiB blobs (chains of 4096 blocks: ~8 ms), 512 MiB batches: the link is the bound
     blen2 = 256 << 10

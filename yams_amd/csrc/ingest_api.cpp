@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "accel_ctx.h"
@@ -39,10 +40,16 @@ yams_status_t make_params(yams_accel_ctx* ctx, const yams_cdc_config_t* cfg, Cdc
     return YAMS_OK;
 }
 
+// A chain lane (yams_ingest_host): the whole-blob digest chains of one batch run on a stream of their own and are
+// NOT joined at the end of the call — the caller joins `join` when it needs the digests (or the batch's data buffer
+// back), so the chains of a batch run beside the NEXT batches' uploads and kernels.  Their tables live in
+// workspace buffers named after the lane.
+struct IngestLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; int index = 0; };
+
 yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64_t* blob_off_h,
                           const uint64_t* blob_len_h, uint64_t n_blobs64,
                           const yams_cdc_config_t* cfg, uint32_t flags, bool do_chunks,
-                          yams_ingest_result_t* out) {
+                          yams_ingest_result_t* out, const IngestLane* lane = nullptr) {
     if (!out) return fail(ctx, YAMS_ERR_INVALID_ARG, "null result");
     std::memset(out, 0, sizeof(*out));
     if (n_blobs64 >= (1ull << 31)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "too many blobs");
@@ -106,22 +113,25 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
             h_slot32[i] = order[i];
         }
         uint64_t* d_sorted;
-        YA_TRY(ws_get(ctx, "ing_meta_blobs", sorted.size() * 8, (void**)&d_sorted));
+        const std::string lane_tag = lane ? "_lane" + std::to_string(lane->index) : std::string();
+        YA_TRY(ws_get(ctx, ("ing_meta_blobs" + lane_tag).c_str(), sorted.size() * 8, (void**)&d_sorted));
         YA_HIP(ctx, hipMemcpyAsync(d_sorted, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, st));
         YA_HIP(ctx, hipStreamSynchronize(st)); // `sorted` is pageable and dies with this scope
-        YA_TRY(ws_get(ctx, "ing_blob_digests", static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
+        YA_TRY(ws_get(ctx, ("ing_blob_digests" + lane_tag).c_str(), static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
         d_sorted_blobs = d_sorted;
     }
     // the side stream's launch: at once, or (`long_after_cdc`) behind boundary detection
+    const hipStream_t aux = lane ? lane->stream : ctx->aux_stream;
+    const hipEvent_t aux_fork = lane ? lane->fork : ctx->aux_fork, aux_join = lane ? lane->join : ctx->aux_join;
     auto fork_long = [&]() -> yams_status_t {
-        YA_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
-        YA_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
-        TimedRegion tr(ctx, "sha256_blobs", ctx->aux_stream);
-        YA_HIP(ctx, launch_sha256_long(ctx->aux_stream, data, d_sorted_blobs, d_sorted_blobs + n_blobs,
+        YA_HIP(ctx, hipEventRecord(aux_fork, st));
+        YA_HIP(ctx, hipStreamWaitEvent(aux, aux_fork, 0));
+        TimedRegion tr(ctx, "sha256_blobs", aux);
+        YA_HIP(ctx, launch_sha256_long(aux, data, d_sorted_blobs, d_sorted_blobs + n_blobs,
                                        reinterpret_cast<const uint32_t*>(d_sorted_blobs + static_cast<size_t>(n_blobs) * 2),
                                        n_blobs, d_blob_digests));
         tr.end();
-        YA_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+        YA_HIP(ctx, hipEventRecord(aux_join, aux));
         return YAMS_OK;
     };
     bool long_after_cdc = false;
@@ -183,7 +193,7 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
                                   d_digests, d_head, nullptr, nullptr, 0, 4096, 1));
         tr.end();
     }
-    if (fork_blobs) YA_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0)); // join the side stream
+    if (fork_blobs && !lane) YA_HIP(ctx, hipStreamWaitEvent(st, aux_join, 0)); // join the side stream (a lane's caller joins later)
     out->n_chunks = n_chunks;
     out->chunk_offset = d_chunk_off;
     out->chunk_size = d_chunk_size;
@@ -272,33 +282,54 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         largest = std::max(largest, bt.bytes);
         batches.push_back(bt);
     }
-    uint8_t* d_buf[2];
-    YA_TRY(ws_get(ctx, "ing_host_buf0", largest + 64, (void**)&d_buf[0]));
-    YA_TRY(ws_get(ctx, "ing_host_buf1", batches.size() > 1 ? largest + 64 : 64, (void**)&d_buf[1]));
+    // Device buffers: two when there are no whole-blob digests (batch i + 1 travels while batch i is worked on); up to
+    // kSlots with them, because a batch's digest chains (one lane per blob, ~35 MB/s: 120 ms for a 4 MiB blob) outlast
+    // its upload and its other kernels many times over — each batch gets a chain lane (a stream of its own) and is
+    // joined only when its buffer is needed again, kSlots - 1 batches later, so the chains of up to three batches run
+    // beside each other and beside the uploads.  (One buffer pair, joined per batch: 2 GiB per 120 ms = 17 GB/s on 4 MiB
+    // blobs however fast the link.)
+    constexpr int kSlots = 4;
+    const bool chains = (flags & YAMS_INGEST_BLOB_DIGESTS) != 0;
+    const int n_slots = static_cast<int>(std::min<size_t>(chains ? kSlots : 2, batches.size()));
+    uint8_t* d_buf[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < n_slots; ++i)
+        YA_TRY(ws_get(ctx, ("ing_host_buf" + std::to_string(i)).c_str(), largest + 64, (void**)&d_buf[i]));
     hipStream_t copy_st = nullptr;
-    hipEvent_t landed[2] = {nullptr, nullptr};
+    hipEvent_t landed[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    IngestLane lanes[kSlots];
     yams_status_t rc = YAMS_OK;
     auto cleanup = [&]() {
         if (copy_st) { (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); }
         for (hipEvent_t e : landed) if (e) (void)hipEventDestroy(e);
+        for (IngestLane& l : lanes) {
+            if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+            if (l.fork) (void)hipEventDestroy(l.fork);
+            if (l.join) (void)hipEventDestroy(l.join);
+        }
     };
     auto hip_ok = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
         rc = fail(ctx, YAMS_ERR_INTERNAL, what);
         return false;
     };
-    if (!hip_ok(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking), "copy stream") ||
-        !hip_ok(hipEventCreateWithFlags(&landed[0], hipEventDisableTiming), "event") ||
-        !hip_ok(hipEventCreateWithFlags(&landed[1], hipEventDisableTiming), "event")) { cleanup(); return rc; }
+    if (!hip_ok(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking), "copy stream")) { cleanup(); return rc; }
+    for (int i = 0; i < n_slots; ++i) {
+        lanes[i].index = i;
+        if (!hip_ok(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming), "event") ||
+            (chains && (!hip_ok(hipStreamCreateWithFlags(&lanes[i].stream, hipStreamNonBlocking), "chain stream") ||
+                        !hip_ok(hipEventCreateWithFlags(&lanes[i].fork, hipEventDisableTiming), "event") ||
+                        !hip_ok(hipEventCreateWithFlags(&lanes[i].join, hipEventDisableTiming), "event")))) { cleanup(); return rc; }
+    }
     std::vector<uint64_t> offs, lens;
-    auto upload = [&](size_t bi) -> bool { // batch bi -> device buffer bi & 1, on the copy stream
+    auto upload = [&](size_t bi) -> bool { // batch bi -> its slot's device buffer, on the copy stream
         const Batch& bt = batches[bi];
+        uint8_t* const dst = d_buf[bi % n_slots];
         // blobs that are neighbours in host memory (one mapped file, one receive buffer) and in the device
         // buffer travel as ONE copy: a copy call costs the host ~10 us whatever its size
         uint64_t at = 0, run_dst = 0, run_len = 0;
         const uint8_t* run_src = nullptr;
         auto flush = [&]() -> bool {
-            const bool ok = run_len == 0 || hip_ok(hipMemcpyAsync(d_buf[bi & 1] + run_dst, run_src, run_len, hipMemcpyHostToDevice, copy_st), "upload");
+            const bool ok = run_len == 0 || hip_ok(hipMemcpyAsync(dst + run_dst, run_src, run_len, hipMemcpyHostToDevice, copy_st), "upload");
             run_len = 0;
             return ok;
         };
@@ -316,17 +347,34 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
             at += (n + 15) & ~15ull;
         }
         if (!flush()) return false;
-        return hip_ok(hipEventRecord(landed[bi & 1], copy_st), "event record");
+        return hip_ok(hipEventRecord(landed[bi % n_slots], copy_st), "event record");
+    };
+    // a batch whose chains are still running: what is needed to fetch its blob digests later
+    struct Pending { bool open = false; const uint8_t* d_digests = nullptr; uint64_t first = 0, count = 0; };
+    Pending pending[kSlots];
+    auto settle = [&](int slot) -> bool { // join the slot's chains, bring their digests home; its buffer is free afterwards
+        Pending& pd = pending[slot];
+        if (!pd.open) return true;
+        pd.open = false;
+        hipStream_t st = ctx->stream;
+        if (!hip_ok(hipStreamWaitEvent(st, lanes[slot].join, 0), "join")) return false;
+        if (out_blob_digest && pd.d_digests &&
+            !hip_ok(hipMemcpyAsync(out_blob_digest + pd.first * 32, pd.d_digests, pd.count * 32, hipMemcpyDeviceToHost, st), "results")) return false;
+        return hip_ok(hipStreamSynchronize(st), "sync");
     };
     uint64_t chunk_base = 0;
     bool too_small = false;
     if (!upload(0)) { cleanup(); return rc; }
     for (size_t bi = 0; bi < batches.size() && rc == YAMS_OK; ++bi) {
         const Batch& bt = batches[bi];
-        // the buffer batch bi + 1 goes into was batch bi - 1's: its kernels and result copies have completed
-        // (every batch ends with a synchronisation of the context's stream)
-        if (bi + 1 < batches.size() && !upload(bi + 1)) break;
-        if (!hip_ok(hipStreamWaitEvent(ctx->stream, landed[bi & 1], 0), "wait")) break;
+        const int slot = static_cast<int>(bi % n_slots);
+        // the buffer batch bi + 1 goes into was batch bi + 1 - n_slots's: its kernels and result copies have completed
+        // (every batch ends with a synchronisation of the context's stream); its chains are joined here
+        if (bi + 1 < batches.size()) {
+            if (!settle(static_cast<int>((bi + 1) % n_slots))) break;
+            if (!upload(bi + 1)) break;
+        }
+        if (!hip_ok(hipStreamWaitEvent(ctx->stream, landed[slot], 0), "wait")) break;
         offs.resize(bt.count); lens.resize(bt.count);
         uint64_t at = 0;
         for (uint64_t j = 0; j < bt.count; ++j) {
@@ -334,7 +382,7 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
             at += (lens[j] + 15) & ~15ull;
         }
         yams_ingest_result_t r;
-        rc = ingest_impl(ctx, d_buf[bi & 1], offs.data(), lens.data(), bt.count, cfg, flags, true, &r);
+        rc = ingest_impl(ctx, d_buf[slot], offs.data(), lens.data(), bt.count, cfg, flags, true, &r, chains ? &lanes[slot] : nullptr);
         if (rc != YAMS_OK) break;
         hipStream_t st = ctx->stream;
         std::vector<uint64_t> first(bt.count + 1);
@@ -346,12 +394,13 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
             if (out_chunk_digest && r.chunk_digest &&
                 !hip_ok(hipMemcpyAsync(out_chunk_digest + chunk_base * 32, r.chunk_digest, r.n_chunks * 32, hipMemcpyDeviceToHost, st), "results")) break;
         }
-        if (out_blob_digest && r.blob_digest &&
-            !hip_ok(hipMemcpyAsync(out_blob_digest + bt.first * 32, r.blob_digest, bt.count * 32, hipMemcpyDeviceToHost, st), "results")) break;
+        if (chains) { pending[slot].open = true; pending[slot].d_digests = r.blob_digest; pending[slot].first = bt.first; pending[slot].count = bt.count; }
         if (!hip_ok(hipStreamSynchronize(st), "sync")) break;
         for (uint64_t j = 0; j <= bt.count; ++j) out_blob_first[bt.first + j] = chunk_base + first[j];
         chunk_base += r.n_chunks;
     }
+    for (int i = 0; i < n_slots && rc == YAMS_OK; ++i)
+        if (!settle(i)) break;
     cleanup();
     if (rc != YAMS_OK) return rc;
     if (out_n_chunks) *out_n_chunks = chunk_base;
