@@ -304,7 +304,7 @@ def ingest_breadth(acc, torch, seed):
     ptrs = [base + i * blen for i in range(n_blobs)]
     cfg = cdc_config("streaming")
     batch = 2 << 30
-    acc.ingest_host(ptrs[:512], [blen] * 512, cfg, flags=3, batch_bytes=batch)       # warm-up (buffers)
+    acc.ingest_host(ptrs, [blen] * n_blobs, cfg, flags=3, batch_bytes=batch)         # warm-up (all four batch buffers + lane tables)
     t0 = time.perf_counter()
     h = acc.ingest_host(ptrs, [blen] * n_blobs, cfg, flags=3, batch_bytes=batch)
     dt = time.perf_counter() - t0
