@@ -3,7 +3,9 @@
 // SHA-256, i.e. the hash + chunk_file phases of ContentStore::store
 // (src/api/content_store_impl.cpp:199-231 in the reference).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -358,22 +360,33 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         pd.open = false;
         hipStream_t st = ctx->stream;
         if (!hip_ok(hipStreamWaitEvent(st, lanes[slot].join, 0), "join")) return false;
-        if (out_blob_digest && pd.d_digests &&
-            !hip_ok(hipMemcpyAsync(out_blob_digest + pd.first * 32, pd.d_digests, pd.count * 32, hipMemcpyDeviceToHost, st), "results")) return false;
-        return hip_ok(hipStreamSynchronize(st), "sync");
+        unsigned char* stage = nullptr;
+        const bool take = out_blob_digest && pd.d_digests;
+        if (take && (rc = pinned_get(ctx, pd.count * 32 + 64, (void**)&stage)) != YAMS_OK) return false;
+        if (take && !hip_ok(hipMemcpyAsync(stage, pd.d_digests, pd.count * 32, hipMemcpyDeviceToHost, st), "results")) return false;
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) return false;
+        if (take) std::memcpy(out_blob_digest + pd.first * 32, stage, pd.count * 32);
+        return true;
     };
     uint64_t chunk_base = 0;
     bool too_small = false;
+#ifdef YAMS_ACCEL_MEASURE
+    const bool trace = std::getenv("YAMS_ACCEL_INGEST_TRACE") != nullptr; // host-side phase times of every batch, to stderr
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+#define YAMS_TRACE_T(var) const double var = trace ? now_ms() : 0.0
+#else
+#define YAMS_TRACE_T(var) do {} while (0)
+#endif
     if (!upload(0)) { cleanup(); return rc; }
     for (size_t bi = 0; bi < batches.size() && rc == YAMS_OK; ++bi) {
         const Batch& bt = batches[bi];
         const int slot = static_cast<int>(bi % n_slots);
-        // the buffer batch bi + 1 goes into was batch bi + 1 - n_slots's: its kernels and result copies have completed
-        // (every batch ends with a synchronisation of the context's stream); its chains are joined here
-        if (bi + 1 < batches.size()) {
-            if (!settle(static_cast<int>((bi + 1) % n_slots))) break;
-            if (!upload(bi + 1)) break;
-        }
+        YAMS_TRACE_T(t0);
+        // the buffer batch bi + 1 will go into was batch bi + 1 - n_slots's: its kernels and result copies have completed
+        // (every batch ends with a synchronisation of the context's stream); its chains are joined here, while the
+        // stream is idle
+        if (bi + 1 < batches.size() && !settle(static_cast<int>((bi + 1) % n_slots))) break;
+        YAMS_TRACE_T(t1);
         if (!hip_ok(hipStreamWaitEvent(ctx->stream, landed[slot], 0), "wait")) break;
         offs.resize(bt.count); lens.resize(bt.count);
         uint64_t at = 0;
@@ -384,21 +397,42 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         yams_ingest_result_t r;
         rc = ingest_impl(ctx, d_buf[slot], offs.data(), lens.data(), bt.count, cfg, flags, true, &r, chains ? &lanes[slot] : nullptr);
         if (rc != YAMS_OK) break;
+        YAMS_TRACE_T(t1b);
+        // Batch bi + 1 starts its journey only NOW, behind this batch's small table uploads: copies of all streams
+        // share the DMA engines first come first served, and issued up front the 512 MiB of the next batch stood in
+        // front of a few KiB of tables for 9 ms per batch (host-side trace, YAMS_ACCEL_INGEST_TRACE).
+        if (bi + 1 < batches.size() && !upload(bi + 1)) break;
+        YAMS_TRACE_T(t2);
         hipStream_t st = ctx->stream;
-        std::vector<uint64_t> first(bt.count + 1);
-        if (!hip_ok(hipMemcpyAsync(first.data(), r.blob_first, (bt.count + 1) * 8, hipMemcpyDeviceToHost, st), "results")) break;
+        // results: one pinned staging area, then plain copies into the caller's (pageable) arrays — four asynchronous
+        // copies into pageable memory were four blocking round trips of ~1 ms each
         if (chunk_base + r.n_chunks > chunk_cap || (r.n_chunks && (!out_chunk_offset || !out_chunk_size))) too_small = true;
-        if (!too_small && r.n_chunks) {
-            if (!hip_ok(hipMemcpyAsync(out_chunk_offset + chunk_base, r.chunk_offset, r.n_chunks * 8, hipMemcpyDeviceToHost, st), "results") ||
-                !hip_ok(hipMemcpyAsync(out_chunk_size + chunk_base, r.chunk_size, r.n_chunks * 8, hipMemcpyDeviceToHost, st), "results")) break;
-            if (out_chunk_digest && r.chunk_digest &&
-                !hip_ok(hipMemcpyAsync(out_chunk_digest + chunk_base * 32, r.chunk_digest, r.n_chunks * 32, hipMemcpyDeviceToHost, st), "results")) break;
-        }
+        const bool take = !too_small && r.n_chunks;
+        const bool take_dg = take && out_chunk_digest && r.chunk_digest;
+        const size_t b_first = (bt.count + 1) * 8, b_tab = take ? r.n_chunks * 8 : 0, b_dg = take_dg ? r.n_chunks * 32 : 0;
+        unsigned char* stage;
+        if ((rc = pinned_get(ctx, b_first + 2 * b_tab + b_dg + 64, (void**)&stage)) != YAMS_OK) break;
+        unsigned char* s_first = stage; unsigned char* s_off = s_first + b_first; unsigned char* s_size = s_off + b_tab; unsigned char* s_dg = s_size + b_tab;
+        if (!hip_ok(hipMemcpyAsync(s_first, r.blob_first, b_first, hipMemcpyDeviceToHost, st), "results")) break;
+        if (take && (!hip_ok(hipMemcpyAsync(s_off, r.chunk_offset, b_tab, hipMemcpyDeviceToHost, st), "results") ||
+                     !hip_ok(hipMemcpyAsync(s_size, r.chunk_size, b_tab, hipMemcpyDeviceToHost, st), "results"))) break;
+        if (take_dg && !hip_ok(hipMemcpyAsync(s_dg, r.chunk_digest, b_dg, hipMemcpyDeviceToHost, st), "results")) break;
         if (chains) { pending[slot].open = true; pending[slot].d_digests = r.blob_digest; pending[slot].first = bt.first; pending[slot].count = bt.count; }
+        YAMS_TRACE_T(t3);
         if (!hip_ok(hipStreamSynchronize(st), "sync")) break;
+        const uint64_t* first = reinterpret_cast<const uint64_t*>(s_first);
         for (uint64_t j = 0; j <= bt.count; ++j) out_blob_first[bt.first + j] = chunk_base + first[j];
+        if (take) {
+            std::memcpy(out_chunk_offset + chunk_base, s_off, b_tab);
+            std::memcpy(out_chunk_size + chunk_base, s_size, b_tab);
+            if (take_dg) std::memcpy(out_chunk_digest + chunk_base * 32, s_dg, b_dg);
+        }
         chunk_base += r.n_chunks;
+#ifdef YAMS_ACCEL_MEASURE
+        if (trace) std::fprintf(stderr, "batch %zu: settle %.2f ms, ingest_impl %.2f ms, next upload issued %.2f ms, result copies issued %.2f ms, sync + copy out %.2f ms\n", bi, t1 - t0, t1b - t1, t2 - t1b, t3 - t2, now_ms() - t3);
+#endif
     }
+#undef YAMS_TRACE_T
     for (int i = 0; i < n_slots && rc == YAMS_OK; ++i)
         if (!settle(i)) break;
     cleanup();
