@@ -54,3 +54,48 @@ def test_no_scratch_traffic_inside_the_mfma_loops(src):
                      "scan_tiles_i8r_kernelILi0ELb1ELb1", "scan_tiles_i8h_kernelILi1ELi0ELi0",
                      "scan_tiles_i8h_kernelILi1ELi0ELi1", "scan_tiles_i8h_kernelILi0ELi0ELi1"):
             assert any(frag in k for k in tiles), frag
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_direct_row_loads_are_not_touched_while_in_flight():
+    """The direct form of the resident-query filter (scan_tiles_i8r_kernel<..., DIRECT>) loads the next slab's row
+    fragments from inline asm into registers the compiler owns, and only an s_waitcnt vmcnt(0) at the head of the next
+    slab makes them valid.  Nothing the compiler puts in between — a copy at a loop edge, a spill, a reuse — may read or
+    write those registers: checked on the assembly in program order (a linear walk; the kernel's loops are the unrolled
+    slab pairs, so program order is what matters between a load and its wait)."""
+    kernels = {k: v for k, v in _kernels("scan_i8_kernel.hip").items() if "scan_tiles_i8r_kernel" in k and k.endswith("ELb1EEEvNS_8ScanArgsEjjjj")}
+    assert len(kernels) == 2, list(kernels)      # cosine and L2
+
+    def regs(tok):
+        tok = tok.strip().split()[0] if tok.strip() else ""
+        m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return [int(m.group(1))] if m else []
+    for name, body in kernels.items():
+        inflight, loads = {}, 0
+        for line in body:
+            t = line.split(";")[0].strip()
+            if not t or t.startswith(".") or t.endswith(":"):
+                continue
+            ops = t.split(None, 1)
+            if ops[0] == "global_load_dwordx4":
+                for r in regs(ops[1].split(",")[0]):
+                    inflight[r] = t
+                loads += 1
+                continue
+            if ops[0] == "s_waitcnt" and "vmcnt(0)" in t:
+                inflight.clear()
+                continue
+            if len(ops) < 2:
+                continue
+            toks = [x for x in ops[1].split(",")]
+            stores = ops[0].startswith(("global_store", "ds_write", "scratch_store", "global_atomic"))
+            for tok in (toks if stores else toks[1:]):
+                for r in regs(tok):
+                    assert r not in inflight, (name, "reads in-flight v%d" % r, t, inflight[r])
+            if not stores and not ops[0].startswith("s_"):
+                for r in regs(toks[0]):
+                    assert r not in inflight, (name, "writes in-flight v%d" % r, t, inflight[r])
+        assert loads >= 12, (name, loads)       # prologue + two slabs of the loop body, four fragments each
