@@ -608,6 +608,15 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     }
     if (diag) {
         unsigned long long h_stat = 0;
+#ifdef YAMS_ACCEL_MEASURE
+        if (std::getenv("YAMS_ACCEL_DUMP_NEEDED")) { // candidates the proof needed per query (rescore_select_kernel)
+            unsigned long long h4[4] = {0, 0, 0, 0};
+            YA_HIP(ctx, hipMemcpyAsync(h4, d_stat, 32, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            if (h4[3]) std::fprintf(stderr, "candidates needed per query: mean %.1f, max %llu over %llu queries (k = %u)\n",
+                                    static_cast<double>(h4[1]) / static_cast<double>(h4[3]), h4[2], h4[3], k);
+        }
+#endif
         YA_HIP(ctx, hipMemcpyAsync(&h_stat, d_stat, 8, hipMemcpyDeviceToHost, st));
         uint32_t* h_counts = h_status; // reuse pinned space
         YA_HIP(ctx, hipMemcpyAsync(h_counts, out_counts, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));

@@ -813,6 +813,20 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
         }
         s_status = status;
         a.out_status[q] = status;
+#ifdef YAMS_ACCEL_MEASURE
+        // measurement: how many candidates (in the order of their bounds) this query NEEDED — the top k by exact score
+        // all lie among the first m, and the (m + 1)-th bound is below the k-th exact score; summed / maximised over
+        // the batch in stat[1] / stat[2] / queries counted in stat[3] (YAMS_ACCEL_DUMP_NEEDED prints them)
+        if (METRIC == YAMS_SCAN_COSINE && a.stat_rescored && status == 0 && nv >= a.k && !a.all_rows_listed) {
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < a.k; ++i) m = sidx[i] + 1 > m ? sidx[i] + 1 : m;
+            const float sim_w = key_score(skey[a.k - 1]);
+            while (m < a.n_cand && !(static_cast<float>(static_cast<double>(key_score(cand[m])) + a.err_bound + 1e-12) < sim_w)) ++m;
+            atomicAdd(a.stat_rescored + 1, static_cast<unsigned long long>(m));
+            atomicMax(a.stat_rescored + 2, static_cast<unsigned long long>(m));
+            atomicAdd(a.stat_rescored + 3, 1ull);
+        }
+#endif
     }
     __syncthreads();
     const uint32_t nv = s_nvalid;
