@@ -328,8 +328,9 @@ YAMS_ACCEL_API yams_status_t yams_scan_merge_records_device(
  * with dlopen when the first communicator is needed), per batch: every shard's exact top-k into a packed
  * record, ONE ncclAllGather of the records on a side stream, merge_topk_kernel on the first shard's
  * device, the merged result downloaded into pinned memory.  A persistent worker thread per (shard, lane)
- * drives its device; `lanes` batches are in flight, so collective + merge of batch i run under the filter
- * sweep of batch i + 1 (submit / wait below; yams_scan_sharded_topk_host is submit + wait).
+ * drives its device; `lanes` batches are in flight: the upload, the query preparation and the sample pass of
+ * batch i + 1 run under the sweep of batch i, and the exchange of batch i runs in the gap before the sweep of
+ * batch i + 1 (see YAMS_SHARDED_FENCE_* below; submit / wait below; yams_scan_sharded_topk_host is submit + wait).
  * `devices[i]` is the HIP device of shard i.  Shards that SHARE a device cannot form a communicator (RCCL
  * refuses two ranks on one device): such handles — the parity tests of a one-GPU box — move their records
  * with device-to-device copies instead.  shards[i] is shard i's view (device pointers valid on devices[i];
@@ -343,14 +344,32 @@ typedef struct yams_scan_sharded yams_scan_sharded;
                                            records (one shard: nothing to exchange)                         */
 #define YAMS_SHARDED_COLLECTIVE_RCCL 1u /* require the communicator — also for ONE shard (a communicator of one
                                            rank: all-gather + merge still run); creation fails with
-                                           YAMS_ERR_UNSUPPORTED when RCCL cannot be loaded or initialised,
-                                           YAMS_ERR_INVALID_ARG when shards share a device                  */
+                                           YAMS_ERR_UNSUPPORTED when the library cannot be loaded or initialised,
+                                           YAMS_ERR_INVALID_ARG when shards share a device and the default
+                                           library is used (RCCL refuses two ranks on one device; a library named
+                                           in `rccl_library` decides for itself)                            */
 #define YAMS_SHARDED_COLLECTIVE_PEER 2u /* never RCCL: device-to-device copies                               */
+/* The filter sweep is a persistent grid that owns every CU of its device (one 160 KiB-LDS, 8 x 256-VGPR
+ * workgroup per CU), and a collective is a CU-resident kernel that spins on its peers.  Left to float, the
+ * all-gather of batch i on GPU g would have to find a CU under the sweep of batch i + 1 and then wait for GPU
+ * h's copy of the kernel, itself queued behind h's sweep: the sweeps of different GPUs get coupled through the
+ * few CUs the collective holds.  So with >= 2 shards the exchange is FENCED: on every shard the sweep of batch
+ * i + 1 begins only after that shard's part of the exchange of batch i (on the root shard also the merge and the
+ * download) has completed — the collective never shares a device with a sweep.  Everything in front of the sweep
+ * (query upload, preparation, the sample pass) still overlaps.  YAMS_SHARDED_FENCE_OFF lifts the fence
+ * (measurements only). */
+#define YAMS_SHARDED_FENCE_AUTO 0u
+#define YAMS_SHARDED_FENCE_OFF 1u
 typedef struct yams_scan_sharded_options_s {
-    uint32_t struct_size; /* sizeof(yams_scan_sharded_options_t)                                  */
+    uint32_t struct_size; /* sizeof(yams_scan_sharded_options_t); the 16-byte round-3 struct is accepted */
     uint32_t lanes;       /* batches in flight, 1..16; 0 = 2                                      */
     uint32_t collective;  /* YAMS_SHARDED_COLLECTIVE_*                                            */
-    uint32_t reserved;
+    uint32_t fence;       /* YAMS_SHARDED_FENCE_*                                                 */
+    const char* rccl_library; /* nullable: the collective library to dlopen instead of librccl.so.1 — any library
+                                 that exports ncclGetVersion / ncclCommInitAll / ncclAllGather / ncclCommDestroy /
+                                 ncclGetErrorString with RCCL's signatures (a site build of RCCL; the test suite's
+                                 stream-ordered stand-in, which lets several ranks share one device).  The string
+                                 is copied. */
 } yams_scan_sharded_options_t;
 YAMS_ACCEL_API yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards,
                                                       yams_scan_sharded** out);
@@ -358,7 +377,7 @@ YAMS_ACCEL_API yams_status_t yams_scan_sharded_create_ex(const int* devices, uin
                                                          const yams_scan_sharded_options_t* options,
                                                          yams_scan_sharded** out);
 YAMS_ACCEL_API uint32_t yams_scan_sharded_lanes(const yams_scan_sharded* s);
-/* {"shards":n,"lanes":l,"devices":[..],"collective":"rccl"|"peer_copy"|"none","rccl_version":..,
+/* {"shards":n,"lanes":l,"devices":[..],"collective":"rccl"|"peer_copy"|"none","fenced":true|false,"rccl_version":..,
  *  "rccl_library":"<path the symbols came from>","batches":..,"collectives":..}; malloc'd, release with
  * yams_accel_free_string. */
 YAMS_ACCEL_API yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char** out_json);

@@ -36,3 +36,27 @@ def build_real_headers_test(reference: str = "/root/reference"):
         raise RuntimeError("real_headers_test failed to compile against the reference headers:\n" + r.stdout.decode())
     return exe
 
+
+
+def build_stub_collective():
+    """Compiles tests/stub_coll/stub_coll.cpp — the stream-ordered stand-in for the five RCCL entry points, with which
+    the sharded search's kRccl code path runs with several ranks on ONE device (test infrastructure; reached only
+    through yams_scan_sharded_options_t.rccl_library).  Host code on the HIP runtime API: plain g++.  The .so is
+    git-ignored and travels to the GPU box; returns its path."""
+    out_dir = os.path.join(ROOT, "tests", "stub_coll", "_build")
+    lib = os.path.join(out_dir, "libyams_stub_coll.so")
+    src = os.path.join(ROOT, "tests", "stub_coll", "stub_coll.cpp")
+    if os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(src):
+        return lib
+    if not os.path.isdir("/opt/rocm/include"):
+        if os.path.exists(lib):
+            return lib
+        raise RuntimeError("no ROCm headers and no prebuilt " + lib)
+    os.makedirs(out_dir, exist_ok=True)
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", "-o", lib, src, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("the stub collective library failed to compile:\n" + r.stdout.decode())
+    return lib

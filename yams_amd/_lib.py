@@ -49,10 +49,12 @@ class ScanCorpus(C.Structure):
 
 
 class ShardedOptions(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("collective", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("collective", C.c_uint32), ("fence", C.c_uint32),
+                ("rccl_library", C.c_char_p)]
 
 
 SHARDED_COLLECTIVE_AUTO, SHARDED_COLLECTIVE_RCCL, SHARDED_COLLECTIVE_PEER = 0, 1, 2
+SHARDED_FENCE_AUTO, SHARDED_FENCE_OFF = 0, 1
 SHARDED_SUBMIT_DIAG = 1
 
 

@@ -123,15 +123,19 @@ class ShardedScan:
     process, one RCCL communicator over the shard devices, all-gather + merge per batch, `lanes` batches in
     flight (shards that share a device, the one-GPU tests, exchange their records with device copies).
     `ctx(i)` is an Accel bound to shard i's lane-0 context — upload the shard's rows and build its shadows
-    through it.  collective: "auto" | "rccl" (require the communicator, also for one shard) | "peer"."""
+    through it.  collective: "auto" | "rccl" (require the communicator, also for one shard) | "peer";
+    rccl_library: the collective library to bind instead of librccl.so.1 (the tests' stand-in lets ranks share a
+    device); fence=False lifts the exchange fence (measurements)."""
 
-    def __init__(self, devices, lanes: int = 0, collective: str = "auto"):
+    def __init__(self, devices, lanes: int = 0, collective: str = "auto", rccl_library: str | None = None, fence: bool = True):
         self.L = _lib.load()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
         opt = _lib.ShardedOptions(C.sizeof(_lib.ShardedOptions), lanes,
                                   {"auto": _lib.SHARDED_COLLECTIVE_AUTO, "rccl": _lib.SHARDED_COLLECTIVE_RCCL,
-                                   "peer": _lib.SHARDED_COLLECTIVE_PEER}[collective], 0)
+                                   "peer": _lib.SHARDED_COLLECTIVE_PEER}[collective],
+                                  _lib.SHARDED_FENCE_AUTO if fence else _lib.SHARDED_FENCE_OFF,
+                                  rccl_library.encode() if rccl_library else None)
         st = self.L.yams_scan_sharded_create_ex(arr, len(devices), C.byref(opt), C.byref(h))
         if st != 0:
             raise AccelError(st, "yams_scan_sharded_create_ex failed")

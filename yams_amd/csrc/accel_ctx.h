@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -21,6 +22,9 @@ struct yams_accel_gate {
 struct yams_accel_ctx {
     int device = 0;
     yams_accel_gate* gate = nullptr;
+    // Called on the host right before a filter sweep is enqueued on `stream` (sharded_api.cpp: the fence that keeps
+    // a shard's next sweep behind its previous exchange).  May block; must not throw.
+    std::function<void(hipStream_t)> before_sweep;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;   // high-priority side stream (whole-blob digest chains)
@@ -61,6 +65,7 @@ yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
 struct GatedSweep {
     yams_accel_ctx* ctx; hipStream_t st; bool held = false;
     GatedSweep(yams_accel_ctx* c, hipStream_t s) : ctx(c), st(s) {
+        if (ctx->before_sweep) ctx->before_sweep(st); // (before the gate's mutex: it may wait for another lane)
         if (!ctx->gate) return;
         ctx->gate->mu.lock(); held = true;
         if (ctx->gate->armed) (void)hipStreamWaitEvent(st, ctx->gate->last, 0);

@@ -1013,7 +1013,8 @@ const char* yams_plugin_get_manifest_json(void) { return kManifest; }
 // legacy one-argument form (abi_plugin_loader.cpp:329-357) is tolerated: the second argument is
 // never dereferenced.  config_json: {"device": n} or {"devices": [..]} (a corpus is dealt to all of
 // them in stripes and searched behind one call), "search_slots": concurrent searches (default 2),
-// "shadows": "both" (default) | "bf16" | "i8" | "none".
+// "shadows": "both" (default) | "bf16" | "i8" | "none", "collective": "auto" | "rccl" | "peer",
+// "rccl_library": "<path>", "fence": "off".
 static int plugin_init_impl(const char* config_json, const void* host_context) {
     (void)host_context;
     std::unique_lock<std::shared_mutex> lk(g.mu);
@@ -1049,6 +1050,16 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
             if (std::strstr(p, "\"rccl\"")) so.collective = YAMS_SHARDED_COLLECTIVE_RCCL;
             else if (std::strstr(p, "\"peer\"")) so.collective = YAMS_SHARDED_COLLECTIVE_PEER;
         }
+        // "rccl_library": "<path>" — the collective library to bind instead of librccl.so.1 (a site build; the test
+        // suite's stand-in, with which several shards may share a device); "fence": "off" lifts the exchange fence
+        std::string library;
+        if (const char* p = config_json ? std::strstr(config_json, "\"rccl_library\"") : nullptr) {
+            p = std::strchr(p + 14, ':');
+            if (p && (p = std::strchr(p, '"'))) { const char* e = std::strchr(p + 1, '"'); if (e) library.assign(p + 1, e); }
+        }
+        if (!library.empty()) so.rccl_library = library.c_str();
+        if (const char* p = config_json ? std::strstr(config_json, "\"fence\"") : nullptr)
+            if (const char* c = std::strchr(p + 7, ':')) { while (*++c == ' ') {} if (std::strncmp(c, "\"off\"", 5) == 0) so.fence = YAMS_SHARDED_FENCE_OFF; }
         if (yams_scan_sharded_create_ex(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &so, &g.sharded) != YAMS_OK)
             return failed("sharded search handle creation failed");
         g.search_slots = static_cast<uint32_t>(slots);

@@ -12,18 +12,29 @@
 //     thread is created per call.  submit() copies the queries into the lane's pinned staging ONCE and
 //     wakes the lane's workers; each uploads the batch to its device, runs the exact per-shard top-k
 //     (yams_scan_topk_device, fp64-exact: the gathered scores are final, the merge is a pure comparison)
-//     into the lane's record, then joins the collective on the lane's SIDE stream: ncclAllGather of the
-//     record, and on the root shard merge_topk_kernel + the download into pinned memory behind it.  The
-//     worker is then free for the lane's next batch; the other lane's sweep has the GPUs meanwhile, so
-//     collective + merge of batch i run under the sweep of batch i + 1.
-//   * collectives of one communicator must be issued in the same order on every rank: a turnstile per shard
-//     admits them in submit order, whichever lane finishes first.
+//     into the lane's record, then joins the exchange on the lane's SIDE stream: ncclAllGather of the
+//     record, and on the root shard merge_topk_kernel + the download into pinned memory behind it.
+//   * exchanges of one communicator must be issued in the same order on every rank: a turnstile per shard
+//     admits them in submit order, whichever lane finishes first.  Every batch that was given a place in that
+//     order takes part in its exchange on every exit path (a failed scan contributes an empty record): a rank
+//     that skipped one would hang the others.
+//   * THE FENCE.  The filter sweep is a persistent grid that owns every CU of its device, and a collective is a
+//     CU-resident kernel that spins on its peers.  Left to float, the all-gather of batch i on GPU g would have to
+//     find a CU under the sweep of batch i + 1 and then wait for GPU h's copy of the kernel, itself queued behind
+//     h's sweep — the sweeps of different GPUs get coupled through the few CUs the collective holds.  So with two
+//     or more shards a shard's sweep of batch i + 1 is enqueued only after its part of the exchange of batch i
+//     has been enqueued, and waits (on the device) for that part to complete: on the root shard all-gather +
+//     merge + download, elsewhere the all-gather.  What still overlaps the sweep of batch i is everything in
+//     front of the sweep of batch i + 1: query upload, preparation, the sample pass.  The price is the gap
+//     between two sweeps (host hand-over + the all-gather of ~1 MB per rank + on the root the merge); what it
+//     buys is that no collective ever shares a device with a sweep.  (accel_ctx.h: before_sweep.)
 //   * the contexts of one device share a sweep gate (yams_accel_gate): big filter sweeps run one after the
 //     other, everything around them overlaps.
-// RCCL is bound at run time (dlopen of librccl.so.1 when the first communicator is needed): a host that
-// hashes files or searches one GPU never maps the 570 MB collective library.  Shards that SHARE a device
-// (the parity tests on a one-GPU box) cannot form a communicator — RCCL refuses duplicate devices — and use
-// device-to-device copies of the records instead; that path is not a second production backend.
+// The collective library is bound at run time (dlopen of librccl.so.1, or of the library the options name, when
+// the first communicator is needed): a host that hashes files or searches one GPU never maps the 570 MB of RCCL.
+// Shards that SHARE a device (the parity tests on a one-GPU box) cannot form an RCCL communicator — RCCL refuses
+// duplicate devices — and use device-to-device copies of the records instead (or, for the tests of the kRccl
+// code path, the stand-in library under tests/stub_coll); that path is not a second production backend.
 // The corpus itself never moves.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -121,10 +132,19 @@ struct Rccl {
     bool ok() const { return handle != nullptr; }
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
+// One binding per library path ("" = the default search for RCCL itself); bindings live for the process.
+Rccl& rccl(const std::string& wanted) {
+    static std::mutex mu;
+    static std::map<std::string, std::unique_ptr<Rccl>> bound;
+    std::lock_guard<std::mutex> lk(mu);
+    std::unique_ptr<Rccl>& slot = bound[wanted];
+    if (slot) return *slot;
+    slot.reset(new Rccl());
+    Rccl& r = *slot;
+    if (!wanted.empty()) {
+        r.handle = dlopen(wanted.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) { if (const char* e = dlerror()) r.error = e; return r; }
+    } else {
         // the SONAME first: a process that already maps RCCL (e.g. through torch) gets that very copy
         const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char* n : names) {
@@ -132,25 +152,25 @@ Rccl& rccl() {
             if (r.handle) break;
             if (const char* e = dlerror()) r.error = e;
         }
-        if (!r.handle) return;
-        auto sym = [&](const char* name) -> void* {
-            void* p = dlsym(r.handle, name);
-            if (!p) { r.error = std::string("librccl lacks ") + name; }
-            return p;
-        };
-        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
-        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        if (!r.GetVersion || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
-            dlclose(r.handle); r.handle = nullptr; return;
-        }
-        r.error.clear();
-        (void)r.GetVersion(&r.version);
-        Dl_info info{};
-        if (dladdr(reinterpret_cast<void*>(r.AllGather), &info) && info.dli_fname) r.path = info.dli_fname;
-    });
+        if (!r.handle) return r;
+    }
+    auto sym = [&](const char* name) -> void* {
+        void* p = dlsym(r.handle, name);
+        if (!p) { r.error = std::string("the collective library lacks ") + name; }
+        return p;
+    };
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.GetVersion || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+        dlclose(r.handle); r.handle = nullptr; return r;
+    }
+    r.error.clear();
+    (void)r.GetVersion(&r.version);
+    Dl_info info{};
+    if (dladdr(reinterpret_cast<void*>(r.AllGather), &info) && info.dli_fname) r.path = info.dli_fname;
     return r;
 }
 
@@ -158,7 +178,9 @@ enum Mode : int { kNone = 0, kRccl = 1, kPeer = 2 };
 
 struct ShardLane {                  // what one lane owns on one shard
     yams_accel_ctx* ctx = nullptr;  // the scan's context: its own stream and workspace
-    hipStream_t side = nullptr;     // collective (and, on the root shard, merge + download) of this lane
+    hipStream_t side = nullptr;     // exchange (and, on the root shard, merge + download) of this lane
+    float* queries = nullptr; size_t queries_cap = 0;           // the batch on this device
+    unsigned char* rec = nullptr; size_t rec_cap = 0;           // this shard's packed record (the send buffer)
     unsigned char* gathered = nullptr; size_t gathered_cap = 0; // [n shards][record stride]
     std::thread worker;
 };
@@ -166,10 +188,11 @@ struct ShardLane {                  // what one lane owns on one shard
 struct Lane {
     // --- state, under yams_scan_sharded::mu
     bool acquired = false, submitted = false, trivial = false, want_diag = false;
-    uint64_t seq = 0;               // position in the collective order (turnstile)
+    bool ordered = false;           // the batch has a place in the exchange order (seq)
+    uint64_t seq = 0;               // position in the exchange order (turnstile)
     uint64_t job = 0;               // generation: the lane's workers run when it moves
     uint32_t pending = 0;           // workers that have not reported yet
-    std::atomic<uint32_t> peer_left{0};
+    uint32_t peer_left = 0;         // kPeer: records that have not landed on the root's device yet
     // --- the batch
     uint32_t nq = 0, dim = 0; yams_scan_params_t prm{}; bool l2 = false;
     const uint32_t* rank_of_row = nullptr; int64_t rank_row_base = 0;
@@ -204,16 +227,20 @@ struct yams_scan_sharded {
     std::vector<int> device;
     uint32_t n = 0, n_lanes = 0;
     int mode = kNone;
+    bool fenced = false;
+    Rccl* R = nullptr;                           // kRccl: the bound collective library
     std::vector<ncclComm_t> comm;                // kRccl: one per shard, one communicator
     std::map<int, yams_accel_gate*> gates;       // one per distinct device
     std::vector<std::unique_ptr<Lane>> lanes;
     std::mutex mu;
-    std::condition_variable cv_job, cv_done, cv_lane, cv_turn;
-    std::vector<uint64_t> coll_next;             // per shard: the seq whose collective is due next
+    std::condition_variable cv_job, cv_done, cv_lane, cv_turn, cv_peer;
+    std::vector<uint64_t> coll_next;             // per shard: the seq whose exchange is due next
+    std::vector<hipEvent_t> fence_ev;            // per shard: end of its part of the most recent exchange
+    std::vector<char> fence_armed;
     uint64_t next_seq = 0;
     bool stop = false;
     std::string last_error, fallback_reason;
-    std::atomic<uint64_t> batches{0}, collectives{0};
+    std::atomic<uint64_t> batches{0}, collectives{0}, fence_waits{0};
 };
 
 namespace {
@@ -252,82 +279,123 @@ void issue_merge(yams_scan_sharded* s, Lane& L) {
     if (r != YAMS_OK) L.merge_err = yams_accel_last_error(m);
 }
 
+// The scan of shard i's part of lane L's batch into the lane's record (worker thread of (shard i, lane L); current
+// device = the shard's).  Returns with the scan's stream idle; never throws.
+yams_status_t scan_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& err) {
+    ShardLane& SL = L.sh[i];
+    yams_accel_ctx* c = SL.ctx;
+    const size_t nq = L.nq, dim = L.dim;
+    yams_status_t st = YAMS_OK;
+    try {
+        // this lane's previous exchange finished long ago (its wait() returned); a stream query, not a stall
+        (void)hipStreamSynchronize(SL.side);
+        if (hipMemcpyAsync(SL.queries, L.h_queries, nq * dim * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            st = fail(c, YAMS_ERR_INTERNAL, "query upload failed");
+        }
+        if (st == YAMS_OK) {
+            yams_scan_params_t prm = L.prm;
+            if (L.l2 && s->mode != kNone) prm.flags |= YAMS_SCAN_FLAG_DEFER_THRESHOLD; // vec0: the k nearest first, the threshold after the merge
+            unsigned char* d_rec = SL.rec;
+            st = yams_scan_topk_device(c, &L.views[i], SL.queries, L.nq, &prm, reinterpret_cast<float*>(d_rec + L.lay.scores_off),
+                                       reinterpret_cast<int64_t*>(d_rec + L.lay.rows_off),
+                                       reinterpret_cast<uint32_t*>(d_rec + L.lay.counts_off),
+                                       L.lay.dist_off != UINT64_MAX ? reinterpret_cast<float*>(d_rec + L.lay.dist_off) : nullptr, nullptr,
+                                       L.want_diag ? &L.dg[i] : nullptr);
+        }
+        if (st != YAMS_OK) err = yams_accel_last_error(c);
+    } catch (const std::exception& e) { st = YAMS_ERR_INTERNAL; err = e.what(); }
+    catch (...) { st = YAMS_ERR_INTERNAL; err = "unknown exception in a shard worker"; }
+    if (st != YAMS_OK) {
+        // the exchange still happens (a rank that skips a collective hangs the others): an empty record
+        (void)hipMemsetAsync(SL.rec, 0, static_cast<size_t>(L.stride), c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
+    }
+    return st;
+}
+
+// Shard i's part of the exchange of lane L's batch, in the handle's exchange order.  Runs on EVERY exit path of a
+// batch that was given a seq; never throws.
+yams_status_t exchange_shard(yams_scan_sharded* s, Lane& L, uint32_t i, yams_status_t st, std::string& err) {
+    ShardLane& SL = L.sh[i];
+    {   // exchanges of one communicator go out in submit order on every rank
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; });
+    }
+    try {
+        if (s->mode == kRccl) {
+            const ncclResult_t r = s->R->AllGather(SL.rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
+            if (r != ncclSuccess) {
+                (void)hipGetLastError();
+                if (st == YAMS_OK) { err = std::string("ncclAllGather failed: ") + s->R->GetErrorString(r); st = YAMS_ERR_INTERNAL; }
+            }
+            if (i == 0) { issue_merge(s, L); ++s->collectives; }
+        } else {
+            // shards that share a device (or a host without RCCL): the record is copied next to the others on the
+            // root's device; the root's worker enqueues the merge once the last one has landed
+            unsigned char* dst = L.sh[0].gathered + L.stride * i;
+            hipError_t e;
+            if (s->device[i] == s->device[0]) e = hipMemcpyAsync(dst, SL.rec, static_cast<size_t>(L.stride), hipMemcpyDeviceToDevice, SL.side);
+            else e = hipMemcpyPeerAsync(dst, s->device[0], SL.rec, s->device[i], static_cast<size_t>(L.stride), SL.side);
+            if (e == hipSuccess && i != 0) e = hipStreamSynchronize(SL.side);
+            if (e != hipSuccess) { (void)hipGetLastError(); if (st == YAMS_OK) { err = "record copy to the merge device failed"; st = YAMS_ERR_INTERNAL; } }
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                --L.peer_left;
+                if (i == 0) s->cv_peer.wait(lk, [&] { return L.peer_left == 0; });
+                else s->cv_peer.notify_all();
+            }
+            if (i == 0) { issue_merge(s, L); ++s->collectives; }
+        }
+    } catch (const std::exception& e) { if (st == YAMS_OK) { st = YAMS_ERR_INTERNAL; err = e.what(); } }
+    catch (...) { if (st == YAMS_OK) { st = YAMS_ERR_INTERNAL; err = "unknown exception in the record exchange"; } }
+    // the fence: this shard's next sweep waits for everything enqueued on the side stream up to here
+    const bool fence = s->fenced && hipEventRecord(s->fence_ev[i], SL.side) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (fence) s->fence_armed[i] = 1;
+        ++s->coll_next[i];
+    }
+    s->cv_turn.notify_all();
+    return st;
+}
+
 // One shard's part of lane L's batch (worker thread of (shard i, lane L); current device = the shard's).
 yams_status_t run_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& err) {
     ShardLane& SL = L.sh[i];
     yams_accel_ctx* c = SL.ctx;
-    const size_t nq = L.nq, k = L.prm.k, dim = L.dim;
-    // this lane's previous exchange finished long ago (its wait() returned); a stream query, not a stall
-    (void)hipStreamSynchronize(SL.side);
-    float* d_q = nullptr; unsigned char* d_rec = nullptr;
-    yams_status_t st = ws_get(c, "shard_queries", nq * dim * 4, (void**)&d_q);
-    if (st == YAMS_OK) st = ws_get(c, "shard_record", static_cast<size_t>(L.stride), (void**)&d_rec);
-    if (st == YAMS_OK && hipMemcpyAsync(d_q, L.h_queries, nq * dim * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        st = fail(c, YAMS_ERR_INTERNAL, "query upload failed");
-    }
-    if (st == YAMS_OK) {
-        yams_scan_params_t prm = L.prm;
-        if (L.l2 && s->mode != kNone) prm.flags |= YAMS_SCAN_FLAG_DEFER_THRESHOLD; // vec0: the k nearest first, the threshold after the merge
-        st = yams_scan_topk_device(c, &L.views[i], d_q, L.nq, &prm, reinterpret_cast<float*>(d_rec + L.lay.scores_off),
-                                   reinterpret_cast<int64_t*>(d_rec + L.lay.rows_off),
-                                   reinterpret_cast<uint32_t*>(d_rec + L.lay.counts_off),
-                                   L.lay.dist_off != UINT64_MAX ? reinterpret_cast<float*>(d_rec + L.lay.dist_off) : nullptr, nullptr,
-                                   L.want_diag ? &L.dg[i] : nullptr);
-    }
-    if (st != YAMS_OK) {
-        err = yams_accel_last_error(c);
-        // the exchange below still happens (a rank that skips a collective hangs the others): an empty record
-        if (d_rec) { (void)hipMemsetAsync(d_rec, 0, static_cast<size_t>(L.stride), c->stream); (void)hipStreamSynchronize(c->stream); }
-    }
-    if (s->mode == kNone) { // one shard: its own ordering (tie ranks included) is final, nothing to merge
-        if (st != YAMS_OK) return st;
-        const OutLayout o = out_layout(nq, k);
-        hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_rec + L.lay.counts_off, nq * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_rec + L.lay.scores_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_rec + L.lay.rows_off, nq * k * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.dist, d_rec + L.lay.dist_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { (void)hipGetLastError(); err = "result download failed"; return YAMS_ERR_INTERNAL; }
-        return YAMS_OK;
-    }
-    if (!d_rec) return st; // (cannot happen: submit() sized the buffers)
-    if (s->mode == kRccl) {
-        {   // collectives of one communicator go out in submit order on every rank
-            std::unique_lock<std::mutex> lk(s->mu);
-            s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; });
-        }
-        const ncclResult_t r = rccl().AllGather(d_rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
-        if (i == 0) { issue_merge(s, L); ++s->collectives; }
-        {
-            std::lock_guard<std::mutex> lk(s->mu);
-            ++s->coll_next[i];
-        }
-        s->cv_turn.notify_all();
-        if (r != ncclSuccess && st == YAMS_OK) {
-            err = std::string("ncclAllGather failed: ") + rccl().GetErrorString(r);
-            st = YAMS_ERR_INTERNAL;
-        }
-        return st;
-    }
-    // shards that share a device (or a host without RCCL): the record is copied next to the others on the root's device
-    hipError_t e;
-    unsigned char* dst = L.sh[0].gathered + L.stride * i;
-    if (s->device[i] == s->device[0]) e = hipMemcpyAsync(dst, d_rec, static_cast<size_t>(L.stride), hipMemcpyDeviceToDevice, c->stream);
-    else e = hipMemcpyPeerAsync(dst, s->device[0], d_rec, s->device[i], static_cast<size_t>(L.stride), c->stream);
+    const size_t nq = L.nq, k = L.prm.k;
+    yams_status_t st = scan_shard(s, L, i, err);
+    if (s->mode != kNone) return exchange_shard(s, L, i, st, err);
+    // one shard: its own ordering (tie ranks included) is final, nothing to merge
+    if (st != YAMS_OK) return st;
+    const OutLayout o = out_layout(nq, k);
+    unsigned char* d_rec = SL.rec;
+    hipError_t e = hipMemcpyAsync(L.h_out + o.counts, d_rec + L.lay.counts_off, nq * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.scores, d_rec + L.lay.scores_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.rows, d_rec + L.lay.rows_off, nq * k * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(L.h_out + o.dist, d_rec + L.lay.dist_off, nq * k * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); if (st == YAMS_OK) { err = "record copy to the merge device failed"; st = YAMS_ERR_INTERNAL; } }
-    if (L.peer_left.fetch_sub(1) == 1) { // the last record has landed: this thread enqueues the merge
-        (void)hipSetDevice(s->device[0]);
-        issue_merge(s, L);
-        (void)hipSetDevice(s->device[i]);
-    }
-    return st;
+    if (e != hipSuccess) { (void)hipGetLastError(); err = "result download failed"; return YAMS_ERR_INTERNAL; }
+    return YAMS_OK;
 }
 
 void worker_main(yams_scan_sharded* s, uint32_t i, uint32_t li) {
     (void)hipSetDevice(s->device[i]);
     Lane& L = *s->lanes[li];
+    if (s->fenced) {
+        // the fence (see the header comment): called by the scan right before it enqueues a sweep on `st`
+        L.sh[i].ctx->before_sweep = [s, &L, i](hipStream_t st) {
+            bool armed;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                if (!L.ordered) return;
+                if (s->coll_next[i] != L.seq) { ++s->fence_waits; s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; }); }
+                armed = s->fence_armed[i] != 0;
+            }
+            if (armed && hipStreamWaitEvent(st, s->fence_ev[i], 0) != hipSuccess) (void)hipGetLastError();
+        };
+    }
     uint64_t seen = 0;
     for (;;) {
         {
@@ -365,9 +433,9 @@ void destroy_handle(yams_scan_sharded* s) {
             if (SL.side) (void)hipStreamSynchronize(SL.side);
         }
     }
-    if (s->mode == kRccl)
+    if (s->mode == kRccl && s->R)
         for (uint32_t i = 0; i < s->comm.size(); ++i)
-            if (s->comm[i]) { (void)hipSetDevice(s->device[i]); (void)rccl().CommDestroy(s->comm[i]); }
+            if (s->comm[i]) { (void)hipSetDevice(s->device[i]); (void)s->R->CommDestroy(s->comm[i]); }
     for (auto& L : s->lanes) {
         (void)hipSetDevice(s->device[0]);
         if (L->merge_ctx) yams_accel_ctx_destroy(L->merge_ctx); // bound to the root's side stream, which it does not own
@@ -378,10 +446,14 @@ void destroy_handle(yams_scan_sharded* s) {
             ShardLane& SL = L->sh[i];
             (void)hipSetDevice(s->device[i]);
             if (SL.ctx) yams_accel_ctx_destroy(SL.ctx);
+            if (SL.queries) (void)hipFree(SL.queries);
+            if (SL.rec) (void)hipFree(SL.rec);
             if (SL.gathered) (void)hipFree(SL.gathered);
             if (SL.side) (void)hipStreamDestroy(SL.side);
         }
     }
+    for (uint32_t i = 0; i < s->fence_ev.size(); ++i)
+        if (s->fence_ev[i]) { (void)hipSetDevice(s->device[i]); (void)hipEventDestroy(s->fence_ev[i]); }
     for (auto& kv : s->gates) yams_accel_gate_destroy(kv.second);
     delete s;
 }
@@ -390,13 +462,16 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
     if (!out) return YAMS_ERR_INVALID_ARG;
     *out = nullptr;
     if (!devices || n_shards == 0 || n_shards > 64) return YAMS_ERR_INVALID_ARG;
-    uint32_t n_lanes = 2, collective = YAMS_SHARDED_COLLECTIVE_AUTO;
+    uint32_t n_lanes = 2, collective = YAMS_SHARDED_COLLECTIVE_AUTO, fence = YAMS_SHARDED_FENCE_AUTO;
+    std::string library;
     if (opt) {
-        if (opt->struct_size < sizeof(yams_scan_sharded_options_t)) return YAMS_ERR_INVALID_ARG;
+        if (opt->struct_size < 16) return YAMS_ERR_INVALID_ARG; // (16: the round-3 struct — lanes, collective, one reserved word)
         if (opt->lanes) n_lanes = opt->lanes;
         collective = opt->collective;
+        fence = opt->fence;
+        if (opt->struct_size >= sizeof(yams_scan_sharded_options_t) && opt->rccl_library) library = opt->rccl_library;
     }
-    if (n_lanes > 16 || collective > YAMS_SHARDED_COLLECTIVE_PEER) return YAMS_ERR_INVALID_ARG;
+    if (n_lanes > 16 || collective > YAMS_SHARDED_COLLECTIVE_PEER || fence > YAMS_SHARDED_FENCE_OFF) return YAMS_ERR_INVALID_ARG;
     const int n_dev = yams_accel_device_count();
     if (n_dev <= 0) return YAMS_ERR_UNSUPPORTED; // no GPU: there is deliberately no CPU fallback
     bool distinct = true;
@@ -404,7 +479,8 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
         if (devices[i] < 0 || devices[i] >= n_dev) return YAMS_ERR_INVALID_ARG;
         for (uint32_t j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
     }
-    if (collective == YAMS_SHARDED_COLLECTIVE_RCCL && !distinct) return YAMS_ERR_INVALID_ARG; // RCCL refuses two ranks on one device
+    // RCCL refuses two ranks on one device; a library the caller names decides for itself
+    if (collective == YAMS_SHARDED_COLLECTIVE_RCCL && !distinct && library.empty()) return YAMS_ERR_INVALID_ARG;
 
     auto* s = new yams_scan_sharded();
     s->n = n_shards; s->n_lanes = n_lanes;
@@ -414,27 +490,34 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
 
     // the communicator: one process, one ncclCommInitAll over the shard devices
     const bool want_rccl = collective == YAMS_SHARDED_COLLECTIVE_RCCL ||
-                           (collective == YAMS_SHARDED_COLLECTIVE_AUTO && distinct && n_shards >= 2);
+                           (collective == YAMS_SHARDED_COLLECTIVE_AUTO && (distinct || !library.empty()) && n_shards >= 2);
     s->mode = n_shards >= 2 ? kPeer : kNone;
     if (want_rccl) {
-        Rccl& R = rccl();
+        Rccl& R = rccl(library);
         std::string why;
-        if (!R.ok()) why = "librccl.so.1 could not be loaded: " + R.error;
+        if (!R.ok()) why = (library.empty() ? std::string("librccl.so.1") : library) + " could not be loaded: " + R.error;
         else {
             s->comm.assign(n_shards, nullptr);
             const ncclResult_t r = R.CommInitAll(s->comm.data(), static_cast<int>(n_shards), s->device.data());
             if (r != ncclSuccess) { why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(r); s->comm.clear(); (void)hipGetLastError(); }
         }
-        if (why.empty()) s->mode = kRccl;
+        if (why.empty()) { s->mode = kRccl; s->R = &R; }
         else if (collective == YAMS_SHARDED_COLLECTIVE_RCCL) {
             std::fprintf(stderr, "[yams_mi355x_accel] %s\n", why.c_str());
             return bail(YAMS_ERR_UNSUPPORTED);
         } else s->fallback_reason = why; // AUTO: device-to-device copies of the records; reported by ..._info_json
     }
+    s->fenced = n_shards >= 2 && fence == YAMS_SHARDED_FENCE_AUTO;
+    s->fence_ev.assign(n_shards, nullptr);
+    s->fence_armed.assign(n_shards, 0);
 
     for (uint32_t i = 0; i < n_shards; ++i) {
         yams_accel_gate*& g = s->gates[devices[i]];
         if (!g && yams_accel_gate_create(devices[i], &g) != YAMS_OK) return bail(YAMS_ERR_INTERNAL);
+        if (s->fenced) {
+            (void)hipSetDevice(devices[i]);
+            if (hipEventCreateWithFlags(&s->fence_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return bail(YAMS_ERR_INTERNAL); }
+        }
     }
     for (uint32_t li = 0; li < n_lanes; ++li) {
         s->lanes.emplace_back(new Lane());
@@ -483,6 +566,15 @@ bool grow_pinned(void** p, size_t* cap, size_t bytes) {
     *cap = want;
     return true;
 }
+// ... and so do its device buffers (the current device is the buffer's; `quiet` = a stream whose work may still use it)
+bool grow_device(void** p, size_t* cap, size_t bytes, hipStream_t quiet) {
+    if (*cap >= bytes && *p) return true;
+    if (*p) { (void)hipStreamSynchronize(quiet); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = ((bytes ? bytes : 16) + bytes / 4 + 255) & ~static_cast<size_t>(255);
+    if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    *cap = want;
+    return true;
+}
 
 yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_corpus_t* shards, const float* queries_host,
                           uint32_t n_queries, const yams_scan_params_t* params, const uint32_t* rank_of_row, int64_t rank_row_base,
@@ -520,30 +612,19 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
             !grow_pinned(reinterpret_cast<void**>(&L.h_out), &L.h_out_cap, out_layout(nq, k).bytes))
             return set_error(s, YAMS_ERR_INTERNAL, "pinned staging could not be allocated");
         // device buffers of the batch are sized HERE, on the caller's thread while the lane is idle, so that no rank
-        // can drop out of a collective later for want of memory
+        // can drop out of an exchange later for want of memory
+        const size_t need = static_cast<size_t>(L.stride) * n;
         for (uint32_t i = 0; i < n; ++i) {
-            void* p;
+            ShardLane& SL = L.sh[i];
             (void)hipSetDevice(s->device[i]);
-            if (ws_get(L.sh[i].ctx, "shard_queries", nq * dim * 4, &p) != YAMS_OK ||
-                ws_get(L.sh[i].ctx, "shard_record", static_cast<size_t>(L.stride), &p) != YAMS_OK) {
+            bool ok = grow_device(reinterpret_cast<void**>(&SL.queries), &SL.queries_cap, nq * dim * 4, SL.ctx->stream) &&
+                      grow_device(reinterpret_cast<void**>(&SL.rec), &SL.rec_cap, static_cast<size_t>(L.stride), SL.side);
+            // receive buffers of the exchange: every rank under RCCL, the root's device otherwise
+            if (ok && s->mode != kNone && (s->mode == kRccl || i == 0))
+                ok = grow_device(reinterpret_cast<void**>(&SL.gathered), &SL.gathered_cap, need, SL.side);
+            if (!ok) {
                 (void)hipSetDevice(dev0);
-                return set_error(s, YAMS_ERR_INTERNAL, yams_accel_last_error(L.sh[i].ctx));
-            }
-        }
-        if (s->mode != kNone) { // receive buffers of the exchange
-            const size_t need = static_cast<size_t>(L.stride) * n;
-            for (uint32_t i = 0; i < n; ++i) {
-                if (s->mode == kPeer && i != 0) break;
-                ShardLane& SL = L.sh[i];
-                if (SL.gathered_cap >= need) continue;
-                (void)hipSetDevice(s->device[i]);
-                if (SL.gathered) { (void)hipStreamSynchronize(SL.side); (void)hipFree(SL.gathered); SL.gathered = nullptr; SL.gathered_cap = 0; }
-                const size_t want = need + need / 4;
-                if (hipMalloc(reinterpret_cast<void**>(&SL.gathered), want) != hipSuccess) {
-                    (void)hipGetLastError(); SL.gathered = nullptr; (void)hipSetDevice(dev0);
-                    return set_error(s, YAMS_ERR_INTERNAL, "receive buffer of the all-gather could not be allocated");
-                }
-                SL.gathered_cap = want;
+                return set_error(s, YAMS_ERR_INTERNAL, "device buffers of the batch could not be allocated");
             }
         }
         (void)hipSetDevice(dev0);
@@ -567,6 +648,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         std::lock_guard<std::mutex> lk(s->mu);
         L.st[0] = st; L.err[0] = std::move(err);
         L.pending = 0;
+        L.ordered = false;
         L.submitted = true;
         ++s->batches;
         return YAMS_OK;
@@ -574,10 +656,11 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
     {
         std::lock_guard<std::mutex> lk(s->mu);
         L.submitted = true;
+        L.ordered = false;
         if (!L.trivial) {
             L.pending = n;
-            L.peer_left.store(n);
-            if (s->mode == kRccl) L.seq = s->next_seq++;
+            L.peer_left = n;
+            if (s->mode != kNone) { L.seq = s->next_seq++; L.ordered = true; }
             ++L.job;
         }
     }
@@ -595,15 +678,20 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
         if (!L.acquired || !L.submitted) { s->last_error = "nothing was submitted on this lane"; return YAMS_ERR_INVALID_ARG; }
         s->cv_done.wait(lk, [&] { return L.trivial || L.pending == 0; });
     }
-    auto release = [&](yams_status_t st, const std::string& m) {
-        {
-            std::lock_guard<std::mutex> lk(s->mu);
-            if (st != YAMS_OK) s->last_error = m;
-            L.acquired = L.submitted = false;
+    // from here on the lane goes back to the pool on EVERY path, an exception included (a lane that stays acquired
+    // would, once all of them are gone, block the next caller in lane_acquire for good)
+    struct Release {
+        yams_scan_sharded* s; Lane& L; yams_status_t st = YAMS_ERR_INTERNAL; std::string msg = "exception while a batch was collected";
+        ~Release() {
+            {
+                std::lock_guard<std::mutex> lk(s->mu);
+                if (st != YAMS_OK) s->last_error = msg;
+                L.acquired = L.submitted = false;
+            }
+            s->cv_lane.notify_one();
         }
-        s->cv_lane.notify_one();
-        return st;
-    };
+    } rel{s, L};
+    auto release = [&](yams_status_t st, const std::string& m) { rel.st = st; rel.msg = m; return st; };
     if (diag) std::memset(diag, 0, sizeof(*diag));
     const size_t nq = L.nq, k = L.prm.k;
     if (L.trivial) {
@@ -682,9 +770,10 @@ extern "C" yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char*
         std::ostringstream os;
         os << "{\"shards\":" << s->n << ",\"lanes\":" << s->n_lanes << ",\"devices\":[";
         for (uint32_t i = 0; i < s->n; ++i) os << (i ? "," : "") << s->device[i];
-        os << "],\"collective\":\"" << (s->mode == kRccl ? "rccl" : (s->mode == kPeer ? "peer_copy" : "none")) << "\"";
-        if (s->mode == kRccl) {
-            const Rccl& R = rccl();
+        os << "],\"collective\":\"" << (s->mode == kRccl ? "rccl" : (s->mode == kPeer ? "peer_copy" : "none")) << "\""
+           << ",\"fenced\":" << (s->fenced ? "true" : "false");
+        if (s->mode == kRccl && s->R) {
+            const Rccl& R = *s->R;
             os << ",\"rccl_version\":" << R.version << ",\"rccl_library\":\"" << R.path << "\",\"communicator_ranks\":" << s->comm.size();
         }
         if (!s->fallback_reason.empty()) {
@@ -692,7 +781,8 @@ extern "C" yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char*
             for (char& ch : r) if (ch == '"' || ch == '\\' || ch == '\n') ch = ' ';
             os << ",\"rccl_unavailable\":\"" << r << "\"";
         }
-        os << ",\"batches\":" << s->batches.load() << ",\"collectives\":" << s->collectives.load() << "}";
+        os << ",\"batches\":" << s->batches.load() << ",\"collectives\":" << s->collectives.load()
+           << ",\"fence_waits\":" << s->fence_waits.load() << "}";
         const std::string str = os.str();
         char* buf = static_cast<char*>(std::malloc(str.size() + 1));
         if (!buf) return YAMS_ERR_INTERNAL;
