@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-telemetry", action="store_true", help="skip the clock / power / throttle-reason window")
     ap.add_argument("--no-c-abi-leg", action="store_true", help="skip the C-ABI sharded leg of the default run")
     ap.add_argument("--no-boundary-leg", action="store_true", help="skip the plugin-door (vector_scan_v1.search_batch from host memory) leg")
+    ap.add_argument("--rccl-library", default=None,
+                    help="--via-c-abi: the collective library the sharded handle binds instead of librccl.so.1 (the test "
+                         "suite's stand-in, tests/stub_coll, lets --single-device runs take the all-gather path)")
+    ap.add_argument("--no-fence", action="store_true", help="--via-c-abi: lift the exchange fence (measurement only)")
     ap.add_argument("--child-json", action="store_true", help=argparse.SUPPRESS)   # --via-c-abi as the child of a torchrun rank 0
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
@@ -466,6 +470,9 @@ def result_digest(rows, scores, counts):
 
 
 def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, oracle_queries=0, collective="rccl"):
+    rccl_library = getattr(a, "rccl_library", None)
+    if rccl_library:
+        collective = "rccl"
     """The multi-GPU form a C++ host gets (sharded_api.cpp): ONE process, `devices` driven through yams_scan_sharded_*
     — persistent shard workers, one RCCL communicator (of one rank on a one-GPU box), per batch one ncclAllGather of
     the packed per-shard records on a side stream + merge_topk_kernel, `lanes` batches in flight so that
@@ -488,7 +495,7 @@ def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, orac
     saved = os.dup(1)
     try:
         os.dup2(2, 1)
-        sh = ShardedScan(devices, lanes=lanes, collective=collective)
+        sh = ShardedScan(devices, lanes=lanes, collective=collective, rccl_library=rccl_library, fence=not getattr(a, "no_fence", False))
     finally:
         os.dup2(saved, 1); os.close(saved)
     info = sh.info()
@@ -699,8 +706,8 @@ def c_abi_main(a):
            "config": {"workload": f"{n}x{d} fp32 cosine top-{k} per GPU (row shard of BASELINE config 4: 100Mx768 over 8 GPUs), "
                                   f"query batch {a.queries}", "rows_per_gpu": n, "corpus_rows": n * a.gpus, "dim": d, "k": k,
                       "query_batch": a.queries,
-                      "parallelism": f"row-shard x{a.gpus}, ONE process through the C ABI (yams_scan_sharded_*): RCCL all-gather + merge "
-                                     "per batch, overlapped with the next sweep", "search_lanes": a.lanes},
+                      "parallelism": f"row-shard x{a.gpus}, ONE process through the C ABI (yams_scan_sharded_*): one all-gather + merge "
+                                     "per batch, fenced in front of the shard's next sweep (DESIGN 4)", "search_lanes": a.lanes},
            "launcher": "single process (--via-c-abi)",
            "roofline": {"bound": "mfma", "kernel": "scan_tiles_i8r_kernel (shard 0's lanes)", "achieved": ach, "peak": PEAK_I8_MFMA_TOPS,
                         "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS if ach else None, "launch_ms": r["filter_launch_ms_shard0"],

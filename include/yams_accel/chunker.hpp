@@ -16,6 +16,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <exception>
+#include <thread>
+
 #include "plugin.hpp"
 
 #ifdef YAMS_ACCEL_USE_HOST_TYPES
@@ -102,6 +106,12 @@ public:
         std::vector<std::vector<Chunk>> chunks;   // per buffer, in order
         std::vector<Hash> bufferHashes;           // per buffer; empty unless asked for
     };
+    // The host's own one-shot SHA-256 (e.g. a lambda around crypto::SHA256Hasher::hash).  With one, chunkMany asks the
+    // device NOT to compute the whole-buffer hash of buffers whose chain would outlast the rest of the call
+    // (YAMS_CHUNK_MANY_DEFER_LONG_BUFFER_HASHES: one 64 MiB file in a batch of small ones holds the device for 1.9 s) and
+    // hashes those on host threads WHILE the device call runs.  Thread-safe callables only.
+    using HostHash = std::function<std::string(std::span<const std::byte>)>;
+    void setHostHash(HostHash h, unsigned maxThreads = 0) { hostHash_ = std::move(h); hostThreads_ = maxThreads; }
     BatchResult chunkMany(const std::vector<std::span<const std::byte>>& buffers, bool withBufferHashes = false, bool lazy = true) {
         BatchResult out;
         out.chunks.resize(buffers.size());
@@ -116,8 +126,33 @@ public:
         std::vector<size_t> lens(buffers.size());
         for (size_t b = 0; b < buffers.size(); ++b) { ptrs[b] = reinterpret_cast<const uint8_t*>(buffers[b].data()); lens[b] = buffers[b].size(); }
         yams_chunk_batch_t* batch = nullptr;
+        // buffers the device will leave to the host (the same predicate the plugin applies): started NOW, joined below
+        const bool defer = withBufferHashes && static_cast<bool>(hostHash_);
+        std::vector<size_t> deferred;
+        std::vector<std::string> deferredHash;
+        std::vector<std::future<void>> workers;
+        if (defer) {
+            uint64_t total = 0;
+            for (size_t l : lens) total += l;
+            const uint64_t above = yams_ingest_defer_threshold_host(total);
+            for (size_t b = 0; b < buffers.size(); ++b) if (lens[b] > above) deferred.push_back(b);
+            deferredHash.resize(deferred.size());
+            if (!deferred.empty()) {
+                unsigned nt = hostThreads_ ? hostThreads_ : std::max(1u, std::thread::hardware_concurrency());
+                nt = static_cast<unsigned>(std::min<size_t>(nt, deferred.size()));
+                auto next = std::make_shared<std::atomic<size_t>>(0);
+                for (unsigned t = 0; t < nt; ++t)
+                    workers.push_back(std::async(std::launch::async, [&, next] {
+                        for (size_t j; (j = next->fetch_add(1)) < deferred.size();) deferredHash[j] = hostHash_(buffers[deferred[j]]);
+                    }));
+            }
+        }
         const yams_status_t st = vt_->chunk_many(vt_->self, ptrs.data(), lens.data(), buffers.size(), &cfg,
-                                                 withBufferHashes ? YAMS_CHUNK_MANY_BUFFER_HASHES : 0u, &batch);
+                                                 (withBufferHashes ? YAMS_CHUNK_MANY_BUFFER_HASHES : 0u) |
+                                                     (defer ? YAMS_CHUNK_MANY_DEFER_LONG_BUFFER_HASHES : 0u), &batch);
+        std::exception_ptr hostError; // (workers are joined on every path; an exception of the host hasher surfaces here)
+        for (auto& w : workers) try { w.get(); } catch (...) { if (!hostError) hostError = std::current_exception(); }
+        if (hostError) { if (batch) vt_->free_chunk_batch(vt_->self, batch); std::rethrow_exception(hostError); }
         if (st != YAMS_OK || !batch) throw std::runtime_error("Failed to chunk the batch on the accelerator");
         try {
             for (size_t b = 0; b < buffers.size(); ++b) {
@@ -128,8 +163,11 @@ public:
                     dst[i].offset = r.offset; dst[i].size = r.size; dst[i].hash.assign(r.hash_hex, 64);
                     if (!lazy) { auto s = buffers[b].subspan(dst[i].offset, dst[i].size); dst[i].data.assign(s.begin(), s.end()); }
                 }
-                if (withBufferHashes) out.bufferHashes.emplace_back(batch->buffer_hash_hex + 65 * b, 64);
+                if (withBufferHashes) out.bufferHashes.emplace_back(batch->buffer_hash_hex + 65 * b, batch->buffer_hash_hex[65 * b] ? 64 : 0);
             }
+            for (size_t j = 0; j < deferred.size(); ++j) out.bufferHashes[deferred[j]] = deferredHash[j];
+            if (withBufferHashes)
+                for (auto& h : out.bufferHashes) if (h.size() != 64) throw std::runtime_error("a buffer hash is missing from the batch");
         } catch (...) { vt_->free_chunk_batch(vt_->self, batch); throw; } // the paired free, also on the exception path (:131-149)
         vt_->free_chunk_batch(vt_->self, batch);
         return out;
@@ -193,6 +231,8 @@ private:
     AccelChunkerKind kind_;
     ChunkingConfig config_;
     ProgressCallback progress_;
+    HostHash hostHash_;
+    unsigned hostThreads_ = 0;
 };
 
 inline Result<std::unique_ptr<IChunker>> createAccelChunker(std::shared_ptr<accel::Plugin> plugin,

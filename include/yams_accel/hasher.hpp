@@ -11,6 +11,7 @@
 #include <functional>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <span>
 #include <string>
 #include <vector>
@@ -46,9 +47,14 @@ public:
 // correct, slow, and documented as such.
 class AccelSHA256Hasher final : public IContentHasher {
 public:
+    // hostHasher serves THIS object's streaming calls (init / update / finalize / hashFile).  oneShotHasher, a SECOND
+    // instance of the host's hasher, serves the one-shot chains the device refuses: the reference's
+    // SHA256Hasher::hash(span) is static and stateless (sha256_hasher.cpp:167-195), so a one-shot hash() between two
+    // update() calls must not touch the chain in progress, and concurrent hash() calls must not share a context
+    // unguarded.  Without one, refused chains take a private stream on the device (correct, slow).
     AccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin, yams_content_hash_v1* vt,
-                      std::unique_ptr<IContentHasher> hostHasher = nullptr)
-        : plugin_(std::move(plugin)), vt_(vt), host_(std::move(hostHasher)) {
+                      std::unique_ptr<IContentHasher> hostHasher = nullptr, std::unique_ptr<IContentHasher> oneShotHasher = nullptr)
+        : plugin_(std::move(plugin)), vt_(vt), host_(std::move(hostHasher)), oneShot_(std::move(oneShotHasher)) {
         if (!host_ && vt_->stream_create(vt_->self, &stream_) != YAMS_OK)
             throw std::runtime_error("Failed to create SHA256 stream on the accelerator");
     }
@@ -149,10 +155,14 @@ public:
         return out;
     }
     bool hasHostHasher() const { return host_ != nullptr; }
+    bool hasOneShotHostHasher() const { return oneShot_ != nullptr; }
 private:
     std::string oneChain(std::span<const std::byte> data) {
-        if (host_) { host_->init(); host_->update(data); return host_->finalize(); }
-        // no host hasher: a private stream on the device (the handle of init/update/finalize stays untouched)
+        if (oneShot_) { // never host_: that one carries the chain of init() / update() / finalize()
+            std::lock_guard<std::mutex> lk(oneShotMu_);
+            oneShot_->init(); oneShot_->update(data); return oneShot_->finalize();
+        }
+        // no host hasher for one-shot chains: a private stream on the device (the handle of init/update/finalize stays untouched)
         void* st = nullptr;
         check(vt_->stream_create(vt_->self, &st), "Failed to create SHA256 stream on the accelerator");
         char hex[65];
@@ -165,17 +175,26 @@ private:
     static void check(yams_status_t st, const char* what) { if (st != YAMS_OK) throw std::runtime_error(what); }
     std::shared_ptr<accel::Plugin> plugin_;
     yams_content_hash_v1* vt_;
-    std::unique_ptr<IContentHasher> host_;
+    std::unique_ptr<IContentHasher> host_, oneShot_;
+    std::mutex oneShotMu_;
     void* stream_ = nullptr;
     ProgressCallback progress_;
 };
 
-// hostHasher: the host's own IContentHasher (e.g. crypto::createSHA256Hasher()) for single chains; may be null.
+// hostHasher / oneShotHasher: two instances of the host's own IContentHasher (e.g. crypto::createSHA256Hasher()) — the
+// first for this object's streaming chain, the second for the one-shot chains the device refuses; either may be null.
 inline Result<std::unique_ptr<AccelSHA256Hasher>> createAccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin,
-                                                                          std::unique_ptr<IContentHasher> hostHasher = nullptr) {
+                                                                          std::unique_ptr<IContentHasher> hostHasher = nullptr,
+                                                                          std::unique_ptr<IContentHasher> oneShotHasher = nullptr) {
     auto vt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, YAMS_IFACE_CONTENT_HASH_V1_VERSION);
     if (!vt) return vt.error();
-    return std::make_unique<AccelSHA256Hasher>(std::move(plugin), vt.value(), std::move(hostHasher));
+    return std::make_unique<AccelSHA256Hasher>(std::move(plugin), vt.value(), std::move(hostHasher), std::move(oneShotHasher));
+}
+// The usual form: a factory for the host's hasher, called twice.
+inline Result<std::unique_ptr<AccelSHA256Hasher>> createAccelSHA256Hasher(std::shared_ptr<accel::Plugin> plugin,
+                                                                          const std::function<std::unique_ptr<IContentHasher>()>& hostHasherFactory) {
+    return createAccelSHA256Hasher(std::move(plugin), hostHasherFactory ? hostHasherFactory() : nullptr,
+                                   hostHasherFactory ? hostHasherFactory() : nullptr);
 }
 
 } // namespace yams::crypto

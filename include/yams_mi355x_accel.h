@@ -500,6 +500,25 @@ YAMS_ACCEL_API yams_status_t yams_cdc_chunk_device(yams_accel_ctx* ctx, const ui
  * (content_store_impl.cpp:199-231).  flags: bit0 = chunk digests, bit1 = blob digests. */
 #define YAMS_INGEST_CHUNK_DIGESTS 1u
 #define YAMS_INGEST_BLOB_DIGESTS 2u
+/* With YAMS_INGEST_BLOB_DIGESTS: do NOT compute the whole-blob digest of blobs whose chain would outlast the rest
+ * of the call.  One SHA-256 chain is sequential — ~35 MB/s on a device lane, > 1 GB/s on a host core with SHA
+ * extensions — so ONE 64 MiB blob in a batch holds the call for 1.9 s while everything else finishes in tens of
+ * milliseconds.  A blob is deferred iff its length exceeds the threshold below (a pure function of the call's total
+ * bytes: the caller evaluates the same predicate, starts its own hasher — ContentStore::store's SHA256Hasher,
+ * content_store_impl.cpp:199-231 — on those blobs BEFORE the call and joins after it); the digest entry of a
+ * deferred blob is 32 zero bytes.  Chunk boundaries and per-chunk digests of deferred blobs are computed as usual.
+ * Thresholds: chain time L / 35 MB/s against the rest of the call at its measured rate — device-resident input
+ * ~340 GB/s (ratio 2^12, rounded towards keeping work on the device), host-streamed input ~25 GB/s (ratio 2^9);
+ * never below the lone-chain limit of content_hash_v1 (1 MiB). */
+#define YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS 4u
+static inline uint64_t yams_ingest_defer_threshold_device(uint64_t total_bytes) {
+    const uint64_t t = total_bytes >> 12;
+    return t > (1ull << 20) ? t : (1ull << 20);
+}
+static inline uint64_t yams_ingest_defer_threshold_host(uint64_t total_bytes) {
+    const uint64_t t = total_bytes >> 9;
+    return t > (1ull << 20) ? t : (1ull << 20);
+}
 YAMS_ACCEL_API yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8_t* data,
                                                 const uint64_t* blob_offsets_host,
                                                 const uint64_t* blob_lengths_host,
@@ -706,6 +725,11 @@ typedef struct yams_chunk_batch_s {
                                   ContentStore::store, content_store_impl.cpp:199-231), or NULL if not asked for  */
 } yams_chunk_batch_t;
 #define YAMS_CHUNK_MANY_BUFFER_HASHES 1u
+/* With YAMS_CHUNK_MANY_BUFFER_HASHES: buffers longer than yams_ingest_defer_threshold_host(sum of lens) come back with
+ * an EMPTY buffer_hash_hex entry (first byte 0) — their whole-buffer chain would outlast the rest of the call; the
+ * adapter's host hasher computes them while the device works (AccelChunker::chunkMany).  See
+ * YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS. */
+#define YAMS_CHUNK_MANY_DEFER_LONG_BUFFER_HASHES 2u
 
 typedef struct yams_chunker_v1 {
     uint32_t abi_version; /* YAMS_IFACE_CHUNKER_V1_VERSION */

@@ -133,6 +133,30 @@ int main(int argc, char** argv) {
         auto res = validator.validateChunks({{bytes(a), ha}, {bytes(b), ha}, {bytes(c), hc}, {bytes(b), "short"}});
         CHECK(res.size() == 4 && res[0].isValid && !res[1].isValid && res[2].isValid && !res[3].isValid);
         CHECK(res[1].errorMessage == "Hash mismatch: expected " + ha.substr(0, 8) + ", got " + hb.substr(0, 8));
+        // a chunk above 1 MiB is a lone long chain — the device REFUSES it (YAMS_ERR_UNSUPPORTED) and the
+        // validator must not report intact data as corrupt for that: it takes such chains one at a time (host hash
+        // where one is given, else the device's streaming door) and verifies the rest as a set.
+        {
+            std::string big(3 * (1 << 20) + 77, 'q');
+            for (size_t i = 0; i < big.size(); i += 811) big[i] = static_cast<char>(i * 7);
+            const std::string hbig = hasher.hash(bytes(big));
+            char hex[65];
+            CHECK(hvt->hash(hvt->self, reinterpret_cast<const uint8_t*>(big.data()), big.size(), hex) == YAMS_ERR_UNSUPPORTED); // (the premise)
+            auto lone = validator.validateChunk(bytes(big), hbig);
+            CHECK(lone.isValid && lone.errorMessage.empty() && lone.chunkSize == big.size());
+            auto wrong = validator.validateChunk(bytes(big), ha);
+            CHECK(!wrong.isValid && wrong.errorMessage == "Hash mismatch: expected " + ha.substr(0, 8) + ", got " + hbig.substr(0, 8));
+            // a small batch dominated by the long chain: refused as a whole, answered chunk by chunk
+            auto mixed = validator.validateChunks({{bytes(a), ha}, {bytes(big), hbig}, {bytes(b), ha}, {bytes(big), hb}});
+            CHECK(mixed.size() == 4 && mixed[0].isValid && mixed[1].isValid && !mixed[2].isValid && !mixed[3].isValid);
+            CHECK(mixed[2].errorMessage == "Hash mismatch: expected " + ha.substr(0, 8) + ", got " + hb.substr(0, 8));
+            CHECK(mixed[3].errorMessage == "Hash mismatch: expected " + hb.substr(0, 8) + ", got " + hbig.substr(0, 8));
+            // with a host hash supplied, the refused chains go to it (and only those)
+            int hostCalls = 0;
+            integrity::AccelChunkValidator withHost(plugin, hvt, [&](std::span<const std::byte> d) { ++hostCalls; return hasher.hash(d); });
+            auto viaHost = withHost.validateChunks({{bytes(a), ha}, {bytes(big), hbig}});
+            CHECK(viaHost[0].isValid && viaHost[1].isValid && hostCalls == 1);
+        }
         integrity::AccelDedupIndex known(plugin, hvt);
         auto first = known.insertAndClassify({ha, hb, ha, hc, hb});
         CHECK(first.has_value() && first.value() == std::vector<bool>({true, true, false, true, false}));

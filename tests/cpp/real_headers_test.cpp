@@ -185,9 +185,24 @@ int main(int argc, char** argv) {
             CHECK(vt.value()->hash_many(vt.value()->self, ptrs.data(), lens.data(), ptrs.size(), out.data()) == YAMS_OK);
             CHECK(std::string(out.data(), 64) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big.data(), size_t(1) << 20)));
         }
-        auto made = crypto::createAccelSHA256Hasher(plugin, std::make_unique<crypto::SHA256Hasher>());
-        CHECK(made.has_value() && made.value()->hasHostHasher());
+        // (the factory form: one host hasher for the streaming chain, a second one for refused one-shot chains)
+        auto made = crypto::createAccelSHA256Hasher(plugin, [] { return std::unique_ptr<crypto::IContentHasher>(std::make_unique<crypto::SHA256Hasher>()); });
+        CHECK(made.has_value() && made.value()->hasHostHasher() && made.value()->hasOneShotHostHasher());
         auto& acc = *made.value();
+        {   // a one-shot hash() of a refused (> 1 MiB) chain between two update() calls must not disturb the
+            // chain in progress — SHA256Hasher::hash(span) is static and stateless in the reference (sha256_hasher.cpp:167-195)
+            acc.init(); acc.update({big.data(), 1000});
+            CHECK(acc.hash(big) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+            acc.update({big.data() + 1000, big.size() - 1000});
+            CHECK(acc.finalize() == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+            // ... also with ONE host hasher only (refused chains then take a private device stream) and with none
+            auto single = crypto::createAccelSHA256Hasher(plugin, std::make_unique<crypto::SHA256Hasher>());
+            CHECK(single.has_value() && single.value()->hasHostHasher() && !single.value()->hasOneShotHostHasher());
+            single.value()->init(); single.value()->update({big.data(), 1000});
+            CHECK(single.value()->hash(big) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+            single.value()->update({big.data() + 1000, big.size() - 1000});
+            CHECK(single.value()->finalize() == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));
+        }
         CHECK(acc.hash(big) == crypto::SHA256Hasher::hash(std::span<const std::byte>(big)));       // host chain
         CHECK(acc.hash(small) == crypto::SHA256Hasher::hash(std::span<const std::byte>(small)));   // device
         acc.init(); acc.update({big.data(), 1000}); acc.update({big.data() + 1000, big.size() - 1000});
@@ -262,6 +277,52 @@ int main(int argc, char** argv) {
             }
         }
         CHECK(batcher.value()->chunkMany({}, true).chunks.empty());
+        {   // a batch must not wait for ONE long chain.  With a host hash the 3 MiB buffer (above
+            // yams_ingest_defer_threshold_host of this 3.3 MiB batch = 1 MiB) is left to the host — hashed on a host
+            // thread while the device call runs — and every buffer hash still equals the reference's.
+            std::atomic<int> hostCalls{0};
+            batcher.value()->setHostHash([&](std::span<const std::byte> d) { ++hostCalls; return crypto::SHA256Hasher::hash(d); });
+            auto res = batcher.value()->chunkMany(bufs, /*withBufferHashes=*/true, true);
+            CHECK(hostCalls.load() == 1 && res.bufferHashes.size() == bufs.size());
+            for (size_t b = 0; b < bufs.size(); ++b) {
+                CHECK(res.bufferHashes[b] == crypto::SHA256Hasher::hash(bufs[b]));
+                auto r = ref->chunkData(bufs[b]);
+                CHECK(res.chunks[b].size() == r.size() && (r.empty() || res.chunks[b].back().hash == r.back().hash));
+            }
+            // the raw door: the deferred entry comes back empty, the others filled
+            auto cvt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, YAMS_IFACE_CHUNKER_V1_VERSION).value();
+            std::vector<const uint8_t*> ptrs; std::vector<size_t> lens;
+            for (auto& b : bufs) { ptrs.push_back(reinterpret_cast<const uint8_t*>(b.data())); lens.push_back(b.size()); }
+            yams_cdc_config_t ccfg{}; cvt->get_default_config(cvt->self, kind ? YAMS_CDC_STREAMING : YAMS_CDC_RABIN, &ccfg);
+            yams_chunk_batch_t* batch = nullptr;
+            CHECK(cvt->chunk_many(cvt->self, ptrs.data(), lens.data(), ptrs.size(), &ccfg,
+                                  YAMS_CHUNK_MANY_BUFFER_HASHES | YAMS_CHUNK_MANY_DEFER_LONG_BUFFER_HASHES, &batch) == YAMS_OK);
+            if (batch) {
+                for (size_t b = 0; b < bufs.size(); ++b) CHECK((batch->buffer_hash_hex[65 * b] == 0) == (lens[b] > (size_t(1) << 20)));
+                cvt->free_chunk_batch(cvt->self, batch);
+            }
+            // min_size == 0 (legal when max_size > 0) and min_size > max_size through chunk_many
+            for (auto mm : {std::pair<uint64_t, uint64_t>{0, 4096}, std::pair<uint64_t, uint64_t>{8192, 1024}}) {
+                yams_cdc_config_t c2 = ccfg; c2.min_size = mm.first; c2.max_size = mm.second;
+                const uint8_t* p1[2] = {reinterpret_cast<const uint8_t*>(data.data()), reinterpret_cast<const uint8_t*>(data.data()) + 5000};
+                const size_t l1[2] = {300000, 70001};
+                yams_chunk_batch_t* b2 = nullptr;
+                CHECK(cvt->chunk_many(cvt->self, p1, l1, 2, &c2, 0, &b2) == YAMS_OK);
+                if (b2) {
+                    for (int j = 0; j < 2; ++j) {
+                        yams_chunk_ref_t* one = nullptr; size_t n1 = 0;
+                        CHECK(cvt->chunk_data(cvt->self, p1[j], l1[j], &c2, &one, &n1) == YAMS_OK);
+                        CHECK(n1 == b2->first_chunk[j + 1] - b2->first_chunk[j]);
+                        for (size_t i = 0; i < n1 && n1 == b2->first_chunk[j + 1] - b2->first_chunk[j]; ++i) {
+                            const auto& m = b2->chunks[b2->first_chunk[j] + i];
+                            CHECK(m.offset == one[i].offset && m.size == one[i].size && std::string(m.hash_hex, 64) == std::string(one[i].hash_hex, 64));
+                        }
+                        cvt->free_chunks(cvt->self, one, n1);
+                    }
+                    cvt->free_chunk_batch(cvt->self, b2);
+                }
+            }
+        }
     }
 
     std::printf("[section] vector store\n");

@@ -51,7 +51,7 @@ struct IngestLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64_t* blob_off_h,
                           const uint64_t* blob_len_h, uint64_t n_blobs64,
                           const yams_cdc_config_t* cfg, uint32_t flags, bool do_chunks,
-                          yams_ingest_result_t* out, const IngestLane* lane = nullptr) {
+                          yams_ingest_result_t* out, const IngestLane* lane = nullptr, uint64_t defer_above = 0) {
     if (!out) return fail(ctx, YAMS_ERR_INVALID_ARG, "null result");
     std::memset(out, 0, sizeof(*out));
     if (n_blobs64 >= (1ull << 31)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "too many blobs");
@@ -100,6 +100,12 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     const bool fork_blobs = (flags & YAMS_INGEST_BLOB_DIGESTS) && n_blobs > 0;
     uint8_t* d_blob_digests = nullptr;
     uint64_t* d_sorted_blobs = nullptr;
+    // YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS: blobs above the threshold get NO whole-blob chain here (one chain is
+    // sequential, ~35 MB/s on a device lane: a 64 MiB blob holds the whole call for 1.9 s while a host core hashes it in
+    // 40 ms) — their digest entries are 32 zero bytes and the caller's host hasher fills them while the device works.
+    if ((flags & YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS) && defer_above == 0) defer_above = yams_ingest_defer_threshold_device(total_bytes);
+    if (!(flags & YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS)) defer_above = 0;
+    uint32_t n_chains = n_blobs;
     if (fork_blobs) {
         // Lanes of one workgroup advance in lock step, so messages are grouped by length
         // (longest first); out_slot maps the sorted position back to the blob index.
@@ -109,7 +115,13 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
                          [&](uint32_t x, uint32_t y) { return h_len[x] > h_len[y]; });
         std::vector<uint64_t> sorted(static_cast<size_t>(n_blobs) * 2 + (static_cast<size_t>(n_blobs) + 1) / 2);
         uint32_t* h_slot32 = reinterpret_cast<uint32_t*>(sorted.data() + static_cast<size_t>(n_blobs) * 2);
-        for (uint32_t i = 0; i < n_blobs; ++i) {
+        if (defer_above) { // (sorted longest first: the deferred blobs are a prefix)
+            uint32_t skip = 0;
+            while (skip < n_blobs && h_len[order[skip]] > defer_above) ++skip;
+            order.erase(order.begin(), order.begin() + skip);
+            n_chains = n_blobs - skip;
+        }
+        for (uint32_t i = 0; i < n_chains; ++i) {
             sorted[i] = h_off[order[i]];
             sorted[static_cast<size_t>(n_blobs) + i] = h_len[order[i]];
             h_slot32[i] = order[i];
@@ -120,6 +132,7 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
         YA_HIP(ctx, hipMemcpyAsync(d_sorted, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, st));
         YA_HIP(ctx, hipStreamSynchronize(st)); // `sorted` is pageable and dies with this scope
         YA_TRY(ws_get(ctx, ("ing_blob_digests" + lane_tag).c_str(), static_cast<size_t>(n_blobs) * 32, (void**)&d_blob_digests));
+        if (n_chains != n_blobs) YA_HIP(ctx, hipMemsetAsync(d_blob_digests, 0, static_cast<size_t>(n_blobs) * 32, st)); // (in front of the fork below)
         d_sorted_blobs = d_sorted;
     }
     // the side stream's launch: at once, or (`long_after_cdc`) behind boundary detection
@@ -129,9 +142,10 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
         YA_HIP(ctx, hipEventRecord(aux_fork, st));
         YA_HIP(ctx, hipStreamWaitEvent(aux, aux_fork, 0));
         TimedRegion tr(ctx, "sha256_blobs", aux);
-        YA_HIP(ctx, launch_sha256_long(aux, data, d_sorted_blobs, d_sorted_blobs + n_blobs,
-                                       reinterpret_cast<const uint32_t*>(d_sorted_blobs + static_cast<size_t>(n_blobs) * 2),
-                                       n_blobs, d_blob_digests));
+        if (n_chains)
+            YA_HIP(ctx, launch_sha256_long(aux, data, d_sorted_blobs, d_sorted_blobs + n_blobs,
+                                           reinterpret_cast<const uint32_t*>(d_sorted_blobs + static_cast<size_t>(n_blobs) * 2),
+                                           n_chains, d_blob_digests));
         tr.end();
         YA_HIP(ctx, hipEventRecord(aux_join, aux));
         return YAMS_OK;
@@ -204,7 +218,6 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     out->chunk_digest = want_chunk_dg ? d_digests : nullptr;
     out->blob_digest = fork_blobs ? d_blob_digests : nullptr;
     ctx->ingest = *out;
-    (void)total_bytes;
     return YAMS_OK;
 }
 
@@ -292,6 +305,13 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
     // blobs however fast the link.)
     constexpr int kSlots = 4;
     const bool chains = (flags & YAMS_INGEST_BLOB_DIGESTS) != 0;
+    // the deferral threshold is a property of the whole call (the caller computes the same one from the same lengths)
+    uint64_t defer_above = 0;
+    if (chains && (flags & YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS)) {
+        uint64_t total = 0;
+        for (uint64_t b = 0; b < n_blobs; ++b) total += blob_lengths[b];
+        defer_above = yams_ingest_defer_threshold_host(total);
+    }
     const int n_slots = static_cast<int>(std::min<size_t>(chains ? kSlots : 2, batches.size()));
     uint8_t* d_buf[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < n_slots; ++i)
@@ -395,7 +415,7 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
             at += (lens[j] + 15) & ~15ull;
         }
         yams_ingest_result_t r;
-        rc = ingest_impl(ctx, d_buf[slot], offs.data(), lens.data(), bt.count, cfg, flags, true, &r, chains ? &lanes[slot] : nullptr);
+        rc = ingest_impl(ctx, d_buf[slot], offs.data(), lens.data(), bt.count, cfg, flags, true, &r, chains ? &lanes[slot] : nullptr, defer_above);
         if (rc != YAMS_OK) break;
         YAMS_TRACE_T(t1b);
         // Batch bi + 1 starts its journey only NOW, behind this batch's small table uploads: copies of all streams

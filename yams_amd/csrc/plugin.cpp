@@ -293,7 +293,7 @@ struct PluginState {
     std::mutex corpora_mu;
     std::map<uint64_t, std::shared_ptr<Corpus>> corpora;
     uint64_t next_id = 1;
-    std::atomic<uint64_t> searches{0}, hashes{0}, chunk_calls{0}, refused_chains{0};
+    std::atomic<uint64_t> searches{0}, hashes{0}, chunk_calls{0}, refused_chains{0}, deferred_chains{0};
 };
 PluginState g;
 
@@ -942,21 +942,34 @@ yams_status_t ck_chunk_many(void*, const uint8_t* const* buffers, const size_t* 
     *out_batch = nullptr;
     if (!cfg || (n && (!buffers || !lens))) return YAMS_ERR_INVALID_ARG;
     const bool want_blob = (flags & YAMS_CHUNK_MANY_BUFFER_HASHES) != 0;
-    const uint64_t floor = std::max<uint64_t>(1, cfg->min_size);
+    const bool defer = want_blob && (flags & YAMS_CHUNK_MANY_DEFER_LONG_BUFFER_HASHES) != 0;
+    // First guess of the chunk count: one chunk per `floor` bytes, where floor is the smallest chunk the configuration
+    // can emit in the common case — min(min, max), but never below 256 bytes (min_size == 0 is a legal configuration:
+    // a per-byte bound would be ~48 bytes of host vectors per input byte).  Should the guess be too low (min > max, or
+    // a degenerate mask) yams_ingest_host reports the required size and the call runs once more with exactly that.
+    uint64_t floor = std::min<uint64_t>(cfg->min_size ? cfg->min_size : cfg->max_size, cfg->max_size ? cfg->max_size : cfg->min_size);
+    floor = std::max<uint64_t>(floor, 256);
     std::vector<uint64_t> len64(n);
-    uint64_t cap = 0;
-    for (size_t i = 0; i < n; ++i) { len64[i] = lens[i]; cap += lens[i] / floor + 2; }
-    std::vector<uint64_t> first(n + 1, 0), off(cap), sz(cap);
-    std::vector<uint8_t> dig(cap * 32), bdig(want_blob ? n * 32 : 0);
+    uint64_t cap = 0, total = 0;
+    for (size_t i = 0; i < n; ++i) { len64[i] = lens[i]; cap += lens[i] / floor + 2; total += lens[i]; }
+    std::vector<uint64_t> first(n + 1, 0), off, sz;
+    std::vector<uint8_t> dig, bdig(want_blob ? n * 32 : 0);
     uint64_t cnt = 0;
     if (n) {
         Lease<yams_accel_ctx*> w(g.work_ctx);
-        const yams_status_t s = yams_ingest_host(w.v, buffers, len64.data(), n, cfg,
-                                                 YAMS_INGEST_CHUNK_DIGESTS | (want_blob ? YAMS_INGEST_BLOB_DIGESTS : 0u), 0,
-                                                 first.data(), off.data(), sz.data(), dig.data(), cap,
-                                                 want_blob ? bdig.data() : nullptr, &cnt);
-        if (s != YAMS_OK) return s;
+        for (int attempt = 0; ; ++attempt) {
+            off.assign(cap, 0); sz.assign(cap, 0); dig.assign(cap * 32, 0);
+            const yams_status_t s = yams_ingest_host(w.v, buffers, len64.data(), n, cfg,
+                                                     YAMS_INGEST_CHUNK_DIGESTS | (want_blob ? YAMS_INGEST_BLOB_DIGESTS : 0u) |
+                                                         (defer ? YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS : 0u), 0,
+                                                     first.data(), off.data(), sz.data(), dig.data(), cap,
+                                                     want_blob ? bdig.data() : nullptr, &cnt);
+            if (s == YAMS_OK) break;
+            if (s == YAMS_ERR_INVALID_ARG && attempt == 0 && cnt > cap) { cap = cnt; continue; } // "chunk arrays too small": cnt is the required size
+            return s;
+        }
     }
+    const uint64_t defer_above = defer ? yams_ingest_defer_threshold_host(total) : UINT64_MAX;
     auto* b = static_cast<yams_chunk_batch_t*>(std::calloc(1, sizeof(yams_chunk_batch_t)));
     if (!b) return YAMS_ERR_INTERNAL;
     b->n_buffers = n; b->n_chunks = static_cast<size_t>(cnt);
@@ -969,7 +982,11 @@ yams_status_t ck_chunk_many(void*, const uint8_t* const* buffers, const size_t* 
         b->chunks[i].offset = off[i]; b->chunks[i].size = sz[i];
         to_hex(dig.data() + 32 * i, b->chunks[i].hash_hex);
     }
-    if (want_blob) for (size_t i = 0; i < n; ++i) to_hex(bdig.data() + 32 * i, b->buffer_hash_hex + 65 * i);
+    if (want_blob)
+        for (size_t i = 0; i < n; ++i) {
+            if (len64[i] > defer_above) { ++g.deferred_chains; continue; } // (calloc'd: the entry stays empty — the host's hasher fills it)
+            to_hex(bdig.data() + 32 * i, b->buffer_hash_hex + 65 * i);
+        }
     g.chunk_calls += n;
     *out_batch = b;
     return YAMS_OK;
@@ -1118,7 +1135,7 @@ static int plugin_health_impl(char** out_json) {
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
        << ",\"chunk_calls\":" << g.chunk_calls.load()
-       << ",\"refused_lone_chains\":" << g.refused_chains.load();
+       << ",\"refused_lone_chains\":" << g.refused_chains.load() << ",\"deferred_buffer_hashes\":" << g.deferred_chains.load();
     if (g.sharded) { // how the shards exchange their records: "collective":"rccl" | "peer_copy" | "none" (one device)
         char* info = nullptr;
         if (yams_scan_sharded_info_json(g.sharded, &info) == YAMS_OK && info) { os << ",\"sharded\":" << info; std::free(info); }

@@ -286,6 +286,23 @@ yams_status_t scan_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string&
     yams_accel_ctx* c = SL.ctx;
     const size_t nq = L.nq, dim = L.dim;
     yams_status_t st = YAMS_OK;
+    // The fence (see the header comment): called by the scan right before it enqueues a sweep on `sst`.  Installed for
+    // the duration of this batch only — between batches the lane-0 contexts are the caller's (uploads, shadow builds,
+    // direct scans through yams_scan_sharded_ctx).
+    struct Hook {
+        yams_accel_ctx* c;
+        ~Hook() { c->before_sweep = nullptr; }
+    } hook{c};
+    if (s->fenced && L.ordered)
+        c->before_sweep = [s, &L, i](hipStream_t sst) {
+            bool armed;
+            {
+                std::unique_lock<std::mutex> lk(s->mu);
+                if (s->coll_next[i] != L.seq) { ++s->fence_waits; s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; }); }
+                armed = s->fence_armed[i] != 0;
+            }
+            if (armed && hipStreamWaitEvent(sst, s->fence_ev[i], 0) != hipSuccess) (void)hipGetLastError();
+        };
     try {
         // this lane's previous exchange finished long ago (its wait() returned); a stream query, not a stall
         (void)hipStreamSynchronize(SL.side);
@@ -383,19 +400,6 @@ yams_status_t run_shard(yams_scan_sharded* s, Lane& L, uint32_t i, std::string& 
 void worker_main(yams_scan_sharded* s, uint32_t i, uint32_t li) {
     (void)hipSetDevice(s->device[i]);
     Lane& L = *s->lanes[li];
-    if (s->fenced) {
-        // the fence (see the header comment): called by the scan right before it enqueues a sweep on `st`
-        L.sh[i].ctx->before_sweep = [s, &L, i](hipStream_t st) {
-            bool armed;
-            {
-                std::unique_lock<std::mutex> lk(s->mu);
-                if (!L.ordered) return;
-                if (s->coll_next[i] != L.seq) { ++s->fence_waits; s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; }); }
-                armed = s->fence_armed[i] != 0;
-            }
-            if (armed && hipStreamWaitEvent(st, s->fence_ev[i], 0) != hipSuccess) (void)hipGetLastError();
-        };
-    }
     uint64_t seen = 0;
     for (;;) {
         {
