@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-l2-leg", action="store_true", help="skip the BASELINE config 3 (10M x 768 L2) leg")
     ap.add_argument("--oracle-queries", type=int, default=None, help="queries checked against the oracle over the whole resident corpus (default 4 at N=1, 2 at N>1; 0 = skip)")
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
+    ap.add_argument("--verify-all-ingest", action="store_true",
+                    help="check EVERY blob of the ingest leg's timed call on the CPU (boundaries, every chunk digest, blob digest; "
+                         "one in eight also through oracle/_ref) instead of a sample of 64 — minutes of host time")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
     ap.add_argument("--no-shadow", action="store_true", help="bare fp32 corpus view: the single-pass filter converts rows in its loop")
@@ -163,7 +166,7 @@ def ingest_cpu_baseline(seed, blen, n_sample=96):
                               "sample_seconds": dt1}}
 
 
-def ingest_leg(acc, torch, gib, seed):
+def ingest_leg(acc, torch, gib, seed, verify_all=False):
     """SHA-256 + CDC over device-resident Philox blobs (4 MiB each, product-default chunker)."""
     from yams_amd.accel import cdc_config
     blen = 4 << 20
@@ -211,7 +214,7 @@ def ingest_leg(acc, torch, gib, seed):
     acc.enable_timing(False)
     total = n_blobs * blen
     # bit-exactness of the timed call's own output on a spread of blobs (all host cores)
-    verified = verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check=64)
+    verified = verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check=n_blobs if verify_all else 64, ref_every=8 if verify_all else 0)
     cpu = ingest_cpu_baseline(seed, blen)
     n_chunks = int(res.n_chunks)
     # Roofline: the call is bound by 32-bit integer VALU issue, not by HBM.
@@ -323,6 +326,23 @@ def ingest_breadth(acc, torch, seed):
                                      "batches later, so a long stream of 2 GiB batches moves at the link's rate; these 8 GiB are four batches, "
                                      "the last one's chains have nothing left to hide under (round 2, chains joined per batch: 13.7 GB/s)",
                             "chunks": h["n_chunks"], "bit_exact_vs_cpu_sample": {"blobs": len(pick), "ok": ok}}
+    # the steady state of the same stream ("a >= 32 GiB run"): the 8 GiB of pinned blobs four times over
+    # (the device neither knows nor cares that batch i + 4 reads the same host pages as batch i) = 16 batches of 2 GiB
+    try:
+        reps_long = 4
+        ptrs_l = ptrs * reps_long
+        t0 = time.perf_counter()
+        hl = acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch)
+        dtl = time.perf_counter() - t0
+        same = all(np.array_equal(hl["blob_digest"][r * n_blobs:(r + 1) * n_blobs], h["blob_digest"]) for r in range(reps_long)) and \
+            hl["n_chunks"] == reps_long * h["n_chunks"] and np.array_equal(hl["chunk_digest"][:h["n_chunks"]], h["chunk_digest"][:h["n_chunks"]])
+        res["host_streamed_32GiB"] = {"value": len(ptrs_l) * blen / dtl / 1e9, "unit": "GB/s", "bytes": len(ptrs_l) * blen, "ms": dtl * 1e3,
+                                      "blobs": len(ptrs_l), "blob_bytes": blen, "batch_bytes": batch, "batches": len(ptrs_l) * blen // batch,
+                                      "source": "pinned host memory (the 8 GiB above, streamed four times in one call)",
+                                      "equals_the_8GiB_call_repeated": bool(same)}
+        del hl
+    except Exception as e:      # noqa: BLE001
+        res["host_streamed_32GiB"] = {"error": repr(e)}
     # the same bytes as 256 KiB blobs (chains of 4096 blocks: ~8 ms), 512 MiB batches: the link is the bound
     blen2 = 256 << 10
     n2 = n_blobs * blen // blen2
@@ -373,6 +393,39 @@ def ingest_breadth(acc, torch, seed):
                               "without_blob_digests": {"value": tot / dt_chunks / 1e9, "unit": "GB/s", "ms": dt_chunks * 1e3,
                                                        "what": "boundaries + per-chunk digests of the same set"},
                               "bit_exact_vs_cpu_sample": {"blobs": len(pick), "ok": ok}}
+    # (ii a) the same set with YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS: blobs whose whole-blob chain would
+    # outlast the rest of the call (> max(1 MiB, total / 4096)) are left to the host's hasher, which works on its own copy
+    # of the bytes WHILE the device call runs; every digest of the combined result is compared with the all-device run
+    # above (itself CPU-checked on the sample)
+    try:
+        thr = max(1 << 20, tot >> 12)
+        deferred = [i for i, n in enumerate(lens) if n > thr]
+        host_bytes = tb[:tot].cpu().numpy()                       # (the host has these bytes: it uploaded them)
+        threads = _oracle.host_threads(64)
+        acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=7); acc.synchronize()
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            futs = [ex.submit(lambda i=i: hashlib.sha256(memoryview(host_bytes[int(offs[i]):int(offs[i]) + lens[i]])).digest()) for i in deferred]
+            r7 = acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=7)
+            acc.synchronize(); dt_dev = time.perf_counter() - t0
+            host_dg = [f.result() for f in futs]
+        dt_all = time.perf_counter() - t0
+        out7 = acc.fetch_ingest(r7, len(lens))
+        bd7 = out7["blob_digest"].copy()
+        zeros_ok = all(not bd7[i].any() for i in deferred)
+        for i, dg in zip(deferred, host_dg):
+            bd7[i] = np.frombuffer(dg, np.uint8)
+        same = bool(zeros_ok and np.array_equal(bd7, out["blob_digest"]) and np.array_equal(out7["chunk_digest"], out["chunk_digest"]) and
+                    np.array_equal(out7["chunk_offset"], out["chunk_offset"]) and np.array_equal(out7["blob_first"], out["blob_first"]))
+        res["skewed_blob_set"]["with_long_chains_deferred_to_the_host"] = {
+            "value": tot / dt_dev / 1e9, "unit": "GB/s", "what": "device call (boundaries + every chunk digest + the whole-blob digests of "
+            "blobs <= threshold), host hashing of the deferred blobs running beside it", "ms_device_call": dt_dev * 1e3,
+            "threshold_bytes": thr, "deferred_blobs": len(deferred), "deferred_bytes": int(sum(lens[i] for i in deferred)),
+            "host_threads": threads, "host_hasher": "hashlib (OpenSSL)", "ms_until_every_digest_is_there": dt_all * 1e3,
+            "overall_GBps": tot / dt_all / 1e9, "all_digests_equal_the_all_device_run": same}
+        del host_bytes
+    except Exception as e:      # noqa: BLE001
+        res["skewed_blob_set"]["with_long_chains_deferred_to_the_host"] = {"error": repr(e)}
     del tb
     torch.cuda.empty_cache()
 
@@ -430,17 +483,22 @@ def ingest_breadth(acc, torch, seed):
     return res
 
 
-def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check):
-    """Blobs spread over the timed call's result, each regenerated on the CPU (Philox), chunked by
-    the oracle and hashed with hashlib; returns {"blobs": n, "ok": bool}."""
+def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check, ref_every=0):
+    """Blobs spread over the timed call's result (ALL of them when n_check >= n_blobs: --verify-all-ingest), each
+    regenerated on the CPU (Philox), chunked by the oracle and hashed with hashlib; with ref_every = r every r-th blob
+    also goes through the reference's own translation units (oracle/_ref) and must give the same chunk list and
+    per-chunk hashes.  Returns {"blobs": n, "ok": bool, ...}."""
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     _oracle = oracle_mod()
     o = _oracle.oracle()
+    rref = _oracle.ref() if ref_every else None
     out = acc.fetch_ingest(res, n_blobs)
     first, co, cs, cd, bd = out["blob_first"], out["chunk_offset"], out["chunk_size"], out["chunk_digest"], out["blob_digest"]
     pick = sorted(set(int(x) for x in np.linspace(0, n_blobs - 1, min(n_check, n_blobs)).round()))
+    t_begin = time.perf_counter()
+    via_ref = [0]
 
     def verify(bi):
         blob = o.synth_bytes(seed, bi, 0, blen)
@@ -451,11 +509,27 @@ def verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check):
         mv = memoryview(blob)
         if bd[bi].tobytes() != hashlib.sha256(mv).digest():
             return False
-        return all(cd[j].tobytes() == hashlib.sha256(mv[int(co[j]):int(co[j] + cs[j])]).digest() for j in range(lo, hi))
+        if not all(cd[j].tobytes() == hashlib.sha256(mv[int(co[j]):int(co[j] + cs[j])]).digest() for j in range(lo, hi)):
+            return False
+        if rref is not None and bi % ref_every == 0:     # the reference's StreamingChunker + SHA256Hasher, built from its own sources
+            roff, rsz, rhx = rref.chunks(blob, "streaming", with_hashes=True)
+            if not (np.array_equal(co[lo:hi], roff) and np.array_equal(cs[lo:hi], rsz)):
+                return False
+            if any(cd[lo + j].tobytes().hex() != rhx[j] for j in range(hi - lo)):
+                return False
+            via_ref[0] += 1
+        return True
 
-    with ThreadPoolExecutor(max_workers=_oracle.host_threads(64)) as ex:
+    threads = _oracle.host_threads(64)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
         ok = all(ex.map(verify, pick))
-    return {"blobs": len(pick), "ok": bool(ok)}
+    r = {"blobs": len(pick), "ok": bool(ok)}
+    if len(pick) == n_blobs or ref_every:
+        r.update({"of_blobs": n_blobs, "bytes": len(pick) * blen, "every_byte": len(pick) == n_blobs,
+                  "checked": "chunk boundaries, every chunk digest, the whole-blob digest of every blob listed",
+                  "blobs_also_through_the_reference_translation_units": via_ref[0] if rref is not None else None,
+                  "host_threads": threads, "seconds": time.perf_counter() - t_begin})
+    return r
 
 
 def result_digest(rows, scores, counts):
@@ -470,19 +544,19 @@ def result_digest(rows, scores, counts):
 
 
 def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, oracle_queries=0, collective="rccl"):
-    rccl_library = getattr(a, "rccl_library", None)
-    if rccl_library:
-        collective = "rccl"
     """The multi-GPU form a C++ host gets (sharded_api.cpp): ONE process, `devices` driven through yams_scan_sharded_*
     — persistent shard workers, one RCCL communicator (of one rank on a one-GPU box), per batch one ncclAllGather of
-    the packed per-shard records on a side stream + merge_topk_kernel, `lanes` batches in flight so that
-    collective + merge of batch i run under the sweep of batch i + 1.  Queries and results live in HOST memory here
+    the packed per-shard records on a side stream + merge_topk_kernel, `lanes` batches in flight; with more than one
+    shard the exchange of batch i is fenced in front of each shard's sweep of batch i + 1.  Queries and results live in HOST memory here
     (pinned staging + PCIe both ways are inside the timed region).  `views`: per-device corpus views to reuse
     (the default N = 1 run hands over its resident shard); otherwise every shard is generated and its shadows built
     through the C ABI alone — no torch tensor is involved."""
     import numpy as np
     from yams_amd.accel import ShardedScan
     from yams_amd._lib import SCAN_COSINE
+    rccl_library = getattr(a, "rccl_library", None)
+    if rccl_library:
+        collective = "rccl"
     n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
     world = len(devices)
     # three batches in flight: with queries and results crossing the host, two lanes leave the GPU waiting for the
@@ -1321,7 +1395,7 @@ def main():
         acc.ctx = None
         acc = Accel(local, torch.cuda.current_stream().cuda_stream)
         torch.cuda.empty_cache()
-        out["ingest"] = ingest_leg(acc, torch, a.ingest_gib, a.seed)
+        out["ingest"] = ingest_leg(acc, torch, a.ingest_gib, a.seed, verify_all=a.verify_all_ingest)
     print(json.dumps(out))
 
 

@@ -11,6 +11,7 @@
 #include <fstream>
 #include <functional>
 #include <future>
+#include <istream>
 #include <memory>
 #include <span>
 #include <string>
@@ -172,6 +173,84 @@ public:
         vt_->free_chunk_batch(vt_->self, batch);
         return out;
     }
+    // ---- the bounded-memory callback form (StreamingChunker::processStream / processFileStream,
+    //      include/yams/chunking/streaming_chunker.h:54-121) ---------------------------------------------------------
+    // The stream is consumed in windows of `windowBytes` (read in 64 KiB pieces exactly as the reference reads: state
+    // cleared, read(), gcount() until it returns 0 — short reads of segmenting streambufs included).  Each window is
+    // ONE device pass (chunker_v1.chunk_window): boundaries + per-chunk SHA-256; every complete chunk goes to
+    // `processor(ChunkRef, bytes)` in stream order with offsets relative to the stream.  What crosses a window: the
+    // open chunk (the last one of a window ends where the window ends, boundary or not — it is carried and chunked
+    // again with the bytes that follow) and 64 bytes in front of it, from which the device rebuilds the rolling hash
+    // exactly (its state is a function of the last 56 bytes; StreamingChunker never resets it at a chunk boundary).
+    // Host memory: windowBytes + maxChunkSize + 64, whatever the stream's length.  The progress callback is called
+    // with (bytes read so far, totalSize) after every read when totalSize > 0 (streaming_chunker.h:103-106) — reads of a
+    // window come before its chunks here, where the reference interleaves them.  Streaming kind only: RabinChunker has
+    // no such entry point in the reference (and restarts its hash at every chunk).
+    template <class F>
+    Result<void> processStream(std::istream& stream, size_t totalSize, F&& processor, size_t windowBytes = size_t(32) << 20) {
+        if (kind_ != AccelChunkerKind::Streaming)
+            return Error{ErrorCode::InvalidOperation, "processStream is the StreamingChunker's entry point"};
+        if (!(vt_->abi_version >= 3 && vt_->chunk_window))
+            return Error{ErrorCode::NotSupported, "this chunker_v1 build has no chunk_window"};
+        constexpr size_t kRead = 64 * 1024, kHistory = 64;
+        if (windowBytes < kRead) windowBytes = kRead;
+        const yams_cdc_config_t cfg = config();
+        std::vector<std::byte> buf;     // [history: h bytes][the open chunk so far + what was read since]
+        size_t h = 0;                   // leading bytes of buf that are history only
+        size_t base = 0;                // stream offset of buf[h]
+        size_t consumed = 0;
+        bool eof = false;
+        while (!eof) {
+            size_t got = 0;
+            while (got < windowBytes) {
+                const size_t at = buf.size();
+                buf.resize(at + kRead);
+                stream.clear(); // (a previous short read may have set failbit / eofbit: rely on gcount() alone)
+                stream.read(reinterpret_cast<char*>(buf.data() + at), static_cast<std::streamsize>(kRead));
+                const std::streamsize rc = stream.gcount();
+                const size_t n = rc > 0 ? static_cast<size_t>(rc) : 0u;
+                buf.resize(at + n);
+                if (n == 0) { eof = true; break; }
+                got += n; consumed += n;
+                if (progress_ && totalSize > 0) progress_(consumed, totalSize);
+            }
+            if (buf.size() == h) break; // nothing pending
+            yams_chunk_ref_t* refs = nullptr; size_t n = 0;
+            const yams_status_t st = vt_->chunk_window(vt_->self, reinterpret_cast<const uint8_t*>(buf.data()), buf.size(), h, &cfg, &refs, &n);
+            if (st != YAMS_OK) return Error{accel::mapStatus(st), "Failed to chunk a window of the stream on the accelerator"};
+            size_t keepFrom = buf.size();
+            try {
+                const size_t emit = eof ? n : (n ? n - 1 : 0);
+                for (size_t i = 0; i < emit; ++i) {
+                    ChunkRef ref;
+                    ref.hash.assign(refs[i].hash_hex, 64);
+                    ref.offset = base + (static_cast<size_t>(refs[i].offset) - h);
+                    ref.size = static_cast<size_t>(refs[i].size);
+                    processor(static_cast<const ChunkRef&>(ref), std::span<const std::byte>(buf.data() + refs[i].offset, ref.size));
+                }
+                if (!eof && n) { // carry the open chunk and the history in front of it
+                    const size_t open = static_cast<size_t>(refs[n - 1].offset);
+                    keepFrom = open >= kHistory ? open - kHistory : 0; // (open < 64 only while buf still begins at the stream's first byte)
+                    base += open - h;
+                    h = open - keepFrom;
+                }
+            } catch (...) { vt_->free_chunks(vt_->self, refs, n); throw; }
+            vt_->free_chunks(vt_->self, refs, n);
+            if (!eof) buf.erase(buf.begin(), buf.begin() + static_cast<std::ptrdiff_t>(keepFrom));
+        }
+        return Result<void>();
+    }
+    template <class F>
+    Result<void> processFileStream(const std::filesystem::path& path, F&& processor, size_t windowBytes = size_t(32) << 20) {
+        std::ifstream file(path, std::ios::binary);
+        if (!file) return Error{ErrorCode::FileNotFound, "Failed to open file: " + path.string()};
+        file.seekg(0, std::ios::end);
+        const auto pos = file.tellg();
+        const size_t fileSize = pos == std::ios::pos_type(-1) ? 0 : static_cast<size_t>(pos); // (progress reporting only)
+        file.seekg(0, std::ios::beg);
+        return processStream(file, fileSize, std::forward<F>(processor), windowBytes);
+    }
+
     // Files: read, then one chunkMany over all of them (bounded: files are grouped so that at most ~maxBytes are in
     // host memory at once).
     BatchResult chunkFiles(const std::vector<std::filesystem::path>& paths, bool withFileHashes = true,

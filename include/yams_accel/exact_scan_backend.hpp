@@ -117,11 +117,8 @@ public:
     Result<std::vector<std::vector<VectorRecord>>>
     searchSimilarBatch(const std::vector<std::vector<float>>& query_embeddings, size_t k,
                        float similarity_threshold = 0.0f, size_t num_threads = 0) override {
-        if (auto s = syncForSearch(); !s) return s.error();
-        std::shared_lock lk(mu_); // searches share (vector_database.cpp:539,618): the plugin's search lanes serve them side by side
-        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
-        if (mirrorStale_ || table_.needsSync()) { lk.unlock(); return searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads); } // a writer slipped in
-        return table_.searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads);
+        // searches share the lock (vector_database.cpp:539,618): the plugin's search lanes serve them side by side
+        return withSyncedMirror([&] { return table_.searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads); });
     }
     // sqlite_vec_backend.cpp:4650-4661: the diagnostics are reset, the caller's collect flag survives
     Result<std::vector<VectorRecord>>
@@ -246,18 +243,21 @@ public:
         return st;
     }
     // ---- transactions: the durable store's; the mirror holds committed state (see the header comment) ---------
+    // The durable store was changed by someone other than this object (another process, a restore): the mirror is
+    // rebuilt from it before the next search.
+    void invalidateMirror() { std::unique_lock lk(mu_); if (durable_) mirrorStale_ = true; }
     Result<void> beginTransaction() override {
         std::unique_lock lk(mu_);
         if (inTxn_) return Error{ErrorCode::InvalidState, "transaction already open"};
         if (durable_) if (auto s = durable_->beginTransaction(); !s) return s;
-        inTxn_ = true; journal_.clear(); undo_.clear();
+        inTxn_ = true; rewarmedInTxn_ = false; journal_.clear(); undo_.clear();
         return {};
     }
     Result<void> commitTransaction() override {
         std::unique_lock lk(mu_);
         if (!inTxn_) return durable_ ? durable_->commitTransaction() : Result<void>{};
         if (durable_) if (auto s = durable_->commitTransaction(); !s) return s; // (still open: the caller rolls back)
-        inTxn_ = false;
+        inTxn_ = false; rewarmedInTxn_ = false;
         undo_.clear();
         std::vector<Op> ops;
         ops.swap(journal_);
@@ -269,7 +269,8 @@ public:
         std::unique_lock lk(mu_);
         if (!inTxn_) return durable_ ? durable_->rollbackTransaction() : Result<void>{};
         inTxn_ = false;
-        journal_.clear(); // (durable mode: the mirror never saw these)
+        journal_.clear(); // (durable mode: the mirror never saw these — unless it was re-warmed inside the transaction)
+        if (rewarmedInTxn_) { mirrorStale_ = true; rewarmedInTxn_ = false; }
         Result<void> rc{};
         if (durable_) rc = durable_->rollbackTransaction();
         else {
@@ -357,6 +358,10 @@ private:
         table_.clear();
         if (auto s = warmLocked(); !s) return s; // (still stale: the next search tries again)
         mirrorStale_ = false;
+        // Inside an open durable transaction the rows just read include its uncommitted changes (the journal will be
+        // applied over them at commit: inserts replace, deletes are idempotent).  Should the transaction roll back, the
+        // mirror would keep rows getVector() cannot resolve — so a rollback marks it stale again (rollbackTransaction).
+        if (inTxn_) rewarmedInTxn_ = true;
         return {};
     }
     static void resetKeepingCollectFlag(VectorSearchDiagnostics& d) {
@@ -368,17 +373,30 @@ private:
     search(const std::vector<float>& q, size_t k, float thr, const std::optional<std::string>& document_hash,
            const std::unordered_set<std::string>& candidate_hashes, const std::map<std::string, std::string>& metadata_filters,
            VectorSearchDiagnostics* diagnostics, ExactRowSelection selection) {
-        if (auto s = syncForSearch(); !s) return s.error();
-        std::shared_lock lk(mu_); // the scan is the long part: searches share the lock, only the mirror upload excludes
-        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
-        if (mirrorStale_ || table_.needsSync()) { // a writer slipped in between the two locks: synchronise again
-            lk.unlock();
-            return search(q, k, thr, document_hash, candidate_hashes, metadata_filters, diagnostics, selection);
+        return withSyncedMirror([&]() -> Result<std::vector<VectorRecord>> {
+            if (q.empty() || (selection == ExactRowSelection::TopK && k == 0)) return std::vector<VectorRecord>{}; // :4123-4126
+            if (selection == ExactRowSelection::AllMatching)
+                return table_.searchSimilarRows(q, k, thr, candidate_hashes, diagnostics, selection);
+            return table_.searchSimilar(q, k, thr, document_hash, candidate_hashes, metadata_filters, diagnostics);
+        });
+    }
+    // Runs `scan` with the mirror in step with the committed state.  The scan is the long part: searches share the
+    // lock, only the mirror upload excludes.  A writer may slip in between the exclusive synchronisation and the shared
+    // lock; that is retried a bounded number of times, then the search runs UNDER the exclusive lock (no recursion,
+    // no livelock under a steady stream of writers).
+    template <class F>
+    auto withSyncedMirror(F&& scan) -> decltype(scan()) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if (auto s = syncForSearch(); !s) return s.error();
+            std::shared_lock lk(mu_);
+            if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+            if (!mirrorStale_ && !table_.needsSync()) return scan();
         }
-        if (q.empty() || (selection == ExactRowSelection::TopK && k == 0)) return std::vector<VectorRecord>{}; // :4123-4126
-        if (selection == ExactRowSelection::AllMatching)
-            return table_.searchSimilarRows(q, k, thr, candidate_hashes, diagnostics, selection);
-        return table_.searchSimilar(q, k, thr, document_hash, candidate_hashes, metadata_filters, diagnostics);
+        std::unique_lock lk(mu_);
+        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (auto s = rewarmIfStaleLocked(); !s) return s.error();
+        if (auto s = table_.sync(); !s) return s.error();
+        return scan();
     }
     // retainBestRecordPerDocument, sqlite_vec_backend.cpp:86-125
     static std::vector<VectorRecord> bestRecordPerDocument(std::vector<VectorRecord> records, size_t limit) {
@@ -408,7 +426,7 @@ private:
     mutable std::shared_mutex mu_;
     bool initialized_ = false, tables_ = false;
     size_t dim_ = 0;
-    bool inTxn_ = false, mirrorStale_ = false;
+    bool inTxn_ = false, mirrorStale_ = false, rewarmedInTxn_ = false;
     std::vector<Op> journal_;   // durable mode: mutations of the open transaction, applied to the mirror at commit
     std::vector<Undo> undo_;    // in-memory mode: how to put the previous rows back on rollback
 };

@@ -551,6 +551,20 @@ YAMS_ACCEL_API yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint
                                                  char* hex /* [cap][65] */, size_t cap,
                                                  size_t* out_count);
 
+/* One WINDOW of a stream (StreamingChunker::processStream / processFileStream, streaming_chunker.h:54-121: the
+ * bounded-memory callback form).  The first context_len bytes of `data_host` are history only — they feed the
+ * rolling hash (its state is a function of the last 56 bytes: 8 inside the 64-bit shift, 48..55 through the byte
+ * that leaves the ring; >= 64 bytes of true history reproduce it exactly), the first chunk starts at offset
+ * context_len; offsets are relative to data_host.  The LAST chunk returned ends at the end of the buffer whether or
+ * not a boundary falls there: a caller that has more data carries that chunk (and 64 bytes in front of it) into the
+ * next window.  Streaming mode only (RabinChunker restarts its hash at every chunk): YAMS_ERR_INVALID_ARG otherwise.
+ * context_len = 0 is yams_cdc_chunk_host. */
+YAMS_ACCEL_API yams_status_t yams_cdc_chunk_window_host(yams_accel_ctx* ctx, const uint8_t* data_host,
+                                                        size_t n, size_t context_len, const yams_cdc_config_t* cfg,
+                                                        uint64_t* offsets, uint64_t* sizes,
+                                                        char* hex /* [cap][65] */, size_t cap,
+                                                        size_t* out_count);
+
 /* ------------------------------------------------------------------------------------------------
  * Chunk dedup lookup: a device-resident set of SHA-256 digests.
  *
@@ -590,8 +604,8 @@ YAMS_ACCEL_API yams_status_t yams_dedup_probe_host(yams_dedup_set* set, const ui
 #define YAMS_IFACE_CONTENT_HASH_V1 "content_hash_v1"
 #define YAMS_IFACE_CONTENT_HASH_V1_VERSION 1u
 #define YAMS_IFACE_CHUNKER_V1 "chunker_v1"
-#define YAMS_IFACE_CHUNKER_V1_VERSION 2u /* 2: chunk_many / free_chunk_batch appended (hosts that asked for 1 see the
-                                           same leading fields) */
+#define YAMS_IFACE_CHUNKER_V1_VERSION 3u /* 2: chunk_many / free_chunk_batch appended; 3: chunk_window appended (hosts
+                                           that asked for an older version see the same leading fields) */
 
 /* The YAMS plugin entry points (include/yams/plugins/abi.h:18-34 in the reference; the declarations
  * are identical, so this header and the reference's can be included together). */
@@ -749,6 +763,11 @@ typedef struct yams_chunker_v1 {
     yams_status_t (*chunk_many)(void* self, const uint8_t* const* buffers, const size_t* lens, size_t n_buffers,
                                 const yams_cdc_config_t* cfg, uint32_t flags, yams_chunk_batch_t** out_batch);
     void (*free_chunk_batch)(void* self, yams_chunk_batch_t* batch);
+    /* ---- version 3 -----------------------------------------------------------------------------------------
+     * One window of a stream (yams_cdc_chunk_window_host): the first context_len bytes are history, chunks start
+     * behind them; what AccelChunker::processStream calls once per window.  Release with free_chunks. */
+    yams_status_t (*chunk_window)(void* self, const uint8_t* data, size_t n, size_t context_len,
+                                  const yams_cdc_config_t* cfg, yams_chunk_ref_t** out_chunks, size_t* out_count);
 } yams_chunker_v1;
 
 #ifdef __cplusplus

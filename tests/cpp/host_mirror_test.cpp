@@ -122,6 +122,27 @@ int main(int argc, char** argv) {
         std::remove(path.c_str());
     }
 
+    {   // the restated vocabulary behaves as include/yams/core/types.h:147-244 (Error() / error())
+        Error none;
+        CHECK(none.code == ErrorCode::Success && none.message.empty());
+        CHECK(Error(ErrorCode::Timeout).message == "Operation timed out" && Error(std::string("boom")).code == ErrorCode::Unknown);
+        CHECK(Error(ErrorCode::NotFound) == ErrorCode::NotFound && ErrorCode::NotFound != Error(ErrorCode::IOError));
+        Result<int> v(7), e(ErrorCode::InvalidState), d;
+        CHECK(v.has_value() && v.value() == 7 && !e.has_value() && e.error().message == "Invalid state");
+        CHECK(!d.has_value() && d.error().code == ErrorCode::InternalError && d.error().message == "Uninitialized Result");
+        bool threw = false;
+        try { (void)v.error(); } catch (const std::runtime_error& x) { threw = std::string(x.what()) == "Result contains value"; }
+        CHECK(threw);
+        threw = false;
+        try { (void)e.value(); } catch (const std::runtime_error& x) { threw = std::string(x.what()) == "Result contains error"; }
+        CHECK(threw);
+        Result<void> ok, bad(ErrorCode::WriteError);
+        CHECK(ok.has_value() && !bad.has_value() && bad.error().message == "Write error");
+        threw = false;
+        try { (void)ok.error(); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    }
+
     // ---- integrity check + dedup lookup (the callers either side of the hash path) -----------------
     {
         auto* hvt = plugin->getInterface<yams_content_hash_v1>(YAMS_IFACE_CONTENT_HASH_V1, 1).value();

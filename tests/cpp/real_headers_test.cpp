@@ -10,6 +10,9 @@
 #include <yams/chunking/chunker.h>
 #include <yams/chunking/streaming_chunker.h>
 #include <atomic>
+#include <istream>
+#include <streambuf>
+#include <sstream>
 #include <csignal>
 #include <execinfo.h>
 #include <thread>
@@ -277,6 +280,65 @@ int main(int argc, char** argv) {
             }
         }
         CHECK(batcher.value()->chunkMany({}, true).chunks.empty());
+        if (kind) {
+            // StreamingChunker::processStream / processFileStream (streaming_chunker.h:54-121,
+            // tests/unit/chunking/chunking_test.cpp:403,496,540) — the bounded-memory callback form, windowed on the
+            // device.  Same ChunkRefs (hash, offset, size) and the same bytes as the reference's, for streams that
+            // hand out 64 KiB, odd-sized and 7-byte pieces, windows from 64 KiB (dozens of windows, the open chunk
+            // carried across many of them) to larger than the stream, and the default configuration (1 MiB chunks).
+            struct SegBuf : std::streambuf { // at most `seg` bytes per refill (the reference test's SegmentingStringBuf idea)
+                const char* p; size_t n, at = 0, seg; std::vector<char> cur;
+                SegBuf(const std::byte* d, size_t len, size_t s) : p(reinterpret_cast<const char*>(d)), n(len), seg(s) {}
+                int_type underflow() override {
+                    if (at >= n) return traits_type::eof();
+                    const size_t k = std::min(seg, n - at);
+                    cur.assign(p + at, p + at + k); at += k;
+                    setg(cur.data(), cur.data(), cur.data() + k);
+                    return traits_type::to_int_type(cur[0]);
+                }
+            };
+            for (int which = 0; which < 2; ++which) {
+                chunking::ChunkingConfig scfg = cfg;
+                if (which) scfg = chunking::ChunkingConfig{};                     // min 16 KiB / max 1 MiB
+                chunking::StreamingChunker refStream(scfg);
+                auto accStream = chunking::createAccelBatchChunker(plugin, chunking::AccelChunkerKind::Streaming, scfg);
+                CHECK(accStream.has_value());
+                for (size_t len : {size_t(0), size_t(1), size_t(100000), data.size()}) {
+                    std::vector<chunking::ChunkRef> want; size_t wantBytes = 0;
+                    {
+                        SegBuf sb(data.data(), len, len ? len : 1); std::istream is(&sb);
+                        CHECK(refStream.processStream(is, len, [&](const chunking::ChunkRef& r, std::span<const std::byte> b) { want.push_back(r); wantBytes += b.size(); }).has_value());
+                    }
+                    CHECK(wantBytes == len);
+                    for (size_t seg : {size_t(64) << 10, size_t(7), size_t(100003), len ? len : size_t(1)})
+                        for (size_t window : {size_t(64) << 10, size_t(1) << 20, size_t(64) << 20}) {
+                            if (seg == 7 && (len > 200000 || window != (size_t(64) << 10))) continue; // (7-byte reads: short streams only)
+                            SegBuf sb(data.data(), len, seg); std::istream is(&sb);
+                            std::vector<chunking::ChunkRef> got; bool bytesOk = true;
+                            auto rc = accStream.value()->processStream(is, len, [&](const chunking::ChunkRef& r, std::span<const std::byte> b) {
+                                got.push_back(r);
+                                bytesOk = bytesOk && b.size() == r.size && r.offset + r.size <= len && std::equal(b.begin(), b.end(), data.begin() + r.offset);
+                            }, window);
+                            CHECK(rc.has_value() && bytesOk && got.size() == want.size());
+                            for (size_t i = 0; i < got.size() && i < want.size(); ++i) CHECK(got[i] == want[i]);
+                        }
+                }
+                // processFileStream + progress; a missing file is FileNotFound (streaming_chunker.h:54-63)
+                const auto pth = std::filesystem::temp_directory_path() / "yams_accel_stream_test.bin";
+                { std::ofstream f(pth, std::ios::binary); f.write(reinterpret_cast<const char*>(data.data()), static_cast<std::streamsize>(data.size())); }
+                std::vector<chunking::ChunkRef> want, got;
+                CHECK(refStream.processFileStream(pth, [&](const chunking::ChunkRef& r, std::span<const std::byte>) { want.push_back(r); }).has_value());
+                uint64_t lastDone = 0, lastTotal = 0;
+                accStream.value()->setProgressCallback([&](uint64_t d, uint64_t t) { lastDone = d; lastTotal = t; });
+                CHECK(accStream.value()->processFileStream(pth, [&](const chunking::ChunkRef& r, std::span<const std::byte>) { got.push_back(r); }, size_t(256) << 10).has_value());
+                CHECK(got == want && lastDone == data.size() && lastTotal == data.size());
+                CHECK(accStream.value()->processFileStream("/tmp/yams_accel_no_such_stream", [](const chunking::ChunkRef&, std::span<const std::byte>) {}).error().code == ErrorCode::FileNotFound);
+                std::filesystem::remove(pth);
+            }
+            auto rabinOnly = chunking::createAccelBatchChunker(plugin, chunking::AccelChunkerKind::Rabin, cfg);
+            std::istringstream empty;
+            CHECK(rabinOnly.value()->processStream(empty, 0, [](const chunking::ChunkRef&, std::span<const std::byte>) {}).error().code == ErrorCode::InvalidOperation);
+        }
         {   // a batch must not wait for ONE long chain.  With a host hash the 3 MiB buffer (above
             // yams_ingest_defer_threshold_host of this 3.3 MiB batch = 1 MiB) is left to the host — hashed on a host
             // thread while the device call runs — and every buffer hash still equals the reference's.
@@ -483,6 +545,32 @@ int main(int argc, char** argv) {
             const auto found = backend->searchSimilar(target.embedding, 10, -1.0f);
             CHECK(found.has_value());
             for (const auto& r : found.value()) CHECK(r.chunk_id != "chunk_never");
+        }
+        if (durableMode) {
+            // a stale mirror re-warmed INSIDE an open transaction reads the transaction's uncommitted rows;
+            // after the rollback those must not stay searchable (the mirror is marked stale again and rebuilt)
+            auto* concrete = dynamic_cast<vector::AccelExactScanBackend*>(backend.get());
+            CHECK(concrete != nullptr);
+            CHECK(backend->beginTransaction().has_value());
+            const auto ghost = rec("chunk_ghost", "doc_ghost");
+            CHECK(backend->insertVector(ghost).has_value());
+            if (concrete) concrete->invalidateMirror();
+            (void)top(ghost.embedding);                                            // re-warms from the durable rows, ghost included
+            CHECK(backend->rollbackTransaction().has_value());
+            CHECK(!backend->getVector("chunk_ghost").value().has_value());
+            const auto found = backend->searchSimilar(ghost.embedding, 10, -1.0f);
+            CHECK(found.has_value());
+            for (const auto& r : found.value()) CHECK(r.chunk_id != "chunk_ghost" && backend->getVector(r.chunk_id).value().has_value());
+            // ... and when such a transaction COMMITS the journal is applied over the re-warmed rows without duplicates
+            CHECK(backend->beginTransaction().has_value());
+            CHECK(backend->insertVector(ghost).has_value());
+            if (concrete) concrete->invalidateMirror();
+            (void)top(ghost.embedding);
+            CHECK(backend->commitTransaction().has_value());
+            CHECK(top(ghost.embedding) == "chunk_ghost" && backend->getVectorCount().value() == 4);
+            const auto again = backend->searchSimilar(ghost.embedding, 10, -1.0f);
+            CHECK(again.has_value() && again.value().size() == 4);
+            CHECK(backend->deleteVector("chunk_ghost").has_value());
         }
         // searches share the lock: four threads at once, same answers
         {

@@ -66,7 +66,7 @@ def test_plugin_identity_and_manifest(accel_lib):
     # docs/spec/schemas/manifest.schema.json (reference): name, version, abi, interfaces[{id,version}]
     assert m["name"] == "yams_mi355x_accel" and m["abi"] == 1 and isinstance(m["version"], str)
     ids = {(i["id"], i["version"]) for i in m["interfaces"]}
-    assert ids == {("vector_scan_v1", 1), ("content_hash_v1", 1), ("chunker_v1", 2)}
+    assert ids == {("vector_scan_v1", 1), ("content_hash_v1", 1), ("chunker_v1", 3)}
 
 
 def test_get_interface_contract(accel_lib):
@@ -81,7 +81,7 @@ def test_get_interface_contract(accel_lib):
     assert L.yams_plugin_get_interface(b"vector_scan_v1", 0, C.byref(p)) == -2
     for name, typ, ver in [(b"vector_scan_v1", _lib.VectorScanV1, 1),
                            (b"content_hash_v1", _lib.ContentHashV1, 1),
-                           (b"chunker_v1", _lib.ChunkerV1, 2)]:
+                           (b"chunker_v1", _lib.ChunkerV1, 3)]:
         assert L.yams_plugin_get_interface(name, ver, C.byref(p)) == 0
         vt = C.cast(p, C.POINTER(typ)).contents
         assert vt.abi_version == ver  # first field, model_provider_v1.h:50-51 convention
@@ -97,7 +97,8 @@ def test_chunker_v1_serves_every_version_up_to_its_own(accel_lib):
     p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
     assert L.yams_plugin_get_interface(b"chunker_v1", 1, C.byref(p1)) == 0
     assert L.yams_plugin_get_interface(b"chunker_v1", 2, C.byref(p2)) == 0 and p1.value == p2.value
-    assert L.yams_plugin_get_interface(b"chunker_v1", 3, C.byref(p3)) == -2
+    assert L.yams_plugin_get_interface(b"chunker_v1", 3, C.byref(p3)) == 0 and p1.value == p3.value
+    assert L.yams_plugin_get_interface(b"chunker_v1", 4, C.byref(p3)) == -2
 
 
 def test_health_json_is_malloced_json(accel_lib):

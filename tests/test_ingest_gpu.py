@@ -348,6 +348,73 @@ def test_ingest_skewed_blob_set_device_and_host_streamed(acc, oracle, mode):
     assert e["n_chunks"] == 0 and list(e["blob_first"]) == [0]
 
 
+def test_cdc_windowed_stream_equals_one_pass(acc, oracle):
+    """yams_cdc_chunk_window_host — the device half of StreamingChunker::processStream (streaming_chunker.h:54-121):
+    a stream consumed in windows, each window = [64 bytes of history][the open chunk][new bytes], must produce exactly
+    the chunks the oracle finds in ONE pass over the whole stream (the reference never resets the rolling hash at a
+    chunk boundary).  Windows of odd sizes, histories of exactly 56 / 64 / 200 bytes, four configurations; Rabin mode
+    refuses a context."""
+    rng = np.random.default_rng(147)
+    data = rng.integers(0, 256, 3_000_017, dtype=np.uint8)
+    data[1_000_000:1_300_000] = 0                                  # a run without candidates: forced max-size chunks
+    for cfg in [dict(min_size=2048, max_size=65536), dict(), dict(min_size=64, max_size=256, mask=0xF),
+                dict(min_size=1, max_size=5000, mask=0x3FF, window=16)]:
+        want_off, want_sz = oracle.chunks(data, "streaming", **cfg)
+        c = cdc_config("streaming", **cfg)
+        for window, hist in [(262_147, 64), (1 << 20, 56), (65_536, 200)]:
+            got_off, got_sz, got_hx = [], [], []
+            start = 0            # stream offset of the open chunk
+            end = 0              # stream bytes read so far
+            while True:
+                end = min(len(data), end + window)
+                eof = end == len(data)
+                h = min(hist, start)
+                off, sz, hx = acc.chunk(data[start - h:end], c, with_hashes=True, context_len=h)
+                keep = len(off) if eof else len(off) - 1
+                for i in range(keep):
+                    got_off.append(start + int(off[i]) - h); got_sz.append(int(sz[i])); got_hx.append(hx[i])
+                if eof:
+                    break
+                start = start + int(off[-1]) - h
+            assert got_off == [int(x) for x in want_off] and got_sz == [int(x) for x in want_sz], (cfg, window, hist)
+            for i in (0, len(got_off) // 2, len(got_off) - 1):
+                assert got_hx[i] == hashlib.sha256(data[got_off[i]:got_off[i] + got_sz[i]].tobytes()).hexdigest()
+    with pytest.raises(_lib.AccelError) as e:
+        acc.chunk(data[:100000], cdc_config("rabin"), context_len=64)
+    assert e.value.status == _lib.YAMS_ERR_INVALID_ARG
+    with pytest.raises(_lib.AccelError):
+        acc.chunk(data[:100], cdc_config("streaming"), context_len=101)
+
+
+def test_ingest_defers_the_whole_blob_digest_of_long_blobs(acc, oracle):
+    """YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS (VERDICT r3 item 6): blobs above yams_ingest_defer_threshold_{device,host}
+    (a pure function of the call's total bytes) come back with an all-zero whole-blob digest — the caller's host hasher
+    fills them — while their chunk tables and chunk digests, and everything about the other blobs, are unchanged."""
+    import torch
+    rng = np.random.default_rng(148)
+    lens = [20 << 20, 3 << 20, 1 << 20, (1 << 20) + 1, 700_000, 0, 1, 5000, 2 << 20, 900_000]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    total = sum(lens)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    tb = torch.from_numpy(np.concatenate(blobs + [np.zeros(64, np.uint8)])).cuda()
+    cfg = cdc_config("streaming")
+    full = acc.fetch_ingest(acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=3), len(lens))
+    for thr, run in [(max(1 << 20, total >> 12), lambda: acc.fetch_ingest(acc.ingest_device(tb.data_ptr(), offs, lens, cfg, flags=7), len(lens))),
+                     (max(1 << 20, total >> 9), lambda: acc.ingest_host([b.ctypes.data for b in blobs], lens, cfg, flags=7, batch_bytes=8 << 20))]:
+        got = run()
+        assert np.array_equal(got["blob_first"], full["blob_first"]) and np.array_equal(got["chunk_offset"], full["chunk_offset"])
+        assert np.array_equal(got["chunk_size"], full["chunk_size"]) and np.array_equal(got["chunk_digest"], full["chunk_digest"])
+        n_deferred = 0
+        for i, n in enumerate(lens):
+            if n > thr:
+                assert not got["blob_digest"][i].any(), i; n_deferred += 1
+            else:
+                assert got["blob_digest"][i].tobytes() == hashlib.sha256(blobs[i].tobytes()).digest(), i
+        assert n_deferred >= 1
+    # without the flag nothing is deferred
+    assert all(full["blob_digest"][i].tobytes() == hashlib.sha256(blobs[i].tobytes()).digest() for i in range(len(lens)))
+
+
 def test_ingest_reference_benchmark_config_4k_16k_64k(acc, oracle):
     """The reference's own chunking benchmark configuration (tests/benchmarks/core_benchmarks.cpp:
     225-229: RabinChunker, min 4096 / target 16384 / max 65536, 1 MiB inputs): 512 such blobs, every one

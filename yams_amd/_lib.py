@@ -169,6 +169,8 @@ class ChunkerV1(C.Structure):
         ("chunk_many", C.CFUNCTYPE(ST, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(CdcConfig), C.c_uint32,
                                    C.POINTER(C.POINTER(ChunkBatch)))),
         ("free_chunk_batch", C.CFUNCTYPE(None, vp, C.POINTER(ChunkBatch))),
+        ("chunk_window", C.CFUNCTYPE(ST, vp, u8p, C.c_size_t, C.c_size_t, C.POINTER(CdcConfig),
+                                     C.POINTER(C.POINTER(ChunkRef)), C.POINTER(C.c_size_t))),
     ]
 
 
@@ -191,7 +193,7 @@ EXPORTS = [
     "yams_sha256_host", "yams_sha256_many_host", "yams_verify_chunks_device", "yams_cdc_default_config",
     "yams_dedup_set_create", "yams_dedup_set_destroy", "yams_dedup_set_size", "yams_dedup_insert_device",
     "yams_dedup_probe_device", "yams_dedup_insert_host", "yams_dedup_probe_host",
-    "yams_cdc_chunk_device", "yams_ingest_device", "yams_ingest_host", "yams_cdc_chunk_host",
+    "yams_cdc_chunk_device", "yams_ingest_device", "yams_ingest_host", "yams_cdc_chunk_host", "yams_cdc_chunk_window_host",
     "yams_plugin_get_abi_version", "yams_plugin_get_name", "yams_plugin_get_version",
     "yams_plugin_get_manifest_json", "yams_plugin_init", "yams_plugin_shutdown",
     "yams_plugin_get_interface", "yams_plugin_get_health_json",
@@ -310,6 +312,8 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
                                    u64p, u64p, u64p, vp, C.c_uint64, vp, u64p]
     L.yams_cdc_chunk_host.argtypes = [vp, vp, C.c_size_t, C.POINTER(CdcConfig), u64p, u64p,
                                       C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.yams_cdc_chunk_window_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(CdcConfig), u64p, u64p,
+                                             C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.yams_plugin_get_abi_version.restype = C.c_int
     L.yams_plugin_get_name.restype = C.c_char_p
     L.yams_plugin_get_version.restype = C.c_char_p

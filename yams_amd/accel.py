@@ -433,8 +433,9 @@ class Accel:
     def dedup_set(self, expected_entries: int = 0) -> "DedupSet":
         return DedupSet(self, expected_entries)
 
-    def chunk(self, data, cfg: CdcConfig | None = None, with_hashes: bool = True):
-        """IChunker::chunkDataLazy over host memory -> (offsets, sizes, hex hashes | None)."""
+    def chunk(self, data, cfg: CdcConfig | None = None, with_hashes: bool = True, context_len: int = 0):
+        """IChunker::chunkDataLazy over host memory -> (offsets, sizes, hex hashes | None).  context_len > 0: one window
+        of a stream (yams_cdc_chunk_window_host) — the leading bytes are history, chunks start behind them."""
         cfg = cfg or cdc_config()
         a = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else \
             np.ascontiguousarray(data, np.uint8)
@@ -444,10 +445,10 @@ class Accel:
         sz = np.zeros(cap, np.uint64)
         hexbuf = C.create_string_buffer(65 * cap) if with_hashes else None
         cnt = C.c_size_t(0)
-        self._check(self.L.yams_cdc_chunk_host(self.ctx, a.ctypes.data if a.size else None, a.size,
-                                               C.byref(cfg), off.ctypes.data_as(_lib.u64p),
-                                               sz.ctypes.data_as(_lib.u64p), hexbuf, cap,
-                                               C.byref(cnt)))
+        self._check(self.L.yams_cdc_chunk_window_host(self.ctx, a.ctypes.data if a.size else None, a.size, context_len,
+                                                      C.byref(cfg), off.ctypes.data_as(_lib.u64p),
+                                                      sz.ctypes.data_as(_lib.u64p), hexbuf, cap,
+                                                      C.byref(cnt)))
         n = cnt.value
         hashes = None
         if with_hashes:

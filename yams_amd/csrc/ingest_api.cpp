@@ -29,6 +29,7 @@ yams_status_t make_params(yams_accel_ctx* ctx, const yams_cdc_config_t* cfg, Cdc
     cp->max_size = cfg->max_size;
     cp->streaming = cfg->mode == YAMS_CDC_STREAMING;
     cp->generic = (cfg->flags & YAMS_CDC_FLAG_GENERIC_KERNEL) ? 1u : 0u;
+    cp->context = 0;
     uint64_t w = cfg->window_size;
     if (cp->streaming) { // streaming_chunker.cpp:44-49 clamps the ring
         if (w == 0) w = 1; else if (w > 48) w = 48;
@@ -51,7 +52,8 @@ struct IngestLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64_t* blob_off_h,
                           const uint64_t* blob_len_h, uint64_t n_blobs64,
                           const yams_cdc_config_t* cfg, uint32_t flags, bool do_chunks,
-                          yams_ingest_result_t* out, const IngestLane* lane = nullptr, uint64_t defer_above = 0) {
+                          yams_ingest_result_t* out, const IngestLane* lane = nullptr, uint64_t defer_above = 0,
+                          uint64_t context = 0) {
     if (!out) return fail(ctx, YAMS_ERR_INVALID_ARG, "null result");
     std::memset(out, 0, sizeof(*out));
     if (n_blobs64 >= (1ull << 31)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "too many blobs");
@@ -59,6 +61,12 @@ yams_status_t ingest_impl(yams_accel_ctx* ctx, const uint8_t* data, const uint64
     if (n_blobs && (!blob_off_h || !blob_len_h)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null blob table");
     CdcParams cp{};
     if (do_chunks) YA_TRY(make_params(ctx, cfg, &cp));
+    if (context) {
+        // only the StreamingChunker carries its rolling hash across chunk boundaries (streaming_chunker.h:146-204);
+        // RabinChunker starts every chunk afresh (rabin_chunker.cpp:63-110): history in front of a chunk means nothing there
+        if (!do_chunks || !cp.streaming) return fail(ctx, YAMS_ERR_INVALID_ARG, "a context prefix needs the streaming chunker");
+        cp.context = context;
+    }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
 
@@ -542,8 +550,15 @@ yams_status_t yams_sha256_host(yams_accel_ctx* ctx, const uint8_t* data_host, si
 yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint8_t* data_host, size_t n,
                                   const yams_cdc_config_t* cfg, uint64_t* offsets, uint64_t* sizes,
                                   char* hex, size_t cap, size_t* out_count) {
+    return yams_cdc_chunk_window_host(ctx, data_host, n, 0, cfg, offsets, sizes, hex, cap, out_count);
+}
+
+yams_status_t yams_cdc_chunk_window_host(yams_accel_ctx* ctx, const uint8_t* data_host, size_t n, size_t context_len,
+                                         const yams_cdc_config_t* cfg, uint64_t* offsets, uint64_t* sizes,
+                                         char* hex, size_t cap, size_t* out_count) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
     if (!out_count || (n && !data_host)) return fail(ctx, YAMS_ERR_INVALID_ARG, "null buffer");
+    if (context_len > n) return fail(ctx, YAMS_ERR_INVALID_ARG, "context_len exceeds the buffer");
     *out_count = 0;
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -554,7 +569,7 @@ yams_status_t yams_cdc_chunk_host(yams_accel_ctx* ctx, const uint8_t* data_host,
     yams_ingest_result_t r;
     // "Empty input produces no chunks" (tests/unit/chunking/chunking_test.cpp:108-113)
     YA_TRY(ingest_impl(ctx, d_data, &off0, &len0, n ? 1 : 0, cfg, hex ? YAMS_INGEST_CHUNK_DIGESTS : 0,
-                       true, &r));
+                       true, &r, nullptr, 0, context_len));
     *out_count = static_cast<size_t>(r.n_chunks);
     if (r.n_chunks > cap) return fail(ctx, YAMS_ERR_INVALID_ARG, "chunk arrays too small");
     if (r.n_chunks == 0) return YAMS_OK;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64) void cdc_walk_kernel(const uint32_t* bitmap,
     const uint64_t minsz = cp.min_size;
     const uint64_t maxe = cp.max_size > cp.min_size ? cp.max_size : cp.min_size;
     const uint64_t delta = cp.streaming ? 1 : 0;
-    uint64_t s = 0, count = 0;
+    uint64_t s = cp.context < N ? cp.context : N, count = 0; // (a windowed stream: the bytes in front of `context` are history)
     while (s < N) {
         uint64_t lo = s + minsz;
         lo = lo >= delta ? lo - delta : 0;

@@ -14,6 +14,7 @@ struct CdcParams {
     uint32_t window;    // effective ring size (1..48)
     uint32_t streaming; // 1 = StreamingChunker semantics, 0 = RabinChunker
     uint32_t generic;   // 1 = use the any-window candidates kernel even where the narrow one applies
+    uint64_t context;   // leading bytes of every blob that are HISTORY only: they feed the rolling hash, the first chunk starts behind them
 };
 
 hipError_t launch_cdc_candidates(hipStream_t st, const uint8_t* data, const uint64_t* blob_off,

@@ -301,7 +301,7 @@ const char kManifest[] =
     "{\"name\":\"yams_mi355x_accel\",\"version\":\"" YAMS_ACCEL_VERSION_STRING "\",\"abi\":1,"
     "\"description\":\"MI355X (gfx950) exact vector scan, SHA-256 and content-defined chunking\","
     "\"interfaces\":[{\"id\":\"vector_scan_v1\",\"version\":1},"
-    "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":2}]}";
+    "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":3}]}";
 
 // Minimal readers for the init config: {"device": 0} | {"devices": [0,1,...], "search_slots": 2,
 // "shadows": "both" | "bf16" | "i8" | "none"}
@@ -897,8 +897,9 @@ yams_status_t ck_default_config(void*, uint32_t mode, yams_cdc_config_t* out_cfg
     return YAMS_OK;
 }
 // re-entrant: ContentStore shares one chunker across its workers (content_store_impl.cpp:1412)
-yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc_config_t* cfg,
-                            yams_chunk_ref_t** out_chunks, size_t* out_count) {
+// One buffer; the first context_len bytes are history (chunk_window: a window of a stream), 0 for chunk_data.
+yams_status_t ck_chunk_window(void*, const uint8_t* data, size_t n, size_t context_len, const yams_cdc_config_t* cfg,
+                              yams_chunk_ref_t** out_chunks, size_t* out_count) {
     NEED_INIT();
     if (!out_chunks || !out_count || !cfg) return YAMS_ERR_INVALID_ARG;
     *out_chunks = nullptr; *out_count = 0;
@@ -910,7 +911,7 @@ yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc
     yams_status_t s;
     {
         Lease<yams_accel_ctx*> w(g.work_ctx);
-        s = yams_cdc_chunk_host(w.v, data, n, cfg, off.data(), sz.data(), hex.data(), cap, &cnt);
+        s = yams_cdc_chunk_window_host(w.v, data, n, context_len, cfg, off.data(), sz.data(), hex.data(), cap, &cnt);
     }
     if (s != YAMS_OK) return s;
     auto* chunks = static_cast<yams_chunk_ref_t*>(std::calloc(std::max<size_t>(cnt, 1), sizeof(yams_chunk_ref_t)));
@@ -922,6 +923,10 @@ yams_status_t ck_chunk_data(void*, const uint8_t* data, size_t n, const yams_cdc
     ++g.chunk_calls;
     *out_chunks = chunks; *out_count = cnt;
     return YAMS_OK;
+}
+yams_status_t ck_chunk_data(void* self, const uint8_t* data, size_t n, const yams_cdc_config_t* cfg,
+                            yams_chunk_ref_t** out_chunks, size_t* out_count) {
+    return ck_chunk_window(self, data, n, 0, cfg, out_chunks, out_count);
 }
 void ck_free_chunks(void*, yams_chunk_ref_t* chunks, size_t) { std::free(chunks); }
 
@@ -994,7 +999,7 @@ yams_status_t ck_chunk_many(void*, const uint8_t* const* buffers, const size_t* 
 
 yams_chunker_v1 g_chunker = {YAMS_IFACE_CHUNKER_V1_VERSION, nullptr, GUARDED(ck_default_config),
                              GUARDED(ck_chunk_data), GUARDED(ck_free_chunks), GUARDED(ck_chunk_many),
-                             GUARDED(ck_free_chunk_batch)};
+                             GUARDED(ck_free_chunk_batch), GUARDED(ck_chunk_window)};
 
 void teardown_locked() { // g.mu held exclusively
     {
