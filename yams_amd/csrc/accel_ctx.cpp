@@ -1,9 +1,13 @@
 // accel_ctx.cpp — context lifecycle, workspace, timing, memory helpers of the C ABI.
 #include "accel_ctx.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <sstream>
+#include <thread>
 
 namespace yams_accel {
 
@@ -80,6 +84,130 @@ void TimedRegion::end() {
     if (!ctx->timing || !a || !b) return;
     (void)hipEventRecord(b, stream);
     ctx->spans[name].push_back({a, b});
+}
+
+// ---- staged host -> device copies -------------------------------------------------------------------------------
+namespace {
+
+class CopyCrew { // a few persistent threads that memcpy slices of one piece in parallel
+public:
+    explicit CopyCrew(unsigned n) {
+        for (unsigned i = 0; i < n; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~CopyCrew() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    // copies [src, src + bytes) to dst with every thread of the crew plus the caller; returns when all of it is there
+    void copy(unsigned char* dst, const unsigned char* src, size_t bytes) {
+        if (bytes == 0) return;
+        const size_t parts = threads_.size() + 1;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = dst; src_ = src; bytes_ = bytes; next_ = 0;
+            slice_ = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
+            remaining_ = (bytes + slice_ - 1) / slice_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return remaining_ == 0; });
+    }
+private:
+    void work() { // slices of the current piece until none is left
+        for (;;) {
+            size_t off, len;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (next_ >= bytes_) return;
+                off = next_; len = std::min(slice_, bytes_ - off); next_ += slice_;
+            }
+            std::memcpy(dst_ + off, src_ + off, len);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--remaining_ == 0) done_.notify_all();
+        }
+    }
+    void run() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || next_ < bytes_; });
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    unsigned char* dst_ = nullptr; const unsigned char* src_ = nullptr;
+    size_t bytes_ = 0, slice_ = 1, next_ = 0, remaining_ = 0;
+    bool stop_ = false;
+};
+
+struct StageRing {
+    static constexpr int kBufs = 3;
+    static constexpr size_t kPiece = size_t(32) << 20;
+    std::mutex mu;                 // one staged upload at a time (the crew and the ring are shared)
+    unsigned char* buf[kBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t landed[kBufs] = {nullptr, nullptr, nullptr};
+    bool used[kBufs] = {false, false, false};
+    int device = -1;               // the events' device
+    std::unique_ptr<CopyCrew> crew;
+    bool broken = false;
+};
+StageRing& ring() { static StageRing* r = new StageRing(); return *r; } // (leaked on purpose: worker threads at exit)
+
+bool source_is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // plain malloc'd memory: "invalid value"
+    return a.type == hipMemoryTypeHost;
+}
+
+} // namespace
+
+hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes < (size_t(8) << 20) || source_is_pinned(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    StageRing& R = ring();
+    std::unique_lock<std::mutex> lk(R.mu, std::try_to_lock);
+    if (!lk.owns_lock() || R.broken) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream); // busy: the plain path
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!R.crew) {
+        unsigned hw = std::thread::hardware_concurrency();
+        R.crew.reset(new CopyCrew(std::max(1u, std::min(7u, hw > 2 ? hw / 2 - 1 : 1u))));
+    }
+    if (R.device != dev) { // (events belong to a device: re-made when another device uploads)
+        for (int i = 0; i < StageRing::kBufs; ++i) {
+            if (R.landed[i]) { (void)hipEventSynchronize(R.landed[i]); (void)hipEventDestroy(R.landed[i]); R.landed[i] = nullptr; }
+            R.used[i] = false;
+        }
+        for (int i = 0; i < StageRing::kBufs; ++i)
+            if (hipEventCreateWithFlags(&R.landed[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); R.broken = true; }
+        R.device = dev;
+    }
+    for (int i = 0; i < StageRing::kBufs && !R.broken; ++i)
+        if (!R.buf[i] && hipHostMalloc(reinterpret_cast<void**>(&R.buf[i]), StageRing::kPiece, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError(); R.buf[i] = nullptr; R.broken = true;
+        }
+    if (R.broken) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    const unsigned char* sp = static_cast<const unsigned char*>(src);
+    unsigned char* dp = static_cast<unsigned char*>(dst);
+    int b = 0;
+    for (size_t off = 0; off < bytes; off += StageRing::kPiece, b = (b + 1) % StageRing::kBufs) {
+        const size_t len = std::min(StageRing::kPiece, bytes - off);
+        if (R.used[b]) { const hipError_t e = hipEventSynchronize(R.landed[b]); if (e != hipSuccess) return e; }
+        R.crew->copy(R.buf[b], sp + off, len);
+        hipError_t e = hipMemcpyAsync(dp + off, R.buf[b], len, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(R.landed[b], stream);
+        if (e != hipSuccess) return e;
+        R.used[b] = true;
+    }
+    // the ring is reused by the next call: everything it holds must have left before the lock goes
+    for (int i = 0; i < StageRing::kBufs; ++i)
+        if (R.used[i]) { const hipError_t e = hipEventSynchronize(R.landed[i]); R.used[i] = false; if (e != hipSuccess) return e; }
+    return hipSuccess;
 }
 
 } // namespace yams_accel
@@ -227,7 +355,7 @@ yams_status_t yams_accel_upload(yams_accel_ctx* ctx, void* dst_dev, const void* 
     if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return YAMS_ERR_INVALID_ARG;
     if (!bytes) return YAMS_OK;
     (void)hipSetDevice(ctx->device);
-    YA_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    YA_HIP(ctx, staged_h2d(dst_dev, src_host, bytes, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return YAMS_OK;
 }

@@ -147,7 +147,7 @@ struct GrowBuf {
                 while (ci < chunk_end.size() && chunk_end[ci] <= off) ++ci;
                 if (ci < chunk_end.size()) end = std::min(end, chunk_end[ci]);
             }
-            if (hipMemcpyAsync(base + off, sp, end - off, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (yams_accel::staged_h2d(base + off, sp, end - off, stream) != hipSuccess) { (void)hipGetLastError(); return false; } // (pinned ring: link rate from pageable memory)
             sp += end - off; bytes -= end - off; off = end;
         }
         return true;
