@@ -197,6 +197,21 @@ typedef struct yams_scan_corpus_s {
                                              too small for it to balance (default: the library chooses);
                                              with YAMS_SCAN_FLAG_WIDE_TILE: never take it.  Results are
                                              identical, only the kernel form differs              */
+/* L2 only — the arithmetic of vec0's distance.  It lives in the ABSENT third_party/sqlite-vec-cpp, so it cannot be
+ * pinned from the reference checkout; every definition that dependency can plausibly have is served and
+ * the HOST picks the one its build of the library uses (plugin config "l2_accumulate"):
+ *   F64    (default) sum (x_i - q_i)^2 in fp64, sequentially, sqrt, round to fp32 — this repository's own definition;
+ *   F32    fp32 difference, fp32 product, fp32 sequential sum, sqrtf — the public sqlite-vec's scalar loop;
+ *   F32X8  / F32X16  the same with 8 / 16 round-robin partial sums (element i goes to lane i % 8 / 16) added left to
+ *          right at the end — its AVX / AVX-512 forms.
+ * Each is bit-exact against oracle_exact_scan_l2 / oracle_exact_scan_l2_f32acc(lanes = 1 / 8 / 16): the order (distance
+ * asc, chunk_id asc), the cosine re-score and the threshold-after-top-k of sqlite_vec_backend.cpp:4464-4512 are
+ * unchanged.  The filter tiers are the same; the completeness proof widens its margin by the fp32 summation bound. */
+#define YAMS_SCAN_FLAG_L2_ACC_F64 0u
+#define YAMS_SCAN_FLAG_L2_ACC_F32 256u
+#define YAMS_SCAN_FLAG_L2_ACC_F32X8 512u
+#define YAMS_SCAN_FLAG_L2_ACC_F32X16 768u
+#define YAMS_SCAN_FLAG_L2_ACC_MASK 768u
 #define YAMS_SCAN_MAX_K 1024u  /* results per query and call; larger k: rounds behind the allow-mask, as
                                   AccelVectorIndex::searchPeeled does (include/yams_accel/vector_index.hpp) */
 #define YAMS_SCAN_MAX_DIM 8192u /* the fp64 re-score stages a query and its candidate rows in LDS */

@@ -171,3 +171,31 @@ def test_model_on_a_ragged_tail_block_and_a_zero_query():
     with np.errstate(invalid="ignore", divide="ignore"):
         q[2, 0] = f32(1e-20)                       # (the model's prep needs a non-zero maximum; the kernel special-cases 0)
     run_model(x, q)
+
+
+def test_fp32_accumulation_never_undercuts_the_proofs_lower_bound(oracle):
+    """The completeness proof of an L2 search under fp32 accumulation (YAMS_SCAN_FLAG_L2_ACC_F32*, scan_kernels.hip
+    rescore_select_kernel) rests on: the distance such arithmetic GIVES a row is at least
+    sqrt(d2 * (1 - (dim + 8) u 1.01) - 1e-30) * (1 - 1.2e-7), d2 the exact squared distance.  Checked here on the CPU
+    against the oracle's fp32 definitions (1, 8, 16 lanes) over dimensions 3 .. 8192 and magnitudes from subnormal
+    squares to 1e15, with an exact (integer-scaled) reference for d2."""
+    rng = np.random.default_rng(31)
+    u = 2.0 ** -24
+    worst = 0.0
+    for dim in (3, 37, 64, 100, 384, 768, 1024, 4096, 8192):
+        for scale in (1e-21, 1e-6, 1.0, 3.0e4, 1e15):
+            rows = (rng.standard_normal((24, dim)) * scale).astype(np.float32)
+            rows[0] = np.abs(rows[0])                       # all differences of one sign: the worst case for a running sum
+            q = (rng.standard_normal(dim) * scale).astype(np.float32)
+            q[::2] = -np.abs(q[::2]) if dim > 4 else q[::2]
+            d2 = np.sum((rows.astype(np.float64) - q.astype(np.float64)) ** 2, axis=1)   # (fp64 of fp32 inputs: relative error 1e-16 * dim)
+            slack = (dim + 8) * u * 1.01
+            lower = np.sqrt(np.maximum(d2 * (1.0 - slack) - 1e-30, 0.0)) * (1.0 - 1.2e-7)
+            for lanes in (1, 8, 16):
+                got = oracle.l2_f32acc_many(rows, q, lanes).astype(np.float64)
+                ok = (got >= lower) | ~np.isfinite(got)     # (inf: the row is skipped, which is never below the bound)
+                assert ok.all(), (dim, scale, lanes, got[~ok][:3], lower[~ok][:3])
+                fin = np.isfinite(got) & (d2 > 1e-20)     # (below: the absolute 1e-30 term carries the bound, squares are subnormal)
+                if fin.any():
+                    worst = max(worst, float(np.max((np.sqrt(d2[fin]) - got[fin]) / np.sqrt(d2[fin]) / (0.5 * slack))))
+    assert worst < 1.0, worst   # the observed undercut stays inside the allowance (it uses a few per cent of it)

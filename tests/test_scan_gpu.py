@@ -858,6 +858,74 @@ def test_sharded_pipeline_on_one_device_equals_the_single_call(oracle):
     sh.close()
 
 
+@pytest.mark.parametrize("lanes,flag", [(1, _lib.FLAG_L2_ACC_F32), (8, _lib.FLAG_L2_ACC_F32X8), (16, _lib.FLAG_L2_ACC_F32X16)])
+def test_l2_under_fp32_accumulation_matches_that_oracle(acc, oracle, lanes, flag):
+    """vec0's distance arithmetic lives in the absent sqlite-vec-cpp, so the host picks it
+    (YAMS_SCAN_FLAG_L2_ACC_*).  Under fp32 accumulation — sequential, 8 or 16 round-robin lanes — rows, order, distances
+    (bits) and the cosine re-score equal oracle_exact_scan_l2_f32acc(lanes) on every tier: int8 (resident and half-tile
+    forms), bf16, the exhaustive fp64-free pipeline, small corpora (the fused kernel is fp64-only and steps aside),
+    dimensions with tails (100: float4 walk + tail, 37: unaligned scalar walk), hostile rows (fp32 overflow -> inf ->
+    skipped, zero rows, NaN), exact ties broken by chunk_id, the threshold applied after the top-k.  Reference:
+    sqlite_vec_backend.cpp:4464-4512."""
+    rng = np.random.default_rng(200 + lanes)
+    cases = [dict(n=60_000, d=256, nq=140, k=20),                                   # int8 tier
+             dict(n=60_000, d=256, nq=140, k=20, flags=FLAG_RESIDENT_QUERIES),       # ... resident-query form
+             dict(n=30_011, d=256, nq=7, k=25, thr=0.05),                            # narrow bf16 form, threshold after top-k
+             dict(n=20_000, d=100, nq=5, k=10, hostile=True),                        # float4 walk with a tail
+             dict(n=9_000, d=37, nq=3, k=10, hostile=True),                          # unaligned rows: scalar walk, exhaustive keys
+             dict(n=5_000, d=384, nq=3, k=10, use_rank=True),                        # small corpus: the fused kernel steps aside
+             dict(n=40_000, d=768, nq=9, k=100, flags=FLAG_FORCE_EXACT, hostile=True, use_rank=True)]
+    for c in cases:
+        n, d, nq, k = c["n"], c["d"], c["nq"], c["k"]
+        thr, flags = c.get("thr", -1.0), c.get("flags", 0)
+        corpus = oracle.synth_rows(77, 0, n, d) * np.float32(rng.uniform(0.5, 2.0))
+        q = oracle.synth_rows(77, 1 << 40, nq, d)
+        corpus[5] = corpus[n - 2] = corpus[n // 2]                 # exact ties
+        q[0] = corpus[5] + np.float32(1e-3)
+        if c.get("hostile"):
+            corpus[7] = 0.0
+            corpus[9] = np.float32(3e38) / 4                       # (x - q)^2 overflows fp32: distance inf, row skipped
+            corpus[11, 3] = np.nan
+            corpus[13] *= np.float32(1e-22)                        # squares underflow to zero / subnormals
+        rank = rng.permutation(n).astype(np.uint32) if c.get("use_rank") else None
+        r = run(acc, corpus, q, k, thr, SCAN_L2, flags | flag, tie_rank=rank, shadow="both")
+        for qi in (range(nq) if nq <= 9 else (0, 1, nq // 2, nq - 1)):
+            rows, dist, sims = oracle.scan_l2_f32acc(corpus, q[qi], k, thr, rank.astype(np.uint64) if rank is not None else None, lanes=lanes)
+            cnt = int(r.counts[qi])
+            assert cnt == len(rows) and np.array_equal(r.rows[qi, :cnt], rows), (c, lanes, qi, r.rows[qi, :6], rows[:6])
+            assert np.array_equal(r.dist[qi, :cnt].view(np.uint32), dist.view(np.uint32)), (c, lanes, qi)
+            assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), (c, lanes, qi)
+    # the default (no flag) is still the fp64 definition
+    corpus = oracle.synth_rows(78, 0, 20_000, 128); q = oracle.synth_rows(78, 1 << 40, 4, 128)
+    r = run(acc, corpus, q, 10, -1.0, SCAN_L2)
+    for qi in range(4):
+        rows, dist, _ = oracle.scan_l2(corpus, q[qi], 10, -1.0)
+        assert np.array_equal(r.rows[qi], rows) and np.array_equal(r.dist[qi].view(np.uint32), dist.view(np.uint32))
+
+
+def test_plugin_serves_the_l2_arithmetic_its_config_names(accel_lib, oracle):
+    """{"l2_accumulate": "f32x8"}: every vec0 search of the plugin uses that arithmetic (a call may still name its own)."""
+    L = accel_lib
+    vt = _vt(L, b'{"device": 0, "l2_accumulate": "f32x8"}')
+    n, d, k = 50_000, 256, 10
+    corpus = oracle.synth_rows(79, 0, n, d) * np.float32(1.7)
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, d, C.byref(cid)) == 0
+    assert vt.corpus_append(None, cid, corpus.ctypes.data_as(_lib.f32p), n) == 0
+    q = oracle.synth_rows(79, 1 << 40, 130, d)
+    for nq in (2, 130):
+        rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q[:nq]), k, metric=1)
+        for qi in (0, nq - 1):
+            assert rows[qi] == list(oracle.scan_l2_f32acc(corpus, q[qi], k, -1.0, lanes=8)[0]), (nq, qi)
+    rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q[:2]), k, metric=1, flags=_lib.FLAG_L2_ACC_F32)
+    assert rows[0] == list(oracle.scan_l2_f32acc(corpus, q[0], k, -1.0, lanes=1)[0])
+    hp = C.c_void_p()
+    assert L.yams_plugin_get_health_json(C.byref(hp)) == 0 and json.loads(C.string_at(hp))["l2_accumulate"] == "f32x8"
+    C.CDLL(None).free(hp)
+    assert vt.corpus_destroy(None, cid) == 0
+    L.yams_plugin_shutdown()
+
+
 def test_l2_definition_gap_measured_from_the_device_result(acc, oracle, capsys):
     """L2 parity is unpinned (the vec0 arithmetic lives in the absent sqlite-vec-cpp): how much does the fp64-vs-fp32
     accumulation choice matter?  The device returns the top 200 under this repository's definition; the fp32-accumulated

@@ -287,6 +287,7 @@ struct PluginState {
     // the lanes of one device share a sweep gate inside the handle (sharded_api.cpp)
     yams_scan_sharded* sharded = nullptr;
     uint32_t search_slots = 0;
+    uint32_t l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64; // config "l2_accumulate": "f64" | "f32" | "f32x8" | "f32x16"
     Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
     std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
     std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
@@ -581,7 +582,10 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
         }
     }
     // only semantic flags cross the vtable; filter selection stays with the library
-    yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_DEFER_THRESHOLD)};
+    yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_DEFER_THRESHOLD |
+                                                          YAMS_SCAN_FLAG_L2_ACC_MASK)};
+    // vec0's distance arithmetic: the call's own choice, else the plugin's ("l2_accumulate" in the init config)
+    if (metric == YAMS_SCAN_L2 && !(prm.flags & YAMS_SCAN_FLAG_L2_ACC_MASK)) prm.flags |= g.l2_acc;
     const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
     std::vector<float> scores(slots), dist(slots);
     std::vector<int64_t> rows(slots);
@@ -1036,7 +1040,7 @@ const char* yams_plugin_get_manifest_json(void) { return kManifest; }
 // never dereferenced.  config_json: {"device": n} or {"devices": [..]} (a corpus is dealt to all of
 // them in stripes and searched behind one call), "search_slots": concurrent searches (default 2),
 // "shadows": "both" (default) | "bf16" | "i8" | "none", "collective": "auto" | "rccl" | "peer",
-// "rccl_library": "<path>", "fence": "off".
+// "rccl_library": "<path>", "fence": "off", "l2_accumulate": "f64" (default) | "f32" | "f32x8" | "f32x16".
 static int plugin_init_impl(const char* config_json, const void* host_context) {
     (void)host_context;
     std::unique_lock<std::shared_mutex> lk(g.mu);
@@ -1052,6 +1056,15 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
         const char* p = std::strstr(config_json, "\"shadows\"");
         g.want_bf16 = std::strstr(p, "\"both\"") || std::strstr(p, "\"bf16\"");
         g.want_i8 = std::strstr(p, "\"both\"") || std::strstr(p, "\"i8\"");
+    }
+    g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;
+    if (const char* p = config_json ? std::strstr(config_json, "\"l2_accumulate\"") : nullptr) {
+        // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header)
+        const char* c = std::strchr(p + 15, ':');
+        const char* v = c ? std::strchr(c, '"') : nullptr;
+        if (v && std::strncmp(v, "\"f32x16\"", 8) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16;
+        else if (v && std::strncmp(v, "\"f32x8\"", 7) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X8;
+        else if (v && std::strncmp(v, "\"f32\"", 5) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32;
     }
     auto failed = [&](const char* why) {
         g.init_error = why;
@@ -1138,6 +1151,7 @@ static int plugin_health_impl(char** out_json) {
     os << "{\"status\":\"" << (g.initialised ? "ok" : "not_initialised") << "\",\"devices\":[";
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
+       << ",\"l2_accumulate\":\"" << (g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64") << "\""
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
        << ",\"chunk_calls\":" << g.chunk_calls.load()
        << ",\"refused_lone_chains\":" << g.refused_chains.load() << ",\"deferred_buffer_hashes\":" << g.deferred_chains.load();

@@ -129,6 +129,8 @@ constexpr uint64_t kSmallRows = 16384;
 constexpr uint32_t kSmallQueries = 16;
 bool small_scan_applies(const yams_scan_corpus_t& c, uint32_t nq, const yams_scan_params_t& p) {
     if (c.n_rows == 0 || c.n_rows > kSmallRows || nq > kSmallQueries) return false;
+    // the fused kernel scores in fp64 only: L2 under an fp32 accumulation goes through the general pipeline
+    if (p.metric == YAMS_SCAN_L2 && (p.flags & YAMS_SCAN_FLAG_L2_ACC_MASK)) return false;
     // callers that name a filter tier or the exhaustive pipeline get what they name
     if (p.flags & (YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER | YAMS_SCAN_FLAG_WIDE_TILE |
                    YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_RESIDENT_QUERIES)) return false;

@@ -546,6 +546,49 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
 // and emits the best k.  `bound_key` carries the best f32 filter score among everything that was
 // NOT re-scored; the result is proven complete when even bound + E cannot reach the k-th result.
 // -------------------------------------------------------------------------------------------------
+// The arithmetic of vec0's L2 distance.  It lives in the ABSENT third_party/sqlite-vec-cpp (parity
+// unpinned), so every definition that dependency can plausibly have is served and the host picks
+// (YAMS_SCAN_FLAG_L2_ACC_*): ACC = 0 fp64 sequential (this repository's own definition, oracle_exact_scan_l2);
+// ACC = 1 fp32 sequential (the public sqlite-vec's scalar loop); ACC = 8 / 16 fp32 in that many round-robin lanes summed
+// left to right at the end (its AVX / AVX-512 forms) — oracle_l2_distance_f32acc(lanes) bit for bit: separate rounded
+// subtract, multiply and add (no contraction), the root rounded once (sqrt in fp64 of an fp32 value, rounded to fp32,
+// IS the correctly rounded fp32 root: 53 >= 2 * 24 + 2).  `i` must be a compile-time constant after unrolling.
+template <int ACC> struct L2Sum {
+    float p[ACC];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int l = 0; l < ACC; ++l) p[l] = 0.f;
+    }
+    __device__ __forceinline__ void add(float x, float q, int i) {
+        const float d = __fsub_rn(x, q);
+        p[i & (ACC - 1)] = __fadd_rn(p[i & (ACC - 1)], __fmul_rn(d, d));
+    }
+    __device__ __forceinline__ double root() const {
+        float s = p[0];
+        if (ACC > 1) {
+            s = 0.f;
+#pragma unroll
+            for (int l = 0; l < ACC; ++l) s = __fadd_rn(s, p[l]);
+        }
+        return static_cast<double>(static_cast<float>(sqrt(static_cast<double>(s))));
+    }
+};
+template <> struct L2Sum<0> {
+    double s;
+    __device__ __forceinline__ void clear() { s = 0.0; }
+    __device__ __forceinline__ void add(float x, float q, int) { const double d = static_cast<double>(x) - static_cast<double>(q); s = fma(d, d, s); }
+    __device__ __forceinline__ double root() const { return sqrt(s); }
+};
+// elements [i0, dim) of a row, i0 a multiple of 16: groups of 16 with static lane indices (tails and unaligned rows)
+template <int ACC>
+__device__ __forceinline__ void l2_sum_tail(L2Sum<ACC>& l2, const float* x, const float* q, uint32_t i0, uint32_t dim) {
+    for (uint32_t i = i0; i < dim; i += 16) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l)
+            if (i + l < dim) l2.add(x[i + l], q[i + l], l);
+    }
+}
+
 struct RescoreArgs {
     const float* rows;
     uint64_t n_rows;
@@ -568,6 +611,7 @@ struct RescoreArgs {
     float threshold;
     uint32_t flags;
     double err_bound;           // E (cosine) ; for L2 the bound is folded into the filter score
+    double l2_acc_slack;        // L2 with fp32 accumulation: relative error of the summed square an outside row may carry
     float* out_scores; int64_t* out_rows; uint32_t* out_counts; float* out_dist;
     uint32_t* out_ranks;
     uint32_t* out_status;       // [nq]: 0 verified, 1 needs widening
@@ -585,7 +629,7 @@ __device__ __forceinline__ int64_t global_row(const RescoreArgs& a, uint32_t row
 constexpr int RS_MAX = 2048; // max candidates per query per launch
 constexpr int RS_STAGE_STRIDE = 36; // floats per staged row chunk (32 + 4 pad: b128 reads of 16 lanes hit 16 bank groups)
 
-template <int METRIC>
+template <int METRIC, int ACC = 0>
 __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // rs = slots the block sorts = next power of two >= n_cand (384 candidates sort as 512)
@@ -624,7 +668,8 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
         const uint32_t row = live ? (a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck)) : 0u;
         const float* x = a.rows + static_cast<uint64_t>(row) * dim;
         if (live) ++local_rescored;
-        double nsq = 0.0, dot = 0.0, dsq = 0.0;
+        double nsq = 0.0, dot = 0.0;
+        L2Sum<ACC> l2; l2.clear();
         const bool vec4 = (dim & 3u) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
         if (staged) {
             const int lane = threadIdx.x & 63;
@@ -663,7 +708,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                             const double qv = static_cast<double>(sq[ch + 4 * m + e]);
                             nsq = fma(sv, sv, nsq);
                             dot = fma(sv, qv, dot);
-                            if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+                            if (METRIC == YAMS_SCAN_L2) l2.add(vv[e], sq[ch + 4 * m + e], 4 * m + e);
                         }
                     }
                     asm volatile("" ::: "memory");
@@ -691,10 +736,11 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                         const double qv = static_cast<double>(sq[i + 4 * j + e]);
                         nsq = fma(sv, sv, nsq);
                         dot = fma(sv, qv, dot);
-                        if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+                        if (METRIC == YAMS_SCAN_L2) l2.add(vv[e], sq[i + 4 * j + e], 4 * j + e);
                     }
                 }
             }
+            if (METRIC == YAMS_SCAN_L2) l2_sum_tail(l2, x, sq, i, dim); // (i is a multiple of 32 here)
             for (; i < dim; i += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(x + i);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -704,7 +750,6 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                     const double qv = static_cast<double>(sq[i + e]);
                     nsq = fma(sv, sv, nsq);
                     dot = fma(sv, qv, dot);
-                    if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
                 }
             }
         } else {
@@ -713,8 +758,8 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                 const double qv = static_cast<double>(sq[i]);
                 nsq = fma(sv, sv, nsq);
                 dot = fma(sv, qv, dot);
-                if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
             }
+            if (METRIC == YAMS_SCAN_L2) l2_sum_tail(l2, x, sq, 0, dim);
         }
         const uint32_t rank = a.tie_rank ? a.tie_rank[row] : row;
         if (METRIC == YAMS_SCAN_COSINE) {
@@ -730,7 +775,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             sidx[c] = c;
         } else {
             if (!isfinite(nsq)) continue; // non-finite rows cannot be stored (vector_database.cpp:1771-1784)
-            const double dd = sqrt(dsq);
+            const double dd = l2.root();
             if (!isfinite(dd)) continue;
             const float dist = static_cast<float>(dd);
             // computeCosineSimilarity (vector_database.cpp:1786-1810): sqrt each norm, 0 on zero norm
@@ -801,8 +846,12 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
                     // d^2 = |q|^2 - 2 g >= |q|^2 - 2 ob
                     if (nv >= a.k) {
                         double d2 = qn * qn - 2.0 * ob;
+                        // fp32 accumulation: the distance an outside row would be GIVEN may undercut its true one by the
+                        // summation error (nonnegative terms: relative), a possible underflow of tiny squares and the
+                        // rounding of the root
+                        if (ACC != 0) d2 = d2 * (1.0 - a.l2_acc_slack) - 1e-30;
                         if (d2 < 0.0) d2 = 0.0;
-                        const float dmin = static_cast<float>(sqrt(d2) * (1.0 - 1e-12));
+                        const float dmin = static_cast<float>(sqrt(d2) * (ACC != 0 ? 1.0 - 1.2e-7 : 1.0 - 1e-12));
                         const float dist_w = -key_score(skey[a.k - 1]);
                         if (!(dmin > dist_w)) status = 1;
                     } else {
@@ -883,7 +932,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
 // verified).  One thread per (row, query slot); key = (score, row) so a multi-level block top-k
 // can reduce it; the survivors then go through rescore_select_kernel like any candidate list.
 // -------------------------------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, int ACC = 0>
 __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint64_t n_rows,
                                                          uint32_t dim, const float* queries,
                                                          const double* qnorm,
@@ -913,14 +962,16 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
         }
     }
     const float* x = rows + row * dim;
-    double nsq = 0.0, dot = 0.0, dsq = 0.0;
+    double nsq = 0.0, dot = 0.0;
+    L2Sum<ACC> l2; l2.clear();
     for (uint32_t i = 0; i < dim; ++i) {
         const double sv = static_cast<double>(x[i]);
         const double qv = static_cast<double>(sq[i]);
         nsq = fma(sv, sv, nsq);
         dot = fma(sv, qv, dot);
-        if (METRIC == YAMS_SCAN_L2) { const double d = sv - qv; dsq = fma(d, d, dsq); }
+        if (METRIC == YAMS_SCAN_L2 && ACC == 0) l2.add(x[i], sq[i], 0);
     }
+    if (METRIC == YAMS_SCAN_L2 && ACC != 0) l2_sum_tail(l2, x, sq, 0, dim);
     uint64_t key = 0;
     const uint32_t kidx = tie_rank ? tie_rank[row] : static_cast<uint32_t>(row);
     if (METRIC == YAMS_SCAN_COSINE) {
@@ -934,7 +985,7 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
         }
     } else {
         if (isfinite(nsq)) {
-            const double dd = sqrt(dsq);
+            const double dd = l2.root();
             if (isfinite(dd)) key = pack_key(-static_cast<float>(dd), kidx);
         }
     }
@@ -1273,9 +1324,19 @@ hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint
     if (n_items == 0) return hipSuccess;
     const uint32_t gx = static_cast<uint32_t>((n_items + 255) / 256);
     const size_t sh = static_cast<size_t>(dim) * sizeof(float);
+    const uint32_t acc = flags & YAMS_SCAN_FLAG_L2_ACC_MASK; // the host's choice of vec0's distance arithmetic (L2 only)
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_COSINE>), dim3(gx, n_slots), dim3(256), sh,
                            st, rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32)
+        hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2, 1>), dim3(gx, n_slots), dim3(256), sh, st,
+                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32X8)
+        hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2, 8>), dim3(gx, n_slots), dim3(256), sh, st,
+                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32X16)
+        hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2, 16>), dim3(gx, n_slots), dim3(256), sh, st,
+                           rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
     else
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2>), dim3(gx, n_slots), dim3(256), sh, st,
                            rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
@@ -1320,9 +1381,19 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
                       ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
                       (threads / 64) * 64 * RS_STAGE_STRIDE * sizeof(float);
+    const uint32_t acc = R.flags & YAMS_SCAN_FLAG_L2_ACC_MASK;
+    // fp32 summation of dim nonnegative squares, each from a rounded difference and a rounded product: relative error
+    // below (dim + 2) u of the sum for ANY order of the additions (sequential is the worst case); 8 spare u, 1 % slack
+    a.l2_acc_slack = (static_cast<double>(R.dim) + 8.0) * 5.9604644775390625e-8 * 1.01;
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(threads),
                            sh, st, a);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 1>), dim3(R.n_slots), dim3(threads), sh, st, a);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32X8)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 8>), dim3(R.n_slots), dim3(threads), sh, st, a);
+    else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32X16)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 16>), dim3(R.n_slots), dim3(threads), sh, st, a);
     else
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2>), dim3(R.n_slots), dim3(threads), sh,
                            st, a);
