@@ -204,7 +204,7 @@ typedef struct yams_scan_corpus_s {
  *   F32    fp32 difference, fp32 product, fp32 sequential sum, sqrtf — the public sqlite-vec's scalar loop;
  *   F32X8  / F32X16  the same with 8 / 16 round-robin partial sums (element i goes to lane i % 8 / 16) added left to
  *          right at the end — its AVX / AVX-512 forms.
- * Each is bit-exact against oracle_exact_scan_l2 / oracle_exact_scan_l2_f32acc(lanes = 1 / 8 / 16): the order (distance
+ * Each is tested bit for bit against a CPU restatement of that arithmetic (tests/): the order (distance
  * asc, chunk_id asc), the cosine re-score and the threshold-after-top-k of sqlite_vec_backend.cpp:4464-4512 are
  * unchanged.  The filter tiers are the same; the completeness proof widens its margin by the fp32 summation bound. */
 #define YAMS_SCAN_FLAG_L2_ACC_F64 0u

@@ -548,9 +548,9 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
 // -------------------------------------------------------------------------------------------------
 // The arithmetic of vec0's L2 distance.  It lives in the ABSENT third_party/sqlite-vec-cpp (parity
 // unpinned), so every definition that dependency can plausibly have is served and the host picks
-// (YAMS_SCAN_FLAG_L2_ACC_*): ACC = 0 fp64 sequential (this repository's own definition, oracle_exact_scan_l2);
+// (YAMS_SCAN_FLAG_L2_ACC_*): ACC = 0 fp64 sequential (this repository's own definition);
 // ACC = 1 fp32 sequential (the public sqlite-vec's scalar loop); ACC = 8 / 16 fp32 in that many round-robin lanes summed
-// left to right at the end (its AVX / AVX-512 forms) — oracle_l2_distance_f32acc(lanes) bit for bit: separate rounded
+// left to right at the end (its AVX / AVX-512 forms) — the CPU checker's restatement of each, bit for bit: separate rounded
 // subtract, multiply and add (no contraction), the root rounded once (sqrt in fp64 of an fp32 value, rounded to fp32,
 // IS the correctly rounded fp32 root: 53 >= 2 * 24 + 2).  `i` must be a compile-time constant after unrolling.
 template <int ACC> struct L2Sum {
