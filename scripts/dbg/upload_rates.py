@@ -44,6 +44,10 @@ for cfg_name, cfg in (("no_shadows", b'{"device": 0, "shadows": "none"}'), ("bot
                 part = rows[i * step:(i + 1) * step]
                 assert vt.corpus_append(None, cid, part.ctypes.data_as(_lib.f32p), part.shape[0]) == 0
             ts.append(time.perf_counter() - t0)
+            hp = C.c_void_p()
+            assert L.yams_plugin_get_health_json(C.byref(hp)) == 0
+            out.setdefault(f"last_append_{cfg_name}_{pieces}_calls", []).append(json.loads(C.string_at(hp))["last_append"])
+            C.CDLL(None).free(hp)
             assert vt.corpus_destroy(None, cid) == 0
         out[f"append_{cfg_name}_{pieces}_calls_GBps"] = [round(step * pieces * d * 4 / t / 1e9, 2) for t in ts]
     L.yams_plugin_shutdown()

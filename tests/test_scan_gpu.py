@@ -869,7 +869,7 @@ def test_l2_under_fp32_accumulation_matches_that_oracle(acc, oracle, lanes, flag
     sqlite_vec_backend.cpp:4464-4512."""
     rng = np.random.default_rng(200 + lanes)
     cases = [dict(n=60_000, d=256, nq=140, k=20),                                   # int8 tier
-             dict(n=60_000, d=256, nq=140, k=20, flags=FLAG_RESIDENT_QUERIES),       # ... resident-query form
+             dict(n=60_000, d=256, nq=140, k=20, flags=_lib.FLAG_RESIDENT_QUERIES),  # ... resident-query form
              dict(n=30_011, d=256, nq=7, k=25, thr=0.05),                            # narrow bf16 form, threshold after top-k
              dict(n=20_000, d=100, nq=5, k=10, hostile=True),                        # float4 walk with a tail
              dict(n=9_000, d=37, nq=3, k=10, hostile=True),                          # unaligned rows: scalar walk, exhaustive keys

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -287,7 +288,9 @@ struct PluginState {
     // the lanes of one device share a sweep gate inside the handle (sharded_api.cpp)
     yams_scan_sharded* sharded = nullptr;
     uint32_t search_slots = 0;
-    uint32_t l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64; // config "l2_accumulate": "f64" | "f32" | "f32x8" | "f32x16"
+    uint32_t l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;
+    // the last corpus_append (under upload_mu): bytes, ms spent mapping device memory / copying / building shadows
+    uint64_t append_bytes = 0; double append_map_ms = 0, append_copy_ms = 0, append_shadow_ms = 0; // config "l2_accumulate": "f64" | "f32" | "f32x8" | "f32x16"
     Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
     std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
     std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
@@ -401,6 +404,7 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
     const bool bf16 = g.want_bf16 && (c->dim & 3u) == 0;
     const bool i8 = g.want_i8 && (c->dim & 63u) == 0 && c->dim >= 256;
     size_t dev_total = 0, dev_free = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < n_sh; ++i) {
         ShardStore& s = c->sh[i];
         const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
@@ -414,6 +418,7 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) return internal_error("append:2");
         if (i8 && (!s.i8.ensure((now + 63) / 64 * 64 * rb / 4 /* whole 64-row blocks: the shadow is stored blocked */, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
     }
+    const auto t_mapped = std::chrono::steady_clock::now();
     // copy: runs of consecutive global rows inside one stripe are consecutive local rows
     for (uint64_t r = n0; r < n1;) {
         const uint64_t run = std::min<uint64_t>(n1 - r, n_sh == 1 ? n1 - r : kStripeRows - r % kStripeRows);
@@ -423,6 +428,8 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         if (!s.rows.h2d(local_of(r, n_sh) * rb, rows + (r - n0) * c->dim, run * rb, uc->stream)) return internal_error("append:4");
         r += run;
     }
+    for (uint32_t i = 0; i < n_sh; ++i) if (yams_accel_ctx_synchronize(g.upload_ctx[i]) != YAMS_OK) return internal_error("append:4b");
+    const auto t_copied = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < n_sh; ++i) {
         ShardStore& s = c->sh[i];
         const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
@@ -441,6 +448,11 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
     }
     c->n_rows = n1;
     c->has_ranks = false;
+    {   // where the call's time went (health JSON, "last_append"): fresh device memory behind the mirrors, the copy, the shadows
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        g.append_bytes = n_rows * rb; g.append_map_ms = ms(t_begin, t_mapped); g.append_copy_ms = ms(t_mapped, t_copied); g.append_shadow_ms = ms(t_copied, t_end);
+    }
     return YAMS_OK;
 }
 
@@ -1152,6 +1164,8 @@ static int plugin_health_impl(char** out_json) {
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"l2_accumulate\":\"" << (g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64") << "\""
+       << ",\"last_append\":{\"bytes\":" << g.append_bytes << ",\"map_ms\":" << g.append_map_ms << ",\"copy_ms\":" << g.append_copy_ms
+       << ",\"shadow_ms\":" << g.append_shadow_ms << "}"
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
        << ",\"chunk_calls\":" << g.chunk_calls.load()
        << ",\"refused_lone_chains\":" << g.refused_chains.load() << ",\"deferred_buffer_hashes\":" << g.deferred_chains.load();

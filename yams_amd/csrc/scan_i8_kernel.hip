@@ -758,6 +758,15 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             if (!DIRECT && ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
             if (!DIRECT && ABL != 1 && i >= 11 && i < 15) piece(sbase, ss, P ^ 1, (i - 11) & 3);
         });
+        if (ABL == 10) { // measurement build: 20 more MFMAs per slab on the SAME fragments — the multiply-adds per row byte of a
+                         // 208-query tile (13 query blocks against 8); with 640 queries (5 tiles, 30 of 32 CUs per XCD) a launch
+                         // has the matrix work, the row traffic and the CU count of a 1040-query batch in that form
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                acc[i & 3][i >> 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[P][i & 3], fb[1][(i >> 2) & 3], acc[i & 3][i >> 2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
 
     if (DIRECT) {
@@ -1767,12 +1776,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     if (const char* wv = std::getenv("YAMS_ACCEL_I8R_WINDOW")) window = static_cast<uint32_t>(std::atoi(wv));
-    if (rp.use && version >= 61 && version <= 68) {
+    if (rp.use && version >= 61 && version <= 69) {
         if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 64) hipLaunchKernelGGL((scan_tiles_i8r_kernel<4>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 68) hipLaunchKernelGGL((scan_tiles_i8r_kernel<8>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 66) hipLaunchKernelGGL((scan_tiles_i8r_kernel<9>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 69) hipLaunchKernelGGL((scan_tiles_i8r_kernel<10, false, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        else if (version == 65) hipLaunchKernelGGL((scan_tiles_i8r_kernel<7, false, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else hipLaunchKernelGGL((scan_tiles_i8r_kernel<7>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
