@@ -1,7 +1,8 @@
 """Run as a subprocess by test_scan_gpu.py with YAMS_ACCEL_MEASURE_LIB=1: the measurement build's alternative forms of
 the resident-query int8 filter — 70: 128 x 128 wave tiles, one wave per SIMD, row fragments loaded straight into
 registers, block entries in the survivor log; 80: 64 x 128 wave tiles with direct row loads (the product's form at
-dims 384 / 768 with >= 512 queries) — against the LDS-ring form (2; the product's form elsewhere) on the same shard: identical results AND identical candidate sets (count),
+dims 384 / 768 with >= 512 queries); 81: the same with the short strip boundary (zero-start accumulators, thresholds and
+survivors in LDS) — against the LDS-ring form (2; the product's form elsewhere) on the same shard: identical results AND identical candidate sets (count),
 on ragged shards (a last strip of 64 rows, a last unit of one tile), with thresholds and an allow-mask.  Prints one
 JSON line."""
 import json, os, sys
@@ -31,7 +32,7 @@ for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, Fal
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr(),
                            row_mask_ptr=mask.data_ptr() if mask is not None else None, row_mask_count=int(allow.sum()) if mask is not None else 0)
     res = {}
-    for v in ("2", "70", "80"):
+    for v in ("2", "70", "80", "81"):
         os.environ["YAMS_ACCEL_BF16_KERNEL"] = v
         os.environ["YAMS_ACCEL_I8R_DIRECT"] = "0" if v == "2" else "1"   # "2": the LDS-ring form whatever the launcher's rule says
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -51,7 +52,7 @@ for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, Fal
     if os.environ.get("FORMS_DUMP"):
         a2, a7 = res["2"][3]["lcount"], res["70"][3]["lcount"]
         rec["lcount_diff"] = [(i, x, y) for i, (x, y) in enumerate(zip(a2, a7)) if x != y][:12]
-    for v in ("70", "80"):
+    for v in ("70", "80", "81"):
         rec["identical_" + v] = bool(torch.equal(res[v][0], res["2"][0]) and torch.equal(res[v][1], res["2"][1]) and torch.equal(res[v][2], res["2"][2]))
     out.append(rec)
 print(json.dumps(out))

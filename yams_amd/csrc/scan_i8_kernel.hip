@@ -533,8 +533,21 @@ constexpr int R_LDS = R_MAX_SLABS * R_B_SLAB + 8 * R_RING; // 160 KiB: everythin
 // blocked shadow already is the fragment image, and a strip's rows are read by one wave only, so the LDS ring bought
 // nothing but latency cover (1.6 slabs against the one slab a register pair gives) at the price of a DMA write and a
 // fragment read per row byte: half of the kernel's LDS traffic, which ran at the LDS's 128 B/clk.
-template <int ABL = 0, bool L2 = false, bool DIRECT = false>
+// ZS (round 4; cosine, DIRECT only): what a wave does BETWEEN two strips is not hidden by its partner on the SIMD — a
+// wave runs one slab ahead of its loads, so it cannot take over the matrix pipe while the other one is busy elsewhere
+// (measured: the same launch without epilogue 6.8 ms against 7.4, at dim 384 3.5 against 4.8).  So the strip boundary
+// is made short: (1) the accumulators are BORN in the strip's first slab (C operand = the constant 0) instead of being
+// set to -T one register at a time (128 moves), the thresholds enter the sign test; (2) the per-query threshold halves
+// live in the LDS the direct form's ring no longer needs (a 100-clock read instead of eight global loads and a drain
+// of the vector-memory counter); (3) survivors go to a per-wave buffer in that same LDS and reach the log in one
+// flush at the end (or when it fills): no global store at a strip boundary, so every wait of the k loop counts loads only.
+constexpr int R_ZS_THR = R_MAX_SLABS * R_B_SLAB;        // {A_lo, B_hi} of the tile's 128 queries: 1 KiB
+constexpr int R_ZS_LOG = R_ZS_THR + 1024;               // per wave: keys u64[R_ZS_ENTRIES] then queries u32[R_ZS_ENTRIES]
+constexpr int R_ZS_ENTRIES = 640;                       // 7.5 KiB per wave, 60 KiB of the ring's 64
+static_assert(R_ZS_LOG + 8 * R_ZS_ENTRIES * 12 <= R_LDS, "the survivor buffers must fit the LDS the ring has left");
+template <int ABL = 0, bool L2 = false, bool DIRECT = false, bool ZS = false>
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
+    static_assert(!ZS || (DIRECT && !L2 && ABL == 0), "the zero-start form exists for the direct cosine kernel");
     __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
 
     const uint32_t bid = blockIdx.x;
@@ -649,6 +662,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int s = 0; s < nslab; ++s)
             lds_dma16_s(baseB + s * qslab_bytes, voffB, __builtin_amdgcn_readfirstlane(lds0 + s * R_B_SLAB + wid * 1024));
     }
+    if (ZS && tid < R_QUERIES) // the tile's threshold halves, resident (q_thr is padded to q_pad queries)
+        reinterpret_cast<f2_t*>(lds + R_ZS_THR)[tid] = reinterpret_cast<const f2_t*>(a.q_thr)[q0 + static_cast<uint32_t>(tid)];
     // ---- work sharing ----------------------------------------------------------------------------------
     // The two waves of a SIMD do not run at the same speed: the arbiter favours the older one, which then
     // moves at the pace its own DMA latency allows while the younger one gets what is left.  With a fixed
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     }
-    qthr_request();
+    if (!ZS) qthr_request();
     if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m0)));
         eb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m1)));
     }
-    qthr_wait();
+    if (ZS) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else qthr_wait();
     __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
 
     // fragment offsets: row block rb adds rb * 1 KiB inside a ring slab, query block cb adds cb * 1 KiB
@@ -700,12 +715,13 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         if (ABL == 4) { i32x4v z = {off, 0, 0, 0}; return z; } // measurement build: no fragment reads
         return *reinterpret_cast<const i32x4v*>(base + off);
     };
-    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler) __attribute__((always_inline)) {
+    auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler, bool first = false) __attribute__((always_inline)) {
+        const i32x4v zero = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rb = i >> 2, c = i & 3;
             if (ABL != 2 && ABL != 4)
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], (ZS && first) ? zero : acc[rb][cb0 + c], 0, 0, 0);
             else if (i == 0)
                 asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
             __builtin_amdgcn_sched_barrier(0);
@@ -736,18 +752,22 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // fragments are requested under half 1, into the registers the previous slab has just left, and waited for at
     // the beginning of the next slab (`early`: the strip's first slab, whose fragments the drain at the end of the
     // previous strip has covered)
-    auto body = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag, const unsigned char* dnext = nullptr) __attribute__((always_inline)) {
+    auto body_impl = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag, const unsigned char* dnext,
+                         auto first_tag, auto&& extra) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
+        constexpr bool first = decltype(first_tag)::value;
         const unsigned char* bq = lds + s * R_B_SLAB;
         const unsigned char* bqn = lds + sn * R_B_SLAB;
-        if (DIRECT && ABL != 1 && !early)
+        // (ZS: every slab waits — a strip's first fragments were requested in the previous strip's last slab and nothing
+        // younger than them is in flight: no store, and the strip counters are requested a slab earlier)
+        if (DIRECT && ABL != 1 && (ZS || !early))
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[P][0]), "+v"(fa[P][1]), "+v"(fa[P][2]), "+v"(fa[P][3]) :: "memory");
         pin4(fa[P]); pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
         half(fa[P], fb[0], 0, [&](int i) __attribute__((always_inline)) {
             if (DIRECT && ABL != 1 && i < 4) dfetch(fa[P ^ 1][i & 3], static_cast<uint32_t>(offF), dnext + static_cast<uint32_t>(i & 3) * piece_row_stride);
             if (DIRECT ? (i >= 4 && i < 8) : i < 4) fb[1][i & 3] = ld(bq, offF + (4 + (i & 3)) * 1024);
-        });
+        }, first);
         if (!DIRECT && ABL != 1 && !early) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pin4(fb[1]);
@@ -757,7 +777,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             if (DIRECT ? i < 4 : (i >= 4 && i < 8)) fb[0][i & 3] = ld(bqn, offF + (i & 3) * 1024);
             if (!DIRECT && ABL != 1 && i == 10) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // the row fragments have left stage P ^ 1
             if (!DIRECT && ABL != 1 && i >= 11 && i < 15) piece(sbase, ss, P ^ 1, (i - 11) & 3);
-        });
+            extra(i);
+        }, first);
         if (ABL == 10) { // measurement build: 20 more MFMAs per slab on the SAME fragments — the multiply-adds per row byte of a
                          // 208-query tile (13 query blocks against 8); with 640 queries (5 tiles, 30 of 32 CUs per XCD) a launch
                          // has the matrix work, the row traffic and the CU count of a 1040-query batch in that form
@@ -767,6 +788,9 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+    auto body = [&](int sn, bool early, const unsigned char* sbase, int ss, int s, auto par_tag, const unsigned char* dnext = nullptr) __attribute__((always_inline)) {
+        body_impl(sn, early, sbase, ss, s, par_tag, dnext, std::false_type{}, [](int) {});
     };
 
     if (DIRECT) {
@@ -810,24 +834,41 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) nt[cb] = THR ? i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g) : 0;
     };
-    thresholds();
+    if (!ZS) thresholds();
     // Survivors go to ONE log region per wave and launch ((stream, query tile, wave): ~500 entries at the bench
     // shape), filled front to back: no per-strip region, count or memset, and the gather kernel gets 2048 dense
     // regions of one query tile each instead of 1.5 million mostly empty ones.
     const uint32_t log_region = (stream * n_qt + qt) * 8u + static_cast<uint32_t>(wid);
     const uint64_t region = static_cast<uint64_t>(log_region) * a.log_cap;
     uint32_t log_pos = 0;
+    // ZS: the wave's survivor buffer in LDS and its flush into the log region (entries keep their order)
+    uint64_t* const zs_key = reinterpret_cast<uint64_t*>(lds + R_ZS_LOG + wid * (R_ZS_ENTRIES * 12));
+    uint32_t* const zs_q = reinterpret_cast<uint32_t*>(zs_key + R_ZS_ENTRIES);
+    uint32_t zs_n = 0;
+    auto zs_flush = [&]() __attribute__((always_inline)) {
+        for (uint32_t i = static_cast<uint32_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); i < zs_n; i += 64u) {
+            const uint64_t key = zs_key[i];
+            const uint32_t qi = zs_q[i];
+            const uint32_t pos = log_pos + i;
+            if (pos < a.log_cap) { a.log_key[region + pos] = key; a.log_q[region + pos] = qi; }
+            else atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+        }
+        log_pos += zs_n;
+        zs_n = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the k loop's waits count loads only)
+    };
 
     if (unit_of(k_cur) < n_units) for (;;) {
         const uint32_t u = unit_of(k_cur);
         const bool more = unit_of(k_nxt) < n_units;
         locate(k_nxt, nxt); // (past the end of the stream: the spare DMA slots read the shard's last row; nobody consumes them)
-        take_request();             // the strip after the next two; older than every piece of this strip
+        if (!ZS) take_request();    // the strip after the next two; older than every piece of this strip (ZS: in the last slab but one)
         unsigned long long meta_n;  // the next strip's block scale, on its way through the scalar cache
         {
             const float* mp = meta_ptr(nxt.row0);
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(meta_n) : "s"(mp) : "memory");
         }
+        if (!ZS) {
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -836,9 +877,31 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 for (int r = 0; r < 4; ++r)
                     acc[rb][cb][r] = L2 ? nt[cb] - __mul24(static_cast<int>((static_cast<uint32_t>(rbias[rb]) >> (8 * r)) & 255u), qbias[cb])
                                         : nt[cb];
+        }
+        uint32_t sib = 0; // pacing: the siblings' strip counters
         // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
         // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
         int s = 0;
+        if (ZS) {
+            // the strip's first two slabs stand apart: the first one gives birth to the accumulators (C = 0)
+            body_impl(1, false, nullptr, 0, 0, C0{}, cur.base + 1024u, std::true_type{}, [](int) {});
+            body(2, false, nullptr, 0, 1, C1{}, cur.base + 2048u);
+            s = 2;
+            do { // (nslab >= 4, even)
+                const bool last_pair = s + 2 >= nslab;
+                // the strip counters — this pair's next strip, the siblings' progress — are requested in the last slab but
+                // one: the last slab's own wait covers them, and nothing is younger than the next strip's first fragments
+                body_impl(s + 1, false, nullptr, 0, s, C0{}, cur.base + static_cast<uint32_t>(s + 1) * 1024u, std::false_type{},
+                     [&](int i) __attribute__((always_inline)) {
+                         if (i == 12 && last_pair) {
+                             take_request();
+                             if (n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+                         }
+                     });
+                body(last_pair ? 0 : s + 2, false, nullptr, 0, s + 1, C1{}, last_pair ? nxt.base : cur.base + static_cast<uint32_t>(s + 2) * 1024u);
+                s += 2;
+            } while (s < nslab);
+        } else
         do { // (nslab >= 4: a loop the compiler knows to run at least once keeps one register assignment)
             int so = s;
             asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for `early`)
@@ -853,9 +916,16 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #ifdef YAMS_ACCEL_MEASURE
         ++units_read;
 #endif
-        uint32_t sib = 0; // pacing: the siblings' strip counters
-        if (THR && n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
-        if (THR) qthr_request();         // for the NEXT unit's thresholds; in flight under the sign test below
+        if (!ZS && THR && n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+        if (!ZS && THR) qthr_request();  // for the NEXT unit's thresholds; in flight under the sign test below
+        // ZS: this strip's thresholds come from the resident halves (LDS) and the strip's block scale, one query block at
+        // a time (nothing of them stays in registers: the survivor pass derives a block's threshold again)
+        const f2_t* const zs_thr = reinterpret_cast<const f2_t*>(lds + R_ZS_THR) + l15;
+        const float zs_is = 1.0f / sb, zs_g = eb * (1.0f / sb); // (the same expressions as thresholds() and i8_log_gather_kernel)
+        if (ZS) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) qthr[cb] = zs_thr[cb * 16];
+        }
         if (THR && L2) { qbias_request(); rbias_request(nxt.row0); }
 
         // ---- epilogue of the unit: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
@@ -872,15 +942,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-                if (m >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+                if ((ZS ? m + i8_neg_threshold(qthr[cb][0], zs_is, qthr[cb][1], zs_g) : m) >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
             }
             if (strip >= a.n_rows) hot = 0;
             // the next unit's thresholds (needs nothing of this unit's accumulators: eight registers)
             sb = __uint_as_float(static_cast<uint32_t>(meta_n));
             eb = __uint_as_float(static_cast<uint32_t>(meta_n >> 32));
-            qthr_wait();
-            thresholds();
-            k_new = take_result(); // (landed with the drain above, like the siblings' counters)
+            if (!ZS) { qthr_wait(); thresholds(); }
+            k_new = take_result(); // (landed with the drain above — ZS: with the last slab's wait —, like the siblings' counters)
             if (n_qt > 1 && more && pacing) {
                 asm volatile("" : "+v"(sib));
                 uint32_t polls = 0;
@@ -912,12 +981,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
             // bound u and moves the entry into its query's candidate list.
             const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
-            uint32_t base = log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
+            uint32_t base = ZS ? zs_n : log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const bool hot_cb = (hot >> cb) & 1u;
                 if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
                 const uint32_t qi = q0 + cb * 16 + l15;
+                int zs_nt = 0; // ZS: -T of this strip and query block, derived again (the sign test kept none of them)
+                if (ZS) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
                 // this lane's 16 elements of the block that survive (straight-line code) ...
                 uint32_t pm = 0;
 #pragma unroll
@@ -927,7 +998,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        pm |= (acc[rb][cb][r] >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                        pm |= ((ZS ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
                 }
                 if (!hot_cb) pm = 0;
                 // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
@@ -937,15 +1008,20 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     const bool p = pm != 0;
                     const uint64_t m = __builtin_amdgcn_ballot_w64(p);
                     if (m == 0) break;
+                    if (ZS && base + 64u > static_cast<uint32_t>(R_ZS_ENTRIES)) { zs_n = base; zs_flush(); base = 0; } // (a trip adds at most 64)
                     const int e = p ? __builtin_ctz(pm) : 0;
                     int val = acc[0][cb][0];
 #pragma unroll
                     for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
+                    if (ZS) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
                     const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
                     base += static_cast<uint32_t>(__builtin_popcountll(m));
                     if (p && ABL != 8) {
                         const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
-                        if (ABL == 9) { // measurement build: slots, but no stores
+                        if (ZS) {
+                            zs_key[pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
+                            zs_q[pos] = qi;
+                        } else if (ABL == 9) { // measurement build: slots, but no stores
                             if (pos == 0x7fffffffu && val == 1) a.list_count[0] = 1;
                         } else if (pos < a.log_cap) {
                             a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
@@ -958,13 +1034,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 }
                 if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
             }
-            log_pos = base;
+            if (ZS) zs_n = base; else log_pos = base;
             if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
         }
         if (!more) break;
         cur = nxt;
         k_cur = k_nxt; k_nxt = k_fut; k_fut = k_new;
     }
+    if (ZS) zs_flush();
     // (the lane id is derived again: holding it over the launch cost the direct form its 256th register and a scratch slot)
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u && ABL == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
@@ -1789,6 +1866,10 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     }
     if (version == 40) {
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        return hipGetLastError();
+    }
+    if (rp.use && version == 81) { // ... with the short strip boundary (ZS: zero-start accumulators, thresholds and survivors in LDS)
+        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
     if (rp.use && version == 80) { // the resident-query form with direct row loads
