@@ -63,7 +63,7 @@ def test_direct_row_loads_are_not_touched_while_in_flight():
     slab makes them valid.  Nothing the compiler puts in between — a copy at a loop edge, a spill, a reuse — may read or
     write those registers: checked on the assembly in program order (a linear walk; the kernel's loops are the unrolled
     slab pairs, so program order is what matters between a load and its wait)."""
-    kernels = {k: v for k, v in _kernels("scan_i8_kernel.hip").items() if "scan_tiles_i8r_kernel" in k and k.endswith("ELb1EEEvNS_8ScanArgsEjjjj")}
+    kernels = {k: v for k, v in _kernels("scan_i8_kernel.hip").items() if "scan_tiles_i8r_kernel" in k and "ELb1ELi" in k}   # <ABL, L2, DIRECT = true, ZSM>
     assert len(kernels) == 2, list(kernels)      # cosine and L2
 
     def regs(tok):

@@ -545,9 +545,19 @@ constexpr int R_ZS_THR = R_MAX_SLABS * R_B_SLAB;        // {A_lo, B_hi} of the t
 constexpr int R_ZS_LOG = R_ZS_THR + 1024;               // per wave: keys u64[R_ZS_ENTRIES] then queries u32[R_ZS_ENTRIES]
 constexpr int R_ZS_ENTRIES = 640;                       // 7.5 KiB per wave, 60 KiB of the ring's 64
 static_assert(R_ZS_LOG + 8 * R_ZS_ENTRIES * 12 <= R_LDS, "the survivor buffers must fit the LDS the ring has left");
-template <int ABL = 0, bool L2 = false, bool DIRECT = false, bool ZS = false>
+// ZSM: which of these a launch uses (measured one by one) — 1 zero-start accumulators + thresholds from LDS, 4 survivors
+// to the LDS buffer, 8 the siblings' counters are looked at every eighth strip only, 16 no drain at the strip's end (the
+// strip counters are requested in the last slab but one, every slab waits for its own fragments)
+template <int ABL = 0, bool L2 = false, bool DIRECT = false, int ZSM = 0>
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
-    static_assert(!ZS || (DIRECT && !L2 && ABL == 0), "the zero-start form exists for the direct cosine kernel");
+    static_assert(ZSM == 0 || (DIRECT && !L2 && ABL == 0), "the short strip boundary exists for the direct cosine kernel");
+    static_assert(!(ZSM & 16) || ((ZSM & 1) && (ZSM & 4)), "no drain needs the thresholds and the survivors in LDS");
+    constexpr bool Z0 = (ZSM & 1) != 0, ZT = (ZSM & 2) != 0, ZL = (ZSM & 4) != 0, ZN = (ZSM & 16) != 0;
+    static_assert(!(ZT && Z0), "2 = the plain form with its threshold halves in LDS (1 has them there anyway)");
+    // `window`: bits 0-15 the strips a pair may run ahead of its slowest sibling, bits 16-23 log2 of the pacing interval —
+    // the siblings' counters are looked at when (strip number & mask) == 0 only: each look is a system-scope load whose
+    // latency the strip boundary pays (every strip: 7.43 / 4.61 ms at dim 768 / 384; every eighth: 7.35 / 4.18)
+    const uint32_t pace_mask = (1u << ((window >> 16) & 255u)) - 1u;
     __shared__ __attribute__((aligned(16))) unsigned char lds[R_LDS];
 
     const uint32_t bid = blockIdx.x;
@@ -615,7 +625,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // set of query fragments is dead — sixteen registers that are free exactly then
     f2_t qthr[8];
     const float* qthr_p = a.q_thr + 2ull * (q0 + l15); // < q_pad: the table is padded
+    bool zt_ready = false; // ZT: the resident copy exists only behind the prologue's barrier (the first request reads global memory)
     auto qthr_request = [&]() __attribute__((always_inline)) {
+        if (ZT && zt_ready) { // 2: the tile's halves are resident in LDS — a 100-clock read, nothing for the drain to wait for
+            const f2_t* lt = reinterpret_cast<const f2_t*>(lds + R_ZS_THR) + l15;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) qthr[cb] = lt[cb * 16];
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
             asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(qthr[cb]) : "v"(qthr_p), "n"(cb * 128) : "memory");
@@ -662,7 +679,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int s = 0; s < nslab; ++s)
             lds_dma16_s(baseB + s * qslab_bytes, voffB, __builtin_amdgcn_readfirstlane(lds0 + s * R_B_SLAB + wid * 1024));
     }
-    if (ZS && tid < R_QUERIES) // the tile's threshold halves, resident (q_thr is padded to q_pad queries)
+    if ((Z0 || ZT) && tid < R_QUERIES) // the tile's threshold halves, resident (q_thr is padded to q_pad queries)
         reinterpret_cast<f2_t*>(lds + R_ZS_THR)[tid] = reinterpret_cast<const f2_t*>(a.q_thr)[q0 + static_cast<uint32_t>(tid)];
     // ---- work sharing ----------------------------------------------------------------------------------
     // The two waves of a SIMD do not run at the same speed: the arbiter favours the older one, which then
@@ -695,7 +712,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     }
-    if (!ZS) qthr_request();
+    if (!Z0) qthr_request();
     if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
@@ -704,8 +721,10 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m0)));
         eb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m1)));
     }
-    if (ZS) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else qthr_wait();
+    if (Z0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else qthr_wait();
+    if (ZT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stash of the threshold halves)
     __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
+    zt_ready = true;
 
     // fragment offsets: row block rb adds rb * 1 KiB inside a ring slab, query block cb adds cb * 1 KiB
     const int offF = l15 * 64 + ((lq ^ i8_swz(l15)) << 4);
@@ -716,12 +735,13 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         return *reinterpret_cast<const i32x4v*>(base + off);
     };
     auto half = [&](const i32x4v (&A)[4], const i32x4v (&B)[4], int cb0, auto&& filler, bool first = false) __attribute__((always_inline)) {
-        const i32x4v zero = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rb = i >> 2, c = i & 3;
-            if (ABL != 2 && ABL != 4)
-                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], (ZS && first) ? zero : acc[rb][cb0 + c], 0, 0, 0);
+            if (Z0 && first) // the accumulator is BORN here: C = the inline constant 0 (no register holds a zero, no earlier value is alive)
+                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=v"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
+            else if (ABL != 2 && ABL != 4)
+                acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
             else if (i == 0)
                 asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
             __builtin_amdgcn_sched_barrier(0);
@@ -760,7 +780,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const unsigned char* bqn = lds + sn * R_B_SLAB;
         // (ZS: every slab waits — a strip's first fragments were requested in the previous strip's last slab and nothing
         // younger than them is in flight: no store, and the strip counters are requested a slab earlier)
-        if (DIRECT && ABL != 1 && (ZS || !early))
+        if (DIRECT && ABL != 1 && (ZN || !early))
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[P][0]), "+v"(fa[P][1]), "+v"(fa[P][2]), "+v"(fa[P][3]) :: "memory");
         pin4(fa[P]); pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -821,7 +841,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // pacing altogether), no correctness depends on it, no workgroup waits for one that is not resident.
     constexpr uint32_t R_POLLS = 1024;
     bool pacing = true;
-    const uint32_t R_WINDOW = window;
+    const uint32_t R_WINDOW = window & 0xffffu;
     const uint32_t* sync_sib = pair_cnt + (static_cast<uint32_t>(lane) < n_qt ? static_cast<uint32_t>(lane) : qt);
 #ifdef YAMS_ACCEL_MEASURE
     uint32_t units_read = 0;
@@ -834,7 +854,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) nt[cb] = THR ? i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g) : 0;
     };
-    if (!ZS) thresholds();
+    if (!Z0) thresholds();
     // Survivors go to ONE log region per wave and launch ((stream, query tile, wave): ~500 entries at the bench
     // shape), filled front to back: no per-strip region, count or memset, and the gather kernel gets 2048 dense
     // regions of one query tile each instead of 1.5 million mostly empty ones.
@@ -862,13 +882,13 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const uint32_t u = unit_of(k_cur);
         const bool more = unit_of(k_nxt) < n_units;
         locate(k_nxt, nxt); // (past the end of the stream: the spare DMA slots read the shard's last row; nobody consumes them)
-        if (!ZS) take_request();    // the strip after the next two; older than every piece of this strip (ZS: in the last slab but one)
+        if (!ZN) take_request();    // the strip after the next two; older than every piece of this strip (ZS: in the last slab but one)
         unsigned long long meta_n;  // the next strip's block scale, on its way through the scalar cache
         {
             const float* mp = meta_ptr(nxt.row0);
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(meta_n) : "s"(mp) : "memory");
         }
-        if (!ZS) {
+        if (!Z0) {
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -882,20 +902,21 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
         // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
         int s = 0;
-        if (ZS) {
-            // the strip's first two slabs stand apart: the first one gives birth to the accumulators (C = 0)
-            body_impl(1, false, nullptr, 0, 0, C0{}, cur.base + 1024u, std::true_type{}, [](int) {});
+        if (Z0) {
+            // the strip's first two slabs stand apart: the first one gives birth to the accumulators (C = 0).  (Without ZN
+            // the first slab's fragments were covered by the drain at the previous strip's end, as in the plain form.)
+            body_impl(1, true, nullptr, 0, 0, C0{}, cur.base + 1024u, std::true_type{}, [](int) {});
             body(2, false, nullptr, 0, 1, C1{}, cur.base + 2048u);
             s = 2;
             do { // (nslab >= 4, even)
                 const bool last_pair = s + 2 >= nslab;
-                // the strip counters — this pair's next strip, the siblings' progress — are requested in the last slab but
+                // ZN: the strip counters — this pair's next strip, the siblings' progress — are requested in the last slab but
                 // one: the last slab's own wait covers them, and nothing is younger than the next strip's first fragments
                 body_impl(s + 1, false, nullptr, 0, s, C0{}, cur.base + static_cast<uint32_t>(s + 1) * 1024u, std::false_type{},
                      [&](int i) __attribute__((always_inline)) {
-                         if (i == 12 && last_pair) {
+                         if (ZN && i == 12 && last_pair) {
                              take_request();
-                             if (n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+                             if (n_qt > 1 && (k_cur & pace_mask) == 0u) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
                          }
                      });
                 body(last_pair ? 0 : s + 2, false, nullptr, 0, s + 1, C1{}, last_pair ? nxt.base : cur.base + static_cast<uint32_t>(s + 2) * 1024u);
@@ -916,15 +937,15 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #ifdef YAMS_ACCEL_MEASURE
         ++units_read;
 #endif
-        if (!ZS && THR && n_qt > 1) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
-        if (!ZS && THR) qthr_request();  // for the NEXT unit's thresholds; in flight under the sign test below
+        const bool pace_now = (k_cur & pace_mask) == 0u;
+        if (!ZN && THR && n_qt > 1 && pace_now) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+        if (!Z0 && THR) qthr_request();  // for the NEXT unit's thresholds; in flight under the sign test below
         // ZS: this strip's thresholds come from the resident halves (LDS) and the strip's block scale, one query block at
         // a time (nothing of them stays in registers: the survivor pass derives a block's threshold again)
         const f2_t* const zs_thr = reinterpret_cast<const f2_t*>(lds + R_ZS_THR) + l15;
         const float zs_is = 1.0f / sb, zs_g = eb * (1.0f / sb); // (the same expressions as thresholds() and i8_log_gather_kernel)
-        if (ZS) {
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) qthr[cb] = zs_thr[cb * 16];
+        if (Z0) { // (two blocks' halves at a time: sixteen registers for all of them are not free here)
+            qthr[0] = zs_thr[0]; qthr[1] = zs_thr[16];
         }
         if (THR && L2) { qbias_request(); rbias_request(nxt.row0); }
 
@@ -942,15 +963,21 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-                if ((ZS ? m + i8_neg_threshold(qthr[cb][0], zs_is, qthr[cb][1], zs_g) : m) >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+                int zs_t = 0;
+                if (Z0) {
+                    zs_t = i8_neg_threshold(qthr[cb & 1][0], zs_is, qthr[cb & 1][1], zs_g);
+                    if (cb + 2 < 8) qthr[cb & 1] = zs_thr[(cb + 2) * 16];
+                }
+                if (m + zs_t >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
             }
             if (strip >= a.n_rows) hot = 0;
             // the next unit's thresholds (needs nothing of this unit's accumulators: eight registers)
             sb = __uint_as_float(static_cast<uint32_t>(meta_n));
             eb = __uint_as_float(static_cast<uint32_t>(meta_n >> 32));
-            if (!ZS) { qthr_wait(); thresholds(); }
+            if (!Z0) { qthr_wait(); thresholds(); }
+            else if (!ZN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the drain of the plain form: strip counters, the next strip's first fragments
             k_new = take_result(); // (landed with the drain above — ZS: with the last slab's wait —, like the siblings' counters)
-            if (n_qt > 1 && more && pacing) {
+            if (n_qt > 1 && more && pacing && pace_now) {
                 asm volatile("" : "+v"(sib));
                 uint32_t polls = 0;
                 for (; polls < R_POLLS; ++polls) {
@@ -981,14 +1008,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
             // bound u and moves the entry into its query's candidate list.
             const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
-            uint32_t base = ZS ? zs_n : log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
+            uint32_t base = ZL ? zs_n : log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const bool hot_cb = (hot >> cb) & 1u;
                 if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
                 const uint32_t qi = q0 + cb * 16 + l15;
                 int zs_nt = 0; // ZS: -T of this strip and query block, derived again (the sign test kept none of them)
-                if (ZS) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
+                if (Z0) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
                 // this lane's 16 elements of the block that survive (straight-line code) ...
                 uint32_t pm = 0;
 #pragma unroll
@@ -998,7 +1025,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        pm |= ((ZS ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                        pm |= ((Z0 ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
                 }
                 if (!hot_cb) pm = 0;
                 // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
@@ -1008,17 +1035,17 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     const bool p = pm != 0;
                     const uint64_t m = __builtin_amdgcn_ballot_w64(p);
                     if (m == 0) break;
-                    if (ZS && base + 64u > static_cast<uint32_t>(R_ZS_ENTRIES)) { zs_n = base; zs_flush(); base = 0; } // (a trip adds at most 64)
+                    if (ZL && base + 64u > static_cast<uint32_t>(R_ZS_ENTRIES)) { zs_n = base; zs_flush(); base = 0; } // (a trip adds at most 64)
                     const int e = p ? __builtin_ctz(pm) : 0;
                     int val = acc[0][cb][0];
 #pragma unroll
                     for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
-                    if (ZS) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
+                    if (Z0) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
                     const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
                     base += static_cast<uint32_t>(__builtin_popcountll(m));
                     if (p && ABL != 8) {
                         const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
-                        if (ZS) {
+                        if (ZL) {
                             zs_key[pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
                             zs_q[pos] = qi;
                         } else if (ABL == 9) { // measurement build: slots, but no stores
@@ -1034,14 +1061,14 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 }
                 if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
             }
-            if (ZS) zs_n = base; else log_pos = base;
+            if (ZL) zs_n = base; else log_pos = base;
             if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
         }
         if (!more) break;
         cur = nxt;
         k_cur = k_nxt; k_nxt = k_fut; k_fut = k_new;
     }
-    if (ZS) zs_flush();
+    if (ZL) zs_flush();
     // (the lane id is derived again: holding it over the launch cost the direct form its 256th register and a scratch slot)
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u && ABL == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
@@ -1839,6 +1866,10 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
+    // the siblings' counters are looked at every 2^pace_log2-th strip (see the kernel).  Direct form, 12.5M rows, 1024 queries,
+    // every strip / 4th / 8th / 32nd / never: dim 768 7.55 / 7.53 / 7.51 / 7.55 / 7.66 ms and 11.2 / 12.4 / 13.2 / 15.2 / 25.0 GB
+    // from HBM; dim 384 4.79 / 4.32 / 4.26 / 4.27 / 4.26 ms and 4.8 GB throughout (scripts/dbg/pace_sweep.sh)
+    uint32_t pace_log2 = direct ? 2u : 0u;
     uint32_t window = 1; // strips a pair may run ahead of its slowest sibling (see "pacing" in the kernel; measured on the bench launch: window 1 17 GB from HBM and 7.6-7.8 ms, 2 / 3 20 GB and 7.9 ms, unpaced 19+ GB)
 #ifdef YAMS_ACCEL_MEASURE
     if (version >= 41 && version <= 48) {
@@ -1852,7 +1883,9 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 7>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
-    if (const char* wv = std::getenv("YAMS_ACCEL_I8R_WINDOW")) window = static_cast<uint32_t>(std::atoi(wv));
+    if (const char* wv = std::getenv("YAMS_ACCEL_I8R_WINDOW")) window = static_cast<uint32_t>(std::atoi(wv)) & 0xffffu;
+    if (const char* pv = std::getenv("YAMS_ACCEL_I8R_PACE_LOG2")) pace_log2 = static_cast<uint32_t>(std::atoi(pv)) & 31u;
+    window |= pace_log2 << 16; pace_log2 = 0;
     if (rp.use && version >= 61 && version <= 69) {
         if (version == 61) hipLaunchKernelGGL((scan_tiles_i8r_kernel<1>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         else if (version == 62) hipLaunchKernelGGL((scan_tiles_i8r_kernel<2>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
@@ -1868,8 +1901,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
-    if (rp.use && version == 81) { // ... with the short strip boundary (ZS: zero-start accumulators, thresholds and survivors in LDS)
-        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    if (rp.use && version >= 81 && version <= 85) { // ... with parts of the short strip boundary (ZSM bits, see the kernel)
+#define YAMS_ZS_LAUNCH(M) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, M>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window)
+        if (version == 81) YAMS_ZS_LAUNCH(1 | 4 | 16);      // everything
+        else if (version == 82) YAMS_ZS_LAUNCH(1);          // zero-start + LDS thresholds, the plain form's drain and stores
+        else if (version == 84) YAMS_ZS_LAUNCH(2);          // the plain form with its threshold halves resident in LDS
+        else if (version == 85) YAMS_ZS_LAUNCH(2 | 4);      // ... and its survivors in the LDS buffer
+        else YAMS_ZS_LAUNCH(1 | 4);                         // ... + survivors in LDS
+#undef YAMS_ZS_LAUNCH
         return hipGetLastError();
     }
     if (rp.use && version == 80) { // the resident-query form with direct row loads
@@ -1877,19 +1916,22 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     if (rp.use && L.i8_q_form && version != 71 && version != 72) { // 128 x 128 wave tiles, one wave per SIMD
-        hipLaunchKernelGGL((scan_tiles_i8q_kernel<0>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<0>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window & 0xffffu);
         return hipGetLastError();
     }
     if (rp.use && L.i8_q_form && version == 72) { // no MFMAs (ablation)
-        hipLaunchKernelGGL((scan_tiles_i8q_kernel<2>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<2>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window & 0xffffu);
         return hipGetLastError();
     }
     if (rp.use && L.i8_q_form && version == 71) { // the same without row loads after the prologue (ablation)
-        hipLaunchKernelGGL((scan_tiles_i8q_kernel<1>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        hipLaunchKernelGGL((scan_tiles_i8q_kernel<1>), dim3(rp.grid), dim3(Q_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window & 0xffffu);
         return hipGetLastError();
     }
 #endif
-    if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    window |= pace_log2 << 16;
+    // the direct form ships with its threshold halves and its survivors in LDS (ZSM 2 | 4: 7.47 -> 7.28 ms at dim 768,
+    // 4.26 -> 4.04 at 384, same candidates; profiles/r04_filter_forms.json)
+    if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 6>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
