@@ -332,12 +332,15 @@ def ingest_breadth(acc, torch, seed):
         reps_long = 4
         ptrs_l = ptrs * reps_long
         t0 = time.perf_counter()
-        hl = acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch)
+        batch_l = 0     # the library's own choice for this call (8 GiB here: 4 MiB blobs, 32 GiB)
+        acc.ingest_host(ptrs_l[:4096], [blen] * 4096, cfg, flags=3, batch_bytes=8 << 30)       # warm-up: buffers of that size
+        hl = acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch_l)
         dtl = time.perf_counter() - t0
         same = all(np.array_equal(hl["blob_digest"][r * n_blobs:(r + 1) * n_blobs], h["blob_digest"]) for r in range(reps_long)) and \
             hl["n_chunks"] == reps_long * h["n_chunks"] and np.array_equal(hl["chunk_digest"][:h["n_chunks"]], h["chunk_digest"][:h["n_chunks"]])
         res["host_streamed_32GiB"] = {"value": len(ptrs_l) * blen / dtl / 1e9, "unit": "GB/s", "bytes": len(ptrs_l) * blen, "ms": dtl * 1e3,
-                                      "blobs": len(ptrs_l), "blob_bytes": blen, "batch_bytes": batch, "batches": len(ptrs_l) * blen // batch,
+                                      "blobs": len(ptrs_l), "blob_bytes": blen, "batch_bytes": "library default (about 2048 of the longest blob, 1-8 GiB, >= 4 batches per call): 8 GiB here",
+                                      "by_batch_size_GBps": "1 / 2 / 4 / 8 GiB batches: 17.5 / 32 / 41 / 46 (scripts/dbg/host_stream_batches.py, round 4)",
                                       "source": "pinned host memory (the 8 GiB above, streamed four times in one call)",
                                       "equals_the_8GiB_call_repeated": bool(same)}
         del hl
@@ -909,6 +912,11 @@ def main():
         gate = SweepGate(local)         # the lanes' filter sweeps run one after the other, the rest overlaps
         for c in accs:
             c.set_gate(gate)
+            # N > 1: the collective behind a batch must not be enqueued under another lane's sweep (a persistent grid that
+            # owns every CU: the all-gather kernel would wait for a CU and keep its peers spinning) — the gate stays closed
+            # behind a lane's sweep until that lane has enqueued its collective + merge ("the fence")
+            if pipe.active:
+                c.set_sweep_hold(True)
     turn = [0]
     turn_cv = threading.Condition()
     batch_no = [0]
@@ -918,15 +926,23 @@ def main():
         pipe.wait(slot)                 # the merge of batch i - lanes has long finished: its record is free
         loc = pipe.local(slot)
         # (the call returns after its own host sync on the query status words: results are complete)
-        diag = accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
-                                           loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
-                                           want_diag=want_diag)
-        with turn_cv:
-            while turn[0] != i:
-                turn_cv.wait()
-            pipe.launch(slot)           # collective + merge on the side stream, under the next sweeps
-            turn[0] += 1
-            turn_cv.notify_all()
+        try:
+            diag = accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, loc["scores"].data_ptr(),
+                                               loc["rows"].data_ptr(), loc["counts"].data_ptr(), flags=scan_flags,
+                                               want_diag=want_diag)
+            with turn_cv:
+                if turn[0] != i and gate is not None and pipe.active:
+                    # not this batch's turn yet (two lanes starting together may reach the gate in either order): a lane
+                    # that holds the gate never waits for another lane — it gives the gate up first
+                    accs[lane].release_sweep_hold(None)
+                while turn[0] != i:
+                    turn_cv.wait()
+                pipe.launch(slot)       # collective + merge on the side stream, in front of the next sweep (N > 1)
+                turn[0] += 1
+                turn_cv.notify_all()
+        finally:
+            if gate is not None and pipe.active:
+                accs[lane].release_sweep_hold(pipe.side_stream_ptr())   # the next sweep starts behind collective + merge
         return diag, slot
 
     def run_steps(count):

@@ -91,6 +91,16 @@ typedef struct yams_accel_gate yams_accel_gate;
 YAMS_ACCEL_API yams_status_t yams_accel_gate_create(int device, yams_accel_gate** out_gate);
 YAMS_ACCEL_API void yams_accel_gate_destroy(yams_accel_gate* gate);
 YAMS_ACCEL_API yams_status_t yams_accel_ctx_set_gate(yams_accel_ctx* ctx, yams_accel_gate* gate);
+/* Sweep hold — for callers that put a COLLECTIVE behind every batch themselves (one process per GPU:
+ * yams_scan_topk_device, then an RCCL all-gather of the record on a side stream, then the merge).  The filter sweep is
+ * a persistent grid that owns every CU of the device; a collective kernel enqueued while another context's sweep runs
+ * would wait for a CU under it and keep its peers on the other GPUs spinning meanwhile.  With the hold on, the gate
+ * stays CLOSED behind this context's sweeps: no other context of the gate starts a sweep until this one calls
+ * yams_accel_ctx_release_sweep_hold(ctx, stream) — after it has enqueued its collective (+ merge) on `stream`; the next
+ * sweep then starts behind that work.  (yams_scan_sharded_* does the same for its own lanes: YAMS_SHARDED_FENCE_AUTO.)
+ * Release on every path, also after a failed scan; releasing without a hold is a no-op. */
+YAMS_ACCEL_API yams_status_t yams_accel_ctx_set_sweep_hold(yams_accel_ctx* ctx, int on);
+YAMS_ACCEL_API yams_status_t yams_accel_ctx_release_sweep_hold(yams_accel_ctx* ctx, void* hip_stream);
 /* Human-readable description of the last failure on this context (static storage, never NULL). */
 YAMS_ACCEL_API const char* yams_accel_last_error(const yams_accel_ctx* ctx);
 /* Device properties as a JSON string (malloc'd; release with yams_accel_free_string). */
@@ -541,8 +551,9 @@ YAMS_ACCEL_API yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8
                                                 uint32_t flags, yams_ingest_result_t* out);
 
 /* The same path for blobs in HOST memory (what ContentStore::store has after reading a file,
- * content_store_impl.cpp:199-231): blobs cross PCIe in batches of ~batch_bytes (0 = 1 GiB; a blob is
- * never split) through two device buffers, batch i + 1 uploading while batch i is chunked and hashed.
+ * content_store_impl.cpp:199-231): blobs cross PCIe in batches of ~batch_bytes (0 = chosen from the call: about
+ * 2048 of its longest blob, 1 to 8 GiB, at least four batches — the digest chains of a batch take (longest blob) /
+ * 35 MB/s and three batches' chains are in flight; a blob is never split) through two device buffers, batch i + 1 uploading while batch i is chunked and hashed.
  * Pinned (page-locked) blob memory uploads at link speed, pageable memory through the runtime's
  * staging.  Results go to caller arrays: out_blob_first[n_blobs + 1] (prefix of chunk counts),
  * out_chunk_offset / out_chunk_size [chunk_cap], out_chunk_digest [chunk_cap][32] (nullable),

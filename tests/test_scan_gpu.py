@@ -1612,3 +1612,46 @@ def test_randomised_self_consistency_of_all_scan_paths():
     res = json.loads(line[-1])
     assert res["cases"] == 150 and res["mismatches"] == 0, res
     assert any("widened1" in p for p in res["paths"]) and any(p.startswith("path1") for p in res["paths"]), res
+
+
+def test_sweep_hold_keeps_the_gate_closed_until_the_collective_is_enqueued(oracle):
+    """yams_accel_ctx_set_sweep_hold (the one-process-per-GPU form of the exchange fence): with the hold on, the
+    gate stays closed behind a context's sweep — a second context's scan blocks at its own sweep until the first calls
+    release_sweep_hold (after enqueuing its collective) — and nothing deadlocks: releasing without a hold is a no-op, a
+    destroyed context gives the gate back, results stay oracle-exact."""
+    import threading, time
+    from yams_amd.accel import Accel, SweepGate
+    n, d, nq, k = 60_000, 256, 140, 10
+    corpus = oracle.synth_rows(91, 0, n, d); q = oracle.synth_rows(91, 1 << 40, nq, d)
+    a, b = Accel(0), Accel(0)
+    gate = SweepGate(0)
+    a.set_gate(gate); b.set_gate(gate)
+    dc = a.to_device(corpus)
+    d8, dm8 = a.alloc(_lib.i8_shadow_rows(n) * d), a.alloc((n + 15) // 16 * 8)
+    a.build_shadow_i8_device(dc.ptr, n, d, d8.ptr, dm8.ptr); a.synchronize()
+    view = a.corpus_view(dc.ptr, n, d, rows_i8_ptr=d8.ptr, rows_i8_meta_ptr=dm8.ptr)
+    a.release_sweep_hold()                       # no hold: a no-op
+    a.set_sweep_hold(True)
+    ra = a.scan_topk(view, q, k, -1.0)           # sweeps, then keeps the gate closed
+    assert ra.diag["filter_tier"] == _lib.TIER_I8
+    done = {}
+    t = threading.Thread(target=lambda: done.setdefault("r", b.scan_topk(view, q, k, -1.0)))
+    t.start()
+    time.sleep(0.3)
+    assert "r" not in done                       # b waits at the gate
+    a.release_sweep_hold()                       # (the collective would have been enqueued on a side stream here)
+    t.join(timeout=30)
+    assert "r" in done
+    for r in (ra, done["r"]):
+        for qi in (0, 70, 139):
+            rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, -1.0)
+            assert np.array_equal(r.rows[qi], rows) and np.array_equal(r.scores[qi].view(np.uint32), sims.view(np.uint32))
+    # a context destroyed while holding gives the gate back
+    a.scan_topk(view, q, k, -1.0)
+    t = threading.Thread(target=lambda: done.setdefault("r2", b.scan_topk(view, q, k, -1.0)))
+    t.start(); time.sleep(0.2)
+    assert "r2" not in done
+    a.set_sweep_hold(False)                      # turning the hold off releases it
+    t.join(timeout=30)
+    assert "r2" in done
+    a.close(); b.close(); gate.close()

@@ -178,7 +178,7 @@ class ChunkerV1(C.Structure):
 # Every symbol include/yams_mi355x_accel.h declares + the abi.h plugin entry points.
 EXPORTS = [
     "yams_accel_device_count", "yams_accel_ctx_create", "yams_accel_ctx_destroy",
-    "yams_accel_ctx_synchronize", "yams_accel_gate_create", "yams_accel_gate_destroy", "yams_accel_ctx_set_gate",
+    "yams_accel_ctx_synchronize", "yams_accel_gate_create", "yams_accel_gate_destroy", "yams_accel_ctx_set_gate", "yams_accel_ctx_set_sweep_hold", "yams_accel_ctx_release_sweep_hold",
     "yams_accel_last_error", "yams_accel_device_info_json",
     "yams_accel_free_string", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
@@ -240,6 +240,8 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_accel_gate_destroy.argtypes = [vp]
     L.yams_accel_gate_destroy.restype = None
     L.yams_accel_ctx_set_gate.argtypes = [vp, vp]
+    L.yams_accel_ctx_set_sweep_hold.argtypes = [vp, C.c_int]
+    L.yams_accel_ctx_release_sweep_hold.argtypes = [vp, vp]
     L.yams_accel_last_error.argtypes = [vp]
     L.yams_accel_last_error.restype = C.c_char_p
     L.yams_accel_device_info_json.argtypes = [vp, C.POINTER(vp)]

@@ -290,6 +290,13 @@ class Accel:
         if st != 0:
             raise AccelError(st, self.L.yams_accel_last_error(self.ctx).decode())
 
+    def set_sweep_hold(self, on: bool):
+        """Keep the sweep gate closed behind this context's sweeps until release_sweep_hold (yams_accel_ctx_set_sweep_hold)."""
+        self._check(self.L.yams_accel_ctx_set_sweep_hold(self.ctx, 1 if on else 0))
+
+    def release_sweep_hold(self, stream_ptr: int | None = None):
+        self._check(self.L.yams_accel_ctx_release_sweep_hold(self.ctx, C.c_void_p(stream_ptr) if stream_ptr else None))
+
     def set_gate(self, gate: "SweepGate | None"):
         """Attach this context to a sweep gate (None detaches).  The gate must outlive the context."""
         self._check(self.L.yams_accel_ctx_set_gate(self.ctx, gate.h if gate is not None else None))

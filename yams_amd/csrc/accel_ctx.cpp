@@ -261,6 +261,7 @@ yams_status_t yams_accel_ctx_create(int device, void* hip_stream, yams_accel_ctx
 
 void yams_accel_ctx_destroy(yams_accel_ctx* ctx) {
     if (!ctx) return;
+    (void)yams_accel_ctx_release_sweep_hold(ctx, nullptr); // (a context must not take its gate with it)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
@@ -298,8 +299,33 @@ void yams_accel_gate_destroy(yams_accel_gate* gate) {
 
 yams_status_t yams_accel_ctx_set_gate(yams_accel_ctx* ctx, yams_accel_gate* gate) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (ctx->gate && ctx->gate != gate) (void)yams_accel_ctx_release_sweep_hold(ctx, nullptr);
     if (gate && gate->device != ctx->device) return yams_accel::fail(ctx, YAMS_ERR_INVALID_ARG, "gate and context are on different devices");
     ctx->gate = gate;
+    return YAMS_OK;
+}
+
+yams_status_t yams_accel_ctx_set_sweep_hold(yams_accel_ctx* ctx, int on) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    ctx->sweep_hold = on != 0;
+    if (!on) return yams_accel_ctx_release_sweep_hold(ctx, nullptr);
+    return YAMS_OK;
+}
+
+yams_status_t yams_accel_ctx_release_sweep_hold(yams_accel_ctx* ctx, void* hip_stream) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    yams_accel_gate* g = ctx->gate;
+    if (!g) return YAMS_OK;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->holder != ctx) return YAMS_OK; // (no sweep ran under the hold: nothing to release)
+        (void)hipSetDevice(ctx->device);
+        // the next sweep of any context of this gate starts behind everything enqueued on that stream so far
+        if (hipEventRecord(g->last, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream) != hipSuccess) (void)hipGetLastError();
+        g->armed = true;
+        g->holder = nullptr;
+    }
+    g->cv.notify_all();
     return YAMS_OK;
 }
 

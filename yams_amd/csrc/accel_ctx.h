@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -15,8 +16,10 @@
 struct yams_accel_gate {
     int device = 0;
     std::mutex mu;
-    hipEvent_t last = nullptr; // end of the most recently enqueued sweep
+    std::condition_variable cv;
+    hipEvent_t last = nullptr; // end of the most recently enqueued sweep (or of what a holder put behind it)
     bool armed = false;
+    yams_accel_ctx* holder = nullptr; // a context that keeps the gate closed behind its sweep (yams_accel_ctx_set_sweep_hold)
 };
 
 struct yams_accel_ctx {
@@ -25,6 +28,7 @@ struct yams_accel_ctx {
     // Called on the host right before a filter sweep is enqueued on `stream` (sharded_api.cpp: the fence that keeps
     // a shard's next sweep behind its previous exchange).  May block; must not throw.
     std::function<void(hipStream_t)> before_sweep;
+    bool sweep_hold = false; // keep the gate closed behind this context's sweeps until yams_accel_ctx_release_sweep_hold
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;   // high-priority side stream (whole-blob digest chains)
@@ -70,18 +74,21 @@ hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
 // Brackets a filter sweep: the stream waits for the previous sweep of the gate, the sweep's end becomes the
 // gate's new tail.  The gate's mutex is held from enter() to leave() (launches only, no host waits).
 struct GatedSweep {
-    yams_accel_ctx* ctx; hipStream_t st; bool held = false;
+    yams_accel_ctx* ctx; hipStream_t st; std::unique_lock<std::mutex> lk;
     GatedSweep(yams_accel_ctx* c, hipStream_t s) : ctx(c), st(s) {
         if (ctx->before_sweep) ctx->before_sweep(st); // (before the gate's mutex: it may wait for another lane)
         if (!ctx->gate) return;
-        ctx->gate->mu.lock(); held = true;
+        lk = std::unique_lock<std::mutex>(ctx->gate->mu);
+        // another context holds the gate closed behind its sweep (its collective has not been enqueued yet)
+        ctx->gate->cv.wait(lk, [&] { return ctx->gate->holder == nullptr || ctx->gate->holder == ctx; });
         if (ctx->gate->armed) (void)hipStreamWaitEvent(st, ctx->gate->last, 0);
     }
     void leave() {
-        if (!held) return;
+        if (!lk.owns_lock()) return;
         (void)hipEventRecord(ctx->gate->last, st);
         ctx->gate->armed = true;
-        ctx->gate->mu.unlock(); held = false;
+        if (ctx->sweep_hold) ctx->gate->holder = ctx;
+        lk.unlock();
     }
     ~GatedSweep() { leave(); }
 };

@@ -288,7 +288,19 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
     (void)hipSetDevice(ctx->device);
     out_blob_first[0] = 0;
     if (n_blobs == 0) return YAMS_OK;
-    if (batch_bytes == 0) batch_bytes = 1ull << 30;
+    if (batch_bytes == 0) {
+        // A batch's whole-blob digest chains take (longest blob) / 35 MB/s whatever the batch holds, and the chains of up
+        // to three batches are in flight: the stream moves at 3 x batch_bytes per chain time until the link takes over.
+        // Measured on 4 MiB blobs, 32 GiB per call (scripts/dbg/host_stream_batches.py): 1 / 2 / 4 / 8 GiB batches =
+        // 17.5 / 32 / 41 / 46 GB/s.  So: about 2048 of the longest blob per batch, between 1 and 8 GiB, and never fewer
+        // than four batches per call (the upload of one must run under the kernels of another).
+        uint64_t longest = 0, total = 0;
+        for (uint64_t b = 0; b < n_blobs; ++b) { longest = std::max<uint64_t>(longest, blob_lengths[b]); total += blob_lengths[b]; }
+        if (!(flags & YAMS_INGEST_BLOB_DIGESTS)) longest = 0; // no chains: the link is the only bound
+        else if (flags & YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS) longest = std::min(longest, yams_ingest_defer_threshold_host(total));
+        const uint64_t cap = std::max<uint64_t>(1ull << 30, std::min<uint64_t>(8ull << 30, total / 4));
+        batch_bytes = std::min(cap, std::max<uint64_t>(1ull << 30, longest * 2048));
+    }
     // batches of consecutive blobs (a blob never straddles two: its digest is one chain); every blob
     // starts on a 16-byte boundary of the device buffer
     struct Batch { uint64_t first, count, bytes; };
