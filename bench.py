@@ -333,7 +333,7 @@ def ingest_breadth(acc, torch, seed):
         ptrs_l = ptrs * reps_long
         t0 = time.perf_counter()
         batch_l = 0     # the library's own choice for this call (8 GiB here: 4 MiB blobs, 32 GiB)
-        acc.ingest_host(ptrs_l[:4096], [blen] * 4096, cfg, flags=3, batch_bytes=8 << 30)       # warm-up: buffers of that size
+        acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch_l)      # warm-up: all four device buffers and lane tables of that size
         hl = acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch_l)
         dtl = time.perf_counter() - t0
         same = all(np.array_equal(hl["blob_digest"][r * n_blobs:(r + 1) * n_blobs], h["blob_digest"]) for r in range(reps_long)) and \
