@@ -1400,7 +1400,10 @@ def main():
         out.update(check)
     if world > 1:
         out["collective"] = {"backend": torch.distributed.get_backend(), "bytes_per_rank": pipe.rec_bytes,
-                             "overlapped": pipe.side is not None and torch.distributed.get_backend() != "gloo"}
+                             "side_stream": pipe.side is not None and torch.distributed.get_backend() != "gloo",
+                             "fenced": bool(gate is not None and pipe.active),
+                             "fence": "the sweep gate stays closed behind a lane's sweep until that lane has enqueued its all-gather + merge: "
+                                      "no collective kernel waits for a CU under a persistent sweep (DESIGN 4)"}
     # CPU baseline and the ingest leg: rank 0 at N = 1 only (at N > 1 the other ranks would sit in the
     # final barrier meanwhile)
     if not a.no_boundary_leg and world == 1:

@@ -3,9 +3,12 @@
 The corpus never crosses xGMI: rank g owns rows [bounds[g], bounds[g+1]); every rank scores the
 same query batch against its shard (fp64-exact per-shard top-k), then ONE all-gather moves
 Q*k*(4+8)+4Q bytes per rank and every rank merges the gathered lists on its own device
-(yams_scan_merge_topk_device).  The collective and the merge of batch i run on a side stream while
-the sweep of batch i+1 runs on the scan stream (`GatherPipeline`).  torch is plumbing here:
-tensors, streams and the collective."""
+(yams_scan_merge_topk_device).  The collective and the merge of batch i run on a side stream
+(`GatherPipeline`); with several lanes per rank the caller keeps the device's sweep gate closed behind
+a batch's sweep until its collective is enqueued (Accel.set_sweep_hold / release_sweep_hold): a filter
+sweep is a persistent grid that owns every CU, and an RCCL kernel waiting for a CU under it would keep
+its peers on the other GPUs spinning ("the fence").  torch is plumbing here: tensors,
+streams and the collective."""
 from __future__ import annotations
 
 import os
