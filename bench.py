@@ -322,25 +322,24 @@ def ingest_breadth(acc, torch, seed):
                             "blobs": n_blobs, "blob_bytes": blen, "batch_bytes": batch, "source": "pinned host memory",
                             "includes": "H2D of every byte + kernels + D2H of chunk tables and digests (never the headline `value`)",
                             "bound": "the SHA-256 chains: one lane per blob, ~120 ms for 4 MiB, 512 chains per 2 GiB batch; each batch's chains run on "
-                                     "a lane of their own and are joined three batches later.  The steady state of a long stream is the "
-                                     "host_streamed_32GiB leg below (measured: the same rate, NOT the link's — round 3's claim that a longer "
-                                     "stream reaches link rate was wrong); 256 KiB blobs reach 41 GB/s",
+                                     "a low-priority lane of their own and are joined three batches later.  This call is only four batches: the last "
+                                     "ones' chains have nothing to hide under.  The steady state is the host_streamed_32GiB leg below",
                             "chunks": h["n_chunks"], "bit_exact_vs_cpu_sample": {"blobs": len(pick), "ok": ok}}
     # the steady state of the same stream ("a >= 32 GiB run"): the 8 GiB of pinned blobs four times over
-    # (the device neither knows nor cares that batch i + 4 reads the same host pages as batch i) = 16 batches of 2 GiB
+    # (the device neither knows nor cares that batch i + 4 reads the same host pages as batch i), in batches of the library's choice
     try:
         reps_long = 4
         ptrs_l = ptrs * reps_long
-        t0 = time.perf_counter()
         batch_l = 0     # the library's own choice for this call (8 GiB here: 4 MiB blobs, 32 GiB)
         acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch_l)      # warm-up: all four device buffers and lane tables of that size
+        t0 = time.perf_counter()
         hl = acc.ingest_host(ptrs_l, [blen] * len(ptrs_l), cfg, flags=3, batch_bytes=batch_l)
         dtl = time.perf_counter() - t0
         same = all(np.array_equal(hl["blob_digest"][r * n_blobs:(r + 1) * n_blobs], h["blob_digest"]) for r in range(reps_long)) and \
             hl["n_chunks"] == reps_long * h["n_chunks"] and np.array_equal(hl["chunk_digest"][:h["n_chunks"]], h["chunk_digest"][:h["n_chunks"]])
         res["host_streamed_32GiB"] = {"value": len(ptrs_l) * blen / dtl / 1e9, "unit": "GB/s", "bytes": len(ptrs_l) * blen, "ms": dtl * 1e3,
                                       "blobs": len(ptrs_l), "blob_bytes": blen, "batch_bytes": "library default (about 2048 of the longest blob, 1-8 GiB, >= 4 batches per call): 8 GiB here",
-                                      "by_batch_size_GBps": "1 / 2 / 4 / 8 GiB batches: 17.5 / 32 / 41 / 46 (scripts/dbg/host_stream_batches.py, round 4)",
+                                      "by_batch_size_GBps": "1 / 2 / 4 / 8 GiB batches: 17.5 / 32 / 41 / 46 before the streams got priority classes of their own, 2 / 8 GiB: 43.6 / 46.2 after (scripts/dbg/host_stream_batches.py, round 4)",
                                       "source": "pinned host memory (the 8 GiB above, streamed four times in one call)",
                                       "equals_the_8GiB_call_repeated": bool(same)}
         del hl

@@ -4,8 +4,16 @@ import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from yams_amd.accel import Accel, cdc_config
-acc = Accel(0)
+import os
+acc = Accel(0, torch.cuda.current_stream().cuda_stream) if os.environ.get("TORCH_STREAM") else Accel(0)
 blen, n_blobs = 4 << 20, 2048
+if os.environ.get("PRE_GIB"):      # what bench.py does before this leg: a device-resident ingest of that many GiB, then its tensor is freed
+    g = int(os.environ["PRE_GIB"]); nb = g * (1 << 30) // blen
+    tb = torch.empty(nb * blen, dtype=torch.uint8, device="cuda")
+    acc.synth_bytes(1, 0, nb, blen, tb.data_ptr())
+    if os.environ.get("PRE_INGEST", "1") == "1":
+        acc.ingest_device(tb.data_ptr(), [i * blen for i in range(nb)], [blen] * nb, cdc_config("streaming"), flags=3); acc.synchronize()
+    del tb; torch.cuda.empty_cache()
 host = torch.empty(n_blobs * blen, dtype=torch.uint8, pin_memory=True)
 stage = torch.empty(256 * blen, dtype=torch.uint8, device="cuda")
 for b0 in range(0, n_blobs, 256):
@@ -18,8 +26,8 @@ lens = [blen] * len(ptrs)
 cfg = cdc_config("streaming")
 out = {}
 ref = None
-for gib in (1, 2, 4, 8):
-    acc.ingest_host(ptrs[:4096], lens[:4096], cfg, flags=3, batch_bytes=gib << 30)      # warm-up: buffers of this size
+for gib in [int(x) for x in os.environ.get("GIBS", "1 2 4 8").split()]:
+    acc.ingest_host(ptrs, lens, cfg, flags=3, batch_bytes=gib << 30)      # warm-up: buffers of this size (gib = 0: the library's choice)
     t0 = time.perf_counter()
     h = acc.ingest_host(ptrs, lens, cfg, flags=3, batch_bytes=gib << 30)
     dt = time.perf_counter() - t0

@@ -354,11 +354,19 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         rc = fail(ctx, YAMS_ERR_INTERNAL, what);
         return false;
     };
-    if (!hip_ok(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking), "copy stream")) { cleanup(); return rc; }
+    // Streams of one priority share a small pool of hardware queues (four by default), handed out by how many streams
+    // already sit on each: in a process that has created many streams the copy stream, the chain lanes and the
+    // context's stream can land on ONE hardware queue, and then the next upload waits behind a 120 ms chain kernel
+    // (measured inside bench.py's process: 22 GB/s for a stream that does 46 on its own).  The three roles therefore
+    // live in three priority classes, whose queue pools are disjoint: uploads high, kernels normal (the context's
+    // stream), chains low — which is also what they are: background work that must not delay anything.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!hip_ok(hipStreamCreateWithPriority(&copy_st, hipStreamNonBlocking, prio_hi), "copy stream")) { cleanup(); return rc; }
     for (int i = 0; i < n_slots; ++i) {
         lanes[i].index = i;
         if (!hip_ok(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming), "event") ||
-            (chains && (!hip_ok(hipStreamCreateWithFlags(&lanes[i].stream, hipStreamNonBlocking), "chain stream") ||
+            (chains && (!hip_ok(hipStreamCreateWithPriority(&lanes[i].stream, hipStreamNonBlocking, prio_lo), "chain stream") ||
                         !hip_ok(hipEventCreateWithFlags(&lanes[i].fork, hipEventDisableTiming), "event") ||
                         !hip_ok(hipEventCreateWithFlags(&lanes[i].join, hipEventDisableTiming), "event")))) { cleanup(); return rc; }
     }
