@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true")
     ap.add_argument("--no-l2-leg", action="store_true", help="skip the BASELINE config 3 (10M x 768 L2) leg")
-    ap.add_argument("--oracle-queries", type=int, default=None, help="queries checked against the oracle over the whole resident corpus (default 4 at N=1, 2 at N>1; 0 = skip)")
+    ap.add_argument("--oracle-queries", type=int, default=None, help="queries checked against the oracle over the whole resident corpus (default 128 at N=1, 16 at N>1 — the batched oracle drivers make a query cost ~0.1 thread-seconds per million rows; 1024 = the whole timed batch; 0 = skip)")
     ap.add_argument("--ingest-gib", type=float, default=100.0)  # BASELINE config 5
     ap.add_argument("--verify-all-ingest", action="store_true",
                     help="check EVERY blob of the ingest leg's timed call on the CPU (boundaries, every chunk digest, blob digest; "
@@ -771,7 +771,7 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
 def c_abi_main(a):
     """`bench.py --gpus N --via-c-abi`: the whole job from ONE process through the C ABI; prints the contract's line."""
     devices = [0] * a.gpus if a.single_device else list(range(a.gpus))
-    oq = a.oracle_queries if a.oracle_queries is not None else (4 if a.gpus == 1 else 0)
+    oq = a.oracle_queries if a.oracle_queries is not None else (64 if a.gpus == 1 else 0)
     r = c_abi_sharded_run(a, devices, n_query_batches=max(1, a.query_batches), oracle_queries=oq,
                           collective="peer" if a.single_device and a.gpus > 1 else "rccl")
     if a.child_json:
@@ -1014,7 +1014,7 @@ def main():
     c_timed = res["counts"].cpu().numpy().copy()
 
     # ---- the timed configuration against the oracle over the whole resident corpus ----------------
-    n_oq = a.oracle_queries if a.oracle_queries is not None else (4 if world == 1 else 2)
+    n_oq = a.oracle_queries if a.oracle_queries is not None else (128 if world == 1 else 16)
     n_oq = min(n_oq, nq)
     check = None
     if n_oq > 0:

@@ -461,6 +461,233 @@ ORACLE_API long oracle_exact_scan_l2_f32acc(const float* corpus, size_t n_rows, 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * MANY queries against one corpus slice: what lets a test check EVERY query of a BASELINE-size batch (1024 queries x
+ * 12.5M rows) instead of two or four of them.  Not a second definition — the same arithmetic as
+ * oracle_exact_scan_cosine / oracle_exact_scan_l2 above, per (row, query) the very same sequence of IEEE double
+ * operations (products of two floats are exact in double; the sums run left to right over the elements), only
+ *   * interleaved across QB queries, whose accumulation chains are independent (the single-query loop is bound by the
+ *     latency of ONE dependent chain of additions; here the queries sit in the lanes of a vector),
+ *   * with |row|^2 and the finite check, which do not depend on the query, computed once per row,
+ *   * with a bounded heap under the same total order (similarity desc / distance asc, then row asc) in place of the
+ *     L2 function's full sort: the k best under a total order do not depend on how they are found.
+ * tests/test_oracle.py pins both against the single-query functions bit for bit (ties, zero rows, non-finite rows,
+ * thresholds, ragged query counts).  Built with -ffp-contract=off like everything here; the vector types are GCC's
+ * generic ones (lane-wise IEEE multiply and add: no reassociation, no fused operations).
+ * ---------------------------------------------------------------------------------------------- */
+#define ORACLE_QB 8
+typedef double oracle_v2d __attribute__((vector_size(16)));
+typedef double oracle_v4d __attribute__((vector_size(32), aligned(32)));
+typedef struct { double v[ORACLE_QB]; } __attribute__((aligned(64))) oracle_vq; /* element i of QB queries, side by side */
+
+/* dot[j] = sum_i row[i] * qT[i][j], left to right over i (the :4256-4266 loop, QB queries at once);
+ * d2[j] = sum_i (row[i] - q_j[i])^2 likewise (oracle_exact_scan_l2's loop).  Two builds of the same statements: 128-bit
+ * lanes (every x86-64 / aarch64) and 256-bit lanes where the host has AVX2 — lane-wise IEEE either way. */
+#define ORACLE_RB 4 /* rows per kernel call: RB x QB independent chains hide the latency of the additions */
+#define ORACLE_QB_KERNELS(SUFFIX, VT, NV, ATTR)                                                                     \
+    ATTR static void dots_qb_##SUFFIX(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {        \
+        VT acc[ORACLE_RB][NV];                                                                                        \
+        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                         \
+        for (size_t i = 0; i < dim; ++i) {                                                                            \
+            const VT* q = (const VT*)qT[i].v;                                                                         \
+            for (int r = 0; r < ORACLE_RB; ++r) {                                                                     \
+                const double sv = (double)row[r][i];                                                                  \
+                for (int v = 0; v < NV; ++v) acc[r][v] = acc[r][v] + sv * q[v];                                       \
+            }                                                                                                         \
+        }                                                                                                             \
+        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v)                                              \
+            for (int l = 0; l < ORACLE_QB / NV; ++l) out[r * ORACLE_QB + v * (ORACLE_QB / NV) + l] = acc[r][v][l];    \
+    }                                                                                                                 \
+    ATTR static void sqdist_qb_##SUFFIX(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {      \
+        VT acc[ORACLE_RB][NV];                                                                                        \
+        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                         \
+        for (size_t i = 0; i < dim; ++i) {                                                                            \
+            const VT* q = (const VT*)qT[i].v;                                                                         \
+            for (int r = 0; r < ORACLE_RB; ++r) {                                                                     \
+                const double sv = (double)row[r][i];                                                                  \
+                for (int v = 0; v < NV; ++v) { const VT d = sv - q[v]; acc[r][v] = acc[r][v] + d * d; }               \
+            }                                                                                                         \
+        }                                                                                                             \
+        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v)                                              \
+            for (int l = 0; l < ORACLE_QB / NV; ++l) out[r * ORACLE_QB + v * (ORACLE_QB / NV) + l] = acc[r][v][l];    \
+    }
+ORACLE_QB_KERNELS(v2, oracle_v2d, 4, )
+#if defined(__x86_64__)
+ORACLE_QB_KERNELS(v4, oracle_v4d, 2, __attribute__((target("avx2"))))
+static int oracle_wide(void) { static int w = -1; if (w < 0) { __builtin_cpu_init(); w = __builtin_cpu_supports("avx2") ? 1 : 0; } return w; }
+static void dots_qb(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {
+    if (oracle_wide()) dots_qb_v4(row, qT, dim, out); else dots_qb_v2(row, qT, dim, out);
+}
+static void sqdist_qb(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {
+    if (oracle_wide()) sqdist_qb_v4(row, qT, dim, out); else sqdist_qb_v2(row, qT, dim, out);
+}
+#else
+#define dots_qb dots_qb_v2
+#define sqdist_qb sqdist_qb_v2
+#endif
+
+#define ORACLE_ROW_BLOCK 64 /* rows per pass over the query groups: 64 x 768 floats = 192 KiB, stays in the core's L2 */
+
+/* out_rows / out_sims: [nq][k], out_counts: [nq].  Returns 0, or -1 when a query is invalid (:4127-4130: that call
+ * fails as a whole in the reference; check such a batch query by query). */
+ORACLE_API long oracle_exact_scan_cosine_many(const float* corpus, size_t n_rows, size_t dim, const float* queries,
+                                              size_t nq, size_t k, float similarity_threshold, int64_t* out_rows,
+                                              float* out_sims, uint32_t* out_counts) {
+    for (size_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    if (dim == 0 || k == 0 || nq == 0) return 0;
+    for (size_t q = 0; q < nq; ++q) if (oracle_query_invalid(queries + q * dim, dim)) return -1;
+    const size_t ng = (nq + ORACLE_QB - 1) / ORACLE_QB;
+    oracle_vq* qT = (oracle_vq*)aligned_alloc(64, sizeof(oracle_vq) * ng * dim);
+    double* qn = (double*)malloc(sizeof(double) * ng * ORACLE_QB);
+    oracle_hit* heaps = (oracle_hit*)malloc(sizeof(oracle_hit) * nq * (k + 1));
+    size_t* hs = (size_t*)calloc(nq, sizeof(size_t));
+    for (size_t g = 0; g < ng; ++g)
+        for (int j = 0; j < ORACLE_QB; ++j) {
+            const size_t q = g * ORACLE_QB + j;
+            double s = 0.0;
+            for (size_t i = 0; i < dim; ++i) {
+                const double v = q < nq ? (double)queries[q * dim + i] : 0.0;
+                qT[g * dim + i].v[j] = v;
+                s += v * v;                                  /* :4206-4210 */
+            }
+            qn[q] = sqrt(s);                                 /* :4211 */
+        }
+    double nsq[ORACLE_ROW_BLOCK]; int live[ORACLE_ROW_BLOCK];
+    for (size_t r0 = 0; r0 < n_rows; r0 += ORACLE_ROW_BLOCK) {
+        const size_t nb = n_rows - r0 < ORACLE_ROW_BLOCK ? n_rows - r0 : ORACLE_ROW_BLOCK;
+        for (size_t b = 0; b < nb; ++b) {
+            const float* e = corpus + (r0 + b) * dim;
+            double s = 0.0; int finite = 1;
+            for (size_t i = 0; i < dim; ++i) {               /* :4256-4266 */
+                if (!isfinite(e[i])) { finite = 0; break; }
+                const double sv = (double)e[i];
+                s += sv * sv;
+            }
+            nsq[b] = s; live[b] = finite && !(s <= 1e-12);   /* :4267-4269 */
+        }
+        for (size_t g = 0; g < ng; ++g)
+            for (size_t b0 = 0; b0 < nb; b0 += ORACLE_RB) {
+                const float* rp[ORACLE_RB]; int any = 0;
+                for (int t = 0; t < ORACLE_RB; ++t) {       /* (a short tail repeats its last row; dead rows are computed and dropped) */
+                    const size_t b = b0 + t < nb ? b0 + t : nb - 1;
+                    rp[t] = corpus + (r0 + b) * dim;
+                    any |= b0 + t < nb && live[b0 + t];
+                }
+                if (!any) continue;
+                double dot[ORACLE_RB * ORACLE_QB];
+                dots_qb(rp, qT + g * dim, dim, dot);
+                for (int t = 0; t < ORACLE_RB && b0 + t < nb; ++t) {
+                    const size_t b = b0 + t;
+                    if (!live[b]) continue;
+                    const double root = sqrt(nsq[b]);
+                    for (int j = 0; j < ORACLE_QB; ++j) {
+                        const size_t q = g * ORACLE_QB + j;
+                        if (q >= nq) break;
+                        const double denom = root * qn[q];       /* :4271 */
+                        const double sd = denom > 0.0 ? dot[t * ORACLE_QB + j] / denom : 0.0;
+                        if (!isfinite(sd)) continue;             /* :4273-4275 */
+                        const float sim = (float)sd;             /* :4276 */
+                        if (sim < similarity_threshold) continue;/* :4277-4279 */
+                        oracle_hit h = {sim, (uint64_t)(r0 + b), (int64_t)(r0 + b)};
+                        oracle_hit* heap = heaps + q * (k + 1);
+                        if (hs[q] < k) { heap[hs[q]] = h; heap_sift_up(heap, hs[q]); ++hs[q]; }
+                        else if (hit_better(&h, &heap[0])) { heap[0] = h; heap_sift_down(heap, hs[q], 0); }
+                    }
+                }
+            }
+    }
+    for (size_t q = 0; q < nq; ++q) {
+        oracle_hit* heap = heaps + q * (k + 1);
+        qsort(heap, hs[q], sizeof(oracle_hit), hit_cmp_best_first);
+        for (size_t i = 0; i < hs[q]; ++i) { out_rows[q * k + i] = heap[i].row; out_sims[q * k + i] = heap[i].sim; }
+        out_counts[q] = (uint32_t)hs[q];
+    }
+    free(hs); free(heaps); free(qn); free(qT);
+    return 0;
+}
+
+static int l2hit_worse(const oracle_l2hit* a, const oracle_l2hit* b) { return l2_cmp(a, b) > 0; }
+static void l2heap_up(oracle_l2hit* h, size_t i) {          /* the WORST retained row at the front */
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (l2hit_worse(&h[i], &h[p])) { oracle_l2hit t = h[p]; h[p] = h[i]; h[i] = t; i = p; }
+        else break;
+    }
+}
+static void l2heap_down(oracle_l2hit* h, size_t n, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && l2hit_worse(&h[l], &h[m])) m = l;
+        if (r < n && l2hit_worse(&h[r], &h[m])) m = r;
+        if (m == i) break;
+        oracle_l2hit t = h[m]; h[m] = h[i]; h[i] = t; i = m;
+    }
+}
+/* The k nearest of every query (distance asc, row asc) with the cosine of each; the cosine threshold of :4508-4510 is
+ * the caller's (it comes AFTER the k-nearest cut, and after the merge when the corpus is scanned slice by slice). */
+ORACLE_API long oracle_exact_scan_l2_many(const float* corpus, size_t n_rows, size_t dim, const float* queries, size_t nq,
+                                          size_t k, int64_t* out_rows, float* out_dist, float* out_sims,
+                                          uint32_t* out_counts) {
+    for (size_t q = 0; q < nq; ++q) out_counts[q] = 0;
+    if (dim == 0 || k == 0 || nq == 0) return 0;
+    const size_t ng = (nq + ORACLE_QB - 1) / ORACLE_QB;
+    oracle_vq* qT = (oracle_vq*)aligned_alloc(64, sizeof(oracle_vq) * ng * dim);
+    oracle_l2hit* heaps = (oracle_l2hit*)malloc(sizeof(oracle_l2hit) * nq * (k + 1));
+    size_t* hs = (size_t*)calloc(nq, sizeof(size_t));
+    for (size_t g = 0; g < ng; ++g)
+        for (int j = 0; j < ORACLE_QB; ++j) {
+            const size_t q = g * ORACLE_QB + j;
+            for (size_t i = 0; i < dim; ++i) qT[g * dim + i].v[j] = q < nq ? (double)queries[q * dim + i] : 0.0;
+        }
+    int live[ORACLE_ROW_BLOCK];
+    for (size_t r0 = 0; r0 < n_rows; r0 += ORACLE_ROW_BLOCK) {
+        const size_t nb = n_rows - r0 < ORACLE_ROW_BLOCK ? n_rows - r0 : ORACLE_ROW_BLOCK;
+        for (size_t b = 0; b < nb; ++b) {
+            const float* e = corpus + (r0 + b) * dim;
+            int finite = 1;
+            for (size_t i = 0; i < dim; ++i) if (!isfinite(e[i])) { finite = 0; break; }
+            live[b] = finite;
+        }
+        for (size_t g = 0; g < ng; ++g)
+            for (size_t b0 = 0; b0 < nb; b0 += ORACLE_RB) {
+                const float* rp[ORACLE_RB]; int any = 0;
+                for (int t = 0; t < ORACLE_RB; ++t) {
+                    const size_t b = b0 + t < nb ? b0 + t : nb - 1;
+                    rp[t] = corpus + (r0 + b) * dim;
+                    any |= b0 + t < nb && live[b0 + t];
+                }
+                if (!any) continue;
+                double d2[ORACLE_RB * ORACLE_QB];
+                sqdist_qb(rp, qT + g * dim, dim, d2);
+                for (int t = 0; t < ORACLE_RB && b0 + t < nb; ++t) {
+                    const size_t b = b0 + t;
+                    if (!live[b]) continue;
+                    for (int j = 0; j < ORACLE_QB; ++j) {
+                        const size_t q = g * ORACLE_QB + j;
+                        if (q >= nq) break;
+                        const double dd = sqrt(d2[t * ORACLE_QB + j]);
+                        if (!isfinite(dd)) continue;
+                        oracle_l2hit h = {(float)dd, (uint64_t)(r0 + b), (int64_t)(r0 + b)};
+                        oracle_l2hit* heap = heaps + q * (k + 1);
+                        if (hs[q] < k) { heap[hs[q]] = h; l2heap_up(heap, hs[q]); ++hs[q]; }
+                        else if (l2_cmp(&h, &heap[0]) < 0) { heap[0] = h; l2heap_down(heap, hs[q], 0); }
+                    }
+                }
+            }
+    }
+    for (size_t q = 0; q < nq; ++q) {
+        oracle_l2hit* heap = heaps + q * (k + 1);
+        qsort(heap, hs[q], sizeof(oracle_l2hit), l2_cmp);
+        for (size_t i = 0; i < hs[q]; ++i) {
+            out_rows[q * k + i] = heap[i].row; out_dist[q * k + i] = heap[i].dist;
+            out_sims[q * k + i] = (float)oracle_cosine_similarity(queries + q * dim, corpus + (size_t)heap[i].row * dim, dim);
+        }
+        out_counts[q] = (uint32_t)hs[q];
+    }
+    free(hs); free(heaps); free(qT);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic-data recipes shared by tests and bench (so the CPU side can regenerate any slice).
  * Philox4x32-10 counter-based generator (Salmon et al., SC'11): key = (seed_lo, seed_hi),
  * counter = (i0, i1, i2, i3).  Used for corpora too large to hold on the host.

@@ -20,6 +20,6 @@ sys.argv = ["bench.py", "--gpus", "1", "--via-c-abi", "--lanes", str(lanes), "--
 a = bench.parse()
 a.child_json = True
 bench.c_abi_main.__globals__["print"] = lambda s_: None
-r = bench.c_abi_sharded_run(a, [0], n_query_batches=max(1, a.query_batches), oracle_queries=0)
+r = bench.c_abi_sharded_run(a, [0], n_query_batches=max(1, a.query_batches))
 print(json.dumps({"normal": n_norm, "high": n_high, "lanes": lanes, "ms_per_step": round(r["ms_per_step"], 3),
                   "filter_launch_ms": round(r["filter_launch_ms_shard0"], 3)}))

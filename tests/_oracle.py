@@ -67,6 +67,12 @@ class Oracle:
         L.oracle_exact_scan_l2.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                            C.c_float, u64p, i64p, f32p, f32p]
         L.oracle_exact_scan_l2.restype = C.c_long
+        u32p_ = C.POINTER(C.c_uint32)
+        L.oracle_exact_scan_cosine_many.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_float,
+                                                    i64p, f32p, u32p_]
+        L.oracle_exact_scan_cosine_many.restype = C.c_long
+        L.oracle_exact_scan_l2_many.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, i64p, f32p, f32p, u32p_]
+        L.oracle_exact_scan_l2_many.restype = C.c_long
         L.oracle_exact_scan_l2_f32acc.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_float, u64p, C.c_int,
                                                   i64p, f32p, f32p]
         L.oracle_exact_scan_l2_f32acc.restype = C.c_long
@@ -122,6 +128,31 @@ class Oracle:
         if cnt < 0:
             return None
         return rows[:cnt].copy(), sims[:cnt].copy(), rv.value, ev.value
+
+    def scan_cosine_many(self, corpus, queries, k, thr=-1.0):
+        """Every query of a batch against one slice (oracle_exact_scan_cosine_many: the single-query arithmetic, the
+        queries in the lanes of a vector).  Returns (rows [nq][k] int64, sims [nq][k] float32, counts [nq]) with rows
+        -1 past a query's count, or None when a query is invalid."""
+        corpus = np.ascontiguousarray(corpus, np.float32); queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
+        n, d = corpus.shape
+        nq = queries.shape[0]
+        rows = np.full((nq, max(k, 1)), -1, np.int64); sims = np.zeros((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        rc = self.L.oracle_exact_scan_cosine_many(_ptr(corpus, f32p), n, d, _ptr(queries, f32p), nq, k, thr, _ptr(rows, i64p),
+                                                  _ptr(sims, f32p), counts.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return None if rc < 0 else (rows, sims, counts)
+
+    def scan_l2_many(self, corpus, queries, k):
+        """The k nearest rows of every query (distance asc, row asc) and their cosine — the vec0 cut; the cosine threshold
+        is the caller's.  Returns (rows, dist, sims, counts)."""
+        corpus = np.ascontiguousarray(corpus, np.float32); queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
+        n, d = corpus.shape
+        nq = queries.shape[0]
+        rows = np.full((nq, max(k, 1)), -1, np.int64); dist = np.zeros((nq, max(k, 1)), np.float32)
+        sims = np.zeros((nq, max(k, 1)), np.float32); counts = np.zeros(nq, np.uint32)
+        self.L.oracle_exact_scan_l2_many(_ptr(corpus, f32p), n, d, _ptr(queries, f32p), nq, k, _ptr(rows, i64p), _ptr(dist, f32p),
+                                         _ptr(sims, f32p), counts.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return rows, dist, sims, counts
 
     def scan_cosine_records(self, corpus, query, k, thr=-1.0, tie_rank=None, allow=None, all_matching=False):
         """The reference's record path (metadata_filters), sqlite_vec_backend.cpp:4333-4409."""
@@ -300,6 +331,9 @@ def host_threads(limit: int | None = None) -> int:
     return max(1, min(n, limit) if limit else n)
 
 
+MANY_FROM = 8   # scan_threaded: batches of at least this many queries go through the batched drivers
+
+
 def scan_threaded(get_slice, n_rows, queries, k, metric="cosine", thr=-1.0, slice_rows=65536,
                   threads=None, stats=None):
     """The scalar oracle scan of every query over a corpus that need not fit in host memory:
@@ -323,13 +357,23 @@ def scan_threaded(get_slice, n_rows, queries, k, metric="cosine", thr=-1.0, slic
         part = np.ascontiguousarray(get_slice(lo, hi), np.float32)
         t1 = time.perf_counter()
         out = []
-        for qi in range(nq):
-            if metric == "cosine":
-                rows, sims, _, _ = o.scan_cosine(part, queries[qi], k, thr)
-                out.append((rows + lo, sims, None))
-            else:
-                rows, dist, sims = o.scan_l2(part, queries[qi], k, -1.0)   # threshold after the merge
-                out.append((rows + lo, sims, dist))
+        many = None
+        if nq >= MANY_FROM:     # the batched drivers (pinned against the single-query functions by test_oracle.py)
+            many = o.scan_cosine_many(part, queries, k, thr) if metric == "cosine" else o.scan_l2_many(part, queries, k)
+        if many is not None and metric == "cosine":
+            rows, sims, counts = many
+            out = [(rows[qi, :counts[qi]] + lo, sims[qi, :counts[qi]], None) for qi in range(nq)]
+        elif many is not None:
+            rows, dist, sims, counts = many
+            out = [(rows[qi, :counts[qi]] + lo, sims[qi, :counts[qi]], dist[qi, :counts[qi]]) for qi in range(nq)]
+        else:
+            for qi in range(nq):
+                if metric == "cosine":
+                    rows, sims, _, _ = o.scan_cosine(part, queries[qi], k, thr)
+                    out.append((rows + lo, sims, None))
+                else:
+                    rows, dist, sims = o.scan_l2(part, queries[qi], k, -1.0)   # threshold after the merge
+                    out.append((rows + lo, sims, dist))
         return out, t1 - t0, time.perf_counter() - t1
 
     t_start = time.perf_counter()

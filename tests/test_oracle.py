@@ -237,6 +237,78 @@ def test_threaded_scan_equals_one_oracle_call(oracle):
         assert np.array_equal(got[qi][1].view(np.uint32), sims.view(np.uint32))
 
 
+def _hard_corpus(oracle, n, d, seed):
+    """Rows that exercise every branch of the scans: exact duplicates (ties broken by row), scaled copies (equal cosine
+    up to rounding), zero and near-zero rows (the 1e-12 skip), non-finite elements, huge and tiny magnitudes."""
+    c = oracle.synth_rows(seed, 0, n, d)
+    rng = np.random.default_rng(seed)
+    for _ in range(n // 10):
+        i, j = rng.integers(0, n, 2)
+        c[i] = c[j]
+    for _ in range(n // 20):
+        i, j = rng.integers(0, n, 2)
+        c[i] = c[j] * np.float32(rng.choice([0.5, 2.0, 3.0, 1e-3]))
+    c[rng.integers(0, n, 5)] = 0.0
+    c[rng.integers(0, n, 3)] = np.float32(1e-8)
+    c[rng.integers(0, n), rng.integers(0, d)] = np.nan
+    c[rng.integers(0, n), rng.integers(0, d)] = np.inf
+    c[rng.integers(0, n)] *= np.float32(1e18)
+    c[rng.integers(0, n)] *= np.float32(1e-18)
+    return c
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(700, 24, 1, 10), (700, 24, 8, 10), (1000, 48, 19, 100), (300, 7, 33, 400), (129, 768, 9, 5),
+                                       (64, 16, 8, 1), (65, 16, 7, 64), (0, 16, 3, 4)])
+def test_batched_scan_drivers_equal_the_single_query_functions(oracle, n, d, nq, k):
+    """oracle_exact_scan_cosine_many / _l2_many (the queries of a batch in the lanes of a vector; what lets a GPU test
+    check EVERY query of a 1024-query batch) against oracle_exact_scan_cosine / oracle_exact_scan_l2, the functions the
+    reference's known-answer tests pin: rows, order, score bits and counts of every query."""
+    corpus = _hard_corpus(oracle, n, d, 11 + n) if n else np.zeros((0, d), np.float32)
+    q = oracle.synth_rows(5, 1 << 40, nq, d)
+    if n:
+        ok = [i for i in range(n) if np.isfinite(corpus[i]).all() and 0.01 < float(np.linalg.norm(corpus[i].astype(np.float64))) < 100.0]
+        q[0] = corpus[ok[3]]                # a query that IS a row: similarity 1, distance 0, duplicates tie with it
+        if nq > 2:
+            q[2] = corpus[ok[len(ok) // 2]] * np.float32(4.0)
+    for thr in (-1.0, 0.05):
+        rows, sims, counts = oracle.scan_cosine_many(corpus, q, k, thr)
+        for qi in range(nq):
+            r1, s1, _, _ = oracle.scan_cosine(corpus, q[qi], k, thr)
+            c = int(counts[qi])
+            assert c == len(r1), (qi, c, len(r1))
+            assert np.array_equal(rows[qi, :c], r1) and np.array_equal(sims[qi, :c].view(np.uint32), s1.view(np.uint32)), qi
+            assert (rows[qi, c:] == -1).all()
+    rows, dist, sims, counts = oracle.scan_l2_many(corpus, q, k)
+    for qi in range(nq):
+        r1, d1, s1 = oracle.scan_l2(corpus, q[qi], k, -1.0)
+        c = int(counts[qi])
+        assert c == len(r1), (qi, c, len(r1))
+        assert np.array_equal(rows[qi, :c], r1) and np.array_equal(dist[qi, :c].view(np.uint32), d1.view(np.uint32)), qi
+        assert np.array_equal(sims[qi, :c].view(np.uint32), s1.view(np.uint32)), qi
+    # an invalid query fails the batched call as the single call fails (:4127-4130)
+    if n:
+        bad = q.copy(); bad[nq - 1] = 0.0
+        assert oracle.scan_cosine_many(corpus, bad, k) is None and oracle.scan_cosine(corpus, bad[nq - 1], k) is None
+
+
+def test_threaded_scan_takes_the_batched_drivers_for_many_queries(oracle):
+    """scan_threaded with >= MANY_FROM queries (the path of the full-batch checks) equals the single-query oracle."""
+    n, d, k, nq = 4000, 32, 30, 21
+    corpus = _hard_corpus(oracle, n, d, 77)
+    q = oracle.synth_rows(8, 1 << 40, nq, d)
+    q[1] = corpus[5]
+    assert nq >= _oracle.MANY_FROM
+    got = _oracle.scan_threaded(lambda lo, hi: corpus[lo:hi], n, q, k, slice_rows=900, threads=3)
+    for qi in range(nq):
+        rows, sims, _, _ = oracle.scan_cosine(corpus, q[qi], k, -1.0)
+        assert np.array_equal(got[qi][0], rows) and np.array_equal(got[qi][1].view(np.uint32), sims.view(np.uint32))
+    got = _oracle.scan_threaded(lambda lo, hi: corpus[lo:hi], n, q, k, metric="l2", thr=0.02, slice_rows=650, threads=3)
+    for qi in range(nq):
+        rows, dist, sims = oracle.scan_l2(corpus, q[qi], k, 0.02)
+        assert np.array_equal(got[qi][0], rows) and np.array_equal(got[qi][2].view(np.uint32), dist.view(np.uint32))
+        assert np.array_equal(got[qi][1].view(np.uint32), sims.view(np.uint32))
+
+
 def test_l2_definitions_fp64_vs_fp32_accumulation_report(oracle, capsys):
     """L2 (BASELINE config 3) is PARITY-UNPINNED: the vec0 arithmetic lives in the absent sqlite-vec-cpp.  This repository
     defines it with fp64 accumulation; the dependency most likely accumulates in fp32.  Distances under both agree well

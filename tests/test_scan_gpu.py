@@ -1019,6 +1019,8 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
     # and against the CPU oracle (all host cores, row slices of the very tensor the GPU scanned,
     # comparator merge: tests/_oracle.py scan_threaded == one oracle call over the whole corpus)
     if n_oracle_queries:
+        if n_oracle_queries == "all":   # EVERY query of the batch (the batched oracle drivers: tests/_oracle.py, MANY_FROM)
+            n_oracle_queries = nq
         qsel_o = [int(x) for x in np.linspace(0, nq - 1, n_oracle_queries).round()]
         queries = tq[qsel_o].cpu().numpy()
         # the device generator is the oracle's Philox recipe: spot-check a slice at the far end
@@ -1035,17 +1037,21 @@ def _full_size(acc, oracle, n, d, nq, k, metric, n_oracle_queries):
 
 
 def test_full_size_config2_1Mx384_cosine_top100_q256(acc, oracle):
-    _full_size(acc, oracle, 1_000_000, 384, 256, 100, SCAN_COSINE, n_oracle_queries=2)
+    """BASELINE config 2, all 256 queries against the oracle over all 1M rows."""
+    _full_size(acc, oracle, 1_000_000, 384, 256, 100, SCAN_COSINE, n_oracle_queries="all")
 
 
 def test_full_size_config3_10Mx768_l2_top100_q1024(acc, oracle):
-    _full_size(acc, oracle, 10_000_000, 768, 1024, 100, SCAN_L2, n_oracle_queries=2)
+    """BASELINE config 3, all 1024 queries against the oracle over all 10M rows (the oracle's L2 is THIS repository's
+    fp64 definition: parity unpinned, oracle/yams_oracle.c)."""
+    _full_size(acc, oracle, 10_000_000, 768, 1024, 100, SCAN_L2, n_oracle_queries="all")
 
 
 def test_full_size_config4_shard_12p5Mx768_cosine_top100_q1024(acc, oracle):
-    """One row shard of BASELINE config 4 (100M x 768 over 8 GPUs) = the bench.py workload: the
-    bf16-shadow filter at Q = 1024 over 12.5M rows, three queries against the oracle over the full shard."""
-    _full_size(acc, oracle, 12_500_000, 768, 1024, 100, SCAN_COSINE, n_oracle_queries=3)
+    """One row shard of BASELINE config 4 (100M x 768 over 8 GPUs) = the bench.py workload: the int8-shadow filter at
+    Q = 1024 over 12.5M rows, EVERY one of the 1024 queries against the oracle over the full shard (rows, order, score
+    bits) — about a minute of the host's cores."""
+    _full_size(acc, oracle, 12_500_000, 768, 1024, 100, SCAN_COSINE, n_oracle_queries="all")
 
 
 def test_full_size_config4_shard_small_batch_takes_the_int8_stream(acc, oracle):
