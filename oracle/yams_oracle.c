@@ -482,45 +482,68 @@ typedef struct { double v[ORACLE_QB]; } __attribute__((aligned(64))) oracle_vq; 
 /* dot[j] = sum_i row[i] * qT[i][j], left to right over i (the :4256-4266 loop, QB queries at once);
  * d2[j] = sum_i (row[i] - q_j[i])^2 likewise (oracle_exact_scan_l2's loop).  Two builds of the same statements: 128-bit
  * lanes (every x86-64 / aarch64) and 256-bit lanes where the host has AVX2 — lane-wise IEEE either way. */
-#define ORACLE_RB 4 /* rows per kernel call: RB x QB independent chains hide the latency of the additions */
-#define ORACLE_QB_KERNELS(SUFFIX, VT, NV, ATTR)                                                                     \
+#define ORACLE_RB_MAX 8 /* rows per kernel call: RB x QB independent chains hide the latency of the additions */
+#define ORACLE_QB_KERNELS(SUFFIX, VT, NV, RB, ATTR)                                                                 \
     ATTR static void dots_qb_##SUFFIX(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {        \
-        VT acc[ORACLE_RB][NV];                                                                                        \
-        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                         \
+        VT acc[RB][NV];                                                                                               \
+        for (int r = 0; r < RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                                \
         for (size_t i = 0; i < dim; ++i) {                                                                            \
             const VT* q = (const VT*)qT[i].v;                                                                         \
-            for (int r = 0; r < ORACLE_RB; ++r) {                                                                     \
+            for (int r = 0; r < RB; ++r) {                                                                            \
                 const double sv = (double)row[r][i];                                                                  \
                 for (int v = 0; v < NV; ++v) acc[r][v] = acc[r][v] + sv * q[v];                                       \
             }                                                                                                         \
         }                                                                                                             \
-        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v)                                              \
+        for (int r = 0; r < RB; ++r) for (int v = 0; v < NV; ++v)                                                     \
             for (int l = 0; l < ORACLE_QB / NV; ++l) out[r * ORACLE_QB + v * (ORACLE_QB / NV) + l] = acc[r][v][l];    \
     }                                                                                                                 \
     ATTR static void sqdist_qb_##SUFFIX(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {      \
-        VT acc[ORACLE_RB][NV];                                                                                        \
-        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                         \
+        VT acc[RB][NV];                                                                                               \
+        for (int r = 0; r < RB; ++r) for (int v = 0; v < NV; ++v) acc[r][v] = (VT){0};                                \
         for (size_t i = 0; i < dim; ++i) {                                                                            \
             const VT* q = (const VT*)qT[i].v;                                                                         \
-            for (int r = 0; r < ORACLE_RB; ++r) {                                                                     \
+            for (int r = 0; r < RB; ++r) {                                                                            \
                 const double sv = (double)row[r][i];                                                                  \
                 for (int v = 0; v < NV; ++v) { const VT d = sv - q[v]; acc[r][v] = acc[r][v] + d * d; }               \
             }                                                                                                         \
         }                                                                                                             \
-        for (int r = 0; r < ORACLE_RB; ++r) for (int v = 0; v < NV; ++v)                                              \
+        for (int r = 0; r < RB; ++r) for (int v = 0; v < NV; ++v)                                                     \
             for (int l = 0; l < ORACLE_QB / NV; ++l) out[r * ORACLE_QB + v * (ORACLE_QB / NV) + l] = acc[r][v][l];    \
     }
-ORACLE_QB_KERNELS(v2, oracle_v2d, 4, )
+ORACLE_QB_KERNELS(v2, oracle_v2d, 4, 2, )
 #if defined(__x86_64__)
-ORACLE_QB_KERNELS(v4, oracle_v4d, 2, __attribute__((target("avx2"))))
-static int oracle_wide(void) { static int w = -1; if (w < 0) { __builtin_cpu_init(); w = __builtin_cpu_supports("avx2") ? 1 : 0; } return w; }
+typedef double oracle_v8d __attribute__((vector_size(64), aligned(64)));
+ORACLE_QB_KERNELS(v4, oracle_v4d, 2, 4, __attribute__((target("avx2"))))
+ORACLE_QB_KERNELS(v8, oracle_v8d, 1, 8, __attribute__((target("avx512f"))))
+/* 0: 128-bit lanes, 1: AVX2, 2: AVX-512 — the widest the host has, unless oracle_set_lanes() pinned a narrower one (the
+ * tests run all the host offers against the single-query functions) */
+static int oracle_width_pin = -1;
+static int oracle_width(void) {
+    static int have = -1;
+    if (have < 0) {
+        __builtin_cpu_init();
+        have = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+    }
+    return oracle_width_pin >= 0 && oracle_width_pin < have ? oracle_width_pin : have;
+}
+/* bits: 128 / 256 / 512, anything else = the widest available; returns the width in effect (not thread-safe: call it
+ * between scans) */
+ORACLE_API int oracle_set_lanes(int bits) {
+    oracle_width_pin = bits == 128 ? 0 : (bits == 256 ? 1 : (bits == 512 ? 2 : -1));
+    return 128 << oracle_width();
+}
+static int oracle_rb(void) { const int w = oracle_width(); return w == 2 ? 8 : (w == 1 ? 4 : 2); }
 static void dots_qb(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {
-    if (oracle_wide()) dots_qb_v4(row, qT, dim, out); else dots_qb_v2(row, qT, dim, out);
+    const int w = oracle_width();
+    if (w == 2) dots_qb_v8(row, qT, dim, out); else if (w == 1) dots_qb_v4(row, qT, dim, out); else dots_qb_v2(row, qT, dim, out);
 }
 static void sqdist_qb(const float* const* row, const oracle_vq* qT, size_t dim, double* out) {
-    if (oracle_wide()) sqdist_qb_v4(row, qT, dim, out); else sqdist_qb_v2(row, qT, dim, out);
+    const int w = oracle_width();
+    if (w == 2) sqdist_qb_v8(row, qT, dim, out); else if (w == 1) sqdist_qb_v4(row, qT, dim, out); else sqdist_qb_v2(row, qT, dim, out);
 }
 #else
+ORACLE_API int oracle_set_lanes(int bits) { (void)bits; return 128; }
+static int oracle_rb(void) { return 2; }
 #define dots_qb dots_qb_v2
 #define sqdist_qb sqdist_qb_v2
 #endif
@@ -552,6 +575,7 @@ ORACLE_API long oracle_exact_scan_cosine_many(const float* corpus, size_t n_rows
             qn[q] = sqrt(s);                                 /* :4211 */
         }
     double nsq[ORACLE_ROW_BLOCK]; int live[ORACLE_ROW_BLOCK];
+    const size_t rb = (size_t)oracle_rb();
     for (size_t r0 = 0; r0 < n_rows; r0 += ORACLE_ROW_BLOCK) {
         const size_t nb = n_rows - r0 < ORACLE_ROW_BLOCK ? n_rows - r0 : ORACLE_ROW_BLOCK;
         for (size_t b = 0; b < nb; ++b) {
@@ -565,17 +589,17 @@ ORACLE_API long oracle_exact_scan_cosine_many(const float* corpus, size_t n_rows
             nsq[b] = s; live[b] = finite && !(s <= 1e-12);   /* :4267-4269 */
         }
         for (size_t g = 0; g < ng; ++g)
-            for (size_t b0 = 0; b0 < nb; b0 += ORACLE_RB) {
-                const float* rp[ORACLE_RB]; int any = 0;
-                for (int t = 0; t < ORACLE_RB; ++t) {       /* (a short tail repeats its last row; dead rows are computed and dropped) */
+            for (size_t b0 = 0; b0 < nb; b0 += rb) {
+                const float* rp[ORACLE_RB_MAX]; int any = 0;
+                for (int t = 0; t < rb; ++t) {              /* (a short tail repeats its last row; dead rows are computed and dropped) */
                     const size_t b = b0 + t < nb ? b0 + t : nb - 1;
                     rp[t] = corpus + (r0 + b) * dim;
                     any |= b0 + t < nb && live[b0 + t];
                 }
                 if (!any) continue;
-                double dot[ORACLE_RB * ORACLE_QB];
+                double dot[ORACLE_RB_MAX * ORACLE_QB];
                 dots_qb(rp, qT + g * dim, dim, dot);
-                for (int t = 0; t < ORACLE_RB && b0 + t < nb; ++t) {
+                for (int t = 0; t < rb && b0 + t < nb; ++t) {
                     const size_t b = b0 + t;
                     if (!live[b]) continue;
                     const double root = sqrt(nsq[b]);
@@ -639,6 +663,7 @@ ORACLE_API long oracle_exact_scan_l2_many(const float* corpus, size_t n_rows, si
             for (size_t i = 0; i < dim; ++i) qT[g * dim + i].v[j] = q < nq ? (double)queries[q * dim + i] : 0.0;
         }
     int live[ORACLE_ROW_BLOCK];
+    const size_t rb = (size_t)oracle_rb();
     for (size_t r0 = 0; r0 < n_rows; r0 += ORACLE_ROW_BLOCK) {
         const size_t nb = n_rows - r0 < ORACLE_ROW_BLOCK ? n_rows - r0 : ORACLE_ROW_BLOCK;
         for (size_t b = 0; b < nb; ++b) {
@@ -648,17 +673,17 @@ ORACLE_API long oracle_exact_scan_l2_many(const float* corpus, size_t n_rows, si
             live[b] = finite;
         }
         for (size_t g = 0; g < ng; ++g)
-            for (size_t b0 = 0; b0 < nb; b0 += ORACLE_RB) {
-                const float* rp[ORACLE_RB]; int any = 0;
-                for (int t = 0; t < ORACLE_RB; ++t) {
+            for (size_t b0 = 0; b0 < nb; b0 += rb) {
+                const float* rp[ORACLE_RB_MAX]; int any = 0;
+                for (int t = 0; t < rb; ++t) {
                     const size_t b = b0 + t < nb ? b0 + t : nb - 1;
                     rp[t] = corpus + (r0 + b) * dim;
                     any |= b0 + t < nb && live[b0 + t];
                 }
                 if (!any) continue;
-                double d2[ORACLE_RB * ORACLE_QB];
+                double d2[ORACLE_RB_MAX * ORACLE_QB];
                 sqdist_qb(rp, qT + g * dim, dim, d2);
-                for (int t = 0; t < ORACLE_RB && b0 + t < nb; ++t) {
+                for (int t = 0; t < rb && b0 + t < nb; ++t) {
                     const size_t b = b0 + t;
                     if (!live[b]) continue;
                     for (int j = 0; j < ORACLE_QB; ++j) {

@@ -73,6 +73,8 @@ class Oracle:
         L.oracle_exact_scan_cosine_many.restype = C.c_long
         L.oracle_exact_scan_l2_many.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_size_t, i64p, f32p, f32p, u32p_]
         L.oracle_exact_scan_l2_many.restype = C.c_long
+        L.oracle_set_lanes.argtypes = [C.c_int]
+        L.oracle_set_lanes.restype = C.c_int
         L.oracle_exact_scan_l2_f32acc.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_float, u64p, C.c_int,
                                                   i64p, f32p, f32p]
         L.oracle_exact_scan_l2_f32acc.restype = C.c_long
@@ -141,6 +143,11 @@ class Oracle:
         rc = self.L.oracle_exact_scan_cosine_many(_ptr(corpus, f32p), n, d, _ptr(queries, f32p), nq, k, thr, _ptr(rows, i64p),
                                                   _ptr(sims, f32p), counts.ctypes.data_as(C.POINTER(C.c_uint32)))
         return None if rc < 0 else (rows, sims, counts)
+
+    def set_lanes(self, bits=0):
+        """Pin the vector width of the batched drivers (128 / 256 / 512 bits; 0 = the widest the host has); returns the
+        width in effect."""
+        return int(self.L.oracle_set_lanes(bits))
 
     def scan_l2_many(self, corpus, queries, k):
         """The k nearest rows of every query (distance asc, row asc) and their cosine — the vec0 cut; the cosine threshold

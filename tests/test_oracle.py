@@ -265,6 +265,16 @@ def test_batched_scan_drivers_equal_the_single_query_functions(oracle, n, d, nq,
     reference's known-answer tests pin: rows, order, score bits and counts of every query."""
     corpus = _hard_corpus(oracle, n, d, 11 + n) if n else np.zeros((0, d), np.float32)
     q = oracle.synth_rows(5, 1 << 40, nq, d)
+    widths = sorted({oracle.set_lanes(b) for b in (128, 256, 512)})     # every vector width this host offers
+    try:
+        for w in widths:
+            assert oracle.set_lanes(w) == w
+            _batched_equals_single(oracle, corpus, q, n, nq, k)
+    finally:
+        oracle.set_lanes(0)
+
+
+def _batched_equals_single(oracle, corpus, q, n, nq, k):
     if n:
         ok = [i for i in range(n) if np.isfinite(corpus[i]).all() and 0.01 < float(np.linalg.norm(corpus[i].astype(np.float64))) < 100.0]
         q[0] = corpus[ok[3]]                # a query that IS a row: similarity 1, distance 0, duplicates tie with it
