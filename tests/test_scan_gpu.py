@@ -80,7 +80,28 @@ def check(acc, oracle, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0
         assert r.diag["filter_tier"] == expect_tier, r.diag
     tr64 = None if tie_rank is None else tie_rank.astype(np.uint64)
     nq = queries.shape[0]
-    for qi in range(nq if max_queries is None else min(nq, max_queries)):
+    n_single = nq if max_queries is None else min(nq, max_queries)
+    # EVERY query of a larger batch through the batched oracle drivers (tests/test_oracle.py pins them to the
+    # single-query functions); `max_queries` then only bounds how many ALSO go through the single-query functions
+    if tie_rank is None and nq >= _oracle.MANY_FROM and n_single < nq:
+        many = oracle.scan_cosine_many(corpus, queries, k, thr) if metric == SCAN_COSINE else oracle.scan_l2_many(corpus, queries, k)
+        if many is not None:
+            for qi in range(nq):
+                if metric == SCAN_COSINE:
+                    cnt = int(many[2][qi]); rows, sims, dist = many[0][qi, :cnt], many[1][qi, :cnt], None
+                else:
+                    cnt = int(many[3][qi])
+                    keep = ~(many[2][qi, :cnt] < np.float32(thr))         # vec0: the k nearest, THEN the cosine threshold
+                    rows, dist, sims = many[0][qi, :cnt][keep], many[1][qi, :cnt][keep], many[2][qi, :cnt][keep]
+                cnt = int(r.counts[qi])
+                assert cnt == len(rows), (qi, cnt, len(rows), r.diag)
+                assert np.array_equal(r.rows[qi, :cnt], rows), (qi, r.rows[qi, :cnt][:10], rows[:10], r.diag)
+                assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), qi
+                if dist is not None:
+                    assert np.array_equal(r.dist[qi, :cnt].view(np.uint32), dist.view(np.uint32)), qi
+                assert (r.rows[qi, cnt:] == -1).all()
+            n_single = min(n_single, 2)
+    for qi in range(n_single):
         if metric == SCAN_COSINE:
             rows, sims, _, _ = oracle.scan_cosine(corpus, queries[qi], k, thr, tr64)
             dist = None
