@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from yams_amd.accel import Accel
 from yams_amd._lib import SCAN_COSINE, SCAN_L2, FLAG_FORCE_EXACT, FLAG_WIDE_TILE, FLAG_RESIDENT_QUERIES
+from yams_amd import _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
@@ -31,6 +32,8 @@ for case in range(a.cases):
     k = int(rng.choice([1, 5, 10, 50, 100, 200]))
     metric = SCAN_L2 if rng.random() < 0.3 else SCAN_COSINE
     thr = float(rng.choice([-1.0, 0.0, 0.1])) if metric == SCAN_COSINE else -1.0
+    # L2: the accumulate arithmetic the host names (fp64 / fp32 sequential / 8 / 16 lanes) rides on every form of the case
+    acc_flag = int(rng.choice([0, _lib.FLAG_L2_ACC_F32, _lib.FLAG_L2_ACC_F32X8, _lib.FLAG_L2_ACC_F32X16])) if metric == SCAN_L2 else 0
     tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 0, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 1 << 40, nq, d, tq.data_ptr())
     if rng.random() < 0.5:      # clustered: a few hundred near-copies of query 0 -> crowded top
@@ -74,8 +77,8 @@ for case in range(a.cases):
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         c = torch.empty(nq, dtype=torch.int32, device="cuda"); dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
         diag = acc.scan_topk_device(view8 if form in ("i8", "i8r") else view, tq.data_ptr(), nq, k, thr, metric, s.data_ptr(), r.data_ptr(), c.data_ptr(),
-                                    dist.data_ptr(), flags=FLAG_FORCE_EXACT if form == "exact" else
-                                    (FLAG_WIDE_TILE if form == "wide" else (FLAG_RESIDENT_QUERIES if form == "i8r" else 0)))
+                                    dist.data_ptr(), flags=acc_flag | (FLAG_FORCE_EXACT if form == "exact" else
+                                    (FLAG_WIDE_TILE if form == "wide" else (FLAG_RESIDENT_QUERIES if form == "i8r" else 0))))
         torch.cuda.synchronize()
         cn = c.cpu().numpy()
         sel = np.arange(k)[None, :] < cn[:, None]        # only the returned prefix is defined
@@ -89,7 +92,7 @@ for case in range(a.cases):
             ok = ok and (o[3] == ref[3]).all()
         if not ok:
             bad.append({"case": case, "form": form, "n": n, "d": d, "nq": nq, "k": k, "metric": int(metric), "thr": thr,
-                        "mask": mask_n, "diag": {kk: int(v) for kk, v in o[4].items()}})
+                        "mask": mask_n, "l2_acc": acc_flag, "diag": {kk: int(v) for kk, v in o[4].items()}})
     dg = out["default"][4]
     key = f"path{dg['path']}/widened{int(dg['widened_queries'] > 0)}/escalated{int(dg['escalated_queries'] > 0)}/fallback{int(dg['exact_fallback_queries'] > 0)}"
     paths[key] = paths.get(key, 0) + 1
