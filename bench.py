@@ -816,6 +816,20 @@ def c_abi_main(a):
     print(json.dumps(out))
 
 
+def plain_read_ceiling(achieved_gbps):
+    """What a plain streaming read reaches on an MI355X (scripts/ubench/hbm_read.hip, the builder's run committed under
+    profiles/): the practical ceiling beside the nominal 8 TB/s."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_read_ubench.json")), reverse=True):
+        try:
+            best = float(json.load(open(f))["best_GBps"])
+            return {"best_GBps": best, "source": os.path.relpath(f, ROOT),
+                    "frac_of_it": achieved_gbps / best if achieved_gbps else None}
+        except Exception:      # noqa: BLE001
+            continue
+    return None
+
+
 def hbm_leg_traffic(n, d, nq, i8):
     """HBM bytes per launch of the small-batch filter from the builder's PMC pass (profiles/*_small_batch_pmc.json),
     when it was taken on this very shape and kernel; labelled as such."""
@@ -1143,6 +1157,7 @@ def main():
                    "algorithmic_bytes_per_launch": byts, "launch_ms": f64_ms, "launches": f64_n,
                    "traffic": hbm_leg_traffic(n, d, q64, i8_64)[0], "traffic_source": hbm_leg_traffic(n, d, q64, i8_64)[1],
                    "ms_per_step": dt64 * 1e3, "qps_on_resident_corpus": q64 / dt64,
+                   "plain_read_ubench": plain_read_ceiling(byts / (f64_ms * 1e-3) / 1e9 if f64_ms else None),
                    "results_identical_to_the_q1024_run": same,
                    "bytes_definition": ("the bytes this sweep has to read: the 1-byte-per-element int8 shadow built at upload "
                                         "(+ 2 B bf16 shadow: 1.75x the fp32 rows resident per shard), NOT SURVEY 8(d)'s fp32 rows "
