@@ -1342,7 +1342,7 @@ def main():
                     and (n_filter_tiles + 1) // 2 >= 12 * n_streams)
         if resident:
             kname = ("scan_tiles_i8r_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "
-                     "workgroup of eight waves per CU, row fragments loaded straight into the register double buffer (LDS rings below 512 queries), "
+                     "workgroup of eight waves per CU, row fragments loaded straight into the register double buffer, "
                      "strips drawn per SIMD pair, exact integer accumulate)")
         else:
             kname = "scan_tiles_i8h_kernel<FILTER> (v_mfma_i32_16x16x64_i8 over the int8 shadow, 128 x 256 half tiles, two workgroups per CU, exact integer accumulate)"

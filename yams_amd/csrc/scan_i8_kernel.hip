@@ -1834,8 +1834,13 @@ hipError_t launch_i8_log_gather(hipStream_t st, const ScanLaunch& L) {
 // Bytes from HBM per launch at 768 x 1024: 17.4 GB / 10.2 GB (algorithmic 9.6: the ring runs three slabs ahead into
 // the next strip and the sibling workgroups of a stream drift further apart).  So: direct when a stream has four or
 // more query tiles — the rows then come from L2 seven times out of eight and one slab of latency cover is enough —
-// and the ring for the small batches whose rows come from HBM.
-static bool i8r_direct_rows(uint32_t dim, uint32_t n_qt) { (void)dim; return n_qt >= 4; }
+// and the ring for the small batches whose rows come from HBM.  That rule still stands for L2 batches (round 4, config 3:
+// 6.21 / 6.20 ms at 1024 queries, 1.25 / 1.24 at 64).  The COSINE direct form has since moved its thresholds and its
+// survivor buffer into the LDS the rings had used and looks at its siblings every 4th strip only, and wins at every
+// shape measured (round 4, same script, ring / direct): 64 queries dim 256 1.79 / 1.78, 384 0.82 / 0.77, 512 1.10 /
+// 1.08, 640 1.33 / 1.30, 768 1.58 / 1.54; 256 queries 1.29 / 1.29, 1.36 / 1.29, 1.69 / 1.63, 2.03 / 1.99, 2.38 / 2.30;
+// 384 queries 2.30 / 2.28, 1.86 / 1.80, 2.34 / 2.25, 2.82 / 2.71, 3.32 / 3.17 — cosine batches always take it.
+static bool i8r_direct_rows(uint32_t dim, uint32_t n_qt, bool l2) { (void)dim; return l2 ? n_qt >= 4 : true; }
 
 // Half tiles (128 rows x 256 queries), XCD-aware block -> tile map as for the bf16 tier.  version:
 // measurement build only — 40 = half tiles where the library would pick the resident-query form;
@@ -1855,7 +1860,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         return hipGetLastError();
     }
     const ResidentPlan rp = i8_resident_plan(L);
-    bool direct = i8r_direct_rows(L.plan.dim, rp.n_qt);
+    bool direct = i8r_direct_rows(L.plan.dim, rp.n_qt, L.i8_l2);
 #ifdef YAMS_ACCEL_MEASURE
     if (const char* dv = std::getenv("YAMS_ACCEL_I8R_DIRECT")) direct = std::atoi(dv) != 0;
 #endif
