@@ -1166,6 +1166,33 @@ def main():
                                        "the 2-byte-per-element bf16 shadow built at upload, not SURVEY 8(d)'s fp32 rows",
                    "fp32_rows_bytes": n * d * 4}
 
+    # ---- the same shard at 256 queries per batch (Q in {64, 256, 1024} on config 4's shard) ----------
+    q256_leg = None
+    if world == 1 and not a.no_hbm_leg and (tb is not None or t8 is not None) and bf16 and nq >= 256:
+        qm = 256
+        sm = torch.empty((qm, k), dtype=torch.float32, device=dev); rm = torch.empty((qm, k), dtype=torch.int64, device=dev)
+        cm = torch.empty(qm, dtype=torch.int32, device=dev)
+
+        def stepm():
+            acc.scan_topk_device(view, tq.data_ptr(), qm, k, -1.0, SCAN_COSINE, sm.data_ptr(), rm.data_ptr(), cm.data_ptr(),
+                                 flags=scan_flags, want_diag=False)
+        for _ in range(max(2, a.warmup)):
+            stepm()
+        acc.enable_timing(True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(a.steps):
+            stepm()
+        torch.cuda.synchronize(); dtm = (time.perf_counter() - t1) / a.steps
+        fm_ms, fm_n = acc.kernel_ms("scan_filter")
+        acc.enable_timing(False)
+        flops_m = 2.0 * qm * d * filt_rows
+        q256_leg = {"queries": qm, "ms_per_step": dtm * 1e3, "qps_on_resident_corpus": qm / dtm,
+                    "value": qm / dtm * (n / HEADLINE_ROWS), "unit": "QPS", "launch_ms": fm_ms, "launches": fm_n,
+                    "achieved_TOPs": flops_m / (fm_ms * 1e-3) / 1e12 if fm_ms else None,
+                    "achieved_GBps": (filt_rows * d) / (fm_ms * 1e-3) / 1e9 if fm_ms else None,
+                    "what": "one batch in flight (one lane): two query tiles per row stream, between the HBM-bound and the MFMA-bound end",
+                    "results_identical_to_the_q1024_run": bool(torch.equal(rm, res["rows"][:qm]) and torch.equal(sm, res["scores"][:qm]))}
+
     # ---- BASELINE config 3 on the same resident rows: 10M x 768, L2 top-k, 1024 queries, N = 1 ------
     # (a prefix of the shard and of its shadows — the blocked int8 shadow of the first 10M rows is a prefix too)
     l2_leg = None
@@ -1422,6 +1449,8 @@ def main():
         out["c_abi_sharded"] = c_abi
     if hbm_leg is not None:
         out["roofline_hbm_leg"] = hbm_leg
+    if q256_leg is not None:
+        out["config4_shard_q256"] = q256_leg
     if l2_leg is not None:
         out["config3_l2"] = l2_leg
     if check is not None:

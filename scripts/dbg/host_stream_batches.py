@@ -14,7 +14,7 @@ if os.environ.get("PRE_GIB"):      # what bench.py does before this leg: a devic
     if os.environ.get("PRE_INGEST", "1") == "1":
         acc.ingest_device(tb.data_ptr(), [i * blen for i in range(nb)], [blen] * nb, cdc_config("streaming"), flags=3); acc.synchronize()
     del tb; torch.cuda.empty_cache()
-host = torch.empty(n_blobs * blen, dtype=torch.uint8, pin_memory=True)
+host = torch.empty(n_blobs * blen, dtype=torch.uint8, pin_memory=not os.environ.get("PAGEABLE"))   # PAGEABLE=1: what a host that read files into ordinary buffers passes
 stage = torch.empty(256 * blen, dtype=torch.uint8, device="cuda")
 for b0 in range(0, n_blobs, 256):
     acc.synth_bytes(7, b0, 256, blen, stage.data_ptr()); acc.synchronize()
