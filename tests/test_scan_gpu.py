@@ -1641,6 +1641,21 @@ def test_randomised_self_consistency_of_all_scan_paths():
     assert any("widened1" in p for p in res["paths"]) and any(p.startswith("path1") for p in res["paths"]), res
 
 
+def test_soak_of_the_bench_configuration_is_deterministic():
+    """tests/soak_scan.py: the bench's shape (12.5M x 768 shard, 1024 queries, top-100, two lanes behind one sweep gate),
+    400 batches over four rotating query batches — every result bit-identical to the first result of its query batch
+    (races between lanes, in the persistent sweep's strip counters and pacing, in the candidate lists would show here;
+    1500 + 800 batches were run by hand in round 4: no difference)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_scan.py"), "--batches", "400"],
+                       capture_output=True, text=True, timeout=280)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res["batches"] == 400 and res["differences"] == 0, res
+
+
 def test_sweep_hold_keeps_the_gate_closed_until_the_collective_is_enqueued(oracle):
     """yams_accel_ctx_set_sweep_hold (the one-process-per-GPU form of the exchange fence): with the hold on, the
     gate stays closed behind a context's sweep — a second context's scan blocks at its own sweep until the first calls
