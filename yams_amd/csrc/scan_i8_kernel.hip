@@ -1866,7 +1866,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
 #endif
     if (L.i8_l2) { // L2 batches: the same two kernel forms with the row / query biases (no measurement forms)
         a.rows_i8_meta = L.i8_l2_meta; // the thresholds meta of the shard; the shadow's own meta is the gather kernel's
-        if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
+        // (the siblings' counters every 4th strip in the direct form, as for cosine below: config 3, 1024 queries, every strip /
+        //  4th / 8th: launch 6.17-6.18 / 6.05-6.15 / 6.16 ms)
+        uint32_t l2_pace_log2 = direct ? 2u : 0u;
+#ifdef YAMS_ACCEL_MEASURE
+        if (const char* pv = std::getenv("YAMS_ACCEL_I8R_L2_PACE_LOG2")) l2_pace_log2 = static_cast<uint32_t>(std::atoi(pv)) & 31u;
+#endif
+        const uint32_t l2_window = 1u | (l2_pace_log2 << 16);
+        if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, l2_window);
         else if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, 1u);
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
