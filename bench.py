@@ -731,6 +731,7 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
         stage = torch.empty((min(n, chunk), d), dtype=torch.float32, device=dev)
         ok = True
         upload_s = 0.0          # the corpus_append calls alone (pageable host memory -> mirror + shadows)
+        append_ms = []
         for r0 in range(0, n, chunk):
             m = min(chunk, n - r0)
             if tc_full is not None and d == a.dim and n == rows_c4:
@@ -741,6 +742,7 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
             ta = time.perf_counter()
             ok &= vt.corpus_append(None, cid, host.ctypes.data_as(_lib.f32p), m) == 0
             upload_s += time.perf_counter() - ta
+            append_ms.append((time.perf_counter() - ta) * 1e3)
         del stage
         staging_s = time.perf_counter() - t0 - upload_s     # this script's own D2H of the rows into fresh pageable arrays (round 3 counted it as upload)
         if not ok:
@@ -752,7 +754,8 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
                "upload_GBps": n * d * 4 / upload_s / 1e9 if upload_s > 0 else None,
                "upload_what": "the corpus_append calls alone: pageable host rows -> device mirror through the pinned staging ring, "
                               "device memory mapped behind the mirrors as they grow, bf16 + int8 shadows built",
-               "bench_host_staging_s": staging_s}
+               "bench_host_staging_s": staging_s,
+               "append_calls": len(append_ms), "append_ms_min_median_max": [round(min(append_ms), 2), round(sorted(append_ms)[len(append_ms) // 2], 2), round(max(append_ms), 2)]}
         for q in (1, 16, 1024):
             hits = C.POINTER(_lib.ScanHit)(); counts = _lib.u32p()
             reps = 30 if (n <= 1_000_000 or q < 1024) else 8
