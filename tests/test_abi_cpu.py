@@ -158,3 +158,26 @@ def test_product_sources_never_touch_the_oracle():
                     if re.search(r"(?<![\w/])oracle(/|_)|libyams_oracle|libyams_ref|_oracle\b", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_integration_index_names_every_exported_entry_point():
+    """INTEGRATION.md section 8 lists the flat C ABI entry point by entry point (with the reference interface each stands
+    in for); a symbol added to the library has to appear there.  The table abbreviates families as
+    `yams_x_create / _destroy`: a `_suffix` replaces trailing components of the name in front of it."""
+    import re
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 8. Index of the flat C ABI"):]
+    names = set()
+    for cell in re.findall(r"`([^`]+)`", sec):
+        base = None
+        for part in (p.strip() for p in re.split(r"\s*/\s*|,\s*", cell)):
+            if part.startswith("yams_"):
+                names.add(part); base = part
+            elif part.startswith("_") and base:
+                toks = base.split("_")
+                for cut in range(len(toks) - 1, 1, -1):
+                    cand = "_".join(toks[:cut]) + part
+                    if cand in _lib.EXPORTS:
+                        names.add(cand); break
+    missing = [e for e in _lib.EXPORTS if e not in names]
+    assert not missing, missing
