@@ -164,9 +164,10 @@ def test_integration_index_names_every_exported_entry_point():
     """INTEGRATION.md section 8 lists the flat C ABI entry point by entry point (with the reference interface each stands
     in for); a symbol added to the library has to appear there.  The table abbreviates families as
     `yams_x_create / _destroy`: a `_suffix` replaces trailing components of the name in front of it."""
-    import re
+    from yams_amd import _lib
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     sec = doc[doc.index("## 8. Index of the flat C ABI"):]
+    assert set(_lib.EXPORTS) == declared_functions()      # (the list the index is held against is the header's)
     names = set()
     for cell in re.findall(r"`([^`]+)`", sec):
         base = None
