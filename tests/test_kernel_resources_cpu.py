@@ -64,7 +64,7 @@ def test_direct_row_loads_are_not_touched_while_in_flight():
     write those registers: checked on the assembly in program order (a linear walk; the kernel's loops are the unrolled
     slab pairs, so program order is what matters between a load and its wait)."""
     kernels = {k: v for k, v in _kernels("scan_i8_kernel.hip").items() if "scan_tiles_i8r_kernel" in k and "ELb1ELi" in k}   # <ABL, L2, DIRECT = true, ZSM>
-    assert len(kernels) == 2, list(kernels)      # cosine and L2
+    assert len(kernels) == 3, list(kernels)      # the cosine filter, the L2 filter, the cosine SAMPLE pass
 
     def regs(tok):
         tok = tok.strip().split()[0] if tok.strip() else ""

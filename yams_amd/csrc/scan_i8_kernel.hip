@@ -548,9 +548,15 @@ static_assert(R_ZS_LOG + 8 * R_ZS_ENTRIES * 12 <= R_LDS, "the survivor buffers m
 // ZSM: which of these a launch uses (measured one by one) — 1 zero-start accumulators + thresholds from LDS, 4 survivors
 // to the LDS buffer, 8 the siblings' counters are looked at every eighth strip only, 16 no drain at the strip's end (the
 // strip counters are requested in the last slab but one, every slab waits for its own fragments)
-template <int ABL = 0, bool L2 = false, bool DIRECT = false, int ZSM = 0>
+// SAMPLE (round 4; cosine, DIRECT, plain strip boundary): the SAMPLE pass in this form — the strips are those of the sample
+// tiles (every stride-th tile), the accumulators start at zero and the epilogue writes the group maxima the half-tile
+// kernel's MODE_SAMPLE writes (the same two fmaf per element, the same group numbering: gmax feeds tau_select and
+// i8_collect_sample_kernel unchanged).  The half-tile form re-stages the query tile for every 128 rows — 1.2 GB of
+// queries for 0.15 GB of sample rows at the bench shape.
+template <int ABL = 0, bool L2 = false, bool DIRECT = false, int ZSM = 0, bool SAMPLE = false>
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
     static_assert(ZSM == 0 || (DIRECT && !L2 && ABL == 0), "the short strip boundary exists for the direct cosine kernel");
+    static_assert(!SAMPLE || (DIRECT && !L2 && ABL == 0 && ZSM == 0), "the sample pass exists in the plain direct cosine form");
     static_assert(!(ZSM & 16) || ((ZSM & 1) && (ZSM & 4)), "no drain needs the thresholds and the survivors in LDS");
     constexpr bool Z0 = (ZSM & 1) != 0, ZT = (ZSM & 2) != 0, ZL = (ZSM & 4) != 0, ZN = (ZSM & 16) != 0;
     static_assert(!(ZT && Z0), "2 = the plain form with its threshold halves in LDS (1 has them there anyway)");
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const uint32_t sel = un_ < n_units ? 2u * un_ + (k & 1u) : 0xffffffffu;
         uint64_t row0 = past_end;
         if (sel < a.n_sel_tiles) {
-            const uint32_t tile = sel + sel / (a.stride - 1u) + 1u;
+            const uint32_t tile = SAMPLE ? sel * a.stride : sel + sel / (a.stride - 1u) + 1u;
             row0 = static_cast<uint64_t>(tile) * I8_ROWS + static_cast<uint32_t>((wid & 3) * 64);
         }
         g.row0 = row0;
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     }
-    if (!Z0) qthr_request();
+    if (!Z0 && !SAMPLE) qthr_request();
     if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
@@ -721,7 +727,13 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m0)));
         eb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m1)));
     }
-    if (Z0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else qthr_wait();
+    // SAMPLE: {t_q, c_q, f_q, 0} of the tile's 128 queries, resident in the LDS the direct form's ring does not use (the
+    // epilogue reads a query block's four floats back: holding them in registers for the launch cost seven spill slots)
+    if (SAMPLE && tid < R_QUERIES)
+        reinterpret_cast<float4*>(lds + R_ZS_THR)[tid] = reinterpret_cast<const float4*>(a.q_meta)[q0 + static_cast<uint32_t>(tid)]; // < q_pad: the table is padded
+    if (Z0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (SAMPLE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else qthr_wait();
     if (ZT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stash of the threshold halves)
     __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
     zt_ready = true;
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     uint32_t units_read = 0;
 #endif
 
-    constexpr bool THR = ABL == 0 || ABL == 8 || ABL == 9;
+    constexpr bool THR = (ABL == 0 || ABL == 8 || ABL == 9) && !SAMPLE;
     int nt[8]; // -T(this strip, query block cb): what the accumulators of the unit start at
     auto thresholds = [&]() __attribute__((always_inline)) {
         const float is = 1.0f / sb, g = eb * is; // (the same expressions as in i8_log_gather_kernel)
@@ -989,6 +1001,34 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 // stops pacing for the rest of the launch rather than pay the timeout at every strip
                 if (polls == R_POLLS) pacing = false;
             }
+        } else if (SAMPLE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the drain of the plain form: strip counters, the next strip's first fragments
+            k_new = take_result();
+            const uint32_t sel_c = 2u * u + (k_cur & 1u);    // the sample tile of this strip
+            if (sel_c < a.n_sel_tiles) {
+                const float ninf = -__builtin_inff();
+                const uint32_t gid = (sel_c * static_cast<uint32_t>(I8_ROWS) + static_cast<uint32_t>((wid & 3) * 64)) / 16u + static_cast<uint32_t>(lq);
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const uint32_t qi = q0 + static_cast<uint32_t>(cb * 16 + l15);
+                    const float4 qm = reinterpret_cast<const float4*>(lds + R_ZS_THR)[cb * 16 + l15];
+                    const float S = sb_cur * qm.x, K = fmaf(eb_cur, qm.y, qm.z); // (as in the half-tile kernel's MODE_SAMPLE)
+                    float m = ninf;
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const uint64_t rbase = strip + static_cast<uint32_t>(16 * rb + 4 * lq);
+                        const uint32_t mw = a.row_mask ? mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u) : 0xfu;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float uu = fmaf(static_cast<float>(acc[rb][cb][r]), S, K);
+                            m = fmaxf(m, (rbase + r < a.n_rows && ((mw >> r) & 1u)) ? uu : ninf);
+                        }
+                    }
+                    if (qi < a.n_queries) a.gmax[static_cast<uint64_t>(qi) * a.n_groups + gid] = (m != m) ? 0xffffffffu : f2ord(m);
+                }
+            }
+            sb = __uint_as_float(static_cast<uint32_t>(meta_n));
+            eb = __uint_as_float(static_cast<uint32_t>(meta_n >> 32));
         } else { // measurement builds: keep the accumulators alive, emit nothing
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             k_new = take_result();
@@ -1070,7 +1110,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     }
     if (ZL) zs_flush();
     // (the lane id is derived again: holding it over the launch cost the direct form its 256th register and a scratch slot)
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u && ABL == 0) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u && ABL == 0 && !SAMPLE) a.log_cnt[log_region] = log_pos < a.log_cap ? log_pos : a.log_cap;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring's last (unused) pieces must land before the LDS is handed back
 #ifdef YAMS_ACCEL_MEASURE
     if (lane == 0 && n_qt <= 8) { // measurement build: when each wave started and ended (100 MHz ticks) and how many strips it took
@@ -1757,7 +1797,9 @@ hipError_t launch_i8_collect_sample(hipStream_t st, const ScanLaunch& L) {
 
 uint64_t i8_sync_words(const ScanLaunch& L) {
     const ResidentPlan r = i8_resident_plan(L);
-    return r.use ? static_cast<uint64_t>(r.n_streams) * 12u * 32u : 0u; // [n_streams][4 pairs][32] strip counters (+ [n_streams][8][32] for the measurement build's timestamps)
+    // [n_streams][4 pairs][32] strip counters (+ [n_streams][8][32] for the measurement build's timestamps), twice: the
+    // filter launch's, then those of a sample pass in the resident form
+    return r.use ? static_cast<uint64_t>(r.n_streams) * 12u * 32u * 2u : 0u;
 }
 
 // entries per log region.  Half tiles: a wave tile is 64 rows x 128 queries and the threshold admits about
@@ -1854,12 +1896,27 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
     a.n_sel_tiles = mode == MODE_SAMPLE ? L.plan.n_sample_tiles : L.plan.n_filter_tiles;
     if (a.n_sel_tiles == 0) return hipSuccess;
     const uint32_t hgrid = ((2u * a.n_sel_tiles + 7) / 8) * a.n_qtiles * 8;
+    const ResidentPlan rp = i8_resident_plan(L);
     if (mode == MODE_SAMPLE) {
-        if (L.i8_l2) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
+        // Cosine batches whose filter pass takes the resident-query form sample in it too, when every row stream gets at
+        // least four units of sample tiles (the bench: 763 sample tiles = 382 units over 32 streams per query tile; a
+        // batch of one query tile has 256 streams and keeps the half-tile kernel, as do short shards and L2 batches)
+        const uint32_t s_units = (L.plan.n_sample_tiles + 1u) / 2u;
+        // (a caller that forces the resident form — YAMS_SCAN_FLAG_RESIDENT_QUERIES, the tests' small shards — gets its
+        //  sample pass in that form whatever the stream length)
+        bool resident_sample = rp.use && !L.i8_l2 && L.i8_sync && L.plan.sample_stride >= 2 &&
+                               (L.i8_form == 2 ? s_units >= 1u : s_units >= 4u * rp.n_streams);
+#ifdef YAMS_ACCEL_MEASURE
+        if (const char* sv = std::getenv("YAMS_ACCEL_I8R_SAMPLE")) resident_sample = resident_sample && std::atoi(sv) != 0;
+        if (version != 2 && version != 3 && version != 0) resident_sample = false; // (the A/B kernel forms keep the half-tile sample pass)
+#endif
+        if (resident_sample) {
+            a.i8_sync = L.i8_sync + i8_sync_words(L) / 2u; // its own strip counters (zeroed with the filter's)
+            hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 0, true>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, s_units, rp.n_qt, rp.n_streams, 1u);
+        } else if (L.i8_l2) hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE, 0, YAMS_SCAN_L2>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_SAMPLE>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
-    const ResidentPlan rp = i8_resident_plan(L);
     bool direct = i8r_direct_rows(L.plan.dim, rp.n_qt, L.i8_l2);
 #ifdef YAMS_ACCEL_MEASURE
     if (const char* dv = std::getenv("YAMS_ACCEL_I8R_DIRECT")) direct = std::atoi(dv) != 0;
