@@ -12,6 +12,11 @@ streams and the collective."""
 from __future__ import annotations
 
 import os
+import time
+
+
+class CollectiveTimeout(RuntimeError):
+    """An exchange (all-gather + merge) did not complete within GatherPipeline.watchdog_s."""
 
 
 def shard_bounds(n_rows: int, world: int) -> list[int]:
@@ -100,10 +105,16 @@ class GatherPipeline:
         if self.active:
             self.gathered = [torch.zeros((self.world, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(depth)]
             self.merged = [torch.zeros(self.rec_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
-            self.done = [torch.cuda.Event() if on_gpu else None for _ in range(depth)]
+            self.done = [torch.cuda.Event(enable_timing=True) if on_gpu else None for _ in range(depth)]
+            self.begun = [torch.cuda.Event(enable_timing=True) if on_gpu else None for _ in range(depth)]
             self.busy = [False] * depth
             self._keep = [None] * depth
         self.merge_fn = None
+        # what the N > 1 bench line reports about the exchange: device time from the head of the all-gather to the
+        # tail of the merge on the side stream (events), per batch; and a deadline after which a collective that
+        # has not completed is declared stuck (CollectiveTimeout) instead of eating the caller's own timeout
+        self.exchange_ms_sum, self.exchange_ms_max, self.exchanges = 0.0, 0.0, 0
+        self.watchdog_s = 30.0
 
     # -- views ---------------------------------------------------------------------------------------
     def _views(self, buf, lead=()):
@@ -135,6 +146,7 @@ class GatherPipeline:
         torch, dist = self.torch, self.dist
         rec, out = self.rec[slot], self.gathered[slot]
         if self.backend == "gloo":      # CPU tests / single-GPU dry runs: the collective runs on the host
+            t_h = time.perf_counter()
             src = rec.cpu()
             parts = [torch.empty_like(src) for _ in range(self.world)]
             dist.all_gather(parts, src)
@@ -146,9 +158,11 @@ class GatherPipeline:
             self._keep[slot] = g        # (allocated on the current stream, read on the side stream)
             if self.done[slot] is not None:
                 self.done[slot].record(self.side)
+            self._host_ms = (time.perf_counter() - t_h) * 1e3
             self.busy[slot] = True
             return
         with torch.cuda.stream(self.side):
+            self.begun[slot].record(self.side)
             work = dist.all_gather_into_tensor(out, rec, async_op=True)
             work.wait()                 # the side stream waits for RCCL's stream; the host does not
             self.merge_fn(self._views(out, (self.world,)), self._views(self.merged[slot]))
@@ -158,9 +172,34 @@ class GatherPipeline:
     def wait(self, slot):
         if not self.active or not self.busy[slot]:
             return
+        ms = None
         if self.done[slot] is not None:
-            self.done[slot].synchronize()
+            ev = self.done[slot]
+            if not ev.query():          # poll under a deadline: a collective whose peer never arrives must not hang the job
+                deadline = time.monotonic() + self.watchdog_s
+                while not ev.query():
+                    if time.monotonic() > deadline:
+                        raise CollectiveTimeout(
+                            f"all-gather + merge of slot {slot} not complete after {self.watchdog_s:.0f} s "
+                            f"(backend {self.backend}, world {self.world}, rank {self.dist.get_rank()}, {self.rec_bytes} B per rank, "
+                            f"{self.exchanges} exchanges completed before it): a peer rank is missing or the link is down")
+                    time.sleep(0.0002)
+            if self.backend != "gloo":
+                ms = self.begun[slot].elapsed_time(ev)
+        if ms is None:
+            ms = getattr(self, "_host_ms", None)
+        if ms is not None:
+            self.exchange_ms_sum += ms; self.exchange_ms_max = max(self.exchange_ms_max, ms); self.exchanges += 1
         self.busy[slot] = False
+
+    def reset_exchange_stats(self):
+        self.exchange_ms_sum, self.exchange_ms_max, self.exchanges = 0.0, 0.0, 0
+
+    def exchange_stats(self):
+        """{exchanges, exchange_ms (mean), exchange_ms_max}: device time of all-gather + merge per batch on the side stream
+        (gloo dry runs: host time of the staged collective + merge launch)."""
+        n = self.exchanges
+        return {"exchanges": n, "exchange_ms": self.exchange_ms_sum / n if n else None, "exchange_ms_max": self.exchange_ms_max if n else None}
 
     def drain(self):
         for s in range(self.depth):
