@@ -101,7 +101,7 @@ def compact_line(out):
     ca = out.get("c_abi_sharded")
     if ca:
         c["c_abi_sharded"] = _pick(ca, ("n_devices", "collective", "communicator_ranks", "collectives", "batches", "ms_per_step", "value",
-                                        "exchange_ms", "identical_to_the_timed_step", "error"))
+                                        "exchange_ms", "launch_ms_min", "launch_ms_max", "identical_to_the_timed_step", "error"))
         if "error" in c["c_abi_sharded"]:
             c["c_abi_sharded"]["error"] = _short(c["c_abi_sharded"]["error"], 200)
         m = ca.get("merged_equals_host_merge_of_per_shard_results")
@@ -193,6 +193,9 @@ def parse():
     # dry-run aids (NOT the contract): run the N>1 code path on a box with one GPU
     ap.add_argument("--dist-backend", default=None, help="override the collective backend (gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry runs only)")
+    ap.add_argument("--watchdog-s", type=float, default=30.0,
+                    help="N > 1: an exchange (all-gather + merge) that has not completed after this many seconds aborts the run "
+                         "with a one-line diagnosis and exit status 3")
     ap.add_argument("--extra-json", default=None, help="where the full result object goes (default: bench_extra.json beside this file)")
     return ap.parse_args()
 
@@ -746,20 +749,30 @@ def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, orac
     # every lane runs once before the timed region (a lane's first batch sizes its workspace and pinned staging: with
     # the default --warmup 2 and three lanes that first batch used to sit inside the timed steps)
     run(max(a.warmup, lanes), 0)
-    timed_ctx = [sh.lane_ctx(0, l) for l in range(lanes)]
-    for c in timed_ctx:
-        c.enable_timing(True)
+    timed_ctx = [[sh.lane_ctx(i, l) for l in range(lanes)] for i in range(world)]
+    for cs in timed_ctx:
+        for c in cs:
+            c.enable_timing(True)
+    info0 = sh.info()
     got = {}
     t0 = time.perf_counter()
     run(a.steps, a.warmup, collect=got)
     dt = time.perf_counter() - t0
-    tot, cnt = 0.0, 0
-    for c in timed_ctx:
-        ms, n_ = c.kernel_ms("scan_filter")
-        if ms is not None and n_:
-            tot += ms * n_; cnt += n_
-        c.enable_timing(False)
-    filt_ms = tot / cnt if cnt else None
+    info1 = sh.info()
+    per_shard_ms = []          # mean filter-sweep launch per shard (a spread says which GPU is the slow one)
+    for cs in timed_ctx:
+        tot, cnt = 0.0, 0
+        for c in cs:
+            ms, n_ = c.kernel_ms("scan_filter")
+            if ms is not None and n_:
+                tot += ms * n_; cnt += n_
+            c.enable_timing(False)
+        per_shard_ms.append(tot / cnt if cnt else None)
+    filt_ms = per_shard_ms[0]
+    have_ms = [m for m in per_shard_ms if m is not None]
+    # the exchange over the timed batches alone: device time of all-gather + merge + download on the root's side stream
+    ex_n = info1.get("exchanges_timed", 0) - info0.get("exchanges_timed", 0)
+    ex_ms = ((info1.get("exchange_ms", 0.0) * info1.get("exchanges_timed", 0) - info0.get("exchange_ms", 0.0) * info0.get("exchanges_timed", 0)) / ex_n) if ex_n else None
     last = a.warmup + a.steps - 1
     res = got[last]
     digests = {}
@@ -780,12 +793,18 @@ def c_abi_sharded_run(a, devices, views=None, keep=None, n_query_batches=4, orac
     out = {"what": "one process, yams_scan_sharded_* (C ABI): persistent shard workers, one RCCL communicator, one ncclAllGather "
                    "of the packed records + merge_topk_kernel per batch on a side stream, submit/wait lanes; queries and "
                    "results in host memory (pinned staging + PCIe both ways inside the timed region)",
-           "n_devices": world, "devices": list(devices), "lanes": lanes, "collective": info.get("collective"),
+           "n_devices": world, "devices": list(devices), "lanes": lanes, "collective": info.get("collective"), "fenced": info.get("fenced"),
            "rccl_version": info.get("rccl_version"), "rccl_library": info.get("rccl_library"),
            "communicator_ranks": info.get("communicator_ranks"), "rccl_unavailable": info.get("rccl_unavailable"),
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
            "qps_on_resident_corpus": nq * a.steps / dt, "value": nq * a.steps / dt * (n * world / HEADLINE_ROWS), "unit": "QPS",
-           "filter_launch_ms_shard0": filt_ms, "collectives": sh.info().get("collectives"),
+           "filter_launch_ms_shard0": filt_ms, "collectives": sh.info().get("collectives"), "batches": sh.info().get("batches"),
+           "timed_batches": a.steps, "timed_collectives": info1.get("collectives", 0) - info0.get("collectives", 0),
+           "exchange_ms": ex_ms, "exchange_ms_max": info1.get("exchange_ms_max"), "exchanges_timed": ex_n,
+           "exchange_what": "events on the root shard's side stream: all-gather + merge + download per batch (the wait for the slowest peer included)",
+           "exchange_timeout_ms": info1.get("exchange_timeout_ms"), "communicator_ranks_source": info.get("communicator_ranks_source"),
+           "launch_ms_per_shard": per_shard_ms, "launch_ms_min": min(have_ms) if have_ms else None,
+           "launch_ms_max": max(have_ms) if have_ms else None,
            "merged_equals_host_merge_of_per_shard_results": {"queries": nchk, "ok": exch_ok},
            "result_digests": digests, "setup_s": setup_s, "distinct_query_batches": n_query_batches}
     if oracle_queries > 0:
@@ -930,7 +949,12 @@ def c_abi_main(a):
            "roofline": {"bound": "mfma", "kernel": "scan_tiles_i8r_kernel (shard 0's lanes)", "achieved": ach, "peak": PEAK_I8_MFMA_TOPS,
                         "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS if ach else None, "launch_ms": r["filter_launch_ms_shard0"],
                         "traffic": None},
-           "c_abi_sharded": r}
+           "c_abi_sharded": r,
+           "collective": {"backend": f"{r.get('collective')} (one process, C ABI)", "communicator_ranks": r.get("communicator_ranks"),
+                          "collectives": r.get("timed_collectives"), "batches": r.get("timed_batches"),
+                          "exchange_ms": r.get("exchange_ms"), "exchange_ms_max": r.get("exchange_ms_max"),
+                          "launch_ms_min": r.get("launch_ms_min"), "launch_ms_max": r.get("launch_ms_max"),
+                          "fenced": r.get("fenced"), "watchdog_s": (r.get("exchange_timeout_ms") or 0) / 1e3}}
     for kk in ("recall_at_k", "bit_exact_vs_oracle", "oracle_queries"):
         if kk in r:
             out[kk] = r[kk]
@@ -981,7 +1005,8 @@ def main():
 
     if a.single_device:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = ydist.init_from_env(a.dist_backend)
+    with ydist.Deadline("rendezvous of the ranks (init_process_group)", 300):
+        rank, world, local = ydist.init_from_env(a.dist_backend)
     assert world == max(1, a.gpus) or world == 1, (world, a.gpus)
     if not a.single_device and local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({torch.cuda.device_count()} visible); "
@@ -1042,6 +1067,11 @@ def main():
                                         g["counts"].data_ptr(), None, None, out["scores"].data_ptr(),
                                         out["rows"].data_ptr(), out["counts"].data_ptr(), None)
         pipe.merge_fn = merge_fn
+        pipe.watchdog_s = a.watchdog_s
+        # the communicator's first collective (RCCL builds its rings / trees here): apart from the steps, under its own deadline
+        with ydist.Deadline(f"first collective of the {world}-rank communicator ({torch.distributed.get_backend()})", 300):
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
 
     scan_flags = 4 if a.f32_filter else (8 if a.split_filter else 0)   # YAMS_SCAN_FLAG_F32_FILTER / _SPLIT_FILTER
     if a.half_tile:
@@ -1124,20 +1154,37 @@ def main():
                 raise errs[0]
         return (first + count - 1) % lanes
 
+    progress = {"phase": "setup"}
+
     def fence():
-        pipe.drain()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        with ydist.Deadline("fence (drain + barrier + device synchronize)", 4 * a.watchdog_s, detail=lambda: progress):
+            pipe.drain()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    def guarded_steps(count, phase):
+        # a run of steps can only hang in an exchange a peer never joins (GatherPipeline.wait raises CollectiveTimeout
+        # after watchdog_s) or under a device that stopped answering: one line of diagnosis, exit 3, no silent hang
+        progress["phase"] = phase
+        try:
+            with ydist.Deadline(f"{count} steps ({phase})", 4 * a.watchdog_s + 0.5 * count,
+                                detail=lambda: {**progress, "batches_issued": batch_no[0], "exchanges_done": pipe.exchanges}):
+                return run_steps(count)
+        except ydist.CollectiveTimeout as e:
+            sys.stderr.write(f"[yams_amd watchdog] rank {rank}/{world}: {e}\n"); sys.stderr.flush()
+            os._exit(3)
 
     if a.warmup:
-        run_steps(a.warmup)
+        guarded_steps(a.warmup, "warmup")
     fence()
     for c in accs:
         c.enable_timing(True)
+    pipe.reset_exchange_stats()
     fence(); t0 = time.perf_counter()
-    last_slot = run_steps(a.steps)
+    last_slot = guarded_steps(a.steps, "timed steps")
     fence(); dt = time.perf_counter() - t0
+    ex_stats = pipe.exchange_stats()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -1151,6 +1198,11 @@ def main():
         return (tot / cnt if cnt else None), cnt
     filt_ms, filt_n = lane_kernel_ms("scan_filter")
     samp_ms, samp_n = lane_kernel_ms("scan_sample")
+    rank_stats = [{"rank": rank, "launch_ms": filt_ms, **ex_stats}]
+    if world > 1:       # every rank's sweep time and view of the exchange: a bad scaling curve can be attributed
+        allr = [None] * world
+        torch.distributed.all_gather_object(allr, rank_stats[0])
+        rank_stats = allr
     for c in accs:
         c.enable_timing(False)
     res = {kk: v.clone() for kk, v in pipe.result(last_slot).items()}   # the merged top-k of the LAST TIMED step
@@ -1577,7 +1629,17 @@ def main():
     if check is not None:
         out.update(check)
     if world > 1:
+        lm = [r_["launch_ms"] for r_ in rank_stats if r_.get("launch_ms") is not None]
+        em = [r_["exchange_ms"] for r_ in rank_stats if r_.get("exchange_ms") is not None]
         out["collective"] = {"backend": torch.distributed.get_backend(), "bytes_per_rank": pipe.rec_bytes,
+                             "communicator_ranks": torch.distributed.get_world_size(),
+                             "collectives": ex_stats["collectives"], "batches": a.steps,
+                             "exchange_ms": (sum(em) / len(em)) if em else None,
+                             "exchange_ms_max": max((r_["exchange_ms_max"] or 0.0) for r_ in rank_stats) if rank_stats else None,
+                             "exchange_what": "per batch, on each rank's side stream: events around all_gather_into_tensor + merge_topk_kernel "
+                                              "(the wait for the slowest rank's scan included); mean over ranks, max over ranks and batches",
+                             "launch_ms_min": min(lm) if lm else None, "launch_ms_max": max(lm) if lm else None,
+                             "per_rank": rank_stats, "watchdog_s": a.watchdog_s,
                              "side_stream": pipe.side is not None and torch.distributed.get_backend() != "gloo",
                              "fenced": bool(gate is not None and pipe.active),
                              "fence": "the sweep gate stays closed behind a lane's sweep until that lane has enqueued its all-gather + merge: "

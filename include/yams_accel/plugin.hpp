@@ -23,6 +23,8 @@ inline ErrorCode mapStatus(yams_status_t st) {
         case YAMS_ERR_IO: return ErrorCode::IOError;
         case YAMS_ERR_INTERNAL: return ErrorCode::InternalError;
         case YAMS_ERR_UNSUPPORTED: return ErrorCode::NotImplemented;
+        case YAMS_ERR_TIMEOUT: return ErrorCode::Timeout;
+        case YAMS_ERR_RESOURCE_EXHAUSTED: return ErrorCode::ResourceExhausted;
         default: return ErrorCode::Unknown;
     }
 }

@@ -59,7 +59,9 @@ enum yams_status_e {
     YAMS_ERR_NOT_FOUND = 2,
     YAMS_ERR_IO = 3,
     YAMS_ERR_INTERNAL = 4,
-    YAMS_ERR_UNSUPPORTED = 5
+    YAMS_ERR_UNSUPPORTED = 5,
+    YAMS_ERR_TIMEOUT = 6,            /* a sharded batch missed its deadline: the handle is stuck (see yams_scan_sharded_wait) */
+    YAMS_ERR_RESOURCE_EXHAUSTED = 7  /* device (or pinned host) memory could not be had; the object is left as it was */
 };
 #endif
 
@@ -395,6 +397,11 @@ typedef struct yams_scan_sharded_options_s {
                                  ncclGetErrorString with RCCL's signatures (a site build of RCCL; the test suite's
                                  stream-ordered stand-in, which lets several ranks share one device).  The string
                                  is copied. */
+    uint32_t exchange_timeout_ms; /* deadline of wait(): a batch whose scan + exchange has not completed by then makes
+                                 wait() return YAMS_ERR_TIMEOUT with a diagnosis in ..._last_error, the communicator is
+                                 aborted and the handle is STUCK (submit fails, destroy does not block).  0 = 30000;
+                                 UINT32_MAX = wait for ever (the round-4 behaviour) */
+    uint32_t reserved0;
 } yams_scan_sharded_options_t;
 YAMS_ACCEL_API yams_status_t yams_scan_sharded_create(const int* devices, uint32_t n_shards,
                                                       yams_scan_sharded** out);
@@ -403,8 +410,10 @@ YAMS_ACCEL_API yams_status_t yams_scan_sharded_create_ex(const int* devices, uin
                                                          yams_scan_sharded** out);
 YAMS_ACCEL_API uint32_t yams_scan_sharded_lanes(const yams_scan_sharded* s);
 /* {"shards":n,"lanes":l,"devices":[..],"collective":"rccl"|"peer_copy"|"none","fenced":true|false,"rccl_version":..,
- *  "rccl_library":"<path the symbols came from>","batches":..,"collectives":..}; malloc'd, release with
- * yams_accel_free_string. */
+ *  "rccl_library":"<path the symbols came from>","communicator_ranks":<ncclCommCount of the root's communicator>,
+ *  "batches":..,"collectives":..,"exchanges_timed":..,"exchange_ms":<mean device time of all-gather + merge + download
+ *  on the root shard's side stream, the wait for the slowest peer included>,"exchange_ms_max":..,
+ *  "exchange_timeout_ms":..,"stuck":true|false}; malloc'd, release with yams_accel_free_string. */
 YAMS_ACCEL_API yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char** out_json);
 /* The context lane `lane` uses on shard `shard` (kernel timings of a pipelined run; the plugin's per-call
  * row masks live in its workspace).  yams_scan_sharded_ctx(s, i) is lane 0's. */

@@ -19,9 +19,14 @@
 //     its own worker thread in the product, as in any thread-per-rank use of RCCL).
 // Fault injection for the tests (environment, read per communicator at ncclCommInitAll):
 //   YAMS_STUB_COLL_FAIL_AT=c     collective number c (0-based) moves no data and returns ncclSystemError on every rank.
+//   YAMS_STUB_COLL_STALL_AT=c    collective number c never completes on any rank's stream (a host function parked on the
+//                                stream, as a collective kernel spins when a peer never joins) — until ncclCommAbort
+//                                or ncclCommDestroy, or two minutes, whichever comes first.
+// Also exported, optional for the caller: ncclCommCount, ncclCommAbort (RCCL's signatures).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -48,9 +53,26 @@ struct Group {
     std::vector<hipEvent_t> ready, done;   // per rank
     bool mismatch = false;
     uint64_t calls = 0;                    // collectives completed
-    long fail_at = -1;
+    long fail_at = -1, stall_at = -1;
     int alive = 0;
+    bool released = false;                 // abort / destroy: parked streams go on
+    int parked = 0;                        // host functions still inside park()
 };
+
+// the stalled collective: parked on the stream until the communicator is aborted or destroyed
+void park(void* p) {
+    Group* g = static_cast<Group*>(p);
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->released; });
+    --g->parked;
+    g->cv.notify_all();
+}
+
+void release_parked(Group* g, std::unique_lock<std::mutex>& lk) {
+    g->released = true;
+    g->cv.notify_all();
+    g->cv.wait_for(lk, std::chrono::seconds(10), [&] { return g->parked == 0; });
+}
 
 // all n ranks meet here; returns after the last one has arrived (classic generation barrier)
 void barrier(Group& g, std::unique_lock<std::mutex>& lk) {
@@ -94,6 +116,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitAll(ncclComm_t* 
     g->send.assign(ndev, nullptr); g->recv.assign(ndev, nullptr); g->bytes.assign(ndev, 0); g->stream.assign(ndev, nullptr);
     g->ready.assign(ndev, nullptr); g->done.assign(ndev, nullptr);
     if (const char* f = std::getenv("YAMS_STUB_COLL_FAIL_AT")) g->fail_at = std::atol(f);
+    if (const char* f = std::getenv("YAMS_STUB_COLL_STALL_AT")) g->stall_at = std::atol(f);
     int before = 0;
     (void)hipGetDevice(&before);
     for (int i = 0; i < ndev; ++i) {
@@ -112,7 +135,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c
     if (!comm) return ncclInvalidArgument;
     Group* g = comm->g;
     bool last;
-    { std::lock_guard<std::mutex> lk(g->mu); last = --g->alive == 0; }
+    { std::unique_lock<std::mutex> lk(g->mu); release_parked(g, lk); last = --g->alive == 0; }
     delete comm;
     if (last) {
         for (int i = 0; i < g->n; ++i) {
@@ -124,6 +147,15 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c
     }
     return ncclSuccess;
 }
+
+__attribute__((visibility("default"))) ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->g->n;
+    return ncclSuccess;
+}
+
+// RCCL's abort frees the communicator as well: so does this one
+__attribute__((visibility("default"))) ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }
 
 __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype,
                                                                   ncclComm_t comm, hipStream_t stream) {
@@ -140,6 +172,10 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* se
     bool bad = g.mismatch;
     for (int j = 0; j < g.n; ++j) bad |= g.bytes[j] != bytes;
     const bool inject = g.fail_at >= 0 && static_cast<uint64_t>(g.fail_at) == call;
+    if (g.stall_at >= 0 && static_cast<uint64_t>(g.stall_at) == call && !g.released) {
+        ++g.parked;
+        if (hipLaunchHostFunc(stream, park, &g) != hipSuccess) { (void)hipGetLastError(); --g.parked; }
+    }
     // phase 2: every rank copies every part into its own receive buffer, on its own stream
     if (!bad && !inject) {
         lk.unlock();

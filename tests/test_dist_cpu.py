@@ -29,3 +29,24 @@ def test_gloo_sharded_search_matches_oracle(world, monkeypatch):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["ok"] and out["world"] == world and out["bounds"] == [3000 * g // world for g in range(world + 1)]
+
+
+def test_deadline_fires_once_with_a_one_line_diagnosis_and_not_when_the_block_finishes():
+    import time
+    fired = []
+    with ydist.Deadline("a block that finishes", 5.0, on_expire=fired.append):
+        pass
+    with ydist.Deadline("a collective nobody joins", 0.2, on_expire=fired.append, detail=lambda: {"exchanges_done": 7}):
+        time.sleep(0.6)
+    time.sleep(0.1)
+    assert len(fired) == 1 and "\n" not in fired[0]
+    assert "a collective nobody joins" in fired[0] and "exchanges_done" in fired[0] and "0 s" in fired[0]
+
+
+def test_deadline_without_a_handler_exits_the_process_with_status_3():
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); from yams_amd import dist as d\n"
+            "with d.Deadline('barrier', 0.2):\n    time.sleep(30)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "[yams_amd watchdog]" in r.stderr and "'barrier'" in r.stderr, (r.returncode, r.stderr)

@@ -278,3 +278,61 @@ def test_plugin_door_over_the_all_gather_path(accel_lib, oracle, stub):
     assert shard_info["collective"] == "rccl" and "stub_coll" in shard_info["rccl_library"] and shard_info["collectives"] >= 3, js
     assert vt.corpus_destroy(None, cid) == 0
     L.yams_plugin_shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_exchange_fields_of_the_info_record(oracle, stub):
+    """What the N > 1 bench line reports about the exchange comes from here: the communicator's rank count as the library
+    itself counts it (ncclCommCount), one timed exchange per batch (events on the root shard's side stream around
+    all-gather + merge + download), collectives == batches."""
+    ranks, n, d, k = 4, 4 * 5000, 256, 10
+    corpus = oracle.synth_rows(81, 0, n, d)
+    q = oracle.synth_rows(81, 1 << 40, 40, d)
+    sh = _handle(stub, ranks, 2)
+    keep, views = _views(sh, corpus, d, ranks)
+    for _ in range(6):
+        _check(oracle, corpus, q[:3], sh.topk(views, q[:3], k, -1.0, SCAN_COSINE), k, -1.0, SCAN_COSINE)
+    info = sh.info()
+    assert info["communicator_ranks"] == ranks and info["communicator_ranks_source"] == "ncclCommCount", info
+    assert info["batches"] == info["collectives"] == info["exchanges_timed"] == 6, info
+    assert 0.0 < info["exchange_ms"] <= info["exchange_ms_max"] < 1000.0, info
+    assert info["exchange_timeout_ms"] == 30000 and info["stuck"] is False, info
+    sh.close()
+
+
+@pytest.mark.timeout(600)
+def test_a_collective_that_never_completes_trips_the_deadline(oracle, stub, monkeypatch):
+    """Collective number 2 never completes on any rank's stream (the stub parks a host function there, as an RCCL kernel
+    spins when a peer never joins).  wait() must come back within the deadline with YAMS_ERR_TIMEOUT and a diagnosis,
+    not hang; the handle is stuck (submit refuses at once), destroy returns promptly (the communicator was aborted,
+    the parked streams drain), and a fresh handle on the same devices serves oracle-exact results afterwards."""
+    ranks, n, d, k = 4, 4 * 4200, 256, 10
+    corpus = oracle.synth_rows(82, 0, n, d)
+    q = oracle.synth_rows(82, 1 << 40, 5, d)
+    monkeypatch.setenv("YAMS_STUB_COLL_STALL_AT", "2")
+    sh = _handle(stub, ranks, 2, exchange_timeout_ms=1500)
+    monkeypatch.delenv("YAMS_STUB_COLL_STALL_AT")
+    keep, views = _views(sh, corpus, d, ranks)
+    for _ in range(2):
+        _check(oracle, corpus, q, sh.topk(views, q, k, -1.0, SCAN_COSINE), k, -1.0, SCAN_COSINE)
+    t0 = time.time()
+    with pytest.raises(_lib.AccelError) as e:
+        sh.topk(views, q, k, -1.0, SCAN_COSINE)
+    took = time.time() - t0
+    assert e.value.status == _lib.YAMS_ERR_TIMEOUT, str(e.value)
+    assert 1.4 < took < 20.0, took
+    msg = str(e.value)
+    assert "batch 2" in msg and "1500 ms" in msg and "4 ranks" in msg, msg
+    info = sh.info()
+    assert info["stuck"] is True and info["exchanges_timed"] == 2, info
+    with pytest.raises(_lib.AccelError) as e2:
+        sh.topk(views, q, k, -1.0, SCAN_COSINE)
+    assert e2.value.status == _lib.YAMS_ERR_TIMEOUT and "stuck" in str(e2.value), str(e2.value)
+    t0 = time.time()
+    sh.close()
+    assert time.time() - t0 < 30.0
+    del keep
+    sh = _handle(stub, ranks, 2)
+    keep, views = _views(sh, corpus, d, ranks)
+    _check(oracle, corpus, q, sh.topk(views, q, k, -1.0, SCAN_COSINE), k, -1.0, SCAN_COSINE)
+    sh.close()

@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libyams_mi355x_accel.so")
 
 YAMS_OK, YAMS_ERR_INVALID_ARG, YAMS_ERR_NOT_FOUND, YAMS_ERR_IO, YAMS_ERR_INTERNAL, \
-    YAMS_ERR_UNSUPPORTED = range(6)
-STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NOT_FOUND", 3: "IO", 4: "INTERNAL", 5: "UNSUPPORTED"}
+    YAMS_ERR_UNSUPPORTED, YAMS_ERR_TIMEOUT, YAMS_ERR_RESOURCE_EXHAUSTED = range(8)
+STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "NOT_FOUND", 3: "IO", 4: "INTERNAL", 5: "UNSUPPORTED", 6: "TIMEOUT",
+                7: "RESOURCE_EXHAUSTED"}
 SCAN_COSINE, SCAN_L2 = 0, 1
 CDC_RABIN, CDC_STREAMING = 0, 1
 FLAG_DEFER_THRESHOLD, FLAG_FORCE_EXACT, FLAG_F32_FILTER, FLAG_SPLIT_FILTER, FLAG_RECORD_PATH = 1, 2, 4, 8, 16
@@ -51,7 +52,7 @@ class ScanCorpus(C.Structure):
 
 class ShardedOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("collective", C.c_uint32), ("fence", C.c_uint32),
-                ("rccl_library", C.c_char_p)]
+                ("rccl_library", C.c_char_p), ("exchange_timeout_ms", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 SHARDED_COLLECTIVE_AUTO, SHARDED_COLLECTIVE_RCCL, SHARDED_COLLECTIVE_PEER = 0, 1, 2

@@ -125,9 +125,11 @@ class ShardedScan:
     `ctx(i)` is an Accel bound to shard i's lane-0 context — upload the shard's rows and build its shadows
     through it.  collective: "auto" | "rccl" (require the communicator, also for one shard) | "peer";
     rccl_library: the collective library to bind instead of librccl.so.1 (the tests' stand-in lets ranks share a
-    device); fence=False lifts the exchange fence (measurements)."""
+    device); fence=False lifts the exchange fence (measurements); exchange_timeout_ms: the deadline of wait()
+    (0 = 30 s; a batch that misses it raises AccelError TIMEOUT and the handle is stuck)."""
 
-    def __init__(self, devices, lanes: int = 0, collective: str = "auto", rccl_library: str | None = None, fence: bool = True):
+    def __init__(self, devices, lanes: int = 0, collective: str = "auto", rccl_library: str | None = None, fence: bool = True,
+                 exchange_timeout_ms: int = 0):
         self.L = _lib.load()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
@@ -135,7 +137,7 @@ class ShardedScan:
                                   {"auto": _lib.SHARDED_COLLECTIVE_AUTO, "rccl": _lib.SHARDED_COLLECTIVE_RCCL,
                                    "peer": _lib.SHARDED_COLLECTIVE_PEER}[collective],
                                   _lib.SHARDED_FENCE_AUTO if fence else _lib.SHARDED_FENCE_OFF,
-                                  rccl_library.encode() if rccl_library else None)
+                                  rccl_library.encode() if rccl_library else None, exchange_timeout_ms, 0)
         st = self.L.yams_scan_sharded_create_ex(arr, len(devices), C.byref(opt), C.byref(h))
         if st != 0:
             raise AccelError(st, "yams_scan_sharded_create_ex failed")

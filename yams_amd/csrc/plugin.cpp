@@ -1105,6 +1105,9 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
             if (p && (p = std::strchr(p, '"'))) { const char* e = std::strchr(p + 1, '"'); if (e) library.assign(p + 1, e); }
         }
         if (!library.empty()) so.rccl_library = library.c_str();
+        // "exchange_timeout_ms": deadline of a sharded batch (default 30000; a batch that misses it fails with
+        // YAMS_ERR_TIMEOUT and the sharded handle is stuck until the plugin is shut down and initialised again)
+        so.exchange_timeout_ms = static_cast<uint32_t>(std::max<long>(0, json_int(config_json, "\"exchange_timeout_ms\"", 0)));
         if (const char* p = config_json ? std::strstr(config_json, "\"fence\"") : nullptr)
             if (const char* c = std::strchr(p + 7, ':')) { while (*++c == ' ') {} if (std::strncmp(c, "\"off\"", 5) == 0) so.fence = YAMS_SHARDED_FENCE_OFF; }
         if (yams_scan_sharded_create_ex(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &so, &g.sharded) != YAMS_OK)

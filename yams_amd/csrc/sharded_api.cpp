@@ -30,6 +30,15 @@
 //     buys is that no collective ever shares a device with a sweep.  (accel_ctx.h: before_sweep.)
 //   * the contexts of one device share a sweep gate (yams_accel_gate): big filter sweeps run one after the
 //     other, everything around them overlaps.
+//   * THE DEADLINE.  A collective whose peer never arrives spins on the device for ever; a host that waits for it
+//     with hipEventSynchronize hangs with it.  wait() therefore polls under a deadline (options.exchange_timeout_ms,
+//     30 s by default): when a batch's workers or its exchange have not finished by then the handle is declared
+//     STUCK — wait() returns YAMS_ERR_TIMEOUT with a one-line diagnosis (which shards, which batch, how many
+//     exchanges completed before it), the communicator is aborted (ncclCommAbort, when the library has it) so that
+//     the spinning kernels leave the devices, every later submit() fails at once, and destroy() returns without
+//     waiting for work that cannot finish (what cannot be freed safely is leaked, and said so on stderr).
+//   * what the exchange costs is measured per batch: events on the root shard's side stream around all-gather +
+//     merge + download (`exchange_ms` in ..._info_json; it includes the wait for the slowest peer's scan).
 // The collective library is bound at run time (dlopen of librccl.so.1, or of the library the options name, when
 // the first communicator is needed): a host that hashes files or searches one GPU never maps the 570 MB of RCCL.
 // Shards that SHARE a device (the parity tests on a one-GPU box) cannot form an RCCL communicator — RCCL refuses
@@ -41,6 +50,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +137,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;   // optional
+    decltype(&ncclCommAbort) CommAbort = nullptr;   // optional
     int version = 0;
     std::string path, error;
     bool ok() const { return handle != nullptr; }
@@ -167,6 +179,8 @@ Rccl& rccl(const std::string& wanted) {
     if (!r.GetVersion || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
         dlclose(r.handle); r.handle = nullptr; return r;
     }
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));
     r.error.clear();
     (void)r.GetVersion(&r.version);
     Dl_info info{};
@@ -205,6 +219,9 @@ struct Lane {
     unsigned char* h_out = nullptr; size_t h_out_cap = 0;   // pinned: counts | scores | rows | dist of the merged result
     yams_accel_ctx* merge_ctx = nullptr;                    // root device, bound to the root's side stream
     hipEvent_t done = nullptr;                              // merged result has landed in h_out
+    hipEvent_t ex_begin = nullptr;                          // head of the exchange on the root shard's side stream
+    bool ex_timed = false;
+    std::vector<char> reported;                             // per shard: its worker is through with the batch
     std::vector<ShardLane> sh;
 };
 
@@ -241,6 +258,11 @@ struct yams_scan_sharded {
     bool stop = false;
     std::string last_error, fallback_reason;
     std::atomic<uint64_t> batches{0}, collectives{0}, fence_waits{0};
+    // the exchange as the root shard's side stream saw it (events): all-gather + merge + download, per batch
+    std::atomic<uint64_t> exchanges_timed{0}, exchange_us_sum{0}, exchange_us_max{0};
+    uint32_t timeout_ms = 30000;                 // the deadline of wait(); UINT32_MAX: none
+    bool stuck = false;                          // a batch missed the deadline (under mu)
+    std::string stuck_why;
 };
 
 namespace {
@@ -339,6 +361,7 @@ yams_status_t exchange_shard(yams_scan_sharded* s, Lane& L, uint32_t i, yams_sta
         std::unique_lock<std::mutex> lk(s->mu);
         s->cv_turn.wait(lk, [&] { return s->coll_next[i] == L.seq; });
     }
+    if (i == 0) L.ex_timed = L.ex_begin && hipEventRecord(L.ex_begin, SL.side) == hipSuccess;
     try {
         if (s->mode == kRccl) {
             const ncclResult_t r = s->R->AllGather(SL.rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
@@ -415,16 +438,50 @@ void worker_main(yams_scan_sharded* s, uint32_t i, uint32_t li) {
         {
             std::lock_guard<std::mutex> lk(s->mu);
             L.st[i] = st; L.err[i] = std::move(err);
+            L.reported[i] = 1;
             if (--L.pending == 0) s->cv_done.notify_all();
         }
+    }
+}
+
+// A batch missed the deadline: the handle is stuck.  Abort the communicator so that spinning collective kernels leave
+// the devices (RCCL: ncclCommAbort); the streams behind them drain, the workers report, destroy() can run.
+void declare_stuck(yams_scan_sharded* s, const std::string& why) {
+    bool first;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        first = !s->stuck;
+        s->stuck = true;
+        if (first) s->stuck_why = why;
+        s->last_error = why;
+    }
+    if (!first) return;
+    std::fprintf(stderr, "[yams_mi355x_accel] sharded search STUCK: %s\n", why.c_str());
+    if (s->mode == kRccl && s->R && s->R->CommAbort) {
+        int before = 0;
+        (void)hipGetDevice(&before);
+        for (uint32_t i = 0; i < s->comm.size(); ++i)
+            if (s->comm[i]) { (void)hipSetDevice(s->device[i]); (void)s->R->CommAbort(s->comm[i]); s->comm[i] = nullptr; }
+        (void)hipSetDevice(before);
     }
 }
 
 void destroy_handle(yams_scan_sharded* s) {
     {
         std::unique_lock<std::mutex> lk(s->mu);
-        // batches in flight run to their end first (their collectives need every rank)
-        s->cv_done.wait(lk, [&] { for (auto& L : s->lanes) if (L->submitted && L->pending) return false; return true; });
+        // batches in flight run to their end first (their collectives need every rank) — unless the handle is stuck:
+        // then they get a few seconds to drain behind the aborted communicator, and what has not drained is leaked
+        auto idle = [&] { for (auto& L : s->lanes) if (L->submitted && L->pending) return false; return true; };
+        if (!s->stuck) s->cv_done.wait(lk, idle);
+        else if (!s->cv_done.wait_for(lk, std::chrono::seconds(5), idle)) {
+            std::fprintf(stderr, "[yams_mi355x_accel] destroy of a stuck sharded handle: workers still blocked, resources leaked\n");
+            s->stop = true;
+            lk.unlock();
+            s->cv_job.notify_all();
+            for (auto& L : s->lanes)
+                for (auto& SL : L->sh) if (SL.worker.joinable()) SL.worker.detach();
+            return; // (the handle and what hangs on it stay allocated: threads may still touch them)
+        }
         s->stop = true;
     }
     s->cv_job.notify_all();
@@ -444,6 +501,7 @@ void destroy_handle(yams_scan_sharded* s) {
         (void)hipSetDevice(s->device[0]);
         if (L->merge_ctx) yams_accel_ctx_destroy(L->merge_ctx); // bound to the root's side stream, which it does not own
         if (L->done) (void)hipEventDestroy(L->done);
+        if (L->ex_begin) (void)hipEventDestroy(L->ex_begin);
         if (L->h_queries) (void)hipHostFree(L->h_queries);
         if (L->h_out) (void)hipHostFree(L->h_out);
         for (uint32_t i = 0; i < L->sh.size(); ++i) {
@@ -466,14 +524,15 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
     if (!out) return YAMS_ERR_INVALID_ARG;
     *out = nullptr;
     if (!devices || n_shards == 0 || n_shards > 64) return YAMS_ERR_INVALID_ARG;
-    uint32_t n_lanes = 2, collective = YAMS_SHARDED_COLLECTIVE_AUTO, fence = YAMS_SHARDED_FENCE_AUTO;
+    uint32_t n_lanes = 2, collective = YAMS_SHARDED_COLLECTIVE_AUTO, fence = YAMS_SHARDED_FENCE_AUTO, timeout_ms = 30000;
     std::string library;
     if (opt) {
         if (opt->struct_size < 16) return YAMS_ERR_INVALID_ARG; // (16: the round-3 struct — lanes, collective, one reserved word)
         if (opt->lanes) n_lanes = opt->lanes;
         collective = opt->collective;
         fence = opt->fence;
-        if (opt->struct_size >= sizeof(yams_scan_sharded_options_t) && opt->rccl_library) library = opt->rccl_library;
+        if (opt->struct_size >= offsetof(yams_scan_sharded_options_t, exchange_timeout_ms) && opt->rccl_library) library = opt->rccl_library;
+        if (opt->struct_size >= sizeof(yams_scan_sharded_options_t) && opt->exchange_timeout_ms) timeout_ms = opt->exchange_timeout_ms;
     }
     if (n_lanes > 16 || collective > YAMS_SHARDED_COLLECTIVE_PEER || fence > YAMS_SHARDED_FENCE_OFF) return YAMS_ERR_INVALID_ARG;
     const int n_dev = yams_accel_device_count();
@@ -487,7 +546,7 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
     if (collective == YAMS_SHARDED_COLLECTIVE_RCCL && !distinct && library.empty()) return YAMS_ERR_INVALID_ARG;
 
     auto* s = new yams_scan_sharded();
-    s->n = n_shards; s->n_lanes = n_lanes;
+    s->n = n_shards; s->n_lanes = n_lanes; s->timeout_ms = timeout_ms;
     s->device.assign(devices, devices + n_shards);
     s->coll_next.assign(n_shards, 0);
     auto bail = [&](yams_status_t st) { destroy_handle(s); return st; };
@@ -538,7 +597,7 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
         }
         (void)hipSetDevice(devices[0]);
         if (yams_accel_ctx_create(devices[0], L.sh[0].side, &L.merge_ctx) != YAMS_OK) return bail(YAMS_ERR_INTERNAL);
-        if (hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return bail(YAMS_ERR_INTERNAL); }
+        if (hipEventCreate(&L.done) != hipSuccess || hipEventCreate(&L.ex_begin) != hipSuccess) { (void)hipGetLastError(); return bail(YAMS_ERR_INTERNAL); }
     }
     if (s->mode == kPeer) {
         // records travel device-to-device: enable peer access towards the merge device where the
@@ -588,6 +647,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
     Lane& L = *s->lanes[lane];
     {
         std::lock_guard<std::mutex> lk(s->mu);
+        if (s->stuck) { s->last_error = "the handle is stuck (" + s->stuck_why + "): destroy it"; return YAMS_ERR_TIMEOUT; }
         if (!L.acquired || L.submitted) { s->last_error = "lane is not acquired, or its batch has not been waited for"; return YAMS_ERR_INVALID_ARG; }
     }
     if (!shards || !params) return set_error(s, YAMS_ERR_INVALID_ARG, "null shards/params");
@@ -635,6 +695,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         std::memcpy(L.h_queries, queries_host, nq * dim * 4);
         L.views.assign(shards, shards + n);
         L.st.assign(n, YAMS_OK); L.err.assign(n, std::string());
+        L.reported.assign(n, 0); L.ex_timed = false;
         L.dg.assign(n, yams_scan_diag_t{});
     }
     // One shard and a handful of queries (the reference's everyday call is ONE query): latency is the product, and two
@@ -680,17 +741,31 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
     {
         std::unique_lock<std::mutex> lk(s->mu);
         if (!L.acquired || !L.submitted) { s->last_error = "nothing was submitted on this lane"; return YAMS_ERR_INVALID_ARG; }
-        s->cv_done.wait(lk, [&] { return L.trivial || L.pending == 0; });
+        auto through = [&] { return L.trivial || L.pending == 0; };
+        if (s->timeout_ms == UINT32_MAX) s->cv_done.wait(lk, through);
+        else if (!s->cv_done.wait_for(lk, std::chrono::milliseconds(s->timeout_ms), through)) {
+            // the lane stays acquired + submitted: its buffers are still in use by whatever hangs
+            std::ostringstream os;
+            os << "batch " << (L.ordered ? L.seq : 0) << " on lane " << lane << ": shard(s)";
+            for (uint32_t i = 0; i < s->n; ++i) if (!L.reported[i]) os << ' ' << i << "(device " << s->device[i] << ")";
+            os << " not through scan + exchange after " << s->timeout_ms << " ms (collective "
+               << (s->mode == kRccl ? "rccl" : (s->mode == kPeer ? "peer_copy" : "none")) << ", " << s->n << " ranks, "
+               << s->collectives.load() << " exchanges issued before): a rank is missing from a collective, or a device hangs";
+            lk.unlock();
+            declare_stuck(s, os.str());
+            return YAMS_ERR_TIMEOUT;
+        }
     }
     // from here on the lane goes back to the pool on EVERY path, an exception included (a lane that stays acquired
     // would, once all of them are gone, block the next caller in lane_acquire for good)
     struct Release {
         yams_scan_sharded* s; Lane& L; yams_status_t st = YAMS_ERR_INTERNAL; std::string msg = "exception while a batch was collected";
+        bool keep = false;
         ~Release() {
             {
                 std::lock_guard<std::mutex> lk(s->mu);
                 if (st != YAMS_OK) s->last_error = msg;
-                L.acquired = L.submitted = false;
+                if (!keep) L.acquired = L.submitted = false;
             }
             s->cv_lane.notify_one();
         }
@@ -703,7 +778,37 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
         if (nq) std::memset(out_counts_host, 0, nq * 4);
         return release(YAMS_OK, "");
     }
-    if (L.merge_issued) (void)hipEventSynchronize(L.done); // also when a shard failed: the lane's buffers must be quiet before reuse
+    if (L.merge_issued) {   // also when a shard failed: the lane's buffers must be quiet before reuse
+        if (s->timeout_ms == UINT32_MAX) (void)hipEventSynchronize(L.done);
+        else {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(s->timeout_ms);
+            unsigned spins = 0;
+            for (;;) {
+                const hipError_t e = hipEventQuery(L.done);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) { (void)hipGetLastError(); break; }
+                if (std::chrono::steady_clock::now() > deadline) {
+                    std::ostringstream os;
+                    os << "batch " << L.seq << " on lane " << lane << ": all-gather + merge not complete on the root shard (device "
+                       << s->device[0] << ") after " << s->timeout_ms << " ms (collective " << (s->mode == kRccl ? "rccl" : "peer_copy")
+                       << ", " << s->n << " ranks, " << s->exchanges_timed.load() << " exchanges completed before): a peer never "
+                          "joined the collective, or the link is down";
+                    rel.keep = true; // buffers still in use: the lane is not handed out again
+                    declare_stuck(s, os.str());
+                    return release(YAMS_ERR_TIMEOUT, os.str());
+                }
+                if (++spins < 2000) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+        float ms = 0.f;
+        if (L.ex_timed && hipEventElapsedTime(&ms, L.ex_begin, L.done) == hipSuccess && ms >= 0.f) {
+            const uint64_t us = static_cast<uint64_t>(ms * 1000.0f + 0.5f);
+            ++s->exchanges_timed; s->exchange_us_sum += us;
+            uint64_t prev = s->exchange_us_max.load();
+            while (us > prev && !s->exchange_us_max.compare_exchange_weak(prev, us)) {}
+        } else (void)hipGetLastError();
+    }
     for (uint32_t i = 0; i < s->n; ++i)
         if (L.st[i] != YAMS_OK) return release(L.st[i], L.err[i]); // a batch fails as a whole (:1635-1647)
     if (s->mode != kNone && L.merge_st != YAMS_OK) return release(L.merge_st, L.merge_err);
@@ -778,15 +883,28 @@ extern "C" yams_status_t yams_scan_sharded_info_json(yams_scan_sharded* s, char*
            << ",\"fenced\":" << (s->fenced ? "true" : "false");
         if (s->mode == kRccl && s->R) {
             const Rccl& R = *s->R;
-            os << ",\"rccl_version\":" << R.version << ",\"rccl_library\":\"" << R.path << "\",\"communicator_ranks\":" << s->comm.size();
+            int ranks = static_cast<int>(s->comm.size());
+            const char* src = "handle";
+            if (R.CommCount && !s->comm.empty() && s->comm[0]) { int c = 0; if (R.CommCount(s->comm[0], &c) == ncclSuccess) { ranks = c; src = "ncclCommCount"; } }
+            os << ",\"rccl_version\":" << R.version << ",\"rccl_library\":\"" << R.path << "\",\"communicator_ranks\":" << ranks
+               << ",\"communicator_ranks_source\":\"" << src << "\"";
         }
         if (!s->fallback_reason.empty()) {
             std::string r = s->fallback_reason;
             for (char& ch : r) if (ch == '"' || ch == '\\' || ch == '\n') ch = ' ';
             os << ",\"rccl_unavailable\":\"" << r << "\"";
         }
+        const uint64_t ex = s->exchanges_timed.load();
         os << ",\"batches\":" << s->batches.load() << ",\"collectives\":" << s->collectives.load()
-           << ",\"fence_waits\":" << s->fence_waits.load() << "}";
+           << ",\"fence_waits\":" << s->fence_waits.load() << ",\"exchanges_timed\":" << ex
+           << ",\"exchange_ms\":" << (ex ? static_cast<double>(s->exchange_us_sum.load()) / 1000.0 / static_cast<double>(ex) : 0.0)
+           << ",\"exchange_ms_max\":" << static_cast<double>(s->exchange_us_max.load()) / 1000.0
+           << ",\"exchange_timeout_ms\":" << s->timeout_ms;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            os << ",\"stuck\":" << (s->stuck ? "true" : "false");
+        }
+        os << "}";
         const std::string str = os.str();
         char* buf = static_cast<char*>(std::malloc(str.size() + 1));
         if (!buf) return YAMS_ERR_INTERNAL;

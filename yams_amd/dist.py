@@ -19,6 +19,45 @@ class CollectiveTimeout(RuntimeError):
     """An exchange (all-gather + merge) did not complete within GatherPipeline.watchdog_s."""
 
 
+class Deadline:
+    """`with Deadline("what", seconds):` — when the block has not finished in time, ONE line of diagnosis goes to stderr
+    and the process exits with status 3 (torchrun then takes the other ranks down).  For the phases of an unattended
+    multi-GPU run that can only hang, never fail: rendezvous, the communicator's first collective, a barrier, a run of
+    steps whose exchange a peer never joins.  `on_expire(message)` replaces the exit (tests)."""
+
+    def __init__(self, what: str, seconds: float, on_expire=None, detail=None):
+        self.what, self.seconds, self.on_expire, self.detail = what, float(seconds), on_expire, detail
+        self._t = None
+
+    def _fire(self):
+        import sys
+        extra = ""
+        if self.detail is not None:
+            try:
+                extra = " | " + str(self.detail())
+            except Exception as e:          # noqa: BLE001
+                extra = f" | (detail failed: {e!r})"
+        msg = (f"[yams_amd watchdog] rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')}: '{self.what}' "
+               f"not finished after {self.seconds:.0f} s{extra} — aborting instead of waiting for the caller's timeout")
+        if self.on_expire is not None:
+            self.on_expire(msg)
+            return
+        sys.stderr.write(msg + "\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self._t = threading.Timer(self.seconds, self._fire)
+        self._t.daemon = True
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+        return False
+
+
 def shard_bounds(n_rows: int, world: int) -> list[int]:
     """Contiguous row ranges: shard g owns rows [n*g/world, n*(g+1)/world)."""
     return [n_rows * g // world for g in range(world + 1)]
@@ -114,6 +153,7 @@ class GatherPipeline:
         # tail of the merge on the side stream (events), per batch; and a deadline after which a collective that
         # has not completed is declared stuck (CollectiveTimeout) instead of eating the caller's own timeout
         self.exchange_ms_sum, self.exchange_ms_max, self.exchanges = 0.0, 0.0, 0
+        self.launched = 0
         self.watchdog_s = 30.0
 
     # -- views ---------------------------------------------------------------------------------------
@@ -160,6 +200,7 @@ class GatherPipeline:
                 self.done[slot].record(self.side)
             self._host_ms = (time.perf_counter() - t_h) * 1e3
             self.busy[slot] = True
+            self.launched += 1
             return
         with torch.cuda.stream(self.side):
             self.begun[slot].record(self.side)
@@ -168,6 +209,7 @@ class GatherPipeline:
             self.merge_fn(self._views(out, (self.world,)), self._views(self.merged[slot]))
             self.done[slot].record(self.side)
         self.busy[slot] = True
+        self.launched += 1
 
     def wait(self, slot):
         if not self.active or not self.busy[slot]:
@@ -193,13 +235,14 @@ class GatherPipeline:
         self.busy[slot] = False
 
     def reset_exchange_stats(self):
-        self.exchange_ms_sum, self.exchange_ms_max, self.exchanges = 0.0, 0.0, 0
+        self.exchange_ms_sum, self.exchange_ms_max, self.exchanges, self.launched = 0.0, 0.0, 0, 0
 
     def exchange_stats(self):
         """{exchanges, exchange_ms (mean), exchange_ms_max}: device time of all-gather + merge per batch on the side stream
         (gloo dry runs: host time of the staged collective + merge launch)."""
         n = self.exchanges
-        return {"exchanges": n, "exchange_ms": self.exchange_ms_sum / n if n else None, "exchange_ms_max": self.exchange_ms_max if n else None}
+        return {"exchanges": n, "collectives": self.launched, "exchange_ms": self.exchange_ms_sum / n if n else None,
+                "exchange_ms_max": self.exchange_ms_max if n else None}
 
     def drain(self):
         for s in range(self.depth):
