@@ -65,3 +65,52 @@ def string_ranks(ids):
         rank[i] = r
     inv = np.array(order, np.uint32)
     return rank, inv
+
+
+# ---- tests/golden/scan.json: inputs are regenerated from the case's recipe, only outputs are stored -------------------
+def _bits_rows(bits):
+    return np.array(bits, dtype=np.uint32).view(np.float32)
+
+
+def golden_scan_matrix(oracle, spec):
+    """{"kind": "mt19937" | "philox" | "normal" | "bits", ...} -> float32 [n][dim]; "overrides": {row: [u32 bits]} replaces rows
+    (NaN / zero / tiny-norm / huge rows), "repeat": [[dst_lo, dst_hi, src]] makes runs of identical rows (ties)."""
+    kind = spec["kind"]
+    if kind == "mt19937":            # the reference's own recipe, vector_backend_engine_compare.cpp:83-107
+        m = oracle.mt19937_rows(spec["seed"], spec.get("skip", 0), spec["n"], spec["dim"])
+    elif kind == "philox":           # SURVEY.md 8(d): the synthetic-embedding recipe of bench.py and the GPU tests
+        m = oracle.synth_rows(spec["seed"], spec.get("row0", 0), spec["n"], spec["dim"])
+    elif kind == "normal":
+        m = np.random.default_rng(spec["seed"]).standard_normal((spec["n"], spec["dim"])).astype(np.float32)
+    elif kind == "bits":
+        m = _bits_rows(spec["rows"])
+    else:
+        raise ValueError(kind)
+    m = np.array(m, np.float32, copy=True)
+    for lo, hi, src in spec.get("repeat", []):
+        m[lo:hi] = m[src]
+    for r, bits in spec.get("overrides", {}).items():
+        m[int(r)] = _bits_rows(bits)
+    return m
+
+
+def golden_scan_ids(case, n):
+    """Chunk ids of the case's rows: explicit, a seeded shuffle of zero-padded numbers, or None (ordinals: chunk-id order
+    == row order)."""
+    ids = case.get("chunk_ids")
+    if isinstance(ids, dict):
+        perm = np.random.default_rng(ids["shuffle_seed"]).permutation(n)
+        return [ids.get("prefix", "id_") + "%06d" % v for v in perm]
+    return ids
+
+
+def golden_scan_inputs(oracle, case):
+    """(corpus, queries, tie_rank | None, allow | None) of one golden case."""
+    corpus = golden_scan_matrix(oracle, case["corpus"])
+    queries = golden_scan_matrix(oracle, case["queries"])
+    ids = golden_scan_ids(case, corpus.shape[0])
+    tie_rank = string_ranks(ids)[0] if ids is not None else None
+    allow = None
+    if case.get("allow_every"):
+        allow = (np.arange(corpus.shape[0]) % case["allow_every"] == 0).astype(np.uint8)
+    return corpus, queries, tie_rank, allow

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libyams_oracle.so")
 _REF_SO = os.path.join(ORACLE_DIR, "_ref", "libyams_ref.so")
+_SCAN_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libyams_scan_ref.so")
 
 u8p = C.POINTER(C.c_uint8)
 u64p = C.POINTER(C.c_uint64)
@@ -36,7 +37,10 @@ DEFAULT_CDC = dict(window=48, min_size=16 * 1024, max_size=1024 * 1024,
 def build():
     src = os.path.join(ORACLE_DIR, "yams_oracle.c")
     stale = (not os.path.exists(_ORACLE_SO)) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(src)
-    need_ref = os.path.isdir("/root/reference/src") and not os.path.exists(_REF_SO)
+    need_ref = os.path.isdir("/root/reference/src") and not (os.path.exists(_REF_SO) and os.path.exists(_SCAN_REF_SO))
+    if not need_ref and os.path.isdir("/root/reference/src"):
+        wrap = os.path.join(ORACLE_DIR, "scan_ref_wrap.cpp")
+        need_ref = os.path.getmtime(_SCAN_REF_SO) < max(os.path.getmtime(wrap), os.path.getmtime(os.path.join(ORACLE_DIR, "gen_scan_ref.py")))
     if stale or need_ref:
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
 
@@ -295,6 +299,96 @@ class Ref:
             raw = hexbuf.raw
             hashes = [raw[65 * i:65 * i + 64].decode() for i in range(n)]
         return off[:n].copy(), sz[:n].copy(), hashes
+
+
+class ScanRef:
+    """The reference's OWN exact-scan loop (oracle/_ref/libyams_scan_ref.so: bruteForceSearchUnlocked + helpers cut
+    verbatim from /root/reference by oracle/gen_scan_ref.py, over an in-memory SQLite).  One instance = one `vectors`
+    table.  Raises FileNotFoundError when the prebuilt .so is absent."""
+
+    def __init__(self):
+        build()
+        if not os.path.exists(_SCAN_REF_SO):
+            raise FileNotFoundError(_SCAN_REF_SO)
+        L = C.CDLL(_SCAN_REF_SO)
+        self.L = L
+        L.scanref_open.restype = C.c_void_p
+        L.scanref_close.argtypes = [C.c_void_p]
+        L.scanref_insert.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_char_p]
+        L.scanref_insert_rows.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_longlong]
+        L.scanref_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_int,
+                                     C.POINTER(C.c_longlong), f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong)]
+        L.scanref_search.restype = C.c_long
+        L.scanref_cosine.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t]
+        L.scanref_cosine.restype = C.c_double
+        self.invalid_argument = -int(L.scanref_error_code_invalid_argument())
+        self.h = C.c_void_p(L.scanref_open())
+        if not self.h:
+            raise OSError("scanref_open failed")
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.scanref_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def insert_rows(self, rows, chunk_ids=None):
+        """Rows as the backend stores them (raw fp32 blobs); chunk ids default to zero-padded ordinals (chunk-id order ==
+        row order)."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n, d = rows.shape
+        ids = None
+        if chunk_ids is not None:
+            enc = [s.encode() for s in chunk_ids]
+            ids = (C.c_char_p * n)(*enc)
+        assert self.L.scanref_insert_rows(self.h, _ptr(rows, f32p), n, d, ids, self.n) == 0
+        self.n += n
+
+    def insert_raw(self, chunk_id, blob: bytes | None, embedding_dim, metadata=None, document_hash="doc"):
+        """One row with an arbitrary blob (wrong sizes, empty) and an optional flat metadata dict."""
+        meta = None
+        if metadata is not None:
+            meta = ("{" + ",".join('"%s":"%s"' % (k, v) for k, v in metadata.items()) + "}").encode()
+        assert self.L.scanref_insert(self.h, chunk_id.encode(), document_hash.encode(), blob, len(blob) if blob else 0,
+                                     embedding_dim, self.n, meta) == 0
+        self.n += 1
+
+    def search(self, query, k, thr=-1.0, metadata_filters=None, all_matching=False):
+        """bruteForceSearchUnlocked(query, k, thr, nullopt, {}, metadata_filters, &diag, TopK | AllMatching): returns
+        (ordinals, scores, diag dict) or the negative ErrorCode."""
+        q = np.ascontiguousarray(query, np.float32)
+        cap = max(self.n if (all_matching or metadata_filters) else k, 1)
+        cap = max(cap, k, 1)
+        ords = np.full(cap, -1, np.int64); sc = np.zeros(cap, np.float32)
+        cnt = C.c_size_t(0); dg = (C.c_ulonglong * 4)()
+        kv = None; n_meta = 0
+        if metadata_filters:
+            flat = []
+            for kk, vv in metadata_filters.items():
+                flat += [kk.encode(), vv.encode()]
+            kv = (C.c_char_p * len(flat))(*flat); n_meta = len(metadata_filters)
+        rc = self.L.scanref_search(self.h, _ptr(q, f32p), q.size, k, thr, kv, n_meta, 1 if all_matching else 0,
+                                   ords.ctypes.data_as(C.POINTER(C.c_longlong)), _ptr(sc, f32p), cap, C.byref(cnt), dg)
+        if rc != 0:
+            return rc
+        assert cnt.value <= cap
+        return ords[:cnt.value].copy(), sc[:cnt.value].copy(), {"rows_visited": dg[0], "exact_distance_evaluations": dg[1],
+                                                               "returned_rows": dg[2], "used_exact_scan": dg[3]}
+
+    def cosine(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        return self.L.scanref_cosine(_ptr(a, f32p), a.size, _ptr(b, f32p), b.size)
+
+
+def scan_ref():
+    """A fresh ScanRef (its own in-memory table), or None when oracle/_ref/libyams_scan_ref.so did not travel."""
+    try:
+        return ScanRef()
+    except (FileNotFoundError, OSError):
+        return None
 
 
 _oracle = None

@@ -1697,3 +1697,42 @@ def test_sweep_hold_keeps_the_gate_closed_until_the_collective_is_enqueued(oracl
     t.join(timeout=30)
     assert "r2" in done
     a.close(); b.close(); gate.close()
+
+
+# ---- the reference's own loop, compiled (oracle/_ref/libyams_scan_ref.so), as golden vectors ------------------------------
+@pytest.mark.parametrize("shadow", [True, False, "both"])
+def test_hip_scan_reproduces_the_reference_compiled_golden_vectors(acc, oracle, shadow):
+    """tests/golden/scan.json holds what SqliteVecBackend::Impl::bruteForceSearchUnlocked ITSELF returned (both paths;
+    compiled from /root/reference by oracle/Makefile, recorded by tests/golden/make_scan_golden.py): the HIP path must
+    return the same rows in the same order with the same score bits — config 1 on the reference's mt19937 recipe,
+    Philox rows at dim 768 / 384 top-100, k > n, ties under shuffled chunk ids, skipped rows and +-FLT_MAX/4, invalid
+    queries, the metadata-filter path (TopK and AllMatching)."""
+    with open(os.path.join(_cases.GOLDEN, "scan.json")) as f:
+        g = json.load(f)
+    n_cases = 0
+    for case in g["cases"]:
+        corpus, queries, tie_rank, allow = _cases.golden_scan_inputs(oracle, case)
+        if shadow == "both" and not (corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256):
+            continue
+        flags, mask, k = 0, None, case["k"]
+        if case["path"] == "record":
+            flags, mask = FLAG_RECORD_PATH, allow.astype(bool)
+            if case.get("all_matching"):
+                k = int(allow.sum())                     # ExactRowSelection::AllMatching = every allowed row (:4398-4400)
+        good = [qi for qi, e in enumerate(case["expected"]) if not e.get("error")]
+        for qi, e in enumerate(case["expected"]):
+            if e.get("error"):                           # :4127-4130 InvalidArgument; a batch fails as a whole (:1635-1647)
+                with pytest.raises(_lib.AccelError) as err:
+                    run(acc, corpus, queries[qi:qi + 1], k, case["threshold"], SCAN_COSINE, flags, tie_rank, shadow=shadow, mask=mask)
+                assert err.value.status == _lib.YAMS_ERR_INVALID_ARG
+        if not good:
+            continue
+        r = run(acc, corpus, queries[good], k, case["threshold"], SCAN_COSINE, flags, tie_rank, shadow=shadow, mask=mask)
+        for j, qi in enumerate(good):
+            e = case["expected"][qi]
+            cnt = int(r.counts[j])
+            assert cnt == len(e["rows"]), (case["name"], qi, cnt, len(e["rows"]), r.diag)
+            assert r.rows[j, :cnt].tolist() == e["rows"], (case["name"], qi, r.diag)
+            assert [int(x) for x in r.scores[j, :cnt].view(np.uint32)] == e["score_bits"], (case["name"], qi)
+        n_cases += 1
+    assert n_cases >= (5 if shadow == "both" else 14)
