@@ -49,6 +49,16 @@ public:
                                    VectorSearchEngine engine = VectorSearchEngine::ExactScan)
         : plugin_(std::move(plugin)), durable_(std::move(durable)), table_(plugin_, engine) {}
 
+    // ---- vec0 L2: settle the distance arithmetic with the host's own function (l2_calibration.hpp) ---------------
+    // Call once after construction when the engine is Vec0L2, e.g.
+    //     backend.calibrateL2(accel_l2::fromCApi(&sqlite3_vec_distance_l2));
+    // Matched: every L2 search runs in that arithmetic (overrides the plugin's "l2_accumulate").  Not matched: the
+    // returned record says so and every L2 search fails with ErrorCode::NotSupported — the host keeps its CPU vec0.
+    Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
+        std::unique_lock lk(mu_);
+        return table_.calibrateL2(fn);
+    }
+
     // ---- lifecycle / schema --------------------------------------------------------------------------
     Result<void> initialize(const std::string& db_path) override {
         std::unique_lock lk(mu_);

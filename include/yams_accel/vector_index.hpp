@@ -22,6 +22,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "l2_calibration.hpp"
 #include "plugin.hpp"
 
 #ifdef YAMS_ACCEL_USE_HOST_TYPES
@@ -65,6 +66,15 @@ enum class VectorSearchEngine { Vec0L2, ExactScan }; // vector_types.h:31-35 (th
 #endif
 
 enum class ExactRowSelection { TopK, AllMatching }; // sqlite_vec_backend.cpp:342-371 / :4398-4400
+
+// vec0 L2: the arithmetic of the host's distance, as settled by calibrateL2 (l2_calibration.hpp).  Uncalibrated: the
+// plugin's configured "l2_accumulate" applies.  Calibrated and matched: the matching YAMS_SCAN_FLAG_L2_ACC_* goes with
+// every L2 search.  Calibrated and NOT matched: L2 searches are refused (ErrorCode::NotSupported).
+struct L2Setting {
+    bool calibrated = false, matched = false;
+    uint32_t flags = 0;
+    std::string detail;
+};
 
 // One dense device matrix per AccelVectorIndex (one embedding dimension).  Row r of the mirror is
 // records_[r]; rows are only ever APPENDED to the device mirror:
@@ -371,6 +381,12 @@ private:
                 return Error{ErrorCode::InvalidArgument, "Query embedding dimension mismatch (expected=" +
                                                              std::to_string(dim_) + ", got=" + std::to_string(q.size()) + ")"};
         if (auto s = syncMirror(); !s) return s.error();
+        if (engine_ == VectorSearchEngine::Vec0L2 && l2_.calibrated) {
+            // a top-k set computed in arithmetic the host's vec0 does not use would differ from the host's own on a fraction
+            // of queries: refuse rather than serve it
+            if (!l2_.matched) return Error{ErrorCode::NotSupported, "vec0 L2 refused: " + l2_.detail};
+            flags |= l2_.flags;
+        }
         if (k > YAMS_SCAN_MAX_K) return searchPeeled(queries, k, thr, diagnostics, rowMask, flags, visited, evaluated);
         std::vector<float> flat(queries.size() * dim_);
         for (size_t i = 0; i < queries.size(); ++i) std::copy(queries[i].begin(), queries[i].end(), flat.begin() + i * dim_);
@@ -452,10 +468,25 @@ private:
         return out;
     }
 
+public:
+    // Ask the HOST's own vec0 distance which arithmetic it uses (l2_calibration.hpp): on a match every later L2 search of
+    // this index carries that YAMS_SCAN_FLAG_L2_ACC_*; on no match L2 searches fail with NotSupported.  Returns the
+    // calibration record either way (Error only when no function was given).
+    Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
+        if (!fn) return Error{ErrorCode::InvalidArgument, "calibrateL2 needs the host's L2 distance function"};
+        const auto c = accel_l2::calibrateL2(fn);
+        setL2(L2Setting{true, c.matched, c.flags, c.detail});
+        return c;
+    }
+    void setL2(const L2Setting& s) { l2_ = s; }
+    const L2Setting& l2() const { return l2_; }
+
+private:
     std::shared_ptr<accel::Plugin> plugin_;
     yams_vector_scan_v1* vt_;
     size_t dim_;
     VectorSearchEngine engine_;
+    L2Setting l2_;
     uint64_t corpus_ = 0;
     bool initialized_ = false, ranksDirty_ = false;
     std::vector<VectorRecord> records_;
@@ -597,12 +628,26 @@ private:
         auto made = createAccelVectorIndex(plugin_, dim, engine_);
         if (!made) return made.error();
         if (auto s = made.value()->initialize(); !s) return s.error();
+        made.value()->setL2(l2_);
         auto* raw = made.value().get();
         byDim_[dim] = std::move(made.value());
         return raw;
     }
+public:
+    // One calibration for the table: every index (dimension), present and future, searches L2 in the host's arithmetic
+    Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
+        if (!fn) return Error{ErrorCode::InvalidArgument, "calibrateL2 needs the host's L2 distance function"};
+        const auto c = accel_l2::calibrateL2(fn);
+        l2_ = L2Setting{true, c.matched, c.flags, c.detail};
+        for (auto& kv : byDim_) kv.second->setL2(l2_);
+        return c;
+    }
+    const L2Setting& l2() const { return l2_; }
+
+private:
     std::shared_ptr<accel::Plugin> plugin_;
     VectorSearchEngine engine_;
+    L2Setting l2_;
     std::map<size_t, std::unique_ptr<AccelVectorIndex>> byDim_;
     std::unordered_map<std::string, size_t> dimOf_;
 };

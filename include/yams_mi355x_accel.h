@@ -224,6 +224,9 @@ typedef struct yams_scan_corpus_s {
 #define YAMS_SCAN_FLAG_L2_ACC_F32X8 512u
 #define YAMS_SCAN_FLAG_L2_ACC_F32X16 768u
 #define YAMS_SCAN_FLAG_L2_ACC_MASK 768u
+#define YAMS_SCAN_FLAG_L2_ACC_EXPLICIT 1024u /* vtable callers: the L2_ACC bits of THIS call are the caller's decision even when
+                                                they read F64 (= 0) — the plugin's configured default is not applied.  Set by the
+                                                adapters after l2_calibration.hpp has asked the host's own distance function. */
 #define YAMS_SCAN_MAX_K 1024u  /* results per query and call; larger k: rounds behind the allow-mask, as
                                   AccelVectorIndex::searchPeeled does (include/yams_accel/vector_index.hpp) */
 #define YAMS_SCAN_MAX_DIM 8192u /* the fp64 re-score stages a query and its candidate rows in LDS */

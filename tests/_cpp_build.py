@@ -60,3 +60,24 @@ def build_stub_collective():
     if r.returncode != 0:
         raise RuntimeError("the stub collective library failed to compile:\n" + r.stdout.decode())
     return lib
+
+
+def build_l2_calibration_test():
+    """Compiles tests/cpp/l2_calibration_test.cpp (plain g++, no GPU, no reference tree) and links it with the oracle's C
+    restatement, whose four L2 definitions play the host's distance function.  Returns the executable."""
+    import _oracle
+    _oracle.build()
+    out_dir = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "l2_calibration_test")
+    src = os.path.join(ROOT, "tests", "cpp", "l2_calibration_test.cpp")
+    hdr = os.path.join(ROOT, "include", "yams_accel", "l2_calibration.hpp")
+    so = os.path.join(ROOT, "oracle", "_build", "libyams_oracle.so")
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in (src, hdr, so)):
+        return exe
+    # -O2 -ffp-contract=fast on purpose: the header's definitions must hold whatever the host's flags are
+    r = subprocess.run([os.environ.get("CXX", "g++"), "-std=c++20", "-O2", "-ffp-contract=fast", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                        "-o", exe, src, so, "-Wl,-rpath," + os.path.dirname(so), "-lm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("l2_calibration_test failed to compile:\n" + r.stdout.decode())
+    return exe

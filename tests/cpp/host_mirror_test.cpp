@@ -433,6 +433,39 @@ int main(int argc, char** argv) {
             size_t keep = 0;
             if (near2) for (const auto& r : near2.value()) keep += r.relevance_score >= 0.1f;
             CHECK(cut.has_value() && cut.value().size() == keep && keep > 0 && keep < 2000);
+            // vec0 L2 self-calibration (l2_calibration.hpp): the HOST's distance function decides the arithmetic.  Each of the
+            // four served definitions plays the host in turn: the index must recognise it and from then on return exactly
+            // the rows a host-side brute force UNDER THAT DEFINITION returns (distance asc, chunk_id asc) — whatever
+            // "l2_accumulate" the plugin was configured with.
+            namespace l2n = vector::accel_l2;
+            for (auto def : l2n::kDefinitions) {
+                auto host = [def](const float* a, const float* b, size_t dim, float* out) { *out = l2n::distance(def, a, b, dim); return true; };
+                auto cal = l2.calibrateL2(host);
+                CHECK(cal.has_value() && cal.value().matched && cal.value().accumulate == def);
+                CHECK(l2.l2().calibrated && l2.l2().matched && l2.l2().flags == (static_cast<uint32_t>(def) | YAMS_SCAN_FLAG_L2_ACC_EXPLICIT));
+                auto got = l2.searchSimilar(qv, 60, -1.0f);
+                CHECK(got.has_value() && got.value().size() == 60);
+                std::vector<std::pair<float, std::string>> brute;
+                for (const auto& r : recs) brute.emplace_back(l2n::distance(def, r.embedding.data(), qv.data(), qv.size()), r.chunk_id);
+                std::sort(brute.begin(), brute.end());
+                if (got) for (size_t i = 0; i < 60; ++i) CHECK(got.value()[i].chunk_id == brute[i].second);
+            }
+            // a host whose arithmetic is none of them (pairwise summation): calibration says so and L2 is REFUSED, not guessed
+            auto pairwise = [](const float* a, const float* b, size_t dim, float* out) {
+                std::vector<float> v(dim);
+                for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; v[i] = d * d; }
+                for (size_t n = dim; n > 1; n = (n + 1) / 2) for (size_t i = 0; i < n / 2; ++i) v[i] = v[i] + v[n - 1 - i];
+                *out = std::sqrt(v[0]);
+                return true;
+            };
+            auto none = l2.calibrateL2(pairwise);
+            CHECK(none.has_value() && !none.value().matched && !l2.l2().matched);
+            auto refused = l2.searchSimilar(qv, 10, -1.0f);
+            CHECK(!refused.has_value() && refused.error().code == ErrorCode::NotSupported);
+            auto refusedBig = l2.searchSimilar(qv, 2000, -1.0f);
+            CHECK(!refusedBig.has_value() && refusedBig.error().code == ErrorCode::NotSupported);
+            // ... while the cosine engine of the same plugin is untouched
+            CHECK(all.searchSimilar(qv, 5, -1.0f).has_value());
         }
         auto ties = all.searchSimilar(recs[500].embedding, 2, -1.0f);
         CHECK(ties.has_value() && ties.value().size() == 2 && ties.value()[0].chunk_id == "chunk_000500" && ties.value()[1].chunk_id == "chunk_000507");

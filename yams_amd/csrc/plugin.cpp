@@ -596,8 +596,9 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
     // only semantic flags cross the vtable; filter selection stays with the library
     yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_DEFER_THRESHOLD |
                                                           YAMS_SCAN_FLAG_L2_ACC_MASK)};
-    // vec0's distance arithmetic: the call's own choice, else the plugin's ("l2_accumulate" in the init config)
-    if (metric == YAMS_SCAN_L2 && !(prm.flags & YAMS_SCAN_FLAG_L2_ACC_MASK)) prm.flags |= g.l2_acc;
+    // vec0's distance arithmetic: the call's own choice (any L2_ACC bit, or L2_ACC_EXPLICIT for a deliberate F64), else
+    // the plugin's ("l2_accumulate" in the init config)
+    if (metric == YAMS_SCAN_L2 && !(flags & (YAMS_SCAN_FLAG_L2_ACC_MASK | YAMS_SCAN_FLAG_L2_ACC_EXPLICIT))) prm.flags |= g.l2_acc;
     const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
     std::vector<float> scores(slots), dist(slots);
     std::vector<int64_t> rows(slots);
