@@ -14,7 +14,7 @@
 // AccelVectorIndex::calibrateL2 / AccelExactScanBackend::calibrateL2.
 //
 // Header-only, std-only, no device: calibration is host arithmetic.  The definitions below are the ones the device
-// kernels implement (scan_kernels.hip, L2Sum) and the ones oracle/yams_oracle.c restates for the tests.
+// kernels implement (scan_kernels.hip, L2Sum); the test suite checks them against an independent C restatement.
 #pragma once
 #include <array>
 #include <cmath>

@@ -313,8 +313,11 @@ private:
         std::vector<float> flat(n * dim_);
         for (size_t i = 0; i < n; ++i)
             std::copy(records_[first + i].embedding.begin(), records_[first + i].embedding.end(), flat.begin() + i * dim_);
-        if (vt_->corpus_append(vt_->self, corpus_, flat.data(), n) != YAMS_OK)
-            return Error{ErrorCode::InternalError, "corpus_append failed"};
+        // Device memory exhausted (YAMS_ERR_RESOURCE_EXHAUSTED -> ErrorCode::ResourceExhausted, core/types.h:49): the device
+        // mirror keeps the rows it had, the rows stay pending HERE, and every search fails with that code (a search over
+        // part of the rows would not be the reference's answer) until an upload succeeds — the next search retries it.
+        if (const yams_status_t st = vt_->corpus_append(vt_->self, corpus_, flat.data(), n); st != YAMS_OK)
+            return Error{accel::mapStatus(st), st == YAMS_ERR_RESOURCE_EXHAUSTED ? "device memory exhausted while the mirror grew" : "corpus_append failed"};
         deviceRows_ = records_.size();
         return {};
     }

@@ -447,6 +447,18 @@ YAMS_ACCEL_API yams_status_t yams_scan_sharded_topk_host(
     int64_t rank_row_base, float* out_scores_host, int64_t* out_rows_host,
     uint32_t* out_counts_host, float* out_dist_host, yams_scan_diag_t* diag);
 
+/* Allocation-failure injection, for tests of the out-of-memory paths (ErrorCode::ResourceExhausted,
+ * include/yams/core/types.h:49 of the reference).  After yams_accel_debug_fail_alloc_after(n) the next n allocations of
+ * device / pinned / VMM-backed memory THIS LIBRARY makes for its own objects (workspaces, mirrors behind corpus_append,
+ * lane buffers, staging rings, digest sets) succeed and every later one fails as hipErrorOutOfMemory does, until
+ * yams_accel_debug_fail_alloc_after(-1).  Process-wide; never armed unless called (the library reads no environment).
+ * yams_accel_alloc — the caller's own buffers — is exempt.  ..._alloc_faults: allocations failed by injection so far.
+ * What the library promises under exhaustion: the failing call returns YAMS_ERR_RESOURCE_EXHAUSTED, the object it
+ * was growing is left as it was (a corpus keeps its rows and answers searches), nothing is leaked (health JSON:
+ * "mirror_bytes_mapped" / "mirror_bytes_parked"), and the same call succeeds once memory is there again. */
+YAMS_ACCEL_API void yams_accel_debug_fail_alloc_after(int64_t n);
+YAMS_ACCEL_API uint64_t yams_accel_debug_alloc_faults(void);
+
 /* Fill a device matrix with the synthetic embedding recipe: Philox4x32-10
  * (seed, row, col/4) -> U[-1,1) -> fp32 L2-normalise.  Used by bench.py and tests so that a
  * corpus larger than host RAM can be generated in HBM and any slice regenerated on the CPU. */

@@ -482,6 +482,43 @@ int main(int argc, char** argv) {
         auto gone = all.searchSimilar(recs[17].embedding, 5, -1.0f, std::optional<std::string>("doc_17"), {});
         CHECK(gone.has_value() && gone.value().empty());
     }
+    {   // device memory exhausted while a mirror grows (allocation-failure injection, yams_accel_debug_fail_alloc_after):
+        // ErrorCode::ResourceExhausted (core/types.h:49), nothing lost on the host side, the same search succeeds — new rows
+        // included — once memory is there again
+        using fail_after_t = void (*)(int64_t);
+        void* self = dlopen(argv[1], RTLD_NOW | RTLD_NOLOAD);
+        auto fail_after = self ? reinterpret_cast<fail_after_t>(dlsym(self, "yams_accel_debug_fail_alloc_after")) : nullptr;
+        CHECK(fail_after != nullptr);
+        if (fail_after) {
+            auto idxR = vector::createAccelVectorIndex(plugin, 64);
+            auto& db = *idxR.value();
+            CHECK(db.initialize().has_value());
+            auto row = [](size_t i) {
+                vector::VectorRecord r;
+                char id[32]; std::snprintf(id, sizeof id, "oom_%07zu", i);
+                r.chunk_id = id; r.document_hash = "doc_oom"; r.embedding.assign(64, 0.0f);
+                r.embedding[i % 64] = 1.0f; r.embedding[(i / 64) % 64] += 0.5f; r.embedding[(i / 4096) % 64] += 0.25f;
+                return r;
+            };
+            std::vector<vector::VectorRecord> first, more;
+            for (size_t i = 0; i < 1000; ++i) first.push_back(row(i));
+            for (size_t i = 1000; i < 201000; ++i) more.push_back(row(i));   // 51 MB of rows: the mirror must map more memory
+            CHECK(db.insertVectorsBatch(first).has_value());
+            auto before = db.searchSimilar(first[7].embedding, 5, -1.0f);
+            CHECK(before.has_value() && before.value().size() == 5 && before.value()[0].chunk_id == "oom_0000007");
+            fail_after(0);
+            CHECK(db.insertVectorsBatch(more).has_value());                 // (host side only: the upload is lazy)
+            auto starved = db.searchSimilar(more[12345].embedding, 5, -1.0f);
+            CHECK(!starved.has_value() && starved.error().code == ErrorCode::ResourceExhausted);
+            auto again = db.searchSimilar(more[12345].embedding, 5, -1.0f);  // still exhausted: still refused, nothing corrupted
+            CHECK(!again.has_value() && again.error().code == ErrorCode::ResourceExhausted);
+            fail_after(-1);
+            auto fed = db.searchSimilar(more[12345].embedding, 5, -1.0f);
+            CHECK(fed.has_value() && fed.value().size() == 5 && fed.value()[0].chunk_id == more[12345].chunk_id);
+            auto old = db.searchSimilar(first[7].embedding, 5, -1.0f);
+            CHECK(old.has_value() && old.value().size() == 5 && old.value()[0].chunk_id == "oom_0000007");
+        }
+    }
     {   // large finite scores (+-FLT_MAX/4) stay finite
         const float L = std::numeric_limits<float>::max() / 4.0f;
         auto idxR = vector::createAccelVectorIndex(plugin, 4);

@@ -2,6 +2,7 @@
 #include "accel_ctx.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -20,8 +21,22 @@ yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what) {
     std::string m = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) +
                     ") in " + what;
     (void)hipGetLastError(); // clear the sticky error
-    // out-of-memory is the only error a caller can act on; everything else is internal
-    return fail(ctx, YAMS_ERR_INTERNAL, m);
+    // out-of-memory is the only error a caller can act on (ErrorCode::ResourceExhausted, core/types.h:49 of the
+    // reference); everything else is internal
+    return fail(ctx, e == hipErrorOutOfMemory ? YAMS_ERR_RESOURCE_EXHAUSTED : YAMS_ERR_INTERNAL, m);
+}
+
+namespace {
+std::atomic<long long> g_fail_after{-1};     // allocations that may still succeed; < 0: injection off
+std::atomic<unsigned long long> g_faults{0}; // allocations failed by injection
+} // namespace
+bool alloc_fault() {
+    long long v = g_fail_after.load(std::memory_order_relaxed);
+    while (v >= 0) {
+        if (v == 0) { ++g_faults; return true; }
+        if (g_fail_after.compare_exchange_weak(v, v - 1)) return false;
+    }
+    return false;
 }
 
 yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -35,7 +50,7 @@ yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void**
         }
         size_t want = bytes + bytes / 8; // a little headroom so steady-state calls never realloc
         want = (want + 255) & ~static_cast<size_t>(255);
-        hipError_t e = hipMalloc(&b.p, want);
+        hipError_t e = ya_malloc(&b.p, want);
         if (e != hipSuccess) {
             b.p = nullptr;
             return hip_fail(ctx, e, (std::string("hipMalloc workspace '") + name + "' of " +
@@ -55,7 +70,7 @@ yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out) {
             ctx->pinned = nullptr; ctx->pinned_cap = 0;
         }
         size_t want = (bytes * 2 + 4095) & ~static_cast<size_t>(4095);
-        YA_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        YA_HIP(ctx, ya_host_malloc(&ctx->pinned, want, hipHostMallocDefault));
         ctx->pinned_cap = want;
     }
     *out = ctx->pinned;
@@ -188,7 +203,7 @@ hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
         R.device = dev;
     }
     for (int i = 0; i < StageRing::kBufs && !R.broken; ++i)
-        if (!R.buf[i] && hipHostMalloc(reinterpret_cast<void**>(&R.buf[i]), StageRing::kPiece, hipHostMallocPortable) != hipSuccess) {
+        if (!R.buf[i] && ya_host_malloc(reinterpret_cast<void**>(&R.buf[i]), StageRing::kPiece, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError(); R.buf[i] = nullptr; R.broken = true;
         }
     if (R.broken) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
@@ -427,3 +442,7 @@ yams_status_t yams_accel_last_kernel_ms(const yams_accel_ctx* cctx, const char* 
 }
 
 } // extern "C"
+
+// ---- allocation fault injection (tests of the out-of-memory paths; see the header) ---------------------------------
+extern "C" void yams_accel_debug_fail_alloc_after(int64_t n) { yams_accel::g_fail_after.store(n < 0 ? -1 : n); }
+extern "C" uint64_t yams_accel_debug_alloc_faults(void) { return yams_accel::g_faults.load(); }

@@ -100,6 +100,22 @@ struct TimedRegion { // RAII-less helper: begin/end record events when timing is
     void end();
 };
 
+// Allocation fault injection (yams_accel_debug_fail_alloc_after): every allocation of device, pinned or VMM-backed memory
+// this library makes goes through one of the three doors below, which fail with hipErrorOutOfMemory once armed.
+bool alloc_fault();
+inline hipError_t ya_malloc(void** p, size_t bytes) {
+    if (alloc_fault()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+inline hipError_t ya_host_malloc(void** p, size_t bytes, unsigned flags) {
+    if (alloc_fault()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(p, bytes, flags);
+}
+inline hipError_t ya_mem_create(hipMemGenericAllocationHandle_t* h, size_t bytes, const hipMemAllocationProp* prop) {
+    if (alloc_fault()) return hipErrorOutOfMemory;
+    return hipMemCreate(h, bytes, prop, 0);
+}
+
 #define YA_HIP(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
     return ::yams_accel::hip_fail((ctx), e__, #expr); } while (0)
 #define YA_TRY(expr) do { yams_status_t s__ = (expr); if (s__ != YAMS_OK) return s__; } while (0)

@@ -28,11 +28,11 @@ yams_status_t alloc_table(yams_accel_ctx* ctx, uint32_t capacity, DedupTable* ou
     DedupTable t{};
     t.capacity = capacity;
     const size_t c = capacity;
-    if (hipMalloc(&t.tags, c * 8) != hipSuccess || hipMalloc(&t.keys, c * 32) != hipSuccess ||
-        hipMalloc(&t.owner, c * 4) != hipSuccess || hipMalloc(&t.fresh, c) != hipSuccess) {
+    if (ya_malloc(reinterpret_cast<void**>(&t.tags), c * 8) != hipSuccess || ya_malloc(reinterpret_cast<void**>(&t.keys), c * 32) != hipSuccess ||
+        ya_malloc(reinterpret_cast<void**>(&t.owner), c * 4) != hipSuccess || ya_malloc(reinterpret_cast<void**>(&t.fresh), c) != hipSuccess) {
         (void)hipGetLastError();
         free_table(t);
-        return fail(ctx, YAMS_ERR_INTERNAL, "out of device memory for the digest set");
+        return fail(ctx, YAMS_ERR_RESOURCE_EXHAUSTED, "out of device memory for the digest set");
     }
     YA_HIP(ctx, hipMemsetAsync(t.tags, 0, c * 8, ctx->stream));
     YA_HIP(ctx, hipMemsetAsync(t.fresh, 0, c, ctx->stream));
@@ -73,7 +73,7 @@ yams_status_t yams_dedup_set_create(yams_accel_ctx* ctx, uint64_t expected_entri
     s->ctx = ctx;
     yams_status_t st = alloc_table(ctx, capacity_for(expected_entries), &s->t);
     if (st != YAMS_OK) { delete s; return st; }
-    if (hipMalloc(&s->d_count, 8) != hipSuccess) { (void)hipGetLastError(); free_table(s->t); delete s; return YAMS_ERR_INTERNAL; }
+    if (ya_malloc(reinterpret_cast<void**>(&s->d_count), 8) != hipSuccess) { (void)hipGetLastError(); free_table(s->t); delete s; return YAMS_ERR_RESOURCE_EXHAUSTED; }
     YA_HIP(ctx, hipMemsetAsync(s->d_count, 0, 8, ctx->stream));
     YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = s;

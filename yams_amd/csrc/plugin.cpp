@@ -104,11 +104,11 @@ struct GrowBuf {
             prop.location.type = hipMemLocationTypeDevice;
             prop.location.id = device;
             hipMemGenericAllocationHandle_t h;
-            hipError_t e = hipMemCreate(&h, add, &prop, 0);
+            hipError_t e = yams_accel::ya_mem_create(&h, add, &prop);
             if (e != hipSuccess && evict_parked(device)) { // parked mirrors of destroyed corpora give their memory back first
                 (void)hipGetLastError();
                 if (mapped + (bytes - mapped + kGran - 1) / kGran * kGran <= reserved) add = (bytes - mapped + kGran - 1) / kGran * kGran;
-                e = hipMemCreate(&h, add, &prop, 0);
+                e = yams_accel::ya_mem_create(&h, add, &prop);
             }
             if (e != hipSuccess) { GROW_TRACE("hipMemCreate", e); (void)hipGetLastError(); return false; }
             hipMemAccessDesc acc{};
@@ -129,7 +129,7 @@ struct GrowBuf {
         // fallback: allocate, copy, free
         const size_t want = std::max(bytes, mapped + mapped / 2);
         void* nd = nullptr;
-        if (hipMalloc(&nd, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (yams_accel::ya_malloc(&nd, want) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (mapped && hipMemcpy(nd, base, mapped, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nd); return false; }
         if (base) (void)hipFree(base);
         base = static_cast<unsigned char*>(nd);
@@ -288,9 +288,13 @@ struct PluginState {
     // the lanes of one device share a sweep gate inside the handle (sharded_api.cpp)
     yams_scan_sharded* sharded = nullptr;
     uint32_t search_slots = 0;
-    uint32_t l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;
-    // the last corpus_append (under upload_mu): bytes, ms spent mapping device memory / copying / building shadows
-    uint64_t append_bytes = 0; double append_map_ms = 0, append_copy_ms = 0, append_shadow_ms = 0; // config "l2_accumulate": "f64" | "f32" | "f32x8" | "f32x16"
+    uint32_t l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;   // config "l2_accumulate": "f64" | "f32" | "f32x8" | "f32x16"
+    // the last corpus_append: bytes, ms spent mapping device memory / copying / building shadows (written under upload_mu,
+    // read by the health call without it: atomics), and the slowest append so far with its split
+    std::atomic<uint64_t> append_bytes{0}, appends{0};
+    std::atomic<double> append_map_ms{0}, append_copy_ms{0}, append_shadow_ms{0};
+    std::atomic<double> slow_append_ms{0}, slow_map_ms{0}, slow_copy_ms{0}, slow_shadow_ms{0};
+    std::atomic<uint64_t> slow_append_bytes{0}, exhausted_appends{0};
     Pool<yams_accel_ctx*> work_ctx;          // hashing / chunking contexts on devices[0]
     std::vector<yams_accel_ctx*> upload_ctx; // one per device, used under a corpus's exclusive lock
     std::mutex upload_mu;                    // (upload contexts are shared by all corpora)
@@ -380,6 +384,17 @@ yams_status_t vs_corpus_create(void*, uint32_t dim, uint64_t* out_id) {
 // Appends rows: they take the next global ids, are dealt to the devices in stripes, copied to the end of
 // each shard's growing mirror, and the shadows of the touched local ranges are (re)built.
 // measure builds say where an internal error came from
+// device memory behind a mirror could not be had (out of memory, or beyond the mirror's share of the address space):
+// the corpus is left exactly as it was — same rows, same shadows, searches go on — and the caller can act on it
+// (ErrorCode::ResourceExhausted, include/yams/core/types.h:49 of the reference)
+inline yams_status_t exhausted(const char* where) {
+#ifdef YAMS_ACCEL_MEASURE
+    std::fprintf(stderr, "[yams_mi355x_accel] device memory exhausted at %s\n", where);
+#else
+    (void)where;
+#endif
+    return YAMS_ERR_RESOURCE_EXHAUSTED;
+}
 inline yams_status_t internal_error(const char* where) {
 #ifdef YAMS_ACCEL_MEASURE
     std::fprintf(stderr, "[yams_mi355x_accel] internal error at %s (hip: %s)\n", where, hipGetErrorString(hipGetLastError()));
@@ -414,9 +429,9 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
             (void)hipGetLastError();
             dev_total = 288ull << 30; // the reservation is address space only: size it for the part this library is written for
         }
-        if (!s.rows.ensure(now * rb, ShardStore::share(dev_total, 0))) return internal_error("append:1");
-        if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) return internal_error("append:2");
-        if (i8 && (!s.i8.ensure((now + 63) / 64 * 64 * rb / 4 /* whole 64-row blocks: the shadow is stored blocked */, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) return internal_error("append:3");
+        if (!s.rows.ensure(now * rb, ShardStore::share(dev_total, 0))) { ++g.exhausted_appends; return exhausted("append:1"); }
+        if (bf16 && (!s.bf16.ensure(now * rb / 2, ShardStore::share(dev_total, 1)) || !s.nsq.ensure(now * 4, ShardStore::share(dev_total, 3)))) { ++g.exhausted_appends; return exhausted("append:2"); }
+        if (i8 && (!s.i8.ensure((now + 63) / 64 * 64 * rb / 4 /* whole 64-row blocks: the shadow is stored blocked */, ShardStore::share(dev_total, 2)) || !s.i8meta.ensure(((now + 63) / 64) * 8, ShardStore::share(dev_total, 4)))) { ++g.exhausted_appends; return exhausted("append:3"); }
     }
     const auto t_mapped = std::chrono::steady_clock::now();
     // copy: runs of consecutive global rows inside one stripe are consecutive local rows
@@ -452,6 +467,11 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
         const auto t_end = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         g.append_bytes = n_rows * rb; g.append_map_ms = ms(t_begin, t_mapped); g.append_copy_ms = ms(t_mapped, t_copied); g.append_shadow_ms = ms(t_copied, t_end);
+        ++g.appends;
+        if (ms(t_begin, t_end) > g.slow_append_ms.load()) {   // an outlier among many appends says where its time went
+            g.slow_append_ms = ms(t_begin, t_end); g.slow_map_ms = ms(t_begin, t_mapped); g.slow_copy_ms = ms(t_mapped, t_copied);
+            g.slow_shadow_ms = ms(t_copied, t_end); g.slow_append_bytes = n_rows * rb;
+        }
     }
     return YAMS_OK;
 }
@@ -484,7 +504,7 @@ yams_status_t vs_corpus_set_tie_ranks(void*, uint64_t id, const uint32_t* ranks,
         std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return glob[x] < glob[y]; });
         for (uint32_t p = 0; p < nl; ++p) { lrank[order[p]] = p; linv[p] = order[p]; }
-        if (!s.tie.ensure(nl * 4, s.rows.reserved / 16) || !s.inv.ensure(nl * 4, s.rows.reserved / 16)) return YAMS_ERR_INTERNAL;
+        if (!s.tie.ensure(nl * 4, s.rows.reserved / 16) || !s.inv.ensure(nl * 4, s.rows.reserved / 16)) return YAMS_ERR_RESOURCE_EXHAUSTED;
         (void)hipSetDevice(s.device);
         if (!s.tie.h2d(0, lrank.data(), nl * 4, g.upload_ctx[i]->stream) || !s.inv.h2d(0, linv.data(), nl * 4, g.upload_ctx[i]->stream) ||
             yams_accel_ctx_synchronize(g.upload_ctx[i]) != YAMS_OK) return YAMS_ERR_INTERNAL;
@@ -588,7 +608,7 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
             yams_accel_ctx* sc = yams_scan_sharded_lane_ctx(g.sharded, i, slot.lane);
             (void)hipSetDevice(s.device);
             uint32_t* d_mask = nullptr;
-            if (yams_accel::ws_get(sc, "plugin_row_mask", words * 4, (void**)&d_mask) != YAMS_OK) return YAMS_ERR_INTERNAL;
+            if (const yams_status_t ws = yams_accel::ws_get(sc, "plugin_row_mask", words * 4, (void**)&d_mask); ws != YAMS_OK) return ws;
             if (yams_accel_upload(sc, d_mask, local.data(), words * 4) != YAMS_OK) return YAMS_ERR_INTERNAL;
             v.row_mask = d_mask; v.row_mask_count = bits;
         }
@@ -1163,13 +1183,33 @@ static int plugin_health_impl(char** out_json) {
     std::shared_lock<std::shared_mutex> lk(g.mu);
     std::ostringstream os;
     size_t n_corpora;
-    { std::lock_guard<std::mutex> cl(g.corpora_mu); n_corpora = g.corpora.size(); }
+    // device memory behind the mirrors: mapped into live corpora, and parked (mappings of destroyed corpora waiting for
+    // the next one) — what an allocation-failure test watches for leaks
+    uint64_t mirror_mapped = 0, mirror_parked = 0;
+    {
+        std::lock_guard<std::mutex> cl(g.corpora_mu);
+        n_corpora = g.corpora.size();
+        for (auto& kv : g.corpora) {
+            for (auto& s : kv.second->sh)
+                for (const GrowBuf* b : {&s.rows, &s.bf16, &s.i8, &s.nsq, &s.i8meta, &s.tie, &s.inv}) mirror_mapped += b->mapped;
+            mirror_mapped += kv.second->rank_of_row.mapped;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> pl(g_park_mu);
+        for (auto& kv : g_parked) for (auto& b : kv.second) mirror_parked += b.mapped;
+    }
     os << "{\"status\":\"" << (g.initialised ? "ok" : "not_initialised") << "\",\"devices\":[";
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"l2_accumulate\":\"" << (g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64") << "\""
-       << ",\"last_append\":{\"bytes\":" << g.append_bytes << ",\"map_ms\":" << g.append_map_ms << ",\"copy_ms\":" << g.append_copy_ms
-       << ",\"shadow_ms\":" << g.append_shadow_ms << "}"
+       << ",\"last_append\":{\"bytes\":" << g.append_bytes.load() << ",\"map_ms\":" << g.append_map_ms.load() << ",\"copy_ms\":" << g.append_copy_ms.load()
+       << ",\"shadow_ms\":" << g.append_shadow_ms.load() << "}"
+       << ",\"appends\":" << g.appends.load() << ",\"exhausted_appends\":" << g.exhausted_appends.load()
+       << ",\"slowest_append\":{\"bytes\":" << g.slow_append_bytes.load() << ",\"ms\":" << g.slow_append_ms.load() << ",\"map_ms\":" << g.slow_map_ms.load()
+       << ",\"copy_ms\":" << g.slow_copy_ms.load() << ",\"shadow_ms\":" << g.slow_shadow_ms.load() << "}"
+       << ",\"mirror_bytes_mapped\":" << mirror_mapped << ",\"mirror_bytes_parked\":" << mirror_parked
+       << ",\"alloc_faults_injected\":" << yams_accel_debug_alloc_faults()
        << ",\"corpora\":" << n_corpora << ",\"searches\":" << g.searches.load() << ",\"hashes\":" << g.hashes.load()
        << ",\"chunk_calls\":" << g.chunk_calls.load()
        << ",\"refused_lone_chains\":" << g.refused_chains.load() << ",\"deferred_buffer_hashes\":" << g.deferred_chains.load();

@@ -625,7 +625,7 @@ bool grow_pinned(void** p, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return true;
     if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
     const size_t want = (bytes + bytes / 4 + 4095) & ~static_cast<size_t>(4095);
-    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    if (ya_host_malloc(p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
     *cap = want;
     return true;
 }
@@ -634,7 +634,7 @@ bool grow_device(void** p, size_t* cap, size_t bytes, hipStream_t quiet) {
     if (*cap >= bytes && *p) return true;
     if (*p) { (void)hipStreamSynchronize(quiet); (void)hipFree(*p); *p = nullptr; *cap = 0; }
     const size_t want = ((bytes ? bytes : 16) + bytes / 4 + 255) & ~static_cast<size_t>(255);
-    if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    if (ya_malloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
     *cap = want;
     return true;
 }
@@ -674,7 +674,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         (void)hipGetDevice(&dev0); // the caller's current device is restored below
         if (!grow_pinned(reinterpret_cast<void**>(&L.h_queries), &L.h_queries_cap, nq * dim * 4) ||
             !grow_pinned(reinterpret_cast<void**>(&L.h_out), &L.h_out_cap, out_layout(nq, k).bytes))
-            return set_error(s, YAMS_ERR_INTERNAL, "pinned staging could not be allocated");
+            return set_error(s, YAMS_ERR_RESOURCE_EXHAUSTED, "pinned staging could not be allocated");
         // device buffers of the batch are sized HERE, on the caller's thread while the lane is idle, so that no rank
         // can drop out of an exchange later for want of memory
         const size_t need = static_cast<size_t>(L.stride) * n;
@@ -688,7 +688,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
                 ok = grow_device(reinterpret_cast<void**>(&SL.gathered), &SL.gathered_cap, need, SL.side);
             if (!ok) {
                 (void)hipSetDevice(dev0);
-                return set_error(s, YAMS_ERR_INTERNAL, "device buffers of the batch could not be allocated");
+                return set_error(s, YAMS_ERR_RESOURCE_EXHAUSTED, "device buffers of the batch could not be allocated");
             }
         }
         (void)hipSetDevice(dev0);
