@@ -577,7 +577,11 @@ YAMS_ACCEL_API yams_status_t yams_ingest_device(yams_accel_ctx* ctx, const uint8
 /* The same path for blobs in HOST memory (what ContentStore::store has after reading a file,
  * content_store_impl.cpp:199-231): blobs cross PCIe in batches of ~batch_bytes (0 = chosen from the call: about
  * 2048 of its longest blob, 1 to 8 GiB, at least four batches — the digest chains of a batch take (longest blob) /
- * 35 MB/s and three batches' chains are in flight; a blob is never split) through two device buffers, batch i + 1 uploading while batch i is chunked and hashed.
+ * 35 MB/s and three batches' chains are in flight; a blob is never split; and never more than a tenth of the device
+ * memory that is free when the call starts, so that four slot buffers + tables take at most half of it) through two to
+ * four device buffers, batch i + 1 uploading while batch i is chunked and hashed.  Device footprint: during the call up
+ * to 4 x batch_bytes + ~25 % of tables; AFTER the call the context keeps no buffer above 1.25 GiB (larger ones are
+ * freed on return: they belong to the call, not to the context).
  * Pinned (page-locked) blob memory uploads at link speed, pageable memory through the runtime's
  * staging.  Results go to caller arrays: out_blob_first[n_blobs + 1] (prefix of chunk counts),
  * out_chunk_offset / out_chunk_size [chunk_cap], out_chunk_digest [chunk_cap][32] (nullable),

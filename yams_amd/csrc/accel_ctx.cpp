@@ -62,6 +62,20 @@ yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void**
     return YAMS_OK;
 }
 
+size_t ws_trim(yams_accel_ctx* ctx, size_t keep_bytes) {
+    size_t freed = 0;
+    bool synced = false;
+    for (auto& kv : ctx->bufs) {
+        auto& b = kv.second;
+        if (!b.p || b.cap <= keep_bytes) continue;
+        if (!synced) { (void)hipStreamSynchronize(ctx->stream); synced = true; }
+        if (hipFree(b.p) != hipSuccess) (void)hipGetLastError();
+        freed += b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
+    return freed;
+}
+
 yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out) {
     if (ctx->pinned_cap < bytes) {
         if (ctx->pinned) {

@@ -62,6 +62,9 @@ yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what);
 
 // Workspace: returns a device pointer of at least `bytes` (contents undefined).
 yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out);
+// Frees every workspace buffer of the context larger than `keep_bytes` (after a synchronisation of its stream); returns
+// the bytes given back.  For calls whose buffers scale with the CALL (GiB-sized ingest batches), not with the device.
+size_t ws_trim(yams_accel_ctx* ctx, size_t keep_bytes);
 yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
 
 // Host -> device copy of `bytes` at `src` (any host memory) to `dst` on `stream`, enqueued like hipMemcpyAsync — the

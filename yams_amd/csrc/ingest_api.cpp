@@ -300,6 +300,14 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         else if (flags & YAMS_INGEST_DEFER_LONG_BLOB_DIGESTS) longest = std::min(longest, yams_ingest_defer_threshold_host(total));
         const uint64_t cap = std::max<uint64_t>(1ull << 30, std::min<uint64_t>(8ull << 30, total / 4));
         batch_bytes = std::min(cap, std::max<uint64_t>(1ull << 30, longest * 2048));
+        // ... within what the device has to spare: four slot buffers + the per-batch tables (about a quarter more) may take
+        // half of the memory that is free NOW — a device that holds a 67 GB mirror still has room, one that is nearly
+        // full gets smaller batches (slower, not an out-of-memory failure of this call or of the next corpus_append)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+            const uint64_t per_slot = static_cast<uint64_t>(free_b) / 2 / 5;
+            batch_bytes = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(256ull << 20, per_slot));
+        } else (void)hipGetLastError();
     }
     // batches of consecutive blobs (a blob never straddles two: its digest is one chain); every blob
     // starts on a 16-byte boundary of the device buffer
@@ -341,6 +349,11 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
     IngestLane lanes[kSlots];
     yams_status_t rc = YAMS_OK;
     auto cleanup = [&]() {
+        // Footprint: the slot buffers and batch tables of GiB-sized batches (up to 4 x 8 GiB + tables for 4 MiB blobs with
+        // whole-blob digests) belong to the CALL — a context that kept them (workspaces only ever grow) would sit on
+        // ~36 GiB for good, in the plugin one such share per pooled context, next to mirrors sized as shares of the
+        // device.  What stays with the context after the call: buffers up to 1 GiB + headroom, as before round 4.
+        struct Trim { yams_accel_ctx* c; bool on; ~Trim() { if (on) (void)ws_trim(c, (1ull << 30) + (1ull << 28)); } } trim{ctx, largest > (1ull << 30)};
         if (copy_st) { (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); }
         for (hipEvent_t e : landed) if (e) (void)hipEventDestroy(e);
         for (IngestLane& l : lanes) {
