@@ -316,14 +316,18 @@ private:
 
 inline Result<std::unique_ptr<IChunker>> createAccelChunker(std::shared_ptr<accel::Plugin> plugin,
                                                             AccelChunkerKind kind, ChunkingConfig config = {}) {
-    auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, YAMS_IFACE_CHUNKER_V1_VERSION);
+    // version 1 is all this adapter NEEDS (a plugin refuses versions above its own): what a newer vtable adds — chunk_many
+    // (2), chunk_window (3) — is used when vt->abi_version says it is there, and has a fallback when it is not
+    auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, 1);
     if (!vt) return vt.error();
     return std::unique_ptr<IChunker>(new AccelChunker(std::move(plugin), vt.value(), kind, std::move(config)));
 }
 // the concrete type, for hosts that batch (chunkMany / chunkFiles)
 inline Result<std::unique_ptr<AccelChunker>> createAccelBatchChunker(std::shared_ptr<accel::Plugin> plugin,
                                                                      AccelChunkerKind kind, ChunkingConfig config = {}) {
-    auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, YAMS_IFACE_CHUNKER_V1_VERSION);
+    // version 1 is all this adapter NEEDS (a plugin refuses versions above its own): what a newer vtable adds — chunk_many
+    // (2), chunk_window (3) — is used when vt->abi_version says it is there, and has a fallback when it is not
+    auto vt = plugin->getInterface<yams_chunker_v1>(YAMS_IFACE_CHUNKER_V1, 1);
     if (!vt) return vt.error();
     return std::make_unique<AccelChunker>(std::move(plugin), vt.value(), kind, std::move(config));
 }

@@ -2,10 +2,12 @@
 #include "accel_ctx.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <thread>
@@ -180,9 +182,10 @@ struct StageRing {
     static constexpr size_t kPiece = size_t(32) << 20;
     std::mutex mu;                 // one staged upload at a time (the crew and the ring are shared)
     unsigned char* buf[kBufs] = {nullptr, nullptr, nullptr};
-    hipEvent_t landed[kBufs] = {nullptr, nullptr, nullptr};
-    bool used[kBufs] = {false, false, false};
-    int device = -1;               // the events' device
+    // events belong to a device: one set per device that ever uploaded (a multi-shard corpus_append alternates devices
+    // with every stripe — re-making the set on each change cost three event destroy / create pairs per stripe)
+    std::map<int, std::array<hipEvent_t, kBufs>> landed_by_device;
+    hipEvent_t guard[kBufs] = {nullptr, nullptr, nullptr};   // the event behind the copy that last read buf[i] (null: idle)
     std::unique_ptr<CopyCrew> crew;
     bool broken = false;
 };
@@ -207,15 +210,14 @@ hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
         unsigned hw = std::thread::hardware_concurrency();
         R.crew.reset(new CopyCrew(std::max(1u, std::min(7u, hw > 2 ? hw / 2 - 1 : 1u))));
     }
-    if (R.device != dev) { // (events belong to a device: re-made when another device uploads)
-        for (int i = 0; i < StageRing::kBufs; ++i) {
-            if (R.landed[i]) { (void)hipEventSynchronize(R.landed[i]); (void)hipEventDestroy(R.landed[i]); R.landed[i] = nullptr; }
-            R.used[i] = false;
-        }
+    auto found = R.landed_by_device.find(dev);
+    if (found == R.landed_by_device.end()) {
+        std::array<hipEvent_t, StageRing::kBufs> ev{};
         for (int i = 0; i < StageRing::kBufs; ++i)
-            if (hipEventCreateWithFlags(&R.landed[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); R.broken = true; }
-        R.device = dev;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); R.broken = true; }
+        found = R.landed_by_device.emplace(dev, ev).first;
     }
+    hipEvent_t* const landed = found->second.data();
     for (int i = 0; i < StageRing::kBufs && !R.broken; ++i)
         if (!R.buf[i] && ya_host_malloc(reinterpret_cast<void**>(&R.buf[i]), StageRing::kPiece, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError(); R.buf[i] = nullptr; R.broken = true;
@@ -226,16 +228,17 @@ hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
     int b = 0;
     for (size_t off = 0; off < bytes; off += StageRing::kPiece, b = (b + 1) % StageRing::kBufs) {
         const size_t len = std::min(StageRing::kPiece, bytes - off);
-        if (R.used[b]) { const hipError_t e = hipEventSynchronize(R.landed[b]); if (e != hipSuccess) return e; }
+        if (R.guard[b]) { const hipError_t e = hipEventSynchronize(R.guard[b]); R.guard[b] = nullptr; if (e != hipSuccess) return e; }
         R.crew->copy(R.buf[b], sp + off, len);
         hipError_t e = hipMemcpyAsync(dp + off, R.buf[b], len, hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipEventRecord(R.landed[b], stream);
+        if (e == hipSuccess) e = hipEventRecord(landed[b], stream);
         if (e != hipSuccess) return e;
-        R.used[b] = true;
+        R.guard[b] = landed[b];
     }
-    // the ring is reused by the next call: everything it holds must have left before the lock goes
+    // the ring is reused by the next call (possibly of another device): everything it holds must have left host memory
+    // before the lock goes — the call returns with the SOURCE free to reuse and the last pieces landed
     for (int i = 0; i < StageRing::kBufs; ++i)
-        if (R.used[i]) { const hipError_t e = hipEventSynchronize(R.landed[i]); R.used[i] = false; if (e != hipSuccess) return e; }
+        if (R.guard[i]) { const hipError_t e = hipEventSynchronize(R.guard[i]); R.guard[i] = nullptr; if (e != hipSuccess) return e; }
     return hipSuccess;
 }
 

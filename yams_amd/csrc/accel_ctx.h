@@ -41,6 +41,7 @@ struct yams_accel_ctx {
     // name prefix of ws_get: a nested scan (the split-filter escalation of a batch) works in its
     // own namespace, so the buffers of the call that is still in flight around it stay intact
     std::string ws_ns;
+    uint32_t emu_calls = 0; // measurement build: batches this context has served (emulation knobs of scan_api.cpp)
     // pinned host staging
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -67,8 +68,11 @@ yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void**
 size_t ws_trim(yams_accel_ctx* ctx, size_t keep_bytes);
 yams_status_t pinned_get(yams_accel_ctx* ctx, size_t bytes, void** out);
 
-// Host -> device copy of `bytes` at `src` (any host memory) to `dst` on `stream`, enqueued like hipMemcpyAsync — the
-// caller synchronises the stream — but at the link's rate from PAGEABLE memory too: the runtime's own staging of a
+// Host -> device copy of `bytes` at `src` (any host memory) to `dst` on `stream`, ordered on the stream like
+// hipMemcpyAsync (the caller synchronises the stream before it reads `dst` from another one).  Large pageable sources:
+// the call RETURNS ONLY AFTER the data has left host memory (the source may be reused at once; the host is blocked for
+// the length of the transfer) and uploads of one process take turns on one ring — in exchange they run at the link's
+// rate from PAGEABLE memory too: the runtime's own staging of a
 // pageable source is one thread and one bounce buffer (measured: 6.2 GB/s for a 38 GB corpus upload), this one fills a
 // ring of pinned buffers with several threads while the previous buffer is on its way.  Pinned / registered sources and
 // small copies go straight to hipMemcpyAsync.  `dst` must lie inside ONE allocation (callers split at chunk borders).

@@ -751,7 +751,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int i = 0; i < 16; ++i) {
             const int rb = i >> 2, c = i & 3;
             if (Z0 && first) // the accumulator is BORN here: C = the inline constant 0 (no register holds a zero, no earlier value is alive)
-                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=v"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
+                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
             else if (ABL != 2 && ABL != 4)
                 acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
             else if (i == 0)
