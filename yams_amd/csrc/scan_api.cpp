@@ -374,6 +374,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
 #ifdef YAMS_ACCEL_MEASURE
         if (bf16_version == 40) L.i8_form = 1; // A/B runs: half tiles where the library would pick the resident-query form
 #endif
+        // Multi-GPU modes (the sharded handle's exchange fence, or a caller that holds the gate for its collective): the
+        // exchange of the previous batch may still be on this device when this batch's SAMPLE pass starts — only the filter
+        // sweep is fenced behind it.  The resident-query sample form is a grid of one 160 KiB workgroup per CU: a collective
+        // kernel would have to wait for it.  The half-tile form (two small workgroups per CU) leaves it room.
+        L.i8_sample_small_grid = static_cast<bool>(ctx->before_sweep) || ctx->sweep_hold;
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         if (i8 && metric == YAMS_SCAN_L2) {

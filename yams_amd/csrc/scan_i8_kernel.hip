@@ -1904,7 +1904,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         const uint32_t s_units = (L.plan.n_sample_tiles + 1u) / 2u;
         // (a caller that forces the resident form — YAMS_SCAN_FLAG_RESIDENT_QUERIES, the tests' small shards — gets its
         //  sample pass in that form whatever the stream length)
-        bool resident_sample = rp.use && !L.i8_l2 && L.i8_sync && L.plan.sample_stride >= 2 &&
+        bool resident_sample = rp.use && !L.i8_l2 && L.i8_sync && L.plan.sample_stride >= 2 && !L.i8_sample_small_grid &&
                                (L.i8_form == 2 ? s_units >= 1u : s_units >= 4u * rp.n_streams);
 #ifdef YAMS_ACCEL_MEASURE
         if (const char* sv = std::getenv("YAMS_ACCEL_I8R_SAMPLE")) resident_sample = resident_sample && std::atoi(sv) != 0;

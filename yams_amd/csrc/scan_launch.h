@@ -23,6 +23,8 @@ struct ScanLaunch {
     const uint8_t* i8_row_bias = nullptr;
     const uint32_t* i8_q_bias = nullptr;
     float l2_eps = 0.f;
+    bool i8_sample_small_grid = false;   // a collective may be in flight on this device (sharded fence / sweep hold): the sample
+                                         // pass must not own every CU — it takes the half-tile form, which leaves room
     int i8_form = 0;                     // int8 filter pass: 0 = the library's choice, 1 = half tiles, 2 = resident queries when possible
     bool i8_q_form = false;              // resident queries with 128 x 128 wave tiles (i8_takes_q_form): the log holds BLOCK entries
     double i8_mask_inflation = 1.0;      // n_rows / rows the allow-mask lets through (block entries are written before the mask is applied)

@@ -25,7 +25,9 @@
 //     or more shards a shard's sweep of batch i + 1 is enqueued only after its part of the exchange of batch i
 //     has been enqueued, and waits (on the device) for that part to complete: on the root shard all-gather +
 //     merge + download, elsewhere the all-gather.  What still overlaps the sweep of batch i is everything in
-//     front of the sweep of batch i + 1: query upload, preparation, the sample pass.  The price is the gap
+//     front of the sweep of batch i + 1: query upload, preparation, the sample pass (in its half-tile form while a
+//     fence or a sweep hold is installed — scan_api.cpp, i8_sample_small_grid: the resident-query sample form would be
+//     a second grid that owns every CU, and the exchange of batch i may still be on the device when it starts).  The price is the gap
 //     between two sweeps (host hand-over + the all-gather of ~1 MB per rank + on the root the merge); what it
 //     buys is that no collective ever shares a device with a sweep.  (accel_ctx.h: before_sweep.)
 //   * the contexts of one device share a sweep gate (yams_accel_gate): big filter sweeps run one after the
