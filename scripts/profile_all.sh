@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 ulimit -c 0
 REPO=$PWD; OUT=$REPO/gpurun_out
-B="python $REPO/bench.py --no-cpu-baseline --no-ingest --no-hbm-leg --no-c-abi-leg --no-boundary-leg --no-telemetry"   # (the HBM leg runs the same kernel at Q = 64: profiled apart, below, so that this trace averages ONE workload)
+B="python $REPO/bench.py --steps 20 --warmup 5 --oracle-queries 0 --no-cpu-baseline --no-ingest --no-hbm-leg --no-l2-leg --no-c-abi-leg --no-boundary-leg --no-telemetry"   # (the HBM leg runs the same kernel at Q = 64: profiled apart, below, so that this trace averages ONE workload)
 # (bench.py builds the bf16 filter shadow before the timed region; shadow_build_kernel shows up once in the trace)
 I="python $REPO/scripts/ingest_bench.py --gib 100 --reps 2"
 rm -rf $OUT/prof_trace $OUT/prof_ingest $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3
