@@ -960,6 +960,14 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
             append_ms.append((time.perf_counter() - ta) * 1e3)
         del stage
         staging_s = time.perf_counter() - t0 - upload_s     # this script's own D2H of the rows into fresh pageable arrays (round 3 counted it as upload)
+        slowest = None
+        try:    # where the slowest append of the series spent its time (health JSON: mapping fresh memory / the copy / the shadows)
+            hp = C.c_void_p()
+            if L.yams_plugin_get_health_json(C.byref(hp)) == 0:
+                hj = json.loads(C.string_at(hp).decode()); L.yams_accel_free_string(hp)
+                slowest = hj.get("slowest_append")
+        except Exception:      # noqa: BLE001
+            slowest = None
         if not ok:
             out[name] = {"error": "corpus_append failed"}; vt.corpus_destroy(None, cid); continue
         qdev = torch.empty((1024, d), dtype=torch.float32, device=dev)
@@ -970,7 +978,8 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
                "upload_what": "the corpus_append calls alone: pageable host rows -> device mirror through the pinned staging ring, "
                               "device memory mapped behind the mirrors as they grow, bf16 + int8 shadows built",
                "bench_host_staging_s": staging_s,
-               "append_calls": len(append_ms), "append_ms_min_median_max": [round(min(append_ms), 2), round(sorted(append_ms)[len(append_ms) // 2], 2), round(max(append_ms), 2)]}
+               "append_calls": len(append_ms), "append_ms_min_median_max": [round(min(append_ms), 2), round(sorted(append_ms)[len(append_ms) // 2], 2), round(max(append_ms), 2)],
+               "slowest_append_so_far": slowest}
         for q in (1, 16, 1024):
             hits = C.POINTER(_lib.ScanHit)(); counts = _lib.u32p()
             reps = 30 if (n <= 1_000_000 or q < 1024) else 8

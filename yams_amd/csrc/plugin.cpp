@@ -1091,6 +1091,8 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
         g.want_i8 = std::strstr(p, "\"both\"") || std::strstr(p, "\"i8\"");
     }
     g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;
+    g.append_bytes = 0; g.appends = 0; g.exhausted_appends = 0; g.append_map_ms = 0; g.append_copy_ms = 0; g.append_shadow_ms = 0;
+    g.slow_append_ms = 0; g.slow_map_ms = 0; g.slow_copy_ms = 0; g.slow_shadow_ms = 0; g.slow_append_bytes = 0;
     if (const char* p = config_json ? std::strstr(config_json, "\"l2_accumulate\"") : nullptr) {
         // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header)
         const char* c = std::strchr(p + 15, ':');
