@@ -113,6 +113,7 @@ if bad:
     print("MISMATCH " + json.dumps(bad[:4]), file=sys.stderr, flush=True)
 if rank == 0:
     print(json.dumps({"ok": bool(t.item() == 1.0), "world": world, "bounds": b, "gpu": bool(use_gpu),
-                      "backend": backend, "merge": "merge_topk_kernel" if use_gpu else "python (test fallback)"}))
+                      "backend": backend, "merge": "merge_topk_kernel" if use_gpu else "python (test fallback)",
+                      "exchange": pipe.exchange_stats(), "batches": n_batches}))
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()

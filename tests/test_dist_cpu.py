@@ -29,6 +29,9 @@ def test_gloo_sharded_search_matches_oracle(world, monkeypatch):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["ok"] and out["world"] == world and out["bounds"] == [3000 * g // world for g in range(world + 1)]
+    # what the N > 1 bench line is built from: one collective per batch, every exchange timed
+    ex = out["exchange"]
+    assert ex["collectives"] == ex["exchanges"] == out["batches"] and 0 < ex["exchange_ms"] <= ex["exchange_ms_max"], ex
 
 
 def test_deadline_fires_once_with_a_one_line_diagnosis_and_not_when_the_block_finishes():

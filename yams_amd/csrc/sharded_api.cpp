@@ -457,6 +457,7 @@ void declare_stuck(yams_scan_sharded* s, const std::string& why) {
         if (first) s->stuck_why = why;
         s->last_error = why;
     }
+    s->cv_lane.notify_all(); // callers blocked in lane_acquire learn about it
     if (!first) return;
     std::fprintf(stderr, "[yams_mi355x_accel] sharded search STUCK: %s\n", why.c_str());
     if (s->mode == kRccl && s->R && s->R->CommAbort) {
@@ -921,6 +922,8 @@ extern "C" yams_status_t yams_scan_sharded_lane_acquire(yams_scan_sharded* s, in
     try {
         std::unique_lock<std::mutex> lk(s->mu);
         for (;;) {
+            // a stuck handle hands out no lanes: the lanes of its hung batches never come back, a caller must not wait for them
+            if (s->stuck) { s->last_error = "the handle is stuck (" + s->stuck_why + "): destroy it"; return YAMS_ERR_TIMEOUT; }
             for (uint32_t li = 0; li < s->n_lanes; ++li)
                 if (!s->lanes[li]->acquired) { s->lanes[li]->acquired = true; s->lanes[li]->submitted = false; *out_lane = li; return YAMS_OK; }
             if (!wait) return YAMS_ERR_NOT_FOUND; // every lane has a batch in flight: wait() for one

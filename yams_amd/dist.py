@@ -218,6 +218,8 @@ class GatherPipeline:
         if self.done[slot] is not None:
             ev = self.done[slot]
             if not ev.query():          # poll under a deadline: a collective whose peer never arrives must not hang the job
+                # (sleeping, not spinning: the other lane's host thread needs the interpreter to enqueue its batch; a slot is
+                #  normally complete long before it is waited for — the loop runs at the drain of a run of steps only)
                 deadline = time.monotonic() + self.watchdog_s
                 while not ev.query():
                     if time.monotonic() > deadline:
@@ -225,7 +227,7 @@ class GatherPipeline:
                             f"all-gather + merge of slot {slot} not complete after {self.watchdog_s:.0f} s "
                             f"(backend {self.backend}, world {self.world}, rank {self.dist.get_rank()}, {self.rec_bytes} B per rank, "
                             f"{self.exchanges} exchanges completed before it): a peer rank is missing or the link is down")
-                    time.sleep(0.0002)
+                    time.sleep(0.0001)
             if self.backend != "gloo":
                 ms = self.begun[slot].elapsed_time(ev)
         if ms is None:
