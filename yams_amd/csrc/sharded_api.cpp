@@ -784,13 +784,18 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
     if (L.merge_issued) {   // also when a shard failed: the lane's buffers must be quiet before reuse
         if (s->timeout_ms == UINT32_MAX) (void)hipEventSynchronize(L.done);
         else {
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(s->timeout_ms);
-            unsigned spins = 0;
+            // (a batch is through in milliseconds: the first 50 ms are polled without sleeping — what hipEventSynchronize
+            //  does as well — so that the deadline costs the caller's turn-around nothing; only a wait that is already
+            //  long sleeps between looks)
+            const auto t_wait = std::chrono::steady_clock::now();
+            const auto deadline = t_wait + std::chrono::milliseconds(s->timeout_ms);
+            const auto spin_until = t_wait + std::chrono::milliseconds(50);
             for (;;) {
                 const hipError_t e = hipEventQuery(L.done);
                 if (e == hipSuccess) break;
                 if (e != hipErrorNotReady) { (void)hipGetLastError(); break; }
-                if (std::chrono::steady_clock::now() > deadline) {
+                const auto now = std::chrono::steady_clock::now();
+                if (now > deadline) {
                     std::ostringstream os;
                     os << "batch " << L.seq << " on lane " << lane << ": all-gather + merge not complete on the root shard (device "
                        << s->device[0] << ") after " << s->timeout_ms << " ms (collective " << (s->mode == kRccl ? "rccl" : "peer_copy")
@@ -800,7 +805,7 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
                     declare_stuck(s, os.str());
                     return release(YAMS_ERR_TIMEOUT, os.str());
                 }
-                if (++spins < 2000) std::this_thread::yield();
+                if (now < spin_until) std::this_thread::yield();
                 else std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
         }
