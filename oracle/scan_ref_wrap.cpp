@@ -135,35 +135,45 @@ __attribute__((visibility("default"))) int scanref_insert(void* hv, const char* 
 
 // n rows of `dim` floats; chunk ids from `chunk_ids` (n C strings) or, when null, "c" + the zero-padded ordinal (so
 // that chunk-id order == row order, the case the oracle's default tie rank restates).
-__attribute__((visibility("default"))) int scanref_insert_rows(void* hv, const float* rows, size_t n, size_t dim, const char* const* chunk_ids,
-                                                               long long first_ordinal) {
+__attribute__((visibility("default"))) int scanref_insert_rows_docs(void* hv, const float* rows, size_t n, size_t dim, const char* const* chunk_ids,
+                                                                    const char* const* document_hashes, long long first_ordinal) {
     char id[32];
     for (size_t r = 0; r < n; ++r) {
         const char* cid = chunk_ids ? chunk_ids[r] : id;
         if (!chunk_ids) std::snprintf(id, sizeof id, "c%018lld", first_ordinal + static_cast<long long>(r));
-        if (scanref_insert(hv, cid, "doc", rows + r * dim, static_cast<int>(dim * sizeof(float)), static_cast<long long>(dim),
+        if (scanref_insert(hv, cid, document_hashes ? document_hashes[r] : "doc", rows + r * dim, static_cast<int>(dim * sizeof(float)), static_cast<long long>(dim),
                            first_ordinal + static_cast<long long>(r), nullptr) != 0)
             return 1;
     }
     return 0;
 }
+__attribute__((visibility("default"))) int scanref_insert_rows(void* hv, const float* rows, size_t n, size_t dim, const char* const* chunk_ids,
+                                                               long long first_ordinal) {
+    return scanref_insert_rows_docs(hv, rows, n, dim, chunk_ids, nullptr, first_ordinal);
+}
 
-// bruteForceSearchUnlocked(query, k, threshold, nullopt, {}, metadata_filters, &diagnostics, rowSelection).
+// bruteForceSearchUnlocked(query, k, threshold, document_hash, candidate_hashes, metadata_filters, &diagnostics, rowSelection).
+// document_hash (nullable) and candidate_hashes restrict the rows the statement visits (:4151-4195: pushed into SQL).
 // meta_kv: n_meta (key, value) pairs, flattened; a NON-EMPTY filter map selects the reference's record path (:4333-4409).
 // Returns 0 and fills out_* (ordinals = start_offset of the returned records, scores = relevance_score; *out_n may
 // exceed cap: the count the reference returned), or the reference's ErrorCode as a negative number.
 // diag[4] = rowsVisited, exactDistanceEvaluations, returnedRows, usedExactScan.
-__attribute__((visibility("default"))) long scanref_search(void* hv, const float* query, size_t dim, size_t k, float threshold,
-                                                           const char* const* meta_kv, size_t n_meta, int all_matching,
-                                                           long long* out_ordinals, float* out_scores, size_t cap, size_t* out_n,
-                                                           unsigned long long* diag) {
+__attribute__((visibility("default"))) long scanref_search_ex(void* hv, const float* query, size_t dim, size_t k, float threshold,
+                                                              const char* document_hash, const char* const* candidate_hashes, size_t n_candidates,
+                                                              const char* const* meta_kv, size_t n_meta, int all_matching,
+                                                              long long* out_ordinals, float* out_scores, size_t cap, size_t* out_n,
+                                                              unsigned long long* diag) {
     auto* h = static_cast<RefScan*>(hv);
     sqlite3_exec(h->db_, "COMMIT", nullptr, nullptr, nullptr); // (no-op when no transaction is open)
     std::vector<float> q(query, query + dim);
     std::map<std::string, std::string> filters;
     for (size_t i = 0; i < n_meta; ++i) filters[meta_kv[2 * i]] = meta_kv[2 * i + 1];
+    std::optional<std::string> doc;
+    if (document_hash) doc = document_hash;
+    std::unordered_set<std::string> cands;
+    for (size_t i = 0; i < n_candidates; ++i) cands.insert(candidate_hashes[i]);
     yams::vector::VectorSearchDiagnostics dg;
-    auto r = h->bruteForceSearchUnlocked(q, k, threshold, std::nullopt, {}, filters, &dg,
+    auto r = h->bruteForceSearchUnlocked(q, k, threshold, doc, cands, filters, &dg,
                                          all_matching ? yams::vector::ExactRowSelection::AllMatching
                                                       : yams::vector::ExactRowSelection::TopK);
     if (diag) { diag[0] = dg.rowsVisited; diag[1] = dg.exactDistanceEvaluations; diag[2] = dg.returnedRows; diag[3] = dg.usedExactScan ? 1 : 0; }
@@ -175,6 +185,15 @@ __attribute__((visibility("default"))) long scanref_search(void* hv, const float
         out_scores[i] = recs[i].relevance_score;
     }
     return 0;
+}
+
+// (the plain form: no document / candidate restriction)
+__attribute__((visibility("default"))) long scanref_search(void* hv, const float* query, size_t dim, size_t k, float threshold,
+                                                           const char* const* meta_kv, size_t n_meta, int all_matching,
+                                                           long long* out_ordinals, float* out_scores, size_t cap, size_t* out_n,
+                                                           unsigned long long* diag) {
+    return scanref_search_ex(hv, query, dim, k, threshold, nullptr, nullptr, 0, meta_kv, n_meta, all_matching, out_ordinals, out_scores, cap,
+                             out_n, diag);
 }
 
 __attribute__((visibility("default"))) double scanref_cosine(const float* a, size_t na, const float* b, size_t nb) {

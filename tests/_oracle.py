@@ -319,6 +319,11 @@ class ScanRef:
         L.scanref_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_int,
                                      C.POINTER(C.c_longlong), f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong)]
         L.scanref_search.restype = C.c_long
+        L.scanref_search_ex.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_char_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_longlong), f32p, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong)]
+        L.scanref_search_ex.restype = C.c_long
+        L.scanref_insert_rows_docs.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_longlong]
         L.scanref_cosine.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t]
         L.scanref_cosine.restype = C.c_double
         self.invalid_argument = -int(L.scanref_error_code_invalid_argument())
@@ -335,16 +340,17 @@ class ScanRef:
     def __del__(self):
         self.close()
 
-    def insert_rows(self, rows, chunk_ids=None):
+    def insert_rows(self, rows, chunk_ids=None, document_hashes=None):
         """Rows as the backend stores them (raw fp32 blobs); chunk ids default to zero-padded ordinals (chunk-id order ==
-        row order)."""
+        row order); document_hashes: one per row (default "doc")."""
         rows = np.ascontiguousarray(rows, np.float32)
         n, d = rows.shape
-        ids = None
+        ids = docs = None
         if chunk_ids is not None:
-            enc = [s.encode() for s in chunk_ids]
-            ids = (C.c_char_p * n)(*enc)
-        assert self.L.scanref_insert_rows(self.h, _ptr(rows, f32p), n, d, ids, self.n) == 0
+            ids = (C.c_char_p * n)(*[s.encode() for s in chunk_ids])
+        if document_hashes is not None:
+            docs = (C.c_char_p * n)(*[s.encode() for s in document_hashes])
+        assert self.L.scanref_insert_rows_docs(self.h, _ptr(rows, f32p), n, d, ids, docs, self.n) == 0
         self.n += n
 
     def insert_raw(self, chunk_id, blob: bytes | None, embedding_dim, metadata=None, document_hash="doc"):
@@ -356,9 +362,9 @@ class ScanRef:
                                      embedding_dim, self.n, meta) == 0
         self.n += 1
 
-    def search(self, query, k, thr=-1.0, metadata_filters=None, all_matching=False):
-        """bruteForceSearchUnlocked(query, k, thr, nullopt, {}, metadata_filters, &diag, TopK | AllMatching): returns
-        (ordinals, scores, diag dict) or the negative ErrorCode."""
+    def search(self, query, k, thr=-1.0, metadata_filters=None, all_matching=False, document_hash=None, candidate_hashes=None):
+        """bruteForceSearchUnlocked(query, k, thr, document_hash, candidate_hashes, metadata_filters, &diag, TopK |
+        AllMatching): returns (ordinals, scores, diag dict) or the negative ErrorCode."""
         q = np.ascontiguousarray(query, np.float32)
         cap = max(self.n if (all_matching or metadata_filters) else k, 1)
         cap = max(cap, k, 1)
@@ -370,8 +376,15 @@ class ScanRef:
             for kk, vv in metadata_filters.items():
                 flat += [kk.encode(), vv.encode()]
             kv = (C.c_char_p * len(flat))(*flat); n_meta = len(metadata_filters)
-        rc = self.L.scanref_search(self.h, _ptr(q, f32p), q.size, k, thr, kv, n_meta, 1 if all_matching else 0,
-                                   ords.ctypes.data_as(C.POINTER(C.c_longlong)), _ptr(sc, f32p), cap, C.byref(cnt), dg)
+        cand = None; n_cand = 0
+        if candidate_hashes:
+            cl = sorted(candidate_hashes)
+            cand = (C.c_char_p * len(cl))(*[c.encode() for c in cl]); n_cand = len(cl)
+            cap = max(cap, self.n)
+            ords = np.full(cap, -1, np.int64); sc = np.zeros(cap, np.float32)
+        rc = self.L.scanref_search_ex(self.h, _ptr(q, f32p), q.size, k, thr, document_hash.encode() if document_hash else None,
+                                      cand, n_cand, kv, n_meta, 1 if all_matching else 0,
+                                      ords.ctypes.data_as(C.POINTER(C.c_longlong)), _ptr(sc, f32p), cap, C.byref(cnt), dg)
         if rc != 0:
             return rc
         assert cnt.value <= cap

@@ -71,6 +71,11 @@ CASES = [
      "corpus": {"kind": "normal", "seed": 21, "n": 600, "dim": 24, "repeat": [[99, 111, 99]],
                 "overrides": {"3": f32bits(*([0.0] * 24)), "6": f32bits(2e-6, *([0.0] * 23)), "9": f32bits(np.nan, *([1.0] * 23))}},
      "queries": {"kind": "normal", "seed": 22, "n": 3, "dim": 24}},
+    # candidate restriction on the FAST path (candidate_hashes pushed into SQL, :4151-4195): every fourth row's document is named
+    {"name": "candidates_fast_path_philox_5000_x256_top40", "path": "fast", "k": 40, "threshold": -1.0, "allow_every": 4,
+     "chunk_ids": {"shuffle_seed": 8, "prefix": "k"},
+     "corpus": {"kind": "philox", "seed": 35, "n": 5000, "dim": 256, "repeat": [[16, 24, 16]]},
+     "queries": {"kind": "philox", "seed": 35, "row0": 1 << 40, "n": 5, "dim": 256}},
     {"name": "record_path_philox_4000_x256_top50", "path": "record", "k": 50, "threshold": -1.0, "allow_every": 2,
      "corpus": {"kind": "philox", "seed": 31, "n": 4000, "dim": 256}, "queries": {"kind": "philox", "seed": 31, "row0": 1 << 40, "n": 4, "dim": 256}},
 ]
@@ -85,16 +90,20 @@ def main():
         corpus, queries, _, allow = _cases.golden_scan_inputs(o, case)
         ids = _cases.golden_scan_ids(case, corpus.shape[0])
         t = _oracle.scan_ref()
+        cands = None
         if case["path"] == "record":
             for i in range(corpus.shape[0]):
                 t.insert_raw(ids[i] if ids else "c%018d" % i, corpus[i].tobytes(), corpus.shape[1],
                              metadata={"tag": "a" if allow[i] else "b"})
+        elif allow is not None:     # fast path behind a candidate set: the allowed rows live in the named document
+            t.insert_rows(corpus, chunk_ids=ids, document_hashes=["named" if a else "other" for a in allow])
+            cands = {"named"}
         else:
             t.insert_rows(corpus, chunk_ids=ids)
         expected = []
         for q in queries:
             r = t.search(q, case["k"], case["threshold"], metadata_filters={"tag": "a"} if case["path"] == "record" else None,
-                         all_matching=case.get("all_matching", False))
+                         all_matching=case.get("all_matching", False), candidate_hashes=cands)
             if isinstance(r, int):
                 assert r == t.invalid_argument, r
                 expected.append({"error": "InvalidArgument"})

@@ -1715,6 +1715,8 @@ def test_hip_scan_reproduces_the_reference_compiled_golden_vectors(acc, oracle, 
         if shadow == "both" and not (corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256):
             continue
         flags, mask, k = 0, None, case["k"]
+        if case["path"] == "fast" and allow is not None:
+            mask = allow.astype(bool)                    # candidate_hashes: the host folds the restriction into the allow-mask
         if case["path"] == "record":
             flags, mask = FLAG_RECORD_PATH, allow.astype(bool)
             if case.get("all_matching"):
@@ -1735,4 +1737,4 @@ def test_hip_scan_reproduces_the_reference_compiled_golden_vectors(acc, oracle, 
             assert r.rows[j, :cnt].tolist() == e["rows"], (case["name"], qi, r.diag)
             assert [int(x) for x in r.scores[j, :cnt].view(np.uint32)] == e["score_bits"], (case["name"], qi)
         n_cases += 1
-    assert n_cases >= (5 if shadow == "both" else 14)
+    assert n_cases >= (6 if shadow == "both" else 15)

@@ -173,7 +173,12 @@ def test_golden_scan_vectors_pin_the_oracle(oracle):
     for case in g["cases"]:
         corpus, queries, tie_rank, allow = _cases.golden_scan_inputs(oracle, case)
         for qi, exp in enumerate(case["expected"]):
-            if case["path"] == "fast":
+            if case["path"] == "fast" and allow is not None:      # a candidate set: the oracle over the allowed rows, mapped back
+                idx = np.flatnonzero(allow)
+                sub_rank = None if tie_rank is None else np.argsort(np.argsort(tie_rank[idx])).astype(np.uint32)
+                out = oracle.scan_cosine(corpus[idx], queries[qi], case["k"], case["threshold"], tie_rank=sub_rank)
+                out = (idx[out[0]], out[1])
+            elif case["path"] == "fast":
                 out = oracle.scan_cosine(corpus, queries[qi], case["k"], case["threshold"], tie_rank=tie_rank)
             else:
                 out = oracle.scan_cosine_records(corpus, queries[qi], case["k"], case["threshold"], tie_rank=tie_rank, allow=allow,
@@ -183,3 +188,44 @@ def test_golden_scan_vectors_pin_the_oracle(oracle):
                 continue
             assert list(out[0]) == exp["rows"], (case["name"], qi)
             assert [int(x) for x in out[1].view(np.uint32)] == exp["score_bits"], (case["name"], qi)
+
+
+def test_reference_candidate_and_document_restriction(oracle, table):
+    """`document_hash` / `candidate_hashes` restrict the rows the reference's statement VISITS (pushed into SQL,
+    :4151-4195): first the reference's own known answer (vector_smoke_catch2_test.cpp:355-401 — 2 rows visited, order
+    allowed_best, allowed_second), then 900 rows over 30 documents: the restricted search equals the oracle over exactly
+    the rows of the named documents, in their order, and rowsVisited / exactDistanceEvaluations count those rows only —
+    the contract the host mirror's allow-mask implements (include/yams_accel/vector_index.hpp)."""
+    t = table
+    t.insert_raw("allowed_best", np.array([1, 0, 0, 0], np.float32).tobytes(), 4, document_hash="allowed")
+    t.insert_raw("allowed_second", np.array([0.8, 0.6, 0, 0], np.float32).tobytes(), 4, document_hash="allowed")
+    t.insert_raw("blocked", np.array([1, 0, 0, 0], np.float32).tobytes(), 4, document_hash="blocked")
+    ords, sc, dg = t.search(np.array([1, 0, 0, 0], np.float32), 4, -1.0, candidate_hashes={"allowed"})
+    assert list(ords) == [0, 1] and dg["rows_visited"] == 2 and dg["exact_distance_evaluations"] == 2 and dg["returned_rows"] == 2
+    rng = np.random.default_rng(33)
+    n, d, k = 900, 32, 15
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    corpus[40:44] = corpus[40]                                        # ties inside and across documents
+    corpus[700] = corpus[40]
+    docs = ["doc_%02d" % (i % 30) for i in range(n)]
+    ids = ["x%05d" % v for v in rng.permutation(n)]
+    rank, _ = _cases.string_ranks(ids)
+    t2 = _oracle.scan_ref()
+    t2.insert_rows(corpus, chunk_ids=ids, document_hashes=docs)
+    q = corpus[40] + 0.1 * rng.standard_normal(d).astype(np.float32)
+    for doc, cands in ((None, {"doc_10", "doc_03", "doc_21"}), ("doc_10", None), ("doc_10", {"doc_10", "doc_11"}), ("doc_10", {"doc_11"}),
+                       (None, {"no_such_doc"})):
+        allowed = np.array([(doc is None or docs[i] == doc) and (cands is None or docs[i] in cands) for i in range(n)])
+        idx = np.flatnonzero(allowed)
+        for thr in (-1.0, 0.1):
+            r = t2.search(q, k, thr, document_hash=doc, candidate_hashes=cands)
+            if len(idx) == 0:
+                assert len(r[0]) == 0 and r[2]["rows_visited"] == 0
+                continue
+            sub_rank, _ = _cases.string_ranks([ids[i] for i in idx])
+            rows, sims, visited, evals = oracle.scan_cosine(corpus[idx], q, k, thr, tie_rank=sub_rank)
+            assert np.array_equal(r[0], idx[rows]), (doc, cands, r[0][:6], idx[rows][:6])
+            assert np.array_equal(r[1].view(np.uint32), sims.view(np.uint32))
+            assert r[2]["rows_visited"] == visited == len(idx) and r[2]["exact_distance_evaluations"] == evals
+    # ... and through the metadata path with a candidate set: the same restriction in front of the record loop
+    t2.close()
