@@ -419,7 +419,9 @@ def ingest_leg(acc, torch, gib, seed, verify_all=False):
     acc.enable_timing(False)
     total = n_blobs * blen
     # bit-exactness of the timed call's own output on a spread of blobs (all host cores)
-    verified = verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check=n_blobs if verify_all else 64, ref_every=8 if verify_all else 0)
+    ht = oracle_mod().host_threads()
+    n_check = (n_blobs if ht >= 12 else max(64, n_blobs * ht // 16)) if verify_all else 64   # (16 threads: 39 s for 25 600 blobs)
+    verified = verify_ingest_sample(acc, res, n_blobs, blen, seed, n_check=n_check, ref_every=8 if verify_all else 0)
     cpu = ingest_cpu_baseline(seed, blen)
     n_chunks = int(res.n_chunks)
     # Roofline: the call is bound by 32-bit integer VALU issue, not by HBM.
@@ -1302,7 +1304,15 @@ def main():
     c_timed = res["counts"].cpu().numpy().copy()
 
     # ---- the timed configuration against the oracle over the whole resident corpus ----------------
-    n_oq = a.oracle_queries if a.oracle_queries is not None else (nq if world == 1 else 16)
+    if a.oracle_queries is not None:
+        n_oq = a.oracle_queries
+    elif world > 1:
+        n_oq = 16
+    else:
+        # the whole timed batch where the host can afford it (16 threads: 47 s); a box that grants fewer threads checks a
+        # proportional spread of the batch instead of stretching the run (never fewer than 128 queries)
+        ht = oracle_mod().host_threads()
+        n_oq = nq if ht >= 12 else max(min(nq, 128), nq * ht // 16)
     n_oq = min(n_oq, nq)
     check = None
     if n_oq > 0:
