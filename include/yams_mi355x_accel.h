@@ -386,7 +386,9 @@ typedef struct yams_scan_sharded yams_scan_sharded;
  * few CUs the collective holds.  So with >= 2 shards the exchange is FENCED: on every shard the sweep of batch
  * i + 1 begins only after that shard's part of the exchange of batch i (on the root shard also the merge and the
  * download) has completed — the collective never shares a device with a sweep.  Everything in front of the sweep
- * (query upload, preparation, the sample pass) still overlaps.  YAMS_SHARDED_FENCE_OFF lifts the fence
+ * (query upload, preparation, the sample pass) still overlaps — the sample pass in its half-tile form while a
+ * fence (or a sweep hold) is installed: its resident-query form would be a second grid that owns every CU, and
+ * the exchange of batch i may still be on the device when it starts.  YAMS_SHARDED_FENCE_OFF lifts the fence
  * (measurements only). */
 #define YAMS_SHARDED_FENCE_AUTO 0u
 #define YAMS_SHARDED_FENCE_OFF 1u
