@@ -299,7 +299,7 @@ def cpu_baseline_scan(tc, tq, rows_total, k, seed_rows=1_250_000):
         with ThreadPoolExecutor(max_workers=threads) as ex:
             tables = list(ex.map(make_table, range(threads)))
         if tables and all(t is not None for t in tables):
-            per_t = 8
+            per_t = 16                                                 # ~20 CPU-seconds on a 16-thread box
             tables[0].search(queries[0], k, -1.0)                      # (page in)
             t0 = time.perf_counter()
             r1 = [tables[0].search(queries[i % len(queries)], k, -1.0) for i in range(4)]
