@@ -56,7 +56,7 @@ public:
     // returned record says so and every L2 search fails with ErrorCode::NotSupported — the host keeps its CPU vec0.
     Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
         std::unique_lock lk(mu_);
-        return table_.calibrateL2(fn);
+        return table_.calibrateL2(fn, dim_);   // (reported for the schema's dimension; every dimension present is calibrated on its own)
     }
 
     // ---- lifecycle / schema --------------------------------------------------------------------------

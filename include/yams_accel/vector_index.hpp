@@ -472,12 +472,12 @@ private:
     }
 
 public:
-    // Ask the HOST's own vec0 distance which arithmetic it uses (l2_calibration.hpp): on a match every later L2 search of
-    // this index carries that YAMS_SCAN_FLAG_L2_ACC_*; on no match L2 searches fail with NotSupported.  Returns the
-    // calibration record either way (Error only when no function was given).
+    // Ask the HOST's own vec0 distance which arithmetic it uses on vectors of THIS index's dimension (l2_calibration.hpp): on
+    // a match every later L2 search of this index carries that YAMS_SCAN_FLAG_L2_ACC_*; on no match L2 searches fail with
+    // NotSupported.  Returns the calibration record either way (Error only when no function was given).
     Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
         if (!fn) return Error{ErrorCode::InvalidArgument, "calibrateL2 needs the host's L2 distance function"};
-        const auto c = accel_l2::calibrateL2(fn);
+        const auto c = accel_l2::calibrateL2(fn, dim_);
         setL2(L2Setting{true, c.matched, c.flags, c.detail});
         return c;
     }
@@ -631,26 +631,31 @@ private:
         auto made = createAccelVectorIndex(plugin_, dim, engine_);
         if (!made) return made.error();
         if (auto s = made.value()->initialize(); !s) return s.error();
-        made.value()->setL2(l2_);
+        if (l2Fn_) (void)made.value()->calibrateL2(l2Fn_); // every dimension is calibrated on its own probes
         auto* raw = made.value().get();
         byDim_[dim] = std::move(made.value());
         return raw;
     }
 public:
-    // One calibration for the table: every index (dimension), present and future, searches L2 in the host's arithmetic
-    Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn) {
+    // One function for the table: every index (dimension), present and future, is calibrated with it on probes of its
+    // own dimension and searches L2 in the arithmetic the host's function shows there (or refuses).  Returns the
+    // calibration at `dim` (the table's main dimension; 0: the largest one present, else 768) for the log.
+    Result<accel_l2::L2Calibration> calibrateL2(const accel_l2::L2DistanceFn& fn, size_t dim = 0) {
         if (!fn) return Error{ErrorCode::InvalidArgument, "calibrateL2 needs the host's L2 distance function"};
-        const auto c = accel_l2::calibrateL2(fn);
-        l2_ = L2Setting{true, c.matched, c.flags, c.detail};
-        for (auto& kv : byDim_) kv.second->setL2(l2_);
-        return c;
+        l2Fn_ = fn;
+        for (auto& kv : byDim_) (void)kv.second->calibrateL2(fn);
+        if (dim == 0) dim = byDim_.empty() ? 768 : byDim_.rbegin()->first;
+        auto it = byDim_.find(dim);
+        l2_ = it != byDim_.end() ? it->second->l2() : [&] { const auto c = accel_l2::calibrateL2(fn, dim); return L2Setting{true, c.matched, c.flags, c.detail}; }();
+        return accel_l2::calibrateL2(fn, dim);
     }
-    const L2Setting& l2() const { return l2_; }
+    const L2Setting& l2() const { return l2_; }   // (of the dimension the last calibrateL2 call reported)
 
 private:
     std::shared_ptr<accel::Plugin> plugin_;
     VectorSearchEngine engine_;
     L2Setting l2_;
+    accel_l2::L2DistanceFn l2Fn_;
     std::map<size_t, std::unique_ptr<AccelVectorIndex>> byDim_;
     std::unordered_map<std::string, size_t> dimOf_;
 };

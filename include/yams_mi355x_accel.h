@@ -215,7 +215,10 @@ typedef struct yams_scan_corpus_s {
  *   F64    (default) sum (x_i - q_i)^2 in fp64, sequentially, sqrt, round to fp32 — this repository's own definition;
  *   F32    fp32 difference, fp32 product, fp32 sequential sum, sqrtf — the public sqlite-vec's scalar loop;
  *   F32X8  / F32X16  the same with 8 / 16 round-robin partial sums (element i goes to lane i % 8 / 16) added left to
- *          right at the end — its AVX / AVX-512 forms.
+ *          right at the end — its AVX / AVX-512 forms;
+ *   ... | FUSED  the three fp32 forms with the square accumulated by one fused multiply-add — those loops as a compiler
+ *          emits them under -mfma, the flag the reference's build gives that dependency on x86.
+ * include/yams_accel/l2_calibration.hpp finds out which one a host's build uses by asking its own distance function.
  * Each is tested bit for bit against a CPU restatement of that arithmetic (tests/): the order (distance
  * asc, chunk_id asc), the cosine re-score and the threshold-after-top-k of sqlite_vec_backend.cpp:4464-4512 are
  * unchanged.  The filter tiers are the same; the completeness proof widens its margin by the fp32 summation bound. */
@@ -224,6 +227,10 @@ typedef struct yams_scan_corpus_s {
 #define YAMS_SCAN_FLAG_L2_ACC_F32X8 512u
 #define YAMS_SCAN_FLAG_L2_ACC_F32X16 768u
 #define YAMS_SCAN_FLAG_L2_ACC_MASK 768u
+#define YAMS_SCAN_FLAG_L2_ACC_FUSED 2048u  /* with F32 / F32X8 / F32X16: every square is accumulated by ONE fused multiply-add,
+                                                p = fma(d, d, p) with d = fl(x - q) — what `sum += d * d` and
+                                                _mm256_add_ps(sum, _mm256_mul_ps(d, d)) compile to under -mfma, which is how the
+                                                reference builds sqlite-vec-cpp on x86 (src/vector/meson.build:80-88).  Ignored with F64. */
 #define YAMS_SCAN_FLAG_L2_ACC_EXPLICIT 1024u /* vtable callers: the L2_ACC bits of THIS call are the caller's decision even when
                                                 they read F64 (= 0) — the plugin's configured default is not applied.  Set by the
                                                 adapters after l2_calibration.hpp has asked the host's own distance function. */

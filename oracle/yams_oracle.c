@@ -414,16 +414,26 @@ ORACLE_API long oracle_exact_scan_l2(const float* corpus, size_t n_rows, size_t 
  * top-k index SET differs only when two rows sit within that of each other at the cut): `lanes` = 1 sequential,
  * else that many round-robin partial sums (element i goes to lane i % lanes) added left to right.
  * ---------------------------------------------------------------------------------------------- */
+/* lanes < 0 (round 5): |lanes| lanes with every square accumulated by ONE fused multiply-add, part = fmaf(d, d, part) — what a
+ * compiler makes of the loops above when the translation unit is built with -mfma, as the reference builds sqlite-vec-cpp on
+ * x86 (src/vector/meson.build:80-88: '-mavx', '-mfma'; GCC contracts `sum += d * d` and _mm256_add_ps(sum, _mm256_mul_ps(d, d))
+ * by default).  fmaf is the correctly rounded fused operation whether or not this host has the instruction. */
 ORACLE_API float oracle_l2_distance_f32acc(const float* a, const float* b, size_t dim, int lanes) {
+    const int fused = lanes < 0;
+    if (fused) lanes = -lanes;
     if (lanes <= 1) {
         float acc = 0.0f;
-        for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; acc += d * d; }
+        for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; acc = fused ? fmaf(d, d, acc) : acc + d * d; }
         return sqrtf(acc);
     }
     float part[64];
     if (lanes > 64) lanes = 64;
     for (int l = 0; l < lanes; ++l) part[l] = 0.0f;
-    for (size_t i = 0; i < dim; ++i) { const float d = a[i] - b[i]; part[i % (size_t)lanes] += d * d; }
+    for (size_t i = 0; i < dim; ++i) {
+        const float d = a[i] - b[i];
+        float* p = &part[i % (size_t)lanes];
+        *p = fused ? fmaf(d, d, *p) : *p + d * d;
+    }
     float acc = 0.0f;
     for (int l = 0; l < lanes; ++l) acc += part[l];
     return sqrtf(acc);

@@ -75,8 +75,10 @@ def build_l2_calibration_test():
     so = os.path.join(ROOT, "oracle", "_build", "libyams_oracle.so")
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in (src, hdr, so)):
         return exe
-    # -O2 -ffp-contract=fast on purpose: the header's definitions must hold whatever the host's flags are
-    r = subprocess.run([os.environ.get("CXX", "g++"), "-std=c++20", "-O2", "-ffp-contract=fast", "-Wall", "-I" + os.path.join(ROOT, "include"),
+    # -O2 -mavx -mfma -ffp-contract=fast on purpose: the reference compiles its sqlite-vec-cpp dependency with '-mavx', '-mfma'
+    # (src/vector/meson.build:80-88) — the header's definitions must hold under those flags, and the test's own AVX-shaped
+    # host function must come out FUSED
+    r = subprocess.run([os.environ.get("CXX", "g++"), "-std=c++20", "-O2", "-mavx", "-mfma", "-ffp-contract=fast", "-Wall", "-I" + os.path.join(ROOT, "include"),
                         "-o", exe, src, so, "-Wl,-rpath," + os.path.dirname(so), "-lm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("l2_calibration_test failed to compile:\n" + r.stdout.decode())

@@ -434,7 +434,7 @@ int main(int argc, char** argv) {
             if (near2) for (const auto& r : near2.value()) keep += r.relevance_score >= 0.1f;
             CHECK(cut.has_value() && cut.value().size() == keep && keep > 0 && keep < 2000);
             // vec0 L2 self-calibration (l2_calibration.hpp): the HOST's distance function decides the arithmetic.  Each of the
-            // four served definitions plays the host in turn: the index must recognise it and from then on return exactly
+            // seven served definitions (fp64; fp32 in 1 / 8 / 16 lanes, plain and with a fused multiply-add) plays the host in turn: the index must recognise it and from then on return exactly
             // the rows a host-side brute force UNDER THAT DEFINITION returns (distance asc, chunk_id asc) — whatever
             // "l2_accumulate" the plugin was configured with.
             namespace l2n = vector::accel_l2;

@@ -34,6 +34,8 @@ for case in range(a.cases):
     thr = float(rng.choice([-1.0, 0.0, 0.1])) if metric == SCAN_COSINE else -1.0
     # L2: the accumulate arithmetic the host names (fp64 / fp32 sequential / 8 / 16 lanes) rides on every form of the case
     acc_flag = int(rng.choice([0, _lib.FLAG_L2_ACC_F32, _lib.FLAG_L2_ACC_F32X8, _lib.FLAG_L2_ACC_F32X16])) if metric == SCAN_L2 else 0
+    if acc_flag and rng.random() < 0.5:
+        acc_flag |= _lib.FLAG_L2_ACC_FUSED       # (the same lanes, squares accumulated with a fused multiply-add)
     tc = torch.empty((n, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 0, n, d, tc.data_ptr())
     tq = torch.empty((nq, d), dtype=torch.float32, device="cuda"); acc.synth_rows(1000 + case, 1 << 40, nq, d, tq.data_ptr())
     if rng.random() < 0.5:      # clustered: a few hundred near-copies of query 0 -> crowded top

@@ -64,11 +64,14 @@ def test_adapters_through_the_reference_base_classes():
 
 
 def test_l2_calibration_recognises_each_definition_and_refuses_the_rest():
-    """include/yams_accel/l2_calibration.hpp: the oracle's four L2 definitions play the host's sqlite3_vec_distance_l2 in
-    turn — each is recognised as itself (also through the C-API shaped adapter); a 4-lane, a pairwise, a fused-multiply-add
-    and a failing host match nothing and are refused.  Host arithmetic only: runs without a GPU."""
+    """include/yams_accel/l2_calibration.hpp: the oracle's seven L2 definitions (fp64; fp32 in 1 / 8 / 16 lanes, plain and
+    with a fused multiply-add) play the host's sqlite3_vec_distance_l2 in turn at dims 768 / 384 / 1024 / 100 — each is
+    recognised as itself (also through the C-API shaped adapter); the AVX loop shape of the public sqlite-vec compiled with
+    the reference's flags for that dependency (-mavx -mfma) comes out as f32x8_fma; a 4-lane, a pairwise and a failing host
+    match nothing and are refused.  Host arithmetic only: runs without a GPU."""
     import _cpp_build
     exe = _cpp_build.build_l2_calibration_test()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "OK (0 failures)" in r.stdout and "host L2 = f32x16" in r.stdout and "matches NO served definition" in r.stdout
+    assert "OK (0 failures)" in r.stdout and "host L2 at dim 768 = f32x16_fma" in r.stdout and "matches NO served definition" in r.stdout
+    assert "AVX loop shape, this TU's flags  -> host L2 at dim 768 = f32x8_fma" in r.stdout

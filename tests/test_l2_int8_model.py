@@ -191,7 +191,7 @@ def test_fp32_accumulation_never_undercuts_the_proofs_lower_bound(oracle):
             d2 = np.sum((rows.astype(np.float64) - q.astype(np.float64)) ** 2, axis=1)   # (fp64 of fp32 inputs: relative error 1e-16 * dim)
             slack = (dim + 8) * u * 1.01
             lower = np.sqrt(np.maximum(d2 * (1.0 - slack) - 1e-30, 0.0)) * (1.0 - 1.2e-7)
-            for lanes in (1, 8, 16):
+            for lanes in (1, 8, 16, -1, -8, -16):       # (negative: the fused multiply-add forms — one rounding fewer per term)
                 got = oracle.l2_f32acc_many(rows, q, lanes).astype(np.float64)
                 ok = (got >= lower) | ~np.isfinite(got)     # (inf: the row is skipped, which is never below the bound)
                 assert ok.all(), (dim, scale, lanes, got[~ok][:3], lower[~ok][:3])

@@ -879,7 +879,9 @@ def test_sharded_pipeline_on_one_device_equals_the_single_call(oracle):
     sh.close()
 
 
-@pytest.mark.parametrize("lanes,flag", [(1, _lib.FLAG_L2_ACC_F32), (8, _lib.FLAG_L2_ACC_F32X8), (16, _lib.FLAG_L2_ACC_F32X16)])
+@pytest.mark.parametrize("lanes,flag", [(1, _lib.FLAG_L2_ACC_F32), (8, _lib.FLAG_L2_ACC_F32X8), (16, _lib.FLAG_L2_ACC_F32X16),
+                                        (-1, _lib.FLAG_L2_ACC_F32 | _lib.FLAG_L2_ACC_FUSED), (-8, _lib.FLAG_L2_ACC_F32X8 | _lib.FLAG_L2_ACC_FUSED),
+                                        (-16, _lib.FLAG_L2_ACC_F32X16 | _lib.FLAG_L2_ACC_FUSED)])
 def test_l2_under_fp32_accumulation_matches_that_oracle(acc, oracle, lanes, flag):
     """vec0's distance arithmetic lives in the absent sqlite-vec-cpp, so the host picks it
     (YAMS_SCAN_FLAG_L2_ACC_*).  Under fp32 accumulation — sequential, 8 or 16 round-robin lanes — rows, order, distances
@@ -887,8 +889,10 @@ def test_l2_under_fp32_accumulation_matches_that_oracle(acc, oracle, lanes, flag
     forms), bf16, the exhaustive fp64-free pipeline, small corpora (the fused kernel is fp64-only and steps aside),
     dimensions with tails (100: float4 walk + tail, 37: unaligned scalar walk), hostile rows (fp32 overflow -> inf ->
     skipped, zero rows, NaN), exact ties broken by chunk_id, the threshold applied after the top-k.  Reference:
-    sqlite_vec_backend.cpp:4464-4512."""
-    rng = np.random.default_rng(200 + lanes)
+    sqlite_vec_backend.cpp:4464-4512.  Negative lanes (round 5): the same lanes with every square accumulated by ONE fused
+    multiply-add (YAMS_SCAN_FLAG_L2_ACC_FUSED) — what the reference's x86 build of its dependency ('-mavx', '-mfma',
+    src/vector/meson.build:80-88) makes of those loops."""
+    rng = np.random.default_rng(200 + abs(lanes) + (50 if lanes < 0 else 0))
     cases = [dict(n=60_000, d=256, nq=140, k=20),                                   # int8 tier
              dict(n=60_000, d=256, nq=140, k=20, flags=_lib.FLAG_RESIDENT_QUERIES),  # ... resident-query form
              dict(n=30_011, d=256, nq=7, k=25, thr=0.05),                            # narrow bf16 form, threshold after top-k
@@ -927,6 +931,19 @@ def test_l2_under_fp32_accumulation_matches_that_oracle(acc, oracle, lanes, flag
 def test_plugin_serves_the_l2_arithmetic_its_config_names(accel_lib, oracle):
     """{"l2_accumulate": "f32x8"}: every vec0 search of the plugin uses that arithmetic (a call may still name its own)."""
     L = accel_lib
+    vt = _vt(L, b'{"device": 0, "l2_accumulate": "f32x8_fma"}')
+    n, d, k = 20_000, 256, 10
+    corpus = oracle.synth_rows(80, 0, n, d) * np.float32(1.3)
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, d, C.byref(cid)) == 0
+    assert vt.corpus_append(None, cid, corpus.ctypes.data_as(_lib.f32p), n) == 0
+    q = oracle.synth_rows(80, 1 << 40, 3, d)
+    rows, _, _ = _vt_search(vt, cid, np.ascontiguousarray(q), k, metric=1)
+    for qi in range(3):
+        assert rows[qi] == list(oracle.scan_l2_f32acc(corpus, q[qi], k, -1.0, lanes=-8)[0]), qi
+    hp = C.c_void_p()
+    assert L.yams_plugin_get_health_json(C.byref(hp)) == 0 and json.loads(C.string_at(hp))["l2_accumulate"] == "f32x8_fma"
+    C.CDLL(None).free(hp)
     vt = _vt(L, b'{"device": 0, "l2_accumulate": "f32x8"}')
     n, d, k = 50_000, 256, 10
     corpus = oracle.synth_rows(79, 0, n, d) * np.float32(1.7)

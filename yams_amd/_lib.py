@@ -25,6 +25,7 @@ FLAG_NO_I8_FILTER = 64
 FLAG_RESIDENT_QUERIES = 128
 FLAG_L2_ACC_F64, FLAG_L2_ACC_F32, FLAG_L2_ACC_F32X8, FLAG_L2_ACC_F32X16 = 0, 256, 512, 768
 FLAG_L2_ACC_EXPLICIT = 1024
+FLAG_L2_ACC_FUSED = 2048
 
 
 def i8_shadow_rows(n_rows: int) -> int:

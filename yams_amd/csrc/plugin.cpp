@@ -615,7 +615,7 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
     }
     // only semantic flags cross the vtable; filter selection stays with the library
     yams_scan_params_t prm{k, threshold, metric, flags & (YAMS_SCAN_FLAG_RECORD_PATH | YAMS_SCAN_FLAG_FORCE_EXACT | YAMS_SCAN_FLAG_DEFER_THRESHOLD |
-                                                          YAMS_SCAN_FLAG_L2_ACC_MASK)};
+                                                          YAMS_SCAN_FLAG_L2_ACC_MASK | YAMS_SCAN_FLAG_L2_ACC_FUSED)};
     // vec0's distance arithmetic: the call's own choice (any L2_ACC bit, or L2_ACC_EXPLICIT for a deliberate F64), else
     // the plugin's ("l2_accumulate" in the init config)
     if (metric == YAMS_SCAN_L2 && !(flags & (YAMS_SCAN_FLAG_L2_ACC_MASK | YAMS_SCAN_FLAG_L2_ACC_EXPLICIT))) prm.flags |= g.l2_acc;
@@ -1097,7 +1097,11 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
         // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header)
         const char* c = std::strchr(p + 15, ':');
         const char* v = c ? std::strchr(c, '"') : nullptr;
-        if (v && std::strncmp(v, "\"f32x16\"", 8) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16;
+        // ("f32_fma" | "f32x8_fma" | "f32x16_fma": the same lanes accumulated with a fused multiply-add)
+        if (v && std::strncmp(v, "\"f32x16_fma\"", 12) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
+        else if (v && std::strncmp(v, "\"f32x8_fma\"", 11) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X8 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
+        else if (v && std::strncmp(v, "\"f32_fma\"", 9) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
+        else if (v && std::strncmp(v, "\"f32x16\"", 8) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16;
         else if (v && std::strncmp(v, "\"f32x8\"", 7) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X8;
         else if (v && std::strncmp(v, "\"f32\"", 5) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32;
     }
@@ -1204,7 +1208,8 @@ static int plugin_health_impl(char** out_json) {
     os << "{\"status\":\"" << (g.initialised ? "ok" : "not_initialised") << "\",\"devices\":[";
     for (size_t i = 0; i < g.devices.size(); ++i) os << (i ? "," : "") << g.devices[i];
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
-       << ",\"l2_accumulate\":\"" << (g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : g.l2_acc == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64") << "\""
+       << ",\"l2_accumulate\":\"" << ((g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : (g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : (g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64")
+       << ((g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_FUSED) ? "_fma" : "") << "\""
        << ",\"last_append\":{\"bytes\":" << g.append_bytes.load() << ",\"map_ms\":" << g.append_map_ms.load() << ",\"copy_ms\":" << g.append_copy_ms.load()
        << ",\"shadow_ms\":" << g.append_shadow_ms.load() << "}"
        << ",\"appends\":" << g.appends.load() << ",\"exhausted_appends\":" << g.exhausted_appends.load()

@@ -553,7 +553,13 @@ __global__ __launch_bounds__(256) void collect_sample_kernel(const float* dense,
 // left to right at the end (its AVX / AVX-512 forms) — the CPU checker's restatement of each, bit for bit: separate rounded
 // subtract, multiply and add (no contraction), the root rounded once (sqrt in fp64 of an fp32 value, rounded to fp32,
 // IS the correctly rounded fp32 root: 53 >= 2 * 24 + 2).  `i` must be a compile-time constant after unrolling.
-template <int ACC> struct L2Sum {
+// FUSED (round 5): the same lanes with the square accumulated by ONE fused multiply-add, p = fma(d, d, p) — what a
+// compiler makes of `sum += d * d` (and of _mm256_add_ps(sum, _mm256_mul_ps(d, d))) when the translation unit is built
+// with -mfma, which is how the reference builds sqlite-vec-cpp on x86 (src/vector/meson.build:80-88: '-mavx', '-mfma').
+// The kernels take the pair as one template number: ACCF = lanes | (fused ? 64 : 0); 0 = fp64.
+constexpr int l2_lanes(int accf) { return accf & 63; }
+constexpr bool l2_fused(int accf) { return (accf & 64) != 0; }
+template <int ACC, bool FUSED = false> struct L2Sum {
     float p[ACC];
     __device__ __forceinline__ void clear() {
 #pragma unroll
@@ -561,7 +567,7 @@ template <int ACC> struct L2Sum {
     }
     __device__ __forceinline__ void add(float x, float q, int i) {
         const float d = __fsub_rn(x, q);
-        p[i & (ACC - 1)] = __fadd_rn(p[i & (ACC - 1)], __fmul_rn(d, d));
+        p[i & (ACC - 1)] = FUSED ? __fmaf_rn(d, d, p[i & (ACC - 1)]) : __fadd_rn(p[i & (ACC - 1)], __fmul_rn(d, d));
     }
     __device__ __forceinline__ double root() const {
         float s = p[0];
@@ -573,15 +579,15 @@ template <int ACC> struct L2Sum {
         return static_cast<double>(static_cast<float>(sqrt(static_cast<double>(s))));
     }
 };
-template <> struct L2Sum<0> {
+template <> struct L2Sum<0, false> {
     double s;
     __device__ __forceinline__ void clear() { s = 0.0; }
     __device__ __forceinline__ void add(float x, float q, int) { const double d = static_cast<double>(x) - static_cast<double>(q); s = fma(d, d, s); }
     __device__ __forceinline__ double root() const { return sqrt(s); }
 };
 // elements [i0, dim) of a row, i0 a multiple of 16: groups of 16 with static lane indices (tails and unaligned rows)
-template <int ACC>
-__device__ __forceinline__ void l2_sum_tail(L2Sum<ACC>& l2, const float* x, const float* q, uint32_t i0, uint32_t dim) {
+template <int ACC, bool FUSED>
+__device__ __forceinline__ void l2_sum_tail(L2Sum<ACC, FUSED>& l2, const float* x, const float* q, uint32_t i0, uint32_t dim) {
     for (uint32_t i = i0; i < dim; i += 16) {
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
         const float* x = a.rows + static_cast<uint64_t>(row) * dim;
         if (live) ++local_rescored;
         double nsq = 0.0, dot = 0.0;
-        L2Sum<ACC> l2; l2.clear();
+        L2Sum<l2_lanes(ACC), l2_fused(ACC)> l2; l2.clear();
         const bool vec4 = (dim & 3u) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
         if (staged) {
             const int lane = threadIdx.x & 63;
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(const float* rows, uint
     }
     const float* x = rows + row * dim;
     double nsq = 0.0, dot = 0.0;
-    L2Sum<ACC> l2; l2.clear();
+    L2Sum<l2_lanes(ACC), l2_fused(ACC)> l2; l2.clear();
     for (uint32_t i = 0; i < dim; ++i) {
         const double sv = static_cast<double>(x[i]);
         const double qv = static_cast<double>(sq[i]);
@@ -1325,9 +1331,15 @@ hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint
     const uint32_t gx = static_cast<uint32_t>((n_items + 255) / 256);
     const size_t sh = static_cast<size_t>(dim) * sizeof(float);
     const uint32_t acc = flags & YAMS_SCAN_FLAG_L2_ACC_MASK; // the host's choice of vec0's distance arithmetic (L2 only)
+    const bool fused = acc != 0 && (flags & YAMS_SCAN_FLAG_L2_ACC_FUSED) != 0; // ... accumulated with one fused multiply-add
+#define YAMS_EXACT_KEYS(ACCF) hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2, ACCF>), dim3(gx, n_slots), dim3(256), sh, st, \
+    rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride)
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_COSINE>), dim3(gx, n_slots), dim3(256), sh,
                            st, rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32) YAMS_EXACT_KEYS(64 | 1);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32X8) YAMS_EXACT_KEYS(64 | 8);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32X16) YAMS_EXACT_KEYS(64 | 16);
     else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32)
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2, 1>), dim3(gx, n_slots), dim3(256), sh, st,
                            rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
@@ -1340,6 +1352,7 @@ hipError_t launch_exact_keys(hipStream_t st, int metric, const float* rows, uint
     else
         hipLaunchKernelGGL((exact_keys_kernel<YAMS_SCAN_L2>), dim3(gx, n_slots), dim3(256), sh, st,
                            rows, n_rows, dim, queries, qnorm, tie_rank, row_mask, rows_sel, n_sel, qmap, threshold, flags, keys, key_stride);
+#undef YAMS_EXACT_KEYS
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1385,9 +1398,16 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     // fp32 summation of dim nonnegative squares, each from a rounded difference and a rounded product: relative error
     // below (dim + 2) u of the sum for ANY order of the additions (sequential is the worst case); 8 spare u, 1 % slack
     a.l2_acc_slack = (static_cast<double>(R.dim) + 8.0) * 5.9604644775390625e-8 * 1.01;
+    const bool fused = acc != 0 && (R.flags & YAMS_SCAN_FLAG_L2_ACC_FUSED) != 0;
     if (metric == YAMS_SCAN_COSINE)
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_COSINE>), dim3(R.n_slots), dim3(threads),
                            sh, st, a);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 64 | 1>), dim3(R.n_slots), dim3(threads), sh, st, a);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32X8)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 64 | 8>), dim3(R.n_slots), dim3(threads), sh, st, a);
+    else if (fused && acc == YAMS_SCAN_FLAG_L2_ACC_F32X16)
+        hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 64 | 16>), dim3(R.n_slots), dim3(threads), sh, st, a);
     else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32)
         hipLaunchKernelGGL((rescore_select_kernel<YAMS_SCAN_L2, 1>), dim3(R.n_slots), dim3(threads), sh, st, a);
     else if (acc == YAMS_SCAN_FLAG_L2_ACC_F32X8)
