@@ -310,6 +310,12 @@ class ScanRef:
         build()
         if not os.path.exists(_SCAN_REF_SO):
             raise FileNotFoundError(_SCAN_REF_SO)
+        try:    # built with the reference's '-mavx', '-mfma' (oracle/Makefile): only for hosts that have them
+            flags = open("/proc/cpuinfo").read()
+            if " avx" not in flags or " fma" not in flags:
+                raise FileNotFoundError("this host lacks AVX / FMA: " + _SCAN_REF_SO + " cannot run here")
+        except OSError:
+            pass
         L = C.CDLL(_SCAN_REF_SO)
         self.L = L
         L.scanref_open.restype = C.c_void_p
