@@ -581,6 +581,49 @@ int main(int argc, char** argv) {
         }
         backend->close();
     }
+    std::printf("[section] vec0 L2 through the host's own classes, calibrated\n");
+    // ---- the Vec0L2 engine behind IVectorStore: the HOST's distance function settles the arithmetic (l2_calibration.hpp) --
+    {
+        namespace l2n = vector::accel_l2;
+        vector::AccelExactScanBackend backend(plugin, nullptr, vector::VectorSearchEngine::Vec0L2);
+        CHECK(backend.initialize(":memory:").has_value() && backend.createTables(256).has_value());
+        const size_t dim = 256, n = 3000;
+        std::mt19937 rng(7);
+        std::vector<vector::VectorRecord> recs;
+        for (size_t i = 0; i < n; ++i) {
+            char id[32];
+            std::snprintf(id, sizeof id, "l2_%06zu", i);
+            auto e = unit(rng, dim);
+            for (auto& v : e) v *= 1.7f;
+            recs.emplace_back(id, "doc", std::move(e), "content");
+        }
+        CHECK(backend.insertVectorsBatch(recs).has_value());
+        const auto q = unit(rng, dim);
+        // a host built like the reference builds its dependency on x86 (-mavx -mfma: eight lanes, fused): recognised, and
+        // from then on the backend's answer is that host's own brute force, row for row
+        const auto def = l2n::L2Accumulate::F32x8Fma;
+        auto host = [def](const float* a, const float* b, size_t d, float* out) { *out = l2n::distance(def, a, b, d); return true; };
+        auto cal = backend.calibrateL2(host);
+        CHECK(cal.has_value() && cal.value().matched && cal.value().accumulate == def && cal.value().dim == dim);
+        auto got = backend.searchSimilar(q, 40, -1.0f);
+        CHECK(got.has_value() && got.value().size() == 40);
+        std::vector<std::pair<float, std::string>> brute;
+        for (const auto& r : recs) brute.emplace_back(l2n::distance(def, r.embedding.data(), q.data(), dim), r.chunk_id);
+        std::sort(brute.begin(), brute.end());
+        if (got) for (size_t i = 0; i < 40; ++i) CHECK(got.value()[i].chunk_id == brute[i].second);
+        // a host that matches nothing is refused with the reference's own error vocabulary
+        auto odd = [](const float* a, const float* b, size_t d, float* out) {
+            float p[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < d; ++i) { const float x = a[i] - b[i]; p[i % 4] += x * x; }
+            *out = std::sqrt((p[0] + p[1]) + (p[2] + p[3]));
+            return true;
+        };
+        auto none = backend.calibrateL2(odd);
+        CHECK(none.has_value() && !none.value().matched);
+        auto refused = backend.searchSimilar(q, 5, -1.0f);
+        CHECK(!refused.has_value() && refused.error().code == ErrorCode::NotSupported);
+        backend.close();
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
     return failures ? 1 : 0;
 }
