@@ -65,7 +65,7 @@ enum yams_status_e {
 };
 #endif
 
-#define YAMS_ACCEL_VERSION_STRING "0.1.0"
+#define YAMS_ACCEL_VERSION_STRING "0.5.0" /* round 5: status codes TIMEOUT / RESOURCE_EXHAUSTED, L2_ACC_FUSED / _EXPLICIT, exchange deadline */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Context                                                                                      */
