@@ -99,6 +99,12 @@ def compact_line(out):
     l2 = out.get("config3_l2")
     if l2:
         c["config3_l2"] = _pick(l2, ("ms_per_step", "qps", "launch_ms", "frac", "results_identical_to_the_bf16_tier", "parity"))
+    c2 = out.get("config2")
+    if c2:
+        c["config2"] = _pick(c2, ("ms_per_step", "qps", "search_lanes", "launch_ms", "bound", "achieved", "peak", "unit", "frac",
+                                  "filter_candidates", "exact_fallback_queries", "results_identical_to_the_oracle_run", "oracle_queries", "error"))
+        if "error" in c["config2"]:
+            c["config2"]["error"] = _short(c["config2"]["error"], 200)
     ca = out.get("c_abi_sharded")
     if ca:
         c["c_abi_sharded"] = _pick(ca, ("n_devices", "collective", "communicator_ranks", "collectives", "batches", "ms_per_step", "value",
@@ -198,6 +204,12 @@ def parse():
                          "digest; one in eight also through oracle/_ref — ~40 s on 16 host threads at 100 GiB")
     ap.add_argument("--verify-sample-ingest", dest="verify_all_ingest", action="store_false",
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
+    ap.add_argument("--no-config2-leg", action="store_true", help="skip the BASELINE config 2 (1M x 384, Q = 256) leg")
+    ap.add_argument("--only-config2", action="store_true", help="run the BASELINE config 2 leg alone (profiling)")
+    ap.add_argument("--config2-lanes", type=int, default=4, help="search lanes of the config 2 leg")
+    ap.add_argument("--config2-lane-sweep", default=None, help="comma-separated lane counts to time in the config 2 leg (the best is reported)")
+    ap.add_argument("--config2-no-gate", action="store_true", help="config 2 leg: no sweep gate between the lanes (measurement)")
+    ap.add_argument("--config2-batches", type=int, default=None)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--f32-filter", action="store_true", help="use the exact-f32 MFMA filter kernel")
     ap.add_argument("--no-shadow", action="store_true", help="bare fp32 corpus view: the single-pass filter converts rows in its loop")
@@ -1009,6 +1021,142 @@ def boundary_leg(a, acc, torch, dev, tc_full, rows_c4):
     return out
 
 
+def config2_leg(a, torch, dev, local, lane_counts=None, batches=None, oracle_queries=None):
+    """BASELINE config 2 (BASELINE.json configs[1]; the reference's searchSimilarBatch, sqlite_vec_backend.cpp:1612-1647):
+    1M x 384 fp32 cosine top-100, query batch 256, one MI355X.  The corpus, both shadows and four distinct query batches are
+    resident before the timed region; a step = one 256-query batch through the whole path (prep, sample, tau, sweep, gather,
+    top-k, fp64 re-score + proof, status words); `lanes` batches are in flight, each on its own context / stream / host
+    thread, as in the headline loop.  The last timed batch is checked against the oracle over all 1M rows, every query."""
+    import threading
+    import numpy as np
+    from yams_amd.accel import Accel, SweepGate
+    from yams_amd._lib import SCAN_COSINE
+    n, d, nq, k = 1_000_000, 384, 256, 100
+    seed = a.seed + 2
+    acc0 = Accel(local, torch.cuda.current_stream().cuda_stream)
+    tc = torch.empty((n, d), dtype=torch.float32, device=dev)
+    acc0.synth_rows(seed, 0, n, d, tc.data_ptr())
+    n_qb = 4
+    tqs = []
+    for b in range(n_qb):
+        t_ = torch.empty((nq, d), dtype=torch.float32, device=dev)
+        acc0.synth_rows(seed, (1 << 40) + b * nq, nq, d, t_.data_ptr())
+        tqs.append(t_)
+    tb = torch.empty((n, d), dtype=torch.bfloat16, device=dev); tn = torch.empty(n, dtype=torch.float32, device=dev)
+    acc0.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
+    t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device=dev)
+    tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
+    acc0.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr())
+    view = acc0.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                            rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
+    acc0.synchronize()
+    lane_counts = list(lane_counts or [a.config2_lanes])
+    batches = batches or max(200, 10 * a.steps)
+    max_l = max(lane_counts)
+    streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(max_l - 1)]
+    accs = [acc0] + [Accel(local, st.cuda_stream) for st in streams[1:]]
+    outs = [(torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev),
+             torch.empty(nq, dtype=torch.int32, device=dev)) for _ in range(max_l)]
+    gate = SweepGate(local) if max_l > 1 else None
+
+    def run(lanes, count, first=0):
+        errs = []
+
+        def lane_fn(lane):
+            try:
+                torch.cuda.set_device(dev)
+                o = outs[lane]
+                for i in range(first + lane, first + count, lanes):
+                    accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(),
+                                                o[2].data_ptr(), flags=0, want_diag=False)
+            except BaseException as e:       # noqa: BLE001 - re-raised on the main thread
+                errs.append(e)
+        if lanes == 1:
+            lane_fn(0)
+        else:
+            th = [threading.Thread(target=lane_fn, args=(l,)) for l in range(lanes)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+
+    sweep = {}
+    best = None
+    for lanes in lane_counts:
+        for c in accs:
+            c.set_gate(gate if (lanes > 1 and not a.config2_no_gate) else None)
+        run(lanes, max(4 * lanes, 2 * a.warmup))
+        for c in accs[:lanes]:
+            c.enable_timing(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(lanes, batches)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / batches
+        tot, cnt = 0.0, 0
+        for c in accs[:lanes]:
+            ms, n_ = c.kernel_ms("scan_filter")
+            if ms is not None and n_:
+                tot += ms * n_; cnt += n_
+            c.enable_timing(False)
+        sweep[str(lanes)] = {"ms_per_step": dt * 1e3, "qps": nq / dt, "launch_ms": tot / cnt if cnt else None, "launches": cnt}
+        if best is None or dt < best[1]:
+            best = (lanes, dt, tot / cnt if cnt else None)
+    lanes, dt, launch_ms = best
+    # the batch the check looks at: one more call on lane 0 (its buffers), diagnostics on
+    last_b = (batches - 1) % n_qb
+    o = outs[0]
+    diag = accs[0].scan_topk_device(view, tqs[last_b].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                    flags=0, want_diag=True)
+    torch.cuda.synchronize()
+    tr = 256
+    n_tiles = (n + tr - 1) // tr
+    stride = max(1, n_tiles // ((min(n, max(n // 64, 8192)) + tr - 1) // tr))
+    filt_rows = min(n, (n_tiles - (n_tiles + stride - 1) // stride) * tr)
+    byts = filt_rows * d + (filt_rows // 64) * 8 + nq * d      # the int8 shadow + its block meta + the int8 queries, read once
+    ops = 2.0 * nq * d * filt_rows
+    i8 = diag.get("filter_tier") == 1
+    leg = {"workload": "BASELINE config 2: 1M x 384 fp32 cosine top-100, query batch 256, corpus + shadows resident",
+           "ms_per_step": dt * 1e3, "qps": nq / dt, "search_lanes": lanes, "batches_timed": batches, "launch_ms": launch_ms,
+           # 2 Q = 512 int8 multiply-adds per shadow byte against a machine balance of 5 POP/s / 8 TB/s = 625: the sweep of this
+           # shape is bound by the ONE read of the int8 shadow from HBM (the MFMA view is beside it)
+           "bound": "hbm", "achieved": byts / (launch_ms * 1e-3) / 1e9 if launch_ms else None, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+           "frac": byts / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if launch_ms else None,
+           "algorithmic_bytes_per_launch": byts, "mfma_view_TOPs": ops / (launch_ms * 1e-3) / 1e12 if launch_ms else None,
+           "step_frac_of_hbm_floor": (byts / PEAK_HBM_GBPS / 1e9) / dt,
+           "kernel": "scan_tiles_i8r_kernel (two 128-query tiles per row stream, 128 streams)" if i8 else "bf16 tier",
+           "filter_tier": diag.get("filter_tier"), "filter_candidates": diag.get("filter_candidates"),
+           "rescored_rows": diag.get("rescored_rows"), "widened_queries": diag.get("widened_queries"),
+           "exact_fallback_queries": diag.get("exact_fallback_queries"), "lane_sweep": sweep}
+    n_oq = nq if oracle_queries is None else min(nq, oracle_queries)
+    if n_oq > 0:
+        _o = oracle_mod()
+        qsel = [int(x) for x in np.linspace(0, nq - 1, n_oq).round()]
+        qh = tqs[last_b][qsel].cpu().numpy()
+        t_or = time.perf_counter()
+        part = _o.scan_threaded(lambda lo, hi: tc[lo:hi].cpu().numpy(), n, qh, k, slice_rows=32768, threads=min(_o.host_threads(), 96))
+        t_or = time.perf_counter() - t_or
+        rr = o[1].cpu().numpy(); ss = o[0].cpu().numpy(); cc = o[2].cpu().numpy()
+        exact = True
+        for j, qi in enumerate(qsel):
+            rows, sims = part[j][0], part[j][1]
+            exact &= bool(cc[qi] == len(rows) and np.array_equal(rr[qi, :len(rows)], rows)
+                          and np.array_equal(ss[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+        leg["results_identical_to_the_oracle_run"] = exact
+        leg["oracle_queries"] = n_oq
+        leg["oracle_seconds"] = t_or
+    for c in accs:
+        c.set_gate(None)
+    for c in accs[1:]:
+        c.close()
+    if gate is not None:
+        gate.close()
+    del tc, tb, tn, t8, tm8, view, outs
+    acc0.close()
+    torch.cuda.empty_cache()
+    return leg
+
+
 def c_abi_main(a):
     """`bench.py --gpus N --via-c-abi`: the whole job from ONE process through the C ABI; prints the contract's line."""
     devices = [0] * a.gpus if a.single_device else list(range(a.gpus))
@@ -1104,6 +1252,12 @@ def main():
                          "one rank per GPU (use --single-device --dist-backend gloo for a dry run)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.only_config2:
+        sweep = [int(x) for x in a.config2_lane_sweep.split(",")] if a.config2_lane_sweep else None
+        leg = config2_leg(a, torch, dev, local, lane_counts=sweep, batches=a.config2_batches, oracle_queries=a.oracle_queries)
+        sys.stderr.write("config2: " + json.dumps(_clean(leg)) + "\n")
+        _print_on_real_stdout(json.dumps(_clean(leg), allow_nan=False))
+        return
     acc = Accel(local, torch.cuda.current_stream().cuda_stream)
     n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
     total_rows = n * world
@@ -1754,6 +1908,12 @@ def main():
             out["boundary"] = {"error": repr(e)}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_scan(tc, tq, n, k)
+    if not a.no_config2_leg and world == 1:
+        try:
+            sweep = [int(x) for x in a.config2_lane_sweep.split(",")] if a.config2_lane_sweep else None
+            out["config2"] = config2_leg(a, torch, dev, local, lane_counts=sweep, batches=a.config2_batches)
+        except Exception as e:          # noqa: BLE001 - the headline number above stands on its own
+            out["config2"] = {"error": repr(e)}
     if not a.no_ingest and world == 1:
         del tc, tb, tn, t8, tm8, view, pipe, res
         acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg

@@ -12,6 +12,7 @@
 // SqliteVecBackend unconditionally); see INTEGRATION.md.
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -384,6 +385,17 @@ private:
                 return Error{ErrorCode::InvalidArgument, "Query embedding dimension mismatch (expected=" +
                                                              std::to_string(dim_) + ", got=" + std::to_string(q.size()) + ")"};
         if (auto s = syncMirror(); !s) return s.error();
+        if (engine_ == VectorSearchEngine::Vec0L2 && !l2_.calibrated) {
+            // Served in the plugin's CONFIGURED arithmetic ("l2_accumulate", fp64 unless set) — which the host's vec0 build may
+            // not use (a reference built with '-mavx', '-mfma' calibrates as f32x8_fma): top-k sets can then differ from the
+            // host's own at the cut on a fraction of a percent of queries.  Said once per index, counted always.
+            ++l2UncalibratedSearches_;
+            if (!l2Warned_) {
+                l2Warned_ = true;
+                std::fprintf(stderr, "[yams_mi355x_accel] vec0 L2 index (dim %zu) is searched WITHOUT calibration: the plugin's configured "
+                                     "\"l2_accumulate\" is used as is; call calibrateL2(host distance function) or setL2() to pin the arithmetic\n", dim_);
+            }
+        }
         if (engine_ == VectorSearchEngine::Vec0L2 && l2_.calibrated) {
             // a top-k set computed in arithmetic the host's vec0 does not use would differ from the host's own on a fraction
             // of queries: refuse rather than serve it
@@ -483,6 +495,8 @@ public:
     }
     void setL2(const L2Setting& s) { l2_ = s; }
     const L2Setting& l2() const { return l2_; }
+    // L2 search calls answered in an arithmetic nobody confirmed (no calibrateL2 / setL2 before them)
+    uint64_t l2UncalibratedSearches() const { return l2UncalibratedSearches_; }
 
 private:
     std::shared_ptr<accel::Plugin> plugin_;
@@ -490,6 +504,8 @@ private:
     size_t dim_;
     VectorSearchEngine engine_;
     L2Setting l2_;
+    uint64_t l2UncalibratedSearches_ = 0;
+    bool l2Warned_ = false;
     uint64_t corpus_ = 0;
     bool initialized_ = false, ranksDirty_ = false;
     std::vector<VectorRecord> records_;

@@ -9,6 +9,10 @@ repository's history) so that oracle/scan_ref_wrap.cpp can compile the reference
                            Impl::recordFromStatement (:3102-3160)              -> scan_ref_members.inc (verbatim)
                            Impl::bruteForceSearchUnlocked (:4114-4409)
   vector_database.cpp      VectorDatabase::computeCosineSimilarity (:1786-1810) -> scan_ref_cosine.inc (verbatim)
+  sqlite_vec_backend.cpp   StmtResetGuard (:319-328), kSelectByRowid (:440-447)  -> scan_ref_vec0_file_scope.inc (verbatim)
+  (round 6: the in-tree      Impl::vec0TableName (:617-619), getVectorByRowidUnlocked (:3084-3099), ensureVec0TableUnlocked
+   half of the L2 path)    (:3236-3249), decodeVectorForDimRowUnlocked (:3251-3266), rebuildVec0DimUnlocked (:3350-3421),
+                           vec0SearchUnlocked (:4450-4530)                      -> scan_ref_vec0_members.inc (verbatim)
 
 Fragments are located by their opening text and closed by brace matching (strings, raw strings and comments skipped), so
 a reference that moves a few lines still extracts; the line spans found are written into the fragments' headers and
@@ -65,7 +69,8 @@ def _line_of(text: str, pos: int) -> int:
     return text.count("\n", 0, pos) + 1
 
 
-def cut(text: str, opening: str, expect: tuple[int, int], what: str, trailing: str = "", to_statement_end: bool = False):
+def cut(text: str, opening: str, expect: tuple[int, int], what: str, trailing: str = "", to_statement_end: bool = False,
+        lines_above: int = 0):
     """(fragment, first line, last line): from the start of the line holding `opening` to the end of its block
     (+ `trailing`, e.g. the `;` of an enum).  to_statement_end: the fragment ends at the first `;` after the opening
     at brace depth 0 (a constant initialised with a raw string)."""
@@ -75,6 +80,8 @@ def cut(text: str, opening: str, expect: tuple[int, int], what: str, trailing: s
     if text.find(opening, at + 1) >= 0:
         raise SystemExit(f"gen_scan_ref: '{what}' is ambiguous in the reference")
     begin = text.rfind("\n", 0, at) + 1
+    for _ in range(lines_above):                 # (a return type that has a line of its own above the name)
+        begin = text.rfind("\n", 0, begin - 1) + 1
     if to_statement_end:
         i = at
         while True:
@@ -144,8 +151,31 @@ def main():
     cos, c0, c1 = cut(vdb, "double VectorDatabase::computeCosineSimilarity(", (1786, 1810), "computeCosineSimilarity")
     with open(os.path.join(a.out, "scan_ref_cosine.inc"), "w") as f:
         f.write(banner(vdb_path, [("computeCosineSimilarity", c0, c1)]) + cos)
+    # ---- round 6: the in-tree half of the L2 (vec0) path --------------------------------------------------------------------
+    guard, g0, g1 = cut(backend, "struct StmtResetGuard {", (319, 328), "StmtResetGuard", trailing=";")
+    sel, q0, q1 = cut(backend, "constexpr const char* kSelectByRowid = R\"sql(", (440, 447), "kSelectByRowid", to_statement_end=True)
+    with open(os.path.join(a.out, "scan_ref_vec0_file_scope.inc"), "w") as f:
+        f.write(banner(backend_path, [("StmtResetGuard", g0, g1), ("kSelectByRowid", q0, q1)]) + guard + "\n" + sel)
+    vparts = [
+        cut(backend, "std::string vec0TableName(size_t dim) const {", (617, 619), "vec0TableName"),
+        cut(backend, "std::optional<VectorRecord> getVectorByRowidUnlocked(int64_t rowid) const {", (3084, 3099), "getVectorByRowidUnlocked"),
+        cut(backend, "Result<void> ensureVec0TableUnlocked(size_t dim) {", (3236, 3249), "ensureVec0TableUnlocked"),
+        cut(backend, "decodeVectorForDimRowUnlocked(sqlite3_stmt* stmt, size_t dim) const {", (3250, 3266), "decodeVectorForDimRowUnlocked",
+            lines_above=1),
+        cut(backend, "Result<void> rebuildVec0DimUnlocked(size_t dim) {", (3350, 3421), "rebuildVec0DimUnlocked"),
+        cut(backend, "    vec0SearchUnlocked(const std::vector<float>& query_embedding, size_t k,", (4450, 4530), "vec0SearchUnlocked",
+            lines_above=1),
+    ]
+    vnames = ["vec0TableName", "getVectorByRowidUnlocked", "ensureVec0TableUnlocked", "decodeVectorForDimRowUnlocked",
+              "rebuildVec0DimUnlocked", "vec0SearchUnlocked"]
+    vspans = [(n_, lo, hi) for n_, (_, lo, hi) in zip(vnames, vparts)]
+    if "Result<std::vector<VectorRecord>>" not in vparts[-1][0].splitlines()[0]:
+        raise SystemExit("gen_scan_ref: unexpected return-type line above vec0SearchUnlocked: " + vparts[-1][0].splitlines()[0].strip())
+    with open(os.path.join(a.out, "scan_ref_vec0_members.inc"), "w") as f:
+        f.write(banner(backend_path, vspans) + "\n".join(t for t, _, _ in vparts))
     with open(os.path.join(a.out, "scan_ref_spans.txt"), "w") as f:
-        for w, lo, hi in spans + [("recordFromStatement", r0, r1), ("bruteForceSearchUnlocked", b0, b1)]:
+        for w, lo, hi in spans + [("recordFromStatement", r0, r1), ("bruteForceSearchUnlocked", b0, b1),
+                                  ("StmtResetGuard", g0, g1), ("kSelectByRowid", q0, q1)] + vspans:
             f.write(f"src/vector/sqlite_vec_backend.cpp:{lo}-{hi} {w}\n")
         f.write(f"src/vector/vector_database.cpp:{c0}-{c1} computeCosineSimilarity\n")
     print("gen_scan_ref: fragments written to", a.out)

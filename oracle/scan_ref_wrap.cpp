@@ -9,6 +9,18 @@
 // few things they touch: a `db_` member over an in-memory SQLite (the image's /opt/conda sqlite3), the reference's own
 // headers for VectorRecord / VectorSearchDiagnostics / Result / ErrorCode, and stand-ins for the two JSON readers
 // recordFromStatement calls (the harness writes the metadata column itself, as a flat {"k":"v"} object).
+// Round 6 — the in-tree half of the L2 path: vec0SearchUnlocked (:4450-4530) with getVectorByRowidUnlocked (:3084-3099),
+// vec0TableName (:617-619), the table's creation and population (ensureVec0TableUnlocked :3236-3249,
+// decodeVectorForDimRowUnlocked :3251-3267, rebuildVec0DimUnlocked :3350-3421) are cut VERBATIM as well.  What they talk to —
+// the `vec0` virtual table of the ABSENT third_party/sqlite-vec-cpp — is a harness module below (Vec0Tab): `embedding MATCH
+// ?1 AND k = ?2` returns the k rows nearest to the query under a PLUGGABLE distance function (the oracle's seven definitions),
+// ties at the cut to the smaller rowid, and hands them to SQLite IN ROWID ORDER — the `ORDER BY distance` of the reference's
+// statement is then executed by SQLite itself, so the order equal distances come back in is what the reference's SQL does
+// with rowid-ordered input, not a guess.  `rowid IN (SELECT value FROM json_each(?3))`: this image's SQLite (3.36) has no
+// sqlite3_vtab_in, so the planner hands the module one rowid per xFilter call; the module answers each with that row and
+// its distance (no k cut inside the module) — identical to a KNN restricted to the candidates whenever no returned row is
+// dropped by the similarity threshold or k >= the number of candidates, which is what the pin tests use.  The DISTANCE
+// ARITHMETIC stays the dependency's: unpinned, calibrated (include/yams_accel/l2_calibration.hpp).
 // What this pins: tests/test_oracle.py compares oracle/yams_oracle.c's oracle_exact_scan_cosine / _records /
 // oracle_cosine_similarity with THIS code, bit for bit, and tests/golden/make_scan_golden.py writes its outputs to
 // tests/golden/scan.json for the GPU box (where /root/reference does not exist).
@@ -24,6 +36,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <optional>
 #include <span>
 #include <string>
@@ -31,11 +44,160 @@
 #include <unordered_set>
 #include <vector>
 
+// ---- harness stand-ins for what the cut vec0 functions name besides SQLite and the reference's own headers ---------------
+namespace spdlog { template <class... A> inline void warn(A&&...) {} }   // (the reference logs a failed prepare / step)
+namespace nlohmann {
+struct json {                                                            // json(std::vector<int64_t>).dump() -> "[1,2,3]"
+    std::string text;
+    explicit json(const std::vector<int64_t>& v) {
+        text = "[";
+        for (size_t i = 0; i < v.size(); ++i) { if (i) text += ','; text += std::to_string(v[i]); }
+        text += "]";
+    }
+    std::string dump() const { return text; }
+};
+} // namespace nlohmann
+
 namespace yams::vector {
 namespace {
+inline int stepWithRetry(sqlite3_stmt* stmt) { return sqlite3_step(stmt); } // (:297-315 retries on SQLITE_BUSY: an in-memory database has no contention)
 
 // ---- verbatim reference text: ExactRowSelection, isZeroNormEmbedding, isFiniteEmbedding, kCreateVectorsTable --------
 #include "_ref/scan_ref_file_scope.inc"
+// ---- verbatim reference text: StmtResetGuard, kSelectByRowid ------------------------------------------------------------
+#include "_ref/scan_ref_vec0_file_scope.inc"
+
+// ---- the harness's `vec0` module: a stand-in for the virtual table of the absent sqlite-vec-cpp (see the header) ---------
+using Vec0Distance = float (*)(const float* a, const float* b, size_t dim, int mode);
+float vec0_distance_f64(const float* a, const float* b, size_t dim, int) { // (the smoke test's "Euclidean distance WITH sqrt", in fp64)
+    double acc = 0.0;
+    for (size_t i = 0; i < dim; ++i) { const double d = static_cast<double>(a[i]) - static_cast<double>(b[i]); acc += d * d; }
+    return static_cast<float>(std::sqrt(acc));
+}
+struct Vec0Shared { Vec0Distance fn = vec0_distance_f64; int mode = 0; unsigned long long knn_queries = 0, rowid_probes = 0; };
+struct Vec0Tab {
+    sqlite3_vtab base{};
+    Vec0Shared* shared = nullptr;
+    size_t dim = 0;
+    std::map<sqlite3_int64, std::vector<float>> rows; // rowid order
+};
+struct Vec0Cur {
+    sqlite3_vtab_cursor base{};
+    std::vector<std::pair<sqlite3_int64, float>> out; // (rowid, distance) in the order they are handed to SQLite
+    bool has_distance = false;
+    size_t pos = 0;
+};
+int vec0Connect(sqlite3* db, void* aux, int argc, const char* const* argv, sqlite3_vtab** out, char**) {
+    auto* t = new Vec0Tab();
+    t->shared = static_cast<Vec0Shared*>(aux);
+    for (int i = 3; i < argc; ++i) {                    // "embedding float[384]"
+        const char* b = std::strchr(argv[i], '[');
+        if (b) t->dim = static_cast<size_t>(std::strtoull(b + 1, nullptr, 10));
+    }
+    const int rc = sqlite3_declare_vtab(db, "CREATE TABLE x(embedding, distance HIDDEN, k HIDDEN)");
+    if (rc != SQLITE_OK) { delete t; return rc; }
+    *out = &t->base;
+    return SQLITE_OK;
+}
+int vec0Disconnect(sqlite3_vtab* v) { delete reinterpret_cast<Vec0Tab*>(v); return SQLITE_OK; }
+int vec0BestIndex(sqlite3_vtab*, sqlite3_index_info* info) {
+    int match = -1, kk = -1, rid = -1;
+    for (int i = 0; i < info->nConstraint; ++i) {
+        const auto& c = info->aConstraint[i];
+        if (!c.usable) continue;
+        if (c.iColumn == 0 && c.op == SQLITE_INDEX_CONSTRAINT_MATCH) match = i;
+        else if (c.iColumn == 2 && c.op == SQLITE_INDEX_CONSTRAINT_EQ) kk = i;
+        else if (c.iColumn == -1 && c.op == SQLITE_INDEX_CONSTRAINT_EQ) rid = i;
+    }
+    info->idxNum = 0;
+    if (match >= 0 && kk >= 0) {
+        info->aConstraintUsage[match].argvIndex = 1; info->aConstraintUsage[match].omit = 1;
+        info->aConstraintUsage[kk].argvIndex = 2; info->aConstraintUsage[kk].omit = 1;
+        info->idxNum = 1;
+        if (rid >= 0) { info->aConstraintUsage[rid].argvIndex = 3; info->idxNum = 3; } // one candidate rowid per xFilter call
+        info->estimatedCost = 10.0;
+    } else {
+        info->estimatedCost = 1e6;                       // full scan (DELETE FROM, SELECT rowid)
+    }
+    info->orderByConsumed = 0;                           // ORDER BY distance is SQLite's to execute
+    return SQLITE_OK;
+}
+int vec0Open(sqlite3_vtab*, sqlite3_vtab_cursor** c) { *c = &(new Vec0Cur())->base; return SQLITE_OK; }
+int vec0Close(sqlite3_vtab_cursor* c) { delete reinterpret_cast<Vec0Cur*>(c); return SQLITE_OK; }
+int vec0Filter(sqlite3_vtab_cursor* cc, int idxNum, const char*, int argc, sqlite3_value** argv) {
+    auto* c = reinterpret_cast<Vec0Cur*>(cc);
+    auto* t = reinterpret_cast<Vec0Tab*>(cc->pVtab);
+    c->out.clear(); c->pos = 0; c->has_distance = idxNum != 0;
+    if (idxNum == 0) {
+        for (const auto& kv : t->rows) c->out.emplace_back(kv.first, 0.f);
+        return SQLITE_OK;
+    }
+    if (argc < 2 || sqlite3_value_type(argv[0]) != SQLITE_BLOB ||
+        static_cast<size_t>(sqlite3_value_bytes(argv[0])) != t->dim * sizeof(float)) {
+        cc->pVtab->zErrMsg = sqlite3_mprintf("vec0: the MATCH operand must be a float[%d] blob", static_cast<int>(t->dim));
+        return SQLITE_ERROR;
+    }
+    std::vector<float> q(t->dim);
+    std::memcpy(q.data(), sqlite3_value_blob(argv[0]), t->dim * sizeof(float));
+    const sqlite3_int64 k = sqlite3_value_int64(argv[1]);
+    if (idxNum == 3) {                                   // rowid = one of the IN list's values
+        ++t->shared->rowid_probes;
+        const auto it = t->rows.find(sqlite3_value_int64(argv[2]));
+        if (it != t->rows.end()) c->out.emplace_back(it->first, t->shared->fn(it->second.data(), q.data(), t->dim, t->shared->mode));
+        return SQLITE_OK;
+    }
+    ++t->shared->knn_queries;
+    std::vector<std::pair<float, sqlite3_int64>> all;   // (distance, rowid)
+    all.reserve(t->rows.size());
+    for (const auto& kv : t->rows) all.emplace_back(t->shared->fn(kv.second.data(), q.data(), t->dim, t->shared->mode), kv.first);
+    const size_t keep = k < 0 ? 0 : std::min<size_t>(static_cast<size_t>(k), all.size());
+    // the k nearest; a tie at the cut goes to the smaller rowid (a rowid-ordered scan that replaces only on `<`)
+    std::partial_sort(all.begin(), all.begin() + static_cast<std::ptrdiff_t>(keep), all.end());
+    all.resize(keep);
+    std::sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.second < b.second; }); // handed over in ROWID order
+    for (const auto& e : all) c->out.emplace_back(e.second, e.first);
+    return SQLITE_OK;
+}
+int vec0Next(sqlite3_vtab_cursor* cc) { ++reinterpret_cast<Vec0Cur*>(cc)->pos; return SQLITE_OK; }
+int vec0Eof(sqlite3_vtab_cursor* cc) { auto* c = reinterpret_cast<Vec0Cur*>(cc); return c->pos >= c->out.size(); }
+int vec0Column(sqlite3_vtab_cursor* cc, sqlite3_context* ctx, int col) {
+    auto* c = reinterpret_cast<Vec0Cur*>(cc);
+    auto* t = reinterpret_cast<Vec0Tab*>(cc->pVtab);
+    if (col == 0) {
+        const auto it = t->rows.find(c->out[c->pos].first);
+        if (it != t->rows.end()) sqlite3_result_blob(ctx, it->second.data(), static_cast<int>(it->second.size() * sizeof(float)), SQLITE_TRANSIENT);
+        else sqlite3_result_null(ctx);
+    } else if (col == 1 && c->has_distance) sqlite3_result_double(ctx, static_cast<double>(c->out[c->pos].second));
+    else sqlite3_result_null(ctx);
+    return SQLITE_OK;
+}
+int vec0Rowid(sqlite3_vtab_cursor* cc, sqlite3_int64* r) { auto* c = reinterpret_cast<Vec0Cur*>(cc); *r = c->out[c->pos].first; return SQLITE_OK; }
+int vec0Update(sqlite3_vtab* v, int argc, sqlite3_value** argv, sqlite3_int64* out_rowid) {
+    auto* t = reinterpret_cast<Vec0Tab*>(v);
+    if (argc == 1) { t->rows.erase(sqlite3_value_int64(argv[0])); return SQLITE_OK; }            // DELETE
+    if (sqlite3_value_type(argv[0]) != SQLITE_NULL) t->rows.erase(sqlite3_value_int64(argv[0]));   // UPDATE: replace
+    sqlite3_int64 rowid = sqlite3_value_type(argv[1]) != SQLITE_NULL ? sqlite3_value_int64(argv[1])
+                                                                      : (t->rows.empty() ? 1 : t->rows.rbegin()->first + 1);
+    if (sqlite3_value_type(argv[2]) != SQLITE_BLOB || static_cast<size_t>(sqlite3_value_bytes(argv[2])) != t->dim * sizeof(float)) {
+        v->zErrMsg = sqlite3_mprintf("vec0: embedding must be a float[%d] blob", static_cast<int>(t->dim));
+        return SQLITE_CONSTRAINT;
+    }
+    std::vector<float> e(t->dim);
+    std::memcpy(e.data(), sqlite3_value_blob(argv[2]), t->dim * sizeof(float));
+    t->rows[rowid] = std::move(e);
+    *out_rowid = rowid;
+    return SQLITE_OK;
+}
+int vec0FindFunction(sqlite3_vtab*, int, const char* name, void (**fn)(sqlite3_context*, int, sqlite3_value**), void**) {
+    // `embedding MATCH ?`: the operator is only ever consumed by xBestIndex; SQLite still wants an overload to exist
+    if (std::strcmp(name, "match") != 0) return 0;
+    *fn = [](sqlite3_context* ctx, int, sqlite3_value**) { sqlite3_result_int(ctx, 1); };
+    return 1;
+}
+const sqlite3_module kVec0Module = {
+    /*iVersion*/ 1, vec0Connect, vec0Connect, vec0BestIndex, vec0Disconnect, vec0Disconnect, vec0Open, vec0Close, vec0Filter,
+    vec0Next, vec0Eof, vec0Column, vec0Rowid, vec0Update, nullptr, nullptr, nullptr, nullptr, vec0FindFunction, nullptr,
+    nullptr, nullptr, nullptr, nullptr};
 
 // ---- harness stand-ins for :540-575 (nlohmann::json readers): flat {"key":"value",...} / ["a","b"] written below ----
 std::string unescape(std::string_view s, size_t& i) { // s[i] == '"' on entry; leaves i past the closing quote
@@ -76,8 +238,17 @@ std::vector<std::string> deserializeStringVector(const std::string& json_str) {
 struct RefScan {
     sqlite3* db_ = nullptr;
     sqlite3_stmt* insert_ = nullptr;
+    // what the cut vec0 members name (sqlite_vec_backend.cpp's Impl: :3160-3175 the prepared statements, the backend's Config)
+    mutable std::mutex stmt_mutex_;
+    sqlite3_stmt* stmt_select_by_rowid_ = nullptr;
+    std::unordered_set<size_t> vec0_dirty_dims_, vec0_ready_dims_;
+    struct { bool vec0_phss_enabled = false; size_t vec0_phss_candidates = 64; } config_;
+    Vec0Shared vec0_;
     // ---- verbatim reference text: recordFromStatement, bruteForceSearchUnlocked ----------------------------------------
 #include "_ref/scan_ref_members.inc"
+    // ---- verbatim reference text: vec0TableName, getVectorByRowidUnlocked, ensureVec0TableUnlocked,
+    //      decodeVectorForDimRowUnlocked, rebuildVec0DimUnlocked, vec0SearchUnlocked ----------------------------------------
+#include "_ref/scan_ref_vec0_members.inc"
 };
 
 } // namespace
@@ -101,6 +272,11 @@ __attribute__((visibility("default"))) void* scanref_open(void) {
     const char* ins = "INSERT INTO vectors (chunk_id, document_hash, embedding, embedding_dim, content, start_offset, "
                       "metadata) VALUES (?1, ?2, ?3, ?4, '', ?5, ?6)";
     if (sqlite3_prepare_v2(h->db_, ins, -1, &h->insert_, nullptr) != SQLITE_OK) { sqlite3_close(h->db_); delete h; return nullptr; }
+    // the L2 path: the harness's vec0 module, and the statement getVectorByRowidUnlocked steps (prepared as :3167 does)
+    if (sqlite3_create_module(h->db_, "vec0", &yams::vector::kVec0Module, &h->vec0_) != SQLITE_OK ||
+        sqlite3_prepare_v2(h->db_, yams::vector::kSelectByRowid, -1, &h->stmt_select_by_rowid_, nullptr) != SQLITE_OK) {
+        sqlite3_finalize(h->insert_); sqlite3_close(h->db_); delete h; return nullptr;
+    }
     sqlite3_exec(h->db_, "BEGIN", nullptr, nullptr, nullptr);
     return h;
 }
@@ -109,6 +285,7 @@ __attribute__((visibility("default"))) void scanref_close(void* hv) {
     auto* h = static_cast<RefScan*>(hv);
     if (!h) return;
     if (h->insert_) sqlite3_finalize(h->insert_);
+    if (h->stmt_select_by_rowid_) sqlite3_finalize(h->stmt_select_by_rowid_);
     if (h->db_) sqlite3_close(h->db_);
     delete h;
 }
@@ -194,6 +371,66 @@ __attribute__((visibility("default"))) long scanref_search(void* hv, const float
                                                            unsigned long long* diag) {
     return scanref_search_ex(hv, query, dim, k, threshold, nullptr, nullptr, 0, meta_kv, n_meta, all_matching, out_ordinals, out_scores, cap,
                              out_n, diag);
+}
+
+// ---- the L2 (vec0) path -------------------------------------------------------------------------------------------------
+// The distance the harness's vec0 module computes: fn(row, query, dim, mode) — e.g. the oracle's oracle_l2_distance_f32acc
+// with mode = its `lanes`; null restores the fp64 default.
+__attribute__((visibility("default"))) void scanref_vec0_set_distance(void* hv, void* fn, int mode) {
+    auto* h = static_cast<RefScan*>(hv);
+    h->vec0_.fn = fn ? reinterpret_cast<yams::vector::Vec0Distance>(fn) : yams::vector::vec0_distance_f64;
+    h->vec0_.mode = mode;
+}
+// rebuildVec0DimUnlocked(dim): the reference's own creation + population of vectors_<dim>_vec0 from `vectors` (rows whose
+// blob is not dim floats or holds a non-finite value are left out, :3251-3267).  0, or the reference's ErrorCode negated.
+__attribute__((visibility("default"))) long scanref_vec0_rebuild(void* hv, size_t dim) {
+    auto* h = static_cast<RefScan*>(hv);
+    sqlite3_exec(h->db_, "COMMIT", nullptr, nullptr, nullptr);
+    auto r = h->rebuildVec0DimUnlocked(dim);
+    return r ? 0 : -static_cast<long>(r.error().code);
+}
+// DELETE FROM vectors WHERE start_offset = ordinal — AFTER a rebuild this leaves a rowid in the vec0 table that
+// getVectorByRowidUnlocked no longer finds (:4501-4504: such hits are skipped)
+__attribute__((visibility("default"))) int scanref_delete_ordinal(void* hv, long long ordinal) {
+    auto* h = static_cast<RefScan*>(hv);
+    sqlite3_exec(h->db_, "COMMIT", nullptr, nullptr, nullptr);
+    char sql[96];
+    std::snprintf(sql, sizeof sql, "DELETE FROM vectors WHERE start_offset = %lld", ordinal);
+    return sqlite3_exec(h->db_, sql, nullptr, nullptr, nullptr) == SQLITE_OK ? 0 : 1;
+}
+__attribute__((visibility("default"))) long long scanref_rowid_of_ordinal(void* hv, long long ordinal) {
+    auto* h = static_cast<RefScan*>(hv);
+    sqlite3_stmt* s = nullptr;
+    long long r = -1;
+    if (sqlite3_prepare_v2(h->db_, "SELECT rowid FROM vectors WHERE start_offset = ?", -1, &s, nullptr) != SQLITE_OK) return -1;
+    sqlite3_bind_int64(s, 1, ordinal);
+    if (sqlite3_step(s) == SQLITE_ROW) r = sqlite3_column_int64(s, 0);
+    sqlite3_finalize(s);
+    return r;
+}
+// vec0SearchUnlocked(query, k, threshold, candidateRowids).  candidate_rowids == nullptr: no restriction (n_candidates is
+// ignored); otherwise n_candidates rowids (0: the reference returns nothing, :4456-4458).  Outputs as scanref_search_ex;
+// stats[2] = KNN queries the module answered, rowid probes it answered (which branch of the SQL ran).
+__attribute__((visibility("default"))) long scanref_vec0_search(void* hv, const float* query, size_t dim, size_t k, float threshold,
+                                                                const long long* candidate_rowids, size_t n_candidates,
+                                                                long long* out_ordinals, float* out_scores, size_t cap, size_t* out_n,
+                                                                unsigned long long* stats) {
+    auto* h = static_cast<RefScan*>(hv);
+    sqlite3_exec(h->db_, "COMMIT", nullptr, nullptr, nullptr);
+    std::vector<float> q(query, query + dim);
+    std::vector<int64_t> cands;
+    if (candidate_rowids) cands.assign(candidate_rowids, candidate_rowids + n_candidates);
+    h->vec0_.knn_queries = h->vec0_.rowid_probes = 0;
+    auto r = h->vec0SearchUnlocked(q, k, threshold, candidate_rowids ? &cands : nullptr);
+    if (stats) { stats[0] = h->vec0_.knn_queries; stats[1] = h->vec0_.rowid_probes; }
+    if (!r) return -static_cast<long>(r.error().code);
+    const auto& recs = r.value();
+    if (out_n) *out_n = recs.size();
+    for (size_t i = 0; i < recs.size() && i < cap; ++i) {
+        out_ordinals[i] = static_cast<long long>(recs[i].start_offset);
+        out_scores[i] = recs[i].relevance_score;
+    }
+    return 0;
 }
 
 __attribute__((visibility("default"))) double scanref_cosine(const float* a, size_t na, const float* b, size_t nb) {

@@ -362,10 +362,24 @@ ORACLE_API double oracle_cosine_similarity(const float* a, const float* b, size_
  * and the caller src/vector/sqlite_vec_backend.cpp:4450-4530: k nearest by distance ascending,
  * each hit re-scored with computeCosineSimilarity (:4506), dropped if below the threshold (:4508),
  * returned in distance order with relevance_score = cosine (:4512).  Restated here as:
- * distance = (float)sqrt(sum_i ((double)a_i - (double)b_i)^2), ascending, ties by tie_rank.
+ * distance = (float)sqrt(sum_i ((double)a_i - (double)b_i)^2), ascending, ties in ROW (= rowid) order.
  * vec0's `k = ?2` bounds the candidate list BEFORE the cosine threshold filter (:4464-4473), so
  * fewer than k rows may come back.
+ * Round 6: everything of this function EXCEPT the distance arithmetic is pinned by the reference's own
+ * vec0SearchUnlocked (+ getVectorByRowidUnlocked, rebuildVec0DimUnlocked), compiled over SQLite with a harness `vec0`
+ * module (oracle/scan_ref_wrap.cpp, tests/test_scan_ref_l2_pin.py): k nearest THEN the threshold, rows the vectors table
+ * no longer holds skipped, non-finite / wrong-size rows never indexed, k > n, the candidate-rowid branch, and the order
+ * of EQUAL distances — the statement is `ORDER BY distance` alone (:4473) and SQLite's sorter returns ties in the order
+ * the table handed the rows over, i.e. rowid order, whatever the chunk ids.  `tie_rank` (the chunk_id ranking of the
+ * cosine comparator, :4218-4223) is therefore IGNORED here; the parameter stays for the callers' convenience.
  * ---------------------------------------------------------------------------------------------- */
+/* the default definition of the distance, with the signature the harness's vec0 module calls (mode unused) */
+ORACLE_API float oracle_l2_distance_f64(const float* a, const float* b, size_t dim, int mode) {
+    (void)mode;
+    double acc = 0.0;
+    for (size_t i = 0; i < dim; ++i) { const double d = (double)a[i] - (double)b[i]; acc += d * d; }
+    return (float)sqrt(acc);
+}
 typedef struct { float dist; uint64_t rank; int64_t row; } oracle_l2hit;
 static int l2_cmp(const void* pa, const void* pb) {
     const oracle_l2hit* a = (const oracle_l2hit*)pa; const oracle_l2hit* b = (const oracle_l2hit*)pb;
@@ -391,7 +405,7 @@ ORACLE_API long oracle_exact_scan_l2(const float* corpus, size_t n_rows, size_t 
         if (!finite) continue; /* insert-time validity, src/vector/vector_database.cpp:1771-1784 */
         double dd = sqrt(acc);
         if (!isfinite(dd)) continue;
-        all[m].dist = (float)dd; all[m].rank = tie_rank ? tie_rank[r] : (uint64_t)r;
+        all[m].dist = (float)dd; all[m].rank = (uint64_t)r; (void)tie_rank; /* ties: rowid order (see above) */
         all[m].row = (int64_t)r; ++m;
     }
     qsort(all, m, sizeof(oracle_l2hit), l2_cmp);
@@ -457,7 +471,7 @@ ORACLE_API long oracle_exact_scan_l2_f32acc(const float* corpus, size_t n_rows, 
         if (!finite) continue;
         const float dd = oracle_l2_distance_f32acc(e, query, dim, lanes);
         if (!isfinite(dd)) continue;
-        all[m].dist = dd; all[m].rank = tie_rank ? tie_rank[r] : (uint64_t)r; all[m].row = (int64_t)r; ++m;
+        all[m].dist = dd; all[m].rank = (uint64_t)r; (void)tie_rank; all[m].row = (int64_t)r; ++m; /* ties: rowid order */
     }
     qsort(all, m, sizeof(oracle_l2hit), l2_cmp);
     size_t take = m < k ? m : k, outn = 0;

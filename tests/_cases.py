@@ -84,6 +84,11 @@ def golden_scan_matrix(oracle, spec):
         m = np.random.default_rng(spec["seed"]).standard_normal((spec["n"], spec["dim"])).astype(np.float32)
     elif kind == "bits":
         m = _bits_rows(spec["rows"])
+    elif kind == "perm_offsets":     # rows = base[0] + a permutation of ONE offset vector: equal distances to base[0] in exact
+        base = golden_scan_matrix(oracle, spec["base"])[0]      # arithmetic, different fp32 roundings per summation order
+        rng = np.random.default_rng(spec["seed"])
+        e = (rng.standard_normal(spec["dim"]) * spec.get("scale", 1.0)).astype(np.float32)
+        m = np.stack([base + e[rng.permutation(spec["dim"])] for _ in range(spec["n"])]).astype(np.float32)
     else:
         raise ValueError(kind)
     m = np.array(m, np.float32, copy=True)

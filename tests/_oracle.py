@@ -332,6 +332,18 @@ class ScanRef:
         L.scanref_insert_rows_docs.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_longlong]
         L.scanref_cosine.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t]
         L.scanref_cosine.restype = C.c_double
+        # round 6: the in-tree half of the L2 path (vec0SearchUnlocked over the harness's vec0 module)
+        self.has_vec0 = hasattr(L, "scanref_vec0_search")
+        if self.has_vec0:
+            L.scanref_vec0_set_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            L.scanref_vec0_rebuild.argtypes = [C.c_void_p, C.c_size_t]
+            L.scanref_vec0_rebuild.restype = C.c_long
+            L.scanref_delete_ordinal.argtypes = [C.c_void_p, C.c_longlong]
+            L.scanref_rowid_of_ordinal.argtypes = [C.c_void_p, C.c_longlong]
+            L.scanref_rowid_of_ordinal.restype = C.c_longlong
+            L.scanref_vec0_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_float, C.POINTER(C.c_longlong), C.c_size_t,
+                                              C.POINTER(C.c_longlong), f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong)]
+            L.scanref_vec0_search.restype = C.c_long
         self.invalid_argument = -int(L.scanref_error_code_invalid_argument())
         self.h = C.c_void_p(L.scanref_open())
         if not self.h:
@@ -400,6 +412,44 @@ class ScanRef:
     def cosine(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         return self.L.scanref_cosine(_ptr(a, f32p), a.size, _ptr(b, f32p), b.size)
+
+    # ---- the L2 (vec0) path: vec0SearchUnlocked, sqlite_vec_backend.cpp:4450-4530 ------------------------------------------
+    def vec0_set_distance(self, lanes=None):
+        """The distance the harness's vec0 module computes: None = fp64 (this repository's default definition), else the
+        oracle's oracle_l2_distance_f32acc with that `lanes` (1 / 8 / 16 sequential or SIMD-style fp32 sums, negative = fused)."""
+        if lanes is None:
+            self.L.scanref_vec0_set_distance(self.h, None, 0)
+        else:
+            fn = C.cast(oracle().L.oracle_l2_distance_f32acc, C.c_void_p)
+            self.L.scanref_vec0_set_distance(self.h, fn, int(lanes))
+
+    def vec0_rebuild(self, dim):
+        """rebuildVec0DimUnlocked(dim): the reference's own creation + population of the vec0 table from `vectors`."""
+        rc = self.L.scanref_vec0_rebuild(self.h, dim)
+        assert rc == 0, rc
+
+    def delete_ordinal(self, ordinal):
+        assert self.L.scanref_delete_ordinal(self.h, ordinal) == 0
+
+    def rowid_of(self, ordinal):
+        return int(self.L.scanref_rowid_of_ordinal(self.h, ordinal))
+
+    def vec0_search(self, query, k, thr=-1.0, candidate_rowids=None):
+        """vec0SearchUnlocked(query, k, thr, candidateRowids): (ordinals, cosine scores, stats) or the negative ErrorCode."""
+        q = np.ascontiguousarray(query, np.float32)
+        cap = max(k, 1)
+        ords = np.full(cap, -1, np.int64); sc = np.zeros(cap, np.float32)
+        cnt = C.c_size_t(0); st = (C.c_ulonglong * 2)()
+        cand = None; n_cand = 0
+        if candidate_rowids is not None:
+            n_cand = len(candidate_rowids)
+            cand = (C.c_longlong * max(n_cand, 1))(*[int(x) for x in candidate_rowids])
+        rc = self.L.scanref_vec0_search(self.h, _ptr(q, f32p), q.size, k, thr, cand, n_cand,
+                                        ords.ctypes.data_as(C.POINTER(C.c_longlong)), _ptr(sc, f32p), cap, C.byref(cnt), st)
+        if rc != 0:
+            return rc
+        assert cnt.value <= cap
+        return ords[:cnt.value].copy(), sc[:cnt.value].copy(), {"knn_queries": st[0], "rowid_probes": st[1]}
 
 
 def scan_ref():

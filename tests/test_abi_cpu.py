@@ -138,6 +138,43 @@ def test_no_gpu_means_refusal_not_fallback(accel_lib):
     L.yams_plugin_shutdown()
 
 
+def test_plugin_configuration_is_read_strictly(accel_lib):
+    """yams_plugin_init's config_json goes through a tokenizer, not substring search: a known key
+    with a value of the wrong type, an enumerated value the plugin does not list (the parity-critical "l2_accumulate" above
+    all: a typo must not silently serve fp64 results) or text that is not a JSON object fail the init with a message in
+    the health JSON; unknown keys — whatever they hold — are ignored.  Runs without a GPU: a well-formed configuration
+    gets as far as the device check."""
+    import json
+    L = accel_lib
+    if L.yams_accel_device_count() > 0:
+        pytest.skip("a GPU is visible here: the device-independent half of init is what this test looks at")
+
+    def init_error(cfg):
+        L.yams_plugin_shutdown()
+        assert L.yams_plugin_init(cfg, None) == -3
+        p = C.c_void_p()
+        assert L.yams_plugin_get_health_json(C.byref(p)) == 0
+        try:
+            return json.loads(C.string_at(p).decode())["error"]
+        finally:
+            L.yams_accel_free_string(p)
+
+    for good in (b"{}", b"", None, b'{"device": 0, "search_slots": 4, "shadows": "i8", "l2_accumulate": "f32x8_fma", "collective": "peer", "fence": "off"}',
+                 b'{"devices": [0, 1], "stripe_rows": 4096, "note": "both", "nested": {"shadows": ["none", {"x": 1}]}, "ratio": 0.5, "on": true}',
+                 b' { "rccl_library" : "/opt/site/lib\\"rccl\\".so" , "exchange_timeout_ms" : 1500 } '):
+        assert init_error(good) == "no gfx950 device visible", good
+    bad = {b'{"l2_accumulate": "f32x8_fmadd"}': "l2_accumulate", b'{"l2_accumulate": 8}': "must be a string",
+           b'{"shadows": "all"}': "shadows", b'{"search_slots": "4"}': "must be an integer", b'{"devices": "0,1"}': "devices",
+           b'{"devices": []}': "devices", b'{"collective": "nccl"}': "collective", b'{"device": 0': "expected", b'["device", 0]': "not a JSON object",
+           b'{"device": 0} trailing': "text after", b'{"stripe_rows": 1.5}': "must be an integer"}
+    for cfg, needle in bad.items():
+        e = init_error(cfg)
+        assert e.startswith("configuration:") and needle in e, (cfg, e)
+    # round 5's reader took the FIRST "both" after "shadows" anywhere in the text: {"shadows":"none","note":"both"} enabled both
+    assert init_error(b'{"shadows": "none", "note": "both"}') == "no gfx950 device visible"
+    L.yams_plugin_shutdown()
+
+
 def test_default_config_matches_reference_constants(accel_lib):
     from yams_amd import _lib
     cfg = _lib.CdcConfig()

@@ -1755,3 +1755,38 @@ def test_hip_scan_reproduces_the_reference_compiled_golden_vectors(acc, oracle, 
             assert [int(x) for x in r.scores[j, :cnt].view(np.uint32)] == e["score_bits"], (case["name"], qi)
         n_cases += 1
     assert n_cases >= (6 if shadow == "both" else 15)
+
+
+# ---- the reference's own vec0SearchUnlocked, compiled, as golden vectors (round 6) ---------------------------------------------
+L2_GOLDEN_FLAGS = {"f64": _lib.FLAG_L2_ACC_F64, "f32": _lib.FLAG_L2_ACC_F32, "f32x8": _lib.FLAG_L2_ACC_F32X8, "f32x16": _lib.FLAG_L2_ACC_F32X16,
+                   "f32_fma": _lib.FLAG_L2_ACC_F32 | _lib.FLAG_L2_ACC_FUSED, "f32x8_fma": _lib.FLAG_L2_ACC_F32X8 | _lib.FLAG_L2_ACC_FUSED,
+                   "f32x16_fma": _lib.FLAG_L2_ACC_F32X16 | _lib.FLAG_L2_ACC_FUSED}
+
+
+@pytest.mark.parametrize("shadow", [True, "both"])
+def test_hip_l2_scan_reproduces_the_reference_compiled_vec0_golden_vectors(acc, oracle, shadow):
+    """tests/golden/scan_l2.json holds what SqliteVecBackend::Impl::vec0SearchUnlocked ITSELF returned (compiled from
+    /root/reference, over the harness's vec0 module with each of the seven distance definitions plugged in): the HIP path under
+    the matching accumulate flag must return the same rows in the same order with the same cosine bits — k nearest then the
+    threshold, k > n, EQUAL DISTANCES IN ROWID ORDER although the view carries a shuffled chunk_id ranking (it belongs to the
+    cosine comparator), the candidate restriction as an allow-mask, and the case whose answer depends on the definition."""
+    with open(os.path.join(_cases.GOLDEN, "scan_l2.json")) as f:
+        g = json.load(f)
+    n_checked = 0
+    for case in g["cases"]:
+        corpus, queries, tie_rank, allow = _cases.golden_scan_inputs(oracle, case)
+        if shadow == "both" and not (corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256):
+            continue
+        mask = allow.astype(bool) if allow is not None else None
+        for name, fl in L2_GOLDEN_FLAGS.items():
+            if name in case["same_as_f64"] and name not in ("f32x8_fma", "f32"):
+                continue        # (identical expectations: two of the fp32 forms stand for the others)
+            exp = case["expected"]["f64" if name in case["same_as_f64"] else name]
+            r = run(acc, corpus, queries, case["k"], case["threshold"], SCAN_L2, fl, tie_rank, shadow=shadow, mask=mask)
+            for qi, e in enumerate(exp):
+                cnt = int(r.counts[qi])
+                assert cnt == len(e["rows"]), (case["name"], name, qi, cnt, len(e["rows"]), r.diag)
+                assert r.rows[qi, :cnt].tolist() == e["rows"], (case["name"], name, qi, r.diag)
+                assert [int(x) for x in r.scores[qi, :cnt].view(np.uint32)] == e["score_bits"], (case["name"], name, qi)
+                n_checked += 1
+    assert n_checked >= (60 if shadow == "both" else 150)

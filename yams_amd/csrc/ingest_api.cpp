@@ -342,8 +342,15 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
     }
     const int n_slots = static_cast<int>(std::min<size_t>(chains ? kSlots : 2, batches.size()));
     uint8_t* d_buf[kSlots] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < n_slots; ++i)
-        YA_TRY(ws_get(ctx, ("ing_host_buf" + std::to_string(i)).c_str(), largest + 64, (void**)&d_buf[i]));
+    for (int i = 0; i < n_slots; ++i) {
+        const yams_status_t a_st = ws_get(ctx, ("ing_host_buf" + std::to_string(i)).c_str(), largest + 64, (void**)&d_buf[i]);
+        if (a_st != YAMS_OK) {
+            // slot i could not be had: the slots before it (up to 3 x 8 GiB) go back at once — the call promises that the
+            // context keeps nothing above 1.25 GiB afterwards, and a retry with smaller batches needs that very memory
+            if (largest > (1ull << 30)) (void)ws_trim(ctx, (1ull << 30) + (1ull << 28));
+            return a_st;
+        }
+    }
     hipStream_t copy_st = nullptr;
     hipEvent_t landed[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     IngestLane lanes[kSlots];
@@ -364,7 +371,7 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
     };
     auto hip_ok = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
-        rc = fail(ctx, YAMS_ERR_INTERNAL, what);
+        rc = hip_fail(ctx, e, what);    // (hipErrorOutOfMemory -> YAMS_ERR_RESOURCE_EXHAUSTED, everything else internal)
         return false;
     };
     // Streams of one priority share a small pool of hardware queues (four by default), handed out by how many streams

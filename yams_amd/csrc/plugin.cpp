@@ -8,6 +8,7 @@
 // yams_plugin_get_manifest_json, then yams_plugin_get_interface(id, version, &vtable).
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <numeric>
+#include <set>
 #include <shared_mutex>
 #include <sstream>
 #include <string>
@@ -311,33 +313,135 @@ const char kManifest[] =
     "\"interfaces\":[{\"id\":\"vector_scan_v1\",\"version\":1},"
     "{\"id\":\"content_hash_v1\",\"version\":1},{\"id\":\"chunker_v1\",\"version\":3}]}";
 
-// Minimal readers for the init config: {"device": 0} | {"devices": [0,1,...], "search_slots": 2,
-// "shadows": "both" | "bf16" | "i8" | "none"}
-long json_int(const char* json, const char* key, long dflt) {
-    if (!json) return dflt;
-    const char* p = std::strstr(json, key);
-    if (!p) return dflt;
-    p = std::strchr(p, ':');
-    return p ? std::atol(p + 1) : dflt;
-}
-std::vector<int> json_devices(const char* json) {
-    std::vector<int> out;
-    const char* p = json ? std::strstr(json, "\"devices\"") : nullptr;
-    if (p && (p = std::strchr(p, '['))) {
-        ++p;
-        while (*p && *p != ']') {
-            while (*p == ' ' || *p == ',') ++p;
-            if (*p == ']' || !*p) break;
-            char* end = nullptr;
-            const long v = std::strtol(p, &end, 10);
-            if (end == p) break;
-            out.push_back(static_cast<int>(v));
-            p = end;
+// ---- the plugin's configuration: a strict reader of ONE flat JSON object ----------------------------------------------------
+// {"key": "string" | integer | [integers] | true | false | null | {...} | [...]}: keys the plugin does not know are skipped
+// (whatever their value, nested or not); a key it knows with a value of the wrong TYPE, an enumerated value it does not
+// list, or text that is not a JSON object fails yams_plugin_init — a host's typo must not silently serve another arithmetic
+// (round 5 read its keys with strstr: {"shadows":"none","note":"both"} enabled both shadows).
+struct Config {
+    std::map<std::string, std::string> strings;
+    std::map<std::string, long> ints;
+    std::map<std::string, std::vector<long>> int_lists;
+    std::set<std::string> other;       // keys present with a value of another type (booleans, null, objects, nested arrays, floats)
+    std::string error;                 // non-empty: the text did not parse
+
+    static void ws(const char*& p) { while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') ++p; }
+    static bool str(const char*& p, std::string& out) {
+        if (*p != '"') return false;
+        out.clear();
+        for (++p; *p && *p != '"'; ++p) {
+            if (*p == '\\') { ++p; if (!*p) return false; out.push_back(*p == 'n' ? '\n' : (*p == 't' ? '\t' : *p)); }
+            else out.push_back(*p);
         }
+        if (*p != '"') return false;
+        ++p;
+        return true;
     }
-    if (out.empty()) out.push_back(static_cast<int>(json_int(json, "\"device\"", 0)));
-    return out;
-}
+    static bool integer(const char*& p, long& v) {
+        char* e = nullptr;
+        v = std::strtol(p, &e, 10);
+        if (e == p || *e == '.' || *e == 'e' || *e == 'E') return false;
+        p = e;
+        return true;
+    }
+    static bool skip(const char*& p, int depth = 0) {   // any JSON value
+        ws(p);
+        if (depth > 32) return false;
+        std::string t;
+        if (*p == '"') return str(p, t);
+        if (*p == '{' || *p == '[') {
+            const char close = *p == '{' ? '}' : ']';
+            const bool object = *p == '{';
+            ++p; ws(p);
+            if (*p == close) { ++p; return true; }
+            for (;;) {
+                ws(p);
+                if (object) { if (!str(p, t)) return false; ws(p); if (*p++ != ':') return false; }
+                if (!skip(p, depth + 1)) return false;
+                ws(p);
+                if (*p == ',') { ++p; continue; }
+                if (*p == close) { ++p; return true; }
+                return false;
+            }
+        }
+        const char* b = p;
+        while (*p && (std::isalnum(static_cast<unsigned char>(*p)) || *p == '-' || *p == '+' || *p == '.')) ++p;
+        return p != b;
+    }
+    explicit Config(const char* json) {
+        if (!json) return;
+        const char* p = json;
+        ws(p);
+        if (!*p) return;                                // "" = no configuration
+        if (*p != '{') { error = "the configuration is not a JSON object"; return; }
+        ++p; ws(p);
+        if (*p == '}') { ++p; ws(p); if (*p) error = "text after the configuration object"; return; }
+        for (;;) {
+            std::string key;
+            ws(p);
+            if (!str(p, key)) { error = "expected a key"; return; }
+            ws(p);
+            if (*p++ != ':') { error = "expected ':' after \"" + key + "\""; return; }
+            ws(p);
+            if (*p == '"') { std::string v; if (!str(p, v)) { error = "unterminated string for \"" + key + "\""; return; } strings[key] = v; }
+            else if (*p == '-' || std::isdigit(static_cast<unsigned char>(*p))) {
+                const char* q = p; long v;
+                if (integer(q, v)) { ints[key] = v; p = q; }
+                else { if (!skip(p)) { error = "bad number for \"" + key + "\""; return; } other.insert(key); }
+            } else if (*p == '[') {
+                const char* q = p + 1; std::vector<long> lst; bool ok = true;
+                ws(q);
+                if (*q == ']') ++q;
+                else for (;;) {
+                    long v; ws(q);
+                    if (!integer(q, v)) { ok = false; break; }
+                    lst.push_back(v); ws(q);
+                    if (*q == ',') { ++q; continue; }
+                    if (*q == ']') { ++q; break; }
+                    ok = false; break;
+                }
+                if (ok) { int_lists[key] = lst; p = q; }
+                else { if (!skip(p)) { error = "bad array for \"" + key + "\""; return; } other.insert(key); }
+            } else { if (!skip(p)) { error = "bad value for \"" + key + "\""; return; } other.insert(key); }
+            ws(p);
+            if (*p == ',') { ++p; continue; }
+            if (*p == '}') { ++p; break; }
+            error = "expected ',' or '}' after \"" + key + "\""; return;
+        }
+        ws(p);
+        if (*p) error = "text after the configuration object";
+    }
+    bool has(const std::string& k) const { return strings.count(k) || ints.count(k) || int_lists.count(k) || other.count(k); }
+    // typed reads: false (with `error` set) when the key is there with another type
+    bool get_int(const std::string& k, long dflt, long& out) {
+        out = dflt;
+        if (!has(k)) return true;
+        const auto it = ints.find(k);
+        if (it == ints.end()) { error = "\"" + k + "\" must be an integer"; return false; }
+        out = it->second;
+        return true;
+    }
+    bool get_string(const std::string& k, std::string& out, bool& present) {
+        present = false;
+        if (!has(k)) return true;
+        const auto it = strings.find(k);
+        if (it == strings.end()) { error = "\"" + k + "\" must be a string"; return false; }
+        out = it->second; present = true;
+        return true;
+    }
+    // an enumerated string: index into `allowed`, dflt when absent; false on any other value
+    bool get_choice(const std::string& k, std::initializer_list<const char*> allowed, int dflt, int& out) {
+        out = dflt;
+        std::string v; bool present;
+        if (!get_string(k, v, present)) return false;
+        if (!present) return true;
+        int i = 0;
+        for (const char* a : allowed) { if (v == a) { out = i; return true; } ++i; }
+        error = "\"" + k + "\": \"" + v + "\" is not one of";
+        for (const char* a : allowed) error += std::string(" \"") + a + "\"";
+        return false;
+    }
+};
 
 std::shared_ptr<Corpus> find_corpus(uint64_t id) {
     std::lock_guard<std::mutex> lk(g.corpora_mu);
@@ -1073,43 +1177,51 @@ const char* yams_plugin_get_manifest_json(void) { return kManifest; }
 // never dereferenced.  config_json: {"device": n} or {"devices": [..]} (a corpus is dealt to all of
 // them in stripes and searched behind one call), "search_slots": concurrent searches (default 2),
 // "shadows": "both" (default) | "bf16" | "i8" | "none", "collective": "auto" | "rccl" | "peer",
-// "rccl_library": "<path>", "fence": "off", "l2_accumulate": "f64" (default) | "f32" | "f32x8" | "f32x16".
+// "rccl_library": "<path>", "fence": "off", "l2_accumulate": "f64" (default) | "f32" | "f32x8" | "f32x16" | "f32_fma" |
+// "f32x8_fma" | "f32x16_fma".  Read by a strict tokenizer (struct Config): unknown keys are ignored, a known key with a value
+// of the wrong type or an enumerated value that is not listed fails the init (YAMS_PLUGIN_ERR_INIT_FAILED).
 static int plugin_init_impl(const char* config_json, const void* host_context) {
     (void)host_context;
     std::unique_lock<std::shared_mutex> lk(g.mu);
     if (g.initialised) return YAMS_PLUGIN_OK;
-    g.devices = json_devices(config_json);
-    const long slots = std::max<long>(1, std::min<long>(16, json_int(config_json, "\"search_slots\"", 2)));
-    {
-        const long sr = json_int(config_json, "\"stripe_rows\"", 65536);
-        kStripeRows = static_cast<uint32_t>(std::max<long>(64, std::min<long>(1 << 24, sr)) / 64 * 64);
-    }
-    g.want_bf16 = g.want_i8 = true;
-    if (config_json && std::strstr(config_json, "\"shadows\"")) {
-        const char* p = std::strstr(config_json, "\"shadows\"");
-        g.want_bf16 = std::strstr(p, "\"both\"") || std::strstr(p, "\"bf16\"");
-        g.want_i8 = std::strstr(p, "\"both\"") || std::strstr(p, "\"i8\"");
-    }
-    g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F64;
-    g.append_bytes = 0; g.appends = 0; g.exhausted_appends = 0; g.append_map_ms = 0; g.append_copy_ms = 0; g.append_shadow_ms = 0;
-    g.slow_append_ms = 0; g.slow_map_ms = 0; g.slow_copy_ms = 0; g.slow_shadow_ms = 0; g.slow_append_bytes = 0;
-    if (const char* p = config_json ? std::strstr(config_json, "\"l2_accumulate\"") : nullptr) {
-        // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header)
-        const char* c = std::strchr(p + 15, ':');
-        const char* v = c ? std::strchr(c, '"') : nullptr;
-        // ("f32_fma" | "f32x8_fma" | "f32x16_fma": the same lanes accumulated with a fused multiply-add)
-        if (v && std::strncmp(v, "\"f32x16_fma\"", 12) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
-        else if (v && std::strncmp(v, "\"f32x8_fma\"", 11) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X8 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
-        else if (v && std::strncmp(v, "\"f32_fma\"", 9) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32 | YAMS_SCAN_FLAG_L2_ACC_FUSED;
-        else if (v && std::strncmp(v, "\"f32x16\"", 8) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X16;
-        else if (v && std::strncmp(v, "\"f32x8\"", 7) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32X8;
-        else if (v && std::strncmp(v, "\"f32\"", 5) == 0) g.l2_acc = YAMS_SCAN_FLAG_L2_ACC_F32;
-    }
     auto failed = [&](const char* why) {
         g.init_error = why;
+        for (char& ch : g.init_error) if (ch == '"' || ch == '\\') ch = '\'';   // (the health JSON quotes it as is)
         teardown_locked();
         return YAMS_PLUGIN_ERR_INIT_FAILED; // the host keeps its built-in CPU backends
     };
+    Config cfg(config_json);
+    if (!cfg.error.empty()) return failed(("configuration: " + cfg.error).c_str());
+    long v_device = 0, slots = 2, sr = 65536, ex_timeout = 0;
+    int shadows = 0, l2 = 0, collective = 0, fence = 0;
+    std::string library; bool has_library = false;
+    const bool cfg_ok =
+        cfg.get_int("device", 0, v_device) && cfg.get_int("search_slots", 2, slots) && cfg.get_int("stripe_rows", 65536, sr) &&
+        cfg.get_int("exchange_timeout_ms", 0, ex_timeout) &&
+        cfg.get_choice("shadows", {"both", "bf16", "i8", "none"}, 0, shadows) &&
+        // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header;
+        // "..._fma": the same lanes accumulated with ONE fused multiply-add per element, what '-mavx', '-mfma' builds do)
+        cfg.get_choice("l2_accumulate", {"f64", "f32", "f32x8", "f32x16", "f32_fma", "f32x8_fma", "f32x16_fma"}, 0, l2) &&
+        cfg.get_choice("collective", {"auto", "rccl", "peer"}, 0, collective) &&
+        cfg.get_choice("fence", {"auto", "on", "off"}, 0, fence) &&
+        cfg.get_string("rccl_library", library, has_library);
+    if (!cfg_ok) return failed(("configuration: " + cfg.error).c_str());
+    g.devices.clear();
+    if (cfg.has("devices")) {
+        const auto it = cfg.int_lists.find("devices");
+        if (it == cfg.int_lists.end() || it->second.empty()) return failed("configuration: \"devices\" must be a non-empty array of integers");
+        for (long d : it->second) g.devices.push_back(static_cast<int>(d));
+    } else g.devices.push_back(static_cast<int>(v_device));
+    slots = std::max<long>(1, std::min<long>(16, slots));
+    kStripeRows = static_cast<uint32_t>(std::max<long>(64, std::min<long>(1 << 24, sr)) / 64 * 64);
+    g.want_bf16 = shadows == 0 || shadows == 1;
+    g.want_i8 = shadows == 0 || shadows == 2;
+    static const uint32_t kL2Acc[7] = {YAMS_SCAN_FLAG_L2_ACC_F64, YAMS_SCAN_FLAG_L2_ACC_F32, YAMS_SCAN_FLAG_L2_ACC_F32X8, YAMS_SCAN_FLAG_L2_ACC_F32X16,
+                                       YAMS_SCAN_FLAG_L2_ACC_F32 | YAMS_SCAN_FLAG_L2_ACC_FUSED, YAMS_SCAN_FLAG_L2_ACC_F32X8 | YAMS_SCAN_FLAG_L2_ACC_FUSED,
+                                       YAMS_SCAN_FLAG_L2_ACC_F32X16 | YAMS_SCAN_FLAG_L2_ACC_FUSED};
+    g.l2_acc = kL2Acc[l2];
+    g.append_bytes = 0; g.appends = 0; g.exhausted_appends = 0; g.append_map_ms = 0; g.append_copy_ms = 0; g.append_shadow_ms = 0;
+    g.slow_append_ms = 0; g.slow_map_ms = 0; g.slow_copy_ms = 0; g.slow_shadow_ms = 0; g.slow_append_bytes = 0;
     for (size_t i = 0; i < g.devices.size(); ++i) {
         yams_accel_ctx* c = nullptr;
         const yams_status_t s = yams_accel_ctx_create(g.devices[i], nullptr, &c);
@@ -1119,24 +1231,14 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
     {
         yams_scan_sharded_options_t so{};
         so.struct_size = sizeof so; so.lanes = static_cast<uint32_t>(slots); so.collective = YAMS_SHARDED_COLLECTIVE_AUTO;
-        if (config_json && std::strstr(config_json, "\"collective\"")) { // "collective": "rccl" (require it) | "peer" | "auto"
-            const char* p = std::strstr(config_json, "\"collective\"");
-            if (std::strstr(p, "\"rccl\"")) so.collective = YAMS_SHARDED_COLLECTIVE_RCCL;
-            else if (std::strstr(p, "\"peer\"")) so.collective = YAMS_SHARDED_COLLECTIVE_PEER;
-        }
-        // "rccl_library": "<path>" — the collective library to bind instead of librccl.so.1 (a site build; the test
-        // suite's stand-in, with which several shards may share a device); "fence": "off" lifts the exchange fence
-        std::string library;
-        if (const char* p = config_json ? std::strstr(config_json, "\"rccl_library\"") : nullptr) {
-            p = std::strchr(p + 14, ':');
-            if (p && (p = std::strchr(p, '"'))) { const char* e = std::strchr(p + 1, '"'); if (e) library.assign(p + 1, e); }
-        }
-        if (!library.empty()) so.rccl_library = library.c_str();
-        // "exchange_timeout_ms": deadline of a sharded batch (default 30000; a batch that misses it fails with
-        // YAMS_ERR_TIMEOUT and the sharded handle is stuck until the plugin is shut down and initialised again)
-        so.exchange_timeout_ms = static_cast<uint32_t>(std::max<long>(0, json_int(config_json, "\"exchange_timeout_ms\"", 0)));
-        if (const char* p = config_json ? std::strstr(config_json, "\"fence\"") : nullptr)
-            if (const char* c = std::strchr(p + 7, ':')) { while (*++c == ' ') {} if (std::strncmp(c, "\"off\"", 5) == 0) so.fence = YAMS_SHARDED_FENCE_OFF; }
+        // "collective": "rccl" (require it) | "peer" | "auto"; "rccl_library": "<path>" — the collective library to bind instead of
+        // librccl.so.1 (a site build; the test suite's stand-in, with which several shards may share a device); "fence": "off"
+        // lifts the exchange fence; "exchange_timeout_ms": deadline of a sharded batch (default 30000; a batch that misses it
+        // fails with YAMS_ERR_TIMEOUT and the sharded handle is stuck until the plugin is shut down and initialised again)
+        so.collective = collective == 1 ? YAMS_SHARDED_COLLECTIVE_RCCL : (collective == 2 ? YAMS_SHARDED_COLLECTIVE_PEER : YAMS_SHARDED_COLLECTIVE_AUTO);
+        if (has_library && !library.empty()) so.rccl_library = library.c_str();
+        so.exchange_timeout_ms = static_cast<uint32_t>(std::max<long>(0, ex_timeout));
+        if (fence == 2) so.fence = YAMS_SHARDED_FENCE_OFF;
         if (yams_scan_sharded_create_ex(g.devices.data(), static_cast<uint32_t>(g.devices.size()), &so, &g.sharded) != YAMS_OK)
             return failed("sharded search handle creation failed");
         g.search_slots = static_cast<uint32_t>(slots);

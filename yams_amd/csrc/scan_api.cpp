@@ -235,6 +235,15 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     if (corpus->stripe_rows && (corpus->n_stripes == 0 || corpus->stripe_index >= corpus->n_stripes))
         return fail(ctx, YAMS_ERR_INVALID_ARG, "striped shard needs stripe_index < n_stripes");
     (void)hipSetDevice(ctx->device);
+    // L2 (vec0) ties: the reference's statement is `ORDER BY distance` alone (:4473) and SQLite's sorter keeps rows of equal
+    // distance in the order the vec0 table handed them over — rowid order, i.e. the order of this mirror — whatever their
+    // chunk ids (pinned by the reference's own vec0SearchUnlocked compiled over SQLite: tests/test_scan_ref_l2_pin.py).  The
+    // chunk_id ranking belongs to the cosine comparator (:4218-4223) only.
+    yams_scan_corpus_t l2_view;
+    if (params->metric == YAMS_SCAN_L2 && corpus->tie_rank) {
+        l2_view = *corpus; l2_view.tie_rank = nullptr; l2_view.rank_row = nullptr;
+        corpus = &l2_view;
+    }
     if (!split_only && small_scan_applies(*corpus, n_queries, *params))
         return small_scan(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts, out_dist, out_ranks, diag);
 
@@ -249,19 +258,27 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     YA_TRY(ws_get(ctx, "qprep", static_cast<size_t>(nq) * dim * 4, (void**)&d_qprep));
     YA_TRY(ws_get(ctx, "qnorm", static_cast<size_t>(nq) * 8, (void**)&d_qnorm));
     YA_TRY(ws_get(ctx, "qnorm_up", static_cast<size_t>(nq) * 4, (void**)&d_qnorm_up));
-    YA_TRY(ws_get(ctx, "qflags", static_cast<size_t>(nq) * 4, (void**)&d_qflags));
-    YA_TRY(ws_get(ctx, "status", static_cast<size_t>(nq) * 4, (void**)&d_status));
-    YA_TRY(ws_get(ctx, "stat", 64, (void**)&d_stat));
-    YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
-    YA_HIP(ctx, hipMemsetAsync(d_status, 0, static_cast<size_t>(nq) * 4, st));
-    YA_HIP(ctx, launch_prep_queries(st, queries, nq, dim, metric, d_qprep, d_qnorm, d_qnorm_up, d_qflags));
+    // The batch's small state words live in ONE block — [query flags nq | counters 16 | status nq | list counts nq]: everything
+    // behind the flags starts at zero, and prep_queries (the first launch of every batch, which writes the flags) clears it —
+    // three fills were three launches of their own; the host reads the whole block back with one copy where it read three.
+    constexpr size_t kStatWords = 16;
+    uint32_t* d_qstate; uint32_t* d_lcount;
+    const size_t nq_al = (static_cast<size_t>(nq) + 3) & ~static_cast<size_t>(3); // (the 64-bit counters stay 16-byte aligned)
+    const size_t qstate_words = 3 * nq_al + kStatWords;
+    YA_TRY(ws_get(ctx, "qstate", qstate_words * 4, (void**)&d_qstate));
+    d_qflags = d_qstate;
+    d_stat = reinterpret_cast<unsigned long long*>(d_qstate + nq_al);
+    d_status = d_qstate + nq_al + kStatWords;
+    d_lcount = d_status + nq_al;
+    YA_HIP(ctx, launch_prep_queries(st, queries, nq, dim, metric, d_qprep, d_qnorm, d_qnorm_up, d_qflags,
+                                    d_qstate + nq_al, static_cast<uint32_t>(qstate_words - nq_al)));
 
     uint32_t* h_pin;
-    YA_TRY(pinned_get(ctx, static_cast<size_t>(nq) * 4 * 4 + 128, (void**)&h_pin));
-    uint32_t* h_flags = h_pin;
-    uint32_t* h_status = h_pin + nq;
-    uint32_t* h_lcount = h_pin + 2 * static_cast<size_t>(nq);
-    float* h_qnup = reinterpret_cast<float*>(h_pin + 3 * static_cast<size_t>(nq));
+    YA_TRY(pinned_get(ctx, (nq_al * 4 + kStatWords) * 4 + 128, (void**)&h_pin));
+    uint32_t* h_flags = h_pin;                                   // (the first three mirror the device block)
+    uint32_t* h_status = h_pin + nq_al + kStatWords;
+    uint32_t* h_lcount = h_status + nq_al;
+    float* h_qnup = reinterpret_cast<float*>(h_lcount + nq_al);
 
     const bool aligned = (reinterpret_cast<uintptr_t>(corpus->rows) & 15u) == 0 && (dim & 3u) == 0;
     // rows that take part in the scan: all of them, or the set bits of the allow-mask
@@ -281,7 +298,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
                               (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                               !(params->flags & (YAMS_SCAN_FLAG_NO_I8_FILTER | YAMS_SCAN_FLAG_F32_FILTER | YAMS_SCAN_FLAG_SPLIT_FILTER)) &&
                               !split_only;
-    uint32_t* h_l2_stats = h_pin + 4 * static_cast<size_t>(nq) + 8;
+    uint32_t* h_l2_stats = h_pin + 4 * nq_al + kStatWords + 8;
     if (use_mfma && metric == YAMS_SCAN_L2) {
         // The L2 filter works on raw magnitudes; queries far outside the fp32 comfort zone take
         // the fp64 path (needs the norms on the host: one small sync).
@@ -320,7 +337,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "mask_rows", static_cast<size_t>(corpus->n_rows) * 4, (void**)&d_sel));
             YA_TRY(ws_get(ctx, "mask_count", 64, (void**)&d_cnt));
             YA_HIP(ctx, launch_compact_mask(st, corpus->row_mask, corpus->n_rows, d_sel, d_cnt));
-            unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_pin + 4 * static_cast<size_t>(nq));
+            unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_pin + 4 * nq_al + kStatWords);
             YA_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
             YA_HIP(ctx, hipStreamSynchronize(st));
             n_sel = *h_cnt;
@@ -408,7 +425,6 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "q_meta", static_cast<size_t>(q_pad) * 16, (void**)&d_qmeta));
             float* d_qthr;
             YA_TRY(ws_get(ctx, "q_thr", static_cast<size_t>(q_pad) * 8, (void**)&d_qthr));
-            YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, q_pad, dim, d_qi8, d_qmeta, L.i8_l2));
             L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_thr = d_qthr; L.q_pad = q_pad; L.sample_layout = 1;
             if (L.i8_l2) { // the per-batch tables of the L2 threshold: built after the sample pass (below)
                 const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
@@ -426,12 +442,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, bf16_slab_k(passes, dim), d_qhi, d_qlo));
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
-        float* d_tau; uint32_t* d_lcount; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
+        float* d_tau; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
         if (i8) L.dense = nullptr; // (the int8 sample pass keeps group maxima only, launch_i8_collect_sample)
         else YA_TRY(ws_get(ctx, "dense", static_cast<size_t>(nq) * plan.sample_rows * 4, (void**)&L.dense));
         YA_TRY(ws_get(ctx, "gmax", static_cast<size_t>(nq) * plan.n_groups * 4, (void**)&L.gmax));
         YA_TRY(ws_get(ctx, "tau", static_cast<size_t>(nq) * 4, (void**)&d_tau));
-        YA_TRY(ws_get(ctx, "lcount", static_cast<size_t>(nq) * 4, (void**)&d_lcount));
         YA_TRY(ws_get(ctx, "list", static_cast<size_t>(nq) * plan.list_cap * 8, (void**)&d_list));
         const uint32_t gchunks = (plan.n_groups + kSelectCap - 1) / kSelectCap;
         YA_TRY(ws_get(ctx, "work32", static_cast<size_t>(2) * nq * std::max(1u, gchunks) * plan.tau_rank * 4, (void**)&d_work32));
@@ -439,7 +454,6 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         const uint32_t keep_max = kRescoreMax + 1;
         YA_TRY(ws_get(ctx, "work64", static_cast<size_t>(2) * nq * lchunks * keep_max * 8, (void**)&d_work64));
         L.tau = d_tau; L.tau_out = d_tau; L.list_count = d_lcount; L.list = d_list;
-        YA_HIP(ctx, hipMemsetAsync(d_lcount, 0, static_cast<size_t>(nq) * 4, st));
         uint32_t* d_qover = nullptr;
         if (i8) { // the int8 filter writes its survivors to a log (scan_i8_kernel.hip), one region per (workgroup, wave)
             L.i8_q_form = i8_takes_q_form(L, bf16_version);
@@ -454,7 +468,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             const size_t z_cnt = (static_cast<size_t>(regions) * 4 + 255) & ~size_t(255), z_over = (static_cast<size_t>(nq) * 4 + 255) & ~size_t(255);
             unsigned char* zeroed;
             YA_TRY(ws_get(ctx, "i8_zeroed", z_cnt + z_over + static_cast<size_t>(sync_words) * 4, (void**)&zeroed));
-            YA_HIP(ctx, hipMemsetAsync(zeroed, 0, z_cnt + z_over + static_cast<size_t>(sync_words) * 4, st));
+            // (cleared by the query preparation of the int8 tier: one launch where there were a fill and a launch)
+            YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, L.q_pad, dim, const_cast<int8_t*>(L.q_i8), const_cast<float*>(L.q_meta), L.i8_l2,
+                                       reinterpret_cast<uint32_t*>(zeroed), (z_cnt + z_over) / 4 + sync_words));
             L.log_cnt = reinterpret_cast<uint32_t*>(zeroed);
             d_qover = reinterpret_cast<uint32_t*>(zeroed + z_cnt);
             L.q_over = d_qover;
@@ -539,9 +555,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_EMU_KPRIME")) kprime1 = std::min<uint32_t>(plan.kprime, std::max<uint32_t>(k, static_cast<uint32_t>(std::atoi(kv)))); // (a tighter bound would re-score this many)
 #endif
         YA_TRY(rescore_stage(nq, nullptr, kprime1));
-        YA_HIP(ctx, hipMemcpyAsync(h_flags, d_qflags, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
-        YA_HIP(ctx, hipMemcpyAsync(h_status, d_status, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
-        YA_HIP(ctx, hipMemcpyAsync(h_lcount, d_lcount, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, st));
+        YA_HIP(ctx, hipMemcpyAsync(h_pin, d_qstate, qstate_words * 4, hipMemcpyDeviceToHost, st)); // flags, status, list counts
         YA_HIP(ctx, hipStreamSynchronize(st));
 #ifdef YAMS_ACCEL_MEASURE
         if (const char* dump = std::getenv("YAMS_ACCEL_DUMP_LCOUNT")) // per-query candidate counts of the filter pass

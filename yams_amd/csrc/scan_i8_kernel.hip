@@ -1406,8 +1406,10 @@ __global__ __launch_bounds__(256) void i8_meta_stats_kernel(const float* meta, u
 // fp64 -> fp32 rounding of the exact similarity).  Padding queries are zero with t_q = 1.
 // raw (L2 batches): the queries are not unit vectors, the absolute slop scales with their norm.
 __global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                                                      int8_t* q_i8, float* q_meta, int raw) {
+                                                      int8_t* q_i8, float* q_meta, int raw, uint32_t* zero_words, uint32_t n_zero_words) {
     const uint32_t q = blockIdx.x;
+    // the filter launch's zero-initialised tables (log region counts, overflow marks, strip counters: scan_api.cpp "i8_zeroed")
+    for (uint32_t i = q * 256u + threadIdx.x; i < n_zero_words; i += gridDim.x * 256u) zero_words[i] = 0u;
     __shared__ float red[256];
     const bool live = q < nq;
     const float* src = qprep + static_cast<uint64_t>(q) * dim;
@@ -1671,9 +1673,11 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
 }
 
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta, bool raw_queries) {
+                          int8_t* q_i8, float* q_meta, bool raw_queries, uint32_t* zero_words, uint64_t n_zero_words) {
     if (q_pad == 0) return hipSuccess;
-    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta, raw_queries ? 1 : 0);
+    if (n_zero_words >> 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta, raw_queries ? 1 : 0,
+                       zero_words, zero_words ? static_cast<uint32_t>(n_zero_words) : 0u);
     return hipGetLastError();
 }
 

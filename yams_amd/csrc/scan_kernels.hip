@@ -283,8 +283,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_tiles_kernel(ScanArgs a)
 // -------------------------------------------------------------------------------------------------
 __global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t dim, int metric,
                                     float* qprep, double* qnorm, float* qnorm_up,
-                                    uint32_t* qflags, int staged) {
+                                    uint32_t* qflags, int staged, uint32_t* zero_words, uint32_t n_zero_words) {
     const uint32_t qi = blockIdx.x;
+    // the batch's state words (counters, status, list counts: scan_api.cpp "qstate") start at zero
+    for (uint32_t i = qi * blockDim.x + threadIdx.x; i < n_zero_words; i += gridDim.x * blockDim.x) zero_words[i] = 0u;
     __shared__ double s_norm;
     __shared__ uint32_t s_flag;
     extern __shared__ float s_stage[]; // dim floats when the launch provides them (staged != 0)
@@ -365,12 +367,99 @@ __device__ __forceinline__ void bitonic_desc(K* s, int m = CAP) {
     }
 }
 
+// The same network with the keys in REGISTERS (blocked layout: thread t holds elements [t E, t E + E) of M = 256 E): a
+// compare-exchange at distance j < E stays inside a thread, one at E <= j < 64 E is a lane exchange inside a wave
+// (ds_bpermute, no barrier), and only j >= 64 E — three passes of the 55 of a 1024-key sort, three of the 78 of a 4096-key
+// one — goes through LDS and a workgroup barrier.  The LDS form above paid a barrier and an LDS round trip for EVERY pass
+// with one workgroup of four waves on a CU: 47 us for the 256 lists of a BASELINE config 2 batch (~1000 keys each), 0.11 ms
+// of every headline step.  Element e keeps the larger key of (e, e ^ j) iff ((e & j) == 0) == ((e & k) == 0).
+template <typename K, int E, int J>
+__device__ __forceinline__ void bitonic_regs_inthread(K (&v)[E], int base, int k) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (i & J) continue;
+        const K a = v[i], b = v[i | J];
+        const bool up = ((base + i) & k) == 0;
+        const K hi = a > b ? a : b, lo = a > b ? b : a;
+        v[i] = up ? hi : lo;
+        v[i | J] = up ? lo : hi;
+    }
+}
+template <typename K>
+__device__ __forceinline__ K lane_xor(K x, int m) {
+    if constexpr (sizeof(K) == 8) {
+        const uint32_t lo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(x)), m));
+        const uint32_t hi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(static_cast<uint64_t>(x) >> 32)), m));
+        return static_cast<K>((static_cast<uint64_t>(hi) << 32) | lo);
+    } else {
+        return static_cast<K>(__shfl_xor(static_cast<int>(x), m));
+    }
+}
+// v: this thread's E keys; xch: LDS, 256 E keys (slot-major: [i][thread], conflict-free for the exchange)
+template <typename K, int E>
+__device__ __forceinline__ void bitonic_desc_regs(K (&v)[E], K* xch) {
+    constexpr int M = 256 * E;
+    const int t = threadIdx.x, base = t * E;
+#pragma unroll 1
+    for (int k = 2; k <= M; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * E) {          // another wave's keys: through LDS
+                const int pt = t ^ (j / E);
+#pragma unroll
+                for (int i = 0; i < E; ++i) xch[i * 256 + t] = v[i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const K y = xch[i * 256 + pt];
+                    const int e = base + i;
+                    const bool keep_max = ((e & j) == 0) == ((e & k) == 0);
+                    v[i] = (keep_max == (v[i] > y)) ? v[i] : y;
+                }
+                __syncthreads();
+            } else if (j >= E) {        // another lane of this wave
+                const int lm = j / E;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const K y = lane_xor<K>(v[i], lm);
+                    const int e = base + i;
+                    const bool keep_max = ((e & j) == 0) == ((e & k) == 0);
+                    v[i] = (keep_max == (v[i] > y)) ? v[i] : y;
+                }
+            } else {                    // this thread's own keys (j a compile-time constant per branch: no dynamic register index)
+                if (E > 1 && j == 1) bitonic_regs_inthread<K, E, 1>(v, base, k);
+                else if (E > 2 && j == 2) bitonic_regs_inthread<K, E, 2>(v, base, k);
+                else if (E > 4 && j == 4) bitonic_regs_inthread<K, E, 4>(v, base, k);
+                else if (E > 8 && j == 8) bitonic_regs_inthread<K, E, 8>(v, base, k);
+            }
+        }
+    }
+}
+template <typename K, int E>
+__device__ __forceinline__ void topk_block_sorted(const K* src, uint64_t c0, uint64_t n, K* dst, uint32_t keep, K* xch) {
+    K v[E];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {       // (which key starts where does not matter to a sort: coalesced loads)
+        const uint64_t e = c0 + static_cast<uint64_t>(i) * 256 + t;
+        v[i] = (e < n) ? src[e] : K(0);
+    }
+    bitonic_desc_regs<K, E>(v, xch);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const uint32_t e = static_cast<uint32_t>(t * E + i);
+        if (e < keep) dst[e] = v[i];
+    }
+    for (uint32_t i = 256u * E + t; i < keep; i += 256) dst[i] = K(0); // (keep beyond what was sorted: 0-padded)
+}
+
 template <typename K, int CAP>
 __global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint32_t* in_counts,
                                                          uint64_t in_stride, uint32_t n_fixed,
                                                          uint32_t count_clip, K* out,
                                                          uint64_t out_stride, uint32_t keep,
                                                          const uint32_t* qmap) {
+    static_assert(CAP == 4096, "the register forms below cover 256 .. 4096 keys");
     __shared__ K s[CAP];
     const uint32_t qslot = blockIdx.y;
     const uint32_t q = qmap ? qmap[qslot] : qslot;
@@ -385,15 +474,12 @@ __global__ __launch_bounds__(256) void topk_block_kernel(const K* in, const uint
     }
     // only the occupied part of the chunk is sorted (keys are non-zero, the 0 padding sorts last)
     const uint64_t left = n - c0;
-    int m = 2;
-    while (m < CAP && static_cast<uint64_t>(m) < left) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 256) {
-        const uint64_t e = c0 + i;
-        s[i] = (e < n) ? src[e] : K(0);
-    }
-    __syncthreads();
-    bitonic_desc<K, CAP, 256>(s, m);
-    for (uint32_t i = threadIdx.x; i < keep; i += 256) dst[i] = (i < static_cast<uint32_t>(m)) ? s[i] : K(0);
+    const uint64_t end = left < static_cast<uint64_t>(CAP) ? n : c0 + CAP;
+    if (left <= 256) topk_block_sorted<K, 1>(src, c0, end, dst, keep, s);
+    else if (left <= 512) topk_block_sorted<K, 2>(src, c0, end, dst, keep, s);
+    else if (left <= 1024) topk_block_sorted<K, 4>(src, c0, end, dst, keep, s);
+    else if (left <= 2048) topk_block_sorted<K, 8>(src, c0, end, dst, keep, s);
+    else topk_block_sorted<K, 16>(src, c0, end, dst, keep, s);
 }
 
 // tau[q] = score of the rank-th best group maximum (or -inf when there are fewer groups).  One workgroup per query.
@@ -1198,10 +1284,10 @@ namespace yams_accel {
 
 hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
-                               uint32_t* qflags) {
+                               uint32_t* qflags, uint32_t* zero_words, uint32_t n_zero_words) {
     const bool staged = static_cast<size_t>(dim) * 4 <= 48 * 1024;
     hipLaunchKernelGGL(prep_queries_kernel, dim3(nq), dim3(128), staged ? static_cast<size_t>(dim) * 4 : 0, st, q,
-                       nq, dim, metric, qprep, qnorm, qnorm_up, qflags, staged ? 1 : 0);
+                       nq, dim, metric, qprep, qnorm, qnorm_up, qflags, staged ? 1 : 0, zero_words, zero_words ? n_zero_words : 0u);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1481,6 +1567,9 @@ hipError_t launch_merge(hipStream_t st, const MergeLaunch& M) {
     a.st_counts = M.st_counts ? M.st_counts : M.n_queries; a.st_dist = M.st_dist ? M.st_dist : dense;
     a.st_ranks = M.st_ranks ? M.st_ranks : dense;
     a.rank_of_row = M.rank_of_row; a.rank_row_base = M.rank_row_base;
+    // L2 (vec0): equal distances come back in rowid order (`ORDER BY distance` alone, :4473) — the chunk_id ranking belongs
+    // to the cosine comparator only (scan_api.cpp scan_impl; tests/test_scan_ref_l2_pin.py)
+    if (M.metric == YAMS_SCAN_L2) { a.in_ranks = nullptr; a.rank_of_row = nullptr; }
     a.out_scores = M.out_scores; a.out_rows = M.out_rows; a.out_counts = M.out_counts;
     a.out_dist = M.out_dist;
     uint32_t cap = 1;

@@ -89,7 +89,7 @@ constexpr uint32_t kRescoreMax = 2047; // + 1 boundary key == kSelectCap / 2 (se
 
 hipError_t launch_prep_queries(hipStream_t st, const float* q, uint32_t nq, uint32_t dim,
                                int metric, float* qprep, double* qnorm, float* qnorm_up,
-                               uint32_t* qflags);
+                               uint32_t* qflags, uint32_t* zero_words = nullptr, uint32_t n_zero_words = 0);
 hipError_t launch_prep_split(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
                              uint32_t slab_k, uint16_t* q_hi, uint16_t* q_lo);
 // k-extent of one LDS stage of the bf16 filter kernels (= the slab size of the query planes):
@@ -100,7 +100,8 @@ hipError_t launch_scan_bf16(hipStream_t st, const ScanLaunch& L, int metric, int
 hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int version);
 // Quantises the prepared (unit) queries of a batch: k-slab-major int8 plane + {t_q, c_q, f_q} per query.
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta, bool raw_queries = false);
+                          int8_t* q_i8, float* q_meta, bool raw_queries = false, uint32_t* zero_words = nullptr,
+                          uint64_t n_zero_words = 0);
 // L2 on the int8 tier.  Per batch and shard: (1) norm statistics of the shard — per 64-row block the smallest row norm,
 // shard-wide the norm range, the largest in-block spread in units of the block scale, and the rows whose squared
 // norm lies outside norm_in_range() (counted and listed: unconditional candidates); stats = 8 words, zeroed first.

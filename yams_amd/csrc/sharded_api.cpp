@@ -225,6 +225,9 @@ struct Lane {
     bool ex_timed = false;
     std::vector<char> reported;                             // per shard: its worker is through with the batch
     std::vector<ShardLane> sh;
+    // ONE deadline per batch, fixed at submit: the handle's exchange timeout + an allowance for the scan itself that grows
+    // with the work the batch asks for (a huge FORCE_EXACT batch is slow, not stuck).  Both phases of wait() look at it.
+    std::chrono::steady_clock::time_point deadline{};
 };
 
 size_t align16s(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
@@ -265,6 +268,9 @@ struct yams_scan_sharded {
     uint32_t timeout_ms = 30000;                 // the deadline of wait(); UINT32_MAX: none
     bool stuck = false;                          // a batch missed the deadline (under mu)
     std::string stuck_why;
+    // kRccl: a shard's communicator is used (exchange_shard) and aborted (declare_stuck) under its own mutex — an abort
+    // frees the communicator, and a worker of another lane may be inside ncclAllGather on it at that moment
+    std::vector<std::unique_ptr<std::mutex>> comm_mu;
 };
 
 namespace {
@@ -366,8 +372,16 @@ yams_status_t exchange_shard(yams_scan_sharded* s, Lane& L, uint32_t i, yams_sta
     if (i == 0) L.ex_timed = L.ex_begin && hipEventRecord(L.ex_begin, SL.side) == hipSuccess;
     try {
         if (s->mode == kRccl) {
-            const ncclResult_t r = s->R->AllGather(SL.rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
-            if (r != ncclSuccess) {
+            bool gone = false;
+            ncclResult_t r = ncclSuccess;
+            {
+                std::lock_guard<std::mutex> ck(*s->comm_mu[i]);
+                if (s->comm[i]) r = s->R->AllGather(SL.rec, SL.gathered, static_cast<size_t>(L.stride), ncclUint8, s->comm[i], SL.side);
+                else gone = true;   // the handle was declared stuck and its communicator aborted: no collective any more
+            }
+            if (gone) {
+                if (st == YAMS_OK) { err = "the communicator was aborted (the handle is stuck)"; st = YAMS_ERR_TIMEOUT; }
+            } else if (r != ncclSuccess) {
                 (void)hipGetLastError();
                 if (st == YAMS_OK) { err = std::string("ncclAllGather failed: ") + s->R->GetErrorString(r); st = YAMS_ERR_INTERNAL; }
             }
@@ -463,8 +477,10 @@ void declare_stuck(yams_scan_sharded* s, const std::string& why) {
     if (s->mode == kRccl && s->R && s->R->CommAbort) {
         int before = 0;
         (void)hipGetDevice(&before);
-        for (uint32_t i = 0; i < s->comm.size(); ++i)
+        for (uint32_t i = 0; i < s->comm.size(); ++i) {
+            std::lock_guard<std::mutex> ck(*s->comm_mu[i]); // (an AllGather call only ENQUEUES: the lock is held for microseconds)
             if (s->comm[i]) { (void)hipSetDevice(s->device[i]); (void)s->R->CommAbort(s->comm[i]); s->comm[i] = nullptr; }
+        }
         (void)hipSetDevice(before);
     }
 }
@@ -490,6 +506,23 @@ void destroy_handle(yams_scan_sharded* s) {
     s->cv_job.notify_all();
     for (auto& L : s->lanes)
         for (auto& SL : L->sh) if (SL.worker.joinable()) SL.worker.join();
+    if (s->stuck) {
+        // The workers have reported, but the DEVICES may still hang (peer-copy mode, or a collective library without
+        // ncclCommAbort: nothing took the spinning kernels off them).  Synchronising or freeing behind such a stream blocks
+        // for good: look first (a query, not a wait), and leak the handle's device resources when anything is incomplete.
+        bool quiet = true;
+        for (auto& L : s->lanes)
+            for (uint32_t i = 0; i < L->sh.size() && quiet; ++i) {
+                ShardLane& SL = L->sh[i];
+                (void)hipSetDevice(s->device[i]);
+                if (SL.side && hipStreamQuery(SL.side) != hipSuccess) { (void)hipGetLastError(); quiet = false; }
+                if (quiet && SL.ctx && SL.ctx->stream && hipStreamQuery(SL.ctx->stream) != hipSuccess) { (void)hipGetLastError(); quiet = false; }
+            }
+        if (!quiet) {
+            std::fprintf(stderr, "[yams_mi355x_accel] destroy of a stuck sharded handle: device work still pending, resources leaked\n");
+            return; // (buffers, streams, contexts stay: whatever hangs may still touch them)
+        }
+    }
     for (auto& L : s->lanes) {
         for (uint32_t i = 0; i < L->sh.size(); ++i) {
             ShardLane& SL = L->sh[i];
@@ -564,6 +597,8 @@ yams_status_t create_impl(const int* devices, uint32_t n_shards, const yams_scan
         if (!R.ok()) why = (library.empty() ? std::string("librccl.so.1") : library) + " could not be loaded: " + R.error;
         else {
             s->comm.assign(n_shards, nullptr);
+            s->comm_mu.clear();
+            for (uint32_t i = 0; i < n_shards; ++i) s->comm_mu.emplace_back(new std::mutex());
             const ncclResult_t r = R.CommInitAll(s->comm.data(), static_cast<int>(n_shards), s->device.data());
             if (r != ncclSuccess) { why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(r); s->comm.clear(); (void)hipGetLastError(); }
         }
@@ -640,6 +675,18 @@ bool grow_device(void** p, size_t* cap, size_t bytes, hipStream_t quiet) {
     if (ya_malloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
     *cap = want;
     return true;
+}
+
+// When must lane L's batch be through?  The exchange timeout of the handle, counted from submit, plus what the scan of the
+// largest shard may honestly take: (queries x rows x dim) at a tenth of the filter's measured rate (1e14 multiply-adds a
+// second), or at the exhaustive fp64 kernel's (2e11) when the caller asks for that path.
+std::chrono::steady_clock::time_point batch_deadline(const yams_scan_sharded* s, const Lane& L) {
+    double work = 0.0;
+    for (const yams_scan_corpus_t& v : L.views) work = std::max(work, static_cast<double>(v.n_rows) * L.nq * std::max<uint32_t>(L.dim, 1u));
+    const bool exhaustive = (L.prm.flags & YAMS_SCAN_FLAG_FORCE_EXACT) != 0;
+    const double allowance_ms = L.trivial ? 0.0 : work / (exhaustive ? 2.0e8 : 1.0e11);
+    const double total = static_cast<double>(s->timeout_ms) + std::min(allowance_ms, 3.6e6);
+    return std::chrono::steady_clock::now() + std::chrono::milliseconds(static_cast<int64_t>(total));
 }
 
 yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_corpus_t* shards, const float* queries_host,
@@ -725,6 +772,7 @@ yams_status_t submit_impl(yams_scan_sharded* s, uint32_t lane, const yams_scan_c
         std::lock_guard<std::mutex> lk(s->mu);
         L.submitted = true;
         L.ordered = false;
+        L.deadline = batch_deadline(s, L);
         if (!L.trivial) {
             L.pending = n;
             L.peer_left = n;
@@ -746,12 +794,12 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
         if (!L.acquired || !L.submitted) { s->last_error = "nothing was submitted on this lane"; return YAMS_ERR_INVALID_ARG; }
         auto through = [&] { return L.trivial || L.pending == 0; };
         if (s->timeout_ms == UINT32_MAX) s->cv_done.wait(lk, through);
-        else if (!s->cv_done.wait_for(lk, std::chrono::milliseconds(s->timeout_ms), through)) {
+        else if (!s->cv_done.wait_until(lk, L.deadline, through)) {
             // the lane stays acquired + submitted: its buffers are still in use by whatever hangs
             std::ostringstream os;
             os << "batch " << (L.ordered ? L.seq : 0) << " on lane " << lane << ": shard(s)";
             for (uint32_t i = 0; i < s->n; ++i) if (!L.reported[i]) os << ' ' << i << "(device " << s->device[i] << ")";
-            os << " not through scan + exchange after " << s->timeout_ms << " ms (collective "
+            os << " not through scan + exchange " << s->timeout_ms << " ms (+ the scan's allowance) after submit (collective "
                << (s->mode == kRccl ? "rccl" : (s->mode == kPeer ? "peer_copy" : "none")) << ", " << s->n << " ranks, "
                << s->collectives.load() << " exchanges issued before): a rank is missing from a collective, or a device hangs";
             lk.unlock();
@@ -787,8 +835,10 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
             // (a batch is through in milliseconds: the first 50 ms are polled without sleeping — what hipEventSynchronize
             //  does as well — so that the deadline costs the caller's turn-around nothing; only a wait that is already
             //  long sleeps between looks)
+            // (the batch's ONE deadline; a batch whose scans used most of their allowance still gets a quarter of the exchange
+            //  timeout for the exchange itself: the caller waits at most 1.25 x what submit promised, not 2 x)
             const auto t_wait = std::chrono::steady_clock::now();
-            const auto deadline = t_wait + std::chrono::milliseconds(s->timeout_ms);
+            const auto deadline = std::max(L.deadline, t_wait + std::chrono::milliseconds(s->timeout_ms / 4 + 1));
             const auto spin_until = t_wait + std::chrono::milliseconds(50);
             for (;;) {
                 const hipError_t e = hipEventQuery(L.done);
@@ -798,7 +848,7 @@ yams_status_t wait_impl(yams_scan_sharded* s, uint32_t lane, float* out_scores_h
                 if (now > deadline) {
                     std::ostringstream os;
                     os << "batch " << L.seq << " on lane " << lane << ": all-gather + merge not complete on the root shard (device "
-                       << s->device[0] << ") after " << s->timeout_ms << " ms (collective " << (s->mode == kRccl ? "rccl" : "peer_copy")
+                       << s->device[0] << ") by the batch's deadline (" << s->timeout_ms << " ms exchange timeout; collective " << (s->mode == kRccl ? "rccl" : "peer_copy")
                        << ", " << s->n << " ranks, " << s->exchanges_timed.load() << " exchanges completed before): a peer never "
                           "joined the collective, or the link is down";
                     rel.keep = true; // buffers still in use: the lane is not handed out again
