@@ -1124,7 +1124,7 @@ def config2_leg(a, torch, dev, local, lane_counts=None, batches=None, oracle_que
            "frac": byts / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if launch_ms else None,
            "algorithmic_bytes_per_launch": byts, "mfma_view_TOPs": ops / (launch_ms * 1e-3) / 1e12 if launch_ms else None,
            "step_frac_of_hbm_floor": (byts / PEAK_HBM_GBPS / 1e9) / dt,
-           "kernel": "scan_tiles_i8r_kernel (two 128-query tiles per row stream, 128 streams)" if i8 else "bf16 tier",
+           "kernel": "scan_tiles_i8d_kernel (two 128-query tiles per row stream, 128 streams)" if i8 else "bf16 tier",
            "filter_tier": diag.get("filter_tier"), "filter_candidates": diag.get("filter_candidates"),
            "rescored_rows": diag.get("rescored_rows"), "widened_queries": diag.get("widened_queries"),
            "exact_fallback_queries": diag.get("exact_fallback_queries"), "lane_sweep": sweep}
@@ -1183,7 +1183,7 @@ def c_abi_main(a):
                       "parallelism": f"row-shard x{a.gpus}, ONE process through the C ABI (yams_scan_sharded_*): one all-gather + merge "
                                      "per batch, fenced in front of the shard's next sweep (DESIGN 4)", "search_lanes": a.lanes},
            "launcher": "single process (--via-c-abi)",
-           "roofline": {"bound": "mfma", "kernel": "scan_tiles_i8r_kernel (shard 0's lanes)", "achieved": ach, "peak": PEAK_I8_MFMA_TOPS,
+           "roofline": {"bound": "mfma", "kernel": "scan_tiles_i8d_kernel (shard 0's lanes)", "achieved": ach, "peak": PEAK_I8_MFMA_TOPS,
                         "unit": "TOP/s", "frac": ach / PEAK_I8_MFMA_TOPS if ach else None, "launch_ms": r["filter_launch_ms_shard0"],
                         "traffic": None},
            "c_abi_sharded": r,
@@ -1219,7 +1219,7 @@ def hbm_leg_traffic(n, d, nq, i8):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_small_batch_pmc.json")), reverse=True):
         try:
             j = json.load(open(f))
-            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq and ("i8r" in j.get("kernel", "")) == bool(i8):
+            if j.get("rows_per_gpu") == n and j.get("dim") == d and j.get("queries") == nq and (("i8r" in j.get("kernel", "")) or ("i8d" in j.get("kernel", ""))) == bool(i8):
                 return j.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(f)} (builder run: rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
                                                        "correction; NOT measured in this run)")
         except Exception:
@@ -1572,7 +1572,7 @@ def main():
         i8_64 = d64.get("filter_tier") == 1
         if i8_64:      # the int8 shadow, streamed once by the resident-query kernel (one query tile: every workgroup has its own row stream)
             byts = filt_rows * d + (filt_rows // 64) * 8 + q64 * d
-            k64 = "scan_tiles_i8r_kernel (int8 shadow, one 128-query tile resident per CU, 256 row streams)"
+            k64 = ("scan_tiles_i8d_kernel" if d in (384, 768) else "scan_tiles_i8r_kernel") + " (int8 shadow, one 128-query tile resident per CU, 256 row streams)"
         else:
             byts = filt_rows * d * 2 + filt_rows * 4 + q64 * d * 2
             k64 = "scan_tiles_bf16n_kernel<FILTER,COSINE,2> (narrow form over the bf16 shadow, Q <= 64)"
@@ -1793,7 +1793,11 @@ def main():
         n_filter_tiles = n_tiles - n_sample
         resident = (not a.half_tile and d % 128 == 0 and 384 <= d <= 768 and 2 <= n_qt <= 8 and (32 // n_qt) * n_qt * 10 >= 32 * 9
                     and (n_filter_tiles + 1) // 2 >= 12 * n_streams)
-        if resident:
+        if resident and d in (384, 768):
+            kname = ("scan_tiles_i8d_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "
+                     "workgroup of eight waves per CU, two slabs of row fragments in flight per wave, "
+                     "strips drawn per SIMD pair, exact integer accumulate)")
+        elif resident:
             kname = ("scan_tiles_i8r_kernel (v_mfma_i32_16x16x64_i8 over the int8 shadow; 128-query tile resident in LDS, one persistent "
                      "workgroup of eight waves per CU, row fragments loaded straight into the register double buffer, "
                      "strips drawn per SIMD pair, exact integer accumulate)")

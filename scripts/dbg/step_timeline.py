@@ -3,7 +3,7 @@ two filter sweeps: per kernel name the mean duration and how much of it is NOT u
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void yams_accel::", "").replace("yams_accel::", "")) for r in rows), key=lambda e: e[0])
-sweeps = [e for e in ev if e[2].startswith("scan_tiles_i8r_kernel<0, false, true, 6")]
+sweeps = [e for e in ev if e[2].startswith(("scan_tiles_i8d_kernel", "scan_tiles_i8r_kernel<0, false, true, 70"))]
 sweeps = sweeps[len(sweeps) // 3:]          # steady state
 if len(sweeps) < 4: sys.exit("too few sweeps")
 t0, t1 = sweeps[0][0], sweeps[-1][1]
@@ -12,7 +12,7 @@ busy = sum(e - s for s, e, _ in sweeps) / 1e6
 print(f"{len(sweeps)} sweeps over {span:.2f} ms: {span / (len(sweeps)):.3f} ms per step (end to end / n), sweep {busy / len(sweeps):.3f} ms each, gaps {(span - busy) / (len(sweeps) - 1):.3f} ms")
 inside = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for s, e, n in ev:
-    if s < t0 or e > t1 or n.startswith("scan_tiles_i8r_kernel<0, false, true, 6"): continue
+    if s < t0 or e > t1 or n.startswith(("scan_tiles_i8d_kernel", "scan_tiles_i8r_kernel<0, false, true, 70")): continue
     under = 0
     for ss, se, _ in sweeps:
         lo, hi = max(s, ss), min(e, se)

@@ -3,7 +3,7 @@ a persistent sweep can only take a CU whole, so whatever sits on CUs at its star
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void yams_accel::", "").replace("yams_accel::", "")) for r in rows), key=lambda e: e[0])
-sweeps = [e for e in ev if e[2].startswith("scan_tiles_i8r_kernel<0, false, true, 6")]
+sweeps = [e for e in ev if e[2].startswith(("scan_tiles_i8d_kernel", "scan_tiles_i8r_kernel<0, false, true, 70"))]
 sweeps = sweeps[len(sweeps) // 3:]
 agg = collections.defaultdict(lambda: [0, 0.0])
 durs = []
@@ -11,7 +11,7 @@ for i, (ss, se, _) in enumerate(sweeps):
     durs.append((se - ss) / 1e3)
     tail = 0.0
     for s, e, n in ev:
-        if n.startswith("scan_tiles_i8r_kernel<0, false, true, 6"): continue
+        if n.startswith(("scan_tiles_i8d_kernel", "scan_tiles_i8r_kernel<0, false, true, 70")): continue
         if s < ss + 20_000 and e > ss:           # running at (or within 20 us after) the sweep's start
             agg[n][0] += 1; agg[n][1] += (e - max(s, ss)) / 1e3
             tail = max(tail, (e - ss) / 1e3)

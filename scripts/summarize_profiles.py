@@ -97,7 +97,7 @@ meta = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py
 json.dump({"meta": meta, "kernels": summary}, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(P, f"{tag}_pmc.json"))
 
-filt = ([k for k in summary if "scan_tiles_i8r_kernel<0, false, true, 6" in k] or     # the shipped sweep (NOT the sample pass <..., 0, true>)
+filt = ([k for k in summary if ("scan_tiles_i8d_kernel" in k or "scan_tiles_i8r_kernel<0, false, true, 70" in k)] or     # the shipped sweep (NOT the sample pass <..., 0, true>)
         [k for k in summary if "scan_tiles_i8r_kernel<0>" in k or ("scan_tiles_i8r_kernel<0, false" in k and not k.rstrip(">").endswith("true"))] or [k for k in summary if "scan_tiles_i8h_kernel<1" in k] or [k for k in summary if "scan_tiles_i8_kernel<1" in k] or [k for k in summary if "bf16p_kernel" in k] or [k for k in summary if "bf16s_kernel<1, 0" in k] or [k for k in summary if "bf16k32_kernel<1, 0" in k]
         or [k for k in summary if "bf16v2_kernel<1, 0" in k] or [k for k in summary if "scan_tiles_kernel<1, 0>" in k])
 if filt and "FETCH_SIZE" in summary[filt[0]]:

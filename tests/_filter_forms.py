@@ -15,6 +15,7 @@ from yams_amd._lib import SCAN_COSINE, FLAG_RESIDENT_QUERIES
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 out = []
 SHAPES = json.loads(os.environ["FORMS_SHAPES"]) if os.environ.get("FORMS_SHAPES") else None
+VERSIONS = os.environ.get("FORMS_VERSIONS", "2,70,80,81").split(",")   # the first one is the yardstick (the LDS-ring form)
 for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, False), (150_080, 384, 300, 50, 0.02, True),
                                    (90_000, 768, 130, 100, -1.0, True), (70_001, 384, 1024, 10, -1.0, False),
                                    (120_000, 512, 260, 20, -1.0, False)]:
@@ -32,7 +33,7 @@ for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, Fal
     view = acc.corpus_view(tc.data_ptr(), n, d, rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr(),
                            row_mask_ptr=mask.data_ptr() if mask is not None else None, row_mask_count=int(allow.sum()) if mask is not None else 0)
     res = {}
-    for v in ("2", "70", "80", "81"):
+    for v in VERSIONS:
         os.environ["YAMS_ACCEL_BF16_KERNEL"] = v
         os.environ["YAMS_ACCEL_I8R_DIRECT"] = "0" if v == "2" else "1"   # "2": the LDS-ring form whatever the launcher's rule says
         s = torch.empty((nq, k), dtype=torch.float32, device="cuda"); r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -49,10 +50,10 @@ for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, Fal
         res[v] = (r.cpu(), s.cpu(), c.cpu(), dg)
     rec = {"shape": [n, d, nq, k, thr, masked], "tier": res["2"][3].get("filter_tier"), "candidates": {v: res[v][3].get("filter_candidates") for v in res},
            "fallback": {v: res[v][3].get("exact_fallback_queries") for v in res}}
-    if os.environ.get("FORMS_DUMP"):
+    if os.environ.get("FORMS_DUMP") and "70" in res:
         a2, a7 = res["2"][3]["lcount"], res["70"][3]["lcount"]
         rec["lcount_diff"] = [(i, x, y) for i, (x, y) in enumerate(zip(a2, a7)) if x != y][:12]
-    for v in ("70", "80", "81"):
+    for v in VERSIONS[1:]:
         rec["identical_" + v] = bool(torch.equal(res[v][0], res["2"][0]) and torch.equal(res[v][1], res["2"][1]) and torch.equal(res[v][2], res["2"][2]))
     out.append(rec)
 print(json.dumps(out))

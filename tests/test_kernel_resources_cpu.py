@@ -99,3 +99,61 @@ def test_direct_row_loads_are_not_touched_while_in_flight():
                 for r in regs(toks[0]):
                     assert r not in inflight, (name, "writes in-flight v%d" % r, t, inflight[r])
         assert loads >= 12, (name, loads)       # prologue + two slabs of the loop body, four fragments each
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_deep_form_row_loads_are_not_touched_while_in_flight():
+    """scan_tiles_i8d_kernel keeps TWO slabs of row fragments in flight per wave and waits for them with COUNTED waits
+    (`s_waitcnt vmcnt(4)`: the four loads of the slab one ahead may stay out).  Its vector-memory operations retire in
+    order, so a walk over the assembly with a FIFO of outstanding operations knows, at every instruction, which registers
+    still have a load due: nothing may read or write them — not a copy, not a spill, not a temporary the allocator parks
+    there (round 6: the flush after the last strip did exactly that and stored through an overwritten address; a bus error
+    on shards of 4M rows and more).  The kernel must not use scratch at all."""
+    kernels = {k: v for k, v in _kernels("scan_i8_kernel.hip").items() if "scan_tiles_i8d_kernel" in k}
+    assert len(kernels) == 1, list(kernels)
+
+    def regs(tok):
+        tok = tok.strip().split()[0] if tok.strip() else ""
+        m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return [int(m.group(1))] if m else []
+    for name, body in kernels.items():
+        assert not any("scratch_" in l for l in body), name
+        fifo, loads, counted = [], 0, 0
+        for line in body:
+            t = line.split(";")[0].strip()
+            if not t or t.startswith(".") or t.endswith(":"):
+                continue
+            ops = t.split(None, 1)
+            op = ops[0]
+            toks = ops[1].split(",") if len(ops) > 1 else []
+            busy = {r: txt for rs, txt in fifo for r in rs}
+            vm_load = op.startswith(("global_load", "global_atomic")) and not op.startswith("global_load_lds")
+            vm_other = op.startswith(("global_store", "global_load_lds", "buffer_", "flat_"))
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", t)
+                if m:
+                    keep = int(m.group(1))
+                    counted += keep == 4
+                    while len(fifo) > keep:
+                        fifo.pop(0)
+                continue
+            sources = toks if (vm_other or op.startswith(("ds_write", "global_atomic"))) else toks[1:]
+            for tok in sources:
+                for r in regs(tok):
+                    assert r not in busy, (name, "reads in-flight v%d" % r, t, busy[r])
+            if vm_load:
+                dst = regs(toks[0]) if not op.startswith("global_atomic") or len(toks) >= 4 else []
+                for r in dst:
+                    assert r not in busy, (name, "loads into in-flight v%d" % r, t, busy[r])
+                fifo.append((dst, t)); loads += op == "global_load_dwordx4"
+                continue
+            if vm_other:
+                fifo.append(([], t))
+                continue
+            if toks and not op.startswith("s_"):
+                for r in regs(toks[0]):
+                    assert r not in busy, (name, "writes in-flight v%d" % r, t, busy[r])
+        assert loads >= 8 + 12 and counted >= 4, (name, loads, counted)    # pipeline fill + three unrolled slabs; the counted waits are there

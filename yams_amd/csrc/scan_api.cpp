@@ -379,7 +379,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (const char* kv = std::getenv("YAMS_ACCEL_BF16_KERNEL")) bf16_version = std::atoi(kv);
         if (const char* pv = std::getenv("YAMS_ACCEL_BF16_PASSES"))
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
-        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 87))) i8 = false;
+        if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 99))) i8 = false;
 #endif
         ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2);
         ScanLaunch L;
@@ -520,7 +520,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
 #endif
 
 #ifdef YAMS_ACCEL_MEASURE
-        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 40 && bf16_version != 50 && bf16_version != 70 && bf16_version != 80 && !(bf16_version >= 81 && bf16_version <= 87)) { // ablated kernels produce no candidates: stop here
+        if (bf16_version != 2 && bf16_version != 3 && bf16_version != 4 && bf16_version != 20 && bf16_version != 30 && bf16_version != 40 && bf16_version != 50 && bf16_version != 70 && bf16_version != 80 && !(bf16_version >= 81 && bf16_version <= 99)) { // ablated kernels produce no candidates: stop here
             YA_HIP(ctx, hipStreamSynchronize(st));
             YA_HIP(ctx, hipMemsetAsync(out_counts, 0, static_cast<size_t>(nq) * 4, st));
             return YAMS_OK;

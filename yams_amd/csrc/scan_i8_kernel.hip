@@ -560,6 +560,16 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     static_assert(!(ZSM & 16) || ((ZSM & 1) && (ZSM & 4)), "no drain needs the thresholds and the survivors in LDS");
     constexpr bool Z0 = (ZSM & 1) != 0, ZT = (ZSM & 2) != 0, ZL = (ZSM & 4) != 0, ZN = (ZSM & 16) != 0;
     static_assert(!(ZT && Z0), "2 = the plain form with its threshold halves in LDS (1 has them there anyway)");
+    // Round 6 — the strip boundary again (it costs 8 % of the launch at dim 768 and 24 % at dim 384, and the partner wave of
+    // the SIMD does not hide it).  64 (EARLY): what the boundary does NOT need the memory for — the survivor emission, the next
+    // strip's thresholds and the accumulator set-up — runs BEFORE the drain of the vector-memory counter instead of behind it,
+    // i.e. under the latency of the next strip's first fragments (requested in the last slab) instead of after it: 7.25 ->
+    // 7.14 ms at dim 768, 4.05 -> 3.92 at dim 384 (12.5M rows, 1024 queries), 146 -> 142 us on BASELINE config 2, same
+    // candidate sets (profiles/r06_filter_forms.json).  Tried with it and dropped: setting only row block 0's accumulators
+    // to -T and letting the first slab's multiply-adds of the other row blocks take them as their C operand (32 moves for
+    // 128) — the second code path of the first slab cost four spills and 2 % of the launch.
+    constexpr bool EARLY = (ZSM & 64) != 0;
+    static_assert(!EARLY || (ZT && ZL && !Z0 && !ZN), "the early boundary builds on the plain form with its threshold halves and its survivors in LDS");
     // `window`: bits 0-15 the strips a pair may run ahead of its slowest sibling, bits 16-23 log2 of the pacing interval —
     // the siblings' counters are looked at when (strip number & mask) == 0 only: each look is a system-scope load whose
     // latency the strip boundary pays (every strip: 7.43 / 4.61 ms at dim 768 / 384; every eighth: 7.35 / 4.18)
@@ -860,6 +870,9 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #endif
 
     constexpr bool THR = (ABL == 0 || ABL == 8 || ABL == 9) && !SAMPLE;
+    uint32_t q_live = 0; // bit cb: this lane's query of block cb exists (q0 + 16 cb + l15 < n_queries)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) q_live |= (q0 + static_cast<uint32_t>(cb * 16 + l15) < a.n_queries) ? 1u << cb : 0u;
     int nt[8]; // -T(this strip, query block cb): what the accumulators of the unit start at
     auto thresholds = [&]() __attribute__((always_inline)) {
         const float is = 1.0f / sb, g = eb * is; // (the same expressions as in i8_log_gather_kernel)
@@ -890,6 +903,18 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the k loop's waits count loads only)
     };
 
+    // what a strip's accumulators start at: -T(strip, query block) (L2: - a_r m_q per element)
+    auto acc_init = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[rb][cb][r] = L2 ? nt[cb] - __mul24(static_cast<int>((static_cast<uint32_t>(rbias[rb]) >> (8 * r)) & 255u), qbias[cb])
+                                        : nt[cb];
+    };
+    if (EARLY) acc_init(); // (the first strip's; every later one is set up at the end of the strip before it, in front of the drain)
     if (unit_of(k_cur) < n_units) for (;;) {
         const uint32_t u = unit_of(k_cur);
         const bool more = unit_of(k_nxt) < n_units;
@@ -900,16 +925,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
             const float* mp = meta_ptr(nxt.row0);
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(meta_n) : "s"(mp) : "memory");
         }
-        if (!Z0) {
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[rb][cb][r] = L2 ? nt[cb] - __mul24(static_cast<int>((static_cast<uint32_t>(rbias[rb]) >> (8 * r)) & 255u), qbias[cb])
-                                        : nt[cb];
-        }
+        if (!Z0 && !EARLY) acc_init();
         uint32_t sib = 0; // pacing: the siblings' strip counters
         // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
         // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
@@ -967,6 +983,69 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const float sb_cur = sb, eb_cur = eb;
         (void)sb_cur; (void)eb_cur;
         uint32_t hot = 0, k_new;
+        auto emit_survivors = [&]() __attribute__((always_inline)) {
+                // One pass over the query blocks that hold a survivor in some lane (one, typically): every element
+                // is tested by the whole wave at once, a ballot hands out the slots of this strip's log region (no
+                // LDS is left for a counter) and the lanes that hold a survivor store it.  An entry is
+                // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
+                // bound u and moves the entry into its query's candidate list.
+                const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
+                uint32_t base = ZL ? zs_n : log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
+    #pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const bool hot_cb = (hot >> cb) & 1u;
+                    if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
+                    const uint32_t qi = q0 + cb * 16 + l15;
+                    int zs_nt = 0; // ZS: -T of this strip and query block, derived again (the sign test kept none of them)
+                    if (Z0) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
+                    // this lane's 16 elements of the block that survive (straight-line code) ...
+                    uint32_t pm = 0;
+    #pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const uint32_t off0 = 16 * rb + 4 * lq; // row of element r of this lane: strip + off0 + r
+                        uint32_t mw = 0xfu;
+                        if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pm |= ((Z0 ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                    }
+                    if (!hot_cb) pm = 0;
+                    // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
+                    // unrolled form (a store block per element, 35 KB of it) ran from a cold instruction cache every time
+                    bool lost = false;
+                    for (;;) {
+                        const bool p = pm != 0;
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                        if (m == 0) break;
+                        if (ZL && base + 64u > static_cast<uint32_t>(R_ZS_ENTRIES)) { zs_n = base; zs_flush(); base = 0; } // (a trip adds at most 64)
+                        const int e = p ? __builtin_ctz(pm) : 0;
+                        int val = acc[0][cb][0];
+    #pragma unroll
+                        for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
+                        if (Z0) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
+                        const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                        base += static_cast<uint32_t>(__builtin_popcountll(m));
+                        if (p && ABL != 8) {
+                            const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
+                            if (ZL) {
+                                zs_key[pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
+                                zs_q[pos] = qi;
+                            } else if (ABL == 9) { // measurement build: slots, but no stores
+                                if (pos == 0x7fffffffu && val == 1) a.list_count[0] = 1;
+                            } else if (pos < a.log_cap) {
+                                a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
+                                a.log_q[region + pos] = qi;
+                            } else {
+                                lost = true;
+                            }
+                        }
+                        pm &= pm - 1u;
+                    }
+                    if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
+                }
+                if (ZL) zs_n = base; else log_pos = base;
+                if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
+        };
         if (THR) {
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
@@ -980,13 +1059,23 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     zs_t = i8_neg_threshold(qthr[cb & 1][0], zs_is, qthr[cb & 1][1], zs_g);
                     if (cb + 2 < 8) qthr[cb & 1] = zs_thr[(cb + 2) * 16];
                 }
-                if (m + zs_t >= 0 && q0 + cb * 16 + l15 < a.n_queries) hot |= 1u << cb;
+                if (m + zs_t >= 0) hot |= 1u << cb;
             }
+            hot &= q_live; // (queries past the end of the batch: ONE mask, not a per-block constant held in a register each)
             if (strip >= a.n_rows) hot = 0;
+            if (EARLY && __builtin_amdgcn_ballot_w64(hot != 0) != 0) emit_survivors(); // (LDS only: nothing the drain below would wait for)
             // the next unit's thresholds (needs nothing of this unit's accumulators: eight registers)
             sb = __uint_as_float(static_cast<uint32_t>(meta_n));
             eb = __uint_as_float(static_cast<uint32_t>(meta_n >> 32));
-            if (!Z0) { qthr_wait(); thresholds(); }
+            if (EARLY) {
+                // thresholds (from the LDS copy of the halves) and the next strip's accumulators FIRST, the drain after them:
+                // its wait — the next strip's first fragments, the strip counters — runs under these ~60 / ~160 instructions
+                thresholds();
+                acc_init();
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (!Z0) { qthr_wait(); thresholds(); }
             else if (!ZN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the drain of the plain form: strip counters, the next strip's first fragments
             k_new = take_result(); // (landed with the drain above — ZS: with the last slab's wait —, like the siblings' counters)
             if (n_qt > 1 && more && pacing && pace_now) {
@@ -1041,69 +1130,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     for (int r = 0; r < 4; ++r) t += acc[rb][cb][r];
             if (t == 123456789 && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
         }
-        if (THR && __builtin_amdgcn_ballot_w64(hot != 0) != 0) { // about half of the strips hold a survivor somewhere
-            // One pass over the query blocks that hold a survivor in some lane (one, typically): every element
-            // is tested by the whole wave at once, a ballot hands out the slots of this strip's log region (no
-            // LDS is left for a counter) and the lanes that hold a survivor store it.  An entry is
-            // (accumulator, row) + the query; i8_log_gather_kernel turns the accumulator back into the score
-            // bound u and moves the entry into its query's candidate list.
-            const uint32_t rows_left = strip < a.n_rows ? static_cast<uint32_t>(a.n_rows - strip < 64 ? a.n_rows - strip : 64) : 0u;
-            uint32_t base = ZL ? zs_n : log_pos; // entries of this wave so far (wave-uniform): ONE log region per wave and launch
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const bool hot_cb = (hot >> cb) & 1u;
-                if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
-                const uint32_t qi = q0 + cb * 16 + l15;
-                int zs_nt = 0; // ZS: -T of this strip and query block, derived again (the sign test kept none of them)
-                if (Z0) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
-                // this lane's 16 elements of the block that survive (straight-line code) ...
-                uint32_t pm = 0;
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const uint32_t off0 = 16 * rb + 4 * lq; // row of element r of this lane: strip + off0 + r
-                    uint32_t mw = 0xfu;
-                    if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        pm |= ((Z0 ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
-                }
-                if (!hot_cb) pm = 0;
-                // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
-                // unrolled form (a store block per element, 35 KB of it) ran from a cold instruction cache every time
-                bool lost = false;
-                for (;;) {
-                    const bool p = pm != 0;
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
-                    if (m == 0) break;
-                    if (ZL && base + 64u > static_cast<uint32_t>(R_ZS_ENTRIES)) { zs_n = base; zs_flush(); base = 0; } // (a trip adds at most 64)
-                    const int e = p ? __builtin_ctz(pm) : 0;
-                    int val = acc[0][cb][0];
-#pragma unroll
-                    for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
-                    if (Z0) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
-                    const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                    base += static_cast<uint32_t>(__builtin_popcountll(m));
-                    if (p && ABL != 8) {
-                        const uint64_t row = strip + static_cast<uint32_t>(16 * (e >> 2) + 4 * lq + (e & 3));
-                        if (ZL) {
-                            zs_key[pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
-                            zs_q[pos] = qi;
-                        } else if (ABL == 9) { // measurement build: slots, but no stores
-                            if (pos == 0x7fffffffu && val == 1) a.list_count[0] = 1;
-                        } else if (pos < a.log_cap) {
-                            a.log_key[region + pos] = (static_cast<uint64_t>(static_cast<uint32_t>(val)) << 32) | static_cast<uint32_t>(row);
-                            a.log_q[region + pos] = qi;
-                        } else {
-                            lost = true;
-                        }
-                    }
-                    pm &= pm - 1u;
-                }
-                if (lost) atomicOr(&a.q_over[qi], 1u); // no room: this query's list is incomplete -> exhaustive path
-            }
-            if (ZL) zs_n = base; else log_pos = base;
-            if (ABL == 8 && base == 0x12345u && a.list_cap == 0xffffffffu) a.list_count[0] = 1;
-        }
+        if (!EARLY && THR && __builtin_amdgcn_ballot_w64(hot != 0) != 0) emit_survivors(); // about half of the strips hold a survivor somewhere
         if (!more) break;
         cur = nxt;
         k_cur = k_nxt; k_nxt = k_fut; k_fut = k_new;
@@ -1123,6 +1150,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 }
 
 
+
+#include "scan_i8d_kernel.h" // the same form with two slabs of row fragments in flight per wave (dims 384 / 768), scan_tiles_i8d_kernel
 
 #ifdef YAMS_ACCEL_MEASURE
 #include "scan_i8q_kernel.h" // measurement build only: the 128 x 128 wave-tile form, scan_tiles_i8q_kernel
@@ -1974,6 +2003,14 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
         return hipGetLastError();
     }
+    if (rp.use && version == 90 && (L.plan.dim == 384 || L.plan.dim == 768)) { // two slabs of row fragments in flight per wave
+        hipLaunchKernelGGL((scan_tiles_i8d_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        return hipGetLastError();
+    }
+    if (rp.use && version == 87) { // the direct form as shipped: thresholds + survivors in LDS, boundary work before the drain (ZSM 2 | 4 | 64)
+        hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 70>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+        return hipGetLastError();
+    }
     if (rp.use && version >= 81 && version <= 85) { // ... with parts of the short strip boundary (ZSM bits, see the kernel)
 #define YAMS_ZS_LAUNCH(M) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, M>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window)
         if (version == 81) YAMS_ZS_LAUNCH(1 | 4 | 16);      // everything
@@ -2003,8 +2040,15 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
 #endif
     window |= pace_log2 << 16;
     // the direct form ships with its threshold halves and its survivors in LDS (ZSM 2 | 4: 7.47 -> 7.28 ms at dim 768,
-    // 4.26 -> 4.04 at 384, same candidates; profiles/r04_filter_forms.json)
-    if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 6>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    // 4.26 -> 4.04 at 384, same candidates; profiles/r04_filter_forms.json) and, since round 6, with the boundary's
+    // memory-independent work in front of the drain (| 64: 7.25 -> 7.14, 4.05 -> 3.92; profiles/r06_filter_forms.json)
+    // dims 384 and 768 (slab counts that are multiples of three) take the form with two slabs of row fragments in flight per
+    // wave (scan_i8d_kernel.h): 12.5M rows, direct form / this form — 256 queries dim 384 1.256 / 1.112 ms, dim 768 2.276 / 2.077;
+    // BASELINE config 2 0.140 / 0.133; 1024 queries 3.91 / 3.88 and 7.13 / 7.11 (power-bound: the bytes in flight are not what
+    // limits it); one query tile (HBM-bound) unchanged.  Same candidate sets (profiles/r06_filter_forms.json).
+    if (rp.use && direct && (L.plan.dim == 384 || L.plan.dim == 768))
+        hipLaunchKernelGGL((scan_tiles_i8d_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
+    else if (rp.use && direct) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 70>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else if (rp.use) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
     else hipLaunchKernelGGL((scan_tiles_i8h_kernel<MODE_FILTER>), dim3(hgrid), dim3(H_THREADS), 0, st, a);
     return hipGetLastError();
