@@ -130,6 +130,27 @@ public:
         // searches share the lock (vector_database.cpp:539,618): the plugin's search lanes serve them side by side
         return withSyncedMirror([&] { return table_.searchSimilarBatch(query_embeddings, k, similarity_threshold, num_threads); });
     }
+    // ---- the product-quantised engine (VectorSearchEngine::SimeonPqAdc, the default: vector_types.h:80) ----------------------
+    // simeonPqSearchUnlocked (sqlite_vec_backend.cpp:3868-4056) with its ADC scan, candidate selection and exact re-rank on the
+    // device.  A patched SqliteVecBackend keeps simeon — it trains, encodes (:3540-3690) and builds the per-query table
+    // (:3895-3901) — and calls these two where it called its own loop: setSimeonPqIndex after every rebuild / load of
+    // simeon_pq_indices_[dim] (codes + the chunk id of every indexed row), searchSimeonPq from searchSimilar when
+    // usesSimeonPqSearchEngine() (:1506-1560).  exact_fallback indexes (:3882-3893) keep calling searchSimilar.
+    Result<void> setSimeonPqIndex(size_t dim, const std::vector<uint8_t>& codes, size_t m, const std::vector<std::string>& chunkIdOfIndex) {
+        std::unique_lock lk(mu_);
+        return table_.setPqIndex(dim, codes, m, chunkIdOfIndex);
+    }
+    Result<std::vector<VectorRecord>>
+    searchSimeonPq(const std::vector<float>& query_embedding, const std::vector<float>& lut, size_t k, float similarity_threshold,
+                   size_t rerank_factor, const std::vector<uint32_t>* candidate_indices = nullptr,
+                   uint32_t sum_flags = YAMS_PQ_SUM_SEQUENTIAL, VectorSearchDiagnostics* diagnostics = nullptr) {
+        if (query_embedding.empty() || k == 0) return std::vector<VectorRecord>{};                  // :3873-3875
+        return withSyncedMirror([&]() -> Result<std::vector<VectorRecord>> {
+            auto r = table_.searchPqBatch({query_embedding}, {lut}, k, similarity_threshold, rerank_factor, candidate_indices, sum_flags, diagnostics);
+            if (!r) return r.error();
+            return std::move(r.value().front());
+        });
+    }
     // sqlite_vec_backend.cpp:4650-4661: the diagnostics are reset, the caller's collect flag survives
     Result<std::vector<VectorRecord>>
     searchSimilarWithDiagnostics(const std::vector<float>& query_embedding, size_t k, float similarity_threshold,

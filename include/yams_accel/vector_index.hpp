@@ -442,6 +442,88 @@ private:
         return out;
     }
 
+public:
+    // ---- the product-quantised engine (VectorSearchEngine::SimeonPqAdc — the product's default, vector_types.h:80) ---------
+    // SqliteVecBackend::Impl::simeonPqSearchUnlocked (sqlite_vec_backend.cpp:3868-4056) with its scan, selection and re-rank
+    // on the device.  The host keeps simeon (training, encoding, the per-query table).  After every (re)build of its
+    // SimeonPqIndexState for this dimension it hands over the codes and, per indexed row, the chunk id (rowids[i] resolved):
+    // the tie-break keys (stableStringKey, :141-148, :3337) and the index -> mirror-row table are derived here.  Rows the
+    // mirror does not (or no longer) hold are skipped by the search, as :4010-4012 does.
+    static uint64_t stableStringKey(const std::string& s) { // FNV-1a 64 (:141-148)
+        uint64_t h = 1469598103934665603ULL;
+        for (const unsigned char b : s) { h ^= b; h *= 1099511628211ULL; }
+        return h;
+    }
+    Result<void> setPqIndex(const std::vector<uint8_t>& codes, size_t m, const std::vector<std::string>& chunkIdOfIndex) {
+        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (!vt_->pq_index_set) return Error{ErrorCode::NotImplemented, "plugin lacks pq_index_set (vector_scan_v1 version 2)"};
+        const size_t n = chunkIdOfIndex.size();
+        if (m == 0 || codes.size() != n * m) return Error{ErrorCode::InvalidArgument, "codes must hold m bytes per indexed row"};
+        if (auto sy = syncMirror(); !sy) return sy.error();   // (may compact: row numbers are final after it)
+        std::vector<uint64_t> keys(n);
+        std::vector<uint32_t> rowOf(n);
+        for (size_t i = 0; i < n; ++i) {
+            keys[i] = stableStringKey(chunkIdOfIndex[i]);
+            const auto it = byId_.find(chunkIdOfIndex[i]);
+            rowOf[i] = it == byId_.end() ? 0xffffffffu : static_cast<uint32_t>(it->second);
+        }
+        pqChunkIds_ = chunkIdOfIndex; pqCodes_ = codes; pqM_ = m; pqRows_ = records_.size();
+        const yams_status_t st = vt_->pq_index_set(vt_->self, corpus_, codes.data(), n, static_cast<uint32_t>(m), keys.data(), rowOf.data());
+        if (st != YAMS_OK) return Error{accel::mapStatus(st), "pq_index_set failed"};
+        return {};
+    }
+    // queries: RAW query embeddings; luts[q]: m x 256 floats, simeon::PQInnerProductQuery's table for the NORMALISED query
+    // (:3895-3901); candidateIndices (nullable): ascending indices into the PQ index (:3910-3937); sumFlags: YAMS_PQ_SUM_*.
+    Result<std::vector<std::vector<VectorRecord>>>
+    searchPqBatch(const std::vector<std::vector<float>>& queries, const std::vector<std::vector<float>>& luts, size_t k, float thr,
+                  size_t rerankFactor, const std::vector<uint32_t>* candidateIndices = nullptr, uint32_t sumFlags = YAMS_PQ_SUM_SEQUENTIAL,
+                  VectorSearchDiagnostics* diagnostics = nullptr) {
+        if (!initialized_) return Error{ErrorCode::NotInitialized, "Database not initialized"};
+        if (!vt_->search_pq) return Error{ErrorCode::NotImplemented, "plugin lacks search_pq (vector_scan_v1 version 2)"};
+        if (queries.empty()) return std::vector<std::vector<VectorRecord>>{};
+        if (luts.size() != queries.size()) return Error{ErrorCode::InvalidArgument, "one table per query"};
+        for (size_t i = 0; i < queries.size(); ++i)
+            if (queries[i].size() != dim_ || luts[i].size() != pqM_ * 256)
+                return Error{ErrorCode::InvalidArgument, "query / table size mismatch"};
+        if (k > YAMS_SCAN_MAX_K) return Error{ErrorCode::NotSupported, "k exceeds YAMS_SCAN_MAX_K for the product-quantised engine"};
+        if (auto sy = syncMirror(); !sy) return sy.error();
+        if (records_.size() != pqRows_ && !pqChunkIds_.empty()) { // the mirror was compacted or grew: the row table is re-derived
+            if (auto r = setPqIndex(pqCodes_, pqM_, pqChunkIds_); !r) return r.error();
+        }
+        std::vector<float> fq(queries.size() * dim_), fl(queries.size() * pqM_ * 256);
+        for (size_t i = 0; i < queries.size(); ++i) {
+            std::copy(queries[i].begin(), queries[i].end(), fq.begin() + i * dim_);
+            std::copy(luts[i].begin(), luts[i].end(), fl.begin() + i * pqM_ * 256);
+        }
+        yams_scan_hit_t* hits = nullptr; uint32_t* counts = nullptr; yams_scan_diag_t diag{};
+        static const uint32_t kNoIndex = 0;     // (an EMPTY candidate list is a list — nothing is searched —, not "no restriction")
+        const uint32_t* cand = candidateIndices ? (candidateIndices->empty() ? &kNoIndex : candidateIndices->data()) : nullptr;
+        const yams_status_t st = vt_->search_pq(vt_->self, corpus_, fq.data(), fl.data(), static_cast<uint32_t>(queries.size()),
+                                                static_cast<uint32_t>(dim_), static_cast<uint32_t>(k), thr, static_cast<uint32_t>(rerankFactor),
+                                                sumFlags, cand, candidateIndices ? candidateIndices->size() : 0, &hits, &counts, &diag);
+        if (st != YAMS_OK) return Error{accel::mapStatus(st), "product-quantised search failed"};
+        std::vector<std::vector<VectorRecord>> out(queries.size());
+        for (size_t q = 0; q < queries.size(); ++q)
+            for (uint32_t i = 0; i < counts[q]; ++i) {
+                const auto& h = hits[q * k + i];
+                VectorRecord rec = records_[static_cast<size_t>(h.row)];
+                if (!alive_[static_cast<size_t>(h.row)]) continue;      // (a tombstone the PQ index still names: the table lost the row)
+                rec.relevance_score = h.similarity; // :4039
+                rec.embedding_dim = dim_;
+                out[q].push_back(std::move(rec));
+            }
+        vt_->free_hits(vt_->self, hits, counts);
+        if (diagnostics) {      // :3938-3945, :4027
+            diagnostics->usedAnn = true; diagnostics->rowsVisitedObserved = true; diagnostics->exactDistanceEvaluationsObserved = true;
+            diagnostics->rowsVisited += diag.rows_visited; diagnostics->exactDistanceEvaluations += diag.exact_distance_evaluations;
+            diagnostics->returnedRows = diag.returned_rows;
+        }
+        return out;
+    }
+
+private:
+    std::vector<std::string> pqChunkIds_; std::vector<uint8_t> pqCodes_; size_t pqM_ = 0, pqRows_ = 0;
+
     // k above what one device call returns (YAMS_SCAN_MAX_K): the reference takes any k
     // (sqlite_vec_backend.cpp:4299-4303 keeps a heap of k), callers that over-fetch for fusion or re-ranking
     // use thousands.  Per query, rounds of at most YAMS_SCAN_MAX_K: every round excludes the rows already
@@ -553,6 +635,22 @@ public:
         return {};
     }
     Result<void> insertVector(const VectorRecord& record) { return insertVectorsBatch({record}); }
+    // The product-quantised engine per dimension (AccelVectorIndex::setPqIndex / searchPqBatch): the host's
+    // SimeonPqIndexState of `dim` (simeon_pq_indices_[dim], sqlite_vec_backend.cpp:3877-3880)
+    Result<void> setPqIndex(size_t dim, const std::vector<uint8_t>& codes, size_t m, const std::vector<std::string>& chunkIdOfIndex) {
+        auto idx = indexFor(dim);
+        if (!idx) return idx.error();
+        return idx.value()->setPqIndex(codes, m, chunkIdOfIndex);
+    }
+    Result<std::vector<std::vector<VectorRecord>>>
+    searchPqBatch(const std::vector<std::vector<float>>& queries, const std::vector<std::vector<float>>& luts, size_t k, float thr,
+                  size_t rerankFactor, const std::vector<uint32_t>* candidateIndices = nullptr, uint32_t sumFlags = YAMS_PQ_SUM_SEQUENTIAL,
+                  VectorSearchDiagnostics* diagnostics = nullptr) {
+        if (queries.empty()) return std::vector<std::vector<VectorRecord>>{};
+        const auto it = byDim_.find(queries.front().size());
+        if (it == byDim_.end()) return std::vector<std::vector<VectorRecord>>(queries.size());   // no index of this dimension (:3877-3880)
+        return it->second->searchPqBatch(queries, luts, k, thr, rerankFactor, candidateIndices, sumFlags, diagnostics);
+    }
     Result<void> deleteVector(const std::string& chunkId) {
         auto it = dimOf_.find(chunkId);
         if (it == dimOf_.end()) return Error{ErrorCode::NotFound, "chunk not found"};

@@ -479,6 +479,63 @@ YAMS_ACCEL_API yams_status_t yams_synth_bytes_device(yams_accel_ctx* ctx, uint64
                                                      uint64_t blob_len, uint8_t* out_dev);
 
 /* ------------------------------------------------------------------------------------------ */
+/* The product-quantised engine: ADC scan over host-supplied codes + exact re-rank (round 6)  */
+/* ------------------------------------------------------------------------------------------ */
+/* Replaces the scoring, selection and re-rank of SqliteVecBackend::Impl::simeonPqSearchUnlocked
+ * (src/vector/sqlite_vec_backend.cpp:3868-4056; VectorSearchEngine::SimeonPqAdc is the product's DEFAULT engine,
+ * include/yams/vector/vector_types.h:80).  The host keeps what third_party/simeon owns — training the product quantiser,
+ * encoding rows (SimeonPqIndexState::codes, :53, :3648-3660) and building the per-query table of inner products
+ * (simeon::PQInnerProductQuery, :3901: lut[j][c] = <sub-vector j of the normalised query, centroid c of sub-quantiser j>) —
+ * and hands over the codes once (a device mirror, appended like rows) and the tables per batch.  Per query the device
+ *   1. scores every indexed row, or every index of `candidates` (:3910-3937, sorted ascending by the host), with
+ *      approxScore = sum over j of lut[j][codes[index * m + j]] in fp32 (:3965-3977; the ORDER of the additions is
+ *      simeon's: YAMS_PQ_SUM_* below — PARITY UNPINNED, simeon is absent from the reference checkout);
+ *   2. keeps the best approxK = min(candidates, max(k, k * rerank_factor)) by (score desc, tie key asc) (:3952-3997);
+ *   3. re-scores them with VectorDatabase::computeCosineSimilarity(raw query, row) in fp64, the reference's summation
+ *      order (:4023-4034), drops similarity < threshold (:4036-4038);
+ *   4. sorts by (similarity desc, chunk_id asc) and cuts to k (:4041-4051).
+ * `exact_fallback` indexes (:3882-3893) are the host's call to yams_scan_topk_device.  DocumentTopK selection
+ * (retainBestRecordPerDocument) stays on the host: ask for k = the candidate count. */
+typedef struct yams_scan_pq_index_s {
+    const uint8_t* codes;       /* device [n_codes][m], 4-byte aligned: code of indexed row i = bytes [i * m, (i + 1) * m)          */
+    uint64_t n_codes;           /* indexed rows (SimeonPqIndexState::rowids.size()), < 2^32                                        */
+    uint32_t m;                 /* sub-quantisers = bytes per code (simeon_pq_subquantizers, default 32), <= 128; 256 centroids each */
+    uint32_t reserved;
+    const uint32_t* tie_rank;   /* device [n_codes], nullable: rank of tie_break_keys[i] (= stableStringKey(chunk_id), :3337) among
+                                   all indexed rows — ascending key, equal keys by index — the second key of the comparator
+                                   :3985-3990.  Null: index order.                                                                 */
+    const uint32_t* key_row;    /* device [n_codes], nullable: the corpus row (yams_scan_corpus_t::rows) of the code whose KEY INDEX
+                                   is r, where the key index of code i is tie_rank[i] (or i without a tie_rank table): the
+                                   rowids[idx] lookup of :4009.  Null: identity.                                                    */
+} yams_scan_pq_index_t;
+
+#define YAMS_PQ_SUM_SEQUENTIAL 0u /* one fp32 sum over j = 0 .. m - 1 (a scalar loop)                                             */
+#define YAMS_PQ_SUM_X4 1u         /* 4 partial sums (element j -> lane j % 4), lanes added left to right (SSE-shaped)            */
+#define YAMS_PQ_SUM_X8 2u         /* 8 partial sums (AVX-shaped)                                                                  */
+#define YAMS_PQ_SUM_X16 3u        /* 16 partial sums (AVX-512-shaped)                                                             */
+#define YAMS_PQ_SUM_MASK 3u
+
+typedef struct yams_scan_pq_params_s {
+    uint32_t k;
+    float similarity_threshold; /* on the EXACT similarity of the re-rank (:4036-4038)                                           */
+    uint32_t rerank_factor;     /* SimeonPqIndexState::rerank_factor (>= 1; 0 is read as 1); k * rerank_factor <= 2047            */
+    uint32_t flags;             /* YAMS_PQ_SUM_*                                                                                  */
+} yams_scan_pq_params_t;
+
+/* corpus: the fp32 rows the re-rank reads (+ tie_rank / rank_row: the chunk_id order of the final sort; row_base / stripes:
+ * how a row becomes the id in out_rows).  queries: device [n_queries][dim] RAW queries (the re-rank's first argument);
+ * luts: device [n_queries][m][256] fp32, 16-byte aligned; candidates: device, nullable — n_candidates ascending indices
+ * into the PQ index (a restriction to documents, :3910-3930; an EMPTY list returns nothing, :3946-3948).
+ * out_scores / out_rows: device [n_queries][k]; out_counts: device [n_queries].  A query whose norm^2 is <= 1e-20 or not
+ * finite returns nothing (:3895-3898).  Synchronous.  diag (nullable): rows_visited = candidates per query summed,
+ * exact_distance_evaluations = rows re-scored, path = 2, filter_tier = 5. */
+YAMS_ACCEL_API yams_status_t yams_scan_pq_topk_device(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus,
+                                                      const yams_scan_pq_index_t* pq, const float* queries, const float* luts,
+                                                      uint32_t n_queries, const yams_scan_pq_params_t* params,
+                                                      const uint32_t* candidates, uint64_t n_candidates, float* out_scores,
+                                                      int64_t* out_rows, uint32_t* out_counts, yams_scan_diag_t* diag);
+
+/* ------------------------------------------------------------------------------------------ */
 /* SHA-256                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 /* Digest n_msgs byte ranges of one device buffer: message i = data[offsets[i] .. +lengths[i]).
@@ -663,7 +720,7 @@ YAMS_ACCEL_API yams_status_t yams_dedup_probe_host(yams_dedup_set* set, const ui
 /* Plugin vtables (obtained through yams_plugin_get_interface)                                  */
 /* ------------------------------------------------------------------------------------------ */
 #define YAMS_IFACE_VECTOR_SCAN_V1 "vector_scan_v1"
-#define YAMS_IFACE_VECTOR_SCAN_V1_VERSION 1u
+#define YAMS_IFACE_VECTOR_SCAN_V1_VERSION 2u /* 2 appends pq_index_set / search_pq; a host that asks for version 1 gets the same table */
 #define YAMS_IFACE_CONTENT_HASH_V1 "content_hash_v1"
 #define YAMS_IFACE_CONTENT_HASH_V1_VERSION 1u
 #define YAMS_IFACE_CHUNKER_V1 "chunker_v1"
@@ -736,6 +793,23 @@ typedef struct yams_vector_scan_v1 {
                                      float similarity_threshold, uint32_t metric, uint32_t flags,
                                      const uint32_t* row_mask, yams_scan_hit_t** out_hits,
                                      uint32_t** out_counts, yams_scan_diag_t* out_diag);
+    /* ---- version 2: the product-quantised engine (VectorSearchEngine::SimeonPqAdc; simeonPqSearchUnlocked,
+     * src/vector/sqlite_vec_backend.cpp:3868-4056) over the same mirror; see yams_scan_pq_topk_device.
+     * pq_index_set: the host's SimeonPqIndexState (:48-62) for this corpus, all HOST arrays: codes [n_codes][m],
+     * tie_keys [n_codes] (tie_break_keys = stableStringKey(chunk_id)), row_of_index [n_codes] (nullable = identity: which
+     * mirror row code i belongs to — rowids[i] mapped to the mirror's ordinal).  Replaces a previous index; n_codes == 0
+     * drops it.  corpus_clear / corpus_append do NOT touch it: the host sets it again after it re-encodes (a PQ index that
+     * names rows the mirror has lost skips them, :4010-4012).  Corpora dealt to several devices: YAMS_ERR_UNSUPPORTED. */
+    yams_status_t (*pq_index_set)(void* self, uint64_t corpus_id, const uint8_t* codes, uint64_t n_codes, uint32_t m,
+                                  const uint64_t* tie_keys, const uint32_t* row_of_index);
+    /* queries: host [n_queries][dim] RAW queries; luts: host [n_queries][m][256] (what simeon::PQInnerProductQuery holds for
+     * the NORMALISED query, :3895-3901); candidates (nullable): n_candidates ascending indices into the PQ index (:3910-3937);
+     * flags: YAMS_PQ_SUM_*.  Hits as search_batch (distance = 1 - similarity); the final order uses the corpus's tie ranks
+     * (corpus_set_tie_ranks: chunk_id order, :4041-4051). */
+    yams_status_t (*search_pq)(void* self, uint64_t corpus_id, const float* queries, const float* luts, uint32_t n_queries,
+                               uint32_t dim, uint32_t k, float similarity_threshold, uint32_t rerank_factor, uint32_t flags,
+                               const uint32_t* candidates, uint64_t n_candidates, yams_scan_hit_t** out_hits,
+                               uint32_t** out_counts, yams_scan_diag_t* out_diag);
 } yams_vector_scan_v1;
 
 /* WHAT THE DEVICE IS WORSE AT IS REFUSED, NOT SERVED SLOWLY.  SHA-256 of one message is one sequential chain: a

@@ -485,6 +485,96 @@ ORACLE_API long oracle_exact_scan_l2_f32acc(const float* corpus, size_t n_rows, 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * The product-quantised engine: SqliteVecBackend::Impl::simeonPqSearchUnlocked,
+ * src/vector/sqlite_vec_backend.cpp:3868-4056, restated.  PARITY UNPINNED: third_party/simeon (ProductQuantizer,
+ * PQInnerProductQuery::inner_product) is absent from the reference checkout — the ORDER of the fp32 additions of the ADC
+ * score is simeon's.  `sum_lanes` = 1: one sequential sum over the sub-quantisers; 4 / 8 / 16: that many partial sums
+ * (element j -> lane j % lanes) added left to right.  Everything around that sum is the reference's own text:
+ *   :3873-3880  empty query / k == 0 / no index -> nothing            :3895-3898  query norm^2 <= 1e-20 -> nothing
+ *   :3938-3948  candidateCount = all indexed rows or the candidate indices; 0 -> nothing
+ *   :3952-3960  approxK = min(candidateCount, max(k, k * rerank_factor)) (k * rerank saturating)
+ *   :3985-3997  best approxK by (score desc, tie key asc); equal (score, key) pairs are ordered by INDEX here (the
+ *               reference leaves that to nth_element / sort)
+ *   :4006-4016  rows the vectors table no longer holds are skipped (row_of_index >= n_rows here)
+ *   :4023-4038  similarity = (float)computeCosineSimilarity(query, row), dropped when < threshold
+ *   :4041-4051  sorted by (similarity desc, chunk_id asc), cut to k.
+ * A NaN similarity (a non-finite row, which cannot be stored: vector_database.cpp:1771-1784) is left out.
+ * out_stats (nullable) = {candidateCount, rows materialised (exactDistanceEvaluations)}.
+ * ---------------------------------------------------------------------------------------------- */
+ORACLE_API float oracle_pq_adc_score(const uint8_t* code, size_t m, const float* lut, int sum_lanes) {
+    if (sum_lanes <= 1) {
+        float acc = 0.0f;
+        for (size_t j = 0; j < m; ++j) acc = acc + lut[j * 256 + code[j]];
+        return acc;
+    }
+    float part[16];
+    if (sum_lanes > 16) sum_lanes = 16;
+    for (int l = 0; l < sum_lanes; ++l) part[l] = 0.0f;
+    for (size_t j = 0; j < m; ++j) part[j % (size_t)sum_lanes] += lut[j * 256 + code[j]];
+    float acc = 0.0f;
+    for (int l = 0; l < sum_lanes; ++l) acc += part[l];
+    return acc;
+}
+typedef struct { float score; uint64_t key; size_t index; } oracle_pqhit;
+static int pq_cmp(const void* pa, const void* pb) {
+    const oracle_pqhit* a = (const oracle_pqhit*)pa; const oracle_pqhit* b = (const oracle_pqhit*)pb;
+    if (a->score != b->score) return a->score > b->score ? -1 : 1;
+    if (a->key != b->key) return a->key < b->key ? -1 : 1;
+    if (a->index != b->index) return a->index < b->index ? -1 : 1;
+    return 0;
+}
+typedef struct { float sim; uint64_t rank; int64_t row; } oracle_pqrec;
+static int pqrec_cmp(const void* pa, const void* pb) {
+    const oracle_pqrec* a = (const oracle_pqrec*)pa; const oracle_pqrec* b = (const oracle_pqrec*)pb;
+    if (a->sim != b->sim) return a->sim > b->sim ? -1 : 1;
+    if (a->rank != b->rank) return a->rank < b->rank ? -1 : 1;
+    return 0;
+}
+ORACLE_API long oracle_pq_search(const float* corpus, size_t n_rows, size_t dim, const uint8_t* codes, size_t n_codes, size_t m,
+                                 const float* lut, const uint64_t* tie_keys, const uint32_t* row_of_index, const uint64_t* chunk_rank,
+                                 const float* query, size_t k, float threshold, size_t rerank_factor, const uint32_t* candidates,
+                                 size_t n_candidates, int sum_lanes, int64_t* out_rows, float* out_sims, uint64_t* out_stats) {
+    if (out_stats) { out_stats[0] = 0; out_stats[1] = 0; }
+    if (dim == 0 || k == 0 || n_codes == 0) return 0;
+    double nsq = 0.0;
+    for (size_t i = 0; i < dim; ++i) nsq += (double)query[i] * (double)query[i];
+    if (!(nsq > 1e-20) || !isfinite(nsq)) return 0;            /* normalizeEmbeddingInPlace fails (:213-226) */
+    const size_t count = candidates ? n_candidates : n_codes;
+    if (out_stats) out_stats[0] = count;
+    if (count == 0) return 0;
+    if (rerank_factor == 0) rerank_factor = 1;
+    const size_t budget = k > (size_t)-1 / rerank_factor ? (size_t)-1 : k * rerank_factor;
+    size_t approx = k > budget ? k : budget;
+    if (approx > count) approx = count;
+    oracle_pqhit* all = (oracle_pqhit*)malloc(sizeof(oracle_pqhit) * count);
+    size_t n = 0;
+    for (size_t c = 0; c < count; ++c) {
+        const size_t idx = candidates ? candidates[c] : c;
+        if (idx >= n_codes) continue;
+        all[n].score = oracle_pq_adc_score(codes + idx * m, m, lut, sum_lanes);
+        all[n].key = tie_keys ? tie_keys[idx] : (uint64_t)idx; all[n].index = idx; ++n;
+    }
+    qsort(all, n, sizeof(oracle_pqhit), pq_cmp);
+    if (approx > n) approx = n;
+    oracle_pqrec* recs = (oracle_pqrec*)malloc(sizeof(oracle_pqrec) * (approx ? approx : 1));
+    size_t nr = 0, materialised = 0;
+    for (size_t i = 0; i < approx; ++i) {
+        const size_t row = row_of_index ? row_of_index[all[i].index] : all[i].index;
+        if (row >= n_rows) continue;                              /* getVectorByRowidUnlocked finds nothing (:4010-4012) */
+        ++materialised;
+        const float sim = (float)oracle_cosine_similarity_impl(query, corpus + row * dim, dim);
+        if (sim != sim || sim < threshold) continue;              /* (:4036-4038; a NaN similarity: see above) */
+        recs[nr].sim = sim; recs[nr].rank = chunk_rank ? chunk_rank[row] : (uint64_t)row; recs[nr].row = (int64_t)row; ++nr;
+    }
+    if (out_stats) out_stats[1] = materialised;
+    qsort(recs, nr, sizeof(oracle_pqrec), pqrec_cmp);
+    if (nr > k) nr = k;
+    for (size_t i = 0; i < nr; ++i) { out_rows[i] = recs[i].row; out_sims[i] = recs[i].sim; }
+    free(all); free(recs);
+    return (long)nr;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * MANY queries against one corpus slice: what lets a test check EVERY query of a BASELINE-size batch (1024 queries x
  * 12.5M rows) instead of two or four of them.  Not a second definition — the same arithmetic as
  * oracle_exact_scan_cosine / oracle_exact_scan_l2 above, per (row, query) the very same sequence of IEEE double

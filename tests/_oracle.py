@@ -216,6 +216,43 @@ class Oracle:
         self.L.oracle_l2_distance_f32acc_many(_ptr(rows, f32p), _ptr(query, f32p), rows.shape[0], rows.shape[1], lanes, _ptr(out, f32p))
         return out
 
+    def pq_search(self, corpus, codes, lut, query, k, thr=-1.0, rerank_factor=2, tie_keys=None, row_of_index=None, chunk_rank=None,
+                  candidates=None, sum_lanes=1):
+        """simeonPqSearchUnlocked restated (oracle_pq_search; PARITY UNPINNED for the order of the ADC sum): returns
+        (rows, sims, {"candidates", "materialised"})."""
+        corpus = np.ascontiguousarray(corpus, np.float32); codes = np.ascontiguousarray(codes, np.uint8)
+        lut = np.ascontiguousarray(lut, np.float32); query = np.ascontiguousarray(query, np.float32)
+        n_rows, dim = corpus.shape
+        n, m = codes.shape
+        rows = np.full(max(k, 1), -1, np.int64); sims = np.zeros(max(k, 1), np.float32)
+        u8p = C.POINTER(C.c_uint8); u32p = C.POINTER(C.c_uint32)
+        tk = roi = cr = cd = None
+        if tie_keys is not None:
+            tie_keys = np.ascontiguousarray(tie_keys, np.uint64); tk = _ptr(tie_keys, u64p)
+        if row_of_index is not None:
+            row_of_index = np.ascontiguousarray(row_of_index, np.uint32); roi = _ptr(row_of_index, u32p)
+        if chunk_rank is not None:
+            chunk_rank = np.ascontiguousarray(chunk_rank, np.uint64); cr = _ptr(chunk_rank, u64p)
+        n_c = 0
+        if candidates is not None:
+            candidates = np.ascontiguousarray(candidates, np.uint32); n_c = candidates.size
+            cd = _ptr(candidates if n_c else np.zeros(1, np.uint32), u32p)
+        st = (C.c_uint64 * 2)()
+        f = self.L.oracle_pq_search
+        f.restype = C.c_long
+        f.argtypes = [f32p, C.c_size_t, C.c_size_t, u8p, C.c_size_t, C.c_size_t, f32p, u64p, u32p, u64p, f32p, C.c_size_t, C.c_float,
+                      C.c_size_t, u32p, C.c_size_t, C.c_int, i64p, f32p, C.POINTER(C.c_uint64)]
+        cnt = f(_ptr(corpus, f32p), n_rows, dim, _ptr(codes, u8p), n, m, _ptr(lut, f32p), tk, roi, cr, _ptr(query, f32p), k, thr,
+                rerank_factor, cd, n_c, sum_lanes, _ptr(rows, i64p), _ptr(sims, f32p), st)
+        return rows[:cnt].copy(), sims[:cnt].copy(), {"candidates": int(st[0]), "materialised": int(st[1])}
+
+    def pq_adc_score(self, code, lut, sum_lanes=1):
+        code = np.ascontiguousarray(code, np.uint8); lut = np.ascontiguousarray(lut, np.float32)
+        f = self.L.oracle_pq_adc_score
+        f.restype = C.c_float
+        f.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, f32p, C.c_int]
+        return float(f(_ptr(code, C.POINTER(C.c_uint8)), code.size, _ptr(lut, f32p), sum_lanes))
+
     def cosine(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         return self.L.oracle_cosine_similarity(_ptr(a, f32p), _ptr(b, f32p), a.size)

@@ -529,6 +529,80 @@ int main(int argc, char** argv) {
         auto res = db.searchSimilar(r.embedding, 1, -1.0f);
         CHECK(res.has_value() && res.value().size() == 1 && std::isfinite(res.value()[0].relevance_score) && res.value()[0].relevance_score > 0.999f);
     }
+    if (config.find("devices") == std::string::npos) {
+        // ---- the product-quantised engine through the adapter (round 6): AccelVectorIndex::setPqIndex / searchPqBatch against
+        //      a host restatement of simeonPqSearchUnlocked (sqlite_vec_backend.cpp:3868-4056).  The quantiser is a stand-in
+        //      (random codes and tables: third_party/simeon is absent) — what is checked is everything the reference's function
+        //      does around it: ADC sum, (score desc, tie key asc), approxK, the exact re-rank, rows the mirror lost, the final
+        //      (similarity desc, chunk_id asc) order.  (Single-device corpora: a striped corpus answers NotImplemented.)
+        const size_t n = 3000, d = 64, m = 8, k = 10, rf = 3;
+        std::mt19937 rng(99);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        auto idxR = vector::createAccelVectorIndex(plugin, d);
+        auto& db = *idxR.value();
+        CHECK(db.initialize().has_value());
+        std::vector<vector::VectorRecord> recs(n);
+        for (size_t i = 0; i < n; ++i) {
+            char id[32]; std::snprintf(id, sizeof id, "pq_%05zu", (i * 7919) % 100003);
+            recs[i].chunk_id = id; recs[i].document_hash = "doc";
+            recs[i].embedding.resize(d);
+            for (auto& v : recs[i].embedding) v = nd(rng) * (1.0f + float(i % 7));
+        }
+        for (size_t i = 40; i < 48; ++i) recs[i].embedding = recs[7].embedding;            // equal exact similarities: chunk ids decide
+        CHECK(db.insertVectorsBatch(recs).has_value());
+        std::vector<uint8_t> codes(n * m);
+        for (auto& c : codes) c = static_cast<uint8_t>(rng() & 255u);
+        for (size_t i = 40; i < 48; ++i) std::copy(codes.begin() + 7 * m, codes.begin() + 8 * m, codes.begin() + i * m); // equal ADC scores: tie keys decide
+        std::vector<std::string> ids(n);
+        for (size_t i = 0; i < n; ++i) ids[i] = recs[i].chunk_id;
+        ids.push_back("pq_gone_1"); ids.push_back("pq_gone_2");                             // indexed rows the table no longer holds
+        codes.resize((n + 2) * m, 3);
+        CHECK(db.setPqIndex(codes, m, ids).has_value());
+        std::vector<std::vector<float>> queries(3, std::vector<float>(d)), luts(3, std::vector<float>(m * 256));
+        for (auto& q : queries) for (auto& v : q) v = nd(rng);
+        for (auto& l : luts) for (auto& v : l) v = nd(rng);
+        for (auto& v : luts[0]) v = 0.f;                                                    // every ADC score equal: the tie keys alone order the candidates
+        std::vector<uint32_t> cand;
+        for (uint32_t i = 1; i < n + 2; i += 3) cand.push_back(i);
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<uint32_t>* cd = pass ? &cand : nullptr;
+            auto got = db.searchPqBatch(queries, luts, k, -1.0f, rf, cd);
+            CHECK(got.has_value());
+            if (!got.has_value()) continue;
+            for (size_t qi = 0; qi < queries.size(); ++qi) {
+                struct Hit { float s; uint64_t key; size_t idx; };
+                std::vector<Hit> hits;
+                const size_t cnt = cd ? cd->size() : n + 2;
+                for (size_t c = 0; c < cnt; ++c) {
+                    const size_t i = cd ? (*cd)[c] : c;
+                    float acc = 0.f;
+                    for (size_t j = 0; j < m; ++j) acc = acc + luts[qi][j * 256 + codes[i * m + j]];
+                    hits.push_back({acc, vector::AccelVectorIndex::stableStringKey(ids[i]), i});
+                }
+                std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.s != b.s ? a.s > b.s : (a.key != b.key ? a.key < b.key : a.idx < b.idx); });
+                hits.resize(std::min(hits.size(), std::max(k, k * rf)));
+                std::vector<std::pair<float, std::string>> want;
+                for (const auto& h : hits) {
+                    if (h.idx >= n) continue;                                                // getVectorByRowidUnlocked finds nothing
+                    double dp = 0, na = 0, nb = 0;
+                    for (size_t t = 0; t < d; ++t) { const double a = queries[qi][t], b = recs[h.idx].embedding[t]; dp += a * b; na += a * a; nb += b * b; }
+                    na = std::sqrt(na); nb = std::sqrt(nb);
+                    want.emplace_back(static_cast<float>((na == 0 || nb == 0) ? 0.0 : dp / (na * nb)), recs[h.idx].chunk_id);
+                }
+                std::sort(want.begin(), want.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+                if (want.size() > k) want.resize(k);
+                const auto& g = got.value()[qi];
+                CHECK(g.size() == want.size());
+                for (size_t i = 0; i < std::min(g.size(), want.size()); ++i) {
+                    CHECK(g[i].chunk_id == want[i].second);
+                    CHECK(std::memcmp(&g[i].relevance_score, &want[i].first, 4) == 0);
+                }
+            }
+        }
+        std::vector<uint32_t> none;
+        auto empty = db.searchPqBatch(queries, luts, k, -1.0f, rf, &none);                  // an empty candidate list: nothing (:3946-3948)
+        CHECK(empty.has_value() && empty.value().size() == 3 && empty.value()[0].empty());
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
     return failures ? 1 : 0;
 }

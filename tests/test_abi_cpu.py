@@ -77,9 +77,11 @@ def test_get_interface_contract(accel_lib):
     assert L.yams_plugin_get_interface(b"vector_scan_v1", 1, None) == -4
     assert L.yams_plugin_get_interface(b"nope_v1", 1, C.byref(p)) == -2    # ERR_NOT_FOUND
     assert p.value is None
-    assert L.yams_plugin_get_interface(b"vector_scan_v1", 2, C.byref(p)) == -2
+    assert L.yams_plugin_get_interface(b"vector_scan_v1", 3, C.byref(p)) == -2
     assert L.yams_plugin_get_interface(b"vector_scan_v1", 0, C.byref(p)) == -2
-    for name, typ, ver in [(b"vector_scan_v1", _lib.VectorScanV1, 1),
+    p1 = C.c_void_p()
+    assert L.yams_plugin_get_interface(b"vector_scan_v1", 1, C.byref(p1)) == 0      # version 1 hosts get the same table
+    for name, typ, ver in [(b"vector_scan_v1", _lib.VectorScanV1, 2),               # (2 appended pq_index_set / search_pq)
                            (b"content_hash_v1", _lib.ContentHashV1, 1),
                            (b"chunker_v1", _lib.ChunkerV1, 3)]:
         assert L.yams_plugin_get_interface(name, ver, C.byref(p)) == 0

@@ -72,6 +72,18 @@ class ScanParams(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+class ScanPqIndex(C.Structure):     # yams_scan_pq_index_t
+    _fields_ = [("codes", vp), ("n_codes", C.c_uint64), ("m", C.c_uint32), ("reserved", C.c_uint32),
+                ("tie_rank", vp), ("key_row", vp)]
+
+
+class ScanPqParams(C.Structure):    # yams_scan_pq_params_t
+    _fields_ = [("k", C.c_uint32), ("similarity_threshold", C.c_float), ("rerank_factor", C.c_uint32), ("flags", C.c_uint32)]
+
+
+PQ_SUM_SEQUENTIAL, PQ_SUM_X4, PQ_SUM_X8, PQ_SUM_X16 = 0, 1, 2, 3
+
+
 class ScanDiag(C.Structure):
     _fields_ = [("used_exact_scan", C.c_uint32), ("rows_visited_observed", C.c_uint32),
                 ("rows_visited", C.c_uint64), ("exact_distance_evaluations", C.c_uint64),
@@ -131,6 +143,11 @@ class VectorScanV1(C.Structure):
                                         C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, u32p,
                                         C.POINTER(C.POINTER(ScanHit)), C.POINTER(u32p),
                                         C.POINTER(ScanDiag))),
+        # version 2: the product-quantised engine over the mirror
+        ("pq_index_set", C.CFUNCTYPE(ST, vp, C.c_uint64, u8p, C.c_uint64, C.c_uint32, u64p, u32p)),
+        ("search_pq", C.CFUNCTYPE(ST, vp, C.c_uint64, f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32,
+                                  C.c_uint32, u32p, C.c_uint64, C.POINTER(C.POINTER(ScanHit)), C.POINTER(u32p),
+                                  C.POINTER(ScanDiag))),
     ]
 
 
@@ -186,7 +203,7 @@ EXPORTS = [
     "yams_accel_free_string", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_accel_debug_fail_alloc_after", "yams_accel_debug_alloc_faults",
-    "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device",
+    "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device", "yams_scan_pq_topk_device",
     "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device",
     "yams_scan_record_layout", "yams_scan_merge_records_device", "yams_scan_sharded_create",
     "yams_scan_sharded_destroy", "yams_scan_sharded_count", "yams_scan_sharded_ctx",
@@ -264,6 +281,8 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_scan_topk_device.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32,
                                         C.POINTER(ScanParams), vp, vp, vp, vp, vp,
                                         C.POINTER(ScanDiag)]
+    L.yams_scan_pq_topk_device.argtypes = [vp, C.POINTER(ScanCorpus), C.POINTER(ScanPqIndex), vp, vp, C.c_uint32, C.POINTER(ScanPqParams),
+                                           vp, C.c_uint64, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_scan_topk_host.argtypes = [vp, C.POINTER(ScanCorpus), vp, C.c_uint32,
                                       C.POINTER(ScanParams), vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_scan_build_shadow_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]

@@ -392,6 +392,56 @@ class Accel:
                                                C.byref(diag)))
         return ScanResult(scores[:, :k], rows[:, :k], counts, dist[:, :k], diag.as_dict())
 
+    def scan_pq_topk(self, corpus: ScanCorpus, codes: np.ndarray, luts: np.ndarray, queries: np.ndarray, k: int, threshold: float = -1.0,
+                     rerank_factor: int = 2, tie_keys: np.ndarray | None = None, row_of_index: np.ndarray | None = None,
+                     candidates: np.ndarray | None = None, sum_lanes: int = 1) -> ScanResult:
+        """The product-quantised engine's search (yams_scan_pq_topk_device; simeonPqSearchUnlocked, sqlite_vec_backend.cpp:
+        3868-4056) from host arrays: codes u8 [n][m], luts f32 [nq][m][256] (what simeon's PQInnerProductQuery holds), raw
+        queries [nq][dim], tie_keys u64 [n] (stableStringKey of the chunk ids), row_of_index u32 [n] (index -> corpus row),
+        candidates: ascending indices or None.  The tie ranks and the key -> row table are derived here, as a host does once
+        per index build."""
+        codes = np.ascontiguousarray(codes, np.uint8)
+        n, m = codes.shape
+        q = np.ascontiguousarray(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        luts = np.ascontiguousarray(luts, np.float32).reshape(nq, m, 256)
+        keep = []
+        d_codes = self.to_device(codes); keep.append(d_codes)
+        d_tie = d_keyrow = None
+        order = None
+        if tie_keys is not None:
+            tk = np.ascontiguousarray(tie_keys, np.uint64)
+            order = np.lexsort((np.arange(n), tk))            # ascending key, equal keys by index
+            rank = np.empty(n, np.uint32); rank[order] = np.arange(n, dtype=np.uint32)
+            d_tie = self.to_device(rank); keep.append(d_tie)
+        if tie_keys is not None or row_of_index is not None:
+            roi = np.arange(n, dtype=np.uint32) if row_of_index is None else np.ascontiguousarray(row_of_index, np.uint32)
+            key_row = roi[order] if order is not None else roi  # key index r -> row of the code with that key index
+            d_keyrow = self.to_device(np.ascontiguousarray(key_row, np.uint32)); keep.append(d_keyrow)
+        pq = _lib.ScanPqIndex(d_codes.ptr, n, m, 0, d_tie.ptr if d_tie else None, d_keyrow.ptr if d_keyrow else None)
+        d_q = self.to_device(q); d_l = self.to_device(luts); keep += [d_q, d_l]
+        d_c = None; n_c = 0
+        if candidates is not None:
+            cand = np.ascontiguousarray(candidates, np.uint32)
+            n_c = cand.size
+            d_c = self.to_device(cand if n_c else np.zeros(1, np.uint32)); keep.append(d_c)
+        kk = max(k, 1)
+        d_s = self.alloc(nq * kk * 4); d_r = self.alloc(nq * kk * 8); d_n = self.alloc(nq * 4)
+        prm = _lib.ScanPqParams(k, threshold, rerank_factor, {1: 0, 4: 1, 8: 2, 16: 3}[sum_lanes])
+        diag = ScanDiag()
+        try:
+            self._check(self.L.yams_scan_pq_topk_device(self.ctx, C.byref(corpus), C.byref(pq), d_q.ptr, d_l.ptr, nq, C.byref(prm),
+                                                        d_c.ptr if d_c else None, n_c, d_s.ptr, d_r.ptr, d_n.ptr, C.byref(diag)))
+            counts = d_n.download(np.uint32, nq)
+            scores = d_s.download(np.float32, nq * kk).reshape(nq, kk)
+            rows = d_r.download(np.int64, nq * kk).reshape(nq, kk)
+        finally:
+            for b in keep + [d_s, d_r, d_n]:
+                b.free()
+        return ScanResult(scores[:, :k], rows[:, :k], counts, None, diag.as_dict())
+
     def merge_topk_device(self, n_shards, nq, k, threshold, metric, in_scores, in_rows, in_counts,
                           in_dist, in_ranks, out_scores, out_rows, out_counts, out_dist):
         prm = ScanParams(k, threshold, metric, 0)

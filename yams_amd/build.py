@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libyams_mi355x_accel.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["scan_kernels.hip", "scan_small_kernel.hip", "scan_bf16_kernel.hip", "scan_i8_kernel.hip", "ingest_kernels.hip", "dedup_kernels.hip", "accel_ctx.cpp",
-           "scan_api.cpp", "sharded_api.cpp", "dedup_api.cpp",
+SOURCES = ["scan_kernels.hip", "scan_small_kernel.hip", "scan_bf16_kernel.hip", "scan_i8_kernel.hip", "pq_kernels.hip", "ingest_kernels.hip", "dedup_kernels.hip", "accel_ctx.cpp",
+           "scan_api.cpp", "pq_api.cpp", "sharded_api.cpp", "dedup_api.cpp",
            "ingest_api.cpp", "plugin.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-x", "hip"]

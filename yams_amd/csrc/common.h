@@ -59,6 +59,9 @@ constexpr int kTileQueries = 128; // queries per workgroup tile
 constexpr int kSlabK = 32;        // k-extent of one LDS stage
 constexpr int kGroupRows = 16;    // rows summarised by one "group maximum" in the sample pass
 constexpr int kSelectCap = 4096;  // elements one select workgroup sorts
+// RescoreLaunch::flags, internal (never a caller's bit): the re-score of the product-quantised engine — the similarity is
+// VectorDatabase::computeCosineSimilarity's (0 on a zero norm, no small-norm skip: sqlite_vec_backend.cpp:4023-4034)
+constexpr uint32_t kRescoreFlagPqRerank = 1u << 30;
 
 struct ScanPlan {
     uint64_t n_rows = 0;

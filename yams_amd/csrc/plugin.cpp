@@ -242,9 +242,24 @@ struct ShardStore {
     }
 };
 
+// The host's product-quantiser index of a corpus (SimeonPqIndexState, sqlite_vec_backend.cpp:48-62), on the corpus's device:
+// codes, the rank of every code's tie-break key, and the mirror row behind every key index.
+struct PqIndex {
+    uint8_t* codes = nullptr; uint32_t* tie_rank = nullptr; uint32_t* key_row = nullptr;
+    uint64_t n = 0; uint32_t m = 0; int device = 0;
+    void release() {
+        if (codes || tie_rank || key_row) (void)hipSetDevice(device);
+        if (codes) (void)hipFree(codes);
+        if (tie_rank) (void)hipFree(tie_rank);
+        if (key_row) (void)hipFree(key_row);
+        codes = nullptr; tie_rank = key_row = nullptr; n = 0; m = 0;
+    }
+};
+
 struct Corpus {
     uint32_t dim = 0;
     uint64_t n_rows = 0;
+    PqIndex pq;                      // (version 2 of the vtable: pq_index_set / search_pq)
     std::vector<ShardStore> sh;      // one per plugin device
     GrowBuf rank_of_row;             // device 0: the corpus-wide chunk_id ranking (cross-shard ties)
     bool has_ranks = false;
@@ -625,6 +640,7 @@ yams_status_t vs_corpus_set_tie_ranks(void*, uint64_t id, const uint32_t* ranks,
 }
 
 void release_corpus(Corpus& c) {
+    c.pq.release();
     for (auto& s : c.sh) s.release();
     c.rank_of_row.release();
     c.n_rows = 0; c.has_ranks = false;
@@ -764,6 +780,97 @@ yams_status_t vs_search_batch(void* self, uint64_t id, const float* queries, uin
                                   out_counts, out_diag);
 }
 
+// ---- version 2: the product-quantised engine over the mirror (yams_scan_pq_topk_device) ------------------------------------
+yams_status_t vs_pq_index_set(void*, uint64_t id, const uint8_t* codes, uint64_t n_codes, uint32_t m, const uint64_t* tie_keys,
+                              const uint32_t* row_of_index) {
+    NEED_INIT();
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (c->sh.size() != 1) return YAMS_ERR_UNSUPPORTED;      // (a PQ index over a striped corpus: not built)
+    c->pq.release();
+    if (n_codes == 0) return YAMS_OK;
+    if (!codes || m == 0 || m > 128 || n_codes >= (1ull << 32)) return YAMS_ERR_INVALID_ARG;
+    // rank of every tie-break key (ascending key, equal keys by index: the comparator of :3985-3990) and the mirror row
+    // behind every key index — once per index build, on the host
+    std::vector<uint32_t> order(n_codes), rank(n_codes), key_row(n_codes);
+    std::iota(order.begin(), order.end(), 0u);
+    if (tie_keys)
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tie_keys[a] != tie_keys[b] ? tie_keys[a] < tie_keys[b] : a < b; });
+    for (uint64_t r = 0; r < n_codes; ++r) { rank[order[r]] = static_cast<uint32_t>(r); key_row[r] = row_of_index ? row_of_index[order[r]] : order[r]; }
+    PqIndex p; p.device = c->sh[0].device; p.n = n_codes; p.m = m;
+    (void)hipSetDevice(p.device);
+    Lease<yams_accel_ctx*> w(g.work_ctx);
+    const size_t code_bytes = (static_cast<size_t>(n_codes) * m + 15) & ~static_cast<size_t>(15);
+    bool ok = yams_accel::ya_malloc(reinterpret_cast<void**>(&p.codes), code_bytes) == hipSuccess &&
+              yams_accel::ya_malloc(reinterpret_cast<void**>(&p.tie_rank), n_codes * 4) == hipSuccess &&
+              yams_accel::ya_malloc(reinterpret_cast<void**>(&p.key_row), n_codes * 4) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); p.release(); return YAMS_ERR_RESOURCE_EXHAUSTED; }
+    ok = yams_accel_upload(w.v, p.codes, codes, static_cast<size_t>(n_codes) * m) == YAMS_OK &&
+         yams_accel_upload(w.v, p.tie_rank, rank.data(), n_codes * 4) == YAMS_OK &&
+         yams_accel_upload(w.v, p.key_row, key_row.data(), n_codes * 4) == YAMS_OK;
+    if (!ok) { p.release(); return YAMS_ERR_INTERNAL; }
+    c->pq = p;
+    return YAMS_OK;
+}
+
+yams_status_t vs_search_pq(void*, uint64_t id, const float* queries, const float* luts, uint32_t nq, uint32_t dim, uint32_t k,
+                           float threshold, uint32_t rerank_factor, uint32_t flags, const uint32_t* candidates, uint64_t n_candidates,
+                           yams_scan_hit_t** out_hits, uint32_t** out_counts, yams_scan_diag_t* out_diag) {
+    NEED_INIT();
+    if (!out_hits || !out_counts) return YAMS_ERR_INVALID_ARG;
+    *out_hits = nullptr; *out_counts = nullptr;
+    if (k > YAMS_SCAN_MAX_K) return YAMS_ERR_UNSUPPORTED;
+    auto c = find_corpus(id);
+    if (!c) return YAMS_ERR_NOT_FOUND;
+    if (dim != c->dim) return YAMS_ERR_INVALID_ARG;
+    if (nq && (!queries || !luts)) return YAMS_ERR_INVALID_ARG;
+    if (candidates == nullptr) n_candidates = 0;
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (c->sh.size() != 1) return YAMS_ERR_UNSUPPORTED;
+    const ShardStore& s = c->sh[0];
+    const PqIndex& p = c->pq;
+    const size_t slots = static_cast<size_t>(nq) * std::max<uint32_t>(k, 1);
+    auto* counts = static_cast<uint32_t*>(std::calloc(std::max<uint32_t>(nq, 1), sizeof(uint32_t)));
+    auto* hits = static_cast<yams_scan_hit_t*>(std::calloc(std::max<size_t>(slots, 1), sizeof(yams_scan_hit_t)));
+    if (!counts || !hits) { std::free(counts); std::free(hits); return YAMS_ERR_INTERNAL; }
+    auto done = [&](yams_status_t st) { if (st != YAMS_OK) { std::free(counts); std::free(hits); } else { *out_hits = hits; *out_counts = counts; } return st; };
+    for (size_t o = 0; o < slots; ++o) hits[o].row = -1;
+    // no index (or an empty one), no rows, k == 0, an empty candidate list: nothing (:3873-3880, :3946-3948)
+    if (nq == 0 || k == 0 || p.n == 0 || s.n_rows == 0 || (candidates && n_candidates == 0)) { if (out_diag) std::memset(out_diag, 0, sizeof *out_diag); return done(YAMS_OK); }
+    (void)hipSetDevice(s.device);
+    Lease<yams_accel_ctx*> w(g.work_ctx);
+    yams_accel_ctx* x = w.v;
+    float* d_q; float* d_l; uint32_t* d_c = nullptr; float* d_s; int64_t* d_r; uint32_t* d_n;
+    yams_status_t st;
+    if ((st = yams_accel::ws_get(x, "plugin_pq_queries", static_cast<size_t>(nq) * dim * 4, (void**)&d_q)) != YAMS_OK) return done(st);
+    if ((st = yams_accel::ws_get(x, "plugin_pq_luts", static_cast<size_t>(nq) * p.m * 1024, (void**)&d_l)) != YAMS_OK) return done(st);
+    if (candidates && (st = yams_accel::ws_get(x, "plugin_pq_candidates", n_candidates * 4, (void**)&d_c)) != YAMS_OK) return done(st);
+    if ((st = yams_accel::ws_get(x, "plugin_pq_scores", slots * 4, (void**)&d_s)) != YAMS_OK) return done(st);
+    if ((st = yams_accel::ws_get(x, "plugin_pq_rows", slots * 8, (void**)&d_r)) != YAMS_OK) return done(st);
+    if ((st = yams_accel::ws_get(x, "plugin_pq_counts", static_cast<size_t>(nq) * 4, (void**)&d_n)) != YAMS_OK) return done(st);
+    if (yams_accel_upload(x, d_q, queries, static_cast<size_t>(nq) * dim * 4) != YAMS_OK ||
+        yams_accel_upload(x, d_l, luts, static_cast<size_t>(nq) * p.m * 1024) != YAMS_OK ||
+        (candidates && yams_accel_upload(x, d_c, candidates, n_candidates * 4) != YAMS_OK)) return done(YAMS_ERR_INTERNAL);
+    yams_scan_corpus_t v;
+    std::memset(&v, 0, sizeof v);
+    v.rows = s.rows.as<float>(); v.n_rows = s.n_rows; v.dim = c->dim;
+    if (s.has_tie) { v.tie_rank = s.tie.as<uint32_t>(); v.rank_row = s.inv.as<uint32_t>(); }
+    yams_scan_pq_index_t pi{p.codes, p.n, p.m, 0, p.tie_rank, p.key_row};
+    yams_scan_pq_params_t prm{k, threshold, rerank_factor, flags & YAMS_PQ_SUM_MASK};
+    if ((st = yams_scan_pq_topk_device(x, &v, &pi, d_q, d_l, nq, &prm, d_c, n_candidates, d_s, d_r, d_n, out_diag)) != YAMS_OK) return done(st);
+    std::vector<float> scores(slots); std::vector<int64_t> rows(slots);
+    if (yams_accel_download(x, counts, d_n, static_cast<size_t>(nq) * 4) != YAMS_OK || yams_accel_download(x, scores.data(), d_s, slots * 4) != YAMS_OK ||
+        yams_accel_download(x, rows.data(), d_r, slots * 8) != YAMS_OK) return done(YAMS_ERR_INTERNAL);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t i = 0; i < k && i < counts[q]; ++i) {
+            const size_t o = static_cast<size_t>(q) * k + i;
+            hits[o].row = rows[o]; hits[o].similarity = scores[o]; hits[o].distance = 1.0f - scores[o];
+        }
+    ++g.searches;
+    return done(YAMS_OK);
+}
+
 void vs_free_hits(void*, yams_scan_hit_t* hits, uint32_t* counts) { std::free(hits); std::free(counts); }
 
 yams_status_t vs_runtime_info(void*, char** out_json) {
@@ -777,7 +884,7 @@ yams_vector_scan_v1 g_vector_scan = {
     YAMS_IFACE_VECTOR_SCAN_V1_VERSION, nullptr, GUARDED(vs_corpus_create), GUARDED(vs_corpus_append),
     GUARDED(vs_corpus_set_tie_ranks), GUARDED(vs_corpus_clear), GUARDED(vs_corpus_destroy), GUARDED(vs_corpus_size),
     GUARDED(vs_search_batch), GUARDED(vs_free_hits), GUARDED(vs_runtime_info), GUARDED(vs_free_string),
-    GUARDED(vs_search_batch_masked), GUARDED(vs_search_batch_ex)};
+    GUARDED(vs_search_batch_masked), GUARDED(vs_search_batch_ex), GUARDED(vs_pq_index_set), GUARDED(vs_search_pq)};
 
 // ---- content_hash_v1 --------------------------------------------------------------------------
 // Every call leases one of the plugin's work contexts (own stream, own workspace), so hashing, chunking

@@ -113,7 +113,7 @@ yams_status_t run_exact(yams_accel_ctx* ctx, const ScanIo& io, const double* d_q
         R.cand = res; R.cand_stride = res_stride; R.n_cand = std::min<uint32_t>(keep, kRescoreMax);
         R.tau = nullptr; R.list_count = nullptr; R.list_cap = 0; R.all_rows_listed = 1;
         R.qmap = d_qmap + b0; R.n_slots = nb; R.k = io.prm.k; R.threshold = io.prm.similarity_threshold;
-        R.flags = io.prm.flags; R.err_bound = 0.0;
+        R.flags = io.prm.flags & ~kRescoreFlagPqRerank; R.err_bound = 0.0;
         R.out_scores = io.out_scores; R.out_rows = io.out_rows; R.out_counts = io.out_counts;
         R.out_dist = io.out_dist; R.out_ranks = io.out_ranks; R.out_status = d_status;
         R.stat_rescored = d_stat;
@@ -543,7 +543,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             R.n_stripes = corpus->n_stripes; R.stripe_index = corpus->stripe_index; R.cand = res; R.cand_stride = res_stride;
             R.n_cand = n_cand; R.tau = d_tau; R.list_count = d_lcount; R.list_cap = plan.list_cap;
             R.all_rows_listed = 0; R.qmap = d_qmap; R.n_slots = n_slots; R.k = k;
-            R.threshold = params->similarity_threshold; R.flags = params->flags;
+            R.threshold = params->similarity_threshold; R.flags = params->flags & ~kRescoreFlagPqRerank;
             R.err_bound = err_bound; R.out_scores = out_scores; R.out_rows = out_rows;
             R.out_counts = out_counts; R.out_dist = out_dist; R.out_ranks = out_ranks;
             R.out_status = d_status; R.stat_rescored = d_stat; R.q_over = d_qover;

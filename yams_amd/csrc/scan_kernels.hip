@@ -756,8 +756,10 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     for (uint32_t round = 0; round < n_rounds; ++round) {
         const uint32_t c = round * blockDim.x + threadIdx.x;
         const uint64_t ck = c < a.n_cand ? cand[c] : 0;
-        const bool live = ck != 0;
-        const uint32_t row = live ? (a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck)) : 0u;
+        bool live = ck != 0;
+        uint32_t row = live ? (a.rank_row ? a.rank_row[key_idx(ck)] : key_idx(ck)) : 0u;
+        // (the product-quantised engine: an indexed row the vectors table no longer holds is skipped, sqlite_vec_backend.cpp:4010-4012)
+        if ((a.flags & kRescoreFlagPqRerank) && row >= a.n_rows) { live = false; row = 0u; }
         const float* x = a.rows + static_cast<uint64_t>(row) * dim;
         if (live) ++local_rescored;
         double nsq = 0.0, dot = 0.0;
@@ -854,7 +856,18 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             if (METRIC == YAMS_SCAN_L2) l2_sum_tail(l2, x, sq, 0, dim);
         }
         const uint32_t rank = a.tie_rank ? a.tie_rank[row] : row;
-        if (METRIC == YAMS_SCAN_COSINE) {
+        if (METRIC == YAMS_SCAN_COSINE && (a.flags & kRescoreFlagPqRerank)) {
+            // the product-quantised engine's re-rank (:4023-4040): computeCosineSimilarity(query, embedding) — each norm's own
+            // square root, 0 when either is zero, NO small-norm rule — then the threshold.  (A row with a non-finite component
+            // cannot be stored, vector_database.cpp:1771-1784: it is left out rather than ranked by a NaN.)
+            if (!isfinite(nsq)) continue;
+            const double na = qn, nb = sqrt(nsq);
+            const double cs = (na == 0.0 || nb == 0.0) ? 0.0 : dot / (na * nb);
+            const float sim = static_cast<float>(cs);
+            if (sim < a.threshold || sim != sim) continue;
+            skey[c] = pack_key(sim, rank);
+            sidx[c] = c;
+        } else if (METRIC == YAMS_SCAN_COSINE) {
             // all elements finite <=> nsq finite (fp64 cannot overflow on fp32 squares)
             // :4258-4269; the record path drops norm^2 < 1e-10 instead (isZeroNormEmbedding, :204-211)
             if (!isfinite(nsq) || ((a.flags & YAMS_SCAN_FLAG_RECORD_PATH) ? nsq < 1e-10 : nsq <= 1e-12)) continue;
