@@ -105,6 +105,19 @@ def compact_line(out):
                                   "filter_candidates", "exact_fallback_queries", "results_identical_to_the_oracle_run", "oracle_queries", "error"))
         if "error" in c["config2"]:
             c["config2"]["error"] = _short(c["config2"]["error"], 200)
+    nu = out.get("non_uniform")
+    if nu:      # one summary object: step time per distribution, the proof outcomes, the oracle verdicts
+        c["non_uniform"] = {}
+        for kd, v in nu.items():
+            if not isinstance(v, dict):
+                continue
+            if "error" in v:
+                c["non_uniform"][kd + "_error"] = _short(v["error"], 120)
+                continue
+            c["non_uniform"][kd + "_ms_per_step"] = v.get("ms_per_step")
+            esc = v.get("escalated_queries")
+            c["non_uniform"][kd + "_escalated_queries"] = (sum(esc) / len(esc)) if isinstance(esc, list) and esc else esc
+            c["non_uniform"][kd + "_bit_exact"] = v.get("bit_exact_vs_oracle")
     ca = out.get("c_abi_sharded")
     if ca:
         c["c_abi_sharded"] = _pick(ca, ("n_devices", "collective", "communicator_ranks", "collectives", "batches", "ms_per_step", "value",
@@ -204,6 +217,9 @@ def parse():
                          "digest; one in eight also through oracle/_ref — ~40 s on 16 host threads at 100 GiB")
     ap.add_argument("--verify-sample-ingest", dest="verify_all_ingest", action="store_false",
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
+    ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic (a throughput leg each on the headline shape; 64 oracle queries each)")
+    ap.add_argument("--only-distribution", action="store_true", help="run the --distribution legs alone")
+    ap.add_argument("--no-distribution-legs", action="store_true", help="skip the clustered / anisotropic legs of the default run")
     ap.add_argument("--no-config2-leg", action="store_true", help="skip the BASELINE config 2 (1M x 384, Q = 256) leg")
     ap.add_argument("--only-config2", action="store_true", help="run the BASELINE config 2 leg alone (profiling)")
     ap.add_argument("--config2-lanes", type=int, default=4, help="search lanes of the config 2 leg")
@@ -1157,6 +1173,137 @@ def config2_leg(a, torch, dev, local, lane_counts=None, batches=None, oracle_que
     return leg
 
 
+def distribution_leg(a, torch, dev, local, kind):
+    """The headline shape (rows_per_gpu x dim, query batch, k) on a corpus that is NOT uniform on the sphere — real embedding
+    corpora are clustered and anisotropic (the reference stores what its embedding models emit, src/vector/vector_database.cpp:
+    1771-1784), and the filter's cost depends on the data: tau comes from a 1/64 row sample, the bound from per-64-row-block
+    residues.  kind = "clustered": 10 000 Gaussian clusters (sigma = 0.35 of the centre's norm per dimension scale), queries are
+    perturbed cluster centres; "anisotropic": independent normal components with a power-law variance (j^-1), the shape of a text
+    embedding's spectrum.  Rows are generated in HBM with torch (plumbing), normalised in fp32.  Reports the step time, the
+    filter launch, the candidate and re-score volumes, the proof outcomes, and checks 64 queries against the oracle."""
+    import threading
+    import numpy as np
+    from yams_amd.accel import Accel, SweepGate
+    from yams_amd._lib import SCAN_COSINE
+    n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + (11 if kind == "clustered" else 13))
+    tc = torch.empty((n, d), dtype=torch.float32, device=dev)
+    chunk = 1 << 20
+    if kind == "clustered":
+        n_c = 10_000
+        centres = torch.randn((n_c, d), generator=g, device=dev)
+        centres /= centres.norm(dim=1, keepdim=True)
+        sigma = 0.35 / (d ** 0.5)
+        for r0 in range(0, n, chunk):
+            m = min(chunk, n - r0)
+            cid = torch.randint(0, n_c, (m,), generator=g, device=dev)
+            x = centres[cid] + sigma * torch.randn((m, d), generator=g, device=dev)
+            tc[r0:r0 + m] = x / x.norm(dim=1, keepdim=True)
+        def make_queries():
+            cid = torch.randint(0, n_c, (nq,), generator=g, device=dev)
+            x = centres[cid] + sigma * torch.randn((nq, d), generator=g, device=dev)
+            return (x / x.norm(dim=1, keepdim=True)).contiguous()
+    elif kind == "anisotropic":
+        scale = (torch.arange(1, d + 1, device=dev, dtype=torch.float32) ** -0.5)
+        for r0 in range(0, n, chunk):
+            m = min(chunk, n - r0)
+            x = torch.randn((m, d), generator=g, device=dev) * scale
+            tc[r0:r0 + m] = x / x.norm(dim=1, keepdim=True)
+        def make_queries():
+            x = torch.randn((nq, d), generator=g, device=dev) * scale
+            return (x / x.norm(dim=1, keepdim=True)).contiguous()
+    else:
+        raise ValueError(kind)
+    n_qb = 4
+    tqs = [make_queries() for _ in range(n_qb)]
+    torch.cuda.synchronize()        # (the lanes' streams are not torch's: the rows and queries must have landed)
+    acc0 = Accel(local, torch.cuda.current_stream().cuda_stream)
+    tb = torch.empty((n, d), dtype=torch.bfloat16, device=dev); tn = torch.empty(n, dtype=torch.float32, device=dev)
+    acc0.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
+    t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device=dev)
+    tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
+    mean_res = acc0.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
+    view = acc0.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
+                            rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
+    acc0.synchronize()
+    lanes = max(1, a.lanes)
+    streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+    accs = [acc0] + [Accel(local, st.cuda_stream) for st in streams[1:]]
+    outs = [(torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev),
+             torch.empty(nq, dtype=torch.int32, device=dev)) for _ in range(lanes)]
+    gate = SweepGate(local) if lanes > 1 else None
+    for c in accs:
+        c.set_gate(gate)
+
+    def run(count):
+        errs = []
+
+        def lane_fn(lane):
+            try:
+                torch.cuda.set_device(dev)
+                o = outs[lane]
+                for i in range(lane, count, lanes):
+                    accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(),
+                                                o[2].data_ptr(), flags=0, want_diag=False)
+            except BaseException as e:       # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=lane_fn, args=(l,)) for l in range(lanes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+    run(max(2 * lanes, a.warmup))
+    for c in accs:
+        c.enable_timing(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    tot, cnt = 0.0, 0
+    for c in accs:
+        ms, n_ = c.kernel_ms("scan_filter")
+        if ms is not None and n_:
+            tot += ms * n_; cnt += n_
+        c.enable_timing(False)
+    o = outs[0]
+    diags = []
+    for b in range(n_qb):       # the proof outcomes of every query batch
+        diags.append(accs[0].scan_topk_device(view, tqs[b].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                              flags=0, want_diag=True))
+    torch.cuda.synchronize()
+    last = n_qb - 1
+    leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
+           "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res,
+           "filter_tier": diags[0].get("filter_tier"),
+           **{kk: [dg.get(kk) for dg in diags] for kk in ("filter_candidates", "rescored_rows", "widened_queries", "escalated_queries", "exact_fallback_queries")}}
+    n_oq = 64 if a.oracle_queries is None else min(64, a.oracle_queries)
+    if n_oq > 0:
+        _o = oracle_mod()
+        qsel = [int(x) for x in np.linspace(0, nq - 1, n_oq).round()]
+        qh = tqs[last][qsel].cpu().numpy()
+        t_or = time.perf_counter()
+        part = _o.scan_threaded(lambda lo, hi: tc[lo:hi].cpu().numpy(), n, qh, k, slice_rows=32768, threads=min(_o.host_threads(), 96))
+        t_or = time.perf_counter() - t_or
+        rr = o[1].cpu().numpy(); ss = o[0].cpu().numpy(); cc = o[2].cpu().numpy()
+        exact = True
+        for j, qi in enumerate(qsel):
+            rows, sims = part[j][0], part[j][1]
+            exact &= bool(cc[qi] == len(rows) and np.array_equal(rr[qi, :len(rows)], rows)
+                          and np.array_equal(ss[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+        leg["bit_exact_vs_oracle"] = exact; leg["oracle_queries"] = n_oq; leg["oracle_seconds"] = t_or
+    for c in accs:
+        c.set_gate(None)
+    for c in accs[1:]:
+        c.close()
+    if gate is not None:
+        gate.close()
+    del tc, tb, tn, t8, tm8, view, outs, tqs
+    acc0.close()
+    torch.cuda.empty_cache()
+    return leg
+
+
 def c_abi_main(a):
     """`bench.py --gpus N --via-c-abi`: the whole job from ONE process through the C ABI; prints the contract's line."""
     devices = [0] * a.gpus if a.single_device else list(range(a.gpus))
@@ -1252,6 +1399,11 @@ def main():
                          "one rank per GPU (use --single-device --dist-backend gloo for a dry run)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.only_distribution:
+        res = {kd: distribution_leg(a, torch, dev, local, kd) for kd in (a.distribution or "clustered,anisotropic").split(",")}
+        sys.stderr.write("distribution: " + json.dumps(_clean(res)) + "\n")
+        _print_on_real_stdout(json.dumps(_clean(res), allow_nan=False))
+        return
     if a.only_config2:
         sweep = [int(x) for x in a.config2_lane_sweep.split(",")] if a.config2_lane_sweep else None
         leg = config2_leg(a, torch, dev, local, lane_counts=sweep, batches=a.config2_batches, oracle_queries=a.oracle_queries)
@@ -1912,6 +2064,12 @@ def main():
             out["boundary"] = {"error": repr(e)}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_scan(tc, tq, n, k)
+    if not a.no_distribution_legs and world == 1 and n >= 1_000_000:
+        # the same shape on corpora that are not uniform on the sphere (after the headline's tensors are gone: each leg builds
+        # a shard of its own)
+        pending_distributions = [kd for kd in (a.distribution or "clustered,anisotropic").split(",") if kd]
+    else:
+        pending_distributions = []
     if not a.no_config2_leg and world == 1:
         try:
             sweep = [int(x) for x in a.config2_lane_sweep.split(",")] if a.config2_lane_sweep else None
@@ -1925,6 +2083,19 @@ def main():
         acc = Accel(local, torch.cuda.current_stream().cuda_stream)
         torch.cuda.empty_cache()
         out["ingest"] = ingest_leg(acc, torch, a.ingest_gib, a.seed, verify_all=a.verify_all_ingest)
+    if pending_distributions:
+        try:
+            del tc, tb, tn, t8, tm8, view, pipe, res
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        nu = {}
+        for kd in pending_distributions:
+            try:
+                nu[kd] = distribution_leg(a, torch, dev, local, kd)
+            except Exception as e:      # noqa: BLE001 - the headline number above stands on its own
+                nu[kd] = {"error": repr(e)}
+        out["non_uniform"] = nu
     emit(out, a.extra_json)
 
 
