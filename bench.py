@@ -219,6 +219,7 @@ def parse():
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
     ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic (a throughput leg each on the headline shape; 64 oracle queries each)")
     ap.add_argument("--only-distribution", action="store_true", help="run the --distribution legs alone")
+    ap.add_argument("--dist-flags", type=int, default=0, help="YAMS_SCAN_FLAG_* bits of the distribution legs' searches (measurement: 64 = no int8 tier)")
     ap.add_argument("--no-distribution-legs", action="store_true", help="skip the clustered / anisotropic legs of the default run")
     ap.add_argument("--no-config2-leg", action="store_true", help="skip the BASELINE config 2 (1M x 384, Q = 256) leg")
     ap.add_argument("--only-config2", action="store_true", help="run the BASELINE config 2 leg alone (profiling)")
@@ -1244,7 +1245,7 @@ def distribution_leg(a, torch, dev, local, kind):
                 o = outs[lane]
                 for i in range(lane, count, lanes):
                     accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(),
-                                                o[2].data_ptr(), flags=0, want_diag=False)
+                                                o[2].data_ptr(), flags=a.dist_flags, want_diag=False)
             except BaseException as e:       # noqa: BLE001
                 errs.append(e)
         th = [threading.Thread(target=lane_fn, args=(l,)) for l in range(lanes)]
@@ -1270,7 +1271,7 @@ def distribution_leg(a, torch, dev, local, kind):
     diags = []
     for b in range(n_qb):       # the proof outcomes of every query batch
         diags.append(accs[0].scan_topk_device(view, tqs[b].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
-                                              flags=0, want_diag=True))
+                                              flags=a.dist_flags, want_diag=True))
     torch.cuda.synchronize()
     last = n_qb - 1
     leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,

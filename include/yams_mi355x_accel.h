@@ -262,7 +262,8 @@ typedef struct yams_scan_diag_s {
     uint32_t escalated_queries;           /* queries re-filtered with the split (3-pass) filter  */
     uint32_t filter_tier;                 /* first filter tier of the call: 0 none (fp64 scan),
                                              1 int8, 2 bf16, 3 split bf16, 4 f32                  */
-    uint32_t reserved;
+    uint32_t retried_queries;             /* int8 tier: queries filtered a second time with the threshold their proof asked for
+                                             (the k-th best exact score found), before any escalation (was: reserved)  */
 } yams_scan_diag_t;
 
 /* Builds the filter shadow of `n_rows` rows (call it when rows are uploaded or appended; pass

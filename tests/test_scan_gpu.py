@@ -1790,3 +1790,62 @@ def test_hip_l2_scan_reproduces_the_reference_compiled_vec0_golden_vectors(acc, 
                 assert [int(x) for x in r.scores[qi, :cnt].view(np.uint32)] == e["score_bits"], (case["name"], name, qi)
                 n_checked += 1
     assert n_checked >= (60 if shadow == "both" else 150)
+
+
+# ---- corpora that are not uniform on the sphere (round 6) --------------------------------------------------------------------
+def _clustered(n, d, n_clusters, seed, nq):
+    rng = np.random.default_rng(seed)
+    centres = rng.standard_normal((n_clusters, d)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    sigma = np.float32(0.35 / np.sqrt(d))
+    x = centres[rng.integers(0, n_clusters, n)] + sigma * rng.standard_normal((n, d)).astype(np.float32)
+    q = centres[rng.integers(0, n_clusters, nq)] + sigma * rng.standard_normal((nq, d)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32), (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_clustered_corpus_is_proven_by_the_int8_retry(acc, oracle):
+    """Queries near the centre of a cluster of ~1000 rows whose similarities differ by less than the int8 bound is wide: the
+    sampled threshold sits inside the cloud and every proof of stage 1 fails.  Stage 2a filters those queries again on the
+    int8 tier with the threshold the proof asks for — the k-th best exact score found, one ulp down — and proves them without
+    the split-bf16 sweep; rows, order and score bits equal the oracle's."""
+    corpus, q = _clustered(300_000, 256, 230, 71, 200)         # ~1300 rows per cluster: more than the sampled threshold lists
+    r = check(acc, oracle, corpus, q, 100, max_queries=24, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    assert r.diag["retried_queries"] >= 10, r.diag
+    assert r.diag["escalated_queries"] <= r.diag["retried_queries"] // 3 and r.diag["exact_fallback_queries"] == 0, r.diag
+    # the same through the resident-query form and with a threshold
+    r2 = check(acc, oracle, corpus, q, 50, thr=0.3, max_queries=12, expect_path=0, shadow="i8", flags=_lib.FLAG_RESIDENT_QUERIES)
+    assert r2.diag["retried_queries"] > 0, r2.diag
+
+
+def test_anisotropic_corpus_teaches_the_context_to_start_on_the_bf16_tier(acc, oracle):
+    """Rows with a power-law spectrum (a few large components, a long tail): the int8 shadow's residue — hence its bound — is
+    several times the isotropic one, every query of an int8 batch escalates.  The context remembers that per corpus: the
+    next batches of more than 128 queries start on the bf16 tier (no escalation), results identical and oracle-exact."""
+    import torch
+    rng = np.random.default_rng(72)
+    n, d, nq, k = 200_000, 256, 160, 50
+    scale = (np.arange(1, d + 1, dtype=np.float32) ** -0.5)
+    x = (rng.standard_normal((n, d)).astype(np.float32) * scale); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    qs = (rng.standard_normal((nq, d)).astype(np.float32) * scale); qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    from yams_amd.accel import Accel
+    a2 = Accel(0, torch.cuda.current_stream().cuda_stream)       # a context of its own: what it learns must not leak into other tests
+    try:
+        tc = torch.from_numpy(x).cuda()
+        tb = torch.empty((n, d), dtype=torch.bfloat16, device="cuda"); tn = torch.empty(n, dtype=torch.float32, device="cuda")
+        a2.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
+        t8 = torch.empty((_lib.i8_shadow_rows(n), d), dtype=torch.int8, device="cuda"); tm = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
+        a2.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm.data_ptr())
+        v = a2.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(), rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm.data_ptr())
+        first = a2.scan_topk(v, qs, k, -1.0)
+        assert first.diag["filter_tier"] == _lib.TIER_I8, first.diag
+        later = a2.scan_topk(v, qs, k, -1.0)
+        if first.diag["escalated_queries"] * 2 > nq:             # the lesson: the int8 batch escalated, the next one starts on bf16
+            assert later.diag["filter_tier"] == 2 and later.diag["escalated_queries"] <= first.diag["escalated_queries"] // 4, (first.diag, later.diag)
+        assert np.array_equal(first.rows, later.rows) and np.array_equal(first.scores.view(np.uint32), later.scores.view(np.uint32))
+        for qi in range(0, nq, 13):
+            rows, sims, _, _ = oracle.scan_cosine(x, qs[qi], k, -1.0)
+            assert np.array_equal(later.rows[qi], rows) and np.array_equal(later.scores[qi].view(np.uint32), sims.view(np.uint32)), qi
+        small = a2.scan_topk(v, qs[:40], k, -1.0)                  # batches of <= 128 queries keep the library's usual choice
+        assert np.array_equal(small.rows, later.rows[:40])
+    finally:
+        a2.close()

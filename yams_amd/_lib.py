@@ -90,7 +90,7 @@ class ScanDiag(C.Structure):
                 ("returned_rows", C.c_uint64), ("filter_candidates", C.c_uint64),
                 ("rescored_rows", C.c_uint64), ("widened_queries", C.c_uint32),
                 ("exact_fallback_queries", C.c_uint32), ("path", C.c_uint32),
-                ("escalated_queries", C.c_uint32), ("filter_tier", C.c_uint32), ("reserved", C.c_uint32)]
+                ("escalated_queries", C.c_uint32), ("filter_tier", C.c_uint32), ("retried_queries", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}

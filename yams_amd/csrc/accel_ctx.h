@@ -41,6 +41,12 @@ struct yams_accel_ctx {
     // name prefix of ws_get: a nested scan (the split-filter escalation of a batch) works in its
     // own namespace, so the buffers of the call that is still in flight around it stay intact
     std::string ws_ns;
+    // What this context has learnt about a corpus's first filter tier (scan_api.cpp, "tier hint"): the int8 tier's bound is as
+    // wide as the shadow's quantisation residue — on strongly anisotropic rows (a few large components, a long tail of small
+    // ones) five times wider than on isotropic ones, and every query then fails its proof and pays a split-bf16 sweep on top.
+    // Keyed by the int8 shadow's address; `bf16_first` batches start on the bf16 tier, every 256th one probes int8 again.
+    struct TierHint { uint64_t n_rows = 0; bool bf16_first = false; uint32_t served = 0; };
+    std::map<const void*, TierHint> tier_hints;
     uint32_t emu_calls = 0; // measurement build: batches this context has served (emulation knobs of scan_api.cpp)
     // pinned host staging
     void* pinned = nullptr;

@@ -197,11 +197,20 @@ yams_status_t small_scan(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, 
     return YAMS_OK;
 }
 
+// The RETRY run of the int8 tier (round 6): queries whose proof failed are filtered again with a threshold nobody has to
+// estimate — the k-th best EXACT score stage 1 found for them (a lower bound of the final k-th best: no row whose upper bound
+// lies below it can enter the result).  On clustered corpora the sampled threshold sits inside a cloud of near-equal scores
+// and every query failed its proof; one more int8 sweep with this threshold lists exactly the rows that matter.
+struct TauRetry {
+    const float* forced_tau = nullptr;      // device [n_queries]: use instead of the sampled threshold
+    std::vector<uint32_t>* unproven = nullptr; // out: queries (of this run) still unproven — the caller escalates them
+};
+
 // split_only: this is the escalation run of a batch whose single-pass filter left queries unproven.
 yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, const float* queries,
                         uint32_t n_queries, const yams_scan_params_t* params, float* out_scores,
                         int64_t* out_rows, uint32_t* out_counts, float* out_dist,
-                        uint32_t* out_ranks, yams_scan_diag_t* diag, bool split_only) {
+                        uint32_t* out_ranks, yams_scan_diag_t* diag, bool split_only, const TauRetry* retry = nullptr) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
     if (!corpus || !params) return fail(ctx, YAMS_ERR_INVALID_ARG, "null corpus/params");
     if (diag) std::memset(diag, 0, sizeof(*diag));
@@ -244,7 +253,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         l2_view = *corpus; l2_view.tie_rank = nullptr; l2_view.rank_row = nullptr;
         corpus = &l2_view;
     }
-    if (!split_only && small_scan_applies(*corpus, n_queries, *params))
+    if (!split_only && !retry && small_scan_applies(*corpus, n_queries, *params))
         return small_scan(ctx, corpus, queries, n_queries, params, out_scores, out_rows, out_counts, out_dist, out_ranks, diag);
 
     const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
@@ -327,7 +336,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     }
 
     uint64_t filter_candidates = 0, rescored_nested = 0;
-    uint32_t widened = 0, exact_fb = 0, escalated = 0, filter_tier = 0;
+    uint32_t widened = 0, exact_fb = 0, escalated = 0, filter_tier = 0, retried = 0;
     std::vector<uint32_t> flags_keep; // h_flags survives a nested (escalation) call through this copy
     if (!use_mfma) {
         const uint32_t* d_rows_sel = nullptr;
@@ -373,6 +382,17 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         bool i8 = bf16 && passes == 1 && (metric == YAMS_SCAN_COSINE || l2_i8_ok) && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                   !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER);
+        // Tier hint: batches of more than 128 cosine queries on a corpus whose int8 batches keep escalating start on the bf16
+        // tier (anisotropic rows, 12.5M x 768, 1024 queries: 59.9 ms per step on the int8 tier — all 1024 queries escalate —
+        // 17.3 ms on the bf16 tier, no query widened; profiles/r06_non_uniform.json).  Learnt per context from the batches it
+        // has served, probed again every 256th batch; results are identical on every tier.
+        yams_accel_ctx::TierHint* hint = nullptr;
+        if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry && corpus->rows_bf16 && corpus->rows_nsq && nq > 128 &&
+            !(params->flags & (YAMS_SCAN_FLAG_RESIDENT_QUERIES | YAMS_SCAN_FLAG_WIDE_TILE))) {
+            hint = &ctx->tier_hints[corpus->rows_i8];
+            if (hint->n_rows != corpus->n_rows) { hint->n_rows = corpus->n_rows; hint->bf16_first = false; hint->served = 0; } // another corpus at this address
+            if (hint->bf16_first && (++hint->served & 255u) != 0) i8 = false;
+        }
 #ifdef YAMS_ACCEL_MEASURE
         // Measurement build only (libyams_mi355x_accel_measure.so, scripts/): kernel-form and
         // ablation selection from the environment.  The product library never reads it.
@@ -382,6 +402,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 99))) i8 = false;
 #endif
         ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2);
+        if (retry) plan.kprime = kRescoreMax;   // (the retry's lists are what the proof needs: all of a list is re-scored)
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
         if (corpus->rows_bf16 && corpus->rows_nsq && (reinterpret_cast<uintptr_t>(corpus->rows_bf16) & 15u) == 0) {
@@ -401,6 +422,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (i8 && metric == YAMS_SCAN_L2) {
             L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);
             plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, false); // (tile geometry unchanged: the form decision above stands)
+            if (retry) plan.kprime = kRescoreMax;
             L.plan = plan;
         }
         L.qprep = d_qprep; L.qnorm_up = d_qnorm_up;
@@ -441,6 +463,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "q_lo", static_cast<size_t>(q_pad) * dim * 2, (void**)&d_qlo)); // unused by the 1-pass kernel
             YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, bf16_slab_k(passes, dim), d_qhi, d_qlo));
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
+        }
+        if (retry && (!i8 || metric != YAMS_SCAN_COSINE)) {    // (the forced threshold is a value of the int8 tier's upper bound)
+            for (uint32_t i = 0; i < nq; ++i) retry->unproven->push_back(i);
+            return YAMS_OK;
         }
         float* d_tau; uint64_t* d_list; uint32_t* d_work32; uint64_t* d_work64;
         if (i8) L.dense = nullptr; // (the int8 sample pass keeps group maxima only, launch_i8_collect_sample)
@@ -490,7 +516,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 0, bf16_version));
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
-        YA_HIP(ctx, launch_select_tau(st, L, d_work32));
+        if (retry) YA_HIP(ctx, hipMemcpyAsync(d_tau, retry->forced_tau, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToDevice, st));
+        else YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         }
         if (emu_no_sample) {
             // (the lists lose the sample rows' candidates: results of the emulation are not checked)
@@ -569,6 +596,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
                 if (h_lcount[i] > plan.list_cap) overflowed.push_back(i); else failed.push_back(i);
             }
         }
+        if (retry) {    // the caller decides what happens to what is still unproven (its lists overflowed, or hold more than can be re-scored)
+            retry->unproven->insert(retry->unproven->end(), failed.begin(), failed.end());
+            retry->unproven->insert(retry->unproven->end(), overflowed.begin(), overflowed.end());
+            if (diag) { diag->filter_candidates = filter_candidates; diag->filter_tier = filter_tier; }
+            return YAMS_OK;
+        }
         if (!failed.empty() && plan.kprime < kRescoreMax) {
             // stage 2: widen to everything the list holds (up to kRescoreMax candidates)
             widened = static_cast<uint32_t>(failed.size());
@@ -582,12 +615,94 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             for (uint32_t q : failed) if (h_status[q] != 0) still.push_back(q);
             failed.swap(still);
         }
+        if (!failed.empty() && i8 && !L.i8_l2 && !split_only && k <= 1024) {
+            // stage 2a (round 6): the int8 tier once more, with the threshold the proof asks for.  For every unproven query
+            // stage 1 / 2 left the k best EXACT scores it found: no row whose upper bound lies below the k-th of them can be in
+            // the answer, so tau' = that score (one ulp down: the proof is a strict comparison) lists exactly what matters.
+            // The sample's group maxima say beforehand how many rows that will be: queries whose list would not fit go
+            // straight to the escalation below.
+            const size_t nf = failed.size();
+            float* d_rtau; uint32_t* d_rest; uint32_t* d_fmap;
+            YA_TRY(ws_get(ctx, "retry_tau", nf * 4, (void**)&d_rtau));
+            YA_TRY(ws_get(ctx, "retry_est", nf * 4, (void**)&d_rest));
+            YA_TRY(ws_get(ctx, "retry_fmap", nf * 4, (void**)&d_fmap));
+            YA_HIP(ctx, hipMemcpyAsync(d_fmap, failed.data(), nf * 4, hipMemcpyHostToDevice, st));
+            YA_HIP(ctx, launch_retry_tau(st, out_scores, out_counts, k, d_fmap, static_cast<uint32_t>(nf), L.gmax, plan.n_groups, d_rtau, d_rest));
+            std::vector<uint32_t> est(nf);
+            YA_HIP(ctx, hipMemcpyAsync(est.data(), d_rest, nf * 4, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            std::vector<uint32_t> sub, rest; // indices into `failed`
+            for (uint32_t i = 0; i < nf; ++i) {
+                // est = sample groups that reach tau' (0xffffffff: stage 1 found fewer than k rows): each stands for `stride` rows
+                const uint64_t rows_est = est[i] == 0xffffffffu ? ~0ull : static_cast<uint64_t>(est[i]) * plan.sample_stride;
+                (rows_est <= kRescoreMax * 3ull / 4 ? sub : rest).push_back(i);
+            }
+            if (!sub.empty()) {
+                const size_t ns = sub.size(), kk = k;
+                std::vector<uint32_t> sub_q(ns);
+                for (size_t i = 0; i < ns; ++i) sub_q[i] = failed[sub[i]];
+                float* s_q; float* s_scores; int64_t* s_rows; uint32_t* s_counts; float* s_dist = nullptr; uint32_t* s_ranks = nullptr;
+                uint32_t* d_submap; float* s_tau;
+                YA_TRY(ws_get(ctx, "sub_queries", ns * dim * 4, (void**)&s_q));
+                YA_TRY(ws_get(ctx, "sub_scores", ns * kk * 4, (void**)&s_scores));
+                YA_TRY(ws_get(ctx, "sub_rows", ns * kk * 8, (void**)&s_rows));
+                YA_TRY(ws_get(ctx, "sub_counts", ns * 4, (void**)&s_counts));
+                if (out_dist) YA_TRY(ws_get(ctx, "sub_dist", ns * kk * 4, (void**)&s_dist));
+                if (out_ranks) YA_TRY(ws_get(ctx, "sub_ranks", ns * kk * 4, (void**)&s_ranks));
+                YA_TRY(ws_get(ctx, "sub_qmap", ns * 4, (void**)&d_submap));
+                YA_TRY(ws_get(ctx, "sub_tau", ns * 4, (void**)&s_tau));
+                YA_HIP(ctx, hipMemcpyAsync(d_submap, sub_q.data(), ns * 4, hipMemcpyHostToDevice, st));
+                YA_HIP(ctx, launch_gather_queries(st, queries, d_submap, static_cast<uint32_t>(ns), dim, s_q));
+                std::vector<uint32_t> sub_slots(sub.begin(), sub.end());
+                uint32_t* d_subslots;
+                YA_TRY(ws_get(ctx, "sub_slots", ns * 4, (void**)&d_subslots));
+                YA_HIP(ctx, hipMemcpyAsync(d_subslots, sub_slots.data(), ns * 4, hipMemcpyHostToDevice, st));
+                YA_HIP(ctx, launch_gather_queries(st, d_rtau, d_subslots, static_cast<uint32_t>(ns), 1, s_tau));
+                YA_HIP(ctx, hipStreamSynchronize(st)); // (the host vectors above are pageable)
+                flags_keep.assign(h_flags, h_flags + nq);
+                std::vector<uint32_t> unproven;
+                TauRetry rt{s_tau, &unproven};
+                yams_scan_diag_t subd{};
+                {
+                    const std::string outer_ns = ctx->ws_ns;
+                    ctx->ws_ns = outer_ns + "retry/";
+                    const yams_status_t r_st = scan_impl(ctx, corpus, s_q, static_cast<uint32_t>(ns), params, s_scores, s_rows, s_counts, s_dist, s_ranks,
+                                                         &subd, false, &rt);
+                    ctx->ws_ns = outer_ns;
+                    YA_TRY(r_st);
+                }
+                retried = static_cast<uint32_t>(ns);
+                filter_candidates += subd.filter_candidates;
+                // the proven ones go back to their places; the others join the queries the escalation takes
+                std::vector<uint8_t> bad(ns, 0);
+                for (uint32_t u : unproven) bad[u] = 1;
+                std::vector<uint32_t> good_src, good_dst;
+                for (uint32_t i = 0; i < ns; ++i) {
+                    if (bad[i]) rest.push_back(sub[i]);
+                    else { good_src.push_back(i); good_dst.push_back(sub_q[i]); }
+                }
+                if (!good_src.empty()) {
+                    uint32_t* d_src; uint32_t* d_dst;
+                    YA_TRY(ws_get(ctx, "retry_src", good_src.size() * 4, (void**)&d_src));
+                    YA_TRY(ws_get(ctx, "retry_dst", good_dst.size() * 4, (void**)&d_dst));
+                    YA_HIP(ctx, hipMemcpyAsync(d_src, good_src.data(), good_src.size() * 4, hipMemcpyHostToDevice, st));
+                    YA_HIP(ctx, hipMemcpyAsync(d_dst, good_dst.data(), good_dst.size() * 4, hipMemcpyHostToDevice, st));
+                    YA_HIP(ctx, launch_scatter_results_from(st, d_src, d_dst, static_cast<uint32_t>(good_src.size()), k, s_scores, s_rows, s_counts, s_dist,
+                                                            s_ranks, out_scores, out_rows, out_counts, out_dist, out_ranks));
+                    YA_HIP(ctx, hipStreamSynchronize(st));
+                }
+            }
+            std::vector<uint32_t> still;
+            std::sort(rest.begin(), rest.end());
+            for (uint32_t i : rest) still.push_back(failed[i]);
+            failed.swap(still);
+        }
         if (!failed.empty() && passes == 1) {
             // stage 2b: precision escalation.  The unproven queries become their own small batch
             // under the split (3-pass) filter, whose bound is ~170x tighter; that run widens and
             // falls back to the exhaustive scan on its own.  Results are scattered back.
             escalated = static_cast<uint32_t>(failed.size());
-            flags_keep.assign(h_flags, h_flags + nq);
+            if (flags_keep.empty()) flags_keep.assign(h_flags, h_flags + nq); // (a retry run above has already taken the pinned words over)
             unsigned long long h_stat0 = 0;
             YA_HIP(ctx, hipMemcpyAsync(&h_stat0, d_stat, 8, hipMemcpyDeviceToHost, st));
             YA_HIP(ctx, hipStreamSynchronize(st));
@@ -627,6 +742,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             // d_stat was read into rescored_nested above; the nested call counted in its own buffer
             YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
         }
+        if (hint && i8) hint->bf16_first = static_cast<uint64_t>(escalated) * 2 > nq;    // (an int8 batch — first or probe — decides for the next 255)
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {
             // stage 3: exhaustive fp64 for the queries that could not be proven complete
@@ -671,6 +787,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         diag->widened_queries = widened;
         diag->exact_fallback_queries = exact_fb;
         diag->escalated_queries = escalated;
+        diag->retried_queries = retried;
         diag->filter_tier = filter_tier;
     }
     return YAMS_OK;

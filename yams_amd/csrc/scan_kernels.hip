@@ -1548,6 +1548,63 @@ __global__ void scatter_results_kernel(const uint32_t* qmap, uint32_t n_slots, u
     if (threadIdx.x == 0) counts[q] = s_counts[s];
 }
 
+// tau' of the int8 tier's retry (scan_api.cpp, stage 2a): for every unproven query the k-th best EXACT score the first stages
+// found, one ulp down (the proof compares strictly), and — from the sample pass's group maxima — how many sample groups reach
+// it (each stands for `stride` rows of the shard: the size of the list the retry will build).  Fewer than k rows found: no
+// usable threshold (est = 0xffffffff).  One workgroup per unproven query.
+__global__ __launch_bounds__(256) void retry_tau_kernel(const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap,
+                                                        const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {
+    __shared__ uint32_t s_cnt;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = fmap[slot];
+    if (counts[q] < k) {
+        if (threadIdx.x == 0) { tau_out[slot] = __builtin_inff(); est_out[slot] = 0xffffffffu; }
+        return;
+    }
+    const float sk = scores[static_cast<uint64_t>(q) * k + (k - 1)];
+    const float t = __uint_as_float(sk > 0.f ? __float_as_uint(sk) - 1u : (sk < 0.f ? __float_as_uint(sk) + 1u : 0x80000001u)); // the next float below
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t key = f2ord(t);
+    const uint32_t* g = gmax + static_cast<uint64_t>(q) * n_groups;
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < n_groups; i += 256) mine += (g[i] != 0xffffffffu && g[i] >= key) ? 1u : 0u;
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { tau_out[slot] = t; est_out[slot] = s_cnt; }
+}
+hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
+                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(retry_tau_kernel, dim3(n_slots), dim3(256), 0, st, scores, counts, k, fmap, gmax, n_groups, tau_out, est_out);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+// results of run slots src[i] -> the caller's queries dst[i]
+__global__ void scatter_results_from_kernel(const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t k, const float* s_scores,
+                                            const int64_t* s_rows, const uint32_t* s_counts, const float* s_dist, const uint32_t* s_ranks,
+                                            float* scores, int64_t* rows, uint32_t* counts, float* dist, uint32_t* ranks) {
+    const uint32_t i0 = blockIdx.x;
+    if (i0 >= n) return;
+    const uint64_t s = src[i0], q = dst[i0];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        scores[q * k + i] = s_scores[s * k + i];
+        rows[q * k + i] = s_rows[s * k + i];
+        if (dist) dist[q * k + i] = s_dist[s * k + i];
+        if (ranks) ranks[q * k + i] = s_ranks[s * k + i];
+    }
+    if (threadIdx.x == 0) counts[q] = s_counts[s];
+}
+hipError_t launch_scatter_results_from(hipStream_t st, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t k, const float* s_scores,
+                                       const int64_t* s_rows, const uint32_t* s_counts, const float* s_dist, const uint32_t* s_ranks,
+                                       float* scores, int64_t* rows, uint32_t* counts, float* dist, uint32_t* ranks) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_results_from_kernel, dim3(n), dim3(128), 0, st, src, dst, n, k, s_scores, s_rows, s_counts, s_dist, s_ranks,
+                       scores, rows, counts, dist, ranks);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_gather_queries(hipStream_t st, const float* queries, const uint32_t* qmap,
                                  uint32_t n_slots, uint32_t dim, float* out) {
     if (n_slots == 0 || dim == 0) return hipSuccess;

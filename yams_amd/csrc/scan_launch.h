@@ -169,6 +169,11 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R);
 hipError_t launch_merge(hipStream_t st, const MergeLaunch& M);
 hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
                                uint16_t* out_bf16, float* out_nsq);
+hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
+                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out);
+hipError_t launch_scatter_results_from(hipStream_t st, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t k, const float* s_scores,
+                                       const int64_t* s_rows, const uint32_t* s_counts, const float* s_dist, const uint32_t* s_ranks,
+                                       float* scores, int64_t* rows, uint32_t* counts, float* dist, uint32_t* ranks);
 hipError_t launch_gather_queries(hipStream_t st, const float* queries, const uint32_t* qmap,
                                  uint32_t n_slots, uint32_t dim, float* out);
 hipError_t launch_scatter_results(hipStream_t st, const uint32_t* qmap, uint32_t n_slots, uint32_t k,
