@@ -108,6 +108,11 @@ YAMS_ACCEL_API const char* yams_accel_last_error(const yams_accel_ctx* ctx);
 /* Device properties as a JSON string (malloc'd; release with yams_accel_free_string). */
 YAMS_ACCEL_API yams_status_t yams_accel_device_info_json(yams_accel_ctx* ctx, char** out_json);
 YAMS_ACCEL_API void yams_accel_free_string(char* s);
+/* The library keeps the call-sized device buffers of its host-streaming entry points (yams_ingest_host: up to four of 8 GiB)
+ * in a process-wide pool between calls — allocating them anew cost every call hundreds of milliseconds — up to 40 GiB per
+ * process; the pool is emptied when one of the library's own allocations fails, and by this call.  device < 0: every device.
+ * Returns the bytes handed back to the driver. */
+YAMS_ACCEL_API uint64_t yams_accel_trim(int device);
 /* Plain device memory helpers for hosts that do not bring their own allocator. */
 YAMS_ACCEL_API yams_status_t yams_accel_malloc(yams_accel_ctx* ctx, size_t bytes, void** out_dev);
 YAMS_ACCEL_API void yams_accel_free(yams_accel_ctx* ctx, void* dev);

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 ulimit -c 0
 REPO=$PWD; OUT=$REPO/gpurun_out
-B="python $REPO/bench.py --steps 20 --warmup 5 --oracle-queries 0 --no-cpu-baseline --no-ingest --no-hbm-leg --no-l2-leg --no-c-abi-leg --no-boundary-leg --no-telemetry"   # (the HBM leg runs the same kernel at Q = 64: profiled apart, below, so that this trace averages ONE workload)
+B="python $REPO/bench.py --steps 20 --warmup 5 --oracle-queries 0 --no-cpu-baseline --no-ingest --no-hbm-leg --no-l2-leg --no-c-abi-leg --no-boundary-leg --no-telemetry --no-config2-leg --no-distribution-legs"   # (the HBM leg runs the same kernel at Q = 64: profiled apart, below, so that this trace averages ONE workload)
 # (bench.py builds the bf16 filter shadow before the timed region; shadow_build_kernel shows up once in the trace)
 I="python $REPO/scripts/ingest_bench.py --gib 100 --reps 2"
 rm -rf $OUT/prof_trace $OUT/prof_ingest $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3
@@ -24,3 +24,11 @@ rm -rf $OUT/prof_small $OUT/prof_small_pmc
 rm -rf $OUT/prof_ingest_pmc1 $OUT/prof_ingest_pmc2
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -f csv -d $OUT/prof_ingest_pmc1 -o ingest -- $I > $OUT/prof_ingest_pmc1.log 2>&1) || true
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_ingest_pmc2 -o ingest -- $I > $OUT/prof_ingest_pmc2.log 2>&1) || true
+
+# BASELINE config 2 (1M x 384, 256 queries, two lanes): the kernels of its step and the sweep's HBM traffic
+C2="python $REPO/bench.py --only-config2 --config2-lane-sweep 2 --config2-batches 200 --oracle-queries 0"
+rm -rf $OUT/prof_c2 $OUT/prof_c2_pmc
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_c2 -o c2 -- $C2 > $OUT/prof_c2.log 2>&1) || true
+(cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/prof_c2_pmc -o c2 -- $C2 > $OUT/prof_c2_pmc.log 2>&1) || true
+# the traces themselves are large: only the summaries travel back
+find $OUT/prof_* -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null || true

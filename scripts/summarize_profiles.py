@@ -32,13 +32,13 @@ copy(os.path.join(G, "prof_small", "small_kernel_stats.csv"), os.path.join(P, f"
 f = os.path.join(G, "prof_small_pmc", "small_counter_collection.csv")
 if os.path.exists(f):
     rows_ = list(csv.DictReader(open(f)))
-    v = [float(r["Counter_Value"]) for r in rows_ if ("scan_tiles_i8r_kernel<0>" in r["Kernel_Name"] or "scan_tiles_i8r_kernel<0, false" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
+    v = [float(r["Counter_Value"]) for r in rows_ if ("scan_tiles_i8r_kernel<0>" in r["Kernel_Name"] or "scan_tiles_i8r_kernel<0, false" in r["Kernel_Name"] or "scan_tiles_i8d_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
     small_i8 = bool(v)
     if not v:
         v = [float(r["Counter_Value"]) for r in rows_ if "bf16n_kernel<1," in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
     if v:
         fs = sum(v) / len(v)
-        out = {"kernel": "scan_tiles_i8r_kernel (int8 shadow, one resident 128-query tile per CU, Q <= 128)" if small_i8 else
+        out = {"kernel": "scan_tiles_i8d_kernel / i8r (int8 shadow, one resident 128-query tile per CU, Q <= 128)" if small_i8 else
                          "scan_tiles_bf16n_kernel<COSINE, 2> (narrow filter, Q <= 64)", "rows_per_gpu": 12_500_000,
                "dim": 768, "queries": 64, "fetch_size_kib": fs, "hbm_bytes_per_launch": 2.0 * fs * 1024.0,
                "algorithmic_bytes_per_launch": 12_500_000 * 768 * (1 if small_i8 else 2) * 63 / 64,
@@ -113,3 +113,16 @@ if filt and "FETCH_SIZE" in summary[filt[0]]:
         out["mfma_busy_frac"] = k2["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (k2["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0)
     json.dump(out, open(os.path.join(P, "scan_filter_pmc.json"), "w"), indent=1)
     print(out)
+
+
+# BASELINE config 2: kernel stats of its step + the sweep's HBM bytes per launch
+copy(os.path.join(G, "prof_c2", "c2_kernel_stats.csv"), os.path.join(P, f"{tag}_config2_kernel_stats.csv"))
+f = os.path.join(G, "prof_c2_pmc", "c2_counter_collection.csv")
+if os.path.exists(f):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "scan_tiles_i8d_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    if v:
+        fs = sum(v) / len(v)
+        out = {"kernel": "scan_tiles_i8d_kernel", "rows": 1_000_000, "dim": 384, "queries": 256, "fetch_size_kib": fs, "hbm_bytes_per_launch": 2.0 * fs * 1024.0,
+               "algorithmic_bytes_per_launch": 378101888, "correction": "2x (gfx950 FETCH_SIZE halves wide coalesced reads)", "launches": len(v), "round": tag}
+        json.dump(out, open(os.path.join(P, f"{tag}_config2_pmc.json"), "w"), indent=1)
+        print(out)

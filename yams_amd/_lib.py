@@ -200,7 +200,7 @@ EXPORTS = [
     "yams_accel_device_count", "yams_accel_ctx_create", "yams_accel_ctx_destroy",
     "yams_accel_ctx_synchronize", "yams_accel_gate_create", "yams_accel_gate_destroy", "yams_accel_ctx_set_gate", "yams_accel_ctx_set_sweep_hold", "yams_accel_ctx_release_sweep_hold",
     "yams_accel_last_error", "yams_accel_device_info_json",
-    "yams_accel_free_string", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
+    "yams_accel_free_string", "yams_accel_trim", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_accel_debug_fail_alloc_after", "yams_accel_debug_alloc_faults",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device", "yams_scan_pq_topk_device",
@@ -269,6 +269,8 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_accel_last_error.argtypes = [vp]
     L.yams_accel_last_error.restype = C.c_char_p
     L.yams_accel_device_info_json.argtypes = [vp, C.POINTER(vp)]
+    L.yams_accel_trim.argtypes = [C.c_int]
+    L.yams_accel_trim.restype = C.c_uint64
     L.yams_accel_free_string.argtypes = [vp]
     L.yams_accel_free_string.restype = None
     L.yams_accel_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -39,6 +40,74 @@ bool alloc_fault() {
         if (g_fail_after.compare_exchange_weak(v, v - 1)) return false;
     }
     return false;
+}
+
+namespace {
+struct BigBuf { void* p; size_t cap; int device; };
+std::mutex g_big_mu;
+std::vector<BigBuf> g_big;      // cached, unused
+}
+hipError_t big_take(int device, size_t bytes, void** p, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_big.size(); ++i)
+            if (g_big[i].device == device && g_big[i].cap >= bytes && g_big[i].cap <= 2 * bytes + (64u << 20) &&
+                (best < 0 || g_big[i].cap < g_big[static_cast<size_t>(best)].cap)) best = static_cast<int>(i);
+        if (best >= 0) {
+            *p = g_big[static_cast<size_t>(best)].p; *cap = g_big[static_cast<size_t>(best)].cap;
+            g_big.erase(g_big.begin() + best);
+            return hipSuccess;
+        }
+    }
+    int before = device;
+    (void)hipGetDevice(&before);
+    (void)hipSetDevice(device);
+    const hipError_t e = ya_malloc(p, bytes);
+    (void)hipSetDevice(before);
+    if (e != hipSuccess) { *p = nullptr; *cap = 0; return e; }
+    *cap = bytes;
+    return hipSuccess;
+}
+void big_give(int device, void* p, size_t cap) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        size_t held = 0;
+        for (const BigBuf& b : g_big) held += b.cap;
+        if (held + cap <= kBigPoolMax) { g_big.push_back({p, cap, device}); return; }
+    }
+    int before = device;
+    (void)hipGetDevice(&before);
+    (void)hipSetDevice(device);
+    if (hipFree(p) != hipSuccess) (void)hipGetLastError();
+    (void)hipSetDevice(before);
+}
+size_t big_held(int device) {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    size_t held = 0;
+    for (const BigBuf& b : g_big) if (b.device == device) held += b.cap;
+    return held;
+}
+size_t big_trim(int device) {
+    std::vector<BigBuf> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        for (size_t i = 0; i < g_big.size();) {
+            if (device < 0 || g_big[i].device == device) { drop.push_back(g_big[i]); g_big.erase(g_big.begin() + static_cast<long>(i)); }
+            else ++i;
+        }
+    }
+    size_t freed = 0;
+    int before = 0;
+    (void)hipGetDevice(&before);
+    for (const BigBuf& b : drop) {
+        (void)hipSetDevice(b.device);
+        if (hipFree(b.p) != hipSuccess) (void)hipGetLastError();
+        freed += b.cap;
+    }
+    (void)hipSetDevice(before);
+    return freed;
 }
 
 yams_status_t ws_get(yams_accel_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -384,8 +453,13 @@ yams_status_t yams_accel_device_info_json(yams_accel_ctx* ctx, char** out_json) 
        << ",\"memory_clock_khz\":" << p.memoryClockRate << ",\"memory_bus_bits\":" << p.memoryBusWidth
        << ",\"hbm_bytes\":" << total_b << ",\"hbm_free_bytes\":" << free_b
        << ",\"lds_per_block\":" << p.sharedMemPerBlock << ",\"wavefront\":" << p.warpSize
-       << ",\"l2_bytes\":" << p.l2CacheSize << ",\"version\":\"" << YAMS_ACCEL_VERSION_STRING
-       << "\"}";
+       << ",\"l2_bytes\":" << p.l2CacheSize << ",\"version\":\"" << YAMS_ACCEL_VERSION_STRING << "\"";
+    const auto& hi = ctx->host_ingest;
+    if (hi.batches)
+        os << ",\"last_host_ingest\":{\"bytes\":" << hi.bytes << ",\"batches\":" << hi.batches << ",\"batch_bytes\":" << hi.batch_bytes
+           << ",\"slots\":" << hi.slots << ",\"alloc_ms\":" << hi.alloc_ms
+           << ",\"release_ms\":" << hi.release_ms << ",\"total_ms\":" << hi.total_ms << "}";
+    os << "}";
     const std::string s = os.str();
     char* buf = static_cast<char*>(std::malloc(s.size() + 1));
     if (!buf) return YAMS_ERR_INTERNAL;
@@ -395,6 +469,8 @@ yams_status_t yams_accel_device_info_json(yams_accel_ctx* ctx, char** out_json) 
 }
 
 void yams_accel_free_string(char* s) { std::free(s); }
+
+uint64_t yams_accel_trim(int device) { return static_cast<uint64_t>(yams_accel::big_trim(device)); }
 
 yams_status_t yams_accel_malloc(yams_accel_ctx* ctx, size_t bytes, void** out_dev) {
     if (!ctx || !out_dev) return YAMS_ERR_INVALID_ARG;

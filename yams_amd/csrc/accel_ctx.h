@@ -58,6 +58,8 @@ struct yams_accel_ctx {
     std::map<std::string, std::vector<Span>> spans;
     std::vector<hipEvent_t> event_pool;
 
+    // where the last yams_ingest_host call spent its set-up and tear-down (device_info_json: "last_host_ingest")
+    struct HostIngestStats { double alloc_ms = 0, release_ms = 0, total_ms = 0; uint64_t batch_bytes = 0, bytes = 0; uint32_t batches = 0, slots = 0; } host_ingest;
     // last ingest result (device arrays live in bufs)
     yams_ingest_result_t ingest{};
 };
@@ -116,9 +118,12 @@ struct TimedRegion { // RAII-less helper: begin/end record events when timing is
 // Allocation fault injection (yams_accel_debug_fail_alloc_after): every allocation of device, pinned or VMM-backed memory
 // this library makes goes through one of the three doors below, which fail with hipErrorOutOfMemory once armed.
 bool alloc_fault();
+size_t big_trim(int device);
 inline hipError_t ya_malloc(void** p, size_t bytes) {
     if (alloc_fault()) { *p = nullptr; return hipErrorOutOfMemory; }
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && big_trim(-1) > 0) { (void)hipGetLastError(); e = hipMalloc(p, bytes); } // the pool's memory first
+    return e;
 }
 inline hipError_t ya_host_malloc(void** p, size_t bytes, unsigned flags) {
     if (alloc_fault()) { *p = nullptr; return hipErrorOutOfMemory; }
@@ -126,8 +131,23 @@ inline hipError_t ya_host_malloc(void** p, size_t bytes, unsigned flags) {
 }
 inline hipError_t ya_mem_create(hipMemGenericAllocationHandle_t* h, size_t bytes, const hipMemAllocationProp* prop) {
     if (alloc_fault()) return hipErrorOutOfMemory;
-    return hipMemCreate(h, bytes, prop, 0);
+    hipError_t e = hipMemCreate(h, bytes, prop, 0);
+    if (e == hipErrorOutOfMemory && big_trim(-1) > 0) { (void)hipGetLastError(); e = hipMemCreate(h, bytes, prop, 0); }
+    return e;
 }
+
+// Call-sized device buffers (the slot buffers of yams_ingest_host: up to four of 8 GiB) come from a process-wide, per-device
+// POOL instead of being allocated and freed by every call: allocating 32 GiB costs the driver hundreds of milliseconds to
+// seconds (round 5: the same 32 GiB stream measured 9 and 46 GB/s), and a context must not keep them either (one such share
+// per pooled context next to mirrors sized as shares of the device).  big_take returns a cached buffer of at least `bytes`
+// (at most twice that) or allocates one; big_give puts it back, unless the pool already holds kBigPoolMax bytes.  The pool
+// gives its memory back when an allocation of this library fails (ya_malloc and ya_mem_create retry once after a trim) and
+// when the host says so (yams_accel_trim).
+constexpr size_t kBigPoolMax = 40ull << 30;
+hipError_t big_take(int device, size_t bytes, void** p, size_t* cap);
+void big_give(int device, void* p, size_t cap);
+size_t big_trim(int device); // device < 0: every device; returns the bytes freed
+size_t big_held(int device); // bytes the pool holds for this device (free memory as far as a caller sizing its batches is concerned)
 
 #define YA_HIP(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
     return ::yams_accel::hip_fail((ctx), e__, #expr); } while (0)

@@ -305,6 +305,7 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         // full gets smaller batches (slower, not an out-of-memory failure of this call or of the next corpus_append)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+            free_b += big_held(ctx->device);    // (what the pool of call-sized buffers holds is this call's to use)
             const uint64_t per_slot = static_cast<uint64_t>(free_b) / 2 / 5;
             batch_bytes = std::min<uint64_t>(batch_bytes, std::max<uint64_t>(256ull << 20, per_slot));
         } else (void)hipGetLastError();
@@ -341,16 +342,36 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         defer_above = yams_ingest_defer_threshold_host(total);
     }
     const int n_slots = static_cast<int>(std::min<size_t>(chains ? kSlots : 2, batches.size()));
+    // The slot buffers belong to the CALL, not to the context: they come from the process-wide pool of call-sized buffers
+    // (accel_ctx.h: big_take / big_give) and go back to it on every exit path — a second call finds them there instead of
+    // paying the driver for 32 GiB again (round 5: the same stream measured 9 and 46 GB/s; the difference was this).
     uint8_t* d_buf[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t d_cap[kSlots] = {0, 0, 0, 0};
+    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto ms_since = [](const timespec& a) { timespec b; clock_gettime(CLOCK_MONOTONIC, &b); return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
+    auto& stats = ctx->host_ingest;
+    stats = {};
+    auto give_back = [&]() {
+        timespec tr; clock_gettime(CLOCK_MONOTONIC, &tr);
+        for (int i = 0; i < kSlots; ++i) { if (d_buf[i]) big_give(ctx->device, d_buf[i], d_cap[i]); d_buf[i] = nullptr; }
+        stats.release_ms += ms_since(tr);
+    };
     for (int i = 0; i < n_slots; ++i) {
-        const yams_status_t a_st = ws_get(ctx, ("ing_host_buf" + std::to_string(i)).c_str(), largest + 64, (void**)&d_buf[i]);
-        if (a_st != YAMS_OK) {
-            // slot i could not be had: the slots before it (up to 3 x 8 GiB) go back at once — the call promises that the
-            // context keeps nothing above 1.25 GiB afterwards, and a retry with smaller batches needs that very memory
-            if (largest > (1ull << 30)) (void)ws_trim(ctx, (1ull << 30) + (1ull << 28));
-            return a_st;
+        void* p = nullptr;
+        const size_t before_cap = d_cap[i];
+        (void)before_cap;
+        const hipError_t e = big_take(ctx->device, largest + 64, &p, &d_cap[i]);
+        if (e != hipSuccess) {
+            // slot i could not be had: the slots before it go back to the pool — which ya_malloc empties before it gives up
+            (void)hipGetLastError();
+            give_back();
+            return hip_fail(ctx, e, "device buffers of the host-streamed ingest");
         }
+        d_buf[i] = static_cast<uint8_t*>(p);
     }
+    stats.alloc_ms = ms_since(ts0);
+    stats.slots = static_cast<uint32_t>(n_slots); stats.batches = static_cast<uint32_t>(batches.size()); stats.batch_bytes = largest;
+    for (const Batch& bt : batches) stats.bytes += bt.bytes;
     hipStream_t copy_st = nullptr;
     hipEvent_t landed[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     IngestLane lanes[kSlots];
@@ -362,12 +383,15 @@ yams_status_t yams_ingest_host(yams_accel_ctx* ctx, const uint8_t* const* blobs_
         // device.  What stays with the context after the call: buffers up to 1 GiB + headroom, as before round 4.
         struct Trim { yams_accel_ctx* c; bool on; ~Trim() { if (on) (void)ws_trim(c, (1ull << 30) + (1ull << 28)); } } trim{ctx, largest > (1ull << 30)};
         if (copy_st) { (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); }
+        (void)hipStreamSynchronize(ctx->stream);    // nothing of this call may still read a slot buffer when it goes back to the pool
         for (hipEvent_t e : landed) if (e) (void)hipEventDestroy(e);
         for (IngestLane& l : lanes) {
             if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
             if (l.fork) (void)hipEventDestroy(l.fork);
             if (l.join) (void)hipEventDestroy(l.join);
         }
+        give_back();
+        stats.total_ms = ms_since(ts0);
     };
     auto hip_ok = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
