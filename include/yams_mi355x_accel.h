@@ -65,7 +65,7 @@ enum yams_status_e {
 };
 #endif
 
-#define YAMS_ACCEL_VERSION_STRING "0.5.0" /* round 5: status codes TIMEOUT / RESOURCE_EXHAUSTED, L2_ACC_FUSED / _EXPLICIT, exchange deadline */
+#define YAMS_ACCEL_VERSION_STRING "0.6.0" /* round 6: yams_scan_pq_topk_device, vector_scan_v1 v2 (pq_index_set / search_pq), yams_accel_trim, strict configuration */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Context                                                                                      */

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(CDC_THREADS) void cdc_candidates_kernel(
 // coalesced; no data staging in LDS), realigns with v_alignbyte, warms up over 4 bytes and rolls.
 // Per byte: 2 LDS table reads + ~9 VALU, about half of the generic kernel above.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CDC_THREADS) void cdc_candidates_w48_kernel(
+// (five waves per SIMD: 96 registers instead of 110 at no spill — a wave issues at most one instruction per ~4.8 clocks, so
+//  issue slots are filled by WAVES, and this kernel shares its SIMDs with the long-chain kernel's waves for most of a call)
+__global__ __launch_bounds__(CDC_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void cdc_candidates_w48_kernel(
     const uint8_t* data, const uint64_t* blob_off, const uint64_t* blob_len,
     const uint64_t* piece_prefix, uint32_t n_blobs, CdcParams cp, uint32_t* bitmap) {
     __shared__ uint32_t s_t32[256];
