@@ -1285,7 +1285,7 @@ def distribution_leg(a, torch, dev, local, kind):
     leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
            "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res,
            "filter_tier": diags[0].get("filter_tier"),
-           **{kk: [dg.get(kk) for dg in diags] for kk in ("filter_candidates", "rescored_rows", "widened_queries", "escalated_queries", "exact_fallback_queries")}}
+           **{kk: [dg.get(kk) for dg in diags] for kk in ("filter_candidates", "rescored_rows", "widened_queries", "retried_queries", "escalated_queries", "exact_fallback_queries")}}
     n_oq = 64 if a.oracle_queries is None else min(64, a.oracle_queries)
     if n_oq > 0:
         _o = oracle_mod()

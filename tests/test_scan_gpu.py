@@ -1793,11 +1793,11 @@ def test_hip_l2_scan_reproduces_the_reference_compiled_vec0_golden_vectors(acc, 
 
 
 # ---- corpora that are not uniform on the sphere (round 6) --------------------------------------------------------------------
-def _clustered(n, d, n_clusters, seed, nq):
+def _clustered(n, d, n_clusters, seed, nq, spread=0.35):
     rng = np.random.default_rng(seed)
     centres = rng.standard_normal((n_clusters, d)).astype(np.float32)
     centres /= np.linalg.norm(centres, axis=1, keepdims=True)
-    sigma = np.float32(0.35 / np.sqrt(d))
+    sigma = np.float32(spread / np.sqrt(d))
     x = centres[rng.integers(0, n_clusters, n)] + sigma * rng.standard_normal((n, d)).astype(np.float32)
     q = centres[rng.integers(0, n_clusters, nq)] + sigma * rng.standard_normal((nq, d)).astype(np.float32)
     return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32), (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
@@ -1815,6 +1815,21 @@ def test_clustered_corpus_is_proven_by_the_int8_retry(acc, oracle):
     # the same through the resident-query form and with a threshold
     r2 = check(acc, oracle, corpus, q, 50, thr=0.3, max_queries=12, expect_path=0, shadow="i8", flags=_lib.FLAG_RESIDENT_QUERIES)
     assert r2.diag["retried_queries"] > 0, r2.diag
+
+
+def test_tight_clusters_are_listed_whole_in_the_first_pass(acc, oracle):
+    """The proof-aware threshold (tau_select_kernel, round 6): 1430 clusters of ~1050 rows whose similarities to a query of
+    their own cluster lie within a fraction of the int8 bound's width.  For the queries whose cluster has 16 or more rows in
+    the sample (six in ten) the rank rule's threshold — the 16th best sampled bound — sits inside the cluster and no list it
+    produces can prove a top-100; the sample shows the crowd (best sampled bound within E of that threshold), so the
+    threshold drops 2 E below the 6th best sampled bound — under the whole cluster — and the FIRST int8 pass lists everything
+    the proof needs: a second pass only for the few queries whose cluster the sample over-represents (more than 22 rows: the
+    deeper list might not fit), no escalation to speak of; rows, order and score bits are the oracle's."""
+    nq = 160
+    corpus, q = _clustered(1_500_000, 256, 1430, 73, nq, spread=0.15)
+    r = check(acc, oracle, corpus, q, 100, max_queries=8, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    assert r.diag["retried_queries"] <= nq // 5 and r.diag["escalated_queries"] <= 5 and r.diag["exact_fallback_queries"] == 0, r.diag
+    assert r.diag["rescored_rows"] >= nq * 900, r.diag      # the lists hold the clusters
 
 
 def test_anisotropic_corpus_teaches_the_context_to_start_on_the_bf16_tier(acc, oracle):

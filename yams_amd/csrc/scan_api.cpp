@@ -5,6 +5,7 @@
 // corpus read ONCE per batch instead of once per query:
 //   prep (validate, fp64 norms)  -> MFMA sample pass -> thresholds -> MFMA filter pass
 //   -> per-query candidate select -> fp64 re-score + verification (-> widen -> exhaustive fp64).
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -337,6 +338,17 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
 
     uint64_t filter_candidates = 0, rescored_nested = 0;
     uint32_t widened = 0, exact_fb = 0, escalated = 0, filter_tier = 0, retried = 0;
+#ifdef YAMS_ACCEL_MEASURE
+    // YAMS_ACCEL_TRACE_STAGES: host time at every stage boundary of one call (each boundary follows a stream synchronize)
+    const bool trace_stages = std::getenv("YAMS_ACCEL_TRACE_STAGES") != nullptr;
+    const auto trace_t0 = std::chrono::steady_clock::now();
+    auto stage_mark = [&](const char* what, size_t n) {
+        if (trace_stages) std::fprintf(stderr, "stage[%s%s] %-18s %8.3f ms  n=%zu\n", ctx->ws_ns.c_str(), split_only ? "split" : (retry ? "retry" : ""), what,
+                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - trace_t0).count(), n);
+    };
+#else
+    auto stage_mark = [](const char*, size_t) {};
+#endif
     std::vector<uint32_t> flags_keep; // h_flags survives a nested (escalation) call through this copy
     if (!use_mfma) {
         const uint32_t* d_rows_sel = nullptr;
@@ -448,6 +460,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             float* d_qthr;
             YA_TRY(ws_get(ctx, "q_thr", static_cast<size_t>(q_pad) * 8, (void**)&d_qthr));
             L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_thr = d_qthr; L.q_pad = q_pad; L.sample_layout = 1;
+            if (!L.i8_l2 && metric == YAMS_SCAN_COSINE) { // proof-aware threshold (tau_select_kernel)
+                L.tau_rows_meta = corpus->rows_i8_meta; L.tau_n_blocks = (corpus->n_rows + 63) / 64;
+                L.tau_rank2 = (k + plan.sample_stride - 1) / plan.sample_stride + 4;     // P(fewer than k rows reach that sample value) < 1 %
+                L.tau_max_groups = kRescoreMax / plan.sample_stride;                         // the list must stay re-scorable as a whole
+            }
             if (L.i8_l2) { // the per-batch tables of the L2 threshold: built after the sample pass (below)
                 const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
                 float* d_l2meta; uint8_t* d_rbias; uint32_t* d_qbias;
@@ -589,6 +606,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h_lcount, 4, nq, f); std::fclose(f); }
 #endif
         std::vector<uint32_t> failed, overflowed;
+        stage_mark("stage1 done", nq);
         for (uint32_t i = 0; i < nq; ++i) {
             filter_candidates += std::min<uint32_t>(h_lcount[i], plan.list_cap);
             if (h_status[i] != 0 && h_flags[i] == 0) {
@@ -614,6 +632,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             std::vector<uint32_t> still;
             for (uint32_t q : failed) if (h_status[q] != 0) still.push_back(q);
             failed.swap(still);
+            stage_mark("widen done, left", failed.size());
         }
         if (!failed.empty() && i8 && !L.i8_l2 && !split_only && k <= 1024) {
             // stage 2a (round 6): the int8 tier once more, with the threshold the proof asks for.  For every unproven query
@@ -635,8 +654,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             for (uint32_t i = 0; i < nf; ++i) {
                 // est = sample groups that reach tau' (0xffffffff: stage 1 found fewer than k rows): each stands for `stride` rows
                 const uint64_t rows_est = est[i] == 0xffffffffu ? ~0ull : static_cast<uint64_t>(est[i]) * plan.sample_stride;
-                (rows_est <= kRescoreMax * 3ull / 4 ? sub : rest).push_back(i);
+                (rows_est <= kRescoreMax * 5ull / 4 ? sub : rest).push_back(i);  // (the estimate's spread is ~ 1 / sqrt(groups): a list a quarter over still has an even chance to fit)
             }
+            stage_mark("retry: fits", sub.size());
             if (!sub.empty()) {
                 const size_t ns = sub.size(), kk = k;
                 std::vector<uint32_t> sub_q(ns);
@@ -696,6 +716,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             std::sort(rest.begin(), rest.end());
             for (uint32_t i : rest) still.push_back(failed[i]);
             failed.swap(still);
+            stage_mark("retry done, left", failed.size());
         }
         if (!failed.empty() && passes == 1) {
             // stage 2b: precision escalation.  The unproven queries become their own small batch
@@ -741,6 +762,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             failed.clear();
             // d_stat was read into rescored_nested above; the nested call counted in its own buffer
             YA_HIP(ctx, hipMemsetAsync(d_stat, 0, 64, st));
+            stage_mark("escalation done", escalated);
         }
         if (hint && i8) hint->bf16_first = static_cast<uint64_t>(escalated) * 2 > nq;    // (an int8 batch — first or probe — decides for the next 255)
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
