@@ -118,6 +118,8 @@ def compact_line(out):
             esc = v.get("escalated_queries")
             c["non_uniform"][kd + "_escalated_queries"] = (sum(esc) / len(esc)) if isinstance(esc, list) and esc else esc
             c["non_uniform"][kd + "_bit_exact"] = v.get("bit_exact_vs_oracle")
+            c["non_uniform"][kd + "_filter_tier"] = v.get("filter_tier")
+            c["non_uniform"][kd + "_i8_layout"] = v.get("i8_layout")
     ca = out.get("c_abi_sharded")
     if ca:
         c["c_abi_sharded"] = _pick(ca, ("n_devices", "collective", "communicator_ranks", "collectives", "batches", "ms_per_step", "value",
@@ -219,6 +221,7 @@ def parse():
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
     ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic (a throughput leg each on the headline shape; 64 oracle queries each)")
     ap.add_argument("--only-distribution", action="store_true", help="run the --distribution legs alone")
+    ap.add_argument("--dist-i8-layout", default="auto", choices=["auto", "plain", "rotated"], help="int8 shadow layout of the distribution legs (auto: yams_scan_choose_i8_layout_device decides)")
     ap.add_argument("--dist-flags", type=int, default=0, help="YAMS_SCAN_FLAG_* bits of the distribution legs' searches (measurement: 64 = no int8 tier)")
     ap.add_argument("--no-distribution-legs", action="store_true", help="skip the clustered / anisotropic legs of the default run")
     ap.add_argument("--no-config2-leg", action="store_true", help="skip the BASELINE config 2 (1M x 384, Q = 256) leg")
@@ -1231,9 +1234,11 @@ def distribution_leg(a, torch, dev, local, kind):
     acc0.build_shadow_device(tc.data_ptr(), n, d, tb.data_ptr(), tn.data_ptr())
     t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device=dev)
     tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
-    mean_res = acc0.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
+    # the layout of the int8 shadow: measured, as the plugin does at a corpus' first append ("i8_layout": "auto")
+    i8_flags, res_plain, res_rot = acc0.choose_i8_layout(tc.data_ptr(), n, d) if a.dist_i8_layout == "auto" else ((1 if a.dist_i8_layout == "rotated" else 0), None, None)
+    mean_res = acc0.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True, i8_flags=i8_flags)
     view = acc0.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
-                            rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr())
+                            rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr(), i8_flags=i8_flags)
     acc0.synchronize()
     lanes = max(1, a.lanes)
     streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
@@ -1283,7 +1288,8 @@ def distribution_leg(a, torch, dev, local, kind):
     torch.cuda.synchronize()
     last = n_qb - 1
     leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
-           "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res,
+           "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res, "i8_layout": "rotated" if i8_flags & 1 else "plain",
+           "sampled_residue_plain": res_plain, "sampled_residue_rotated": res_rot,
            "filter_tier": diags[0].get("filter_tier"),
            **{kk: [dg.get(kk) for dg in diags] for kk in ("filter_candidates", "rescored_rows", "widened_queries", "retried_queries", "escalated_queries", "exact_fallback_queries")}}
     n_oq = 64 if a.oracle_queries is None else min(64, a.oracle_queries)
@@ -1449,17 +1455,20 @@ def main():
     # the INT8 shadow (first filter tier of cosine batches > 128 queries), also built at upload time
     t8 = tm8 = None
     shadow_i8_ms = i8_mean_err = None
+    i8_flags, i8_res_plain, i8_res_rot = 0, None, None
     if tb is not None and not a.no_i8 and d % 64 == 0 and d >= 256 and not a.f32_filter and not a.split_filter:
         t8 = torch.empty(((n + 63) // 64 * 64, d), dtype=torch.int8, device=dev)
         tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
         acc.synchronize(); t_sh = time.perf_counter()
-        i8_mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True)
+        # the layout is measured, as the plugin does at a corpus' first append (the uniform synthetic rows keep the plain one)
+        i8_flags, i8_res_plain, i8_res_rot = acc.choose_i8_layout(tc.data_ptr(), n, d)
+        i8_mean_err = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True, i8_flags=i8_flags)
         shadow_i8_ms = (time.perf_counter() - t_sh) * 1e3
     view = acc.corpus_view(tc.data_ptr(), n, d, row_base=row_base,
                            rows_bf16_ptr=tb.data_ptr() if tb is not None else None,
                            rows_nsq_ptr=tn.data_ptr() if tn is not None else None,
                            rows_i8_ptr=t8.data_ptr() if t8 is not None else None,
-                           rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None)
+                           rows_i8_meta_ptr=tm8.data_ptr() if tm8 is not None else None, i8_flags=i8_flags if t8 is not None else 0)
     acc.synchronize()
 
     # the step after the scan: all-gather + merge, two batches in flight (yams_amd/dist.py)
@@ -2002,7 +2011,8 @@ def main():
                 # `peak` above is the nominal 2x-bf16 figure (5000), the stricter of the two
                 "frac_of_guide_i8_ubench_ceiling": (ach_tf / 3944.0) if (ach_tf and i8) else None,
                 "sample_pass_ms": samp_ms,
-                "shadow_build_ms": shadow_ms, "shadow_i8_build_ms": shadow_i8_ms, "shadow_i8_mean_residue": i8_mean_err,
+                "shadow_build_ms": shadow_ms, "shadow_i8_build_ms": shadow_i8_ms, "shadow_i8_mean_residue": i8_mean_err, "shadow_i8_layout": "rotated" if i8_flags & 1 else "plain",
+                "shadow_i8_sampled_residue": {"plain": i8_res_plain, "rotated": i8_res_rot},
                 # the other floor of this kernel: one read of the filter rows from HBM per launch
                 "hbm_floor_view": {"algorithmic_bytes_per_launch": filt_rows * d * row_bytes,
                                    "achieved_GBps": (filt_rows * d * row_bytes) / (filt_ms * 1e-3) / 1e9 if filt_ms else None,

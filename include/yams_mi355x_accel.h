@@ -189,8 +189,18 @@ typedef struct yams_scan_corpus_s {
                                   so the default tie-break (row id) stays the reference's.        */
     uint32_t n_stripes;
     uint32_t stripe_index;
-    uint32_t reserved2;
+    uint32_t i8_flags;         /* YAMS_SCAN_I8_*: the layout rows_i8 was built in — what
+                                  yams_scan_build_shadow_i8_layout_device was given (0 for
+                                  yams_scan_build_shadow_i8_device).  (was: reserved2, 0)            */
 } yams_scan_corpus_t;
+
+/* int8 shadow layouts.  ROTATED: rows (and, per batch, queries) go through a fixed orthogonal map — sign flips and two
+ * overlapping Walsh-Hadamard transforms — before they are quantised: dot products and norms stay where they were, the
+ * energy of a few large components (outlier dimensions of an embedding model, a power-law spectrum) spreads over all of
+ * them and the measured residue — the width of the filter's bound — drops from ~0.05 to ~0.01.  Rows with uniform
+ * components quantise better WITHOUT it; yams_scan_choose_i8_layout_device measures both on a sample.  256 <= dim <= 4096.
+ * Like every filter property it changes candidate counts, never results. */
+#define YAMS_SCAN_I8_ROTATED 1u
 
 #define YAMS_SCAN_FLAG_DEFER_THRESHOLD 1u /* L2 only: do not apply similarity_threshold (a sharded
                                              caller applies it after merging per-shard lists)  */
@@ -297,6 +307,20 @@ YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ct
                                                               uint64_t first_row, uint64_t n_rows,
                                                               uint32_t dim, int8_t* out_rows_i8,
                                                               float* out_meta, double* out_mean_err);
+
+/* The same with the layout named (YAMS_SCAN_I8_* bits; the view must carry the same bits in i8_flags).  Blocks of one mirror
+ * must all be built in one layout: a host that changes its mind rebuilds from row 0. */
+YAMS_ACCEL_API yams_status_t yams_scan_build_shadow_i8_layout_device(yams_accel_ctx* ctx, const float* rows,
+                                                                     uint64_t first_row, uint64_t n_rows,
+                                                                     uint32_t dim, uint32_t i8_flags, int8_t* out_rows_i8,
+                                                                     float* out_meta, double* out_mean_err);
+
+/* Which layout quantises these rows better: the mean residue of up to 256 blocks of 64 rows spread over [0, n_rows) under
+ * both layouts (host, nullable outputs; nothing on the device is written), *out_i8_flags = YAMS_SCAN_I8_ROTATED when the
+ * rotated one is at least a fifth smaller, else 0.  Synchronises the stream.  A host decides once per mirror (first upload). */
+YAMS_ACCEL_API yams_status_t yams_scan_choose_i8_layout_device(yams_accel_ctx* ctx, const float* rows, uint64_t n_rows,
+                                                               uint32_t dim, uint32_t* out_i8_flags,
+                                                               double* out_mean_err_plain, double* out_mean_err_rotated);
 
 /* Batched exact top-k, everything device-resident.  Any batch size: more than 4096 queries run as
  * slices of 4096 (the per-batch workspace grows with the query count); diagnostics are summed.

@@ -161,12 +161,12 @@ def test_plugin_configuration_is_read_strictly(accel_lib):
         finally:
             L.yams_accel_free_string(p)
 
-    for good in (b"{}", b"", None, b'{"device": 0, "search_slots": 4, "shadows": "i8", "l2_accumulate": "f32x8_fma", "collective": "peer", "fence": "off"}',
+    for good in (b"{}", b"", None, b'{"device": 0, "search_slots": 4, "shadows": "i8", "i8_layout": "rotated", "l2_accumulate": "f32x8_fma", "collective": "peer", "fence": "off"}',
                  b'{"devices": [0, 1], "stripe_rows": 4096, "note": "both", "nested": {"shadows": ["none", {"x": 1}]}, "ratio": 0.5, "on": true}',
                  b' { "rccl_library" : "/opt/site/lib\\"rccl\\".so" , "exchange_timeout_ms" : 1500 } '):
         assert init_error(good) == "no gfx950 device visible", good
     bad = {b'{"l2_accumulate": "f32x8_fmadd"}': "l2_accumulate", b'{"l2_accumulate": 8}': "must be a string",
-           b'{"shadows": "all"}': "shadows", b'{"search_slots": "4"}': "must be an integer", b'{"devices": "0,1"}': "devices",
+           b'{"shadows": "all"}': "shadows", b'{"i8_layout": "rotate"}': "i8_layout", b'{"search_slots": "4"}': "must be an integer", b'{"devices": "0,1"}': "devices",
            b'{"devices": []}': "devices", b'{"collective": "nccl"}': "collective", b'{"device": 0': "expected", b'["device", 0]': "not a JSON object",
            b'{"device": 0} trailing': "text after", b'{"stripe_rows": 1.5}': "must be an integer"}
     for cfg, needle in bad.items():

@@ -35,8 +35,13 @@ def unblock_i8_shadow(t8, d):
     return rowmajor.reshape(npad, d)
 
 
+# YAMS_TEST_I8_FLAGS=1: every int8 shadow these tests build is in the ROTATED layout (test_int8_tier_tests_pass_in_the_rotated_layout
+# runs the tier's tests again that way)
+_I8_FLAGS = int(os.environ.get("YAMS_TEST_I8_FLAGS", "0"))
+
+
 def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None, row_base=0,
-        shadow=True, mask=None):
+        shadow=True, mask=None, i8_flags=None):
     """shadow=True: the corpus view carries the bf16 filter shadow, as the plugin's device mirror
     always does (plugin.cpp corpus_append); shadow=False: a bare fp32 view (flat C-ABI callers);
     shadow="i8": only the INT8 shadow (every batch size takes the int8 tier); shadow="both": both
@@ -50,7 +55,9 @@ def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank
         acc.build_shadow_device(dc.ptr, corpus.shape[0], corpus.shape[1], db.ptr, dn.ptr)
     if shadow in ("i8", "both") and corpus.size and corpus.shape[1] % 64 == 0 and corpus.shape[1] >= 256:
         d8, dm8 = acc.alloc(_lib.i8_shadow_rows(corpus.shape[0]) * corpus.shape[1]), acc.alloc((corpus.shape[0] + 15) // 16 * 8)
-        acc.build_shadow_i8_device(dc.ptr, corpus.shape[0], corpus.shape[1], d8.ptr, dm8.ptr)
+        if i8_flags is None:
+            i8_flags = _I8_FLAGS if corpus.shape[1] <= 4096 else 0
+        acc.build_shadow_i8_device(dc.ptr, corpus.shape[0], corpus.shape[1], d8.ptr, dm8.ptr, i8_flags=i8_flags)
     dmask, n_allowed = None, 0
     if mask is not None:
         n = corpus.shape[0]
@@ -66,14 +73,14 @@ def run(acc, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank
                            dr.ptr if dr else None, di.ptr if di else None, row_base,
                            dmask.ptr if dmask else None, n_allowed,
                            rows_bf16_ptr=db.ptr if db else None, rows_nsq_ptr=dn.ptr if dn else None,
-                           rows_i8_ptr=d8.ptr if d8 else None, rows_i8_meta_ptr=dm8.ptr if dm8 else None)
+                           rows_i8_ptr=d8.ptr if d8 else None, rows_i8_meta_ptr=dm8.ptr if dm8 else None, i8_flags=(i8_flags or 0) if d8 else 0)
     return acc.scan_topk(view, queries, k, thr, metric, flags)
 
 
 def check(acc, oracle, corpus, queries, k, thr=-1.0, metric=SCAN_COSINE, flags=0, tie_rank=None,
-          max_queries=None, expect_path=None, shadow=True, expect_tier=None):
+          max_queries=None, expect_path=None, shadow=True, expect_tier=None, i8_flags=None):
     queries = np.atleast_2d(np.ascontiguousarray(queries, np.float32))
-    r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank, shadow=shadow)
+    r = run(acc, corpus, queries, k, thr, metric, flags, tie_rank, shadow=shadow, i8_flags=i8_flags)
     if expect_path is not None:
         assert r.diag["path"] == expect_path, r.diag
     if expect_tier is not None:
@@ -962,6 +969,43 @@ def test_plugin_serves_the_l2_arithmetic_its_config_names(accel_lib, oracle):
     C.CDLL(None).free(hp)
     assert vt.corpus_destroy(None, cid) == 0
     L.yams_plugin_shutdown()
+
+
+def test_plugin_chooses_the_int8_layout_per_corpus(accel_lib, oracle):
+    """{"i8_layout": "auto"} (the default): a corpus of rows with outlier dimensions gets the rotated int8 shadow at its first
+    append, a corpus of uniform rows the plain one, in the same plugin; "plain" / "rotated" fix it.  Searches of batches that
+    take the int8 tier return the oracle's rows either way."""
+    L = accel_lib
+    n, d, k, nq = 60_000, 256, 20, 140
+    rng = np.random.default_rng(81)
+    out = rng.standard_normal((n, d)).astype(np.float32); out[:, [3, 100, 200]] *= np.float32(15.0)
+    uni = oracle.synth_rows(81, 0, n, d)
+    qo = rng.standard_normal((nq, d)).astype(np.float32); qo[:, [3, 100, 200]] *= np.float32(15.0)
+    qu = oracle.synth_rows(81, 1 << 40, nq, d)
+
+    def health():
+        hp = C.c_void_p()
+        assert L.yams_plugin_get_health_json(C.byref(hp)) == 0
+        h = json.loads(C.string_at(hp)); C.CDLL(None).free(hp)
+        return h
+
+    for cfg, want in ((b'{"device": 0}', (1, 1)), (b'{"device": 0, "i8_layout": "plain"}', (0, 0)), (b'{"device": 0, "i8_layout": "rotated"}', (1, 2))):
+        vt = _vt(L, cfg)
+        ids = []
+        for rows_, qs_, after in ((out, qo, want[0]), (uni, qu, want[1])):
+            cid = C.c_uint64()
+            assert vt.corpus_create(None, d, C.byref(cid)) == 0
+            assert vt.corpus_append(None, cid, rows_[:n // 2].ctypes.data_as(_lib.f32p), n // 2) == 0
+            assert vt.corpus_append(None, cid, np.ascontiguousarray(rows_[n // 2:]).ctypes.data_as(_lib.f32p), n - n // 2) == 0   # (appends keep the layout)
+            assert health()["corpora_with_rotated_i8_shadow"] == after, (cfg, health())
+            got, _, _ = _vt_search(vt, cid, np.ascontiguousarray(qs_), k)
+            for qi in (0, 77, nq - 1):
+                assert got[qi] == list(oracle.scan_cosine(rows_, qs_[qi], k, -1.0)[0]), (cfg, qi)
+            ids.append(cid)
+        assert health()["i8_layout"] == ("auto" if b"i8_layout" not in cfg else cfg.split(b'"')[-2].decode())
+        for cid in ids:
+            assert vt.corpus_destroy(None, cid) == 0
+        L.yams_plugin_shutdown()
 
 
 def test_l2_definition_gap_measured_from_the_device_result(acc, oracle, capsys):
@@ -1864,3 +1908,129 @@ def test_anisotropic_corpus_teaches_the_context_to_start_on_the_bf16_tier(acc, o
         assert np.array_equal(small.rows, later.rows[:40])
     finally:
         a2.close()
+
+
+# ---- the rotated int8 layout (round 6) ---------------------------------------------------------------------------------
+def _rot_sign_np(idx, salt):
+    """scan_i8_kernel.hip rot_sign: +1 / -1 per component index."""
+    v = (idx.astype(np.uint64) * 2654435761 + salt * 0x9E3779B9) & 0xffffffff
+    v ^= v >> 15; v = (v * 2246822519) & 0xffffffff
+    v ^= v >> 13; v = (v * 3266489917) & 0xffffffff
+    v ^= v >> 16
+    return np.where(v & 1, -1.0, 1.0)
+
+
+def _rotate_np(v):
+    """The map the rotated layout claims, in fp64: R = H_B S_2 H_A S_1 (windows [0, P) and [d - P, d), P = 2^floor(log2 d))."""
+    from scipy.linalg import hadamard
+    d = v.shape[1]
+    p = 1 << (d.bit_length() - 1)
+    h = hadamard(p).astype(np.float64) / np.sqrt(p)
+    idx = np.arange(d)
+    w = v.astype(np.float64) * _rot_sign_np(idx, 1)
+    w[:, :p] = w[:, :p] @ h
+    if p < d:
+        w[:, d - p:] = (w[:, d - p:] * _rot_sign_np(idx[d - p:], 2)) @ h
+    return w
+
+
+def _mixed_rows(rng, n, d):
+    """Rows of four kinds: uniform components, a power-law spectrum, a few outlier dimensions, a common mean."""
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    x[n // 4:n // 2] = rng.standard_normal((n // 2 - n // 4, d)).astype(np.float32) * (np.arange(1, d + 1, dtype=np.float32) ** -0.5)
+    x[n // 2:3 * n // 4] = rng.standard_normal((3 * n // 4 - n // 2, d)).astype(np.float32)
+    x[n // 2:3 * n // 4, [3, d // 3, d - 5]] *= np.float32(12.0)
+    x[3 * n // 4:] = (0.6 + rng.standard_normal((n - 3 * n // 4, d))).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("d", [256, 384, 768, 1024, 1536, 4096])
+def test_rotated_int8_shadow_is_the_rotation_it_claims(acc, d):
+    """The residue the rotated shadow RECORDS (meta e_b) bounds the distance between every de-quantised int8 row and the EXACT
+    rotation (fp64, scipy's Hadamard matrix) of the exactly normalised row — the property the filter's bound stands on — and
+    is not needlessly loose; a dimension that is a power of two takes one transform, the others two overlapping ones."""
+    import torch
+    rng = np.random.default_rng(600 + d)
+    n = 200
+    x = _mixed_rows(rng, n, d)
+    x[17] = 0.0; x[44, 5] = np.inf
+    tc = torch.from_numpy(x).cuda()
+    t8 = torch.empty((_lib.i8_shadow_rows(n), d), dtype=torch.int8, device="cuda"); tm = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
+    mean = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm.data_ptr(), want_mean_err=True, i8_flags=_lib.I8_ROTATED)
+    xi = unblock_i8_shadow(t8, d).cpu().numpy().astype(np.float64)
+    meta = tm.cpu().numpy().astype(np.float64)
+    ok = np.isfinite(x).all(axis=1) & (np.abs(x).max(axis=1) > 0)
+    unit = np.zeros((n, d)); unit[ok] = x[ok].astype(np.float64) / np.linalg.norm(x[ok].astype(np.float64), axis=1, keepdims=True)
+    y = _rotate_np(unit)
+    assert np.abs(np.linalg.norm(y[ok], axis=1) - 1.0).max() < 1e-12          # (the reference map is orthogonal)
+    worst = 0.0
+    for b in range((n + 63) // 64):
+        rows = slice(64 * b, min(n, 64 * b + 64))
+        dist = np.linalg.norm(meta[b, 0] * xi[rows] - y[rows], axis=1)
+        okb = ok[rows]
+        assert (xi[rows][~okb] == 0).all()
+        assert dist[okb].max() <= meta[b, 1] + 1.75e-6, (b, dist[okb].max(), meta[b, 1])   # + the rotation's own rounding (in the query slop)
+        assert meta[b, 1] <= dist[okb].max() * 1.02 + 2e-4, (b, dist[okb].max(), meta[b, 1])
+        worst = max(worst, dist[okb].max())
+    assert 0 < mean <= worst * 1.02 + 2e-4
+    assert (xi[n:] == 0).all()
+
+
+def test_layout_choice_follows_the_measured_residues(acc):
+    """yams_scan_choose_i8_layout_device: uniform components keep the plain layout (the rotation would more than double their
+    residue), isotropic Gaussian rows too (nothing to gain), a power-law spectrum and outlier dimensions take the rotated one;
+    the two means it reports are those of full builds."""
+    import torch
+    rng = np.random.default_rng(611)
+    n, d = 40_000, 768
+    kinds = {"uniform": rng.uniform(-1, 1, (n, d)).astype(np.float32),
+             "gauss": rng.standard_normal((n, d)).astype(np.float32),
+             "powerlaw": rng.standard_normal((n, d)).astype(np.float32) * (np.arange(1, d + 1, dtype=np.float32) ** -0.5)}
+    o = rng.standard_normal((n, d)).astype(np.float32); o[:, [7, 300, 301, 700]] *= np.float32(10.0); kinds["outliers"] = o
+    want = {"uniform": 0, "gauss": 0, "powerlaw": _lib.I8_ROTATED, "outliers": _lib.I8_ROTATED}
+    for name, x in kinds.items():
+        tc = torch.from_numpy(x).cuda()
+        fl, plain, rot = acc.choose_i8_layout(tc.data_ptr(), n, d)
+        assert fl == want[name], (name, fl, plain, rot)
+        t8 = torch.empty((_lib.i8_shadow_rows(n), d), dtype=torch.int8, device="cuda"); tm = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device="cuda")
+        full_plain = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm.data_ptr(), want_mean_err=True)
+        full_rot = acc.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm.data_ptr(), want_mean_err=True, i8_flags=_lib.I8_ROTATED)
+        assert abs(plain - full_plain) < 0.1 * full_plain and abs(rot - full_rot) < 0.1 * full_rot, (name, plain, full_plain, rot, full_rot)
+        if name in ("powerlaw", "outliers"):
+            assert full_rot < 0.3 * full_plain, (name, full_plain, full_rot)
+    assert acc.choose_i8_layout(tc.data_ptr(), 100, d)[0] == _lib.I8_ROTATED           # (two blocks of the outlier rows still answer)
+
+
+def test_anisotropic_corpus_stays_on_the_int8_tier_in_the_rotated_layout(acc, oracle):
+    """The corpus of test_anisotropic_corpus_teaches_the_context_to_start_on_the_bf16_tier (a power-law spectrum: on the bench
+    shard every query of an int8 batch escalates in the plain layout) with the shadow in the rotated layout: the bound is as
+    tight as for isotropic rows, the batch is proven on the int8 tier (no escalation, no exhaustive fallback), the results
+    are the oracle's and those of the plain layout."""
+    rng = np.random.default_rng(72)
+    n, d, nq, k = 200_000, 256, 160, 50
+    scale = (np.arange(1, d + 1, dtype=np.float32) ** -0.5)
+    x = (rng.standard_normal((n, d)).astype(np.float32) * scale); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    qs = (rng.standard_normal((nq, d)).astype(np.float32) * scale); qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    r = check(acc, oracle, x, qs, k, max_queries=8, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8, i8_flags=_lib.I8_ROTATED)
+    assert r.diag["escalated_queries"] == 0 and r.diag["exact_fallback_queries"] == 0, r.diag
+    plain = run(acc, x, qs, k, shadow="i8", i8_flags=0)
+    assert np.array_equal(plain.rows, r.rows) and np.array_equal(plain.scores.view(np.uint32), r.scores.view(np.uint32))
+    # L2 over the same rows (raw queries through the same map), and a batch small enough for the resident-query form
+    check(acc, oracle, x * np.float32(3.0), qs * np.float32(0.5), k, metric=SCAN_L2, max_queries=6, shadow="both", i8_flags=_lib.I8_ROTATED)
+    check(acc, oracle, x, qs[:40], k, max_queries=6, shadow="i8", expect_tier=_lib.TIER_I8, i8_flags=_lib.I8_ROTATED)
+
+
+def test_int8_tier_tests_pass_in_the_rotated_layout():
+    """Every test of this file that exercises the int8 tier through run() / check(), once more with YAMS_TEST_I8_FLAGS=1: all
+    their int8 shadows are built in the rotated layout (hostile rows, masks, ties, thresholds, L2 under every accumulate
+    definition, clustered corpora, batches of every size) — the results must not notice."""
+    import subprocess, sys
+    if _I8_FLAGS:
+        pytest.skip("this IS the rotated run")
+    env = dict(os.environ, YAMS_TEST_I8_FLAGS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "int8 or i8 or hostile or clustered or tight_clusters or l2_under or golden or small_batches or resident"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail

@@ -34,6 +34,7 @@ def i8_shadow_rows(n_rows: int) -> int:
 TIER_NONE, TIER_I8, TIER_BF16, TIER_SPLIT, TIER_F32 = range(5)
 CDC_FLAG_GENERIC_KERNEL = 1
 INGEST_CHUNK_DIGESTS, INGEST_BLOB_DIGESTS = 1, 2
+I8_ROTATED = 1      # YAMS_SCAN_I8_ROTATED (yams_scan_corpus_t.i8_flags)
 
 vp = C.c_void_p
 u8p = C.POINTER(C.c_uint8)
@@ -49,7 +50,7 @@ class ScanCorpus(C.Structure):
                 ("row_mask", vp), ("row_mask_count", C.c_uint64),
                 ("rows_bf16", vp), ("rows_nsq", vp), ("rows_i8", vp), ("rows_i8_meta", vp),
                 ("stripe_rows", C.c_uint32), ("n_stripes", C.c_uint32), ("stripe_index", C.c_uint32),
-                ("reserved2", C.c_uint32)]
+                ("i8_flags", C.c_uint32)]
 
 
 class ShardedOptions(C.Structure):
@@ -204,7 +205,7 @@ EXPORTS = [
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
     "yams_accel_debug_fail_alloc_after", "yams_accel_debug_alloc_faults",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device", "yams_scan_pq_topk_device",
-    "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device",
+    "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device", "yams_scan_build_shadow_i8_layout_device", "yams_scan_choose_i8_layout_device",
     "yams_scan_record_layout", "yams_scan_merge_records_device", "yams_scan_sharded_create",
     "yams_scan_sharded_destroy", "yams_scan_sharded_count", "yams_scan_sharded_ctx",
     "yams_scan_sharded_last_error", "yams_scan_sharded_topk_host", "yams_scan_sharded_create_ex",
@@ -289,6 +290,8 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
                                       C.POINTER(ScanParams), vp, vp, vp, vp, C.POINTER(ScanDiag)]
     L.yams_scan_build_shadow_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
     L.yams_scan_build_shadow_i8_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
+    L.yams_scan_build_shadow_i8_layout_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_double)]
+    L.yams_scan_choose_i8_layout_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.yams_scan_merge_topk_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(ScanParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.yams_scan_record_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(RecordLayout)]

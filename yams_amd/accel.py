@@ -340,10 +340,10 @@ class Accel:
                     row_mask_ptr: int | None = None, row_mask_count: int = 0,
                     rows_bf16_ptr: int | None = None, rows_nsq_ptr: int | None = None,
                     rows_i8_ptr: int | None = None, rows_i8_meta_ptr: int | None = None,
-                    stripe_rows: int = 0, n_stripes: int = 0, stripe_index: int = 0) -> ScanCorpus:
+                    stripe_rows: int = 0, n_stripes: int = 0, stripe_index: int = 0, i8_flags: int = 0) -> ScanCorpus:
         return ScanCorpus(rows_ptr, n_rows, dim, 0, tie_rank_ptr, rank_row_ptr, row_base,
                           row_mask_ptr, row_mask_count, rows_bf16_ptr, rows_nsq_ptr,
-                          rows_i8_ptr, rows_i8_meta_ptr, stripe_rows, n_stripes, stripe_index, 0)
+                          rows_i8_ptr, rows_i8_meta_ptr, stripe_rows, n_stripes, stripe_index, i8_flags)
 
     def build_shadow_device(self, rows_ptr: int, n_rows: int, dim: int, out_bf16_ptr: int,
                             out_nsq_ptr: int) -> None:
@@ -352,14 +352,21 @@ class Accel:
                                                          out_bf16_ptr, out_nsq_ptr))
 
     def build_shadow_i8_device(self, rows_ptr: int, n_rows: int, dim: int, out_i8_ptr: int,
-                               out_meta_ptr: int, want_mean_err: bool = False, first_row: int = 0):
+                               out_meta_ptr: int, want_mean_err: bool = False, first_row: int = 0, i8_flags: int = 0):
         """INT8 filter shadow of rows [first_row, first_row + n_rows) of the mirror whose arrays start
         at the given BASE pointers: int8 rows [n][dim] + {scale, residue bound} per block of 64 rows
-        ([ceil(n / 64)][2] fp32).  Asynchronous unless the mean residue bound is asked for."""
+        ([ceil(n / 64)][2] fp32), in the layout `i8_flags` names (the view must carry the same bits).
+        Asynchronous unless the mean residue bound is asked for."""
         me = C.c_double(0.0)
-        self._check(self.L.yams_scan_build_shadow_i8_device(self.ctx, rows_ptr, first_row, n_rows, dim, out_i8_ptr,
-                                                            out_meta_ptr, C.byref(me) if want_mean_err else None))
+        self._check(self.L.yams_scan_build_shadow_i8_layout_device(self.ctx, rows_ptr, first_row, n_rows, dim, i8_flags, out_i8_ptr,
+                                                                   out_meta_ptr, C.byref(me) if want_mean_err else None))
         return me.value if want_mean_err else None
+
+    def choose_i8_layout(self, rows_ptr: int, n_rows: int, dim: int):
+        """(i8_flags, mean residue plain, mean residue rotated) measured on a sample of blocks; synchronises."""
+        fl = C.c_uint32(0); a = C.c_double(0.0); b = C.c_double(0.0)
+        self._check(self.L.yams_scan_choose_i8_layout_device(self.ctx, rows_ptr, n_rows, dim, C.byref(fl), C.byref(a), C.byref(b)))
+        return fl.value, a.value, b.value
 
     def scan_topk_device(self, corpus: ScanCorpus, queries_ptr: int, nq: int, k: int,
                          threshold: float, metric: int, out_scores: int, out_rows: int,

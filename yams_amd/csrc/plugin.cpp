@@ -259,6 +259,7 @@ struct PqIndex {
 struct Corpus {
     uint32_t dim = 0;
     uint64_t n_rows = 0;
+    int i8_flags = -1;               // layout of the int8 shadow (YAMS_SCAN_I8_*), decided at the first append; -1: not yet
     PqIndex pq;                      // (version 2 of the vtable: pq_index_set / search_pq)
     std::vector<ShardStore> sh;      // one per plugin device
     GrowBuf rank_of_row;             // device 0: the corpus-wide chunk_id ranking (cross-shard ties)
@@ -299,6 +300,7 @@ struct PluginState {
     bool initialised = false;
     std::vector<int> devices;        // config "devices": [..] (or "device": n); rows are striped over them
     bool want_bf16 = true, want_i8 = true;
+    int i8_layout = 0;               // configuration "i8_layout": 0 auto (measured at a corpus' first append), 1 plain, 2 rotated
     std::string init_error;
     // searches: ONE sharded handle over the plugin's devices (one RCCL communicator when there are several),
     // "search_slots" lanes = concurrent searches in flight, each on its own contexts / streams / worker threads;
@@ -564,6 +566,24 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
     }
     for (uint32_t i = 0; i < n_sh; ++i) if (yams_accel_ctx_synchronize(g.upload_ctx[i]) != YAMS_OK) return internal_error("append:4b");
     const auto t_copied = std::chrono::steady_clock::now();
+    if (i8 && c->i8_flags < 0) {
+        // the layout of this corpus' int8 shadow, once: the configured one, or whichever quantises the first rows better
+        c->i8_flags = 0;
+        if (g.i8_layout == 2) {
+            if (c->dim <= 4096) c->i8_flags = static_cast<int>(YAMS_SCAN_I8_ROTATED);   // (the rotated layout exists for 256 <= dim <= 4096)
+        } else if (g.i8_layout == 0) {
+            for (uint32_t i = 0; i < n_sh; ++i) {
+                const uint64_t now = shard_rows(n1, n_sh, i);
+                if (!now) continue;
+                uint32_t fl = 0;
+                (void)hipSetDevice(c->sh[i].device);
+                if (yams_scan_choose_i8_layout_device(g.upload_ctx[i], c->sh[i].rows.as<float>(), now, c->dim, &fl, nullptr, nullptr) != YAMS_OK)
+                    return internal_error("append:4c");
+                c->i8_flags = static_cast<int>(fl);
+                break;
+            }
+        }
+    }
     for (uint32_t i = 0; i < n_sh; ++i) {
         ShardStore& s = c->sh[i];
         const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
@@ -572,8 +592,8 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
             if (bf16 && yams_scan_build_shadow_device(uc, s.rows.as<float>() + old * c->dim, now - old, c->dim,
                                                       s.bf16.as<uint16_t>() + old * c->dim, s.nsq.as<float>() + old) != YAMS_OK)
                 return internal_error("append:5");
-            if (i8 && yams_scan_build_shadow_i8_device(uc, s.rows.as<float>(), old, now - old, c->dim, s.i8.as<int8_t>(),
-                                                       s.i8meta.as<float>(), nullptr) != YAMS_OK)
+            if (i8 && yams_scan_build_shadow_i8_layout_device(uc, s.rows.as<float>(), old, now - old, c->dim, static_cast<uint32_t>(c->i8_flags),
+                                                              s.i8.as<int8_t>(), s.i8meta.as<float>(), nullptr) != YAMS_OK)
                 return internal_error("append:6");
         }
         if (yams_accel_ctx_synchronize(uc) != YAMS_OK) return internal_error("append:7");
@@ -643,7 +663,7 @@ void release_corpus(Corpus& c) {
     c.pq.release();
     for (auto& s : c.sh) s.release();
     c.rank_of_row.release();
-    c.n_rows = 0; c.has_ranks = false;
+    c.n_rows = 0; c.has_ranks = false; c.i8_flags = -1;
 }
 
 // The rows are gone, the mirror's memory stays mapped for the re-upload that usually follows (compaction).
@@ -653,7 +673,7 @@ yams_status_t vs_corpus_clear(void*, uint64_t id) {
     if (!c) return YAMS_ERR_NOT_FOUND;
     std::unique_lock<std::shared_mutex> lk(c->mu);
     for (auto& s : c->sh) { s.n_rows = 0; s.has_tie = false; }
-    c->n_rows = 0; c->has_ranks = false;
+    c->n_rows = 0; c->has_ranks = false; c->i8_flags = -1;
     return YAMS_OK;
 }
 
@@ -710,7 +730,7 @@ yams_status_t vs_search_batch_ex(void*, uint64_t id, const float* queries, uint3
         v.rows = s.rows.as<float>(); v.n_rows = s.n_rows; v.dim = c->dim;
         if (s.has_tie) { v.tie_rank = s.tie.as<uint32_t>(); v.rank_row = s.inv.as<uint32_t>(); }
         if (g.want_bf16 && (c->dim & 3u) == 0 && s.n_rows) { v.rows_bf16 = s.bf16.as<uint16_t>(); v.rows_nsq = s.nsq.as<float>(); }
-        if (g.want_i8 && (c->dim & 63u) == 0 && c->dim >= 256 && s.n_rows) { v.rows_i8 = s.i8.as<int8_t>(); v.rows_i8_meta = s.i8meta.as<float>(); }
+        if (g.want_i8 && (c->dim & 63u) == 0 && c->dim >= 256 && s.n_rows) { v.rows_i8 = s.i8.as<int8_t>(); v.rows_i8_meta = s.i8meta.as<float>(); v.i8_flags = c->i8_flags > 0 ? static_cast<uint32_t>(c->i8_flags) : 0u; }
         if (n_sh > 1) { v.stripe_rows = kStripeRows; v.n_stripes = n_sh; v.stripe_index = i; }
         if (row_mask_host && s.n_rows) { // document_hash / candidate_hashes restriction (:4137-4175), dealt like the rows
             const size_t words = (s.n_rows + 31) / 32;
@@ -1306,6 +1326,8 @@ static int plugin_init_impl(const char* config_json, const void* host_context) {
         cfg.get_int("device", 0, v_device) && cfg.get_int("search_slots", 2, slots) && cfg.get_int("stripe_rows", 65536, sr) &&
         cfg.get_int("exchange_timeout_ms", 0, ex_timeout) &&
         cfg.get_choice("shadows", {"both", "bf16", "i8", "none"}, 0, shadows) &&
+        // layout of the int8 shadow (YAMS_SCAN_I8_ROTATED in the header): measured per corpus at its first append, or fixed
+        cfg.get_choice("i8_layout", {"auto", "plain", "rotated"}, 0, g.i8_layout) &&
         // the arithmetic of vec0's L2 distance the host's sqlite-vec-cpp build uses (YAMS_SCAN_FLAG_L2_ACC_* in the header;
         // "..._fma": the same lanes accumulated with ONE fused multiply-add per element, what '-mavx', '-mfma' builds do)
         cfg.get_choice("l2_accumulate", {"f64", "f32", "f32x8", "f32x16", "f32_fma", "f32x8_fma", "f32x16_fma"}, 0, l2) &&
@@ -1401,10 +1423,12 @@ static int plugin_health_impl(char** out_json) {
     // device memory behind the mirrors: mapped into live corpora, and parked (mappings of destroyed corpora waiting for
     // the next one) — what an allocation-failure test watches for leaks
     uint64_t mirror_mapped = 0, mirror_parked = 0;
+    size_t rotated_corpora = 0;
     {
         std::lock_guard<std::mutex> cl(g.corpora_mu);
         n_corpora = g.corpora.size();
         for (auto& kv : g.corpora) {
+            rotated_corpora += kv.second->i8_flags > 0 && (kv.second->i8_flags & static_cast<int>(YAMS_SCAN_I8_ROTATED));
             for (auto& s : kv.second->sh)
                 for (const GrowBuf* b : {&s.rows, &s.bf16, &s.i8, &s.nsq, &s.i8meta, &s.tie, &s.inv}) mirror_mapped += b->mapped;
             mirror_mapped += kv.second->rank_of_row.mapped;
@@ -1419,6 +1443,7 @@ static int plugin_health_impl(char** out_json) {
     os << "],\"device\":" << (g.devices.empty() ? 0 : g.devices[0]) << ",\"search_slots\":" << g.search_slots
        << ",\"l2_accumulate\":\"" << ((g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32X16 ? "f32x16" : (g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32X8 ? "f32x8" : (g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_MASK) == YAMS_SCAN_FLAG_L2_ACC_F32 ? "f32" : "f64")
        << ((g.l2_acc & YAMS_SCAN_FLAG_L2_ACC_FUSED) ? "_fma" : "") << "\""
+       << ",\"i8_layout\":\"" << (g.i8_layout == 2 ? "rotated" : g.i8_layout == 1 ? "plain" : "auto") << "\",\"corpora_with_rotated_i8_shadow\":" << rotated_corpora
        << ",\"last_append\":{\"bytes\":" << g.append_bytes.load() << ",\"map_ms\":" << g.append_map_ms.load() << ",\"copy_ms\":" << g.append_copy_ms.load()
        << ",\"shadow_ms\":" << g.append_shadow_ms.load() << "}"
        << ",\"appends\":" << g.appends.load() << ",\"exhausted_appends\":" << g.exhausted_appends.load()

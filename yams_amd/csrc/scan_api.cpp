@@ -394,6 +394,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         bool i8 = bf16 && passes == 1 && (metric == YAMS_SCAN_COSINE || l2_i8_ok) && (dim & 63u) == 0 && dim >= 256 && corpus->rows_i8 &&
                   corpus->rows_i8_meta && (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
                   !(params->flags & YAMS_SCAN_FLAG_NO_I8_FILTER);
+        if (i8 && (corpus->i8_flags & ~YAMS_SCAN_I8_ROTATED)) return fail(ctx, YAMS_ERR_INVALID_ARG, "unknown bits in yams_scan_corpus_t.i8_flags");
+        if (i8 && (corpus->i8_flags & YAMS_SCAN_I8_ROTATED) && !i8_rotation_window(dim))
+            return fail(ctx, YAMS_ERR_INVALID_ARG, "no rotated int8 layout exists for this dimension");
         // Tier hint: batches of more than 128 cosine queries on a corpus whose int8 batches keep escalating start on the bf16
         // tier (anisotropic rows, 12.5M x 768, 1024 queries: 59.9 ms per step on the int8 tier — all 1024 queries escalate —
         // 17.3 ms on the bf16 tier, no query widened; profiles/r06_non_uniform.json).  Learnt per context from the batches it
@@ -513,7 +516,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "i8_zeroed", z_cnt + z_over + static_cast<size_t>(sync_words) * 4, (void**)&zeroed));
             // (cleared by the query preparation of the int8 tier: one launch where there were a fill and a launch)
             YA_HIP(ctx, launch_prep_i8(st, d_qprep, nq, L.q_pad, dim, const_cast<int8_t*>(L.q_i8), const_cast<float*>(L.q_meta), L.i8_l2,
-                                       reinterpret_cast<uint32_t*>(zeroed), (z_cnt + z_over) / 4 + sync_words));
+                                       reinterpret_cast<uint32_t*>(zeroed), (z_cnt + z_over) / 4 + sync_words,
+                                       (corpus->i8_flags & YAMS_SCAN_I8_ROTATED) != 0));
             L.log_cnt = reinterpret_cast<uint32_t*>(zeroed);
             d_qover = reinterpret_cast<uint32_t*>(zeroed + z_cnt);
             L.q_over = d_qover;
@@ -893,7 +897,51 @@ extern "C" yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, c
                                                           uint64_t first_row, uint64_t n_rows, uint32_t dim,
                                                           int8_t* out_rows_i8, float* out_meta,
                                                           double* out_mean_err) {
+    return yams_scan_build_shadow_i8_layout_device(ctx, rows, first_row, n_rows, dim, 0u, out_rows_i8, out_meta, out_mean_err);
+}
+
+extern "C" yams_status_t yams_scan_choose_i8_layout_device(yams_accel_ctx* ctx, const float* rows, uint64_t n_rows, uint32_t dim,
+                                                           uint32_t* out_i8_flags, double* out_mean_err_plain,
+                                                           double* out_mean_err_rotated) {
     if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (out_i8_flags) *out_i8_flags = 0;
+    if (out_mean_err_plain) *out_mean_err_plain = 0.0;
+    if (out_mean_err_rotated) *out_mean_err_rotated = 0.0;
+    if (!out_i8_flags) return fail(ctx, YAMS_ERR_INVALID_ARG, "null out_i8_flags");
+    if (n_rows == 0) return YAMS_OK;
+    if (!rows || dim < 256 || (dim & 63u) || (reinterpret_cast<uintptr_t>(rows) & 15u))
+        return fail(ctx, YAMS_ERR_INVALID_ARG, "the int8 shadow needs dim % 64 == 0, dim >= 256 and 16-byte aligned rows");
+    if (!i8_rotation_window(dim)) return YAMS_OK;     // only the plain layout exists
+    (void)hipSetDevice(ctx->device);
+    // the residues of up to 256 blocks spread over the mirror, under both layouts (nothing is written but the two sums)
+    const uint64_t n_blocks = (n_rows + 63) / 64;
+    const uint64_t stride = std::max<uint64_t>(1, n_blocks / 256);
+    double* d_stats;
+    YA_TRY(ws_get(ctx, "i8_layout_stats", 32, (void**)&d_stats));
+    YA_HIP(ctx, hipMemsetAsync(d_stats, 0, 32, ctx->stream));
+    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, 0, n_rows, dim, nullptr, nullptr, nullptr, false, stride, d_stats));
+    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, 0, n_rows, dim, nullptr, nullptr, nullptr, true, stride, d_stats + 2));
+    double h[4] = {0, 0, 0, 0};
+    YA_HIP(ctx, hipMemcpyAsync(h, d_stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+    YA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c0, c1;
+    std::memcpy(&c0, &h[1], 8); std::memcpy(&c1, &h[3], 8);
+    const double plain = c0 ? h[0] / static_cast<double>(c0) : 0.0, rotated = c1 ? h[2] / static_cast<double>(c1) : 0.0;
+    if (out_mean_err_plain) *out_mean_err_plain = plain;
+    if (out_mean_err_rotated) *out_mean_err_rotated = rotated;
+    // the rotation has to pay for itself: a fifth less residue at least (isotropic Gaussian rows measure the same both ways)
+    if (c0 && c1 && rotated < 0.8 * plain) *out_i8_flags = YAMS_SCAN_I8_ROTATED;
+    return YAMS_OK;
+}
+
+extern "C" yams_status_t yams_scan_build_shadow_i8_layout_device(yams_accel_ctx* ctx, const float* rows,
+                                                                 uint64_t first_row, uint64_t n_rows, uint32_t dim, uint32_t i8_flags,
+                                                                 int8_t* out_rows_i8, float* out_meta,
+                                                                 double* out_mean_err) {
+    if (!ctx) return YAMS_ERR_INVALID_ARG;
+    if (i8_flags & ~YAMS_SCAN_I8_ROTATED) return fail(ctx, YAMS_ERR_INVALID_ARG, "unknown i8_flags");
+    const bool rotated = (i8_flags & YAMS_SCAN_I8_ROTATED) != 0;
+    if (rotated && !i8_rotation_window(dim)) return fail(ctx, YAMS_ERR_UNSUPPORTED, "no rotated int8 layout exists for this dimension (256 <= dim <= 4096)");
     if (out_mean_err) *out_mean_err = 0.0;
     if (n_rows == 0) return YAMS_OK;
     if (!rows || !out_rows_i8 || !out_meta) return fail(ctx, YAMS_ERR_INVALID_ARG, "null shadow buffers");
@@ -907,7 +955,7 @@ extern "C" yams_status_t yams_scan_build_shadow_i8_device(yams_accel_ctx* ctx, c
         YA_HIP(ctx, hipMemsetAsync(d_stats, 0, 16, ctx->stream));
     }
     TimedRegion tr(ctx, "shadow_build_i8");
-    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, first_row, n_rows, dim, out_rows_i8, out_meta, d_stats));
+    YA_HIP(ctx, launch_shadow_build_i8(ctx->stream, rows, first_row, n_rows, dim, out_rows_i8, out_meta, d_stats, rotated));
     tr.end();
     if (out_mean_err) {
         double h[2] = {0.0, 0.0};

@@ -1329,15 +1329,95 @@ __global__ __launch_bounds__(256) void i8_collect_sample_kernel(const uint32_t* 
 // [first_row, first_row + n_rows) is rebuilt from its first row on (an append that starts inside a
 // block re-quantises that block's earlier rows with the new common scale).
 // -------------------------------------------------------------------------------------------------
+// ---- the ROTATED layout (round 6) ----------------------------------------------------------------------------------------
+// Rows whose energy sits in a few components (an embedding model's outlier dimensions, a power-law spectrum) quantise badly
+// under ONE scale per block: the large components set the step, the many small ones round to nothing — measured residue
+// 0.047 against 0.010 for isotropic rows, a bound too loose to prove anything (the tier escalated every query).  An
+// orthogonal map of rows AND queries leaves every dot product and norm where it was and spreads the energy: R = H_B S_2 H_A S_1,
+// S_1 / S_2 fixed pseudo-random sign flips, H_A / H_B Walsh-Hadamard transforms (scaled by 1 / sqrt(P)) over the first and the
+// last P = 2^floor(log2 dim) components (two overlapping windows mix all of a dimension that is not a power of two; S_2 keeps
+// the second transform from undoing the first: the Hadamard transform of a Walsh function is a spike).  Residue of the
+// anisotropic bench corpus 0.047 -> 0.011, of rows with four outlier dimensions 0.045 -> 0.010; uniform components get WORSE
+// (0.004 -> 0.010: the rotated components are Gaussian), so the layout is chosen per corpus from the measured residues of a
+// sample (yams_scan_choose_i8_layout_device) and recorded in the view (yams_scan_corpus_t.i8_flags).
+// Rounding: the butterflies are fp32 adds; s stages leave a relative error of at most s u in the 2-norm (each stage is
+// sqrt(2) x orthogonal with componentwise relative error u), the scale adds 1.5 u per window: with P <= 4096 a rotated unit
+// vector is within 1.75e-6 of the exact rotation.  The residues are MEASURED on the computed vectors; the distance between
+// computed and exact rotation of row and query enters the bound as an absolute 1e-5 in the query's slop (prep_i8_kernel).
+__device__ inline uint32_t rot_sign(uint32_t i, uint32_t salt) {  // bit 31: flip component i (salt 1 / 2: S_1 / S_2)
+    uint32_t v = i * 2654435761u + salt * 0x9E3779B9u;
+    v ^= v >> 15; v *= 2246822519u; v ^= v >> 13; v *= 3266489917u; v ^= v >> 16;
+    return v << 31;
+}
+__device__ inline void wave_lds_fence() {   // LDS written by some lanes of this wave, read by others: order the accesses for the compiler too
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// One Walsh-Hadamard transform of P = 64 EPL floats at `w` (wave-private LDS) by one wave; sign_salt != 0: component i of the
+// window (global index g0 + i) is flipped first.
+template <int EPL>
+__device__ inline void wave_fwht(float* w, int lane, uint32_t g0, uint32_t sign_salt, float scale) {
+    float v[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const uint32_t idx = static_cast<uint32_t>(lane) * EPL + i;
+        float x = w[idx];
+        if (sign_salt) x = __uint_as_float(__float_as_uint(x) ^ rot_sign(g0 + idx, sign_salt));
+        v[i] = x;
+    }
+#pragma unroll
+    for (int len = 1; len < EPL; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (!(i & len)) { const float a = v[i], b = v[i + len]; v[i] = a + b; v[i + len] = a - b; }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const float o = __shfl_xor(v[i], m);
+            v[i] = (lane & m) ? o - v[i] : v[i] + o;
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) w[static_cast<uint32_t>(lane) * EPL + i] = v[i] * scale;
+    wave_lds_fence();
+}
+
+// EPL = 0: the plain layout.  Else: rotated, P = 64 EPL.  block_stride > 1 / dry != nullptr: the residues of a SAMPLE of blocks
+// only (nothing but dry[0] += e_b, dry[1] (uint64) += 1 is written).
+template <int EPL>
 __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows, uint64_t first_block, uint64_t end_row,
-                                                              uint32_t dim, int8_t* out_i8, float* out_meta) {
+                                                              uint32_t dim, int8_t* out_i8, float* out_meta, float rot_scale,
+                                                              uint64_t block_stride, double* dry) {
     __shared__ float rinv_s[4][I8_BLOCK_ROWS]; // per wave, per row: the normalising factor, 0 for an unusable row
-    const uint64_t blk = first_block + static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    extern __shared__ float rot_s[];             // rotated layout: [4 waves][dim] floats
+    const uint64_t blk = first_block + (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * block_stride;
     const uint64_t r0 = blk * I8_BLOCK_ROWS;
     if (r0 >= end_row) return;
     const int lane = threadIdx.x & 63;
     const int nr = static_cast<int>(end_row - r0 < I8_BLOCK_ROWS ? end_row - r0 : I8_BLOCK_ROWS);
     float* rinv = rinv_s[threadIdx.x >> 6];  // (wave-private; written and read by the same wave in program order)
+    float* buf = rot_s + static_cast<size_t>(threadIdx.x >> 6) * dim;
+    // rotated layout: the normalised row, rotated, into buf
+    auto stage_row = [&](const float* src, float inv) {
+        if constexpr (EPL != 0) {
+            wave_lds_fence();
+            for (uint32_t c = lane * 4; c < dim; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                float4 o;
+                o.x = __uint_as_float(__float_as_uint(v.x * inv) ^ rot_sign(c + 0, 1));
+                o.y = __uint_as_float(__float_as_uint(v.y * inv) ^ rot_sign(c + 1, 1));
+                o.z = __uint_as_float(__float_as_uint(v.z * inv) ^ rot_sign(c + 2, 1));
+                o.w = __uint_as_float(__float_as_uint(v.w * inv) ^ rot_sign(c + 3, 1));
+                if (inv == 0.f) o = make_float4(0.f, 0.f, 0.f, 0.f);     // (an unusable row may hold NaN / inf)
+                *reinterpret_cast<float4*>(buf + c) = o;
+            }
+            wave_lds_fence();
+            constexpr uint32_t P = 64u * EPL;
+            wave_fwht<EPL>(buf, lane, 0, 0, rot_scale);
+            if (P < dim) wave_fwht<EPL>(buf + (dim - P), lane, dim - P, 2, rot_scale);
+        }
+    };
     float umax = 0.f;                   // largest |x~_i| of the block
     for (int rr = 0; rr < nr; ++rr) {
         const float* src = rows + (r0 + rr) * dim;
@@ -1366,8 +1446,21 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
         for (int d = 32; d >= 1; d >>= 1) nsq += __shfl_xor(nsq, d);
         const float inv = ok ? ia * rsqrtf(nsq) : 0.f;  // x~ = x * inv (nsq in [1, dim]: no range trouble)
         if (lane == 0) rinv[rr] = inv;
-        if (ok) umax = fmaxf(umax, rsqrtf(nsq));         // |x~|_max = (amax * ia) * rsqrt(nsq)
+        if constexpr (EPL == 0) {
+            if (ok) umax = fmaxf(umax, rsqrtf(nsq));         // |x~|_max = (amax * ia) * rsqrt(nsq)
+        } else if (ok) {
+            stage_row(src, inv);
+            float m = 0.f;
+            for (uint32_t c = lane * 4; c < dim; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(buf + c);
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+            umax = fmaxf(umax, m);
+        }
     }
+    wave_lds_fence();   // (rinv)
     const bool any = umax > 0.f;
     const float sc = any ? umax / 127.0f : 1.0f;
     const float isc = any ? 127.0f / umax : 0.f;
@@ -1375,10 +1468,17 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
     for (int rr = 0; rr < nr; ++rr) {
         const float* src = rows + (r0 + rr) * dim;
         const float inv = rinv[rr];
+        if constexpr (EPL != 0) stage_row(src, inv);
         float esq = 0.f;
         for (uint32_t c = lane * 4; c < dim; c += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(src + c);
-            const float x[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+            float x[4];
+            if constexpr (EPL == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                x[0] = v.x * inv; x[1] = v.y * inv; x[2] = v.z * inv; x[3] = v.w * inv;
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(buf + c);
+                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            }
             uint32_t packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1388,20 +1488,25 @@ __global__ __launch_bounds__(256) void shadow_build_i8_kernel(const float* rows,
                 esq = fmaf(d, d, esq);
                 packed |= (static_cast<uint32_t>(static_cast<int>(qf)) & 0xffu) << (8 * e);
             }
-            *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = inv != 0.f ? packed : 0u;
+            if (!dry) *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = inv != 0.f ? packed : 0u;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) esq += __shfl_xor(esq, d);
         if (inv != 0.f) emax = fmaxf(emax, esq);
     }
-    for (int rr = nr; rr < I8_BLOCK_ROWS; ++rr) // the padding rows of the last block: defined (zero), never emitted
-        for (uint32_t c = lane * 4; c < dim; c += 256)
-            *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = 0u;
+    if (!dry)
+        for (int rr = nr; rr < I8_BLOCK_ROWS; ++rr) // the padding rows of the last block: defined (zero), never emitted
+            for (uint32_t c = lane * 4; c < dim; c += 256)
+                *reinterpret_cast<uint32_t*>(out_i8 + i8_blocked_offset(r0 + rr, c, dim)) = 0u;
     if (lane == 0) {
         const float fd = static_cast<float>(dim);
         const float e = any ? sqrtf(emax) * (1.0f + (fd + 16.f) * 5.9604645e-8f) + (fd + 64.f) * 5.9604645e-8f : 0.f;
-        out_meta[2 * blk] = sc;
-        out_meta[2 * blk + 1] = e;
+        if (dry) {
+            if (e > 0.f) { atomicAdd(dry, static_cast<double>(e)); atomicAdd(reinterpret_cast<unsigned long long*>(dry) + 1, 1ull); }
+        } else {
+            out_meta[2 * blk] = sc;
+            out_meta[2 * blk + 1] = e;
+        }
     }
 }
 
@@ -1434,14 +1539,42 @@ __global__ __launch_bounds__(256) void i8_meta_stats_kernel(const float* meta, u
 // f_q >= |q~ - t_q qi| + 1e-6 (the absolute slop covers the fp32 evaluation of the score bound and the
 // fp64 -> fp32 rounding of the exact similarity).  Padding queries are zero with t_q = 1.
 // raw (L2 batches): the queries are not unit vectors, the absolute slop scales with their norm.
+// rot_p != 0: the corpus' shadow is in the ROTATED layout (shadow_build_i8_kernel): the query goes through the same map first
+// (one workgroup, the Walsh-Hadamard stages through LDS), and its slop takes the distance between the computed and the exact
+// rotations of row and query (1e-5 of the query's norm: see the bound above wave_fwht).
 __global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                                                      int8_t* q_i8, float* q_meta, int raw, uint32_t* zero_words, uint32_t n_zero_words) {
+                                                      int8_t* q_i8, float* q_meta, int raw, uint32_t* zero_words, uint32_t n_zero_words,
+                                                      uint32_t rot_p, float rot_scale) {
     const uint32_t q = blockIdx.x;
     // the filter launch's zero-initialised tables (log region counts, overflow marks, strip counters: scan_api.cpp "i8_zeroed")
     for (uint32_t i = q * 256u + threadIdx.x; i < n_zero_words; i += gridDim.x * 256u) zero_words[i] = 0u;
     __shared__ float red[256];
+    extern __shared__ float qrot[];     // rotated layout: [dim]
     const bool live = q < nq;
     const float* src = qprep + static_cast<uint64_t>(q) * dim;
+    if (rot_p) {
+        for (uint32_t i = threadIdx.x; i < dim; i += 256) qrot[i] = live ? __uint_as_float(__float_as_uint(src[i]) ^ rot_sign(i, 1)) : 0.f;
+        __syncthreads();
+        for (int win = 0; win < 2; ++win) {
+            if (win == 1 && rot_p >= dim) break;
+            float* w = qrot + (win ? dim - rot_p : 0u);
+            if (win) {
+                for (uint32_t i = threadIdx.x; i < rot_p; i += 256) w[i] = __uint_as_float(__float_as_uint(w[i]) ^ rot_sign(dim - rot_p + i, 2));
+                __syncthreads();
+            }
+            for (uint32_t len = 1; len < rot_p; len <<= 1) {
+                for (uint32_t t = threadIdx.x; t < rot_p / 2; t += 256) {
+                    const uint32_t i = ((t & ~(len - 1)) << 1) | (t & (len - 1));
+                    const float a = w[i], b = w[i + len];
+                    w[i] = a + b; w[i + len] = a - b;
+                }
+                __syncthreads();
+            }
+            for (uint32_t i = threadIdx.x; i < rot_p; i += 256) w[i] *= rot_scale;
+            __syncthreads();
+        }
+        src = qrot;
+    }
     float amax = 0.f;
     if (live)
         for (uint32_t i = threadIdx.x; i < dim; i += 256) amax = fmaxf(amax, fabsf(src[i]));
@@ -1486,8 +1619,9 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const float* qprep, uint32
         const float up = 1.0f + (fd + 16.f) * 5.9604645e-8f;
         q_meta[4 * q + 0] = t;
         q_meta[4 * q + 1] = ok ? sqrtf(csum) * up : 0.f;
-        const float unit = raw ? sqrtf(csum) * up : 1.0f;
-        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + ((fd + 32.f) * 5.9604645e-8f + 1e-6f) * unit : 0.f;
+        // (raw queries, rotated: |q| <= |t qi| + |q - t qi|, both measured on the rotated vector, which keeps |q| to 2e-6)
+        const float unit = raw ? (rot_p ? (sqrtf(csum) + sqrtf(red[0])) * up * 1.00001f : sqrtf(csum) * up) : 1.0f;
+        q_meta[4 * q + 2] = ok ? sqrtf(red[0]) * up + ((fd + 32.f) * 5.9604645e-8f + 1e-6f + (rot_p ? 1e-5f : 0.f)) * unit : 0.f;
         q_meta[4 * q + 3] = 0.f;
     }
 }
@@ -1685,15 +1819,43 @@ namespace yams_accel {
 
 ScanArgs make_scan_args(const ScanLaunch& L); // scan_kernels.hip
 
+uint32_t i8_rotation_window(uint32_t dim) { // P = 2^floor(log2 dim); 0: the rotated layout is not offered for this dimension
+    if (dim < 256 || dim > 4096) return 0;
+    uint32_t p = 256;
+    while (p * 2 <= dim) p *= 2;
+    return p;
+}
+static float i8_rotation_scale(uint32_t p) { return static_cast<float>(1.0 / std::sqrt(static_cast<double>(p))); }
+
+// dry != nullptr: the residues of every block_stride-th block only ({sum of e_b, count} at dry), nothing else is written
 hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
-                                  int8_t* out_i8, float* out_meta, double* stats) {
+                                  int8_t* out_i8, float* out_meta, double* stats, bool rotated, uint64_t block_stride, double* dry) {
     if (n_rows == 0) return hipSuccess;
+    if (block_stride == 0) block_stride = 1;
     const uint64_t first_block = first_row / I8_BLOCK_ROWS;
     const uint64_t end_row = first_row + n_rows;
-    const uint64_t n_blocks = (end_row + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS - first_block;
-    hipLaunchKernelGGL(shadow_build_i8_kernel, dim3(static_cast<uint32_t>((n_blocks + 3) / 4)), dim3(256), 0, st,
-                       rows, first_block, end_row, dim, out_i8, out_meta);
-    if (stats) {
+    const uint64_t n_blocks = ((end_row + I8_BLOCK_ROWS - 1) / I8_BLOCK_ROWS - first_block + block_stride - 1) / block_stride;
+    const dim3 grid(static_cast<uint32_t>((n_blocks + 3) / 4));
+    const uint32_t p = rotated ? i8_rotation_window(dim) : 0;
+    if (rotated && !p) return hipErrorInvalidValue;
+    const float sc = p ? i8_rotation_scale(p) : 0.f;
+    const size_t lds = p ? static_cast<size_t>(dim) * 16 : 0;
+#define YA_BUILD_I8(EPL) hipLaunchKernelGGL((shadow_build_i8_kernel<EPL>), grid, dim3(256), lds, st, rows, first_block, end_row, dim, out_i8, out_meta, sc, block_stride, dry)
+    switch (p / 64) {
+        case 0: YA_BUILD_I8(0); break;
+        case 4: YA_BUILD_I8(4); break;
+        case 8: YA_BUILD_I8(8); break;
+        case 16: YA_BUILD_I8(16); break;
+        case 32: YA_BUILD_I8(32); break;
+        case 64: {
+            static bool attr = false;   // 64 KiB of dynamic LDS: above the default limit
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shadow_build_i8_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
+            YA_BUILD_I8(64); break;
+        }
+        default: return hipErrorInvalidValue;
+    }
+#undef YA_BUILD_I8
+    if (stats && !dry) {
         uint32_t g = static_cast<uint32_t>((n_blocks + 255) / 256);
         if (g > 256) g = 256;
         hipLaunchKernelGGL(i8_meta_stats_kernel, dim3(g), dim3(256), 0, st, out_meta, first_block, first_block + n_blocks, stats);
@@ -1702,11 +1864,13 @@ hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t fi
 }
 
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
-                          int8_t* q_i8, float* q_meta, bool raw_queries, uint32_t* zero_words, uint64_t n_zero_words) {
+                          int8_t* q_i8, float* q_meta, bool raw_queries, uint32_t* zero_words, uint64_t n_zero_words, bool rotated) {
     if (q_pad == 0) return hipSuccess;
     if (n_zero_words >> 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), 0, st, qprep, nq, q_pad, dim, q_i8, q_meta, raw_queries ? 1 : 0,
-                       zero_words, zero_words ? static_cast<uint32_t>(n_zero_words) : 0u);
+    const uint32_t p = rotated ? i8_rotation_window(dim) : 0;
+    if (rotated && !p) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prep_i8_kernel, dim3(q_pad), dim3(256), p ? static_cast<size_t>(dim) * 4 : 0, st, qprep, nq, q_pad, dim, q_i8, q_meta, raw_queries ? 1 : 0,
+                       zero_words, zero_words ? static_cast<uint32_t>(n_zero_words) : 0u, p, p ? i8_rotation_scale(p) : 0.f);
     return hipGetLastError();
 }
 

@@ -103,7 +103,7 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
 // Quantises the prepared (unit) queries of a batch: k-slab-major int8 plane + {t_q, c_q, f_q} per query.
 hipError_t launch_prep_i8(hipStream_t st, const float* qprep, uint32_t nq, uint32_t q_pad, uint32_t dim,
                           int8_t* q_i8, float* q_meta, bool raw_queries = false, uint32_t* zero_words = nullptr,
-                          uint64_t n_zero_words = 0);
+                          uint64_t n_zero_words = 0, bool rotated = false);
 // L2 on the int8 tier.  Per batch and shard: (1) norm statistics of the shard — per 64-row block the smallest row norm,
 // shard-wide the norm range, the largest in-block spread in units of the block scale, and the rows whose squared
 // norm lies outside norm_in_range() (counted and listed: unconditional candidates); stats = 8 words, zeroed first.
@@ -124,7 +124,9 @@ float i8_l2_eps(uint32_t dim);
 // (Re)builds the INT8 shadow of every 16-row block that intersects rows [first_row, first_row + n_rows)
 // of the mirror at `rows`; stats (nullable) = {sum of e_b (double), blocks counted (u64 bits)}.
 hipError_t launch_shadow_build_i8(hipStream_t st, const float* rows, uint64_t first_row, uint64_t n_rows, uint32_t dim,
-                                  int8_t* out_i8, float* out_meta, double* stats);
+                                  int8_t* out_i8, float* out_meta, double* stats, bool rotated = false, uint64_t block_stride = 1,
+                                  double* dry = nullptr);
+uint32_t i8_rotation_window(uint32_t dim);   // 0: no rotated layout for this dimension
 // After the sample pass: q_thr[q] = per-query halves of the filter's integer thresholds.
 // int8 tier: workgroups of the filter launch (the survivor log has 8 regions of log_cap entries per group)
 uint64_t i8_log_regions(const ScanLaunch& L);
