@@ -1224,6 +1224,14 @@ def distribution_leg(a, torch, dev, local, kind):
         def make_queries():
             x = torch.randn((nq, d), generator=g, device=dev) * scale
             return (x / x.norm(dim=1, keepdim=True)).contiguous()
+    elif kind == "gaussian":        # isotropic normal components: what the rotated layout makes of any corpus, and the int8 bound's
+        for r0 in range(0, n, chunk):   # usual width (uniform components, the headline's synthetic rows, quantise 2.4x better)
+            m = min(chunk, n - r0)
+            x = torch.randn((m, d), generator=g, device=dev)
+            tc[r0:r0 + m] = x / x.norm(dim=1, keepdim=True)
+        def make_queries():
+            x = torch.randn((nq, d), generator=g, device=dev)
+            return (x / x.norm(dim=1, keepdim=True)).contiguous()
     else:
         raise ValueError(kind)
     n_qb = 4
@@ -1236,7 +1244,9 @@ def distribution_leg(a, torch, dev, local, kind):
     tm8 = torch.empty(((n + 15) // 16, 2), dtype=torch.float32, device=dev)
     # the layout of the int8 shadow: measured, as the plugin does at a corpus' first append ("i8_layout": "auto")
     i8_flags, res_plain, res_rot = acc0.choose_i8_layout(tc.data_ptr(), n, d) if a.dist_i8_layout == "auto" else ((1 if a.dist_i8_layout == "rotated" else 0), None, None)
+    acc0.synchronize(); t_b8 = time.perf_counter()
     mean_res = acc0.build_shadow_i8_device(tc.data_ptr(), n, d, t8.data_ptr(), tm8.data_ptr(), want_mean_err=True, i8_flags=i8_flags)
+    t_b8 = (time.perf_counter() - t_b8) * 1e3
     view = acc0.corpus_view(tc.data_ptr(), n, d, rows_bf16_ptr=tb.data_ptr(), rows_nsq_ptr=tn.data_ptr(),
                             rows_i8_ptr=t8.data_ptr(), rows_i8_meta_ptr=tm8.data_ptr(), i8_flags=i8_flags)
     acc0.synchronize()
@@ -1289,7 +1299,7 @@ def distribution_leg(a, torch, dev, local, kind):
     last = n_qb - 1
     leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
            "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res, "i8_layout": "rotated" if i8_flags & 1 else "plain",
-           "sampled_residue_plain": res_plain, "sampled_residue_rotated": res_rot,
+           "sampled_residue_plain": res_plain, "sampled_residue_rotated": res_rot, "shadow_i8_build_ms": t_b8,
            "filter_tier": diags[0].get("filter_tier"),
            **{kk: [dg.get(kk) for dg in diags] for kk in ("filter_candidates", "rescored_rows", "widened_queries", "retried_queries", "escalated_queries", "exact_fallback_queries")}}
     n_oq = 64 if a.oracle_queries is None else min(64, a.oracle_queries)

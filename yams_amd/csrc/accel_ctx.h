@@ -45,7 +45,9 @@ struct yams_accel_ctx {
     // wide as the shadow's quantisation residue — on strongly anisotropic rows (a few large components, a long tail of small
     // ones) five times wider than on isotropic ones, and every query then fails its proof and pays a split-bf16 sweep on top.
     // Keyed by the int8 shadow's address; `bf16_first` batches start on the bf16 tier, every 256th one probes int8 again.
-    struct TierHint { uint64_t n_rows = 0; bool bf16_first = false; uint32_t served = 0; };
+    // depth: what the int8 tier's batches on this corpus needed — 0: the plan's stage 1 (3k + 64 candidates) proves them;
+    // 1: most proofs needed the whole list (stage 1 re-scores all of it at once); 2: and many lists were too short (deeper lists)
+    struct TierHint { uint64_t n_rows = 0; bool bf16_first = false; uint32_t served = 0; uint8_t depth = 0; uint32_t served_deep = 0; };
     std::map<const void*, TierHint> tier_hints;
     uint32_t emu_calls = 0; // measurement build: batches this context has served (emulation knobs of scan_api.cpp)
     // pinned host staging

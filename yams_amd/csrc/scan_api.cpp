@@ -29,7 +29,8 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 // filter needs more candidates re-scored before the proof can succeed, not a different threshold.
 // l2_band: the single-pass L2 filter of the bf16 tier (its score carries +E itself, the band around the k-th best
 // is 2E wide); the int8 tier's L2 bound is as tight as its cosine bound and plans like it.
-ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes, bool l2_band) {
+// depth (int8 tier, learnt per corpus: TierHint): 1 = stage 1 re-scores the whole list, 2 = and the lists are half as long again.
+ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool bf16, int passes, bool l2_band, int depth = 0) {
     ScanPlan p;
     p.n_rows = n_rows; p.dim = dim; p.n_queries = nq;
     p.tile_rows = bf16 ? 256 : kTileRows;
@@ -53,6 +54,10 @@ ScanPlan make_plan(uint64_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, bool 
     // 2.7x what the proof needs, the chance of a list too short to prove is ~1e-7 per query)
     const uint32_t need_rank = (2 * p.kprime + p.kprime / 2 + 32 + p.sample_stride - 1) / p.sample_stride;
     p.tau_rank = std::min<uint32_t>(std::max<uint32_t>(16, round_up(need_rank, 16)), kRescoreMax);
+    // (a list longer than what can be re-scored does not hurt the proof: the best kRescoreMax bounds are re-scored and the next
+    // one is the proof's threshold; a list cut short by a threshold the sample put too high does)
+    if (depth >= 2 && p.tau_rank * 2 <= 256 && p.n_groups >= p.tau_rank * 2) p.tau_rank *= 2;
+    if (depth >= 1) p.kprime = kRescoreMax;
     // expected list length tau_rank * stride (relative spread ~1/sqrt(tau_rank)): 4x is > 15 sigma
     uint64_t cap = std::max<uint64_t>(4096, 4ull * p.tau_rank * p.sample_stride);
     if (p.n_groups < p.tau_rank) cap = std::max<uint64_t>(cap, n_rows); // threshold is -inf
@@ -416,7 +421,19 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             if (bf16 && !split_only) passes = std::atoi(pv) == 3 ? 3 : 1;
         if (passes != 1 || (bf16_version != 2 && bf16_version != 3 && bf16_version != 30 && bf16_version != 31 && bf16_version != 32 && bf16_version != 37 && bf16_version != 38 && !(bf16_version >= 40 && bf16_version <= 99))) i8 = false;
 #endif
-        ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2);
+        // Depth hint (round 6): on rows with Gaussian components — what embedding models emit, and what the rotated layout makes
+        // of any corpus — the int8 bound is 2.4x as wide as on the bench's uniform rows and the proof of a top-100 over 12.5M
+        // rows needs ~850 candidates re-scored, not the plan's 384: every query failed stage 1 and was widened, a third found
+        // its list too short and went through a second sweep (11.4 ms per batch instead of 7.6).  The context remembers per
+        // corpus what its batches needed and plans the next ones for it (probed without the hint every 256th batch).
+        yams_accel_ctx::TierHint* dhint = nullptr;
+        int depth = 0;
+        if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry) {
+            dhint = hint ? hint : &ctx->tier_hints[corpus->rows_i8];
+            if (dhint->n_rows != corpus->n_rows) { *dhint = yams_accel_ctx::TierHint{}; dhint->n_rows = corpus->n_rows; }
+            if (dhint->depth && (++dhint->served_deep & 255u) != 0) depth = dhint->depth;
+        }
+        ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2, depth);
         if (retry) plan.kprime = kRescoreMax;   // (the retry's lists are what the proof needs: all of a list is re-scored)
         ScanLaunch L;
         L.plan = plan; L.rows = corpus->rows; L.row_mask = corpus->row_mask;
@@ -433,6 +450,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // kernel would have to wait for it.  The half-tile form (two small workgroups per CU) leaves it room.
         L.i8_sample_small_grid = static_cast<bool>(ctx->before_sweep) || ctx->sweep_hold;
         if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
+        if (!i8 && depth) { depth = 0; dhint = nullptr; plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2); L.plan = plan; } // (the hint is the int8 tier's)
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         if (i8 && metric == YAMS_SCAN_L2) {
             L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);
@@ -466,7 +484,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             if (!L.i8_l2 && metric == YAMS_SCAN_COSINE) { // proof-aware threshold (tau_select_kernel)
                 L.tau_rows_meta = corpus->rows_i8_meta; L.tau_n_blocks = (corpus->n_rows + 63) / 64;
                 L.tau_rank2 = (k + plan.sample_stride - 1) / plan.sample_stride + 4;     // P(fewer than k rows reach that sample value) < 1 %
-                L.tau_max_groups = kRescoreMax / plan.sample_stride;                         // the list must stay re-scorable as a whole
+                L.tau_max_groups = kRescoreMax * 3u / 2 / plan.sample_stride;               // what the crowd is estimated at must fit the list (cap: 4096 rows or more)
             }
             if (L.i8_l2) { // the per-batch tables of the L2 threshold: built after the sample pass (below)
                 const uint64_t n_blocks = (corpus->n_rows + 63) / 64;
@@ -769,6 +787,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             stage_mark("escalation done", escalated);
         }
         if (hint && i8) hint->bf16_first = static_cast<uint64_t>(escalated) * 2 > nq;    // (an int8 batch — first or probe — decides for the next 255)
+        if (dhint && i8) {
+            if (depth == 0) dhint->depth = static_cast<uint64_t>(retried) * 8 > nq ? 2 : (static_cast<uint64_t>(widened) * 4 > nq ? 1 : 0); // (a plain batch decides)
+            else if (depth == 1 && static_cast<uint64_t>(retried) * 8 > nq) dhint->depth = 2;
+        }
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {
             // stage 3: exhaustive fp64 for the queries that could not be proven complete
