@@ -219,7 +219,7 @@ def parse():
                          "digest; one in eight also through oracle/_ref — ~40 s on 16 host threads at 100 GiB")
     ap.add_argument("--verify-sample-ingest", dest="verify_all_ingest", action="store_false",
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
-    ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic (a throughput leg each on the headline shape; 64 oracle queries each)")
+    ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic, gaussian (a throughput leg each on the headline shape; 64 oracle queries each)")
     ap.add_argument("--only-distribution", action="store_true", help="run the --distribution legs alone")
     ap.add_argument("--dist-i8-layout", default="auto", choices=["auto", "plain", "rotated"], help="int8 shadow layout of the distribution legs (auto: yams_scan_choose_i8_layout_device decides)")
     ap.add_argument("--dist-flags", type=int, default=0, help="YAMS_SCAN_FLAG_* bits of the distribution legs' searches (measurement: 64 = no int8 tier)")
@@ -1425,7 +1425,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.only_distribution:
-        res = {kd: distribution_leg(a, torch, dev, local, kd) for kd in (a.distribution or "clustered,anisotropic").split(",")}
+        res = {kd: distribution_leg(a, torch, dev, local, kd) for kd in (a.distribution or "clustered,anisotropic,gaussian").split(",")}
         sys.stderr.write("distribution: " + json.dumps(_clean(res)) + "\n")
         _print_on_real_stdout(json.dumps(_clean(res), allow_nan=False))
         return
@@ -2096,7 +2096,7 @@ def main():
     if not a.no_distribution_legs and world == 1 and n >= 1_000_000:
         # the same shape on corpora that are not uniform on the sphere (after the headline's tensors are gone: each leg builds
         # a shard of its own)
-        pending_distributions = [kd for kd in (a.distribution or "clustered,anisotropic").split(",") if kd]
+        pending_distributions = [kd for kd in (a.distribution or "clustered,anisotropic,gaussian").split(",") if kd]
     else:
         pending_distributions = []
     if not a.no_config2_leg and world == 1:
