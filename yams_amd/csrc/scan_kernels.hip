@@ -812,7 +812,35 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     // 16-byte pieces from 64 different lines per instruction: 4-8x the traffic between L1, L2 and HBM.
     const bool staged = (dim & 31u) == 0 && ((reinterpret_cast<uintptr_t>(a.rows) & 15u) == 0);
     const uint32_t n_rounds = (a.n_cand + blockDim.x - 1) / blockDim.x;
+    // Early close (round 6; cosine, lists longer than one round — the widened and the deep stage): the candidates come in
+    // the order of their bounds, so once k of the rows re-scored so far beat the bound of the NEXT candidate (by the proof's
+    // own margin) no later candidate can enter the result and the proof will hold with what has been re-scored: the walk
+    // stops there (Gaussian rows, 12.5M x 768: a top-100 needs ~850 of the ~1900 listed candidates).
+    __shared__ uint32_t s_beat, s_ncand;
+    const bool may_close = METRIC == YAMS_SCAN_COSINE && n_rounds > 1 && !a.all_rows_listed && !(a.flags & kRescoreFlagPqRerank);
+    if (threadIdx.x == 0) { s_beat = 0; s_ncand = a.n_cand; }
     for (uint32_t round = 0; round < n_rounds; ++round) {
+        if (may_close && round > 0) {
+            const uint32_t n_done = round * blockDim.x;             // candidates [0, n_done) are re-scored, their keys in skey
+            __syncthreads();
+            const uint64_t nextk = cand[n_done];
+            bool stop = nextk == 0;                                  // (the list ends here: nothing left to walk)
+            if (!stop) {
+                const double ob = static_cast<double>(key_score(nextk));
+                const float reach = static_cast<float>(ob + a.err_bound + 1e-12);
+                uint32_t mine = 0;
+                for (uint32_t c = threadIdx.x; c < n_done; c += blockDim.x) mine += skey[c] != 0 && reach < key_score(skey[c]);
+                if (mine) atomicAdd(&s_beat, mine);
+                __syncthreads();
+                stop = ob == ob && s_beat >= a.k;
+                __syncthreads();
+                if (threadIdx.x == 0) s_beat = 0;
+            }
+            if (stop) {
+                if (threadIdx.x == 0) s_ncand = n_done;
+                break;
+            }
+        }
         const uint32_t c = round * blockDim.x + threadIdx.x;
         const uint64_t ck = c < a.n_cand ? cand[c] : 0;
         bool live = ck != 0;
@@ -990,7 +1018,8 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             const float ninf = -__builtin_inff();
             double ob = 0.0;
             bool has_outside = false;
-            const uint64_t nextk = (a.n_cand < a.cand_stride) ? cand[a.n_cand] : 0;
+            const uint32_t n_walked = s_ncand;      // (< n_cand when the walk closed early)
+            const uint64_t nextk = (n_walked < a.cand_stride) ? cand[n_walked] : 0;
             if (nextk != 0) { has_outside = true; ob = static_cast<double>(key_score(nextk)); }
             else if (a.tau && a.tau[q] > ninf) { has_outside = true; ob = static_cast<double>(a.tau[q]); }
             // (a NaN tau admitted every row to the list, so nothing is outside)
@@ -1549,6 +1578,9 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     if (rs > static_cast<size_t>(RS_MAX)) rs = RS_MAX;
     // one round of the candidate walk when the candidates fit a block (384 candidates: 6 waves)
     uint32_t threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
+    // longer lists (the widened / deep stage): rounds of 256 candidates — the walk can close after any of them, and two
+    // workgroups fit a CU's LDS where one of 512 threads did
+    if (R.n_cand > 512 && metric == YAMS_SCAN_COSINE && !(R.flags & kRescoreFlagPqRerank)) threads = 256;
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
                       ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
                       (threads / 64) * 64 * RS_STAGE_STRIDE * sizeof(float);
