@@ -105,6 +105,11 @@ def compact_line(out):
                                   "filter_candidates", "exact_fallback_queries", "results_identical_to_the_oracle_run", "oracle_queries", "error"))
         if "error" in c["config2"]:
             c["config2"]["error"] = _short(c["config2"]["error"], 200)
+    pqv = out.get("pq")
+    if pqv:
+        c["pq"] = _pick(pqv, ("ms_per_step", "qps", "adc_launch_ms", "achieved", "frac", "lds_TBps", "lds_frac", "identical_to_the_restated_oracle", "error"))
+        if "error" in c["pq"]:
+            c["pq"]["error"] = _short(c["pq"]["error"], 200)
     nu = out.get("non_uniform")
     if nu:      # one summary object: step time per distribution, the proof outcomes, the oracle verdicts
         c["non_uniform"] = {}
@@ -225,6 +230,8 @@ def parse():
     ap.add_argument("--dist-flags", type=int, default=0, help="YAMS_SCAN_FLAG_* bits of the distribution legs' searches (measurement: 64 = no int8 tier)")
     ap.add_argument("--no-distribution-legs", action="store_true", help="skip the clustered / anisotropic legs of the default run")
     ap.add_argument("--no-config2-leg", action="store_true", help="skip the BASELINE config 2 (1M x 384, Q = 256) leg")
+    ap.add_argument("--only-pq", action="store_true", help="run the product-quantised engine's leg alone")
+    ap.add_argument("--no-pq-leg", action="store_true", help="skip the product-quantised engine's leg of the default run")
     ap.add_argument("--only-config2", action="store_true", help="run the BASELINE config 2 leg alone (profiling)")
     ap.add_argument("--config2-lanes", type=int, default=4, help="search lanes of the config 2 leg")
     ap.add_argument("--config2-lane-sweep", default="2,4", help="comma-separated lane counts to time in the config 2 leg (the best is reported)")
@@ -1185,6 +1192,85 @@ def config2_leg(a, torch, dev, local, lane_counts=None, batches=None, oracle_que
     return leg
 
 
+def pq_leg(a, torch, dev, local, batches=40, oracle_queries=8):
+    """SURVEY 8(f) N4 — the product-quantised engine (the reference's default SimeonPqAdc, simeonPqSearchUnlocked,
+    sqlite_vec_backend.cpp:3868-4056) on the shape of BASELINE config 2: 1M x 384 rows, the reference's default index (32
+    sub-quantisers, rerank factor 2: sqlite_vec_backend.h:55-64), 256 queries per batch, top-100.  Codes, the per-query tables
+    (what simeon's PQInnerProductQuery holds — the host builds them, simeon being the host's), tie ranks and rows are resident;
+    a step = one batch through yams_scan_pq_topk_device (ADC scan of every code, the best 200 per query, their cosine re-rank
+    over the fp32 rows, final order).  Synthetic index: random code bytes and N(0, 0.05) table entries — the arithmetic and
+    the traffic are those of a trained index, the recall is not a quantity here.  A few queries are checked against the
+    restated oracle (parity of the ADC sum order is unpinned: simeon is absent from the checkout)."""
+    import ctypes as C
+    import numpy as np
+    from yams_amd import _lib
+    from yams_amd.accel import Accel
+    n, d, m, nq, k, rf = 1_000_000, 384, 32, 256, 100, 2
+    acc = Accel(local, torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + 31)
+    tc = torch.empty((n, d), dtype=torch.float32, device=dev)
+    acc.synth_rows(a.seed + 31, 0, n, d, tc.data_ptr())
+    codes = torch.randint(0, 256, (n, m), generator=g, device=dev, dtype=torch.uint8)
+    luts = (torch.randn((nq, m, 256), generator=g, device=dev) * 0.05).contiguous()
+    tq = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    acc.synth_rows(a.seed + 31, 1 << 40, nq, d, tq.data_ptr())
+    perm = torch.randperm(n, generator=g, device=dev).to(torch.int32)          # rank of every code's tie-break key
+    key_row = torch.empty(n, dtype=torch.int32, device=dev); key_row[perm.long()] = torch.arange(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    view = acc.corpus_view(tc.data_ptr(), n, d)
+    pq = _lib.ScanPqIndex(codes.data_ptr(), n, m, 0, perm.data_ptr(), key_row.data_ptr())
+    prm = _lib.ScanPqParams(k, -1.0, rf, 0)
+    o_s = torch.empty((nq, k), dtype=torch.float32, device=dev); o_r = torch.empty((nq, k), dtype=torch.int64, device=dev); o_c = torch.empty(nq, dtype=torch.int32, device=dev)
+    diag = _lib.ScanDiag()
+
+    def step(want_diag=False):
+        acc._check(acc.L.yams_scan_pq_topk_device(acc.ctx, C.byref(view), C.byref(pq), tq.data_ptr(), luts.data_ptr(), nq, C.byref(prm), None, 0,
+                                                  o_s.data_ptr(), o_r.data_ptr(), o_c.data_ptr(), C.byref(diag) if want_diag else None))
+    for _ in range(3):
+        step()
+    acc.enable_timing(True)
+    acc.synchronize(); t0 = time.perf_counter()
+    for _ in range(batches):
+        step()
+    acc.synchronize(); dt = (time.perf_counter() - t0) / batches
+    adc_ms, adc_n = acc.kernel_ms("pq_adc")
+    acc.enable_timing(False)
+    step(want_diag=True); acc.synchronize()
+    groups = (nq + 3) // 4
+    leg = {"workload": "product-quantised engine (SimeonPqAdc): 1M x 384 rows, 32 sub-quantisers, rerank factor 2, 256 queries per batch, top-100; index and tables resident",
+           "ms_per_step": dt * 1e3, "qps": nq / dt, "adc_launch_ms": adc_ms, "adc_launches": adc_n,
+           "kernel": "pq_adc_filter_kernel<.., 4, 2> (four queries' tables interleaved in LDS: one 16-byte LDS read per code byte; keys only of the codes that reach the sampled threshold)",
+           "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+           "algorithmic_bytes_per_launch": n * m + nq * m * 1024,
+           "bytes_moved_by_design_per_launch": n * m * groups + nq * m * 1024,
+           "lds_bytes_per_launch": n * m * nq * 4, "lds_peak_TBps": 256 * 256 * 2.4e9 / 1e12,
+           "rescored_rows": diag.as_dict().get("rescored_rows"), "filter_candidates": diag.as_dict().get("filter_candidates")}
+    if adc_ms:
+        leg["achieved"] = leg["algorithmic_bytes_per_launch"] / (adc_ms * 1e-3) / 1e9
+        leg["frac"] = leg["achieved"] / 8000.0
+        leg["design_bytes_GBps"] = leg["bytes_moved_by_design_per_launch"] / (adc_ms * 1e-3) / 1e9
+        leg["lds_TBps"] = leg["lds_bytes_per_launch"] / (adc_ms * 1e-3) / 1e12       # the resource that binds: one table entry per (query, code byte)
+        leg["lds_frac"] = leg["lds_TBps"] / leg["lds_peak_TBps"]
+        leg["note"] = ("the HBM view prices the launch against reading every code byte once; four queries' tables fill the LDS, so the codes are "
+                       "re-read (from L2 / MALL) once per four queries, and the table look-ups — random 16-byte LDS reads — are what the launch spends its time on")
+    n_oq = oracle_queries if a.oracle_queries is None else min(oracle_queries, a.oracle_queries)
+    if n_oq > 0:
+        o = oracle_mod().oracle()
+        hc = tc.cpu().numpy(); hcodes = codes.cpu().numpy(); hl = luts.cpu().numpy(); hq = tq.cpu().numpy()
+        tie = perm.cpu().numpy().astype(np.uint64)      # (any keys in the same order as the ranks)
+        rr = o_r.cpu().numpy(); ss = o_s.cpu().numpy(); cc = o_c.cpu().numpy()
+        t_or = time.perf_counter(); exact = True
+        for qi in [int(x) for x in np.linspace(0, nq - 1, n_oq).round()]:
+            rows, sims, _ = o.pq_search(hc, hcodes, hl[qi], hq[qi], k, -1.0, rf, tie_keys=tie, chunk_rank=np.arange(n, dtype=np.uint64))
+            cnt = int(cc[qi])
+            exact = exact and cnt == len(rows) and np.array_equal(rr[qi, :cnt], rows) and np.array_equal(ss[qi, :cnt].view(np.uint32), np.asarray(sims, np.float32).view(np.uint32))
+        leg["identical_to_the_restated_oracle"] = bool(exact); leg["oracle_queries"] = n_oq; leg["oracle_seconds"] = time.perf_counter() - t_or
+        leg["parity"] = "unpinned for the order of the ADC sum (third_party/simeon absent); the rest restated from sqlite_vec_backend.cpp:3868-4056"
+    acc.close()
+    return leg
+
+
+
 def distribution_leg(a, torch, dev, local, kind):
     """The headline shape (rows_per_gpu x dim, query batch, k) on a corpus that is NOT uniform on the sphere — real embedding
     corpora are clustered and anisotropic (the reference stores what its embedding models emit, src/vector/vector_database.cpp:
@@ -1428,6 +1514,11 @@ def main():
         res = {kd: distribution_leg(a, torch, dev, local, kd) for kd in (a.distribution or "clustered,anisotropic,gaussian").split(",")}
         sys.stderr.write("distribution: " + json.dumps(_clean(res)) + "\n")
         _print_on_real_stdout(json.dumps(_clean(res), allow_nan=False))
+        return
+    if a.only_pq:
+        leg = pq_leg(a, torch, dev, local)
+        sys.stderr.write("pq: " + json.dumps(_clean(leg)) + "\n")
+        _print_on_real_stdout(json.dumps(_clean(leg), allow_nan=False))
         return
     if a.only_config2:
         sweep = [int(x) for x in a.config2_lane_sweep.split(",")] if a.config2_lane_sweep else None
@@ -2105,6 +2196,11 @@ def main():
             out["config2"] = config2_leg(a, torch, dev, local, lane_counts=sweep, batches=a.config2_batches)
         except Exception as e:          # noqa: BLE001 - the headline number above stands on its own
             out["config2"] = {"error": repr(e)}
+    if not a.no_pq_leg and world == 1:
+        try:
+            out["pq"] = pq_leg(a, torch, dev, local)
+        except Exception as e:          # noqa: BLE001 - the headline number above stands on its own
+            out["pq"] = {"error": repr(e)}
     if not a.no_ingest and world == 1:
         del tc, tb, tn, t8, tm8, view, pipe, res
         acc.L.yams_accel_ctx_destroy(acc.ctx)   # drop the scan workspace before the ingest leg

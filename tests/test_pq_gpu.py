@@ -130,3 +130,70 @@ def test_pq_search_at_the_reference_default_scale(acc, oracle):
         cnt = int(r.counts[qi])
         assert cnt == len(rows) and r.rows[qi, :cnt].tolist() == rows.tolist(), qi
         assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), qi
+
+
+def _random_index(rng, n, m, d, n_rows=8_000):
+    """Random codes over n index entries that point at n_rows distinct rows (the scan does not care where codes came from)."""
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    keys = rng.integers(0, 1 << 63, n).astype(np.uint64)
+    roi = rng.integers(0, n_rows, n).astype(np.uint32)
+    return codes, keys, roi
+
+
+@pytest.mark.parametrize("m,lanes,k,rf", [(32, 1, 100, 2), (32, 8, 10, 4), (8, 4, 50, 2), (40, 16, 100, 2), (100, 1, 20, 2), (7, 1, 30, 3), (32, 1, 1000, 2)])
+def test_filtered_adc_scan_lists_exactly_the_best(acc, oracle, m, lanes, k, rf):
+    """Indexes of >= 65 536 entries go through the FILTERED form (pq_adc_filter_kernel: sample -> threshold -> keys of the codes
+    that reach it): the best approxK of each list must be the best approxK of all codes — rows, order and score bits equal the
+    oracle's — under every served sum order, every table-group size (m <= 36: four queries' tables per workgroup, <= 72: two,
+    else one), an m that is not a multiple of four, approxK up to 2000."""
+    n, d = 150_001, (m * 8 if m % 4 == 0 else m * 16)
+    rng = np.random.default_rng(300 + m + lanes)
+    corpus = oracle.synth_rows(300 + m, 0, 8_000, d)
+    pq = _pq.Pq(_pq.unit(corpus), m, 300 + m)
+    codes, keys, roi = _random_index(rng, n, m, d)
+    codes[500:560] = codes[499]                                              # a run of equal ADC scores: the tie key decides
+    queries = oracle.synth_rows(300 + m, 1 << 40, 9, d)
+    luts = np.stack([pq.lut(q) for q in queries])
+    d_rows = acc.to_device(corpus)
+    v = acc.corpus_view(d_rows.ptr, corpus.shape[0], d)
+    r = acc.scan_pq_topk(v, codes, luts, queries, k, -1.0, rf, tie_keys=keys, row_of_index=roi, sum_lanes=lanes)
+    d_rows.free()
+    assert r.diag["exact_fallback_queries"] == 0, r.diag                     # every query was served by the filtered form
+    for qi in range(9):
+        rows, sims, _ = oracle.pq_search(corpus, codes, luts[qi], queries[qi], k, -1.0, rf, tie_keys=keys, row_of_index=roi, sum_lanes=lanes)
+        cnt = int(r.counts[qi])
+        assert cnt == len(rows) and r.rows[qi, :cnt].tolist() == rows.tolist(), (qi, r.diag)
+        assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), qi
+
+
+def test_filtered_adc_scan_falls_back_where_its_lists_are_no_use(acc, oracle):
+    """Tables that make every code score the same (all zeros: the threshold is that score, every code reaches it, the list is
+    cut off), a table with infinite entries (checked on the codes whose score is a number: a NaN score sorts nowhere in the
+    reference's comparator — undefined there, left out here) and a table whose best scores tie by the thousand:
+    those queries are served by the unfiltered form, the others by the filtered one, all identical to the oracle.  Plus a
+    candidate restriction of 70 000 indices (filtered) and one of 3 000 (unfiltered)."""
+    n, m, d, k = 120_000, 16, 128, 25
+    rng = np.random.default_rng(321)
+    corpus = oracle.synth_rows(321, 0, 8_000, d)
+    pq = _pq.Pq(_pq.unit(corpus), m, 321)
+    codes, keys, roi = _random_index(rng, n, m, d)
+    queries = oracle.synth_rows(321, 1 << 40, 6, d)
+    luts = np.stack([pq.lut(q) for q in queries])
+    luts[1] = 0.0                                                            # every score 0.0
+    luts[3, 2, 17] = np.inf; luts[3, 9, 200] = -np.inf                       # infinite entries: scores of +inf and -inf ...
+    codes[(codes[:, 2] == 17) & (codes[:, 9] == 200), 9] = 201               # ... but no code with both (NaN: undefined in the reference)
+    luts[4] = np.round(luts[4] * 4) / 4                                      # a coarse table: thousands of equal scores
+    d_rows = acc.to_device(corpus)
+    v = acc.corpus_view(d_rows.ptr, corpus.shape[0], d)
+    for cand in (None, np.sort(rng.choice(n, 70_000, replace=False)).astype(np.uint32), np.sort(rng.choice(n, 3_000, replace=False)).astype(np.uint32)):
+        r = acc.scan_pq_topk(v, codes, luts, queries, k, -1.0, 2, tie_keys=keys, row_of_index=roi, candidates=cand)
+        if cand is None or cand.size >= 65536:
+            assert 1 <= r.diag["exact_fallback_queries"] <= 3, r.diag        # the all-equal table for certain
+        else:
+            assert r.diag["exact_fallback_queries"] == 6, r.diag
+        for qi in range(6):
+            rows, sims, _ = oracle.pq_search(corpus, codes, luts[qi], queries[qi], k, -1.0, 2, tie_keys=keys, row_of_index=roi, candidates=cand)
+            cnt = int(r.counts[qi])
+            assert cnt == len(rows) and r.rows[qi, :cnt].tolist() == rows.tolist(), (qi, cand is None, r.diag)
+            assert np.array_equal(r.scores[qi, :cnt].view(np.uint32), sims.view(np.uint32)), qi
+    d_rows.free()
