@@ -494,9 +494,13 @@ YAMS_ACCEL_API yams_status_t yams_scan_sharded_topk_host(
  * yams_accel_alloc — the caller's own buffers — is exempt.  ..._alloc_faults: allocations failed by injection so far.
  * What the library promises under exhaustion: the failing call returns YAMS_ERR_RESOURCE_EXHAUSTED, the object it
  * was growing is left as it was (a corpus keeps its rows and answers searches), nothing is leaked (health JSON:
- * "mirror_bytes_mapped" / "mirror_bytes_parked"), and the same call succeeds once memory is there again. */
+ * "mirror_bytes_mapped" / "mirror_bytes_parked"), and the same call succeeds once memory is there again.
+ * MEASUREMENT BUILD ONLY (libyams_mi355x_accel_measure.so, -DYAMS_ACCEL_MEASURE): in the product library the three entry points
+ * exist — one ABI for both builds — and do nothing: no code in a host process can arm allocation failures there, and the
+ * allocation paths carry no check.  yams_accel_debug_alloc_injection_compiled() says which build this is (1 / 0). */
 YAMS_ACCEL_API void yams_accel_debug_fail_alloc_after(int64_t n);
 YAMS_ACCEL_API uint64_t yams_accel_debug_alloc_faults(void);
+YAMS_ACCEL_API int yams_accel_debug_alloc_injection_compiled(void);
 
 /* Fill a device matrix with the synthetic embedding recipe: Philox4x32-10
  * (seed, row, col/4) -> U[-1,1) -> fp32 L2-normalise.  Used by bench.py and tests so that a

@@ -10,6 +10,7 @@ Every result is compared with the oracle; the C++ adapter's side (ErrorCode::Res
 is tests/cpp/host_mirror_test.cpp."""
 import ctypes as C
 import json
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,31 @@ import pytest
 from yams_amd import _lib
 
 pytestmark = pytest.mark.gpu
+
+# The injection exists in the MEASUREMENT build only (the product library's doors are inert: ADVICE r5): a plain run of this
+# file re-runs it once with YAMS_ACCEL_MEASURE_LIB=1, where the tests below do their work.
+_MEASURE = bool(os.environ.get("YAMS_ACCEL_MEASURE_LIB"))
+needs_injection = pytest.mark.skipif(not _MEASURE, reason="allocation-failure injection is compiled into the measurement build only")
+
+
+@pytest.mark.skipif(_MEASURE, reason="this IS the measurement-build run")
+def test_exhaustion_tests_pass_on_the_measurement_build(accel_lib):
+    """The product library cannot be armed (the doors are there — one ABI — and do nothing) ..."""
+    import subprocess, sys
+    from yams_amd import build as _build
+    assert accel_lib.yams_accel_debug_alloc_injection_compiled() == 0
+    accel_lib.yams_accel_debug_fail_alloc_after(0)
+    assert accel_lib.yams_accel_debug_alloc_faults() == 0
+    accel_lib.yams_accel_debug_fail_alloc_after(-1)
+    # ... and the exhaustion tests run against the measurement build of the same sources
+    if not os.path.exists(_build.MEASURE_LIB):
+        _build.build(measure=True)
+    env = dict(os.environ, YAMS_ACCEL_MEASURE_LIB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
 
 
 def _health(L):
@@ -63,6 +89,7 @@ def armed(accel_lib):
     accel_lib.yams_accel_debug_fail_alloc_after(-1)
 
 
+@needs_injection
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("config", [b'{"device": 0}', b'{"devices": [0, 0], "stripe_rows": 4096}'])
 def test_an_append_that_exhausts_memory_leaves_the_corpus_serving(armed, oracle, config):
@@ -118,6 +145,7 @@ def test_an_append_that_exhausts_memory_leaves_the_corpus_serving(armed, oracle,
     L.yams_plugin_shutdown()
 
 
+@needs_injection
 @pytest.mark.timeout(600)
 def test_a_search_whose_workspace_cannot_grow_fails_alone(armed, oracle):
     """The scan's workspace and the sharded lanes' batch buffers grow with the batch: a batch that cannot get them fails
@@ -144,6 +172,7 @@ def test_a_search_whose_workspace_cannot_grow_fails_alone(armed, oracle):
     L.yams_plugin_shutdown()
 
 
+@needs_injection
 @pytest.mark.timeout(600)
 def test_flat_entry_points_report_exhaustion(armed, oracle):
     """yams_scan_topk (workspace), yams_dedup_set_create (digest set), yams_ingest_device (bitmaps / slots): status 7 with a

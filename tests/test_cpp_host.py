@@ -29,7 +29,19 @@ def test_host_mirror_reference_style_suite(config):
     exe, lib = _exe()
     r = subprocess.run([exe, lib, "--config", config], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "OK (0 failures)" in r.stdout
+    assert "OK (0 failures)" in r.stdout and "allocation-failure injection: not compiled into this library" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_mirror_suite_on_the_measurement_build_reaches_resource_exhausted():
+    """ErrorCode::ResourceExhausted through AccelVectorIndex needs allocation-failure injection, which only the measurement
+    build of the library carries: the same suite against libyams_mi355x_accel_measure.so, where that block runs."""
+    from yams_amd import build as b
+    exe, _ = _exe()
+    lib = b.build(measure=True)
+    r = subprocess.run([exe, lib, "--config", '{"device":0}'], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK (0 failures)" in r.stdout and "allocation-failure injection: exercised" in r.stdout
 
 
 def test_adapters_compile_against_the_reference_headers(accel_lib):

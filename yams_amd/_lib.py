@@ -203,7 +203,7 @@ EXPORTS = [
     "yams_accel_last_error", "yams_accel_device_info_json",
     "yams_accel_free_string", "yams_accel_trim", "yams_accel_malloc", "yams_accel_free", "yams_accel_upload",
     "yams_accel_download", "yams_accel_last_kernel_ms", "yams_accel_enable_kernel_timing",
-    "yams_accel_debug_fail_alloc_after", "yams_accel_debug_alloc_faults",
+    "yams_accel_debug_fail_alloc_after", "yams_accel_debug_alloc_faults", "yams_accel_debug_alloc_injection_compiled",
     "yams_scan_topk_device", "yams_scan_topk_host", "yams_scan_merge_topk_device", "yams_scan_pq_topk_device",
     "yams_scan_build_shadow_device", "yams_scan_build_shadow_i8_device", "yams_scan_build_shadow_i8_layout_device", "yams_scan_choose_i8_layout_device",
     "yams_scan_record_layout", "yams_scan_merge_records_device", "yams_scan_sharded_create",
@@ -257,6 +257,7 @@ def load(share_torch_runtime: bool = True) -> C.CDLL:
     L.yams_accel_debug_fail_alloc_after.argtypes = [C.c_int64]
     L.yams_accel_debug_fail_alloc_after.restype = None
     L.yams_accel_debug_alloc_faults.restype = C.c_uint64
+    L.yams_accel_debug_alloc_injection_compiled.restype = C.c_int
     L.yams_accel_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.yams_accel_ctx_destroy.argtypes = [vp]
     L.yams_accel_ctx_destroy.restype = None

@@ -29,6 +29,7 @@ yams_status_t hip_fail(yams_accel_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, e == hipErrorOutOfMemory ? YAMS_ERR_RESOURCE_EXHAUSTED : YAMS_ERR_INTERNAL, m);
 }
 
+#ifdef YAMS_ACCEL_MEASURE   // allocation-failure injection exists in the measurement build only (the product's doors are inert)
 namespace {
 std::atomic<long long> g_fail_after{-1};     // allocations that may still succeed; < 0: injection off
 std::atomic<unsigned long long> g_faults{0}; // allocations failed by injection
@@ -41,6 +42,7 @@ bool alloc_fault() {
     }
     return false;
 }
+#endif
 
 namespace {
 struct BigBuf { void* p; size_t cap; int device; };
@@ -537,5 +539,12 @@ yams_status_t yams_accel_last_kernel_ms(const yams_accel_ctx* cctx, const char* 
 } // extern "C"
 
 // ---- allocation fault injection (tests of the out-of-memory paths; see the header) ---------------------------------
+#ifdef YAMS_ACCEL_MEASURE
 extern "C" void yams_accel_debug_fail_alloc_after(int64_t n) { yams_accel::g_fail_after.store(n < 0 ? -1 : n); }
 extern "C" uint64_t yams_accel_debug_alloc_faults(void) { return yams_accel::g_faults.load(); }
+extern "C" int yams_accel_debug_alloc_injection_compiled(void) { return 1; }
+#else   // the product library: the symbols stay (one ABI for both builds), nothing can be armed
+extern "C" void yams_accel_debug_fail_alloc_after(int64_t) {}
+extern "C" uint64_t yams_accel_debug_alloc_faults(void) { return 0; }
+extern "C" int yams_accel_debug_alloc_injection_compiled(void) { return 0; }
+#endif

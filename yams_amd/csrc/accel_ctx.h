@@ -119,7 +119,11 @@ struct TimedRegion { // RAII-less helper: begin/end record events when timing is
 
 // Allocation fault injection (yams_accel_debug_fail_alloc_after): every allocation of device, pinned or VMM-backed memory
 // this library makes goes through one of the three doors below, which fail with hipErrorOutOfMemory once armed.
+#ifdef YAMS_ACCEL_MEASURE
 bool alloc_fault();
+#else
+constexpr bool alloc_fault() { return false; }   // (the product build: no injection, no atomic load on the allocation paths)
+#endif
 size_t big_trim(int device);
 inline hipError_t ya_malloc(void** p, size_t bytes) {
     if (alloc_fault()) { *p = nullptr; return hipErrorOutOfMemory; }
