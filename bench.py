@@ -226,6 +226,7 @@ def parse():
                     help="check a spread of 64 blobs of the ingest leg instead of all of them")
     ap.add_argument("--distribution", default=None, help="comma-separated corpora beside the uniform headline: clustered, anisotropic, gaussian (a throughput leg each on the headline shape; 64 oracle queries each)")
     ap.add_argument("--only-distribution", action="store_true", help="run the --distribution legs alone")
+    ap.add_argument("--dist-metric", default="cosine", choices=["cosine", "l2"], help="metric of the distribution legs (measurement)")
     ap.add_argument("--dist-i8-layout", default="auto", choices=["auto", "plain", "rotated"], help="int8 shadow layout of the distribution legs (auto: yams_scan_choose_i8_layout_device decides)")
     ap.add_argument("--dist-flags", type=int, default=0, help="YAMS_SCAN_FLAG_* bits of the distribution legs' searches (measurement: 64 = no int8 tier)")
     ap.add_argument("--no-distribution-legs", action="store_true", help="skip the clustered / anisotropic legs of the default run")
@@ -1282,7 +1283,8 @@ def distribution_leg(a, torch, dev, local, kind):
     import threading
     import numpy as np
     from yams_amd.accel import Accel, SweepGate
-    from yams_amd._lib import SCAN_COSINE
+    from yams_amd._lib import SCAN_COSINE, SCAN_L2
+    metric_id = SCAN_L2 if a.dist_metric == "l2" else SCAN_COSINE
     n, d, nq, k = a.rows_per_gpu, a.dim, a.queries, a.k
     g = torch.Generator(device=dev); g.manual_seed(a.seed + (11 if kind == "clustered" else 13))
     tc = torch.empty((n, d), dtype=torch.float32, device=dev)
@@ -1353,7 +1355,7 @@ def distribution_leg(a, torch, dev, local, kind):
                 torch.cuda.set_device(dev)
                 o = outs[lane]
                 for i in range(lane, count, lanes):
-                    accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(),
+                    accs[lane].scan_topk_device(view, tqs[i % n_qb].data_ptr(), nq, k, -1.0, metric_id, o[0].data_ptr(), o[1].data_ptr(),
                                                 o[2].data_ptr(), flags=a.dist_flags, want_diag=False)
             except BaseException as e:       # noqa: BLE001
                 errs.append(e)
@@ -1379,11 +1381,11 @@ def distribution_leg(a, torch, dev, local, kind):
     o = outs[0]
     diags = []
     for b in range(n_qb):       # the proof outcomes of every query batch
-        diags.append(accs[0].scan_topk_device(view, tqs[b].data_ptr(), nq, k, -1.0, SCAN_COSINE, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+        diags.append(accs[0].scan_topk_device(view, tqs[b].data_ptr(), nq, k, -1.0, metric_id, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
                                               flags=a.dist_flags, want_diag=True))
     torch.cuda.synchronize()
     last = n_qb - 1
-    leg = {"distribution": kind, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
+    leg = {"distribution": kind, "metric": a.dist_metric, "rows": n, "dim": d, "queries": nq, "k": k, "search_lanes": lanes, "ms_per_step": dt * 1e3, "qps_on_resident_corpus": nq / dt,
            "launch_ms": tot / cnt if cnt else None, "shadow_i8_mean_residue": mean_res, "i8_layout": "rotated" if i8_flags & 1 else "plain",
            "sampled_residue_plain": res_plain, "sampled_residue_rotated": res_rot, "shadow_i8_build_ms": t_b8,
            "filter_tier": diags[0].get("filter_tier"),
@@ -1394,14 +1396,21 @@ def distribution_leg(a, torch, dev, local, kind):
         qsel = [int(x) for x in np.linspace(0, nq - 1, n_oq).round()]
         qh = tqs[last][qsel].cpu().numpy()
         t_or = time.perf_counter()
-        part = _o.scan_threaded(lambda lo, hi: tc[lo:hi].cpu().numpy(), n, qh, k, slice_rows=32768, threads=min(_o.host_threads(), 96))
+        part = _o.scan_threaded(lambda lo, hi: tc[lo:hi].cpu().numpy(), n, qh, k, metric=a.dist_metric, slice_rows=32768, threads=min(_o.host_threads(), 96))
         t_or = time.perf_counter() - t_or
         rr = o[1].cpu().numpy(); ss = o[0].cpu().numpy(); cc = o[2].cpu().numpy()
         exact = True
         for j, qi in enumerate(qsel):
             rows, sims = part[j][0], part[j][1]
-            exact &= bool(cc[qi] == len(rows) and np.array_equal(rr[qi, :len(rows)], rows)
-                          and np.array_equal(ss[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+            ok_q = bool(cc[qi] == len(rows) and np.array_equal(rr[qi, :len(rows)], rows)
+                        and np.array_equal(ss[qi, :len(rows)].view(np.uint32), sims.view(np.uint32)))
+            if not ok_q and "first_mismatch" not in leg:       # what differs, for whoever has to look
+                m = min(int(cc[qi]), len(rows))
+                bad = [i for i in range(m) if rr[qi, i] != rows[i] or ss[qi, i] != sims[i]][:3]
+                leg["first_mismatch"] = {"query": qi, "count_device": int(cc[qi]), "count_oracle": len(rows),
+                                         "at": [{"rank": i, "row_device": int(rr[qi, i]), "row_oracle": int(rows[i]), "sim_device": float(ss[qi, i]),
+                                                 "sim_oracle": float(sims[i])} for i in bad]}
+            exact &= ok_q
         leg["bit_exact_vs_oracle"] = exact; leg["oracle_queries"] = n_oq; leg["oracle_seconds"] = t_or
     for c in accs:
         c.set_gate(None)

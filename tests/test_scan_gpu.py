@@ -2070,3 +2070,32 @@ def test_context_learns_how_deep_the_int8_proofs_of_a_corpus_go(oracle):
         assert np.array_equal(small.rows, later.rows[:40]) and small.diag["widened_queries"] == 0, small.diag
     finally:
         a2.close()
+
+
+def test_clustered_corpus_under_l2_takes_the_int8_second_pass(oracle):
+    """Stage 2a under L2 (round 6): the filter's score is g = q.x - |x|^2 / 2, the second pass's threshold the g of the k-th
+    smallest exact distance found — (|q|^2 - d_k^2) / 2, lowered by the proof's own margins (wider under fp32 accumulation).
+    Queries near the centre of a cluster of ~1300 near-equidistant rows: the first pass's lists cannot prove a top-100, the
+    second one does — no escalation to the bf16 tiers to speak of; rows, order, distances and similarities are the oracle's,
+    under fp64 accumulation and under eight fp32 lanes.  Contexts of their own (what they learn about the corpus stays there)."""
+    import torch
+    from yams_amd.accel import Accel
+    corpus, q = _clustered(300_000, 256, 230, 71, 200)
+    corpus = (corpus * np.float32(1.7)).astype(np.float32); q = (q * np.float32(0.6)).astype(np.float32)
+    a2 = Accel(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        first = check(a2, oracle, corpus, q, 100, metric=SCAN_L2, max_queries=10, expect_path=0, shadow="both", expect_tier=_lib.TIER_I8)
+        assert first.diag["retried_queries"] >= 10 and first.diag["escalated_queries"] <= first.diag["retried_queries"] // 3, first.diag
+        assert first.diag["exact_fallback_queries"] == 0, first.diag
+    finally:
+        a2.close()
+    a3 = Accel(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        r = run(a3, corpus, q, 100, metric=SCAN_L2, flags=_lib.FLAG_L2_ACC_F32X8, shadow="both")
+        assert r.diag["filter_tier"] == _lib.TIER_I8 and r.diag["retried_queries"] >= 10 and r.diag["exact_fallback_queries"] == 0, r.diag
+        for qi in range(0, 200, 23):
+            rows, dist, sims = oracle.scan_l2_f32acc(corpus, q[qi], 100, -1.0, lanes=8)
+            assert np.array_equal(r.rows[qi], rows), qi
+            assert np.array_equal(r.dist[qi].view(np.uint32), dist.view(np.uint32)) and np.array_equal(r.scores[qi].view(np.uint32), sims.view(np.uint32)), qi
+    finally:
+        a3.close()

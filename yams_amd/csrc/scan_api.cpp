@@ -265,6 +265,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     const uint32_t nq = n_queries, dim = corpus->dim, k = params->k;
     const int metric = static_cast<int>(params->metric);
     hipStream_t st = ctx->stream;
+    if (metric == YAMS_SCAN_L2 && !out_dist && corpus->rows_i8 && k) {
+        // (the int8 tier's second pass takes its threshold from the k-th exact DISTANCE found: kept even when the caller does not ask)
+        YA_TRY(ws_get(ctx, "l2_dist_own", static_cast<size_t>(nq) * k * 4, (void**)&out_dist));
+    }
     ScanIo io{corpus, queries, nq, *params, out_scores, out_rows, out_counts, out_dist, out_ranks};
 
     // ---- prep --------------------------------------------------------------------------------
@@ -428,7 +432,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // corpus what its batches needed and plans the next ones for it (probed without the hint every 256th batch).
         yams_accel_ctx::TierHint* dhint = nullptr;
         int depth = 0;
-        if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry) {
+        if (i8 && !split_only && !retry) {       // (both metrics: the L2 batches of the int8 tier plan the same lists)
             dhint = hint ? hint : &ctx->tier_hints[corpus->rows_i8];
             if (dhint->n_rows != corpus->n_rows) { *dhint = yams_accel_ctx::TierHint{}; dhint->n_rows = corpus->n_rows; }
             if (dhint->depth && (++dhint->served_deep & 255u) != 0) depth = dhint->depth;
@@ -449,12 +453,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // sweep is fenced behind it.  The resident-query sample form is a grid of one 160 KiB workgroup per CU: a collective
         // kernel would have to wait for it.  The half-tile form (two small workgroups per CU) leaves it room.
         L.i8_sample_small_grid = static_cast<bool>(ctx->before_sweep) || ctx->sweep_hold;
-        if (i8 && nq <= 128 && corpus->rows_bf16 && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16
+        if (i8 && nq <= 128 && corpus->rows_bf16 && !retry && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16 (a second pass stays: its threshold is the int8 tier's)
         if (!i8 && depth) { depth = 0; dhint = nullptr; plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2); L.plan = plan; } // (the hint is the int8 tier's)
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         if (i8 && metric == YAMS_SCAN_L2) {
             L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);
-            plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, false); // (tile geometry unchanged: the form decision above stands)
+            plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, false, depth); // (tile geometry unchanged: the form decision above stands)
             if (retry) plan.kprime = kRescoreMax;
             L.plan = plan;
         }
@@ -502,7 +506,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, bf16_slab_k(passes, dim), d_qhi, d_qlo));
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
-        if (retry && (!i8 || metric != YAMS_SCAN_COSINE)) {    // (the forced threshold is a value of the int8 tier's upper bound)
+        if (retry && !i8) {    // (the forced threshold is a value of the int8 tier's score: the bound of the similarity, or of g under L2)
             for (uint32_t i = 0; i < nq; ++i) retry->unproven->push_back(i);
             return YAMS_OK;
         }
@@ -656,7 +660,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             failed.swap(still);
             stage_mark("widen done, left", failed.size());
         }
-        if (!failed.empty() && i8 && !L.i8_l2 && !split_only && k <= 1024) {
+        if (!failed.empty() && i8 && (!L.i8_l2 || out_dist) && !split_only && k <= 1024) {
             // stage 2a (round 6): the int8 tier once more, with the threshold the proof asks for.  For every unproven query
             // stage 1 / 2 left the k best EXACT scores it found: no row whose upper bound lies below the k-th of them can be in
             // the answer, so tau' = that score (one ulp down: the proof is a strict comparison) lists exactly what matters.
@@ -668,6 +672,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_TRY(ws_get(ctx, "retry_est", nf * 4, (void**)&d_rest));
             YA_TRY(ws_get(ctx, "retry_fmap", nf * 4, (void**)&d_fmap));
             YA_HIP(ctx, hipMemcpyAsync(d_fmap, failed.data(), nf * 4, hipMemcpyHostToDevice, st));
+            if (L.i8_l2) {
+                const bool f32acc = (params->flags & YAMS_SCAN_FLAG_L2_ACC_MASK) != 0;
+                const double margin = 1e-6 + (f32acc ? 2.0 * (static_cast<double>(dim) + 8.0) * 5.9604644775390625e-8 * 1.01 : 0.0);
+                YA_HIP(ctx, launch_retry_tau_l2(st, out_dist, out_counts, k, d_fmap, static_cast<uint32_t>(nf), d_qnorm, margin, L.gmax, plan.n_groups, d_rtau, d_rest));
+            } else
             YA_HIP(ctx, launch_retry_tau(st, out_scores, out_counts, k, d_fmap, static_cast<uint32_t>(nf), L.gmax, plan.n_groups, d_rtau, d_rest));
             std::vector<uint32_t> est(nf);
             YA_HIP(ctx, hipMemcpyAsync(est.data(), d_rest, nf * 4, hipMemcpyDeviceToHost, st));
@@ -788,8 +797,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         }
         if (hint && i8) hint->bf16_first = static_cast<uint64_t>(escalated) * 2 > nq;    // (an int8 batch — first or probe — decides for the next 255)
         if (dhint && i8) {
-            if (depth == 0) dhint->depth = static_cast<uint64_t>(retried) * 8 > nq ? 2 : (static_cast<uint64_t>(widened) * 4 > nq ? 1 : 0); // (a plain batch decides)
-            else if (depth == 1 && static_cast<uint64_t>(retried) * 8 > nq) dhint->depth = 2;
+            // (lists cut short show as second passes under cosine and as escalations under L2, which has no second pass)
+            const uint64_t cut_short = static_cast<uint64_t>(retried) + escalated;
+            if (depth == 0) dhint->depth = cut_short * 8 > nq ? 2 : (static_cast<uint64_t>(widened) * 4 > nq ? 1 : 0); // (a plain batch decides)
+            else if (depth == 1 && cut_short * 8 > nq) dhint->depth = 2;
         }
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     // own margin) no later candidate can enter the result and the proof will hold with what has been re-scored: the walk
     // stops there (Gaussian rows, 12.5M x 768: a top-100 needs ~850 of the ~1900 listed candidates).
     __shared__ uint32_t s_beat, s_ncand;
-    const bool may_close = METRIC == YAMS_SCAN_COSINE && n_rounds > 1 && !a.all_rows_listed && !(a.flags & kRescoreFlagPqRerank);
+    const bool may_close = n_rounds > 1 && !a.all_rows_listed && !(a.flags & kRescoreFlagPqRerank);
     if (threadIdx.x == 0) { s_beat = 0; s_ncand = a.n_cand; }
     for (uint32_t round = 0; round < n_rounds; ++round) {
         if (may_close && round > 0) {
@@ -827,9 +827,17 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             bool stop = nextk == 0;                                  // (the list ends here: nothing left to walk)
             if (!stop) {
                 const double ob = static_cast<double>(key_score(nextk));
-                const float reach = static_cast<float>(ob + a.err_bound + 1e-12);
                 uint32_t mine = 0;
-                for (uint32_t c = threadIdx.x; c < n_done; c += blockDim.x) mine += skey[c] != 0 && reach < key_score(skey[c]);
+                if (METRIC == YAMS_SCAN_COSINE) {
+                    const float reach = static_cast<float>(ob + a.err_bound + 1e-12);
+                    for (uint32_t c = threadIdx.x; c < n_done; c += blockDim.x) mine += skey[c] != 0 && reach < key_score(skey[c]);
+                } else {    // (the verification's own bound: the distance no outside row can undercut)
+                    double d2 = qn * qn - 2.0 * ob;
+                    if (ACC != 0) d2 = d2 * (1.0 - a.l2_acc_slack) - 1e-30;
+                    if (d2 < 0.0) d2 = 0.0;
+                    const float dmin = static_cast<float>(sqrt(d2) * (ACC != 0 ? 1.0 - 1.2e-7 : 1.0 - 1e-12));
+                    for (uint32_t c = threadIdx.x; c < n_done; c += blockDim.x) mine += skey[c] != 0 && dmin > -key_score(skey[c]);
+                }
                 if (mine) atomicAdd(&s_beat, mine);
                 __syncthreads();
                 stop = ob == ob && s_beat >= a.k;
@@ -1580,7 +1588,7 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     uint32_t threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
     // longer lists (the widened / deep stage): rounds of 256 candidates — the walk can close after any of them, and two
     // workgroups fit a CU's LDS where one of 512 threads did
-    if (R.n_cand > 512 && metric == YAMS_SCAN_COSINE && !(R.flags & kRescoreFlagPqRerank)) threads = 256;
+    if (R.n_cand > 512 && !(R.flags & kRescoreFlagPqRerank)) threads = 256;
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
                       ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
                       (threads / 64) * 64 * RS_STAGE_STRIDE * sizeof(float);
@@ -1663,6 +1671,43 @@ __global__ __launch_bounds__(256) void retry_tau_kernel(const float* scores, con
     if (mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) { tau_out[slot] = t; est_out[slot] = s_cnt; }
+}
+// The same under L2 (the filter's score is g = q.x - |x|^2 / 2 = (|q|^2 - d^2) / 2): a row that can still enter the k nearest has
+// d <= d_k, the k-th smallest exact distance found, i.e. g >= (|q|^2 - d_k^2) / 2.  `margin` keeps the proof's strict comparison
+// (and, under fp32 accumulation, its summation slack) on the safe side; two ulps down for the cast.
+__global__ __launch_bounds__(256) void retry_tau_l2_kernel(const float* dist, const uint32_t* counts, uint32_t k, const uint32_t* fmap,
+                                                           const double* qnorm, double margin, const uint32_t* gmax, uint32_t n_groups,
+                                                           float* tau_out, uint32_t* est_out) {
+    __shared__ uint32_t s_cnt;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t q = fmap[slot];
+    const float dk = counts[q] < k ? __builtin_inff() : dist[static_cast<uint64_t>(q) * k + (k - 1)];
+    const double qn = qnorm[q];
+    const double g = 0.5 * (qn * qn - static_cast<double>(dk) * static_cast<double>(dk) * (1.0 + margin));
+    if (!(dk < __builtin_inff()) || !(g == g) || !(g > -3.0e38 && g < 3.0e38)) {
+        if (threadIdx.x == 0) { tau_out[slot] = __builtin_inff(); est_out[slot] = 0xffffffffu; }
+        return;
+    }
+    float t = static_cast<float>(g);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        t = __uint_as_float(t > 0.f ? __float_as_uint(t) - 1u : (t < 0.f ? __float_as_uint(t) + 1u : 0x80000001u)); // the next float below
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t key = f2ord(t);
+    const uint32_t* gm = gmax + static_cast<uint64_t>(q) * n_groups;
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < n_groups; i += 256) mine += (gm[i] != 0xffffffffu && gm[i] >= key) ? 1u : 0u;
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { tau_out[slot] = t; est_out[slot] = s_cnt; }
+}
+hipError_t launch_retry_tau_l2(hipStream_t st, const float* dist, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
+                               const double* qnorm, double margin, const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(retry_tau_l2_kernel, dim3(n_slots), dim3(256), 0, st, dist, counts, k, fmap, qnorm, margin, gmax, n_groups, tau_out, est_out);
+    LAUNCH_CHECK();
+    return hipSuccess;
 }
 hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
                             const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {

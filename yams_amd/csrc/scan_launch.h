@@ -173,6 +173,8 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R);
 hipError_t launch_merge(hipStream_t st, const MergeLaunch& M);
 hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_rows, uint32_t dim,
                                uint16_t* out_bf16, float* out_nsq);
+hipError_t launch_retry_tau_l2(hipStream_t st, const float* dist, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
+                               const double* qnorm, double margin, const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out);
 hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
                             const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out);
 hipError_t launch_scatter_results_from(hipStream_t st, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t k, const float* s_scores,
