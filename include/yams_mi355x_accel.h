@@ -75,9 +75,13 @@ typedef struct yams_accel_ctx yams_accel_ctx;
 /* Number of visible HIP devices (0 when there is no GPU or no driver). */
 YAMS_ACCEL_API int yams_accel_device_count(void);
 /* Create a context bound to `device`.  `hip_stream` may be NULL (the context creates its own
- * non-blocking stream) or an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
- * on which all work of this context is enqueued.  A context is single-threaded; create one per
- * host thread (mirrors "one SHA256Hasher per thread", src/crypto/sha256_hasher.cpp:34). */
+ * non-blocking stream) or an existing hipStream_t on which all work of this context is enqueued.
+ * NOTE: the handle of HIP's legacy default stream IS the null pointer — a caller that passes it
+ * (torch.cuda.current_stream().cuda_stream is 0 unless a torch.cuda.Stream is current) gets the
+ * context's own stream, and work it queued on the default stream (tensors still being filled) is
+ * NOT ordered with the context's: synchronise first, or pass a created stream.  A context is
+ * single-threaded; create one per host thread (mirrors "one SHA256Hasher per thread",
+ * src/crypto/sha256_hasher.cpp:34). */
 YAMS_ACCEL_API yams_status_t yams_accel_ctx_create(int device, void* hip_stream,
                                                    yams_accel_ctx** out_ctx);
 YAMS_ACCEL_API void yams_accel_ctx_destroy(yams_accel_ctx* ctx);

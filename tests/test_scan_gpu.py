@@ -1690,7 +1690,8 @@ def test_randomised_self_consistency_of_all_scan_paths():
     """tests/stress_scan.py: 150 random shapes (rows, dim, batch 1..200, k, metric, threshold,
     allow-mask, clustered tops, zero / huge rows); the default path (narrow or 256-query filter,
     widening, escalation, fallback) must equal the exhaustive fp64 path and the wide form bit for
-    bit.  (1680 further cases were run by hand with seeds 1-5: no mismatch.)"""
+    bit.  Round 6: rows of four component distributions, either int8 shadow layout, every int8 call twice (learnt hints).
+    (1680 further cases were run by hand with seeds 1-5 in round 4, 900 in round 6: no mismatch.)"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_scan.py"), "--cases", "150", "--seed", "7"],
@@ -1700,6 +1701,30 @@ def test_randomised_self_consistency_of_all_scan_paths():
     res = json.loads(line[-1])
     assert res["cases"] == 150 and res["mismatches"] == 0, res
     assert any("widened1" in p for p in res["paths"]) and any(p.startswith("path1") for p in res["paths"]), res
+
+
+def test_every_rescored_candidate_lies_inside_its_filter_bound():
+    """Bound honesty (round 6; the measurement build counts it in rescore_select_kernel): for EVERY candidate the tiers
+    re-score, the filter's score against the exact similarity — |score - cos| <= the tier's error bound on the f32 / bf16 /
+    split tiers, cos <= score on the int8 tier (its score is an upper bound), in either shadow layout.  The proofs stand on
+    exactly this; a final result can be right while a bound is not.  120 random cases of tests/stress_scan.py (uniform /
+    Gaussian / power-law / outlier-dimension rows, masks, clusters, learnt hints) on the measurement build: no candidate
+    outside its bound, no mismatch.  (Round 6 ran 900 cases, 1 800 calls, by hand: none.)"""
+    import json, os, re, subprocess, sys
+    from yams_amd import build as _build
+    if not os.path.exists(_build.MEASURE_LIB):
+        _build.build(measure=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YAMS_ACCEL_MEASURE_LIB="1", YAMS_ACCEL_DUMP_NEEDED="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_scan.py"), "--cases", "120", "--seed", "21"],
+                       capture_output=True, text=True, timeout=280, env=env)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res["cases"] == 120 and res["mismatches"] == 0, res
+    counts = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"bound honesty: (\d+) of (\d+) re-scored candidates outside their filter bound \(tier (\d)\)", r.stderr)]
+    assert len(counts) >= 150 and {t for _, _, t in counts} >= {1, 2}, (len(counts), {t for _, _, t in counts})
+    assert all(v == 0 for v, _, _ in counts), [c for c in counts if c[0]][:5]
 
 
 def test_soak_of_the_bench_configuration_is_deterministic():

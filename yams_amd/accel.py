@@ -265,6 +265,9 @@ class SweepGate:
 
 class Accel:
     def __init__(self, device: int = 0, stream: int | None = None):
+        """stream: a hipStream_t handle, or None / 0 for a non-blocking stream of the context's own.  torch's DEFAULT stream has
+        the handle 0: a context created with torch.cuda.current_stream().cuda_stream while no torch.cuda.Stream is current runs
+        on its own stream, unordered with torch's work — torch.cuda.synchronize() before handing it tensors torch has just written."""
         self.L = _lib.load()
         if self.L.yams_accel_device_count() <= 0:
             raise AccelError(_lib.YAMS_ERR_UNSUPPORTED,

@@ -62,6 +62,7 @@ constexpr int kSelectCap = 4096;  // elements one select workgroup sorts
 // RescoreLaunch::flags, internal (never a caller's bit): the re-score of the product-quantised engine — the similarity is
 // VectorDatabase::computeCosineSimilarity's (0 on a zero norm, no small-norm skip: sqlite_vec_backend.cpp:4023-4034)
 constexpr uint32_t kRescoreFlagPqRerank = 1u << 30;
+constexpr uint32_t kRescoreFlagNoEarlyClose = 1u << 29;   // (measurement build: the re-score walk never closes early)
 
 struct ScanPlan {
     uint64_t n_rows = 0;

@@ -345,6 +345,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         }
     }
 
+#ifdef YAMS_ACCEL_MEASURE
+    if (std::getenv("YAMS_ACCEL_HONESTY_PRINT")) { const unsigned long long magic = 0x5eed; YA_HIP(ctx, hipMemcpyAsync(d_stat + 6, &magic, 8, hipMemcpyHostToDevice, st)); YA_HIP(ctx, hipStreamSynchronize(st)); }
+#endif
     uint64_t filter_candidates = 0, rescored_nested = 0;
     uint32_t widened = 0, exact_fb = 0, escalated = 0, filter_tier = 0, retried = 0;
 #ifdef YAMS_ACCEL_MEASURE
@@ -559,6 +562,18 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
           if (i8) YA_HIP(ctx, launch_scan_i8(st, L, 0, bf16_version));
           else if (bf16) YA_HIP(ctx, launch_scan_bf16(st, L, metric, 0, passes, bf16_version)); else YA_HIP(ctx, launch_scan_sample(st, L, metric));
           tr.end(); }
+#ifdef YAMS_ACCEL_MEASURE
+        if (L.dense && ctx->ws_ns.empty()) if (const char* dump = std::getenv("YAMS_ACCEL_DUMP_DENSE")) {     // the sample pass's scores, [sample_row / 4][query][4]
+            const size_t nf = static_cast<size_t>(nq) * plan.sample_rows;
+            std::vector<float> h(nf);
+            YA_HIP(ctx, hipMemcpyAsync(h.data(), L.dense, nf * 4, hipMemcpyDeviceToHost, st));
+            YA_HIP(ctx, hipStreamSynchronize(st));
+            if (FILE* f = std::fopen(dump, "wb")) {
+                const uint64_t hdr[4] = {nq, plan.sample_rows, plan.tile_rows, plan.sample_stride};
+                std::fwrite(hdr, 8, 4, f); std::fwrite(h.data(), 4, nf, f); std::fclose(f);
+            }
+        }
+#endif
         if (retry) YA_HIP(ctx, hipMemcpyAsync(d_tau, retry->forced_tau, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToDevice, st));
         else YA_HIP(ctx, launch_select_tau(st, L, d_work32));
         }
@@ -613,7 +628,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             R.n_stripes = corpus->n_stripes; R.stripe_index = corpus->stripe_index; R.cand = res; R.cand_stride = res_stride;
             R.n_cand = n_cand; R.tau = d_tau; R.list_count = d_lcount; R.list_cap = plan.list_cap;
             R.all_rows_listed = 0; R.qmap = d_qmap; R.n_slots = n_slots; R.k = k;
-            R.threshold = params->similarity_threshold; R.flags = params->flags & ~kRescoreFlagPqRerank;
+            R.threshold = params->similarity_threshold; R.flags = params->flags & ~(kRescoreFlagPqRerank | kRescoreFlagNoEarlyClose);
             R.err_bound = err_bound; R.out_scores = out_scores; R.out_rows = out_rows;
             R.out_counts = out_counts; R.out_dist = out_dist; R.out_ranks = out_ranks;
             R.out_status = d_status; R.stat_rescored = d_stat; R.q_over = d_qover;
@@ -823,9 +838,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         unsigned long long h_stat = 0;
 #ifdef YAMS_ACCEL_MEASURE
         if (std::getenv("YAMS_ACCEL_DUMP_NEEDED")) { // candidates the proof needed per query (rescore_select_kernel)
-            unsigned long long h4[4] = {0, 0, 0, 0};
-            YA_HIP(ctx, hipMemcpyAsync(h4, d_stat, 32, hipMemcpyDeviceToHost, st));
+            unsigned long long h4[6] = {0, 0, 0, 0, 0, 0};
+            YA_HIP(ctx, hipMemcpyAsync(h4, d_stat, 48, hipMemcpyDeviceToHost, st));
             YA_HIP(ctx, hipStreamSynchronize(st));
+            if (h4[5]) std::fprintf(stderr, "bound honesty: %llu of %llu re-scored candidates outside their filter bound (tier %u)\n", h4[4], h4[5], filter_tier);
             if (h4[3]) std::fprintf(stderr, "candidates needed per query: mean %.1f, max %llu over %llu queries (k = %u)\n",
                                     static_cast<double>(h4[1]) / static_cast<double>(h4[3]), h4[2], h4[3], k);
         }

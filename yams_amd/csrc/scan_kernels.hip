@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
     // own margin) no later candidate can enter the result and the proof will hold with what has been re-scored: the walk
     // stops there (Gaussian rows, 12.5M x 768: a top-100 needs ~850 of the ~1900 listed candidates).
     __shared__ uint32_t s_beat, s_ncand;
-    const bool may_close = n_rounds > 1 && !a.all_rows_listed && !(a.flags & kRescoreFlagPqRerank);
+    const bool may_close = n_rounds > 1 && !a.all_rows_listed && !(a.flags & (kRescoreFlagPqRerank | kRescoreFlagNoEarlyClose));
     if (threadIdx.x == 0) { s_beat = 0; s_ncand = a.n_cand; }
     for (uint32_t round = 0; round < n_rounds; ++round) {
         if (may_close && round > 0) {
@@ -970,6 +970,18 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             const double sd = denom > 0.0 ? dot / denom : 0.0;
             if (!isfinite(sd)) continue;                            // :4273-4275
             const float sim = static_cast<float>(sd);               // :4276
+#ifdef YAMS_ACCEL_MEASURE
+            // bound honesty (YAMS_ACCEL_DUMP_NEEDED prints the counts): the filter's score of a re-scored candidate against its exact
+            // similarity — |score - cos| <= err_bound on the bf16 / f32 tiers, cos <= score on the int8 tier (err_bound 0)
+            if (a.stat_rescored && !a.all_rows_listed && !a.rank_row) {
+                const double fs = static_cast<double>(key_score(ck));
+                if (a.err_bound > 0.0 ? fabs(sd - fs) > a.err_bound + 1e-7 : sd > fs + 1e-7) {
+                    const unsigned long long nth = atomicAdd(a.stat_rescored + 4, 1ull);
+                    if (nth < 6 && a.stat_rescored[6] == 0x5eed) printf("  honesty: query %u cand %u row %u exact %.7f filter %.7f bound %.5f nsq %.6g\n", q, c, row, sd, fs, a.err_bound, nsq);
+                }
+                atomicAdd(a.stat_rescored + 5, 1ull);
+            }
+#endif
             if (sim < a.threshold) continue;                        // :4277-4279
             skey[c] = pack_key(sim, rank);
             sidx[c] = c;
@@ -1589,6 +1601,13 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     // longer lists (the widened / deep stage): rounds of 256 candidates — the walk can close after any of them, and two
     // workgroups fit a CU's LDS where one of 512 threads did
     if (R.n_cand > 512 && !(R.flags & kRescoreFlagPqRerank)) threads = 256;
+#ifdef YAMS_ACCEL_MEASURE
+    if (const char* e = std::getenv("YAMS_ACCEL_RESCORE_FORM")) {   // 1: no early close, 2: 512-thread rounds, 3: both
+        const int v = std::atoi(e);
+        if (v & 1) a.flags |= kRescoreFlagNoEarlyClose;
+        if (v & 2) threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
+    }
+#endif
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
                       ((static_cast<size_t>(R.dim) + 3) & ~static_cast<size_t>(3)) * sizeof(float) +
                       (threads / 64) * 64 * RS_STAGE_STRIDE * sizeof(float);
