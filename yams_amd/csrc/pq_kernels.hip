@@ -132,14 +132,22 @@ __global__ __launch_bounds__(1024) void pq_adc_filter_kernel(const uint8_t* code
         const uint64_t idx = candidates ? candidates[item] : item;
         const bool live = idx < n_codes;
         const uint8_t* code = codes + (live ? idx : 0) * m;
-        float part[QG][LANES];
+        // partial sums as PAIRS of queries (QG = 4: two packed fp32 adds per table entry instead of four scalar ones — the same
+        // IEEE additions, v_pk_add_f32)
+        typedef float pq_f2 __attribute__((ext_vector_type(2)));
+        constexpr int NP = (QG + 1) / 2;
+        pq_f2 part2[NP][LANES];
 #pragma unroll
-        for (int s = 0; s < QG; ++s)
+        for (int s = 0; s < NP; ++s)
 #pragma unroll
-            for (int l = 0; l < LANES; ++l) part[s][l] = 0.f;
+            for (int l = 0; l < LANES; ++l) part2[s][l] = pq_f2{0.f, 0.f};
+        const bool quads = words && (m & 15u) == 0 && ((reinterpret_cast<uintptr_t>(codes) & 15u) == 0);
         for (uint32_t j0 = 0; j0 < m; j0 += 16) {
             uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (words) {
+            if (quads) {
+                const uint4 q4 = *reinterpret_cast<const uint4*>(code + j0);
+                w[0] = q4.x; w[1] = q4.y; w[2] = q4.z; w[3] = q4.w;
+            } else if (words) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
                     if (j0 + 4u * tt < m) w[tt] = *reinterpret_cast<const uint32_t*>(code + j0 + 4u * tt);
@@ -153,17 +161,23 @@ __global__ __launch_bounds__(1024) void pq_adc_filter_kernel(const uint8_t* code
                 if (j0 + jj >= m) break;
                 const uint32_t c = (w[jj >> 2] >> (8 * (jj & 3))) & 255u;
                 const float* e = lut + static_cast<size_t>((j0 + jj) * 256u + c) * QG;
-                float v[QG];
-                if constexpr (QG == 4) { const float4 x = *reinterpret_cast<const float4*>(e); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
-                else if constexpr (QG == 2) { const float2 x = *reinterpret_cast<const float2*>(e); v[0] = x.x; v[1] = x.y; }
-                else v[0] = e[0];
-#pragma unroll
-                for (int s = 0; s < QG; ++s) {
-                    float& pp = part[s][jj % LANES];
-                    pp = __fadd_rn(pp, v[s]);
+                if constexpr (QG == 4) {
+                    typedef float pq_f4 __attribute__((ext_vector_type(4)));
+                    const pq_f4 x = *reinterpret_cast<const pq_f4*>(e);
+                    part2[0][jj % LANES] += pq_f2{x.x, x.y};
+                    part2[1][jj % LANES] += pq_f2{x.z, x.w};
+                } else if constexpr (QG == 2) {
+                    part2[0][jj % LANES] += *reinterpret_cast<const pq_f2*>(e);
+                } else {
+                    part2[0][jj % LANES].x = __fadd_rn(part2[0][jj % LANES].x, e[0]);
                 }
             }
         }
+        float part[QG][LANES];
+#pragma unroll
+        for (int s = 0; s < QG; ++s)
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) part[s][l] = (s & 1) ? part2[s >> 1][l].y : part2[s >> 1][l].x;
         uint32_t kidx = 0;
         if (MODE == 2) kidx = tie_rank ? tie_rank[live ? idx : 0] : static_cast<uint32_t>(idx);
 #pragma unroll
