@@ -126,3 +126,21 @@ if os.path.exists(f):
                "algorithmic_bytes_per_launch": 378101888, "correction": "2x (gfx950 FETCH_SIZE halves wide coalesced reads)", "launches": len(v), "round": tag}
         json.dump(out, open(os.path.join(P, f"{tag}_config2_pmc.json"), "w"), indent=1)
         print(out)
+
+
+# the product-quantised engine's leg and the non-uniform legs: kernel stats; LDS counters of the ADC scan
+copy(os.path.join(G, "prof_pq", "pq_kernel_stats.csv"), os.path.join(P, f"{tag}_pq_kernel_stats.csv"))
+copy(os.path.join(G, "prof_dist", "dist_kernel_stats.csv"), os.path.join(P, f"{tag}_non_uniform_kernel_stats.csv"))
+f = os.path.join(G, "prof_pq_pmc", "pq_counter_collection.csv")
+if os.path.exists(f):
+    acc_ = {}
+    for r in csv.DictReader(open(f)):
+        if "pq_adc_filter_kernel" in r["Kernel_Name"] and ", 2>" in r["Kernel_Name"]:
+            acc_.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if acc_:
+        out = {c: sum(v) / len(v) for c, v in acc_.items()}
+        out["launches"] = max(len(v) for v in acc_.values())
+        if out.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_bank_conflict_frac"] = out.get("SQ_LDS_BANK_CONFLICT", 0.0) / out["SQ_LDS_IDX_ACTIVE"]
+        json.dump({"kernel": "pq_adc_filter_kernel<.., 4, 2>", "round": tag, "counters": out}, open(os.path.join(P, f"{tag}_pq_pmc.json"), "w"), indent=1)
+        print(out)

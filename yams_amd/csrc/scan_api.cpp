@@ -413,6 +413,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // tier (anisotropic rows, 12.5M x 768, 1024 queries: 59.9 ms per step on the int8 tier — all 1024 queries escalate —
         // 17.3 ms on the bf16 tier, no query widened; profiles/r06_non_uniform.json).  Learnt per context from the batches it
         // has served, probed again every 256th batch; results are identical on every tier.
+        if (ctx->tier_hints.size() > 4096) ctx->tier_hints.clear();   // (keyed by shadow address: a long-lived context that has seen thousands of mirrors forgets)
         yams_accel_ctx::TierHint* hint = nullptr;
         if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry && corpus->rows_bf16 && corpus->rows_nsq && nq > 128 &&
             !(params->flags & (YAMS_SCAN_FLAG_RESIDENT_QUERIES | YAMS_SCAN_FLAG_WIDE_TILE))) {
