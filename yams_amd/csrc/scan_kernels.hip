@@ -1598,14 +1598,19 @@ hipError_t launch_rescore(hipStream_t st, int metric, const RescoreLaunch& R) {
     if (rs > static_cast<size_t>(RS_MAX)) rs = RS_MAX;
     // one round of the candidate walk when the candidates fit a block (384 candidates: 6 waves)
     uint32_t threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
-    // longer lists (the widened / deep stage): rounds of 256 candidates — the walk can close after any of them, and two
-    // workgroups fit a CU's LDS where one of 512 threads did
-    if (R.n_cand > 512 && !(R.flags & kRescoreFlagPqRerank)) threads = 256;
+    // Rounds of 128 candidates wherever the walk may close early (every proof-carrying re-score): the plan's stage 1 (384
+    // candidates) mostly closes after two of its three rounds — the uniform bench rows need ~250 — and several workgroups fit a
+    // CU's LDS where one of 384 / 512 threads did (headline step 7.71 -> 7.62 ms, config 2 0.268 -> 0.244 on one box); the
+    // widened / deep stage closes after any round.
+    // (lists of more than 512: rounds of 256 measured 3 % better on the non-uniform legs than rounds of 128)
+    if (R.n_cand > 128 && !(R.flags & kRescoreFlagPqRerank)) threads = R.n_cand > 512 ? 256 : 128;
 #ifdef YAMS_ACCEL_MEASURE
     if (const char* e = std::getenv("YAMS_ACCEL_RESCORE_FORM")) {   // 1: no early close, 2: 512-thread rounds, 3: both
         const int v = std::atoi(e);
         if (v & 1) a.flags |= kRescoreFlagNoEarlyClose;
         if (v & 2) threads = (std::min<uint32_t>(std::max<uint32_t>(R.n_cand, 64u), 512u) + 63u) & ~63u;
+        if ((v & 4) && R.n_cand > 256 && !(R.flags & kRescoreFlagPqRerank)) threads = 256;   // 4 / 8: rounds of 256 / 192 candidates
+        if ((v & 8) && R.n_cand > 192 && !(R.flags & kRescoreFlagPqRerank)) threads = 192;
     }
 #endif
     const size_t sh = rs * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(float)) +
