@@ -1,8 +1,8 @@
 """Run as a subprocess by test_scan_gpu.py with YAMS_ACCEL_MEASURE_LIB=1: the measurement build's alternative forms of
 the resident-query int8 filter — 70: 128 x 128 wave tiles, one wave per SIMD, row fragments loaded straight into
-registers, block entries in the survivor log; 80: 64 x 128 wave tiles with direct row loads (the product's form at
-dims 384 / 768 with >= 512 queries); 81: the same with the short strip boundary (zero-start accumulators, thresholds and
-survivors in LDS) — against the LDS-ring form (2; the product's form elsewhere) on the same shard: identical results AND identical candidate sets (count),
+registers, block entries in the survivor log; 80: 64 x 128 wave tiles with direct row loads, the plain strip boundary; 87: the
+same with the short strip boundary as shipped (thresholds and survivors in LDS, the boundary's work in front of the drain); 90:
+two slabs of row fragments in flight per wave (the product's form at dims 384 / 768) — against the LDS-ring form (2; the product's form elsewhere) on the same shard: identical results AND identical candidate sets (count),
 on ragged shards (a last strip of 64 rows, a last unit of one tile), with thresholds and an allow-mask.  Prints one
 JSON line."""
 import json, os, sys
@@ -15,7 +15,7 @@ from yams_amd._lib import SCAN_COSINE, FLAG_RESIDENT_QUERIES
 acc = Accel(0, torch.cuda.current_stream().cuda_stream)
 out = []
 SHAPES = json.loads(os.environ["FORMS_SHAPES"]) if os.environ.get("FORMS_SHAPES") else None
-VERSIONS = os.environ.get("FORMS_VERSIONS", "2,70,80,81").split(",")   # the first one is the yardstick (the LDS-ring form)
+VERSIONS = os.environ.get("FORMS_VERSIONS", "2,70,80,87,90").split(",")   # the first one is the yardstick (the LDS-ring form)
 for (n, d, nq, k, thr, masked) in SHAPES or [(300_001, 768, 1024, 100, -1.0, False), (150_080, 384, 300, 50, 0.02, True),
                                    (90_000, 768, 130, 100, -1.0, True), (70_001, 384, 1024, 10, -1.0, False),
                                    (120_000, 512, 260, 20, -1.0, False)]:

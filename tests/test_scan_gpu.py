@@ -381,9 +381,9 @@ def test_measurement_build_filter_forms_agree_with_the_product_form():
     assert len(recs) == 5
     for r in recs:
         assert r["tier"] == _lib.TIER_I8, r
-        assert r["identical_70"] and r["identical_80"] and r["identical_81"], r
-        assert r["candidates"]["70"] == r["candidates"]["2"] == r["candidates"]["80"] == r["candidates"]["81"], r
-        assert r["fallback"] == {"2": 0, "70": 0, "80": 0, "81": 0}, r
+        assert r["identical_70"] and r["identical_80"] and r["identical_87"] and r["identical_90"], r
+        assert r["candidates"]["70"] == r["candidates"]["2"] == r["candidates"]["80"] == r["candidates"]["87"] == r["candidates"]["90"], r
+        assert r["fallback"] == {"2": 0, "70": 0, "80": 0, "87": 0, "90": 0}, r
 
 
 def test_massive_ties_take_the_exhaustive_fp64_path(acc, oracle):

@@ -545,9 +545,10 @@ constexpr int R_ZS_THR = R_MAX_SLABS * R_B_SLAB;        // {A_lo, B_hi} of the t
 constexpr int R_ZS_LOG = R_ZS_THR + 1024;               // per wave: keys u64[R_ZS_ENTRIES] then queries u32[R_ZS_ENTRIES]
 constexpr int R_ZS_ENTRIES = 640;                       // 7.5 KiB per wave, 60 KiB of the ring's 64
 static_assert(R_ZS_LOG + 8 * R_ZS_ENTRIES * 12 <= R_LDS, "the survivor buffers must fit the LDS the ring has left");
-// ZSM: which of these a launch uses (measured one by one) — 1 zero-start accumulators + thresholds from LDS, 4 survivors
-// to the LDS buffer, 8 the siblings' counters are looked at every eighth strip only, 16 no drain at the strip's end (the
-// strip counters are requested in the last slab but one, every slab waits for its own fragments)
+// ZSM: which parts of the short strip boundary a launch uses — 2 the tile's threshold halves resident in LDS, 4 survivors to
+// the LDS buffer, 64 the boundary's memory-independent work in front of the drain.  (Two more forms were built and measured
+// slower in round 4 — accumulators born from the strip's first multiply-add with the thresholds applied at the end, and a
+// strip end without a drain: profiles/r04_filter_forms.json, docs/LAB_NOTES.md; their code left the kernel in round 6.)
 // SAMPLE (round 4; cosine, DIRECT, plain strip boundary): the SAMPLE pass in this form — the strips are those of the sample
 // tiles (every stride-th tile), the accumulators start at zero and the epilogue writes the group maxima the half-tile
 // kernel's MODE_SAMPLE writes (the same two fmaf per element, the same group numbering: gmax feeds tau_select and
@@ -557,9 +558,8 @@ template <int ABL = 0, bool L2 = false, bool DIRECT = false, int ZSM = 0, bool S
 __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a, uint32_t n_units, uint32_t n_qt, uint32_t n_streams, uint32_t window) {
     static_assert(ZSM == 0 || (DIRECT && !L2 && ABL == 0), "the short strip boundary exists for the direct cosine kernel");
     static_assert(!SAMPLE || (DIRECT && !L2 && ABL == 0 && ZSM == 0), "the sample pass exists in the plain direct cosine form");
-    static_assert(!(ZSM & 16) || ((ZSM & 1) && (ZSM & 4)), "no drain needs the thresholds and the survivors in LDS");
-    constexpr bool Z0 = (ZSM & 1) != 0, ZT = (ZSM & 2) != 0, ZL = (ZSM & 4) != 0, ZN = (ZSM & 16) != 0;
-    static_assert(!(ZT && Z0), "2 = the plain form with its threshold halves in LDS (1 has them there anyway)");
+    static_assert((ZSM & ~(2 | 4 | 64)) == 0, "ZSM bits: 2 thresholds in LDS, 4 survivors in LDS, 64 early boundary");
+    constexpr bool ZT = (ZSM & 2) != 0, ZL = (ZSM & 4) != 0;
     // Round 6 — the strip boundary again (it costs 8 % of the launch at dim 768 and 24 % at dim 384, and the partner wave of
     // the SIMD does not hide it).  64 (EARLY): what the boundary does NOT need the memory for — the survivor emission, the next
     // strip's thresholds and the accumulator set-up — runs BEFORE the drain of the vector-memory counter instead of behind it,
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // to -T and letting the first slab's multiply-adds of the other row blocks take them as their C operand (32 moves for
     // 128) — the second code path of the first slab cost four spills and 2 % of the launch.
     constexpr bool EARLY = (ZSM & 64) != 0;
-    static_assert(!EARLY || (ZT && ZL && !Z0 && !ZN), "the early boundary builds on the plain form with its threshold halves and its survivors in LDS");
+    static_assert(!EARLY || (ZT && ZL), "the early boundary builds on the plain form with its threshold halves and its survivors in LDS");
     // `window`: bits 0-15 the strips a pair may run ahead of its slowest sibling, bits 16-23 log2 of the pacing interval —
     // the siblings' counters are looked at when (strip number & mask) == 0 only: each look is a system-scope load whose
     // latency the strip boundary pays (every strip: 7.43 / 4.61 ms at dim 768 / 384; every eighth: 7.35 / 4.18)
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         for (int s = 0; s < nslab; ++s)
             lds_dma16_s(baseB + s * qslab_bytes, voffB, __builtin_amdgcn_readfirstlane(lds0 + s * R_B_SLAB + wid * 1024));
     }
-    if ((Z0 || ZT) && tid < R_QUERIES) // the tile's threshold halves, resident (q_thr is padded to q_pad queries)
+    if (ZT && tid < R_QUERIES) // the tile's threshold halves, resident (q_thr is padded to q_pad queries)
         reinterpret_cast<f2_t*>(lds + R_ZS_THR)[tid] = reinterpret_cast<const f2_t*>(a.q_thr)[q0 + static_cast<uint32_t>(tid)];
     // ---- work sharing ----------------------------------------------------------------------------------
     // The two waves of a SIMD do not run at the same speed: the arbiter favours the older one, which then
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) piece(cur.base, s, s, rb);
     }
-    if (!Z0 && !SAMPLE) qthr_request();
+    if (!SAMPLE) qthr_request();
     if (L2) { qbias_request(); rbias_request(cur.row0); }
     float sb, eb; // block scale and residue bound of the current strip (wave-uniform)
     {
@@ -741,8 +741,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
     // epilogue reads a query block's four floats back: holding them in registers for the launch cost seven spill slots)
     if (SAMPLE && tid < R_QUERIES)
         reinterpret_cast<float4*>(lds + R_ZS_THR)[tid] = reinterpret_cast<const float4*>(a.q_meta)[q0 + static_cast<uint32_t>(tid)]; // < q_pad: the table is padded
-    if (Z0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if (SAMPLE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SAMPLE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else qthr_wait();
     if (ZT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stash of the threshold halves)
     __builtin_amdgcn_s_barrier(); // the only one: the query tile is shared, everything after it is wave-private
@@ -760,9 +759,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rb = i >> 2, c = i & 3;
-            if (Z0 && first) // the accumulator is BORN here: C = the inline constant 0 (no register holds a zero, no earlier value is alive)
-                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc[rb][cb0 + c]) : "v"(A[rb]), "v"(B[c]));
-            else if (ABL != 2 && ABL != 4)
+            if (ABL != 2 && ABL != 4)
                 acc[rb][cb0 + c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rb], B[c], acc[rb][cb0 + c], 0, 0, 0);
             else if (i == 0)
                 asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]));
@@ -802,7 +799,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const unsigned char* bqn = lds + sn * R_B_SLAB;
         // (ZS: every slab waits — a strip's first fragments were requested in the previous strip's last slab and nothing
         // younger than them is in flight: no store, and the strip counters are requested a slab earlier)
-        if (DIRECT && ABL != 1 && (ZN || !early))
+        if (DIRECT && ABL != 1 && !early)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[P][0]), "+v"(fa[P][1]), "+v"(fa[P][2]), "+v"(fa[P][3]) :: "memory");
         pin4(fa[P]); pin4(fb[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -879,7 +876,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) nt[cb] = THR ? i8_neg_threshold(qthr[cb][0], is, qthr[cb][1], g) : 0;
     };
-    if (!Z0) thresholds();
+    thresholds();
     // Survivors go to ONE log region per wave and launch ((stream, query tile, wave): ~500 entries at the bench
     // shape), filled front to back: no per-strip region, count or memset, and the gather kernel gets 2048 dense
     // regions of one query tile each instead of 1.5 million mostly empty ones.
@@ -919,38 +916,17 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         const uint32_t u = unit_of(k_cur);
         const bool more = unit_of(k_nxt) < n_units;
         locate(k_nxt, nxt); // (past the end of the stream: the spare DMA slots read the shard's last row; nobody consumes them)
-        if (!ZN) take_request();    // the strip after the next two; older than every piece of this strip (ZS: in the last slab but one)
+        take_request();    // the strip after the next two; older than every piece of this strip
         unsigned long long meta_n;  // the next strip's block scale, on its way through the scalar cache
         {
             const float* mp = meta_ptr(nxt.row0);
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(meta_n) : "s"(mp) : "memory");
         }
-        if (!Z0 && !EARLY) acc_init();
+        if (!EARLY) acc_init();
         uint32_t sib = 0; // pacing: the siblings' strip counters
         // two slabs per trip (the buffer parity is a compile-time constant); the pieces issued during the last
         // three slabs already belong to the next strip: uniform selects, not a second copy of the loop body
         int s = 0;
-        if (Z0) {
-            // the strip's first two slabs stand apart: the first one gives birth to the accumulators (C = 0).  (Without ZN
-            // the first slab's fragments were covered by the drain at the previous strip's end, as in the plain form.)
-            body_impl(1, true, nullptr, 0, 0, C0{}, cur.base + 1024u, std::true_type{}, [](int) {});
-            body(2, false, nullptr, 0, 1, C1{}, cur.base + 2048u);
-            s = 2;
-            do { // (nslab >= 4, even)
-                const bool last_pair = s + 2 >= nslab;
-                // ZN: the strip counters — this pair's next strip, the siblings' progress — are requested in the last slab but
-                // one: the last slab's own wait covers them, and nothing is younger than the next strip's first fragments
-                body_impl(s + 1, false, nullptr, 0, s, C0{}, cur.base + static_cast<uint32_t>(s + 1) * 1024u, std::false_type{},
-                     [&](int i) __attribute__((always_inline)) {
-                         if (ZN && i == 12 && last_pair) {
-                             take_request();
-                             if (n_qt > 1 && (k_cur & pace_mask) == 0u) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
-                         }
-                     });
-                body(last_pair ? 0 : s + 2, false, nullptr, 0, s + 1, C1{}, last_pair ? nxt.base : cur.base + static_cast<uint32_t>(s + 2) * 1024u);
-                s += 2;
-            } while (s < nslab);
-        } else
         do { // (nslab >= 4: a loop the compiler knows to run at least once keeps one register assignment)
             int so = s;
             asm volatile("" : "+s"(so)); // (opaque: the compiler must not peel the first trip off the loop for `early`)
@@ -966,15 +942,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
         ++units_read;
 #endif
         const bool pace_now = (k_cur & pace_mask) == 0u;
-        if (!ZN && THR && n_qt > 1 && pace_now) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
-        if (!Z0 && THR) qthr_request();  // for the NEXT unit's thresholds; in flight under the sign test below
-        // ZS: this strip's thresholds come from the resident halves (LDS) and the strip's block scale, one query block at
-        // a time (nothing of them stays in registers: the survivor pass derives a block's threshold again)
-        const f2_t* const zs_thr = reinterpret_cast<const f2_t*>(lds + R_ZS_THR) + l15;
-        const float zs_is = 1.0f / sb, zs_g = eb * (1.0f / sb); // (the same expressions as thresholds() and i8_log_gather_kernel)
-        if (Z0) { // (two blocks' halves at a time: sixteen registers for all of them are not free here)
-            qthr[0] = zs_thr[0]; qthr[1] = zs_thr[16];
-        }
+        if (THR && n_qt > 1 && pace_now) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(sib) : "v"(sync_sib) : "memory");
+        if (THR) qthr_request();  // for the NEXT unit's thresholds; in flight under the sign test below
         if (THR && L2) { qbias_request(); rbias_request(nxt.row0); }
 
         // ---- epilogue of the unit: acc[rb][cb][r] is row = row0 + 16 rb + 4 lq + r, query = q0 + 16 cb + l15;
@@ -996,8 +965,6 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                     const bool hot_cb = (hot >> cb) & 1u;
                     if (__builtin_amdgcn_ballot_w64(hot_cb) == 0) continue;
                     const uint32_t qi = q0 + cb * 16 + l15;
-                    int zs_nt = 0; // ZS: -T of this strip and query block, derived again (the sign test kept none of them)
-                    if (Z0) { const f2_t qh = zs_thr[cb * 16]; zs_nt = i8_neg_threshold(qh[0], zs_is, qh[1], zs_g); }
                     // this lane's 16 elements of the block that survive (straight-line code) ...
                     uint32_t pm = 0;
     #pragma unroll
@@ -1007,7 +974,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                         if (a.row_mask) { const uint64_t rbase = strip + off0; mw = mask_word(a.row_mask, rbase & ~31ull, a.n_rows) >> (rbase & 31u); }
     #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            pm |= ((Z0 ? acc[rb][cb][r] + zs_nt : acc[rb][cb][r]) >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
+                            pm |= (acc[rb][cb][r] >= 0 && off0 + r < rows_left && ((mw >> r) & 1u)) ? 1u << (4 * rb + r) : 0u;
                     }
                     if (!hot_cb) pm = 0;
                     // ... then one trip per survivor of the busiest lane (one, typically): compact code — the fully
@@ -1022,7 +989,6 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                         int val = acc[0][cb][0];
     #pragma unroll
                         for (int i = 1; i < 16; ++i) val = e == i ? acc[i >> 2][cb][i & 3] : val;
-                        if (Z0) val += zs_nt; // (the log holds I - T, as the gather kernel expects)
                         const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
                         base += static_cast<uint32_t>(__builtin_popcountll(m));
                         if (p && ABL != 8) {
@@ -1054,12 +1020,7 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = acc[rb][cb][r] > m ? acc[rb][cb][r] : m;
-                int zs_t = 0;
-                if (Z0) {
-                    zs_t = i8_neg_threshold(qthr[cb & 1][0], zs_is, qthr[cb & 1][1], zs_g);
-                    if (cb + 2 < 8) qthr[cb & 1] = zs_thr[(cb + 2) * 16];
-                }
-                if (m + zs_t >= 0) hot |= 1u << cb;
+                if (m >= 0) hot |= 1u << cb;
             }
             hot &= q_live; // (queries past the end of the batch: ONE mask, not a per-block constant held in a register each)
             if (strip >= a.n_rows) hot = 0;
@@ -1075,9 +1036,8 @@ __global__ __launch_bounds__(R_THREADS, 1) void scan_tiles_i8r_kernel(ScanArgs a
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-            } else if (!Z0) { qthr_wait(); thresholds(); }
-            else if (!ZN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the drain of the plain form: strip counters, the next strip's first fragments
-            k_new = take_result(); // (landed with the drain above — ZS: with the last slab's wait —, like the siblings' counters)
+            } else { qthr_wait(); thresholds(); }
+            k_new = take_result(); // (landed with the drain above, like the siblings' counters)
             if (n_qt > 1 && more && pacing && pace_now) {
                 asm volatile("" : "+v"(sib));
                 uint32_t polls = 0;
@@ -2175,13 +2135,10 @@ hipError_t launch_scan_i8(hipStream_t st, const ScanLaunch& L, int mode, int ver
         hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, 70>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window);
         return hipGetLastError();
     }
-    if (rp.use && version >= 81 && version <= 85) { // ... with parts of the short strip boundary (ZSM bits, see the kernel)
+    if (rp.use && (version == 84 || version == 85)) { // ... with parts of the short strip boundary (ZSM bits, see the kernel)
 #define YAMS_ZS_LAUNCH(M) hipLaunchKernelGGL((scan_tiles_i8r_kernel<0, false, true, M>), dim3(rp.grid), dim3(R_THREADS), 0, st, a, rp.n_units, rp.n_qt, rp.n_streams, window)
-        if (version == 81) YAMS_ZS_LAUNCH(1 | 4 | 16);      // everything
-        else if (version == 82) YAMS_ZS_LAUNCH(1);          // zero-start + LDS thresholds, the plain form's drain and stores
-        else if (version == 84) YAMS_ZS_LAUNCH(2);          // the plain form with its threshold halves resident in LDS
-        else if (version == 85) YAMS_ZS_LAUNCH(2 | 4);      // ... and its survivors in the LDS buffer
-        else YAMS_ZS_LAUNCH(1 | 4);                         // ... + survivors in LDS
+        if (version == 84) YAMS_ZS_LAUNCH(2);               // the plain form with its threshold halves resident in LDS
+        else YAMS_ZS_LAUNCH(2 | 4);                         // ... and its survivors in the LDS buffer
 #undef YAMS_ZS_LAUNCH
         return hipGetLastError();
     }
