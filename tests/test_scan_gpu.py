@@ -1393,7 +1393,13 @@ def test_int8_tier_widens_escalates_and_falls_back(acc, oracle):
         corpus[r_] = (s_ * qu + np.sqrt(1.0 - s_ * s_) * v).astype(np.float32) * np.float32(rng.uniform(0.5, 2.0))
     corpus[pool[100:100 + 300]] = q[4]                       # 300 ties: more than k' = 214, fewer than the list: widened
     rank = np.random.default_rng(35).permutation(n).astype(np.uint32)
-    r = check(acc, oracle, corpus, q, 50, tie_rank=rank, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    import torch
+    from yams_amd.accel import Accel
+    fresh = Accel(0, torch.cuda.current_stream().cuda_stream)  # (what a context learnt about another corpus at this address would change the road taken)
+    try:
+        r = check(fresh, oracle, corpus, q, 50, tie_rank=rank, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    finally:
+        fresh.close()
     assert r.diag["escalated_queries"] >= 1 and r.diag["exact_fallback_queries"] >= 1 and r.diag["widened_queries"] >= 1, r.diag
 
 
@@ -1877,8 +1883,14 @@ def test_clustered_corpus_is_proven_by_the_int8_retry(acc, oracle):
     sampled threshold sits inside the cloud and every proof of stage 1 fails.  Stage 2a filters those queries again on the
     int8 tier with the threshold the proof asks for — the k-th best exact score found, one ulp down — and proves them without
     the split-bf16 sweep; rows, order and score bits equal the oracle's."""
+    import torch
+    from yams_amd.accel import Accel
     corpus, q = _clustered(300_000, 256, 230, 71, 200)         # ~1300 rows per cluster: more than the sampled threshold lists
-    r = check(acc, oracle, corpus, q, 100, max_queries=24, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    fresh = Accel(0, torch.cuda.current_stream().cuda_stream)  # (a context that has learnt nothing about any corpus at this address)
+    try:
+        r = check(fresh, oracle, corpus, q, 100, max_queries=24, expect_path=0, shadow="i8", expect_tier=_lib.TIER_I8)
+    finally:
+        fresh.close()
     assert r.diag["retried_queries"] >= 10, r.diag
     assert r.diag["escalated_queries"] <= r.diag["retried_queries"] // 3 and r.diag["exact_fallback_queries"] == 0, r.diag
     # the same through the resident-query form and with a threshold (a context that has just served this corpus at this address

@@ -418,7 +418,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry && corpus->rows_bf16 && corpus->rows_nsq && nq > 128 &&
             !(params->flags & (YAMS_SCAN_FLAG_RESIDENT_QUERIES | YAMS_SCAN_FLAG_WIDE_TILE))) {
             hint = &ctx->tier_hints[corpus->rows_i8];
-            if (hint->n_rows != corpus->n_rows) { hint->n_rows = corpus->n_rows; hint->bf16_first = false; hint->served = 0; } // another corpus at this address
+            // (a mirror that GROWS keeps its address and its character: what was learnt stays; a row count that halved or
+            // more than doubled is another corpus at this address)
+            if (corpus->n_rows * 2 < hint->n_rows || corpus->n_rows > hint->n_rows * 2 || hint->n_rows == 0) { *hint = yams_accel_ctx::TierHint{}; }
+            hint->n_rows = corpus->n_rows;
             if (hint->bf16_first && (++hint->served & 255u) != 0) i8 = false;
         }
 #ifdef YAMS_ACCEL_MEASURE
@@ -438,7 +441,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         int depth = 0;
         if (i8 && !split_only && !retry) {       // (both metrics: the L2 batches of the int8 tier plan the same lists)
             dhint = hint ? hint : &ctx->tier_hints[corpus->rows_i8];
-            if (dhint->n_rows != corpus->n_rows) { *dhint = yams_accel_ctx::TierHint{}; dhint->n_rows = corpus->n_rows; }
+            if (corpus->n_rows * 2 < dhint->n_rows || corpus->n_rows > dhint->n_rows * 2 || dhint->n_rows == 0) { *dhint = yams_accel_ctx::TierHint{}; }
+            dhint->n_rows = corpus->n_rows;
             if (dhint->depth && (++dhint->served_deep & 255u) != 0) depth = dhint->depth;
         }
         ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2, depth);
