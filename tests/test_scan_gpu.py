@@ -989,7 +989,8 @@ def test_plugin_chooses_the_int8_layout_per_corpus(accel_lib, oracle):
         h = json.loads(C.string_at(hp)); C.CDLL(None).free(hp)
         return h
 
-    for cfg, want in ((b'{"device": 0}', (1, 1)), (b'{"device": 0, "i8_layout": "plain"}', (0, 0)), (b'{"device": 0, "i8_layout": "rotated"}', (1, 2))):
+    for cfg, want in ((b'{"device": 0}', (1, 1)), (b'{"device": 0, "i8_layout": "plain"}', (0, 0)), (b'{"device": 0, "i8_layout": "rotated"}', (1, 2)),
+                      (b'{"devices": [0, 0], "stripe_rows": 4096, "i8_layout": "rotated"}', (1, 2)), (b'{"devices": [0, 0, 0], "stripe_rows": 8192}', (1, 1))):
         vt = _vt(L, cfg)
         ids = []
         for rows_, qs_, after in ((out, qo, want[0]), (uni, qu, want[1])):
@@ -1002,7 +1003,7 @@ def test_plugin_chooses_the_int8_layout_per_corpus(accel_lib, oracle):
             for qi in (0, 77, nq - 1):
                 assert got[qi] == list(oracle.scan_cosine(rows_, qs_[qi], k, -1.0)[0]), (cfg, qi)
             ids.append(cid)
-        assert health()["i8_layout"] == ("auto" if b"i8_layout" not in cfg else cfg.split(b'"')[-2].decode())
+        assert health()["i8_layout"] == ("auto" if b"i8_layout" not in cfg else cfg.split(b'"i8_layout": "')[1].split(b'"')[0].decode())
         for cid in ids:
             assert vt.corpus_destroy(None, cid) == 0
         L.yams_plugin_shutdown()
