@@ -2137,3 +2137,24 @@ def test_clustered_corpus_under_l2_takes_the_int8_second_pass(oracle):
             assert np.array_equal(r.dist[qi].view(np.uint32), dist.view(np.uint32)) and np.array_equal(r.scores[qi].view(np.uint32), sims.view(np.uint32)), qi
     finally:
         a3.close()
+
+
+def test_bf16_tier_takes_the_second_pass_and_learns_the_depth_too(oracle):
+    """Dims that are not a multiple of 64 (here 304 = 19 x 16) stay on the single-pass bf16 tier; its lists are cut by the same sampled
+    threshold, so clusters of ~1300 near-equal rows leave it as unproven as the int8 tier.  Round 6: the second pass serves
+    this tier too (its score is within the error bound of the similarity either way: the threshold is the k-th exact score
+    minus that bound), and the context learns the depth per tier: the next batch needs neither widening nor a second pass.
+    Rows, order and score bits are the oracle's both times."""
+    import torch
+    from yams_amd.accel import Accel
+    corpus, q = _clustered(300_000, 304, 230, 75, 200, spread=0.1)
+    a2 = Accel(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        first = check(a2, oracle, corpus, q, 100, max_queries=10, expect_path=0, shadow=True, expect_tier=2)
+        assert first.diag["retried_queries"] >= 10 and first.diag["escalated_queries"] <= first.diag["retried_queries"] // 3, first.diag
+        assert first.diag["exact_fallback_queries"] == 0, first.diag
+        later = check(a2, oracle, corpus, q, 100, max_queries=4, expect_path=0, shadow=True, expect_tier=2)
+        assert later.diag["widened_queries"] == 0 and later.diag["retried_queries"] <= first.diag["retried_queries"] // 4, (first.diag, later.diag)
+        assert np.array_equal(first.rows, later.rows) and np.array_equal(first.scores.view(np.uint32), later.scores.view(np.uint32))
+    finally:
+        a2.close()

@@ -47,7 +47,8 @@ struct yams_accel_ctx {
     // Keyed by the int8 shadow's address; `bf16_first` batches start on the bf16 tier, every 256th one probes int8 again.
     // depth: what the int8 tier's batches on this corpus needed — 0: the plan's stage 1 (3k + 64 candidates) proves them;
     // 1: most proofs needed the whole list (stage 1 re-scores all of it at once); 2: and many lists were too short (deeper lists)
-    struct TierHint { uint64_t n_rows = 0; bool bf16_first = false; uint32_t served = 0; uint8_t depth = 0; uint32_t served_deep = 0; };
+    // (depth per tier — [0] the int8 tier, [1] the single-pass bf16 tier: the same corpus may crowd one bound and not the other)
+    struct TierHint { uint64_t n_rows = 0; bool bf16_first = false; uint32_t served = 0; uint8_t depth[2] = {0, 0}; uint32_t served_deep[2] = {0, 0}; };
     std::map<const void*, TierHint> tier_hints;
     uint32_t emu_calls = 0; // measurement build: batches this context has served (emulation knobs of scan_api.cpp)
     // pinned host staging

@@ -417,7 +417,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         yams_accel_ctx::TierHint* hint = nullptr;
         if (i8 && metric == YAMS_SCAN_COSINE && !split_only && !retry && corpus->rows_bf16 && corpus->rows_nsq && nq > 128 &&
             !(params->flags & (YAMS_SCAN_FLAG_RESIDENT_QUERIES | YAMS_SCAN_FLAG_WIDE_TILE))) {
-            hint = &ctx->tier_hints[corpus->rows_i8];
+            hint = &ctx->tier_hints[corpus->rows];
             // (a mirror that GROWS keeps its address and its character: what was learnt stays; a row count that halved or
             // more than doubled is another corpus at this address)
             if (corpus->n_rows * 2 < hint->n_rows || corpus->n_rows > hint->n_rows * 2 || hint->n_rows == 0) { *hint = yams_accel_ctx::TierHint{}; }
@@ -437,13 +437,19 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // rows needs ~850 candidates re-scored, not the plan's 384: every query failed stage 1 and was widened, a third found
         // its list too short and went through a second sweep (11.4 ms per batch instead of 7.6).  The context remembers per
         // corpus what its batches needed and plans the next ones for it (probed without the hint every 256th batch).
+        // The single-pass bf16 tier (dims that are not a multiple of 64, views without an int8 shadow) learns the same way, under
+        // cosine: its lists are cut by the same sampled threshold.
         yams_accel_ctx::TierHint* dhint = nullptr;
-        int depth = 0;
-        if (i8 && !split_only && !retry) {       // (both metrics: the L2 batches of the int8 tier plan the same lists)
-            dhint = hint ? hint : &ctx->tier_hints[corpus->rows_i8];
+        int depth = 0, hint_tier = 0;
+        auto depth_for = [&](int tier) {          // what the context has learnt for this tier of this corpus (0 every 256th batch: a probe)
+            return dhint && dhint->depth[tier] && (++dhint->served_deep[tier] & 255u) != 0 ? static_cast<int>(dhint->depth[tier]) : 0;
+        };
+        if ((i8 || (bf16 && passes == 1 && metric == YAMS_SCAN_COSINE)) && !split_only && !retry) {   // (int8 tier: both metrics — its L2 batches plan the same lists)
+            dhint = hint ? hint : &ctx->tier_hints[corpus->rows];
             if (corpus->n_rows * 2 < dhint->n_rows || corpus->n_rows > dhint->n_rows * 2 || dhint->n_rows == 0) { *dhint = yams_accel_ctx::TierHint{}; }
             dhint->n_rows = corpus->n_rows;
-            if (dhint->depth && (++dhint->served_deep & 255u) != 0) depth = dhint->depth;
+            hint_tier = i8 ? 0 : 1;
+            depth = depth_for(hint_tier);
         }
         ScanPlan plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2, depth);
         if (retry) plan.kprime = kRescoreMax;   // (the retry's lists are what the proof needs: all of a list is re-scored)
@@ -462,7 +468,12 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
         // kernel would have to wait for it.  The half-tile form (two small workgroups per CU) leaves it room.
         L.i8_sample_small_grid = static_cast<bool>(ctx->before_sweep) || ctx->sweep_hold;
         if (i8 && nq <= 128 && corpus->rows_bf16 && !retry && !i8_takes_resident_form(L)) i8 = false; // small batch on a small shard: narrow bf16 (a second pass stays: its threshold is the int8 tier's)
-        if (!i8 && depth) { depth = 0; dhint = nullptr; plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2); L.plan = plan; } // (the hint is the int8 tier's)
+        if (dhint && !i8 && hint_tier == 0) {   // the batch left the int8 tier after it was planned: the other tier's lesson applies (none under L2)
+            hint_tier = 1;
+            if (metric != YAMS_SCAN_COSINE) dhint = nullptr;
+            const int d2 = depth_for(1);
+            if (d2 != depth) { depth = d2; plan = make_plan(corpus->n_rows, dim, nq, k, bf16, passes, metric == YAMS_SCAN_L2, depth); L.plan = plan; }
+        }
         if (i8) { L.rows_i8 = corpus->rows_i8; L.rows_i8_meta = corpus->rows_i8_meta; }
         if (i8 && metric == YAMS_SCAN_L2) {
             L.i8_l2 = true; L.rows_nsq = corpus->rows_nsq; L.l2_eps = i8_l2_eps(dim);
@@ -514,7 +525,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             YA_HIP(ctx, launch_prep_split(st, d_qprep, nq, q_pad, dim, bf16_slab_k(passes, dim), d_qhi, d_qlo));
             L.q_hi = d_qhi; L.q_lo = d_qlo; L.q_pad = q_pad;
         }
-        if (retry && !i8) {    // (the forced threshold is a value of the int8 tier's score: the bound of the similarity, or of g under L2)
+        if (retry && !i8 && !(bf16 && passes == 1 && metric == YAMS_SCAN_COSINE)) {    // (the forced threshold is a value of the caller's tier's score)
             for (uint32_t i = 0; i < nq; ++i) retry->unproven->push_back(i);
             return YAMS_OK;
         }
@@ -680,7 +691,8 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             failed.swap(still);
             stage_mark("widen done, left", failed.size());
         }
-        if (!failed.empty() && i8 && (!L.i8_l2 || out_dist) && !split_only && k <= 1024) {
+        const bool bf16_single = !i8 && bf16 && passes == 1 && metric == YAMS_SCAN_COSINE;
+        if (!failed.empty() && ((i8 && (!L.i8_l2 || out_dist)) || bf16_single) && !split_only && k <= 1024) {
             // stage 2a (round 6): the int8 tier once more, with the threshold the proof asks for.  For every unproven query
             // stage 1 / 2 left the k best EXACT scores it found: no row whose upper bound lies below the k-th of them can be in
             // the answer, so tau' = that score (one ulp down: the proof is a strict comparison) lists exactly what matters.
@@ -697,7 +709,9 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
                 const double margin = 1e-6 + (f32acc ? 2.0 * (static_cast<double>(dim) + 8.0) * 5.9604644775390625e-8 * 1.01 : 0.0);
                 YA_HIP(ctx, launch_retry_tau_l2(st, out_dist, out_counts, k, d_fmap, static_cast<uint32_t>(nf), d_qnorm, margin, L.gmax, plan.n_groups, d_rtau, d_rest));
             } else
-            YA_HIP(ctx, launch_retry_tau(st, out_scores, out_counts, k, d_fmap, static_cast<uint32_t>(nf), L.gmax, plan.n_groups, d_rtau, d_rest));
+            // (bf16 tier: its score is within err_bound of the similarity either way: a row that can still enter scores >= s_k - err_bound)
+            YA_HIP(ctx, launch_retry_tau(st, out_scores, out_counts, k, d_fmap, static_cast<uint32_t>(nf), L.gmax, plan.n_groups, d_rtau, d_rest,
+                                         bf16_single ? static_cast<float>(err_bound * 1.000001 + 1e-7) : 0.f));
             std::vector<uint32_t> est(nf);
             YA_HIP(ctx, hipMemcpyAsync(est.data(), d_rest, nf * 4, hipMemcpyDeviceToHost, st));
             YA_HIP(ctx, hipStreamSynchronize(st));
@@ -816,11 +830,11 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             stage_mark("escalation done", escalated);
         }
         if (hint && i8) hint->bf16_first = static_cast<uint64_t>(escalated) * 2 > nq;    // (an int8 batch — first or probe — decides for the next 255)
-        if (dhint && i8) {
-            // (lists cut short show as second passes under cosine and as escalations under L2, which has no second pass)
+        if (dhint && (i8 ? hint_tier == 0 : hint_tier == 1)) {
+            // (lists cut short show as second passes, or as escalations where there is no second pass)
             const uint64_t cut_short = static_cast<uint64_t>(retried) + escalated;
-            if (depth == 0) dhint->depth = cut_short * 8 > nq ? 2 : (static_cast<uint64_t>(widened) * 4 > nq ? 1 : 0); // (a plain batch decides)
-            else if (depth == 1 && cut_short * 8 > nq) dhint->depth = 2;
+            if (depth == 0) dhint->depth[hint_tier] = cut_short * 8 > nq ? 2 : (static_cast<uint64_t>(widened) * 4 > nq ? 1 : 0); // (a plain batch decides)
+            else if (depth == 1 && cut_short * 8 > nq) dhint->depth[hint_tier] = 2;
         }
         failed.insert(failed.end(), overflowed.begin(), overflowed.end());
         if (!failed.empty()) {

@@ -1676,7 +1676,7 @@ __global__ void scatter_results_kernel(const uint32_t* qmap, uint32_t n_slots, u
 // it (each stands for `stride` rows of the shard: the size of the list the retry will build).  Fewer than k rows found: no
 // usable threshold (est = 0xffffffff).  One workgroup per unproven query.
 __global__ __launch_bounds__(256) void retry_tau_kernel(const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap,
-                                                        const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {
+                                                        const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out, float slack) {
     __shared__ uint32_t s_cnt;
     const uint32_t slot = blockIdx.x;
     const uint32_t q = fmap[slot];
@@ -1684,7 +1684,7 @@ __global__ __launch_bounds__(256) void retry_tau_kernel(const float* scores, con
         if (threadIdx.x == 0) { tau_out[slot] = __builtin_inff(); est_out[slot] = 0xffffffffu; }
         return;
     }
-    const float sk = scores[static_cast<uint64_t>(q) * k + (k - 1)];
+    const float sk = scores[static_cast<uint64_t>(q) * k + (k - 1)] - slack;     // (slack: the tier's error bound — 0 where the score IS an upper bound)
     const float t = __uint_as_float(sk > 0.f ? __float_as_uint(sk) - 1u : (sk < 0.f ? __float_as_uint(sk) + 1u : 0x80000001u)); // the next float below
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -1734,9 +1734,9 @@ hipError_t launch_retry_tau_l2(hipStream_t st, const float* dist, const uint32_t
     return hipSuccess;
 }
 hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
-                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out) {
+                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out, float slack) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(retry_tau_kernel, dim3(n_slots), dim3(256), 0, st, scores, counts, k, fmap, gmax, n_groups, tau_out, est_out);
+    hipLaunchKernelGGL(retry_tau_kernel, dim3(n_slots), dim3(256), 0, st, scores, counts, k, fmap, gmax, n_groups, tau_out, est_out, slack);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -176,7 +176,7 @@ hipError_t launch_shadow_build(hipStream_t st, const float* rows, uint64_t n_row
 hipError_t launch_retry_tau_l2(hipStream_t st, const float* dist, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
                                const double* qnorm, double margin, const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out);
 hipError_t launch_retry_tau(hipStream_t st, const float* scores, const uint32_t* counts, uint32_t k, const uint32_t* fmap, uint32_t n_slots,
-                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out);
+                            const uint32_t* gmax, uint32_t n_groups, float* tau_out, uint32_t* est_out, float slack = 0.f);
 hipError_t launch_scatter_results_from(hipStream_t st, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t k, const float* s_scores,
                                        const int64_t* s_rows, const uint32_t* s_counts, const float* s_dist, const uint32_t* s_ranks,
                                        float* scores, int64_t* rows, uint32_t* counts, float* dist, uint32_t* ranks);
