@@ -1009,6 +1009,39 @@ def test_plugin_chooses_the_int8_layout_per_corpus(accel_lib, oracle):
         L.yams_plugin_shutdown()
 
 
+def test_plugin_measures_the_layout_again_once_enough_rows_are_there(accel_lib, oracle):
+    """A host that inserts a handful of vectors and searches before the bulk arrives: the layout measured on 64 rows (uniform
+    here: plain) is measured again when the corpus passes 4096 rows (outlier-dimension rows now: rotated) and the whole shadow
+    is rebuilt in it; searches before and after return the oracle's rows."""
+    L = accel_lib
+    vt = _vt(L, b'{"device": 0}')
+    d, k = 256, 10
+    rng = np.random.default_rng(83)
+    head = oracle.synth_rows(83, 0, 64, d)
+    bulk = rng.standard_normal((50_000, d)).astype(np.float32); bulk[:, [5, 77, 200]] *= np.float32(15.0)
+    cid = C.c_uint64()
+    assert vt.corpus_create(None, d, C.byref(cid)) == 0
+    assert vt.corpus_append(None, cid, head.ctypes.data_as(_lib.f32p), 64) == 0
+
+    def rotated():
+        hp = C.c_void_p()
+        assert L.yams_plugin_get_health_json(C.byref(hp)) == 0
+        h = json.loads(C.string_at(hp)); C.CDLL(None).free(hp)
+        return h["corpora_with_rotated_i8_shadow"]
+    assert rotated() == 0
+    got, _, _ = _vt_search(vt, cid, np.ascontiguousarray(head[:3]), k)
+    assert got[0] == list(oracle.scan_cosine(head, head[0], k, -1.0)[0])
+    assert vt.corpus_append(None, cid, bulk.ctypes.data_as(_lib.f32p), bulk.shape[0]) == 0
+    assert rotated() == 1
+    allrows = np.concatenate([head, bulk])
+    qs = np.ascontiguousarray(np.concatenate([bulk[:140] * np.float32(0.5), head[:4]]))
+    got, _, _ = _vt_search(vt, cid, qs, k)
+    for qi in (0, 77, 139, 141):
+        assert got[qi] == list(oracle.scan_cosine(allrows, qs[qi], k, -1.0)[0]), qi
+    assert vt.corpus_destroy(None, cid) == 0
+    L.yams_plugin_shutdown()
+
+
 def test_l2_definition_gap_measured_from_the_device_result(acc, oracle, capsys):
     """L2 parity is unpinned (the vec0 arithmetic lives in the absent sqlite-vec-cpp): how much does the fp64-vs-fp32
     accumulation choice matter?  The device returns the top 200 under this repository's definition; the fp32-accumulated

@@ -260,6 +260,7 @@ struct Corpus {
     uint32_t dim = 0;
     uint64_t n_rows = 0;
     int i8_flags = -1;               // layout of the int8 shadow (YAMS_SCAN_I8_*), decided at the first append; -1: not yet
+    uint64_t i8_decided_rows = 0;    // rows the "auto" decision looked at (one taken from fewer than 4096 rows is taken again once they are there)
     PqIndex pq;                      // (version 2 of the vtable: pq_index_set / search_pq)
     std::vector<ShardStore> sh;      // one per plugin device
     GrowBuf rank_of_row;             // device 0: the corpus-wide chunk_id ranking (cross-shard ties)
@@ -566,9 +567,14 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
     }
     for (uint32_t i = 0; i < n_sh; ++i) if (yams_accel_ctx_synchronize(g.upload_ctx[i]) != YAMS_OK) return internal_error("append:4b");
     const auto t_copied = std::chrono::steady_clock::now();
-    if (i8 && c->i8_flags < 0) {
-        // the layout of this corpus' int8 shadow, once: the configured one, or whichever quantises the first rows better
+    bool relayout = false;          // the shadow is rebuilt from row 0 (the measured layout changed once enough rows were there)
+    if (i8 && (c->i8_flags < 0 || (g.i8_layout == 0 && c->i8_decided_rows < 4096 && n1 >= 4096))) {
+        // the layout of this corpus' int8 shadow: the configured one, or whichever quantises the rows better — measured at the
+        // first append and, if that one brought fewer than 4096 rows (a host that inserts a few vectors, then searches), once
+        // more when 4096 are there
+        const int before = c->i8_flags;
         c->i8_flags = 0;
+        c->i8_decided_rows = n1;
         if (g.i8_layout == 2) {
             if (c->dim <= 4096) c->i8_flags = static_cast<int>(YAMS_SCAN_I8_ROTATED);   // (the rotated layout exists for 256 <= dim <= 4096)
         } else if (g.i8_layout == 0) {
@@ -583,11 +589,17 @@ yams_status_t vs_corpus_append(void*, uint64_t id, const float* rows, uint64_t n
                 break;
             }
         }
+        relayout = before >= 0 && before != c->i8_flags;
     }
     for (uint32_t i = 0; i < n_sh; ++i) {
         ShardStore& s = c->sh[i];
         const uint64_t old = s.n_rows, now = shard_rows(n1, n_sh, i);
         yams_accel_ctx* uc = g.upload_ctx[i];
+        if (relayout && i8 && now) {     // every block of this shard again, in the layout the rows turned out to want
+            if (yams_scan_build_shadow_i8_layout_device(uc, s.rows.as<float>(), 0, old, c->dim, static_cast<uint32_t>(c->i8_flags),
+                                                        s.i8.as<int8_t>(), s.i8meta.as<float>(), nullptr) != YAMS_OK)
+                return internal_error("append:6b");
+        }
         if (now != old) {
             if (bf16 && yams_scan_build_shadow_device(uc, s.rows.as<float>() + old * c->dim, now - old, c->dim,
                                                       s.bf16.as<uint16_t>() + old * c->dim, s.nsq.as<float>() + old) != YAMS_OK)
@@ -663,7 +675,7 @@ void release_corpus(Corpus& c) {
     c.pq.release();
     for (auto& s : c.sh) s.release();
     c.rank_of_row.release();
-    c.n_rows = 0; c.has_ranks = false; c.i8_flags = -1;
+    c.n_rows = 0; c.has_ranks = false; c.i8_flags = -1; c.i8_decided_rows = 0;
 }
 
 // The rows are gone, the mirror's memory stays mapped for the re-upload that usually follows (compaction).
@@ -673,7 +685,7 @@ yams_status_t vs_corpus_clear(void*, uint64_t id) {
     if (!c) return YAMS_ERR_NOT_FOUND;
     std::unique_lock<std::shared_mutex> lk(c->mu);
     for (auto& s : c->sh) { s.n_rows = 0; s.has_tie = false; }
-    c->n_rows = 0; c->has_ranks = false; c->i8_flags = -1;
+    c->n_rows = 0; c->has_ranks = false; c->i8_flags = -1; c->i8_decided_rows = 0;
     return YAMS_OK;
 }
 
