@@ -1945,6 +1945,9 @@ hipError_t launch_i8_collect_sample(hipStream_t st, const ScanLaunch& L) {
     if (L.plan.sample_rows == 0 || L.plan.n_groups == 0) return hipSuccess;
     uint32_t gx = (L.plan.n_groups + 255) / 256;
     if (gx > 64) gx = 64;
+#ifdef YAMS_ACCEL_MEASURE
+    if (const char* e = std::getenv("YAMS_ACCEL_COLLECT_GX")) { const uint32_t v = static_cast<uint32_t>(std::atoi(e)); if (v >= 1 && v < gx) gx = v; }
+#endif
     hipLaunchKernelGGL(i8_collect_sample_kernel, dim3(gx, L.plan.n_queries), dim3(256), 0, st, L.gmax, L.plan.n_groups,
                        L.plan.n_queries, L.rows_i8, L.rows_i8_meta, L.q_i8, L.q_meta, L.q_pad, L.plan.dim, L.plan.sample_stride,
                        L.plan.n_rows, L.row_mask, L.tau, L.list_count, L.list, L.plan.list_cap,
