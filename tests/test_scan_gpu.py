@@ -1408,6 +1408,17 @@ def test_int8_shadow_built_in_appends_equals_one_build(acc, oracle):
     sc = am[:, 0].double().repeat_interleave(64)[:n, None]
     assert ((unit - a8.double() * sc).norm(dim=-1) <= am[:, 1].double().repeat_interleave(64)[:n]).all()
     assert (a8.abs().amax(dim=-1).view(-1)[:64 * (n // 64)].view(-1, 64).amax(dim=-1) == 127).all()   # every block uses its full range
+    # the rotated layout: ragged appends == one build, too (a row's rotation does not depend on its neighbours)
+    a8 = torch.full((npad, d), 99, dtype=torch.int8, device="cuda"); am = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    b8 = torch.full((npad, d), 99, dtype=torch.int8, device="cuda"); bm = torch.zeros((nb, 2), dtype=torch.float32, device="cuda")
+    acc.build_shadow_i8_device(tc.data_ptr(), n, d, a8.data_ptr(), am.data_ptr(), i8_flags=_lib.I8_ROTATED)
+    first = 0
+    for step in (1000, 1, 7, 2995, 1000):
+        acc.build_shadow_i8_device(tc.data_ptr(), step, d, b8.data_ptr(), bm.data_ptr(), first_row=first, i8_flags=_lib.I8_ROTATED)
+        first += step
+    acc.synchronize()
+    assert torch.equal(a8, b8) and torch.equal(am, bm)
+    assert (unblock_i8_shadow(a8, d)[:64 * (n // 64)].abs().amax(dim=-1).view(-1, 64).amax(dim=-1) == 127).all()
 
 
 def test_int8_tier_widens_escalates_and_falls_back(acc, oracle):
