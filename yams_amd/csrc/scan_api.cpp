@@ -312,6 +312,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
     bool l2_i8_ok = false;
     float* d_l2_nmin = nullptr; uint32_t* d_l2_stats = nullptr; uint32_t* d_l2_special = nullptr;
     uint32_t l2_n_special = 0;
+    float l2_nsq_hi = 0.f;      // largest squared row norm of the shard (L2 on the int8 tier)
     const bool l2_i8_wanted = use_mfma && metric == YAMS_SCAN_L2 && corpus->rows_i8 && corpus->rows_i8_meta && corpus->rows_nsq &&
                               (dim & 63u) == 0 && dim >= 256 && corpus->n_rows >= 4096 &&
                               (reinterpret_cast<uintptr_t>(corpus->rows_i8) & 15u) == 0 &&
@@ -342,6 +343,7 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             // a few rows without a usable norm ride along as unconditional candidates; the others within a factor of two
             l2_n_special = h_l2_stats[3];
             l2_i8_ok = l2_n_special <= i8_l2_max_special() && h_l2_stats[1] != 0 && hi <= 4.0f * lo;
+            l2_nsq_hi = hi;
         }
     }
 
@@ -504,7 +506,10 @@ yams_status_t scan_impl(yams_accel_ctx* ctx, const yams_scan_corpus_t* corpus, c
             float* d_qthr;
             YA_TRY(ws_get(ctx, "q_thr", static_cast<size_t>(q_pad) * 8, (void**)&d_qthr));
             L.q_i8 = d_qi8; L.q_meta = d_qmeta; L.q_thr = d_qthr; L.q_pad = q_pad; L.sample_layout = 1;
-            if (!L.i8_l2 && metric == YAMS_SCAN_COSINE) { // proof-aware threshold (tau_select_kernel)
+            if (metric == YAMS_SCAN_COSINE || metric == YAMS_SCAN_L2) { // proof-aware threshold (tau_select_kernel)
+                // (under L2 the sample values are g = n (x~ . q) - n^2 / 2: the bound's width in those units is n E, taken at the
+                // shard's largest norm — L.i8_l2 is decided below, the fields are harmless on the other tiers)
+                L.tau_e_scale = metric == YAMS_SCAN_L2 ? std::sqrt(std::max(l2_nsq_hi, 0.f)) * 1.0001f : 1.0f;
                 L.tau_rows_meta = corpus->rows_i8_meta; L.tau_n_blocks = (corpus->n_rows + 63) / 64;
                 L.tau_rank2 = (k + plan.sample_stride - 1) / plan.sample_stride + 4;     // P(fewer than k rows reach that sample value) < 1 %
                 L.tau_max_groups = kRescoreMax * 3u / 2 / plan.sample_stride;               // what the crowd is estimated at must fit the list (cap: 4096 rows or more)

@@ -506,7 +506,7 @@ constexpr int TAU_LIST = 2048;
 // crowded, or the crowd is far too large).  A heuristic in front of a proof: it changes list sizes, never results.
 __global__ __launch_bounds__(256) void tau_select_kernel(const uint32_t* gmax, uint32_t n_groups,
                                                          uint32_t rank, float* tau, const float* rows_meta, uint64_t n_blocks,
-                                                         const float* q_meta, uint32_t rank2, uint32_t max_groups) {
+                                                         const float* q_meta, uint32_t rank2, uint32_t max_groups, float e_scale) {
     __shared__ uint32_t hist[2048]; // fast path: [0, 256) the thread maxima, then the collected keys
     __shared__ uint32_t s_prefix, s_rank, s_count, s_v1, s_v2, s_va;
     __shared__ float s_red[4];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const uint32_t* gmax, u
             if (v1 && v2 && va) {
                 e = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
                 const float4 qm = reinterpret_cast<const float4*>(q_meta)[q]; // {t_q, c_q, f_q, 0}
-                const float E = fmaf(e, qm.y, qm.z);
+                const float E = fmaf(e, qm.y, qm.z) * e_scale;   // (e_scale: the largest row norm under L2, 1 under cosine)
                 tp = ord2f(v2) - 2.0f * E;
                 want = ord2f(va) - t_out < E && tp < t_out;   // crowded, and the rank rule does not already list deeper than the proof needs
             }
@@ -1502,7 +1502,7 @@ hipError_t launch_select_tau(hipStream_t st, const ScanLaunch& L, uint32_t* /*wo
     const uint32_t nq = L.plan.n_queries;
     if (nq == 0) return hipSuccess;
     hipLaunchKernelGGL(tau_select_kernel, dim3(nq), dim3(256), 0, st, L.gmax, L.plan.n_groups,
-                       L.plan.tau_rank, L.tau_out, L.tau_rows_meta, L.tau_n_blocks, L.q_meta, L.tau_rank2, L.tau_max_groups);
+                       L.plan.tau_rank, L.tau_out, L.tau_rows_meta, L.tau_n_blocks, L.q_meta, L.tau_rank2, L.tau_max_groups, L.tau_e_scale);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -39,7 +39,7 @@ struct ScanLaunch {
     const float* tau = nullptr;   // read by filter / collect
     float* tau_out = nullptr;     // written by select_tau
     // proof-aware threshold (tau_select_kernel): int8 tier under cosine only
-    const float* tau_rows_meta = nullptr; uint64_t tau_n_blocks = 0; uint32_t tau_rank2 = 0, tau_max_groups = 0;
+    const float* tau_rows_meta = nullptr; uint64_t tau_n_blocks = 0; uint32_t tau_rank2 = 0, tau_max_groups = 0; float tau_e_scale = 1.0f;
     uint32_t* list_count = nullptr;
     uint64_t* list = nullptr;
     const float* qnorm_up = nullptr;
