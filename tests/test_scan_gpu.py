@@ -1757,10 +1757,11 @@ def test_randomised_self_consistency_of_all_scan_paths():
 def test_every_rescored_candidate_lies_inside_its_filter_bound():
     """Bound honesty (round 6; the measurement build counts it in rescore_select_kernel): for EVERY candidate the tiers
     re-score, the filter's score against the exact similarity — |score - cos| <= the tier's error bound on the f32 / bf16 /
-    split tiers, cos <= score on the int8 tier (its score is an upper bound), in either shadow layout.  The proofs stand on
+    split tiers, cos <= score on the int8 tier (its score is an upper bound), in either shadow layout; under L2, on every tier,
+    g = q.x - |x|^2 / 2 <= score.  The proofs stand on
     exactly this; a final result can be right while a bound is not.  120 random cases of tests/stress_scan.py (uniform /
     Gaussian / power-law / outlier-dimension rows, masks, clusters, learnt hints) on the measurement build: no candidate
-    outside its bound, no mismatch.  (Round 6 ran 900 cases, 1 800 calls, by hand: none.)"""
+    outside its bound, no mismatch.  (Round 6 ran 1 950 cases, 4 000 calls, by hand: none.)"""
     import json, os, re, subprocess, sys
     from yams_amd import build as _build
     if not os.path.exists(_build.MEASURE_LIB):

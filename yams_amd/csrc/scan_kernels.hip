@@ -990,6 +990,18 @@ __global__ __launch_bounds__(512) void rescore_select_kernel(RescoreArgs a) {
             const double dd = l2.root();
             if (!isfinite(dd)) continue;
             const float dist = static_cast<float>(dd);
+#ifdef YAMS_ACCEL_MEASURE
+            // bound honesty under L2: on every tier the filter's score is an UPPER bound of g = q.x - |x|^2 / 2 (the error term is
+            // folded into it); rows the int8 tier lists unconditionally (no usable norm) carry +inf
+            if (a.stat_rescored && !a.all_rows_listed && !a.rank_row) {
+                const double g = dot - 0.5 * nsq, fs = static_cast<double>(key_score(ck));
+                if (g > fs + 1e-6 * (fabs(dot) + 0.5 * nsq) + 1e-30) {
+                    const unsigned long long nth = atomicAdd(a.stat_rescored + 4, 1ull);
+                    if (nth < 6 && a.stat_rescored[6] == 0x5eed) printf("  honesty (L2): query %u cand %u row %u g %.9g filter %.9g nsq %.6g\n", q, c, row, g, fs, nsq);
+                }
+                atomicAdd(a.stat_rescored + 5, 1ull);
+            }
+#endif
             // computeCosineSimilarity (vector_database.cpp:1786-1810): sqrt each norm, 0 on zero norm
             const double na = qn, nb = sqrt(nsq);
             const double cs = (na == 0.0 || nb == 0.0) ? 0.0 : dot / (na * nb);
